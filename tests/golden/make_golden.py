@@ -1,0 +1,276 @@
+"""Generate golden fixtures by running the REFERENCE (read-only, /root/reference) on CPU.
+
+Run once in the build container:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+Only data (inputs + expected outputs) is written, as small .npz files next to this script;
+weights are never stored -- both sides rebuild them from the seeded recipe
+``oracle.dppo_oracle.init_params``.  The reference cannot travel to the GPU box; these
+fixtures can.
+"""
+import os
+import sys
+from contextlib import contextmanager
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+from oracle import dppo_oracle as O  # noqa: E402  (seeded weight recipe + specs only)
+
+from dppo.model.common.critic import CriticObs  # noqa: E402
+from dppo.model.diffusion.diffusion_ppo import PPODiffusion  # noqa: E402
+from dppo.model.diffusion.eta import EtaFixed  # noqa: E402
+from dppo.model.diffusion.mlp_diffusion import DiffusionMLP  # noqa: E402
+from dppo.util.reward_scaling import RunningRewardScaler  # noqa: E402
+
+torch.set_num_threads(4)
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"wrote {name}.npz: {len(out)} arrays, {sum(v.nbytes for v in out.values())} bytes raw")
+
+
+GRAD_STRIDE = 61  # big gradient tensors are stored as flat[::61] plus their 2-norm and sum
+
+
+def put_grad(out, key, g):
+    g = g.detach().cpu().numpy()
+    if g.size > 4096:
+        out[key + "__sub"] = g.reshape(-1)[::GRAD_STRIDE].copy()
+        out[key + "__norm"] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        out[key + "__sum"] = np.float64(g.astype(np.float64).sum())
+    else:
+        out[key] = g
+
+
+def ref_actor(spec: O.NetSpec, params):
+    m = DiffusionMLP(action_dim=spec.action_dim, horizon_steps=spec.horizon_steps, cond_dim=spec.cond_dim,
+                     time_dim=spec.time_dim, mlp_dims=list(spec.mlp_dims), cond_mlp_dims=spec.cond_mlp_dims,
+                     activation_type=spec.activation, use_layernorm=spec.use_layernorm,
+                     residual_style=spec.residual)
+    m.load_state_dict(params, strict=True)
+    return m
+
+
+def ref_critic(spec: O.NetSpec, params):
+    m = CriticObs(cond_dim=spec.cond_dim, mlp_dims=list(spec.mlp_dims), activation_type=spec.activation,
+                  use_layernorm=spec.use_layernorm, residual_style=spec.residual)
+    m.load_state_dict(params, strict=True)
+    return m
+
+
+def ref_model(aspec, cspec, seed, **kw):
+    base = O.init_params(aspec, seed)
+    ft = O.init_params(aspec, seed + 1)
+    cr = O.init_params(cspec, seed + 2)
+    model = PPODiffusion(actor=ref_actor(aspec, base), critic=ref_critic(cspec, cr),
+                         horizon_steps=aspec.horizon_steps, obs_dim=aspec.cond_dim,
+                         action_dim=aspec.action_dim, device="cpu", **kw)
+    model.actor_ft.load_state_dict(ft, strict=True)
+    return model
+
+
+@contextmanager
+def recorded_noise(noise):
+    """Feed pre-drawn N(0,1) tensors to torch.randn / randn_like, in call order."""
+    it = iter(noise)
+    r0, r1 = torch.randn, torch.randn_like
+    torch.randn = lambda *a, **k: next(it).clone()
+    torch.randn_like = lambda *a, **k: next(it).clone()
+    try:
+        yield
+    finally:
+        torch.randn, torch.randn_like = r0, r1
+
+
+specs = O.named_specs
+
+
+# ---------------------------------------------------------------- G1 tables
+def g1_tables():
+    out = {}
+    for K in (20, 100):
+        a, c = specs("hopper")
+        m = ref_model(a, c, 7, gamma_denoising=0.99, clip_ploss_coef=0.01, ft_denoising_steps=10,
+                      denoising_steps=K)
+        for k in ("betas", "alphas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+                  "sqrt_recipm1_alphas_cumprod", "ddpm_var", "ddpm_logvar_clipped", "ddpm_mu_coef1",
+                  "ddpm_mu_coef2"):
+            out[f"K{K}_{k}"] = getattr(m, k)
+    a, c = specs("hopper")
+    m = ref_model(a, c, 7, gamma_denoising=0.99, clip_ploss_coef=0.01, ft_denoising_steps=5,
+                  denoising_steps=100, use_ddim=True, ddim_steps=5, eta=EtaFixed(base_eta=1.0))
+    for k in ("ddim_t", "ddim_alphas", "ddim_alphas_sqrt", "ddim_alphas_prev", "ddim_sqrt_one_minus_alphas"):
+        out[f"ddim100_5_{k}"] = getattr(m, k)
+    out["eta_fixed_base1"] = m.eta({"state": torch.zeros(1, 1, 11)}).reshape(-1)
+    out["eta_fixed_base05"] = EtaFixed(base_eta=0.5)({"state": torch.zeros(1, 1, 11)}).reshape(-1)
+    save("g1_tables", **out)
+
+
+# ---------------------------------------------------------------- G2 network forwards
+def g2_forward():
+    rs = np.random.RandomState(100)
+    out = {}
+    for name in ("hopper", "can", "halfcheetah", "furniture_like", "plain_mlp"):
+        a, c = specs(name)
+        B = 8
+        pa, pc = O.init_params(a, 11), O.init_params(c, 12)
+        x = torch.from_numpy(rs.randn(B, a.horizon_steps, a.action_dim).astype(np.float32))
+        t = torch.from_numpy(rs.randint(0, 20, size=(B,)).astype(np.int64))
+        s = torch.from_numpy(rs.uniform(-1, 1, size=(B, 1, a.cond_dim)).astype(np.float32))
+        with torch.no_grad():
+            y = ref_actor(a, pa)(x, t, cond={"state": s})
+            v = ref_critic(c, pc)({"state": s})
+        out.update({f"{name}_x": x, f"{name}_t": t, f"{name}_state": s, f"{name}_eps": y, f"{name}_value": v})
+    save("g2_forward", **out)
+
+
+# ---------------------------------------------------------------- G3/G4 sampling chains + log-probs
+def g3_g4_chains():
+    cases = {
+        # name: (spec, B, model kwargs, deterministic)
+        "ddpm20_ft10": ("hopper", 6, dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3), False),
+        "ddpm20_ft10_det": ("hopper", 6, dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3), True),
+        "ddpm20_ft20": ("hopper", 4, dict(denoising_steps=20, ft_denoising_steps=20, randn_clip_value=3,
+                                          final_action_clip_value=1.0), False),
+        "ddpm100_can": ("can", 4, dict(denoising_steps=100, ft_denoising_steps=10, randn_clip_value=3,
+                                       min_sampling_denoising_std=0.08), False),
+        "ddim100_5": ("hopper", 5, dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
+                                        randn_clip_value=3, eps_clip_value=2.0,
+                                        min_sampling_denoising_std=0.1), False),
+        "ddim100_5_det": ("hopper", 5, dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True,
+                                            ddim_steps=5, randn_clip_value=3), True),
+        "ddim100_10_ft4": ("halfcheetah", 3, dict(denoising_steps=100, ft_denoising_steps=4, use_ddim=True,
+                                                  ddim_steps=10, randn_clip_value=3), False),
+        "furniture_like": ("furniture_like", 4, dict(denoising_steps=20, ft_denoising_steps=5,
+                                                     randn_clip_value=3), False),
+    }
+    out = {}
+    rs = np.random.RandomState(200)
+    for cname, (sname, B, kw, det) in cases.items():
+        a, c = specs(sname)
+        if kw.get("use_ddim"):
+            kw = dict(kw, eta=EtaFixed(base_eta=1.0))
+        m = ref_model(a, c, 21, gamma_denoising=0.99, clip_ploss_coef=0.01, **kw)
+        n_steps = kw["ddim_steps"] if kw.get("use_ddim") else kw["denoising_steps"]
+        state = torch.from_numpy(rs.uniform(-1, 1, size=(B, 1, a.cond_dim)).astype(np.float32))
+        noise = torch.from_numpy(rs.randn(n_steps + 1, B, a.horizon_steps, a.action_dim).astype(np.float32))
+        with recorded_noise(list(noise)):
+            smp = m(cond={"state": state}, deterministic=det, return_chain=True)
+        with torch.no_grad():
+            lp = m.get_logprobs({"state": state}, smp.chains)
+        out.update({f"{cname}_state": state, f"{cname}_noise": noise, f"{cname}_traj": smp.trajectories,
+                    f"{cname}_chains": smp.chains, f"{cname}_logprobs": lp})
+    save("g3_chains", **out)
+
+
+# ---------------------------------------------------------------- G5 PPO loss + grads
+def g5_loss():
+    cases = {
+        "default": ("hopper", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01,
+                                   clip_ploss_coef_base=0.001), 4),
+        "vclip_nonorm": ("hopper", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.1,
+                                        clip_ploss_coef_base=0.01, clip_vloss_coef=0.2, norm_adv=False), 4),
+        "quantile_rh2": ("hopper", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01,
+                                        clip_advantage_lower_quantile=0.05, clip_advantage_upper_quantile=0.95), 2),
+        "can_k100": ("can", dict(denoising_steps=100, ft_denoising_steps=10, clip_ploss_coef=0.01), 4),
+        "ddim": ("hopper", dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
+                                clip_ploss_coef=0.01), 4),
+        "furniture_like": ("furniture_like", dict(denoising_steps=20, ft_denoising_steps=5, clip_ploss_coef=0.01), 4),
+    }
+    out = {}
+    rs = np.random.RandomState(300)
+    N = 64
+    for cname, (sname, kw, rh) in cases.items():
+        a, c = specs(sname)
+        if kw.get("use_ddim"):
+            kw = dict(kw, eta=EtaFixed(base_eta=1.0))
+        m = ref_model(a, c, 31, gamma_denoising=0.99, randn_clip_value=3, **kw)
+        Kft = kw["ft_denoising_steps"]
+        n_steps = kw["ddim_steps"] if kw.get("use_ddim") else kw["denoising_steps"]
+        # a realistic rollout: chains sampled by the policy itself, old log-probs from slightly different weights
+        state = torch.from_numpy(rs.uniform(-1, 1, size=(N, 1, a.cond_dim)).astype(np.float32))
+        noise = torch.from_numpy(rs.randn(n_steps + 1, N, a.horizon_steps, a.action_dim).astype(np.float32))
+        with recorded_noise(list(noise)):
+            chains = m(cond={"state": state}, deterministic=False, return_chain=True).chains
+        kinds = torch.from_numpy(rs.randint(0, Kft, size=(N,)).astype(np.int64))
+        rows = torch.arange(N)
+        prev, nxt = chains[rows, kinds], chains[rows, kinds + 1]
+        with torch.no_grad():
+            oldlp_all = m.get_logprobs({"state": state}, chains).reshape(N, Kft, a.horizon_steps, a.action_dim)
+            oldlp = oldlp_all[rows, kinds] + torch.from_numpy(
+                rs.normal(0, 0.02, size=(N, a.horizon_steps, a.action_dim)).astype(np.float32))
+            oldv = m.critic({"state": state}).view(-1) + torch.from_numpy(rs.normal(0, 0.3, N).astype(np.float32))
+        ret = torch.from_numpy(rs.normal(0, 1, N).astype(np.float32))
+        adv = torch.from_numpy(rs.normal(0.3, 2.0, N).astype(np.float32))
+        res = m.loss({"state": state}, prev, nxt, kinds, ret, oldv, adv.clone(), oldlp,
+                     use_bc_loss=False, reward_horizon=rh)
+        pg, ent, vl = res[0], res[1], res[2]
+        (pg + 0.5 * vl).backward()
+        out.update({f"{cname}_state": state, f"{cname}_prev": prev, f"{cname}_next": nxt, f"{cname}_kinds": kinds,
+                    f"{cname}_returns": ret, f"{cname}_oldvalues": oldv, f"{cname}_adv": adv,
+                    f"{cname}_oldlogprobs": oldlp, f"{cname}_reward_horizon": rh,
+                    f"{cname}_stats": np.array([pg.item(), float(ent), vl.item(), res[3], res[4], res[5],
+                                                float(res[6]), res[7]], dtype=np.float64)})
+        for k, p in m.actor_ft.named_parameters():
+            put_grad(out, f"{cname}_gactor_{k}", p.grad)
+        for k, p in m.critic.named_parameters():
+            put_grad(out, f"{cname}_gcritic_{k}", p.grad)
+    save("g5_loss", **out)
+
+
+# ---------------------------------------------------------------- G6 reward scaler (GAE loop is not importable)
+def g6_reward_scaler():
+    rs = np.random.RandomState(400)
+    n_envs, n_steps = 4, 16
+    sc = RunningRewardScaler(n_envs)
+    out = {}
+    for it in range(3):
+        r = rs.normal(1.0, 2.0, size=(n_envs, n_steps))
+        f = (rs.uniform(size=(n_envs, n_steps)) < 0.15).astype(np.float64)
+        out[f"it{it}_reward"] = r
+        out[f"it{it}_first"] = f
+        out[f"it{it}_scaled"] = sc(reward=r, first=f)
+        out[f"it{it}_var"] = np.float64(sc.ret_rms.var)
+    save("g6_reward_scaler", **out)
+
+
+# ---------------------------------------------------------------- G7 one optimiser step (torch.optim.AdamW)
+def g7_adamw():
+    rs = np.random.RandomState(500)
+    p0 = rs.normal(size=(257,)).astype(np.float32)
+    out = {"p0": p0}
+    p = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.AdamW([p], lr=1e-3, weight_decay=0.01)
+    for i in range(3):
+        g = rs.normal(size=(257,)).astype(np.float32)
+        p.grad = torch.from_numpy(g.copy())
+        opt.step()
+        out[f"g{i}"] = g
+        out[f"p{i + 1}"] = p.detach().clone()
+    g = torch.from_numpy(rs.normal(size=(257,)).astype(np.float32))
+    q = torch.nn.Parameter(torch.zeros(257))
+    q.grad = g.clone()
+    out["clip_in"] = g
+    out["clip_total"] = torch.nn.utils.clip_grad_norm_([q], 1.5)
+    out["clip_out"] = q.grad
+    save("g7_adamw", **out)
+
+
+if __name__ == "__main__":
+    g1_tables()
+    g2_forward()
+    g3_g4_chains()
+    g5_loss()
+    g6_reward_scaler()
+    g7_adamw()
