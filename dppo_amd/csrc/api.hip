@@ -1,0 +1,667 @@
+// C ABI of libdppo_hip.so (include/dppo_hip.h): argument checks, layouts, workspace carving and the
+// launch sequences.  No allocation, no synchronisation, no global mutable state.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "gemm.h"
+#include "ppo.h"
+#include "sampler.h"
+
+using namespace dppo;
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+static int check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail((int)e, "HIP launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// layouts
+// ------------------------------------------------------------------------------------------------
+struct ParamLayout {  // float offsets into the flat fp32 parameter / gradient buffer (state-dict order)
+  int64_t te1_w, te1_b, te2_w, te2_b, W0, b0, l1w[MAX_BLOCKS], l1b[MAX_BLOCKS], l2w[MAX_BLOCKS], l2b[MAX_BLOCKS], Wout,
+      bout, total;
+};
+static ParamLayout param_layout(const dppo_net_desc& d) {
+  ParamLayout L;
+  memset(&L, 0, sizeof(L));
+  int64_t o = 0;
+  const int td = d.time_dim, H = d.hidden;
+  if (d.kind == 0) {
+    L.te1_w = o, o += 2 * td * td;
+    L.te1_b = o, o += 2 * td;
+    L.te2_w = o, o += td * 2 * td;
+    L.te2_b = o, o += td;
+  }
+  L.W0 = o, o += (int64_t)H * d.in_dim;
+  L.b0 = o, o += H;
+  for (int b = 0; b < d.n_blocks; ++b) {
+    L.l1w[b] = o, o += (int64_t)H * H;
+    L.l1b[b] = o, o += H;
+    L.l2w[b] = o, o += (int64_t)H * H;
+    L.l2b[b] = o, o += H;
+  }
+  L.Wout = o, o += (int64_t)d.out_dim * H;
+  L.bout = o, o += d.out_dim;
+  L.total = o;
+  return L;
+}
+
+struct PackLayout {  // byte offsets into the packed image
+  // every offset depends on (net, prec) only; the time table sits last so that only `total` grows with n_time
+  size_t W0, W1[MAX_BLOCKS], W2[MAX_BLOCKS], Wout, W1T[MAX_BLOCKS], W2T[MAX_BLOCKS], WoutT, W0tT, sstream, ostream,
+      temb, total;
+  int Kp0, Kpo, tdp;
+};
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+template <class P>
+static PackLayout pack_layout(const dppo_net_desc& d, int n_time) {
+  PackLayout L;
+  memset(&L, 0, sizeof(L));
+  const size_t ES = P::ESIZE;
+  const int H = d.hidden;
+  L.Kp0 = round_up(d.in_dim, 64);
+  L.Kpo = round_up(d.out_dim, 64);
+  L.tdp = round_up(d.time_dim > 0 ? d.time_dim : 1, 16);
+  size_t o = 0;
+  L.W0 = o, o = al256(o + (size_t)H * L.Kp0 * ES);
+  for (int b = 0; b < d.n_blocks; ++b) {
+    L.W1[b] = o, o = al256(o + (size_t)H * H * ES);
+    L.W2[b] = o, o = al256(o + (size_t)H * H * ES);
+    L.W1T[b] = o, o = al256(o + (size_t)H * H * ES);
+    L.W2T[b] = o, o = al256(o + (size_t)H * H * ES);
+  }
+  L.Wout = o, o = al256(o + (size_t)d.out_dim * H * ES);
+  L.WoutT = o, o = al256(o + (size_t)H * L.Kpo * ES);
+  if (d.kind == 0) {
+    L.W0tT = o, o = al256(o + (size_t)d.time_dim * H * ES);
+    const SamplerGeom g = sampler_geom<P>(d);
+    L.sstream = o, o = al256(o + (size_t)SAMPLER_WAVES * g.hidden_frags_per_wave * 64 * 16);
+    L.ostream = o, o = al256(o + (size_t)SAMPLER_WAVES * g.out_frags_per_wave * 64 * 16);
+  }
+  L.temb = o, o = al256(o + (size_t)n_time * (d.time_dim > 0 ? d.time_dim : 0) * 4);
+  L.total = o;
+  return L;
+}
+
+static int check_net(const dppo_net_desc* d) {
+  if (!d) return fail(-1, "null net descriptor");
+  if (d->kind != 0 && d->kind != 1) return fail(-1, "net.kind must be 0 (actor) or 1 (critic)");
+  if (d->hidden < 128 || d->hidden % 128) return fail(-1, "hidden=%d must be a positive multiple of 128", d->hidden);
+  if (d->n_blocks < 0 || d->n_blocks > MAX_BLOCKS) return fail(-1, "n_blocks=%d out of [0,%d]", d->n_blocks, MAX_BLOCKS);
+  if (d->act != DPPO_ACT_RELU && d->act != DPPO_ACT_MISH) return fail(-1, "activation %d unsupported", d->act);
+  if (d->out_dim < 1 || d->out_dim > 128) return fail(-1, "out_dim=%d out of [1,128]", d->out_dim);
+  if (d->kind == 0) {
+    if (d->time_dim < 4 || d->time_dim % 2) return fail(-1, "time_dim=%d must be even and >= 4", d->time_dim);
+    if (d->act_flat != d->out_dim) return fail(-1, "actor out_dim must equal act_flat");
+    if (d->in_dim != d->act_flat + d->time_dim + d->cond_dim) return fail(-1, "actor in_dim mismatch");
+  } else {
+    if (d->in_dim != d->cond_dim) return fail(-1, "critic in_dim must equal cond_dim");
+    if (d->out_dim != 1) return fail(-1, "critic out_dim must be 1");
+  }
+  if (d->in_dim < 1 || d->in_dim > 1024) return fail(-1, "in_dim=%d out of [1,1024]", d->in_dim);
+  return 0;
+}
+static int check_prec(int prec) {
+  if (prec != DPPO_PREC_F32 && prec != DPPO_PREC_BF16) return fail(-1, "prec must be DPPO_PREC_F32 or DPPO_PREC_BF16");
+  return 0;
+}
+#define DPPO_DISPATCH(prec, CALL)        \
+  ((prec) == DPPO_PREC_F32 ? CALL(F32) : CALL(BF16))
+
+// ------------------------------------------------------------------------------------------------
+// pack
+// ------------------------------------------------------------------------------------------------
+template <class P>
+static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char* pk, hipStream_t s) {
+  const ParamLayout pl = param_layout(d);
+  const PackLayout L = pack_layout<P>(d, n_time);
+  const int H = d.hidden;
+  if (d.kind == 0)
+    launch_time_table(prm + pl.te1_w, prm + pl.te1_b, prm + pl.te2_w, prm + pl.te2_b, d.time_dim, n_time,
+                      (float*)(pk + L.temb), s);
+  launch_cast_pad<P>(prm + pl.W0, H, d.in_dim, d.in_dim, pk + L.W0, L.Kp0, s);
+  for (int b = 0; b < d.n_blocks; ++b) {
+    launch_cast_pad<P>(prm + pl.l1w[b], H, H, H, pk + L.W1[b], H, s);
+    launch_cast_pad<P>(prm + pl.l2w[b], H, H, H, pk + L.W2[b], H, s);
+    launch_transpose_cast<P>(prm + pl.l1w[b], H, H, H, 0, pk + L.W1T[b], H, s);
+    launch_transpose_cast<P>(prm + pl.l2w[b], H, H, H, 0, pk + L.W2T[b], H, s);
+  }
+  launch_cast_pad<P>(prm + pl.Wout, d.out_dim, H, H, pk + L.Wout, H, s);
+  // WoutT[h][o] = Wout[o][h] : src rows = out_dim, cols = H  -> dst [H][Kpo]
+  launch_transpose_cast<P>(prm + pl.Wout, d.out_dim, H, H, 0, pk + L.WoutT, L.Kpo, s);
+  if (d.kind == 0) {
+    // W0tT[j][h] = W0[h][act_flat + j]
+    launch_transpose_cast<P>(prm + pl.W0, H, d.time_dim, d.in_dim, d.act_flat, pk + L.W0tT, H, s);
+    const SamplerGeom g = sampler_geom<P>(d);
+    u32x4* ss = (u32x4*)(pk + L.sstream);
+    launch_pack_hidden<P>(prm + pl.W0, H, d.in_dim, d.in_dim, g.KS0, g.TPW, 0, g.total_pos, ss, s);
+    for (int b = 0; b < d.n_blocks; ++b) {
+      launch_pack_hidden<P>(prm + pl.l1w[b], H, H, H, g.KSH, g.TPW, g.KS0 + 2 * b * g.KSH, g.total_pos, ss, s);
+      launch_pack_hidden<P>(prm + pl.l2w[b], H, H, H, g.KSH, g.TPW, g.KS0 + (2 * b + 1) * g.KSH, g.total_pos, ss, s);
+    }
+    launch_pack_out<P>(prm + pl.Wout, d.out_dim, H, g.OT, g.CNT, (u32x4*)(pk + L.ostream), s);
+  }
+  return check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// MLP forward / backward drivers on the GEMM path
+// ------------------------------------------------------------------------------------------------
+struct Carver {
+  char* base;
+  size_t off, cap;
+  void* take(size_t bytes) {
+    off = al256(off);
+    void* p = base ? base + off : nullptr;
+    off += bytes;
+    return p;
+  }
+};
+
+template <class P>
+struct MlpBufs {  // activations of one network for M rows
+  void* in;                    // [M][Kp0] elem
+  float* h[MAX_BLOCKS + 1];    // [M][H] f32 residual stream (h[0] = layer-0 output)
+  void* a1[MAX_BLOCKS];        // act(h[b])
+  void* z1[MAX_BLOCKS];        // l1 pre-activation (elem)
+  void* a2[MAX_BLOCKS];        // act(z1)
+  void* hE;                    // elem(h[nb])
+  float* out;                  // [M][ldout] f32
+  int ldout;
+  // backward
+  void* d_out;  // [M][Kpo] elem
+  void* dh;     // [M][H] elem
+  void* dz1;    // [M][H] elem
+  float* dtemb; // [M][tdp] f32 (actor)
+  float* slab;  // split-M partial weight gradients
+  float* part;  // column-sum / segment-sum partials
+  size_t slab_floats, part_floats;
+};
+
+constexpr int REDUCE_BLOCKS = 256;
+
+template <class P>
+static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, bool bwd, MlpBufs<P>& B) {
+  const size_t ES = P::ESIZE;
+  const int H = d.hidden, nb = d.n_blocks;
+  const int Kp0 = round_up(d.in_dim, 64), Kpo = round_up(d.out_dim, 64);
+  memset(&B, 0, sizeof(B));
+  B.in = c.take((size_t)M * Kp0 * ES);
+  const int nh = keep ? nb + 1 : (nb > 0 ? 2 : 1);
+  float* hbuf[MAX_BLOCKS + 1];
+  for (int i = 0; i < nh; ++i) hbuf[i] = (float*)c.take((size_t)M * H * 4);
+  for (int b = 0; b <= nb; ++b) B.h[b] = keep ? hbuf[b] : hbuf[b & 1];
+  void* a1s = nullptr;
+  void* a2s = nullptr;
+  for (int b = 0; b < nb; ++b) {
+    if (keep || b == 0) {
+      a1s = c.take((size_t)M * H * ES);
+      a2s = c.take((size_t)M * H * ES);
+    }
+    B.a1[b] = a1s;
+    B.a2[b] = a2s;
+    B.z1[b] = keep ? c.take((size_t)M * H * ES) : nullptr;
+  }
+  B.hE = c.take((size_t)M * H * ES);
+  B.ldout = round_up(d.out_dim, 16);
+  B.out = (float*)c.take((size_t)M * B.ldout * 4);
+  if (bwd) {
+    B.d_out = c.take((size_t)M * Kpo * ES);
+    B.dh = c.take((size_t)M * H * ES);
+    B.dz1 = c.take((size_t)M * H * ES);
+    const int tdp = round_up(d.time_dim > 0 ? d.time_dim : 1, 16);
+    B.dtemb = d.kind == 0 ? (float*)c.take((size_t)M * tdp * 4) : nullptr;
+    // largest slab: H x max(H, Kp0) with up to 64 splits of a <=4-tile output, or 16+ splits of H x H
+    const size_t tiles_hh = (size_t)((H + 127) / 128) * ((H + 127) / 128);
+    size_t splits_hh = (512 + tiles_hh - 1) / tiles_hh;
+    B.slab_floats = splits_hh * (size_t)H * H;
+    const size_t alt = (size_t)128 * H * (size_t)(Kp0 > 128 ? Kp0 : 128);  // thin outputs, up to 128 splits
+    if (alt > B.slab_floats) B.slab_floats = alt;
+    B.slab = (float*)c.take(B.slab_floats * 4);
+    B.part_floats = (size_t)REDUCE_BLOCKS * (H > 1024 ? H : 1024);
+    B.part = (float*)c.take(B.part_floats * 4);
+  }
+}
+
+template <class P>
+static void mlp_forward(const dppo_net_desc& d, const float* prm, const char* pk, const PackLayout& L, int64_t M,
+                        MlpBufs<P>& B, bool keep, hipStream_t s) {
+  const ParamLayout pl = param_layout(d);
+  const int H = d.hidden, nb = d.n_blocks;
+  GemmNT g;
+  memset(&g, 0, sizeof(g));
+  g.M = (int)M;
+  // layer 0
+  g.X = B.in, g.ldx = L.Kp0, g.W = pk + L.W0, g.ldw = L.Kp0, g.Kp = L.Kp0, g.N = H, g.bias = prm + pl.b0;
+  g.out_f32 = B.h[0], g.ldo32 = H, g.ldo = H, g.act = d.act;
+  g.out_act = nb > 0 ? B.a1[0] : nullptr;
+  g.out_pre = nb > 0 ? nullptr : B.hE;
+  launch_gemm_nt<P>(g, s);
+  for (int b = 0; b < nb; ++b) {
+    memset(&g, 0, sizeof(g));
+    g.M = (int)M, g.N = H, g.Kp = H, g.ldx = H, g.ldw = H, g.ldo = H, g.ldo32 = H, g.act = d.act;
+    g.X = B.a1[b], g.W = pk + L.W1[b], g.bias = prm + pl.l1b[b];
+    g.out_pre = keep ? B.z1[b] : nullptr, g.out_act = B.a2[b];
+    launch_gemm_nt<P>(g, s);
+    g.X = B.a2[b], g.W = pk + L.W2[b], g.bias = prm + pl.l2b[b];
+    g.res = B.h[b], g.ldres = H;
+    g.out_f32 = B.h[b + 1];
+    g.out_act = b + 1 < nb ? B.a1[b + 1] : nullptr;
+    g.out_pre = b + 1 < nb ? nullptr : B.hE;
+    launch_gemm_nt<P>(g, s);
+  }
+  memset(&g, 0, sizeof(g));
+  g.M = (int)M, g.N = d.out_dim, g.Kp = H, g.ldx = H, g.ldw = H;
+  g.X = B.hE, g.W = pk + L.Wout, g.bias = prm + pl.bout, g.out_f32 = B.out, g.ldo32 = B.ldout;
+  launch_gemm_nt<P>(g, s);
+}
+
+template <class P>
+static void weight_grad(const void* A, int lda, int N1, const void* Bm, int ldb, int N2, int64_t M, MlpBufs<P>& B,
+                        float* gw, int ldgw, hipStream_t s) {
+  const size_t tiles = (size_t)((N1 + 127) / 128) * ((N2 + 127) / 128);
+  int64_t splits = (512 + tiles - 1) / tiles;
+  const int64_t max_splits = (M + 63) / 64;
+  if (splits > max_splits) splits = max_splits;
+  if (splits > 128) splits = 128;
+  while (splits > 1 && (size_t)splits * N1 * N2 > B.slab_floats) --splits;
+  int64_t rps = (M + splits - 1) / splits;
+  rps = (rps + 63) / 64 * 64;
+  splits = (M + rps - 1) / rps;
+  GemmTN t;
+  t.A = A, t.B = Bm, t.M = (int)M, t.N1 = N1, t.N2 = N2, t.lda = lda, t.ldb = ldb;
+  t.slab = B.slab, t.ldc = N2, t.splits = (int)splits, t.rows_per_split = (int)rps;
+  launch_gemm_tn<P>(t, s);
+  launch_slab_reduce_2d(B.slab, (int)splits, N1, N2, N2, gw, ldgw, 1.f, s);
+}
+
+// d_out (B.d_out, [M][Kpo] elem) -> gradients of every parameter of the network into `grad`
+template <class P>
+static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* pk, const PackLayout& L, int64_t M,
+                         MlpBufs<P>& B, float* grad, const int32_t* krow, const dppo_step* ksteps, int Kft,
+                         hipStream_t s) {
+  const ParamLayout pl = param_layout(d);
+  const int H = d.hidden, nb = d.n_blocks;
+  // output layer parameters
+  weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.hE, H, H, M, B, grad + pl.Wout, H, s);
+  launch_colsum<P>(B.d_out, (int)M, d.out_dim, L.Kpo, B.part, REDUCE_BLOCKS, grad + pl.bout, 1.f, s);
+  // dh = d_out . Wout
+  GemmNT g;
+  memset(&g, 0, sizeof(g));
+  g.M = (int)M, g.N = H, g.Kp = L.Kpo, g.ldx = L.Kpo, g.ldw = L.Kpo, g.ldo = H;
+  g.X = B.d_out, g.W = pk + L.WoutT, g.out_pre = B.dh;
+  launch_gemm_nt<P>(g, s);
+  for (int b = nb - 1; b >= 0; --b) {
+    // l2: dz2 = dh
+    weight_grad<P>(B.dh, H, H, B.a2[b], H, H, M, B, grad + pl.l2w[b], H, s);
+    launch_colsum<P>(B.dh, (int)M, H, H, B.part, REDUCE_BLOCKS, grad + pl.l2b[b], 1.f, s);
+    // dz1 = (dh . W2) * act'(z1)
+    memset(&g, 0, sizeof(g));
+    g.M = (int)M, g.N = H, g.Kp = H, g.ldx = H, g.ldw = H, g.ldo = H;
+    g.X = B.dh, g.W = pk + L.W2T[b], g.dsrc = B.z1[b], g.dsrc_kind = 2, g.dsrc_ld = H, g.dact = d.act;
+    g.out_pre = B.dz1;
+    launch_gemm_nt<P>(g, s);
+    weight_grad<P>(B.dz1, H, H, B.a1[b], H, H, M, B, grad + pl.l1w[b], H, s);
+    launch_colsum<P>(B.dz1, (int)M, H, H, B.part, REDUCE_BLOCKS, grad + pl.l1b[b], 1.f, s);
+    // dh <- dh + (dz1 . W1) * act'(h[b])      (in place: each element is read then written by one lane)
+    memset(&g, 0, sizeof(g));
+    g.M = (int)M, g.N = H, g.Kp = H, g.ldx = H, g.ldw = H, g.ldo = H;
+    g.X = B.dz1, g.W = pk + L.W1T[b], g.dsrc = B.h[b], g.dsrc_kind = 1, g.dsrc_ld = H, g.dact = d.act;
+    g.add = B.dh, g.ldadd = H, g.out_pre = B.dh;
+    launch_gemm_nt<P>(g, s);
+  }
+  // layer 0: dW0[h][c] = sum_m dh[m][h] in[m][c]
+  weight_grad<P>(B.dh, H, H, B.in, L.Kp0, d.in_dim, M, B, grad + pl.W0, d.in_dim, s);
+  launch_colsum<P>(B.dh, (int)M, H, H, B.part, REDUCE_BLOCKS, grad + pl.b0, 1.f, s);
+  if (d.kind == 0) {
+    // d temb = dh . W0[:, temb columns]; summed per fine-tuned step; back through the tiny time MLP
+    const int td = d.time_dim;
+    memset(&g, 0, sizeof(g));
+    g.M = (int)M, g.N = td, g.Kp = H, g.ldx = H, g.ldw = H;
+    g.X = B.dh, g.W = pk + L.W0tT, g.out_f32 = B.dtemb, g.ldo32 = L.tdp;
+    launch_gemm_nt<P>(g, s);
+    launch_temb_segsum(B.dtemb, L.tdp, krow, M, Kft, td, B.part, REDUCE_BLOCKS, s);
+    float* G = B.part + (size_t)REDUCE_BLOCKS * Kft * td;
+    launch_slab_reduce(B.part, REDUCE_BLOCKS, (size_t)Kft * td, G, 1.f, s);
+    launch_time_backward(prm + pl.te1_w, prm + pl.te1_b, prm + pl.te2_w, G, ksteps, Kft, td, grad + pl.te1_w,
+                         grad + pl.te1_b, grad + pl.te2_w, grad + pl.te2_b, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exported functions
+// ------------------------------------------------------------------------------------------------
+// Exported functions take C linkage from their declarations in include/dppo_hip.h.
+
+int dppo_version(void) { return 1; }
+const char* dppo_last_error(void) { return g_err; }
+
+int64_t dppo_net_param_count(const dppo_net_desc* net) {
+  if (check_net(net)) return -1;
+  return param_layout(*net).total;
+}
+
+int64_t dppo_packed_bytes(const dppo_net_desc* net, int prec, int n_time) {
+  if (check_net(net) || check_prec(prec)) return -1;
+  if (n_time < 0) return fail(-1, "n_time < 0");
+#define CALL(P) (int64_t) pack_layout<P>(*net, n_time).total
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
+}
+
+int dppo_pack_net(const dppo_net_desc* net, int prec, int n_time, const float* params, void* packed,
+                  dppo_stream_t stream) {
+  if (int e = check_net(net)) return e;
+  if (int e = check_prec(prec)) return e;
+  if (!params || !packed) return fail(-1, "null pointer");
+  if (net->kind == 0 && n_time < 1) return fail(-1, "actor needs n_time >= 1");
+#define CALL(P) pack_impl<P>(*net, n_time, params, (char*)packed, (hipStream_t)stream)
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
+}
+
+// ---- forwards --------------------------------------------------------------------------------------
+template <class P>
+static int64_t fwd_ws_bytes(const dppo_net_desc& d, int64_t rows) {
+  Carver c{nullptr, 0, 0};
+  MlpBufs<P> B;
+  carve_mlp<P>(c, d, rows, false, false, B);
+  return (int64_t)al256(c.off);
+}
+int64_t dppo_mlp_forward_workspace_bytes(const dppo_net_desc* net, int prec, int64_t rows) {
+  if (check_net(net) || check_prec(prec)) return -1;
+  if (rows < 0 || rows > 0x7fffffff) return fail(-1, "rows out of range");
+#define CALL(P) fwd_ws_bytes<P>(*net, rows)
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
+}
+
+template <class P>
+static int net_forward_impl(const dppo_net_desc& d, const float* prm, const char* pk, const float* x,
+                            const int64_t* t, const float* state, int64_t M, float* out, void* ws, int64_t wsb,
+                            hipStream_t s) {
+  Carver c{(char*)ws, 0, (size_t)wsb};
+  MlpBufs<P> B;
+  carve_mlp<P>(c, d, M, false, false, B);
+  if ((int64_t)c.off > wsb) return fail(-1, "workspace too small: need %zu bytes, got %lld", c.off, (long long)wsb);
+  const PackLayout L = pack_layout<P>(d, 0);
+  launch_build_direct<P>(x, t, state, (const float*)(pk + L.temb), d.act_flat, d.time_dim, d.cond_dim, M, B.in, L.Kp0,
+                         s);
+  mlp_forward<P>(d, prm, pk, L, M, B, false, s);
+  launch_slab_reduce_2d(B.out, 1, (int)M, d.out_dim, B.ldout, out, d.out_dim, 1.f, s);
+  return check_launch();
+}
+
+int dppo_actor_forward(const dppo_net_desc* net, int prec, const float* params, const void* packed, const float* x,
+                       const int64_t* t, const float* state, int64_t rows, float* eps, void* workspace,
+                       int64_t workspace_bytes, dppo_stream_t stream) {
+  if (int e = check_net(net)) return e;
+  if (int e = check_prec(prec)) return e;
+  if (net->kind != 0) return fail(-1, "dppo_actor_forward needs an actor descriptor");
+  if (!params || !packed || !x || !t || !state || !eps || !workspace) return fail(-1, "null pointer");
+  if (rows <= 0 || rows > 0x7fffffff) return fail(-1, "rows out of range");
+#define CALL(P) \
+  net_forward_impl<P>(*net, params, (const char*)packed, x, t, state, rows, eps, workspace, workspace_bytes, (hipStream_t)stream)
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
+}
+
+int dppo_critic_forward(const dppo_net_desc* net, int prec, const float* params, const void* packed,
+                        const float* state, int64_t rows, float* values, void* workspace, int64_t workspace_bytes,
+                        dppo_stream_t stream) {
+  if (int e = check_net(net)) return e;
+  if (int e = check_prec(prec)) return e;
+  if (net->kind != 1) return fail(-1, "dppo_critic_forward needs a critic descriptor");
+  if (!params || !packed || !state || !values || !workspace) return fail(-1, "null pointer");
+  if (rows <= 0 || rows > 0x7fffffff) return fail(-1, "rows out of range");
+#define CALL(P)                                                                                                    \
+  net_forward_impl<P>(*net, params, (const char*)packed, nullptr, nullptr, state, rows, values, workspace, workspace_bytes, \
+                      (hipStream_t)stream)
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
+}
+
+// ---- sampler -----------------------------------------------------------------------------------------
+template <class P>
+static int sample_impl(const dppo_net_desc& d, const float* pb, const char* kb, const float* pf, const char* kf,
+                       const dppo_diffusion_cfg& cfg, const dppo_step* sched, int n_steps, const float* obs,
+                       const float* noise, int64_t B, float* traj, float* chains, int chain_len, int init_slot,
+                       hipStream_t s) {
+  const SamplerGeom g = sampler_geom<P>(d);
+  const PackLayout L = pack_layout<P>(d, 0);
+  const ParamLayout pl = param_layout(d);
+  SampleArgs a;
+  memset(&a, 0, sizeof(a));
+  a.wstream[0] = (const u32x4*)(kb + L.sstream), a.wstream[1] = (const u32x4*)(kf + L.sstream);
+  a.ostream[0] = (const u32x4*)(kb + L.ostream), a.ostream[1] = (const u32x4*)(kf + L.ostream);
+  a.params[0] = pb, a.params[1] = pf;
+  a.temb[0] = (const float*)(kb + L.temb), a.temb[1] = (const float*)(kf + L.temb);
+  a.bias_off[0] = (int)pl.b0;
+  for (int b = 0; b < d.n_blocks; ++b) a.bias_off[1 + 2 * b] = (int)pl.l1b[b], a.bias_off[2 + 2 * b] = (int)pl.l2b[b];
+  a.bias_off[1 + 2 * d.n_blocks] = (int)pl.bout;
+  a.obs = obs, a.noise = noise, a.traj = traj, a.chains = chains, a.sched = sched;
+  a.B = (int)B, a.AF = d.act_flat, a.td = d.time_dim, a.cond = d.cond_dim, a.Kp0 = g.Kp0, a.nb = d.n_blocks;
+  a.n_steps = n_steps, a.chain_len = chain_len, a.init_slot = init_slot, a.act = d.act, a.use_ddim = cfg.use_ddim;
+  a.has_dclip = cfg.has_denoised_clip, a.has_eclip = cfg.has_eps_clip, a.has_fclip = cfg.has_final_clip;
+  a.dclip = cfg.denoised_clip, a.eclip = cfg.eps_clip, a.rclip = cfg.randn_clip, a.fclip = cfg.final_clip;
+  const int rc = launch_sample_chain<P>(g, a, s);
+  if (rc == -1) return fail(-1, "sampler: hidden=%d / out_dim=%d not instantiated (hidden in {256,512,1024}, out_dim <= 64)", d.hidden, d.out_dim);
+  if (rc == -2) return fail(-1, "sampler: LDS image exceeds 160 KiB for hidden=%d at this precision", d.hidden);
+  return check_launch();
+}
+
+int dppo_sample_chain(const dppo_net_desc* actor, int prec, const float* params_base, const void* packed_base,
+                      const float* params_ft, const void* packed_ft, const dppo_diffusion_cfg* cfg,
+                      const dppo_step* sched, int n_steps, const float* obs, const float* noise, int64_t B, float* traj,
+                      float* chains, int chain_len, int init_slot, dppo_stream_t stream) {
+  if (int e = check_net(actor)) return e;
+  if (int e = check_prec(prec)) return e;
+  if (actor->kind != 0) return fail(-1, "dppo_sample_chain needs an actor descriptor");
+  if (!params_base || !packed_base || !params_ft || !packed_ft || !cfg || !sched || !obs || !noise || !traj)
+    return fail(-1, "null pointer");
+  if (n_steps < 1) return fail(-1, "n_steps must be >= 1");
+  if (B < 1 || B > (1 << 24)) return fail(-1, "B out of range");
+  if (chain_len < 0 || (chain_len > 0 && !chains)) return fail(-1, "chains buffer missing");
+  if (init_slot >= chain_len) return fail(-1, "init_slot outside the chain");
+#define CALL(P)                                                                                                   \
+  sample_impl<P>(*actor, params_base, (const char*)packed_base, params_ft, (const char*)packed_ft, *cfg, sched, n_steps, obs, \
+                 noise, B, traj, chains, chain_len, init_slot, (hipStream_t)stream)
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
+}
+
+// ---- chain log-probs ---------------------------------------------------------------------------------
+template <class P>
+static int64_t logprob_ws_bytes(const dppo_net_desc& d, int64_t rows) {
+  Carver c{nullptr, 0, 0};
+  MlpBufs<P> B;
+  carve_mlp<P>(c, d, rows, false, false, B);
+  c.take((size_t)rows * 4);
+  c.take((size_t)rows * 4);
+  return (int64_t)al256(c.off);
+}
+int64_t dppo_chain_logprob_workspace_bytes(const dppo_net_desc* actor, int prec, int64_t B, int Kft) {
+  if (check_net(actor) || check_prec(prec)) return -1;
+  if (B < 0 || Kft < 1 || B * Kft > 0x7fffffff) return fail(-1, "B*Kft out of range");
+#define CALL(P) logprob_ws_bytes<P>(*actor, B* Kft)
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
+}
+
+template <class P>
+static int logprob_impl(const dppo_net_desc& d, const float* prm, const char* pk, const dppo_diffusion_cfg& cfg,
+                        const dppo_step* ksteps, int Kft, const float* obs, const float* chains, int64_t Bn, float* logp,
+                        void* ws, int64_t wsb, hipStream_t s) {
+  const int64_t M = Bn * Kft;
+  Carver c{(char*)ws, 0, (size_t)wsb};
+  MlpBufs<P> B;
+  carve_mlp<P>(c, d, M, false, false, B);
+  int32_t* brow = (int32_t*)c.take((size_t)M * 4);
+  int32_t* krow = (int32_t*)c.take((size_t)M * 4);
+  if ((int64_t)c.off > wsb) return fail(-1, "workspace too small: need %zu bytes, got %lld", c.off, (long long)wsb);
+  const PackLayout L = pack_layout<P>(d, 0);
+  BuildRows br;
+  memset(&br, 0, sizeof(br));
+  br.chains = chains, br.obs = obs, br.temb = (const float*)(pk + L.temb), br.ksteps = ksteps;
+  br.Kft = Kft, br.AF = d.act_flat, br.td = d.time_dim, br.cond = d.cond_dim, br.M = M;
+  br.inA = B.in, br.KpA = L.Kp0, br.brow = brow, br.krow = krow;
+  launch_build_rows<P>(br, s);
+  mlp_forward<P>(d, prm, pk, L, M, B, false, s);
+  LogprobArgs la;
+  la.eps = B.out, la.lde = B.ldout, la.chains = chains, la.ksteps = ksteps, la.cfg = cfg, la.Kft = Kft;
+  la.AF = d.act_flat, la.M = M, la.logp = logp;
+  launch_logprob(la, s);
+  return check_launch();
+}
+
+int dppo_chain_logprob(const dppo_net_desc* actor, int prec, const float* params, const void* packed,
+                       const dppo_diffusion_cfg* cfg, const dppo_step* ksteps, int Kft, const float* obs,
+                       const float* chains, int64_t B, float* logprobs, void* workspace, int64_t workspace_bytes,
+                       dppo_stream_t stream) {
+  if (int e = check_net(actor)) return e;
+  if (int e = check_prec(prec)) return e;
+  if (actor->kind != 0) return fail(-1, "dppo_chain_logprob needs an actor descriptor");
+  if (!params || !packed || !cfg || !ksteps || !obs || !chains || !logprobs || !workspace) return fail(-1, "null pointer");
+  if (B < 1 || Kft < 1 || B * Kft > 0x7fffffff) return fail(-1, "B*Kft out of range");
+#define CALL(P)                                                                                                 \
+  logprob_impl<P>(*actor, params, (const char*)packed, *cfg, ksteps, Kft, obs, chains, B, logprobs, workspace, workspace_bytes, \
+                  (hipStream_t)stream)
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
+}
+
+// ---- GAE ---------------------------------------------------------------------------------------------
+int dppo_gae(const double* reward, const float* values, const float* terminated, const float* last_values, int n_steps,
+             int n_envs, double gamma, double gae_lambda, double reward_scale_const, double* adv64, double* ret64,
+             float* adv32, float* ret32, dppo_stream_t stream) {
+  if (!reward || !values || !terminated || !last_values) return fail(-1, "null pointer");
+  if (n_steps < 1 || n_envs < 1) return fail(-1, "empty rollout");
+  launch_gae(reward, values, terminated, last_values, n_steps, n_envs, gamma, gae_lambda, reward_scale_const, adv64,
+             ret64, adv32, ret32, (hipStream_t)stream);
+  return check_launch();
+}
+
+// ---- PPO update --------------------------------------------------------------------------------------
+template <class P>
+struct PpoWs {
+  MlpBufs<P> A, C;
+  int32_t *brow, *krow;
+  double* moments;
+};
+template <class P>
+static size_t carve_ppo(Carver& c, const dppo_net_desc& a, const dppo_net_desc& cr, int64_t N, PpoWs<P>& W) {
+  W.moments = (double*)c.take(256);
+  W.brow = (int32_t*)c.take((size_t)N * 4);
+  W.krow = (int32_t*)c.take((size_t)N * 4);
+  carve_mlp<P>(c, a, N, true, true, W.A);
+  carve_mlp<P>(c, cr, N, true, true, W.C);
+  return al256(c.off);
+}
+int64_t dppo_ppo_workspace_bytes(const dppo_net_desc* actor, const dppo_net_desc* critic, int prec, int64_t N) {
+  if (check_net(actor) || check_net(critic) || check_prec(prec)) return -1;
+  if (N < 2 || N > 0x7fffffff) return fail(-1, "N out of range");
+  Carver c{nullptr, 0, 0};
+  if (prec == DPPO_PREC_F32) {
+    PpoWs<F32> W;
+    return (int64_t)carve_ppo<F32>(c, *actor, *critic, N, W);
+  }
+  PpoWs<BF16> W;
+  return (int64_t)carve_ppo<BF16>(c, *actor, *critic, N, W);
+}
+
+template <class P>
+static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float* ap, const char* ak, const float* cp,
+                    const char* ck, const dppo_diffusion_cfg& dcfg, const dppo_ppo_cfg& pcfg, const dppo_step* ksteps,
+                    const float* obs_k, const float* chains_k, const float* returns_k, const float* values_k,
+                    const float* adv_k, const float* logprobs_k, const int64_t* inds, const int64_t* kinds, int64_t N,
+                    const double* gmom, float* agrad, float* cgrad, double* stats, void* ws, int64_t wsb, hipStream_t s) {
+  Carver c{(char*)ws, 0, (size_t)wsb};
+  PpoWs<P> W;
+  const size_t need = carve_ppo<P>(c, a, cr, N, W);
+  if ((int64_t)need > wsb) return fail(-1, "workspace too small: need %zu bytes, got %lld", need, (long long)wsb);
+  const PackLayout LA = pack_layout<P>(a, 0), LC = pack_layout<P>(cr, 0);
+  const int Kft = pcfg.ft_denoising_steps;
+  (void)hipMemsetAsync(stats, 0, DPPO_STAT_COUNT * sizeof(double), s);
+  (void)hipMemsetAsync(W.moments, 0, 256, s);
+  BuildRows br;
+  memset(&br, 0, sizeof(br));
+  br.inds = inds, br.kinds = kinds, br.chains = chains_k, br.obs = obs_k, br.temb = (const float*)(ak + LA.temb);
+  br.ksteps = ksteps;
+  br.Kft = Kft, br.AF = a.act_flat, br.td = a.time_dim, br.cond = a.cond_dim, br.M = N;
+  br.inA = W.A.in, br.KpA = LA.Kp0, br.inC = W.C.in, br.KpC = LC.Kp0, br.brow = W.brow, br.krow = W.krow;
+  launch_build_rows<P>(br, s);
+  if (gmom == nullptr) launch_adv_moments(adv_k, W.brow, N, W.moments, s);
+  mlp_forward<P>(a, ap, ak, LA, N, W.A, true, s);
+  mlp_forward<P>(cr, cp, ck, LC, N, W.C, true, s);
+  LossArgs la;
+  memset(&la, 0, sizeof(la));
+  la.eps = W.A.out, la.lde = W.A.ldout, la.vnew = W.C.out, la.ldv = W.C.ldout, la.brow = W.brow, la.krow = W.krow;
+  la.gathered = kinds != nullptr;
+  la.chains = chains_k, la.logprobs_k = logprobs_k, la.returns_k = returns_k, la.values_k = values_k, la.adv_k = adv_k;
+  la.ksteps = ksteps, la.dcfg = dcfg, la.pcfg = pcfg, la.AF = a.act_flat, la.N = N;
+  la.moments = gmom ? gmom : W.moments;
+  la.d_eps = W.A.d_out, la.ldde = LA.Kpo, la.d_v = W.C.d_out, la.lddv = LC.Kpo, la.stats = stats;
+  launch_ppo_loss<P>(la, s);
+  mlp_backward<P>(a, ap, ak, LA, N, W.A, agrad, W.krow, ksteps, Kft, s);
+  mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s);
+  return check_launch();
+}
+
+int dppo_ppo_loss_fwd_bwd(const dppo_net_desc* actor, const dppo_net_desc* critic, int prec, const float* actor_params,
+                          const void* actor_packed, const float* critic_params, const void* critic_packed,
+                          const dppo_diffusion_cfg* dcfg, const dppo_ppo_cfg* pcfg, const dppo_step* ksteps,
+                          const float* obs_k, const float* chains_k, const float* returns_k, const float* values_k,
+                          const float* adv_k, const float* logprobs_k, const int64_t* inds, const int64_t* kinds,
+                          int64_t N, const double* global_moments, float* actor_grad, float* critic_grad,
+                          double* stats, void* workspace, int64_t workspace_bytes, dppo_stream_t stream) {
+  if (int e = check_net(actor)) return e;
+  if (int e = check_net(critic)) return e;
+  if (int e = check_prec(prec)) return e;
+  if (actor->kind != 0 || critic->kind != 1) return fail(-1, "descriptor kinds must be (actor, critic)");
+  if (actor->cond_dim != critic->cond_dim) return fail(-1, "actor and critic observe different cond_dim");
+  if (!actor_params || !actor_packed || !critic_params || !critic_packed || !dcfg || !pcfg || !ksteps || !obs_k ||
+      !chains_k || !returns_k || !values_k || !adv_k || !logprobs_k || !actor_grad || !critic_grad || !stats ||
+      !workspace)
+    return fail(-1, "null pointer");
+  if ((inds == nullptr) == (kinds == nullptr)) return fail(-1, "pass exactly one of inds (rollout mode) / kinds (gathered mode)");
+  if (N < 2 || N > 0x7fffffff) return fail(-1, "N out of range");
+  if (pcfg->ft_denoising_steps < 1 || pcfg->ft_denoising_steps > 1024) return fail(-1, "Kft out of range");
+  if (pcfg->horizon_steps * pcfg->action_dim != actor->act_flat) return fail(-1, "Ta*Da != act_flat");
+  if (pcfg->reward_horizon < 1) return fail(-1, "reward_horizon must be >= 1");
+#define CALL(P)                                                                                                        \
+  ppo_impl<P>(*actor, *critic, actor_params, (const char*)actor_packed, critic_params, (const char*)critic_packed, *dcfg,     \
+              *pcfg, ksteps, obs_k, chains_k, returns_k, values_k, adv_k, logprobs_k, inds, kinds, N, global_moments, actor_grad, critic_grad, stats, \
+              workspace, workspace_bytes, (hipStream_t)stream)
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
+}
+
+// ---- optimiser ----------------------------------------------------------------------------------------
+int dppo_grad_sq_norm(const float* grad, int64_t n, double* scratch, double* out, dppo_stream_t stream) {
+  if (!grad || !scratch || !out || n < 1) return fail(-1, "bad argument");
+  launch_sq_norm(grad, n, scratch, out, (hipStream_t)stream);
+  return check_launch();
+}
+
+int dppo_adamw_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step, double lr,
+                    double beta1, double beta2, double eps, double weight_decay, const double* sq_norm, double max_norm,
+                    dppo_stream_t stream) {
+  if (!params || !grad || !exp_avg || !exp_avg_sq || n < 1 || step < 1) return fail(-1, "bad argument");
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  launch_adamw(params, grad, exp_avg, exp_avg_sq, n, (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2,
+               (float)(1.0 - beta2), (float)(lr / bc1), (float)sqrt(bc2), (float)eps, sq_norm, (float)max_norm,
+               (hipStream_t)stream);
+  return check_launch();
+}
+

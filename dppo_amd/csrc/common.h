@@ -1,0 +1,79 @@
+// Shared device/host definitions for the DPPO gfx950 kernels.
+//
+// Precision policy: every dense contraction runs on MFMA with fp32 accumulation.  Two operand
+// precisions are built from one source via the Prec traits below:
+//   F32  : v_mfma_f32_16x16x4_f32   (exact fp32 products; parity mode, tolerance 1e-5 class)
+//   BF16 : v_mfma_f32_16x16x32_bf16 (operands rounded to bf16; throughput mode)
+// Both consume operands as "64-byte k-steps": each of the 16 operand rows of a tile contributes 64
+// contiguous bytes of K (16 fp32 or 32 bf16); lane l = (r = l & 15, g = l >> 4) holds bytes
+// [16g, 16g+16) of row r.  For bf16 that is exactly the hardware map A[r][8g..8g+7]; for fp32 the
+// four MFMAs of a k-step use element s of both operands, i.e. k = 4g + s -- a permutation of k that
+// is the same for A and B and therefore leaves the product unchanged.
+// D layout (both): lane (r, g) holds D[4g + e][r], e = 0..3.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dppo {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short i16x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;  // one 16-byte MFMA fragment per lane (native vector: stays in VGPRs)
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+enum { ACT_RELU = 0, ACT_MISH = 1, ACT_NONE = 2 };
+
+__device__ __forceinline__ uint16_t f2bf(float x) {
+  __bf16 b = (__bf16)x;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+  return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+
+struct F32 {
+  typedef float elem_t;
+  static constexpr int KB = 16;  // elements per 64-byte k-step
+  static constexpr int ESIZE = 4;
+  static __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    return c;
+  }
+  static __device__ __forceinline__ elem_t from_f32(float x) { return x; }
+  static __device__ __forceinline__ float to_f32(elem_t x) { return x; }
+};
+
+struct BF16 {
+  typedef uint16_t elem_t;
+  static constexpr int KB = 32;
+  static constexpr int ESIZE = 2;
+  static __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
+                                                   0, 0, 0);
+  }
+  static __device__ __forceinline__ elem_t from_f32(float x) { return f2bf(x); }
+  static __device__ __forceinline__ float to_f32(elem_t x) { return bf2f(x); }
+};
+
+// nn.Mish = x * tanh(softplus(x)), softplus threshold 20 (torch default)
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float mish_f(float x) { return x * tanhf(softplus_f(x)); }
+__device__ __forceinline__ float mish_grad_f(float x) {
+  // d/dx [x tanh(sp(x))] = tanh(sp) + x (1 - tanh(sp)^2) sigmoid(x)   (sp' = sigmoid; =1 above the threshold)
+  float sp = softplus_f(x);
+  float th = tanhf(sp);
+  float sg = x > 20.f ? 1.f : 1.f / (1.f + expf(-x));
+  return th + x * (1.f - th * th) * sg;
+}
+__device__ __forceinline__ float act_f(int act, float x) {
+  return act == ACT_RELU ? fmaxf(x, 0.f) : (act == ACT_MISH ? mish_f(x) : x);
+}
+__device__ __forceinline__ float act_grad_f(int act, float x) {
+  return act == ACT_RELU ? (x > 0.f ? 1.f : 0.f) : (act == ACT_MISH ? mish_grad_f(x) : 1.f);
+}
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+}  // namespace dppo

@@ -1,0 +1,55 @@
+// MFMA GEMM kernels for the big-batch side of the DPPO path (log-prob precompute, PPO update).
+//
+//  gemm_nt : Y[M,N] = epi( X[M,Kp] . W[N,Kp]^T )          forward layers and backward-data
+//  gemm_tn : C[N1,N2] (+)= A[M,N1]^T . B[M,N2]             weight gradients, split over M into slabs
+//
+// Both are written "transposed": the MFMA's 16-row operand (A) is the weight / gradient-feature
+// side and its 16-column operand (B) is the batch-row side, so every lane ends up owning ONE batch
+// row and a run of 4*TN consecutive features -- epilogue loads/stores are 16-byte vectors and one
+// wave instruction covers 16 rows x 128 contiguous bytes.
+#pragma once
+#include "common.h"
+
+namespace dppo {
+
+struct GemmNT {
+  const void* X;  // [M][ldx] elem (row-major), columns >= Kp never read
+  const void* W;  // [N][ldw] elem (nn.Linear layout), rows >= N treated as zero
+  const float* bias;  // [N] or null
+  int M, N, Kp;       // Kp: multiple of 128 bytes / esize
+  int ldx, ldw;
+  // epilogue, in this order:  v = acc + bias;  v *= act'(dsrc);  v += res + add;  stores
+  const void* dsrc;  // pre-activation the derivative is taken at: f32 (dsrc_kind 1) or elem (2)
+  int dsrc_kind, dsrc_ld, dact;
+  const float* res;  // f32 addend [M][ldres]
+  int ldres;
+  const void* add;  // elem addend [M][ldadd]
+  int ldadd;
+  float* out_f32;  // [M][ldo32]
+  int ldo32;
+  void* out_pre;  // elem(v)        [M][ldo]
+  void* out_act;  // elem(act(v))   [M][ldo]
+  int ldo, act;
+};
+
+struct GemmTN {
+  const void* A;  // [M][lda] elem ; contributes rows of C (N1)
+  const void* B;  // [M][ldb] elem ; contributes columns of C (N2)
+  int M, N1, N2, lda, ldb;
+  float* slab;  // [splits][N1][ldc] partial sums
+  int ldc, splits, rows_per_split;  // rows_per_split multiple of 64
+};
+
+template <class P>
+void launch_gemm_nt(const GemmNT& a, hipStream_t s);
+template <class P>
+void launch_gemm_tn(const GemmTN& a, hipStream_t s);
+
+// out[n] (+)= sum_s slab[s][n]  (fixed order => reproducible)
+void launch_slab_reduce(const float* slab, int splits, size_t n, float* out, float scale, hipStream_t s);
+// colsum[j] = sum_m A[m][j] for j < N ; deterministic two-stage
+template <class P>
+void launch_colsum(const void* A, int M, int N, int lda, float* partial /*[blocks][N]*/, int blocks, float* out,
+                   float scale, hipStream_t s);
+
+}  // namespace dppo

@@ -1,0 +1,393 @@
+// See gemm.h.  gfx950 only.
+#include "gemm.h"
+
+namespace dppo {
+
+// ------------------------------------------------------------------------------------------------
+// gemm_nt
+// ------------------------------------------------------------------------------------------------
+// Block = WN x WM waves; a wave owns TN x TM MFMA tiles (16 features x 16 batch rows each).
+// One LDS stage holds 128 bytes of K (two 64-byte k-steps) for BN weight rows and BM batch rows;
+// 16-byte chunk c of tile row q lives at chunk position c ^ (q & 7): conflict-free for both the
+// 8-lanes-per-row ds_write_b128 of the loader and the fragment ds_read_b128 (lane (r,g) reads
+// chunk 4s+g of row r: the 16 lanes of each b128 lane group land on 16 distinct 16-byte slots).
+// LDS weight row q is NOT feature feat0+q: rows are permuted so that MFMA output row i = 4g+e of
+// tile tn is feature 4*TN*g + 4*tn + e of the wave's slice, which gives each lane 4*TN consecutive
+// features of one batch row in its accumulators.
+template <class P, int WN, int WM, int TN, int TM>
+__global__ __launch_bounds__(WN* WM * 64) void gemm_nt_kernel(const GemmNT a) {
+  typedef typename P::elem_t E;
+  constexpr int BN = WN * TN * 16, BM = WM * TM * 16, T = WN * WM * 64, ES = P::ESIZE;
+  constexpr int NW = (BN * 8 + T - 1) / T, NX = (BM * 8 + T - 1) / T;
+  constexpr int STAGE = (BN + BM) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int wn = wid % WN, wm = wid / WN;
+  const int row0 = blockIdx.x * BM, feat0 = blockIdx.y * BN;
+  const char* Xb = (const char*)a.X;
+  const char* Wb = (const char*)a.W;
+  const int nk = a.Kp * ES / 128;
+
+  u32x4 wreg[NW], xreg[NX];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int q = (tid + i * T) % (BN * 8);  // BN*8 < T (skinny tiles): surplus threads reload a valid chunk
+      const int rho = q >> 3, c = q & 7;
+      const int w_ = rho / (16 * TN), tn = (rho >> 4) % TN, ii = rho & 15;
+      const int feat = feat0 + w_ * 16 * TN + 4 * TN * (ii >> 2) + 4 * tn + (ii & 3);
+      const bool ok = feat < a.N;
+      const u32x4 v = *(const u32x4*)(Wb + (size_t)(ok ? feat : 0) * a.ldw * ES + (size_t)kt * 128 + c * 16);
+      wreg[i] = ok ? v : (u32x4){0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int q = tid + i * T;
+      const int rr = q >> 3, c = q & 7;
+      int row = row0 + rr;
+      row = row < a.M ? row : a.M - 1;
+      xreg[i] = *(const u32x4*)(Xb + (size_t)row * a.ldx * ES + (size_t)kt * 128 + c * 16);
+    }
+  };
+  auto sstore = [&](int st) {
+    char* Ws = smem + st * STAGE;
+    char* Xs = Ws + BN * 128;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int q = (tid + i * T) % (BN * 8);  // duplicates write identical bytes to the same address
+      const int rho = q >> 3, c = q & 7;
+      *(u32x4*)(Ws + rho * 128 + ((c ^ (rho & 7)) << 4)) = wreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int q = tid + i * T;
+      const int rr = q >> 3, c = q & 7;
+      *(u32x4*)(Xs + rr * 128 + ((c ^ (rr & 7)) << 4)) = xreg[i];
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const char* Ws = smem + cur * STAGE;
+    const char* Xs = Ws + BN * 128;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4 af[TN], bf[TM];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int rho = wn * TN * 16 + tn * 16 + r;
+        af[tn] = *(const u32x4*)(Ws + rho * 128 + (((s * 4 + g) ^ (rho & 7)) << 4));
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int rr = wm * TM * 16 + tm * 16 + r;
+        bf[tm] = *(const u32x4*)(Xs + rr * 128 + (((s * 4 + g) ^ (rr & 7)) << 4));
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = P::mma(af[tn], bf[tm], acc[tn][tm]);
+    }
+    if (kt + 1 < nk) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane (r,g) owns batch row (.. + r) and features f0 .. f0 + 4*TN - 1
+  const int f0 = feat0 + wn * 16 * TN + 4 * TN * g;
+  const int nst = (a.N + 15) & ~15;  // stored width: buffers are padded to >= round_up(N,16) columns
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int row = row0 + wm * TM * 16 + tm * 16 + r;
+    if (row >= a.M) continue;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int f = f0 + 4 * tn;
+      if (f >= nst) continue;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = acc[tn][tm][e];
+        if (a.bias != nullptr && f + e < a.N) v[e] += a.bias[f + e];
+      }
+      if (a.dsrc_kind == 1) {
+        const float4 d = *(const float4*)((const float*)a.dsrc + (size_t)row * a.dsrc_ld + f);
+        v[0] *= act_grad_f(a.dact, d.x);
+        v[1] *= act_grad_f(a.dact, d.y);
+        v[2] *= act_grad_f(a.dact, d.z);
+        v[3] *= act_grad_f(a.dact, d.w);
+      } else if (a.dsrc_kind == 2) {
+        const E* d = (const E*)a.dsrc + (size_t)row * a.dsrc_ld + f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= act_grad_f(a.dact, P::to_f32(d[e]));
+      }
+      if (a.res != nullptr) {
+        const float4 d = *(const float4*)(a.res + (size_t)row * a.ldres + f);
+        v[0] += d.x;
+        v[1] += d.y;
+        v[2] += d.z;
+        v[3] += d.w;
+      }
+      if (a.add != nullptr) {
+        const E* d = (const E*)a.add + (size_t)row * a.ldadd + f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += P::to_f32(d[e]);
+      }
+      if (a.out_f32 != nullptr)
+        *(float4*)(a.out_f32 + (size_t)row * a.ldo32 + f) = make_float4(v[0], v[1], v[2], v[3]);
+      if (a.out_pre != nullptr) {
+        E* o = (E*)a.out_pre + (size_t)row * a.ldo + f;
+        if constexpr (ES == 4) {
+          *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          u32x2 pk;
+          pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+          pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          *(u32x2*)o = pk;
+        }
+      }
+      if (a.out_act != nullptr) {
+        E* o = (E*)a.out_act + (size_t)row * a.ldo + f;
+        float w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = act_f(a.act, v[e]);
+        if constexpr (ES == 4) {
+          *(float4*)o = make_float4(w[0], w[1], w[2], w[3]);
+        } else {
+          u32x2 pk;
+          pk.x = (uint32_t)f2bf(w[0]) | ((uint32_t)f2bf(w[1]) << 16);
+          pk.y = (uint32_t)f2bf(w[2]) | ((uint32_t)f2bf(w[3]) << 16);
+          *(u32x2*)o = pk;
+        }
+      }
+    }
+  }
+}
+
+template <class P, int WN, int WM, int TN, int TM>
+static void launch_nt_cfg(const GemmNT& a, hipStream_t s) {
+  constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
+  dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
+  const size_t lds = 2 * (BN + BM) * 128;
+  hipLaunchKernelGGL((gemm_nt_kernel<P, WN, WM, TN, TM>), grid, dim3(WN * WM * 64), lds, s, a);
+}
+
+template <class P>
+void launch_gemm_nt(const GemmNT& a, hipStream_t s) {
+  if (a.M <= 0) return;
+  if (a.N <= 16)
+    launch_nt_cfg<P, 1, 4, 1, 4>(a, s);  // 16 features x 256 rows
+  else if (a.N <= 64)
+    launch_nt_cfg<P, 1, 4, 4, 2>(a, s);  // 64 x 128
+  else
+    launch_nt_cfg<P, 2, 2, 4, 4>(a, s);  // 128 x 128
+}
+template void launch_gemm_nt<F32>(const GemmNT&, hipStream_t);
+template void launch_gemm_nt<BF16>(const GemmNT&, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// gemm_tn  (weight gradients): C[n1][n2] = sum_m A[m][n1] * B[m][n2]
+// ------------------------------------------------------------------------------------------------
+// 128 x 128 output tile per block, 4 waves (2 x 2), each 64 x 64 = 4 x 4 MFMA tiles.  The
+// contraction runs over batch rows, which are the slow dimension of both operands, so fragments
+// need a transpose on the way out of LDS:
+//   bf16: ds_read_b64_tr_b16 -- a 16-lane group reads a 4-row x 16-column block and gets it
+//         column-major; lane group g takes rows 8g..8g+7 of a 32-row k-step in two reads.  Odd g
+//         swap the two halves (a k-permutation common to A and B) so that with a 288-byte row
+//         stride the 8 rows touched by a 32-lane half are distinct mod 8: conflict-free.
+//   fp32: one dword per lane per MFMA, read straight down the column (stride 576 B, conflict-free).
+template <class P>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN a) {
+  constexpr int ES = P::ESIZE;
+  constexpr int ROWS = (ES == 2) ? 64 : 32;     // batch rows per LDS stage (two k-steps)
+  constexpr int RSTR = (ES == 2) ? 288 : 576;   // LDS row stride in bytes (128 features + pad)
+  constexpr int CPR = 128 * ES / 16;            // 16-byte chunks per tile row
+  constexpr int NCH = ROWS * CPR / 256;         // chunks per thread per operand (= 4)
+  constexpr int OPB = ROWS * RSTR;              // bytes per operand tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int wa = wid & 1, wb = wid >> 1;
+  const int fa0 = blockIdx.x * 128, fb0 = blockIdx.y * 128;
+  const int m_begin = blockIdx.z * a.rows_per_split;
+  const int m_end = min(a.M, m_begin + a.rows_per_split);
+  const char* Ab = (const char*)a.A;
+  const char* Bb = (const char*)a.B;
+
+  u32x4 areg[NCH], breg[NCH];
+  auto gload = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int q = tid + i * 256;
+      const int rr = q / CPR, c = q % CPR;
+      const int row = m0 + rr;
+      const int ca = fa0 + c * (16 / ES), cb = fb0 + c * (16 / ES);
+      const bool oka = row < m_end && ca < a.lda, okb = row < m_end && cb < a.ldb;
+      const u32x4 va = *(const u32x4*)(Ab + ((size_t)(oka ? row : 0) * a.lda + (oka ? ca : 0)) * ES);
+      const u32x4 vb = *(const u32x4*)(Bb + ((size_t)(okb ? row : 0) * a.ldb + (okb ? cb : 0)) * ES);
+      areg[i] = oka ? va : (u32x4){0, 0, 0, 0};
+      breg[i] = okb ? vb : (u32x4){0, 0, 0, 0};
+    }
+  };
+  auto sstore = [&](int st) {
+    char* As = smem + st * 2 * OPB;
+    char* Bs = As + OPB;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int q = tid + i * 256;
+      const int rr = q / CPR, c = q % CPR;
+      *(u32x4*)(As + rr * RSTR + c * 16) = areg[i];
+      *(u32x4*)(Bs + rr * RSTR + c * 16) = breg[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nst = (m_end - m_begin + ROWS - 1) / ROWS;
+  if (nst > 0) {
+    gload(m_begin);
+    sstore(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < nst; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < nst) gload(m_begin + (st + 1) * ROWS);
+    const char* As = smem + cur * 2 * OPB;
+    const char* Bs = As + OPB;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4 af[4], bf[4];
+      if constexpr (ES == 2) {
+        // rows of this k-step: 32s .. 32s+31 ; lane group g: 32s + 8g + {0..7}
+        const int q = r >> 2, p = r & 3;
+        const int rbase = 32 * s + 8 * g;
+        const int rA = rbase + ((g & 1) ? 4 : 0) + q;  // first read
+        const int rB = rbase + ((g & 1) ? 0 : 4) + q;  // second read
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int ca = (wa * 64 + t * 16 + 4 * p) * 2, cb = (wb * 64 + t * 16 + 4 * p) * 2;
+          typedef __attribute__((address_space(3))) i16x4 lds_v;
+          i16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(As + rA * RSTR + ca));
+          i16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(As + rB * RSTR + ca));
+          i16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(Bs + rA * RSTR + cb));
+          i16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(Bs + rB * RSTR + cb));
+          const u32x2 ua0 = __builtin_bit_cast(u32x2, a0), ua1 = __builtin_bit_cast(u32x2, a1);
+          const u32x2 ub0 = __builtin_bit_cast(u32x2, b0), ub1 = __builtin_bit_cast(u32x2, b1);
+          af[t] = (u32x4){ua0.x, ua0.y, ua1.x, ua1.y};
+          bf[t] = (u32x4){ub0.x, ub0.y, ub1.x, ub1.y};
+        }
+      } else {
+        // rows of this k-step: 16s .. 16s+15 ; MFMA j of the step uses row 16s + 4j + g
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int ca = (wa * 64 + t * 16 + r) * 4, cb = (wb * 64 + t * 16 + r) * 4;
+          uint32_t va[4], vb[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int row = 16 * s + 4 * j + g;
+            va[j] = *(const uint32_t*)(As + row * RSTR + ca);
+            vb[j] = *(const uint32_t*)(Bs + row * RSTR + cb);
+          }
+          af[t] = (u32x4){va[0], va[1], va[2], va[3]};
+          bf[t] = (u32x4){vb[0], vb[1], vb[2], vb[3]};
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = P::mma(af[i], bf[j], acc[i][j]);
+    }
+    if (st + 1 < nst) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  float* out = a.slab + (size_t)blockIdx.z * a.N1 * a.ldc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n1 = fa0 + wa * 64 + i * 16 + 4 * g + e;
+      if (n1 >= a.N1) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n2 = fb0 + wb * 64 + j * 16 + r;
+        if (n2 < a.N2) out[(size_t)n1 * a.ldc + n2] = acc[i][j][e];
+      }
+    }
+}
+
+template <class P>
+void launch_gemm_tn(const GemmTN& a, hipStream_t s) {
+  dim3 grid((a.N1 + 127) / 128, (a.N2 + 127) / 128, a.splits);
+  static bool attr_set = false;  // 72 KiB of dynamic LDS needs the cap raised once per kernel
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_tn_kernel<P>), grid, dim3(256), 73728, s, a);
+}
+template void launch_gemm_tn<F32>(const GemmTN&, hipStream_t);
+template void launch_gemm_tn<BF16>(const GemmTN&, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// small reductions
+// ------------------------------------------------------------------------------------------------
+__global__ void slab_reduce_kernel(const float* slab, int splits, size_t n, float* out, float scale) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += slab[(size_t)k * n + i];
+  out[i] = s * scale;
+}
+void launch_slab_reduce(const float* slab, int splits, size_t n, float* out, float scale, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slab, splits, n, out,
+                     scale);
+}
+
+// partial[b][j] = sum over this block's row range of A[m][j]; 256 threads = 4 row-lanes x 64 column-lanes
+template <class P>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* A_, int M, int N, int lda, float* partial) {
+  typedef typename P::elem_t E;
+  const E* A = (const E*)A_;
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int rows_per_block = (M + gridDim.x - 1) / gridDim.x;
+  const int m0 = blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  for (int c0 = 0; c0 < N; c0 += 64) {
+    const int c = c0 + cl;
+    float s = 0.f;
+    if (c < N)
+      for (int m = m0 + rl; m < m1; m += 4) s += P::to_f32(A[(size_t)m * lda + c]);
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < N) partial[(size_t)blockIdx.x * N + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    __syncthreads();
+  }
+}
+template <class P>
+void launch_colsum(const void* A, int M, int N, int lda, float* partial, int blocks, float* out, float scale,
+                   hipStream_t s) {
+  hipLaunchKernelGGL((colsum_kernel<P>), dim3(blocks), dim3(256), 0, s, A, M, N, lda, partial);
+  launch_slab_reduce(partial, blocks, (size_t)N, out, scale, s);
+}
+template void launch_colsum<F32>(const void*, int, int, int, float*, int, float*, float, hipStream_t);
+template void launch_colsum<BF16>(const void*, int, int, int, float*, int, float*, float, hipStream_t);
+
+}  // namespace dppo

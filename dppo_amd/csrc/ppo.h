@@ -1,0 +1,115 @@
+// Element-wise / reduction kernels of the DPPO path: minibatch gather, fused PPO loss (forward
+// statistics + d loss / d eps), Gaussian log-prob epilogue, time-embedding table forward/backward,
+// GAE scan, AdamW, parameter packing for the GEMM path.
+#pragma once
+#include "common.h"
+#include "../../include/dppo_hip.h"
+
+namespace dppo {
+
+// ---- packing ------------------------------------------------------------------------------------
+// dst[r][c] (ldd, elem) = c < cols ? src[r][c] (lds, f32) : 0     for r < rows, c < ldd
+template <class P>
+void launch_cast_pad(const float* src, int rows, int cols, int lds, void* dst, int ldd, hipStream_t s);
+// dst[c][r] (ldd, elem) = src[r][coff + c] for r < rows, c < cols ; zero for rows <= r < ldd
+template <class P>
+void launch_transpose_cast(const float* src, int rows, int cols, int lds, int coff, void* dst, int ldd,
+                           hipStream_t s);
+// time-embedding table: temb[t][td] for t < n_time (model/diffusion/mlp_diffusion.py:191-196,
+// modules.py:20-27); hid[t][2td] keeps the pre-Mish activations for the backward
+void launch_time_table(const float* w1, const float* b1, const float* w2, const float* b2, int td, int n_time,
+                       float* temb, hipStream_t s);
+
+// ---- row building -------------------------------------------------------------------------------
+struct BuildRows {
+  // rollout mode (kinds == null): sample n: ind = inds ? inds[n] : n ; b = ind / Kft ; k = ind % Kft ;
+  //   chains [R][Kft+1][AF].   gathered mode (kinds != null): b = n, k = kinds[n], chains [M][2][AF] = (x_k, x_k+1)
+  const int64_t* inds;
+  const int64_t* kinds;
+  const float* chains;  // [R][Kft+1][AF]
+  const float* obs;     // [R][cond]
+  const float* temb;    // [n_time][td]
+  const dppo_step* ksteps;
+  int Kft, AF, td, cond;
+  int64_t M;
+  void* inA;  // [M][KpA] elem : [x_k | temb(t_k) | obs | 0]
+  int KpA;
+  void* inC;  // [M][KpC] elem : [obs | 0]   (may be null)
+  int KpC;
+  int32_t* brow;  // [M]
+  int32_t* krow;  // [M]
+};
+template <class P>
+void launch_build_rows(const BuildRows& a, hipStream_t s);
+
+// direct rows (DiffusionMLP.forward / CriticObs.forward called on explicit tensors)
+template <class P>
+void launch_build_direct(const float* x, const int64_t* t, const float* state, const float* temb, int AF, int td,
+                         int cond, int64_t M, void* in, int Kp, hipStream_t s);
+
+// ---- log-prob epilogue (diffusion_vpg.py:381-396) -------------------------------------------------
+struct LogprobArgs {
+  const float* eps;  // [M][lde]
+  int lde;
+  const float* chains;  // [B][Kft+1][AF] ; row n = (b = n / Kft, k = n % Kft)
+  const dppo_step* ksteps;
+  dppo_diffusion_cfg cfg;
+  int Kft, AF;
+  int64_t M;
+  float* logp;  // [M][AF]
+};
+void launch_logprob(const LogprobArgs& a, hipStream_t s);
+
+// ---- fused PPO loss (diffusion_ppo.py:85-199) -----------------------------------------------------
+struct LossArgs {
+  const float* eps;  // [N][lde] actor output
+  int lde;
+  const float* vnew;  // [N][ldv] critic output (column 0)
+  int ldv;
+  const int32_t* brow;
+  const int32_t* krow;
+  int gathered;             // 1: chains [N][2][AF], logprobs_k [N][AF] (already gathered per sample)
+  const float* chains;      // [R][Kft+1][AF]
+  const float* logprobs_k;  // [R][Kft][AF]
+  const float* returns_k;
+  const float* values_k;
+  const float* adv_k;
+  const dppo_step* ksteps;
+  dppo_diffusion_cfg dcfg;
+  dppo_ppo_cfg pcfg;
+  int AF;
+  int64_t N;
+  const double* moments;  // [3] sum(adv), sum(adv^2), count over the (global) minibatch
+  void* d_eps;            // [N][ldde] elem, zero padded
+  int ldde;
+  void* d_v;  // [N][lddv] elem, column 0, zero padded
+  int lddv;
+  double* stats;  // [DPPO_STAT_COUNT], zeroed by the caller
+};
+template <class P>
+void launch_ppo_loss(const LossArgs& a, hipStream_t s);
+// moments[0] += sum adv_k[brow[n]], [1] += sum of squares, [2] += N (float64; zeroed by the caller)
+void launch_adv_moments(const float* adv_k, const int32_t* brow, int64_t N, double* moments, hipStream_t s);
+
+// ---- time-embedding backward ---------------------------------------------------------------------
+// partial[blk][k][j] = sum over the block's rows with krow == k of dtemb[row][j]
+void launch_temb_segsum(const float* dtemb, int ld, const int32_t* krow, int64_t M, int Kft, int td, float* partial,
+                        int blocks, hipStream_t s);
+// G[k][td] (already reduced) -> grads of time_embedding.{1,3}.{weight,bias}; ksteps[k].t gives the time
+void launch_time_backward(const float* w1, const float* b1, const float* w2, const float* G, const dppo_step* ksteps,
+                          int Kft, int td, float* gw1, float* gb1, float* gw2, float* gb2, hipStream_t s);
+
+// out[r][c] (ldo) = scale * sum_s slab[s][r][c] (lds) for r < rows, c < cols
+void launch_slab_reduce_2d(const float* slab, int splits, int rows, int cols, int lds, float* out, int ldo,
+                           float scale, hipStream_t s);
+
+// ---- GAE / optimiser -----------------------------------------------------------------------------
+void launch_gae(const double* reward, const float* values, const float* terminated, const float* last_values, int S,
+                int E, double gamma, double lam, double rconst, double* adv64, double* ret64, float* adv32,
+                float* ret32, hipStream_t s);
+void launch_sq_norm(const float* g, int64_t n, double* scratch, double* out, hipStream_t s);
+void launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr_wd_mul, float one_m_b1, float b2,
+                  float one_m_b2, float step_size, float bc2_sqrt, float eps, const double* sq_norm, float max_norm,
+                  hipStream_t s);
+
+}  // namespace dppo

@@ -1,0 +1,568 @@
+// See ppo.h.  gfx950 only.  Compiled with -ffp-contract=off: the loss / posterior arithmetic keeps
+// the reference's op sequence.
+#include "ppo.h"
+
+namespace dppo {
+
+// =================================================================================================
+// packing
+// =================================================================================================
+template <class P>
+__global__ void cast_pad_kernel(const float* src, int rows, int cols, int lds, typename P::elem_t* dst, int ldd) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * ldd) return;
+  const int r = (int)(i / ldd), c = (int)(i % ldd);
+  dst[i] = P::from_f32(c < cols ? src[(size_t)r * lds + c] : 0.f);
+}
+template <class P>
+void launch_cast_pad(const float* src, int rows, int cols, int lds, void* dst, int ldd, hipStream_t s) {
+  const size_t n = (size_t)rows * ldd;
+  hipLaunchKernelGGL((cast_pad_kernel<P>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, rows, cols, lds,
+                     (typename P::elem_t*)dst, ldd);
+}
+template void launch_cast_pad<F32>(const float*, int, int, int, void*, int, hipStream_t);
+template void launch_cast_pad<BF16>(const float*, int, int, int, void*, int, hipStream_t);
+
+template <class P>
+__global__ void transpose_cast_kernel(const float* src, int rows, int cols, int lds, int coff,
+                                      typename P::elem_t* dst, int ldd) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)cols * ldd) return;
+  const int c = (int)(i / ldd), r = (int)(i % ldd);
+  dst[i] = P::from_f32(r < rows ? src[(size_t)r * lds + coff + c] : 0.f);
+}
+template <class P>
+void launch_transpose_cast(const float* src, int rows, int cols, int lds, int coff, void* dst, int ldd,
+                           hipStream_t s) {
+  const size_t n = (size_t)cols * ldd;
+  hipLaunchKernelGGL((transpose_cast_kernel<P>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, rows, cols,
+                     lds, coff, (typename P::elem_t*)dst, ldd);
+}
+template void launch_transpose_cast<F32>(const float*, int, int, int, int, void*, int, hipStream_t);
+template void launch_transpose_cast<BF16>(const float*, int, int, int, int, void*, int, hipStream_t);
+
+// sinusoid -> Linear(td,2td) -> Mish -> Linear(2td,td); one block per diffusion time
+__device__ __forceinline__ float sinus_feat(int t, int j, int td) {
+  const int half = td / 2;
+  const float step = (float)(-(log(10000.0) / (double)(half - 1)));  // scalar cast to f32 like torch does
+  const int jj = j < half ? j : j - half;
+  const float ang = (float)t * expf((float)jj * step);
+  return j < half ? sinf(ang) : cosf(ang);
+}
+__global__ void time_table_kernel(const float* w1, const float* b1, const float* w2, const float* b2, int td,
+                                  float* temb) {
+  extern __shared__ float sh[];  // [td] sinusoid, [2td] hidden
+  float* e0 = sh;
+  float* a1 = sh + td;
+  const int t = blockIdx.x;
+  for (int j = threadIdx.x; j < td; j += blockDim.x) e0[j] = sinus_feat(t, j, td);
+  __syncthreads();
+  for (int o = threadIdx.x; o < 2 * td; o += blockDim.x) {
+    float s = b1[o];
+    for (int j = 0; j < td; ++j) s += w1[o * td + j] * e0[j];
+    a1[o] = mish_f(s);
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < td; o += blockDim.x) {
+    float s = b2[o];
+    for (int j = 0; j < 2 * td; ++j) s += w2[o * 2 * td + j] * a1[j];
+    temb[(size_t)t * td + o] = s;
+  }
+}
+void launch_time_table(const float* w1, const float* b1, const float* w2, const float* b2, int td, int n_time,
+                       float* temb, hipStream_t s) {
+  hipLaunchKernelGGL(time_table_kernel, dim3(n_time), dim3(64), 3 * td * sizeof(float), s, w1, b1, w2, b2, td, temb);
+}
+
+// =================================================================================================
+// row building
+// =================================================================================================
+template <class P>
+__global__ void build_rows_kernel(const BuildRows a) {
+  typedef typename P::elem_t E;
+  const int64_t n = blockIdx.x;
+  if (n >= a.M) return;
+  int64_t b;
+  int k;
+  if (a.kinds != nullptr) {
+    b = n;
+    k = (int)a.kinds[n];
+  } else {
+    const int64_t ind = a.inds ? a.inds[n] : n;
+    b = ind / a.Kft;
+    k = (int)(ind - b * a.Kft);
+  }
+  if (threadIdx.x == 0) {
+    a.brow[n] = (int32_t)b;
+    a.krow[n] = k;
+  }
+  const int t = a.ksteps[k].t;
+  E* ia = (E*)a.inA + (size_t)n * a.KpA;
+  const float* xk = a.kinds != nullptr ? a.chains + (size_t)b * 2 * a.AF : a.chains + ((size_t)b * (a.Kft + 1) + k) * a.AF;
+  const float* ob = a.obs + (size_t)b * a.cond;
+  for (int c = threadIdx.x; c < a.KpA; c += blockDim.x) {
+    float v = 0.f;
+    if (c < a.AF)
+      v = xk[c];
+    else if (c < a.AF + a.td)
+      v = a.temb[(size_t)t * a.td + (c - a.AF)];
+    else if (c < a.AF + a.td + a.cond)
+      v = ob[c - a.AF - a.td];
+    ia[c] = P::from_f32(v);
+  }
+  if (a.inC != nullptr) {
+    E* ic = (E*)a.inC + (size_t)n * a.KpC;
+    for (int c = threadIdx.x; c < a.KpC; c += blockDim.x) ic[c] = P::from_f32(c < a.cond ? ob[c] : 0.f);
+  }
+}
+template <class P>
+void launch_build_rows(const BuildRows& a, hipStream_t s) {
+  if (a.M <= 0) return;
+  hipLaunchKernelGGL((build_rows_kernel<P>), dim3((unsigned)a.M), dim3(64), 0, s, a);
+}
+template void launch_build_rows<F32>(const BuildRows&, hipStream_t);
+template void launch_build_rows<BF16>(const BuildRows&, hipStream_t);
+
+template <class P>
+__global__ void build_direct_kernel(const float* x, const int64_t* t, const float* state, const float* temb, int AF,
+                                    int td, int cond, int64_t M, typename P::elem_t* in, int Kp) {
+  const int64_t n = blockIdx.x;
+  if (n >= M) return;
+  const int tt = t ? (int)t[n] : 0;
+  for (int c = threadIdx.x; c < Kp; c += blockDim.x) {
+    float v = 0.f;
+    if (c < AF)
+      v = x[(size_t)n * AF + c];
+    else if (c < AF + td)
+      v = temb[(size_t)tt * td + (c - AF)];
+    else if (c < AF + td + cond)
+      v = state[(size_t)n * cond + (c - AF - td)];
+    in[(size_t)n * Kp + c] = P::from_f32(v);
+  }
+}
+template <class P>
+void launch_build_direct(const float* x, const int64_t* t, const float* state, const float* temb, int AF, int td,
+                         int cond, int64_t M, void* in, int Kp, hipStream_t s) {
+  if (M <= 0) return;
+  hipLaunchKernelGGL((build_direct_kernel<P>), dim3((unsigned)M), dim3(64), 0, s, x, t, state, temb, AF, td, cond, M,
+                     (typename P::elem_t*)in, Kp);
+}
+template void launch_build_direct<F32>(const float*, const int64_t*, const float*, const float*, int, int, int, int64_t,
+                                       void*, int, hipStream_t);
+template void launch_build_direct<BF16>(const float*, const int64_t*, const float*, const float*, int, int, int,
+                                        int64_t, void*, int, hipStream_t);
+
+// =================================================================================================
+// posterior mean (VPGDiffusion.p_mean_var, diffusion_vpg.py:165-223) and its derivative wrt eps
+// =================================================================================================
+__device__ __forceinline__ void posterior(const dppo_diffusion_cfg& c, const dppo_step& st, float x, float eps,
+                                          float& mu, float& dmu_deps) {
+  if (!c.use_ddim) {
+    float x0 = st.c0 * x - st.c1 * eps;
+    float pass = 1.f;
+    if (c.has_denoised_clip) {
+      pass = (x0 >= -c.denoised_clip && x0 <= c.denoised_clip) ? 1.f : 0.f;  // clamp backward: inclusive
+      x0 = fminf(fmaxf(x0, -c.denoised_clip), c.denoised_clip);
+    }
+    mu = st.c2 * x0 + st.c3 * x;
+    dmu_deps = -(st.c2 * st.c1) * pass;
+  } else {
+    float x0 = (x - st.c1 * eps) / st.c0;
+    float dx0 = -st.c1 / st.c0;  // d x0 / d eps
+    float e2 = eps, de2 = 1.f;   // eps after the re-derivation, d e2 / d eps
+    if (c.has_denoised_clip) {
+      const float pass = (x0 >= -c.denoised_clip && x0 <= c.denoised_clip) ? 1.f : 0.f;
+      x0 = fminf(fmaxf(x0, -c.denoised_clip), c.denoised_clip);
+      dx0 *= pass;
+      e2 = (x - st.c0 * x0) / st.c1;
+      de2 = -(st.c0 / st.c1) * dx0;
+    }
+    if (c.has_eps_clip) {
+      const float pass = (e2 >= -c.eps_clip && e2 <= c.eps_clip) ? 1.f : 0.f;
+      e2 = fminf(fmaxf(e2, -c.eps_clip), c.eps_clip);
+      de2 *= pass;
+    }
+    mu = st.c2 * x0 + st.c3 * e2;
+    dmu_deps = st.c2 * dx0 + st.c3 * de2;
+  }
+}
+
+#define DPPO_LOG_SQRT_2PI 0.91893853320467274178f
+
+__global__ void logprob_kernel(const LogprobArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.M * a.AF) return;
+  const int64_t n = i / a.AF;
+  const int j = (int)(i - n * a.AF);
+  const int64_t b = n / a.Kft;
+  const int k = (int)(n - b * a.Kft);
+  const dppo_step st = a.ksteps[k];
+  const float* ch = a.chains + ((size_t)b * (a.Kft + 1) + k) * a.AF;
+  const float x = ch[j], xn = ch[a.AF + j];
+  float mu, dmu;
+  posterior(a.cfg, st, x, a.eps[(size_t)n * a.lde + j], mu, dmu);
+  const float var = st.std * st.std;
+  const float d = xn - mu;
+  a.logp[i] = -(d * d) / (2.f * var) - logf(st.std) - DPPO_LOG_SQRT_2PI;
+}
+void launch_logprob(const LogprobArgs& a, hipStream_t s) {
+  const int64_t n = a.M * a.AF;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(logprob_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// =================================================================================================
+// fused PPO loss
+// =================================================================================================
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  // 256 threads: wave shuffle then 4 partials through LDS
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void adv_moments_kernel(const float* adv_k, const int32_t* brow, int64_t N,
+                                                          double* moments) {
+  __shared__ double sh[4];
+  double s = 0, q = 0;
+  for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
+    const double v = adv_k[brow[n]];
+    s += v;
+    q += v * v;
+  }
+  s = block_sum(s, sh);
+  q = block_sum(q, sh);
+  if (threadIdx.x == 0) {
+    atomicAdd(&moments[0], s);
+    atomicAdd(&moments[1], q);
+    if (blockIdx.x == 0) atomicAdd(&moments[2], (double)N);
+  }
+}
+void launch_adv_moments(const float* adv_k, const int32_t* brow, int64_t N, double* moments, hipStream_t s) {
+  const int blocks = (int)min((int64_t)256, (N + 255) / 256);
+  hipLaunchKernelGGL(adv_moments_kernel, dim3(blocks), dim3(256), 0, s, adv_k, brow, N, moments);
+}
+
+template <class P>
+__global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
+  typedef typename P::elem_t E;
+  __shared__ double sh[4];
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const dppo_ppo_cfg& pc = a.pcfg;
+  const int Kft = pc.ft_denoising_steps, AF = a.AF, Da = pc.action_dim;
+  const int rh = pc.reward_horizon < pc.horizon_steps ? pc.reward_horizon : pc.horizon_steps;
+  const int cnt = rh * Da;
+  double s_pg = 0, s_v = 0, s_kl = 0, s_cf = 0, s_ratio = 0;
+  const double Nn = a.moments[2];  // samples in the (global) minibatch: means and 1/N scaling use this count
+  if (n < a.N) {
+    const int b = a.brow[n], k = a.krow[n];
+    const dppo_step st = a.ksteps[k];
+    const float* ch = a.gathered ? a.chains + (size_t)b * 2 * AF : a.chains + ((size_t)b * (Kft + 1) + k) * AF;
+    const float* olp = a.gathered ? a.logprobs_k + (size_t)b * AF : a.logprobs_k + ((size_t)b * Kft + k) * AF;
+    const float* ep = a.eps + (size_t)n * a.lde;
+    const float var = st.std * st.std, lstd = logf(st.std);
+    // ---- new / old log-probs, clamped to [-5, 2], averaged over the first `rh` chunk steps (:93-102)
+    float sum_new = 0.f, sum_old = 0.f;
+    for (int j = 0; j < cnt; ++j) {
+      float mu, dmu;
+      posterior(a.dcfg, st, ch[j], ep[j], mu, dmu);
+      const float d = ch[AF + j] - mu;
+      const float lp = -(d * d) / (2.f * var) - lstd - DPPO_LOG_SQRT_2PI;
+      sum_new += fminf(fmaxf(lp, -5.f), 2.f);
+      sum_old += fminf(fmaxf(olp[j], -5.f), 2.f);
+    }
+    const float newlp = sum_new / (float)cnt, oldlp = sum_old / (float)cnt;
+    // ---- advantage: normalise over the minibatch, quantile clip, denoising discount (:129-144)
+    float adv = a.adv_k[b];
+    const double mean = a.moments[0] / Nn;
+    if (pc.norm_adv) {
+      const double varu = (a.moments[1] - Nn * mean * mean) / (Nn - 1.0);  // unbiased (torch.std)
+      const float sd = (float)sqrt(varu > 0 ? varu : 0);
+      adv = (adv - (float)mean) / (sd + 1e-8f);
+    }
+    if (pc.has_adv_clip) adv = fminf(fmaxf(adv, pc.adv_clip_lo), pc.adv_clip_hi);
+    adv *= (float)pow(pc.gamma_denoising, (double)(Kft - k - 1));
+    // ---- ratio, per-step clip range (:147-159)
+    const float logratio = newlp - oldlp;
+    const float ratio = expf(logratio);
+    float eps_k;
+    if (Kft > 1) {
+      const float t = (float)k / (float)(Kft - 1);
+      const float num = expf((float)pc.clip_ploss_coef_rate * t) - 1.f;
+      eps_k = (float)pc.clip_ploss_coef_base +
+              (float)(pc.clip_ploss_coef - pc.clip_ploss_coef_base) * num / (float)(exp(pc.clip_ploss_coef_rate) - 1.0);
+    } else {
+      eps_k = (float)k / (float)(Kft - 1);
+    }
+    s_kl = (double)((ratio - 1.f) - logratio);
+    s_cf = fabsf(ratio - 1.f) > eps_k ? 1.0 : 0.0;
+    s_ratio = ratio;
+    // ---- clipped surrogate (:170-174) and d L / d ratio with torch.max / clamp sub-gradients
+    const float lo = 1.f - eps_k, hi = 1.f + eps_k;
+    const float rc = fminf(fmaxf(ratio, lo), hi);
+    const float pg1 = -adv * ratio, pg2 = -adv * rc;
+    s_pg = fmaxf(pg1, pg2);
+    const float w1 = pg1 > pg2 ? 1.f : (pg1 == pg2 ? 0.5f : 0.f);
+    const float within = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+    const float dL_dratio = -adv * (w1 + (1.f - w1) * within);
+    const float coef = dL_dratio * ratio / ((float)Nn * (float)cnt);  // d mean(L) / d lp_j (before clamp mask)
+    E* de = (E*)a.d_eps + (size_t)n * a.ldde;
+    for (int j = 0; j < a.ldde; ++j) {
+      float gj = 0.f;
+      if (j < cnt) {
+        float mu, dmu;
+        posterior(a.dcfg, st, ch[j], ep[j], mu, dmu);
+        const float d = ch[AF + j] - mu;
+        const float lp = -(d * d) / (2.f * var) - lstd - DPPO_LOG_SQRT_2PI;
+        if (lp >= -5.f && lp <= 2.f) gj = coef * (d / var) * dmu;
+      }
+      de[j] = P::from_f32(gj);
+    }
+    // ---- value loss (:177-189)
+    const float v = a.vnew[(size_t)n * a.ldv];
+    const float ret = a.returns_k[b];
+    float dv;
+    if (pc.has_vclip) {
+      const float ov = a.values_k[b];
+      const float c = (float)pc.clip_vloss_coef;
+      const float dlt = v - ov;
+      const float vc = ov + fminf(fmaxf(dlt, -c), c);
+      const float lu = (v - ret) * (v - ret), lc = (vc - ret) * (vc - ret);
+      s_v = 0.5 * (double)fmaxf(lu, lc);
+      const float inr = (dlt >= -c && dlt <= c) ? 1.f : 0.f;
+      const float wu = lu > lc ? 1.f : (lu == lc ? 0.5f : 0.f);
+      dv = wu * (v - ret) + (1.f - wu) * (vc - ret) * inr;
+    } else {
+      s_v = 0.5 * (double)((v - ret) * (v - ret));
+      dv = v - ret;
+    }
+    E* dvp = (E*)a.d_v + (size_t)n * a.lddv;
+    dvp[0] = P::from_f32(dv / (float)Nn);
+    for (int j = 1; j < a.lddv; ++j) dvp[j] = P::from_f32(0.f);
+  }
+  const double inv = 1.0 / Nn;
+  s_pg = block_sum(s_pg, sh);
+  s_v = block_sum(s_v, sh);
+  s_kl = block_sum(s_kl, sh);
+  s_cf = block_sum(s_cf, sh);
+  s_ratio = block_sum(s_ratio, sh);
+  if (threadIdx.x == 0) {
+    atomicAdd(&a.stats[DPPO_STAT_PG_LOSS], s_pg * inv);
+    atomicAdd(&a.stats[DPPO_STAT_V_LOSS], s_v * inv);
+    atomicAdd(&a.stats[DPPO_STAT_APPROX_KL], s_kl * inv);
+    atomicAdd(&a.stats[DPPO_STAT_CLIPFRAC], s_cf * inv);
+    atomicAdd(&a.stats[DPPO_STAT_RATIO], s_ratio * inv);
+    if (blockIdx.x == 0) {
+      const double mean = a.moments[0] / Nn;
+      const double varu = Nn > 1 ? (a.moments[1] - Nn * mean * mean) / (Nn - 1.0) : 0.0;
+      a.stats[DPPO_STAT_ADV_MEAN] = mean;
+      a.stats[DPPO_STAT_ADV_STD] = sqrt(varu > 0 ? varu : 0);
+    }
+  }
+}
+template <class P>
+void launch_ppo_loss(const LossArgs& a, hipStream_t s) {
+  if (a.N <= 0) return;
+  hipLaunchKernelGGL((ppo_loss_kernel<P>), dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, s, a);
+}
+template void launch_ppo_loss<F32>(const LossArgs&, hipStream_t);
+template void launch_ppo_loss<BF16>(const LossArgs&, hipStream_t);
+
+// =================================================================================================
+// time-embedding backward
+// =================================================================================================
+// grid (blocks, Kft); 256 threads = 16 row-lanes x 16 column-lanes
+__global__ __launch_bounds__(256) void temb_segsum_kernel(const float* dtemb, int ld, const int32_t* krow, int64_t M,
+                                                          int Kft, int td, float* partial) {
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int k = blockIdx.y;
+  const int64_t per = (M + gridDim.x - 1) / gridDim.x;
+  const int64_t m0 = (int64_t)blockIdx.x * per, m1 = m0 + per < M ? m0 + per : M;
+  for (int c0 = 0; c0 < td; c0 += 16) {
+    const int c = c0 + cl;
+    float s = 0.f;
+    if (c < td)
+      for (int64_t m = m0 + rl; m < m1; m += 16)
+        if (krow[m] == k) s += dtemb[(size_t)m * ld + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < td) {
+      float t = 0.f;
+      for (int i = 0; i < 16; ++i) t += red[i][cl];
+      partial[((size_t)blockIdx.x * Kft + k) * td + c] = t;
+    }
+    __syncthreads();
+  }
+}
+void launch_temb_segsum(const float* dtemb, int ld, const int32_t* krow, int64_t M, int Kft, int td, float* partial,
+                        int blocks, hipStream_t s) {
+  hipLaunchKernelGGL(temb_segsum_kernel, dim3(blocks, Kft), dim3(256), 0, s, dtemb, ld, krow, M, Kft, td, partial);
+}
+
+// single block: recompute the tiny time MLP per fine-tuned step and back-propagate G[k][td] through it
+__global__ __launch_bounds__(256) void time_backward_kernel(const float* w1, const float* b1, const float* w2,
+                                                            const float* G, const dppo_step* ksteps, int Kft, int td,
+                                                            float* gw1, float* gb1, float* gw2, float* gb2) {
+  extern __shared__ float sh[];  // per k: e0[td], z1[2td], a1[2td], dz1[2td]
+  const int per = 7 * td;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < Kft * td; i += 256) {
+    const int k = i / td, j = i % td;
+    sh[k * per + j] = sinus_feat(ksteps[k].t, j, td);
+  }
+  __syncthreads();
+  for (int i = tid; i < Kft * 2 * td; i += 256) {
+    const int k = i / (2 * td), o = i % (2 * td);
+    float s = b1[o];
+    for (int j = 0; j < td; ++j) s += w1[o * td + j] * sh[k * per + j];
+    sh[k * per + td + o] = s;
+    sh[k * per + 3 * td + o] = mish_f(s);
+  }
+  __syncthreads();
+  for (int i = tid; i < Kft * 2 * td; i += 256) {
+    const int k = i / (2 * td), o = i % (2 * td);
+    float s = 0.f;
+    for (int j = 0; j < td; ++j) s += w2[j * 2 * td + o] * G[k * td + j];
+    sh[k * per + 5 * td + o] = s * mish_grad_f(sh[k * per + td + o]);
+  }
+  __syncthreads();
+  for (int i = tid; i < td * 2 * td; i += 256) {  // gw2[o][j] = sum_k G[k][o] a1[k][j]
+    const int o = i / (2 * td), j = i % (2 * td);
+    float s = 0.f;
+    for (int k = 0; k < Kft; ++k) s += G[k * td + o] * sh[k * per + 3 * td + j];
+    gw2[i] = s;
+  }
+  for (int o = tid; o < td; o += 256) {
+    float s = 0.f;
+    for (int k = 0; k < Kft; ++k) s += G[k * td + o];
+    gb2[o] = s;
+  }
+  for (int i = tid; i < 2 * td * td; i += 256) {  // gw1[o][j] = sum_k dz1[k][o] e0[k][j]
+    const int o = i / td, j = i % td;
+    float s = 0.f;
+    for (int k = 0; k < Kft; ++k) s += sh[k * per + 5 * td + o] * sh[k * per + j];
+    gw1[i] = s;
+  }
+  for (int o = tid; o < 2 * td; o += 256) {
+    float s = 0.f;
+    for (int k = 0; k < Kft; ++k) s += sh[k * per + 5 * td + o];
+    gb1[o] = s;
+  }
+}
+void launch_time_backward(const float* w1, const float* b1, const float* w2, const float* G, const dppo_step* ksteps,
+                          int Kft, int td, float* gw1, float* gb1, float* gw2, float* gb2, hipStream_t s) {
+  hipLaunchKernelGGL(time_backward_kernel, dim3(1), dim3(256), (size_t)Kft * 7 * td * sizeof(float), s, w1, b1, w2, G,
+                     ksteps, Kft, td, gw1, gb1, gw2, gb2);
+}
+
+__global__ void slab_reduce_2d_kernel(const float* slab, int splits, int rows, int cols, int lds, float* out, int ldo,
+                                      float scale) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i % cols);
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += slab[((size_t)k * rows + r) * lds + c];
+  out[(size_t)r * ldo + c] = s * scale;
+}
+void launch_slab_reduce_2d(const float* slab, int splits, int rows, int cols, int lds, float* out, int ldo,
+                           float scale, hipStream_t s) {
+  const size_t n = (size_t)rows * cols;
+  if (n == 0) return;
+  hipLaunchKernelGGL(slab_reduce_2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slab, splits, rows,
+                     cols, lds, out, ldo, scale);
+}
+
+// =================================================================================================
+// GAE: one thread per env, float64 reverse scan (train_ppo_diffusion_agent.py:255-279)
+// =================================================================================================
+__global__ void gae_kernel(const double* reward, const float* values, const float* terminated,
+                           const float* last_values, int S, int E, double gamma, double lam, double rconst,
+                           double* adv64, double* ret64, float* adv32, float* ret32) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  double last = 0.0;
+  double nextv = (double)last_values[e];
+  for (int t = S - 1; t >= 0; --t) {
+    const size_t i = (size_t)t * E + e;
+    const double v = (double)values[i];
+    const double nonterm = 1.0 - (double)terminated[i];
+    const double delta = reward[i] * rconst + gamma * nextv * nonterm - v;
+    last = delta + gamma * lam * nonterm * last;
+    const double ret = last + v;
+    if (adv64) adv64[i] = last;
+    if (ret64) ret64[i] = ret;
+    if (adv32) adv32[i] = (float)last;
+    if (ret32) ret32[i] = (float)ret;
+    nextv = v;
+  }
+}
+void launch_gae(const double* reward, const float* values, const float* terminated, const float* last_values, int S,
+                int E, double gamma, double lam, double rconst, double* adv64, double* ret64, float* adv32,
+                float* ret32, hipStream_t s) {
+  if (E <= 0) return;
+  hipLaunchKernelGGL(gae_kernel, dim3((E + 63) / 64), dim3(64), 0, s, reward, values, terminated, last_values, S, E,
+                     gamma, lam, rconst, adv64, ret64, adv32, ret32);
+}
+
+// =================================================================================================
+// optimiser
+// =================================================================================================
+__global__ __launch_bounds__(256) void sq_norm_stage1(const float* g, int64_t n, double* scratch) {
+  __shared__ double sh[4];
+  double s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double v = g[i];
+    s += v * v;
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) scratch[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sq_norm_stage2(const double* scratch, int nb, double* out) {
+  __shared__ double sh[4];
+  double s = 0;
+  for (int i = threadIdx.x; i < nb; i += 256) s += scratch[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) out[0] = s;
+}
+void launch_sq_norm(const float* g, int64_t n, double* scratch, double* out, hipStream_t s) {
+  const int nb = (int)min((int64_t)1024, max((int64_t)1, (n + 4095) / 4096));
+  hipLaunchKernelGGL(sq_norm_stage1, dim3(nb), dim3(256), 0, s, g, n, scratch);
+  hipLaunchKernelGGL(sq_norm_stage2, dim3(1), dim3(256), 0, s, scratch, nb, out);
+}
+
+// torch.optim.AdamW single-tensor path: p *= 1 - lr*wd; m.lerp_(g, 1-b1); v = b2 v + (1-b2) g g;
+// p -= step_size * m / (sqrt(v) / sqrt(bc2) + eps)
+__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr_wd_mul,
+                             float one_m_b1, float b2, float one_m_b2, float step_size, float bc2_sqrt, float eps,
+                             const double* sq_norm, float max_norm) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float gi = g[i];
+  if (sq_norm != nullptr) {
+    const float total = (float)sqrt(sq_norm[0]);
+    const float coef = fminf(max_norm / (total + 1e-6f), 1.0f);
+    gi *= coef;
+  }
+  float pi = p[i] * lr_wd_mul;
+  float mi = m[i];
+  mi = mi + one_m_b1 * (gi - mi);
+  float vi = v[i] * b2 + one_m_b2 * (gi * gi);
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  pi = pi - step_size * (mi / denom);
+  p[i] = pi;
+  m[i] = mi;
+  v[i] = vi;
+}
+void launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr_wd_mul, float one_m_b1, float b2,
+                  float one_m_b2, float step_size, float bc2_sqrt, float eps, const double* sq_norm, float max_norm,
+                  hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr_wd_mul,
+                     one_m_b1, b2, one_m_b2, step_size, bc2_sqrt, eps, sq_norm, max_norm);
+}
+
+}  // namespace dppo

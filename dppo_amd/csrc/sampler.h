@@ -1,0 +1,56 @@
+// Persistent K-step DDPM/DDIM sampler (reference: model/diffusion/diffusion_vpg.py:139-315).
+//
+// One 512-thread workgroup (8 waves) owns 16 env rows for ALL denoising steps: x, the observation
+// and the hidden activations never leave LDS/registers, the chain is written once, coalesced.
+// The MLP runs transposed on MFMA 16x16: A = weight fragments, B = the 16 rows' activations.  At 16
+// rows per workgroup each weight element is used by exactly one wave, so weights are NOT staged in
+// LDS: the host packs every network once into a per-wave "fragment stream" (consumption order, one
+// perfectly coalesced 1 KiB read per wave-instruction) that each wave walks linearly through a
+// 4-deep register ring that prefetches across layer and step boundaries.
+#pragma once
+#include "common.h"
+#include "../../include/dppo_hip.h"
+
+namespace dppo {
+
+constexpr int SAMPLER_WAVES = 8;
+// ring depth in k-step positions: 4 (16-32 KiB of weights in flight per wave); 2 at H = 1024 to stay under 256 VGPRs
+__host__ __device__ constexpr int sampler_pd(int hidden) { return hidden >= 1024 ? 2 : 4; }
+constexpr int MAX_BLOCKS = 8;
+
+// geometry of a packed actor for the sampler
+struct SamplerGeom {
+  int H, nb, in_dim, out_dim, Kp0, KS0, KSH, TPW, OT, CNT, total_pos;
+  size_t hidden_frags_per_wave, out_frags_per_wave;
+};
+template <class P>
+SamplerGeom sampler_geom(const dppo_net_desc& d);
+
+struct SampleArgs {
+  const u32x4* wstream[2];
+  const u32x4* ostream[2];
+  const float* params[2];
+  const float* temb[2];  // [n_time][td]
+  int bias_off[2 + 2 * MAX_BLOCKS];  // L0, (l1,l2) x nb, out  -- float offsets into params
+  const float* obs;     // [B][cond]
+  const float* noise;   // [n_steps+1][B][AF]
+  float* traj;          // [B][AF]
+  float* chains;        // [B][chain_len][AF]
+  const dppo_step* sched;
+  int B, AF, td, cond, Kp0, nb, n_steps, chain_len, init_slot, act, use_ddim;
+  int has_dclip, has_eclip, has_fclip;
+  float dclip, eclip, rclip, fclip;
+};
+
+template <class P>
+int launch_sample_chain(const SamplerGeom& g, const SampleArgs& a, hipStream_t s);  // 0 ok, <0 unsupported
+
+// W: [H][ld] fp32 (nn.Linear layout).  Writes the fragments of one hidden layer (KS k-steps) into
+// every wave's stream at position pos0.
+template <class P>
+void launch_pack_hidden(const float* W, int H, int in_valid, int ld, int KS, int TPW, int pos0, int total_pos,
+                        u32x4* stream, hipStream_t s);
+template <class P>
+void launch_pack_out(const float* W, int out_dim, int H, int OT, int CNT, u32x4* stream, hipStream_t s);
+
+}  // namespace dppo

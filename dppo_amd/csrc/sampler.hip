@@ -1,0 +1,367 @@
+// See sampler.h.  gfx950 only.  Compiled with -ffp-contract=off so the posterior arithmetic is
+// the reference's op sequence (separate multiplies/adds, no fused contraction).
+#include "sampler.h"
+
+namespace dppo {
+
+// LDS activation images: row-major [16 rows][rb bytes]; 16-byte chunk c of row q is stored at chunk
+// c ^ (q & kmask).  kmask = min(16, largest power of two dividing rb/16) - 1, so the XOR never leaves
+// the row.  With rb a multiple of 256 (every hidden buffer) kmask = 15 and the B-fragment
+// ds_read_b128 (lane (r,g) reads chunk 4*ks+g of row r) is conflict-free.
+__device__ __forceinline__ int kmask_of(int rb) {
+  const int n = rb >> 4;
+  const int p = n & (-n);
+  return (p > 16 ? 16 : p) - 1;
+}
+template <class P>
+__device__ __forceinline__ void lds_put(char* buf, int rb, int kmask, int row, int col, float v) {
+  const int byte = col * P::ESIZE;
+  char* p = buf + row * rb + ((((byte >> 4) ^ (row & kmask)) << 4) | (byte & 15));
+  *(typename P::elem_t*)p = P::from_f32(v);
+}
+
+template <class P, int TPW, int OT>
+__global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
+  constexpr int PD = sampler_pd(128 * TPW), ES = P::ESIZE, KB = P::KB;
+  constexpr int H = 128 * TPW, KSH = H / KB, CNT = (KSH + SAMPLER_WAVES - 1) / SAMPLER_WAVES;
+  constexpr int HRB = H * ES;  // hidden row bytes
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int grow0 = blockIdx.x * 16;
+  const int AF = a.AF, td = a.td, cond = a.cond, Kp0 = a.Kp0, nb = a.nb, B = a.B;
+  const int in_rb = Kp0 * ES, in_km = kmask_of(in_rb);
+  const int KS0 = Kp0 / KB;
+  const int total = KS0 + 2 * nb * KSH;
+
+  char* xin = smem;
+  char* bufA = xin + 16 * in_rb;
+  char* bufB = bufA + 16 * HRB;
+  float* xcur = (float*)(bufB + 16 * HRB);            // [16][AF]
+  float* part = xcur + ((16 * AF + 3) & ~3);          // [8 waves][OT*16 features][16 rows]
+
+  // ---- one-time: observation + zero padding of the input image, x_K, time embedding of step 0
+  for (int idx = tid; idx < 16 * Kp0; idx += 512) {
+    const int row = idx / Kp0, c = idx - row * Kp0;
+    if (c >= AF + td) {
+      const int j = c - AF - td;
+      const int grow = min(grow0 + row, B - 1);
+      lds_put<P>(xin, in_rb, in_km, row, c, j < cond ? a.obs[(size_t)grow * cond + j] : 0.f);
+    }
+  }
+  {
+    const dppo_step s0 = a.sched[0];
+    for (int idx = tid; idx < 16 * AF; idx += 512) {
+      const int row = idx / AF, j = idx - row * AF;
+      const int grow = grow0 + row;
+      const float v = a.noise[(size_t)min(grow, B - 1) * AF + j];
+      xcur[row * AF + j] = v;
+      lds_put<P>(xin, in_rb, in_km, row, j, v);
+      if (a.init_slot >= 0 && a.chains != nullptr && grow < B) a.chains[((size_t)grow * a.chain_len + a.init_slot) * AF + j] = v;
+    }
+    for (int idx = tid; idx < 16 * td; idx += 512) {
+      const int row = idx / td, j = idx - row * td;
+      lds_put<P>(xin, in_rb, in_km, row, AF + j, a.temb[s0.net][s0.t * td + j]);
+    }
+  }
+
+  const size_t wave_stride = (size_t)total * TPW * 64;
+  const u32x4* ws[2] = {a.wstream[0] + wid * wave_stride + lane, a.wstream[1] + wid * wave_stride + lane};
+  const u32x4* os[2] = {a.ostream[0] + (size_t)wid * CNT * OT * 64 + lane,
+                        a.ostream[1] + (size_t)wid * CNT * OT * 64 + lane};
+  const int fb = wid * 16 * TPW + 4 * TPW * g;  // first of this lane's 4*TPW consecutive hidden features
+
+  u32x4 ring[PD][TPW];
+  {
+    const int n0 = a.sched[0].net;
+#pragma unroll
+    for (int p = 0; p < PD; ++p)
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp) ring[p][tp] = ws[n0][(p * TPW + tp) * 64];
+  }
+  __syncthreads();
+
+  for (int i = 0; i < a.n_steps; ++i) {
+    const dppo_step st = a.sched[i];
+    const int net = st.net;
+    const int nnet = (i + 1 < a.n_steps) ? a.sched[i + 1].net : net;
+    const u32x4* cur = ws[net];
+    const u32x4* nxt = ws[nnet];
+    const float* prm = a.params[net];
+
+    u32x4 of[CNT][OT];
+#pragma unroll
+    for (int c = 0; c < CNT; ++c)
+#pragma unroll
+      for (int to = 0; to < OT; ++to) of[c][to] = os[net][(c * OT + to) * 64];
+
+    f32x4 h[TPW], acc[TPW];
+    int pos = 0;
+
+    // one hidden layer: nks k-step positions starting at stream position `pos`, B operand from `src`
+    auto run_layer = [&](const char* src, int rb, int km, int nks, int boff) {
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[tp][e] = prm[boff + fb + 4 * tp + e];
+      for (int k0 = 0; k0 < nks; k0 += PD) {
+#pragma unroll
+        for (int p = 0; p < PD; ++p) {
+          const int ks = k0 + p;
+          const u32x4 xb = *(const u32x4*)(src + r * rb + (((ks * 4 + g) ^ (r & km)) << 4));
+#pragma unroll
+          for (int tp = 0; tp < TPW; ++tp) acc[tp] = P::mma(ring[p][tp], xb, acc[tp]);
+          // refill the slot just consumed with the fragments PD positions ahead (next layer / next step included)
+          const int np = pos + ks + PD;
+          const u32x4* src_w = np < total ? cur + (size_t)np * TPW * 64 : nxt + (size_t)(np - total) * TPW * 64;
+#pragma unroll
+          for (int tp = 0; tp < TPW; ++tp) ring[p][tp] = src_w[tp * 64];
+        }
+      }
+      pos += nks;
+    };
+    // write this lane's 4*TPW features of batch row r (optionally activated) into an LDS image
+    auto put_hidden = [&](char* dst, const f32x4 (&v)[TPW], int actk) {
+      if constexpr (ES == 4) {
+#pragma unroll
+        for (int tp = 0; tp < TPW; ++tp) {
+          const int c = ((fb + 4 * tp) * 4) >> 4;
+          float4 o = make_float4(act_f(actk, v[tp][0]), act_f(actk, v[tp][1]), act_f(actk, v[tp][2]),
+                                 act_f(actk, v[tp][3]));
+          *(float4*)(dst + r * HRB + ((c ^ (r & 15)) << 4)) = o;
+        }
+      } else {
+#pragma unroll
+        for (int tp = 0; tp < TPW; tp += 2) {
+          const int c = ((fb + 4 * tp) * 2) >> 4;
+          u32x4 o;
+          o.x = (uint32_t)f2bf(act_f(actk, v[tp][0])) | ((uint32_t)f2bf(act_f(actk, v[tp][1])) << 16);
+          o.y = (uint32_t)f2bf(act_f(actk, v[tp][2])) | ((uint32_t)f2bf(act_f(actk, v[tp][3])) << 16);
+          if constexpr (TPW >= 2) {
+            o.z = (uint32_t)f2bf(act_f(actk, v[tp + 1][0])) | ((uint32_t)f2bf(act_f(actk, v[tp + 1][1])) << 16);
+            o.w = (uint32_t)f2bf(act_f(actk, v[tp + 1][2])) | ((uint32_t)f2bf(act_f(actk, v[tp + 1][3])) << 16);
+            *(u32x4*)(dst + r * HRB + ((c ^ (r & 15)) << 4)) = o;
+          } else {
+            *(u32x2*)(dst + r * HRB + ((c ^ (r & 15)) << 4) + (((fb * 2) & 15))) = (u32x2){o.x, o.y};
+          }
+        }
+      }
+    };
+
+    // ---- layer 0
+    run_layer(xin, in_rb, in_km, KS0, a.bias_off[0]);
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) h[tp] = acc[tp];
+    put_hidden(bufA, h, nb > 0 ? a.act : ACT_NONE);
+    __syncthreads();
+    // ---- residual blocks: h += l2(act(l1(act(h))))
+    for (int b = 0; b < nb; ++b) {
+      run_layer(bufA, HRB, 15, KSH, a.bias_off[1 + 2 * b]);
+      put_hidden(bufB, acc, a.act);
+      __syncthreads();
+      run_layer(bufB, HRB, 15, KSH, a.bias_off[2 + 2 * b]);
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp) h[tp] += acc[tp];
+      put_hidden(bufA, h, b + 1 < nb ? a.act : ACT_NONE);
+      __syncthreads();
+    }
+    // ---- output layer: K split over the 8 waves, partial tiles reduced through LDS
+    {
+      f32x4 oacc[OT];
+#pragma unroll
+      for (int to = 0; to < OT; ++to) oacc[to] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < CNT; ++c) {
+        const int ks = wid * CNT + c;
+        if (ks < KSH) {
+          const u32x4 xb = *(const u32x4*)(bufA + r * HRB + (((ks * 4 + g) ^ (r & 15)) << 4));
+#pragma unroll
+          for (int to = 0; to < OT; ++to) oacc[to] = P::mma(of[c][to], xb, oacc[to]);
+        }
+      }
+#pragma unroll
+      for (int to = 0; to < OT; ++to)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[(wid * OT * 16 + to * 16 + 4 * g + e) * 16 + r] = oacc[to][e];
+    }
+    __syncthreads();
+    // ---- posterior + noise: diffusion_vpg.py:165-223 (p_mean_var) and :279-311 (sampling loop)
+    {
+      const dppo_step sn = a.sched[min(i + 1, a.n_steps - 1)];
+      const float* nz = a.noise + (size_t)(i + 1) * B * AF;
+      for (int idx = tid; idx < 16 * AF; idx += 512) {
+        const int row = idx / AF, j = idx - row * AF;
+        const int grow = grow0 + row;
+        float eps = prm[a.bias_off[1 + 2 * nb] + j];
+#pragma unroll
+        for (int w = 0; w < SAMPLER_WAVES; ++w) eps += part[(w * OT * 16 + j) * 16 + row];
+        const float x = xcur[row * AF + j];
+        float x0, mu;
+        if (!a.use_ddim) {
+          x0 = st.c0 * x - st.c1 * eps;
+          if (a.has_dclip) x0 = fminf(fmaxf(x0, -a.dclip), a.dclip);
+          mu = st.c2 * x0 + st.c3 * x;
+        } else {
+          x0 = (x - st.c1 * eps) / st.c0;
+          if (a.has_dclip) {
+            x0 = fminf(fmaxf(x0, -a.dclip), a.dclip);
+            eps = (x - st.c0 * x0) / st.c1;
+          }
+          if (a.has_eclip) eps = fminf(fmaxf(eps, -a.eclip), a.eclip);
+          mu = st.c2 * x0 + st.c3 * eps;
+        }
+        float z = nz[(size_t)min(grow, B - 1) * AF + j];
+        z = fminf(fmaxf(z, -a.rclip), a.rclip);
+        float xn = mu + st.std * z;
+        if (st.final_clip) xn = fminf(fmaxf(xn, -a.fclip), a.fclip);
+        xcur[row * AF + j] = xn;
+        lds_put<P>(xin, in_rb, in_km, row, j, xn);
+        if (grow < B) {
+          if (st.chain_slot >= 0 && a.chains != nullptr) a.chains[((size_t)grow * a.chain_len + st.chain_slot) * AF + j] = xn;
+          if (i + 1 == a.n_steps) a.traj[(size_t)grow * AF + j] = xn;
+        }
+      }
+      for (int idx = tid; idx < 16 * td; idx += 512) {
+        const int row = idx / td, j = idx - row * td;
+        lds_put<P>(xin, in_rb, in_km, row, AF + j, a.temb[sn.net][sn.t * td + j]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <class P>
+SamplerGeom sampler_geom(const dppo_net_desc& d) {
+  SamplerGeom g;
+  g.H = d.hidden;
+  g.nb = d.n_blocks;
+  g.in_dim = d.in_dim;
+  g.out_dim = d.out_dim;
+  g.Kp0 = round_up(d.in_dim, sampler_pd(d.hidden) * P::KB);
+  g.KS0 = g.Kp0 / P::KB;
+  g.KSH = g.H / P::KB;
+  g.TPW = g.H / 128;
+  const int ot = (d.out_dim + 15) / 16;
+  g.OT = ot <= 1 ? 1 : (ot <= 4 ? 4 : 8);
+  g.CNT = (g.KSH + SAMPLER_WAVES - 1) / SAMPLER_WAVES;
+  g.total_pos = g.KS0 + 2 * g.nb * g.KSH;
+  g.hidden_frags_per_wave = (size_t)g.total_pos * g.TPW;
+  g.out_frags_per_wave = (size_t)g.CNT * g.OT;
+  return g;
+}
+template SamplerGeom sampler_geom<F32>(const dppo_net_desc&);
+template SamplerGeom sampler_geom<BF16>(const dppo_net_desc&);
+
+template <class P, int TPW, int OT>
+static int launch_cfg(const SamplerGeom& g, const SampleArgs& a, hipStream_t s) {
+  const int ES = P::ESIZE;
+  size_t lds = (size_t)16 * a.Kp0 * ES + 2 * (size_t)16 * g.H * ES + (size_t)((16 * a.AF + 3) & ~3) * 4 +
+               (size_t)SAMPLER_WAVES * OT * 16 * 16 * 4;
+  if (lds > 160 * 1024) return -2;
+  static bool attr_set = false;  // raising the dynamic-LDS cap is idempotent; racing setters are harmless
+  auto kern = sample_chain_kernel<P, TPW, OT>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((a.B + 15) / 16), dim3(512), lds, s, a);
+  return 0;
+}
+
+template <class P>
+int launch_sample_chain(const SamplerGeom& g, const SampleArgs& a, hipStream_t s) {
+#define DPPO_CASE(T, O) \
+  if (g.TPW == T && g.OT == O) return launch_cfg<P, T, O>(g, a, s);
+  DPPO_CASE(2, 1)
+  DPPO_CASE(2, 4)
+  DPPO_CASE(4, 1)
+  DPPO_CASE(4, 4)
+  DPPO_CASE(8, 1)
+  DPPO_CASE(8, 4)
+#undef DPPO_CASE
+  return -1;
+}
+template int launch_sample_chain<F32>(const SamplerGeom&, const SampleArgs&, hipStream_t);
+template int launch_sample_chain<BF16>(const SamplerGeom&, const SampleArgs&, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// fragment-stream packing
+// ------------------------------------------------------------------------------------------------
+// hidden stream: [wave w][position][tp][lane] u32x4.  Lane (r,g) of tile tp holds
+// W[feature(w,tp,r)][ks*KB + (16/ES)*g + 0..], feature(w,tp,i) = w*16*TPW + 4*TPW*(i>>2) + 4*tp + (i&3).
+template <class P>
+__global__ void pack_hidden_kernel(const float* W, int in_valid, int ld, int KS, int TPW, int pos0, int total_pos,
+                                   u32x4* stream) {
+  const int lane = threadIdx.x & 63;
+  const int tp = blockIdx.x % TPW;
+  const int ks = (blockIdx.x / TPW) % KS;
+  const int w = blockIdx.x / (TPW * KS);
+  const int r = lane & 15, g = lane >> 4;
+  const int feat = w * 16 * TPW + 4 * TPW * (r >> 2) + 4 * tp + (r & 3);
+  constexpr int EPL = 16 / P::ESIZE;  // elements per lane
+  const int k0 = ks * P::KB + EPL * g;
+  uint32_t out[4];
+  if constexpr (P::ESIZE == 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + j;
+      out[j] = __float_as_uint(k < in_valid ? W[(size_t)feat * ld + k] : 0.f);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + 2 * j;
+      const float lo = k < in_valid ? W[(size_t)feat * ld + k] : 0.f;
+      const float hi = k + 1 < in_valid ? W[(size_t)feat * ld + k + 1] : 0.f;
+      out[j] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    }
+  }
+  stream[(((size_t)w * total_pos + pos0 + ks) * TPW + tp) * 64 + lane] = (u32x4){out[0], out[1], out[2], out[3]};
+}
+template <class P>
+void launch_pack_hidden(const float* W, int H, int in_valid, int ld, int KS, int TPW, int pos0, int total_pos,
+                        u32x4* stream, hipStream_t s) {
+  hipLaunchKernelGGL((pack_hidden_kernel<P>), dim3(SAMPLER_WAVES * KS * TPW), dim3(64), 0, s, W, in_valid, ld, KS, TPW,
+                     pos0, total_pos, stream);
+}
+template void launch_pack_hidden<F32>(const float*, int, int, int, int, int, int, int, u32x4*, hipStream_t);
+template void launch_pack_hidden<BF16>(const float*, int, int, int, int, int, int, int, u32x4*, hipStream_t);
+
+// out stream: [wave w][c][to][lane]; wave w owns k-steps w*CNT + c; rows >= out_dim are zero.
+template <class P>
+__global__ void pack_out_kernel(const float* W, int out_dim, int H, int OT, int CNT, u32x4* stream) {
+  const int lane = threadIdx.x & 63;
+  const int to = blockIdx.x % OT;
+  const int c = (blockIdx.x / OT) % CNT;
+  const int w = blockIdx.x / (OT * CNT);
+  const int r = lane & 15, g = lane >> 4;
+  const int o = to * 16 + r;
+  const int ks = w * CNT + c;
+  constexpr int EPL = 16 / P::ESIZE;
+  const int k0 = ks * P::KB + EPL * g;
+  const bool ok = o < out_dim && k0 < H;
+  uint32_t out[4];
+  if constexpr (P::ESIZE == 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = __float_as_uint(ok ? W[(size_t)o * H + k0 + j] : 0.f);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float lo = ok ? W[(size_t)o * H + k0 + 2 * j] : 0.f;
+      const float hi = ok ? W[(size_t)o * H + k0 + 2 * j + 1] : 0.f;
+      out[j] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    }
+  }
+  stream[(((size_t)w * CNT + c) * OT + to) * 64 + lane] = (u32x4){out[0], out[1], out[2], out[3]};
+}
+template <class P>
+void launch_pack_out(const float* W, int out_dim, int H, int OT, int CNT, u32x4* stream, hipStream_t s) {
+  hipLaunchKernelGGL((pack_out_kernel<P>), dim3(SAMPLER_WAVES * CNT * OT), dim3(64), 0, s, W, out_dim, H, OT, CNT,
+                     stream);
+}
+template void launch_pack_out<F32>(const float*, int, int, int, int, u32x4*, hipStream_t);
+template void launch_pack_out<BF16>(const float*, int, int, int, int, u32x4*, hipStream_t);
+
+}  // namespace dppo

@@ -1,0 +1,130 @@
+"""ctypes binding of libdppo_hip.so (C ABI: include/dppo_hip.h).
+
+The shared library is built in-tree by ``dppo_amd/csrc/build.sh`` (hipcc, gfx950) into
+``dppo_amd/lib/``.  There is NO fallback: if the library cannot be loaded every compute entry point
+raises, by design -- the product path is the HIP path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdppo_hip.so")
+
+PREC_F32, PREC_BF16 = 0, 1
+ACT_RELU, ACT_MISH = 0, 1
+STAT_PG_LOSS, STAT_V_LOSS, STAT_APPROX_KL, STAT_CLIPFRAC, STAT_RATIO, STAT_ADV_MEAN, STAT_ADV_STD = range(7)
+STAT_COUNT = 8
+
+PREC_BY_NAME = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": PREC_BF16, "bfloat16": PREC_BF16}
+
+
+class NetDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("kind", "in_dim", "hidden", "n_blocks", "out_dim", "act", "time_dim", "act_flat", "cond_dim")]
+
+
+class DiffusionCfg(C.Structure):
+    _fields_ = [("use_ddim", C.c_int32), ("has_denoised_clip", C.c_int32), ("has_eps_clip", C.c_int32),
+                ("has_final_clip", C.c_int32), ("denoised_clip", C.c_float), ("eps_clip", C.c_float),
+                ("randn_clip", C.c_float), ("final_clip", C.c_float)]
+
+
+class PpoCfg(C.Structure):
+    _fields_ = [("ft_denoising_steps", C.c_int32), ("horizon_steps", C.c_int32), ("action_dim", C.c_int32),
+                ("reward_horizon", C.c_int32), ("norm_adv", C.c_int32), ("has_adv_clip", C.c_int32),
+                ("has_vclip", C.c_int32), ("pad", C.c_int32),
+                ("gamma_denoising", C.c_double), ("clip_ploss_coef", C.c_double),
+                ("clip_ploss_coef_base", C.c_double), ("clip_ploss_coef_rate", C.c_double),
+                ("clip_vloss_coef", C.c_double), ("adv_clip_lo", C.c_float), ("adv_clip_hi", C.c_float)]
+
+
+# numpy mirror of `dppo_step` (40 bytes) so schedules are built vectorised on the host
+STEP_DTYPE = np.dtype([("net", "<i4"), ("t", "<i4"), ("chain_slot", "<i4"), ("final_clip", "<i4"),
+                       ("c0", "<f4"), ("c1", "<f4"), ("c2", "<f4"), ("c3", "<f4"), ("std", "<f4"), ("pad", "<f4")])
+assert STEP_DTYPE.itemsize == 40
+
+# every symbol include/dppo_hip.h declares: name -> (restype, argtypes)
+_P, _I, _L, _D = C.c_void_p, C.c_int, C.c_int64, C.c_double
+_ND = C.POINTER(NetDesc)
+SYMBOLS = {
+    "dppo_version": (C.c_int, []),
+    "dppo_last_error": (C.c_char_p, []),
+    "dppo_net_param_count": (_L, [_ND]),
+    "dppo_packed_bytes": (_L, [_ND, _I, _I]),
+    "dppo_pack_net": (_I, [_ND, _I, _I, _P, _P, _P]),
+    "dppo_mlp_forward_workspace_bytes": (_L, [_ND, _I, _L]),
+    "dppo_actor_forward": (_I, [_ND, _I, _P, _P, _P, _P, _P, _L, _P, _P, _L, _P]),
+    "dppo_critic_forward": (_I, [_ND, _I, _P, _P, _P, _L, _P, _P, _L, _P]),
+    "dppo_sample_chain": (_I, [_ND, _I, _P, _P, _P, _P, C.POINTER(DiffusionCfg), _P, _I, _P, _P, _L, _P, _P, _I, _I,
+                               _P]),
+    "dppo_chain_logprob_workspace_bytes": (_L, [_ND, _I, _L, _I]),
+    "dppo_chain_logprob": (_I, [_ND, _I, _P, _P, C.POINTER(DiffusionCfg), _P, _I, _P, _P, _L, _P, _P, _L, _P]),
+    "dppo_gae": (_I, [_P, _P, _P, _P, _I, _I, _D, _D, _D, _P, _P, _P, _P, _P]),
+    "dppo_ppo_workspace_bytes": (_L, [_ND, _ND, _I, _L]),
+    "dppo_ppo_loss_fwd_bwd": (_I, [_ND, _ND, _I, _P, _P, _P, _P, C.POINTER(DiffusionCfg), C.POINTER(PpoCfg), _P,
+                                   _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P]),
+    "dppo_grad_sq_norm": (_I, [_P, _L, _P, _P, _P]),
+    "dppo_adamw_step": (_I, [_P, _P, _P, _P, _L, _I, _D, _D, _D, _D, _D, _P, _D, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class DppoHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once).  Raises DppoHipError when it is missing -- there is no CPU path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DppoHipError(
+                f"{LIB_PATH} not found: build it with dppo_amd/csrc/build.sh (or __graft_entry__.build()). "
+                "dppo_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().dppo_last_error().decode()
+        raise DppoHipError(f"{what} failed (rc={rc}): {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    assert t.is_contiguous(), "dppo_amd kernels take contiguous tensors"
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise DppoHipError(f"{what}: tensor is on {t.device}; the DPPO hot path runs on an MI355X only "
+                           "(no CPU fallback)")
+
+
+class Workspace:
+    """Grow-only device scratch buffer (one per purpose, reused across calls)."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
+            self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        return self.buf

@@ -1,0 +1,48 @@
+"""State-value critic.  Mirrors ``dppo/model/common/critic.py:15-54`` (reference ``CriticObs``)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Union
+
+import torch
+
+from dppo_amd import hip
+from dppo_amd.model.common.mlp import HipNet, ResidualMLP
+
+
+class CriticObs(HipNet):
+    """V(s) = ResidualMLP([To*Do] + mlp_dims + [1]) on the flattened observation history."""
+
+    def __init__(self, cond_dim, mlp_dims, activation_type="Mish", use_layernorm=False, residual_style=False,
+                 precision="bf16", **kwargs):
+        super().__init__()
+        if not residual_style:
+            raise NotImplementedError("dppo_amd: CriticObs needs residual_style=True (plain MLP not built yet)")
+        self.Q1 = ResidualMLP([cond_dim] + list(mlp_dims) + [1], activation_type=activation_type,
+                              out_activation_type="Identity", use_layernorm=use_layernorm)
+        self.cond_dim = cond_dim
+        self.prec = hip.PREC_BY_NAME[precision]
+        object.__setattr__(self, "_ws", hip.Workspace())
+
+    def net_desc(self) -> hip.NetDesc:
+        q = self.Q1
+        return hip.NetDesc(kind=1, in_dim=self.cond_dim, hidden=q.hidden, n_blocks=q.n_blocks, out_dim=1, act=q.act,
+                           time_dim=0, act_flat=0, cond_dim=self.cond_dim)
+
+    @torch.no_grad()
+    def forward(self, cond: Union[dict, torch.Tensor]) -> torch.Tensor:
+        """cond: {"state": (B,To,Do)} or (B, To*Do) -> (B,1).  Inference only; the training forward/backward of
+        the critic lives inside PPODiffusion.loss (fused)."""
+        state = cond["state"] if isinstance(cond, dict) else cond
+        hip.require_gpu(state, "CriticObs.forward")
+        B = state.shape[0]
+        state = state.reshape(B, -1).contiguous().float()
+        lib, d = hip.load(), self.net_desc()
+        flat, pk = self.flat_params(), self.packed(self.prec, 0)
+        out = torch.empty(B, dtype=torch.float32, device=state.device)
+        wsb = lib.dppo_mlp_forward_workspace_bytes(C.byref(d), self.prec, B)
+        ws = self._ws.get(wsb, state.device)
+        hip.check(lib.dppo_critic_forward(C.byref(d), self.prec, flat.data_ptr(), pk.data_ptr(), state.data_ptr(), B,
+                                          out.data_ptr(), ws.data_ptr(), ws.numel(), hip.stream()),
+                  "dppo_critic_forward")
+        return out.view(B, 1)

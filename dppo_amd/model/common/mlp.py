@@ -1,0 +1,154 @@
+"""Parameter containers for the reference's MLP family, backed by one flat fp32 device buffer.
+
+Mirrors ``dppo/model/common/mlp.py`` (reference): ``ResidualMLP`` (:84-125) with
+``TwoLayerPreActivationResNetLinear`` blocks (:128-154).  The modules own nn.Parameters under the
+reference's state-dict names; the arithmetic is done by the HIP library on the flat image, so these
+classes have no torch ``forward`` math at all.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from dppo_amd import hip
+
+SUPPORTED_ACT = {"ReLU": hip.ACT_RELU, "Mish": hip.ACT_MISH}
+
+
+class TwoLayerPreActivationResNetLinear(nn.Module):
+    """h + l2(act(l1(act(h))))  (reference mlp.py:128-154, LayerNorm variant not built yet)."""
+
+    def __init__(self, hidden_dim: int):
+        super().__init__()
+        self.l1 = nn.Linear(hidden_dim, hidden_dim)
+        self.l2 = nn.Linear(hidden_dim, hidden_dim)
+
+
+class ResidualMLP(nn.Module):
+    """Linear(in,H) -> n x block -> Linear(H,out); ``layers.{i}`` names as in reference mlp.py:103-125."""
+
+    def __init__(self, dim_list: List[int], activation_type: str = "Mish", out_activation_type: str = "Identity",
+                 use_layernorm: bool = False, use_layernorm_final: bool = False, dropout: float = 0):
+        super().__init__()
+        if use_layernorm or use_layernorm_final:
+            raise NotImplementedError("dppo_amd: LayerNorm in ResidualMLP is not built yet (SURVEY.md 8f)")
+        if dropout:
+            raise NotImplementedError("Dropout not implemented for residual MLP!")  # same as the reference
+        if out_activation_type != "Identity":
+            raise NotImplementedError("dppo_amd: only out_activation_type='Identity' is built")
+        if activation_type not in SUPPORTED_ACT:
+            raise NotImplementedError(f"dppo_amd: activation {activation_type!r} not built (ReLU, Mish are)")
+        hidden = dim_list[1]
+        n_hidden = len(dim_list) - 3
+        assert n_hidden % 2 == 0
+        assert all(d == hidden for d in dim_list[1:-1]), "residual MLP needs one hidden width"
+        self.layers = nn.ModuleList([nn.Linear(dim_list[0], hidden)])
+        self.layers.extend([TwoLayerPreActivationResNetLinear(hidden) for _ in range(1, n_hidden, 2)])
+        self.layers.append(nn.Linear(hidden, dim_list[-1]))
+        self.hidden, self.n_blocks = hidden, n_hidden // 2
+        self.in_dim, self.out_dim = dim_list[0], dim_list[-1]
+        self.act = SUPPORTED_ACT[activation_type]
+
+
+class HipNet(nn.Module):
+    """Base of DiffusionMLP / CriticObs: keeps every parameter a view of ONE flat fp32 buffer (state-dict
+    order = the C ABI's flat layout) and caches the packed kernel image per (precision, n_time)."""
+
+    def __init__(self):
+        super().__init__()
+        object.__setattr__(self, "_flat", None)
+        object.__setattr__(self, "_flat_grad", None)
+        object.__setattr__(self, "_packed", {})
+        object.__setattr__(self, "_epoch", 0)  # bumped by optimiser kernels that write the flat buffer directly
+
+    # subclasses fill this
+    def net_desc(self) -> hip.NetDesc:
+        raise NotImplementedError
+
+    def __deepcopy__(self, memo):
+        # default Module deepcopy would alias the private caches; copy parameters only
+        cls = self.__class__
+        new = cls.__new__(cls)
+        nn.Module.__init__(new)
+        import copy
+        for k, v in self.__dict__.items():
+            if k in ("_flat", "_flat_grad", "_packed", "_epoch"):
+                continue
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        object.__setattr__(new, "_flat", None)
+        object.__setattr__(new, "_flat_grad", None)
+        object.__setattr__(new, "_packed", {})
+        object.__setattr__(new, "_epoch", 0)
+        return new
+
+    def flat_params(self) -> torch.Tensor:
+        ps = list(self.parameters())
+        flat = self._flat
+        ok = flat is not None and flat.device == ps[0].device
+        if ok:
+            off = 0
+            base = flat.data_ptr()
+            for p in ps:
+                if p.data_ptr() != base + 4 * off or not p.is_contiguous():
+                    ok = False
+                    break
+                off += p.numel()
+        if not ok:
+            total = sum(p.numel() for p in ps)
+            flat = torch.empty(total, dtype=torch.float32, device=ps[0].device)
+            off = 0
+            for p in ps:
+                n = p.numel()
+                flat[off:off + n].copy_(p.data.reshape(-1).float())
+                p.data = flat[off:off + n].view(p.shape)
+                off += n
+            object.__setattr__(self, "_flat", flat)
+            self._packed.clear()
+            d = self.net_desc()
+            if flat.is_cuda:
+                want = hip.load().dppo_net_param_count(C.byref(d))
+                assert want == total, f"flat layout mismatch: python {total} vs C ABI {want}"
+        return flat
+
+    def flat_grads(self) -> torch.Tensor:
+        flat = self.flat_params()
+        g = self._flat_grad
+        if g is None or g.device != flat.device or g.numel() != flat.numel():
+            g = torch.zeros_like(flat)
+            object.__setattr__(self, "_flat_grad", g)
+        return g
+
+    def grad_views(self) -> List[torch.Tensor]:
+        g = self.flat_grads()
+        out, off = [], 0
+        for p in self.parameters():
+            out.append(g[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        return out
+
+    def mark_updated(self):
+        """Call after a kernel wrote the flat parameter buffer behind torch's back (fused AdamW)."""
+        object.__setattr__(self, "_epoch", self._epoch + 1)
+
+    def packed(self, prec: int, n_time: int) -> torch.Tensor:
+        flat = self.flat_params()
+        hip.require_gpu(flat, type(self).__name__)
+        key = (prec, n_time)
+        stamp = (flat.data_ptr(), flat._version, self._epoch)
+        hit = self._packed.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        lib = hip.load()
+        d = self.net_desc()
+        nbytes = lib.dppo_packed_bytes(C.byref(d), prec, n_time)
+        if nbytes < 0:
+            hip.check(int(nbytes), "dppo_packed_bytes")
+        buf = hit[1] if hit is not None and hit[1].numel() == nbytes else torch.empty(
+            nbytes, dtype=torch.uint8, device=flat.device)
+        hip.check(lib.dppo_pack_net(C.byref(d), prec, n_time, flat.data_ptr(), buf.data_ptr(), hip.stream()),
+                  "dppo_pack_net")
+        self._packed[key] = (stamp, buf)
+        return buf

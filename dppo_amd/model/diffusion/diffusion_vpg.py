@@ -1,0 +1,228 @@
+"""Diffusion policy with a frozen base net and a fine-tuned copy.
+
+Mirrors ``dppo/model/diffusion/diffusion_vpg.py:27-461`` (reference ``VPGDiffusion``): constructor surface,
+``forward`` (K-step sampling with chain capture), ``get_logprobs``, ``get_logprobs_subsample``, ``step``.
+The K-step loop, both networks and the posterior arithmetic run in ONE persistent HIP kernel
+(``dppo_sample_chain``); the host only prepares the per-step coefficient table, in fp32 torch ops that
+repeat the reference's own expressions so the coefficients are bit-identical.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+import logging
+
+import numpy as np
+import torch
+
+from dppo_amd import hip
+from dppo_amd.model.diffusion.diffusion import DiffusionModel, Sample
+
+log = logging.getLogger(__name__)
+
+
+class VPGDiffusion(DiffusionModel):
+    def __init__(self, actor, critic, ft_denoising_steps, ft_denoising_steps_d=0, ft_denoising_steps_t=0,
+                 network_path=None, min_sampling_denoising_std=0.1, min_logprob_denoising_std=0.1, eta=None,
+                 learn_eta=False, **kwargs):
+        super().__init__(network=actor, network_path=network_path, **kwargs)
+        assert ft_denoising_steps <= self.denoising_steps
+        assert ft_denoising_steps <= self.ddim_steps if self.use_ddim else True
+        assert not (learn_eta and not self.use_ddim), "Cannot learn eta with DDPM."
+        if learn_eta:
+            raise NotImplementedError("dppo_amd: learn_eta=True is out of scope (all shipped cfgs keep eta fixed)")
+        self.ft_denoising_steps = ft_denoising_steps
+        self.ft_denoising_steps_d = ft_denoising_steps_d
+        self.ft_denoising_steps_t = ft_denoising_steps_t
+        self.ft_denoising_steps_cnt = 0
+        self.min_sampling_denoising_std = min_sampling_denoising_std
+        self.min_logprob_denoising_std = min_logprob_denoising_std
+        self.learn_eta = learn_eta
+        if eta is not None:
+            self.eta = eta.to(self.device)
+            for p in self.eta.parameters():
+                p.requires_grad = False
+        self.actor = self.network
+        self.actor_ft = copy.deepcopy(self.actor)
+        for p in self.actor.parameters():
+            p.requires_grad = False
+        self.critic = critic.to(self.device)
+        if network_path is not None:
+            checkpoint = torch.load(network_path, map_location=self.device, weights_only=True)
+            if "ema" not in checkpoint:
+                self.load_state_dict(checkpoint["model"], strict=False)
+        object.__setattr__(self, "_sched_cache", {})
+        object.__setattr__(self, "_ws_logprob", hip.Workspace())
+
+    # ------------------------------------------------------------------ annealing (reference :102-136)
+    def step(self):
+        if type(self.min_sampling_denoising_std) is not float:
+            self.min_sampling_denoising_std.step()
+        self.ft_denoising_steps_cnt += 1
+        if (self.ft_denoising_steps_d > 0 and self.ft_denoising_steps_t > 0
+                and self.ft_denoising_steps_cnt % self.ft_denoising_steps_t == 0):
+            self.ft_denoising_steps = max(0, self.ft_denoising_steps - self.ft_denoising_steps_d)
+            self.actor = self.actor_ft
+            self.actor_ft = copy.deepcopy(self.actor)
+            for p in self.actor.parameters():
+                p.requires_grad = False
+            self._sched_cache.clear()
+
+    def get_min_sampling_denoising_std(self):
+        if type(self.min_sampling_denoising_std) is float:
+            return self.min_sampling_denoising_std
+        return self.min_sampling_denoising_std()
+
+    # ------------------------------------------------------------------ per-step coefficient tables
+    def _eta_value(self, deterministic: bool) -> float:
+        if deterministic:
+            return 0.0
+        return self.eta.value() if hasattr(self, "eta") else 1.0
+
+    def _ddim_coefs(self, i: int, eta: float):
+        """(c0..c3, std_raw) of DDIM index i; expressions of reference :171-213, fp32 torch scalars."""
+        al, alp = self.ddim_alphas[i], self.ddim_alphas_prev[i]
+        som = self.ddim_sqrt_one_minus_alphas[i]
+        etas = torch.tensor(eta, dtype=torch.float32)
+        sigma = (etas * ((1 - alp) / (1 - al) * (1 - al / alp)) ** 0.5).clamp(min=1e-10)
+        dirc = (1.0 - alp - sigma ** 2).clamp(min=0).sqrt()
+        logvar = torch.log(sigma ** 2)
+        return float(al ** 0.5), float(som), float(alp ** 0.5), float(dirc), torch.exp(0.5 * logvar)
+
+    def _ddpm_coefs(self, t: int):
+        return (float(self.sqrt_recip_alphas_cumprod[t]), float(self.sqrt_recipm1_alphas_cumprod[t]),
+                float(self.ddpm_mu_coef1[t]), float(self.ddpm_mu_coef2[t]),
+                torch.exp(0.5 * self.ddpm_logvar_clipped[t]))
+
+    def _sampling_schedule(self, deterministic: bool, use_base_policy: bool, device):
+        """dppo_step table of the sampling loop (reference :258-311) + chain geometry."""
+        min_std = float(self.get_min_sampling_denoising_std())
+        key = ("sample", deterministic, use_base_policy, min_std, self.ft_denoising_steps, str(device),
+               self._eta_value(deterministic))
+        hit = self._sched_cache.get(key)
+        if hit is not None:
+            return hit
+        Kft = self.ft_denoising_steps
+        if self.use_ddim:
+            t_all = [int(v) for v in self.ddim_t]
+            n_steps = self.ddim_steps
+        else:
+            t_all = list(reversed(range(self.denoising_steps)))
+            n_steps = self.denoising_steps
+        tab = np.zeros(n_steps, dtype=hip.STEP_DTYPE)
+        init_slot = 0 if Kft == n_steps else -1
+        slot = 1 if Kft == n_steps else 0
+        for i, t in enumerate(t_all):
+            if self.use_ddim:
+                ft = i >= (self.ddim_steps - Kft)
+                c0, c1, c2, c3, std = self._ddim_coefs(i, self._eta_value(deterministic))
+                std = torch.zeros_like(std) if deterministic else torch.clip(std, min=min_std)
+                keep = i >= (self.ddim_steps - Kft - 1)
+            else:
+                ft = t < Kft
+                c0, c1, c2, c3, std = self._ddpm_coefs(t)
+                if deterministic and t == 0:
+                    std = torch.zeros_like(std)
+                elif deterministic:
+                    std = torch.clip(std, min=1e-3)
+                else:
+                    std = torch.clip(std, min=min_std)
+                keep = t <= Kft
+            tab[i] = (int(ft and not use_base_policy), t, slot if keep else -1,
+                      int(self.final_action_clip_value is not None and i == n_steps - 1), c0, c1, c2, c3,
+                      float(std), 0.0)
+            slot += int(keep)
+        out = (torch.from_numpy(tab.view(np.uint8)).to(device), n_steps, slot, init_slot)
+        self._sched_cache[key] = out
+        return out
+
+    def _logprob_schedule(self, device):
+        """dppo_step table of chain position k = 0..Kft-1 (reference :351-370, :388-389)."""
+        key = ("logprob", self.ft_denoising_steps, float(self.min_logprob_denoising_std), str(device),
+               self._eta_value(False))
+        hit = self._sched_cache.get(key)
+        if hit is not None:
+            return hit
+        Kft = self.ft_denoising_steps
+        tab = np.zeros(Kft, dtype=hip.STEP_DTYPE)
+        for k in range(Kft):
+            if self.use_ddim:
+                i = self.ddim_steps - Kft + k
+                t = int(self.ddim_t[i])
+                c0, c1, c2, c3, std = self._ddim_coefs(i, self._eta_value(False))
+            else:
+                t = Kft - 1 - k
+                c0, c1, c2, c3, std = self._ddpm_coefs(t)
+            std = torch.clip(std, min=self.min_logprob_denoising_std)
+            tab[k] = (1, t, -1, 0, c0, c1, c2, c3, float(std), 0.0)
+        out = torch.from_numpy(tab.view(np.uint8)).to(device)
+        self._sched_cache[key] = out
+        return out
+
+    # ------------------------------------------------------------------ sampling (reference :227-315)
+    @torch.no_grad()
+    def forward(self, cond, deterministic=False, return_chain=True, use_base_policy=False, noise=None):
+        """cond {"state": (B,To,Do)} -> Sample(trajectories (B,Ta,Da), chains (B,Kft+1,Ta,Da)).
+
+        ``noise`` (n_steps+1,B,Ta,Da) replaces the internal ``torch.randn`` draw (parity tests): noise[0] is the
+        initial x, noise[i+1] the draw of step i.
+        """
+        state = cond["state"]
+        hip.require_gpu(state, "VPGDiffusion.forward")
+        B = state.shape[0]
+        dev = state.device
+        AF = self.horizon_steps * self.action_dim
+        sched, n_steps, chain_len, init_slot = self._sampling_schedule(deterministic, use_base_policy, dev)
+        if noise is None:
+            noise = torch.randn((n_steps + 1, B, AF), device=dev, dtype=torch.float32)
+        noise = noise.reshape(n_steps + 1, B, AF).contiguous().float()
+        obs = state.reshape(B, -1).contiguous().float()
+        traj = torch.empty((B, AF), device=dev, dtype=torch.float32)
+        chains = torch.empty((B, chain_len, AF), device=dev, dtype=torch.float32) if return_chain else None
+        lib = hip.load()
+        d = self.actor.net_desc()
+        K = self.denoising_steps
+        cfg = self.diffusion_cfg()
+        hip.check(lib.dppo_sample_chain(
+            C.byref(d), self.prec, self.actor.flat_params().data_ptr(), self.actor.packed(self.prec, K).data_ptr(),
+            self.actor_ft.flat_params().data_ptr(), self.actor_ft.packed(self.prec, K).data_ptr(), C.byref(cfg),
+            sched.data_ptr(), n_steps, obs.data_ptr(), noise.data_ptr(), B, traj.data_ptr(),
+            chains.data_ptr() if return_chain else None, chain_len if return_chain else 0,
+            init_slot if return_chain else -1, hip.stream()), "dppo_sample_chain")
+        traj = traj.view(B, self.horizon_steps, self.action_dim)
+        if return_chain:
+            chains = chains.view(B, chain_len, self.horizon_steps, self.action_dim)
+        return Sample(traj, chains)
+
+    # ------------------------------------------------------------------ log-probs (reference :319-396)
+    @torch.no_grad()
+    def get_logprobs(self, cond, chains, get_ent: bool = False, use_base_policy: bool = False):
+        """chains (B,Kft+1,Ta,Da) -> log N(x_{k+1}; mu(x_k), sigma_k) elementwise, (B*Kft,Ta,Da).
+
+        Inference only (the rollout precompute); the differentiable evaluation happens fused inside
+        ``PPODiffusion.loss``.
+        """
+        state = cond["state"]
+        hip.require_gpu(state, "VPGDiffusion.get_logprobs")
+        B, dev = chains.shape[0], chains.device
+        Kft = self.ft_denoising_steps
+        AF = self.horizon_steps * self.action_dim
+        net = self.actor if use_base_policy else self.actor_ft
+        lib, d = hip.load(), net.net_desc()
+        ch = chains.reshape(B, Kft + 1, AF).contiguous().float()
+        obs = state.reshape(B, -1).contiguous().float()
+        out = torch.empty((B * Kft, AF), device=dev, dtype=torch.float32)
+        ks = self._logprob_schedule(dev)
+        cfg = self.diffusion_cfg()
+        wsb = lib.dppo_chain_logprob_workspace_bytes(C.byref(d), self.prec, B, Kft)
+        ws = self._ws_logprob.get(wsb, dev)
+        hip.check(lib.dppo_chain_logprob(
+            C.byref(d), self.prec, net.flat_params().data_ptr(), net.packed(self.prec, self.denoising_steps).data_ptr(),
+            C.byref(cfg), ks.data_ptr(), Kft, obs.data_ptr(), ch.data_ptr(), B, out.data_ptr(), ws.data_ptr(),
+            ws.numel(), hip.stream()), "dppo_chain_logprob")
+        out = out.view(B * Kft, self.horizon_steps, self.action_dim)
+        if get_ent:
+            eta = torch.full_like(out, 1.0) if not self.use_ddim else torch.full(
+                (B * Kft, 1, 1), self._eta_value(False), device=dev)
+            return out, eta
+        return out

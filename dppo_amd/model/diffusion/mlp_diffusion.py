@@ -1,0 +1,65 @@
+"""Denoiser backbone.  Mirrors ``dppo/model/diffusion/mlp_diffusion.py:174-250`` (reference ``DiffusionMLP``)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import nn
+
+from dppo_amd import hip
+from dppo_amd.model.common.mlp import HipNet, ResidualMLP
+
+
+class _NoParams(nn.Module):
+    """Placeholder for the parameter-free stages of the reference's nn.Sequential (keeps indices 1 and 3)."""
+
+
+class DiffusionMLP(HipNet):
+    """eps(x, t, state) = ResidualMLP(cat[x, time_mlp(sinusoid(t)), state]).
+
+    Parameter names match the reference state dict: ``time_embedding.{1,3}.*``, ``mlp_mean.layers.*``.
+    """
+
+    def __init__(self, action_dim, horizon_steps, cond_dim, time_dim=16, mlp_dims=[256, 256], cond_mlp_dims=None,
+                 activation_type="Mish", out_activation_type="Identity", use_layernorm=False, residual_style=False,
+                 precision="bf16"):
+        super().__init__()
+        if cond_mlp_dims is not None:
+            raise NotImplementedError("dppo_amd: cond_mlp (obs encoder) is not built yet (SURVEY.md 8f)")
+        if not residual_style:
+            raise NotImplementedError("dppo_amd: DiffusionMLP needs residual_style=True (plain MLP not built yet)")
+        self.time_embedding = nn.Sequential(_NoParams(), nn.Linear(time_dim, time_dim * 2), _NoParams(),
+                                            nn.Linear(time_dim * 2, time_dim))
+        out_dim = action_dim * horizon_steps
+        in_dim = time_dim + out_dim + cond_dim
+        self.mlp_mean = ResidualMLP([in_dim] + list(mlp_dims) + [out_dim], activation_type=activation_type,
+                                    out_activation_type=out_activation_type, use_layernorm=use_layernorm)
+        self.time_dim, self.action_dim, self.horizon_steps, self.cond_dim = time_dim, action_dim, horizon_steps, cond_dim
+        self.prec = hip.PREC_BY_NAME[precision]
+        self.n_time = 1000  # rows of the time-embedding table built for stand-alone forward() calls
+        object.__setattr__(self, "_ws", hip.Workspace())
+
+    def net_desc(self) -> hip.NetDesc:
+        m = self.mlp_mean
+        return hip.NetDesc(kind=0, in_dim=m.in_dim, hidden=m.hidden, n_blocks=m.n_blocks, out_dim=m.out_dim, act=m.act,
+                           time_dim=self.time_dim, act_flat=m.out_dim, cond_dim=self.cond_dim)
+
+    @torch.no_grad()
+    def forward(self, x, time, cond, **kwargs):
+        """x (B,Ta,Da), time (B,) or int, cond {"state": (B,To,Do)} -> (B,Ta,Da).  Inference only."""
+        hip.require_gpu(x, "DiffusionMLP.forward")
+        B, Ta, Da = x.shape
+        if not torch.is_tensor(time):
+            time = torch.full((B,), int(time), device=x.device, dtype=torch.long)
+        t = time.reshape(B).to(torch.long).contiguous()
+        state = cond["state"].reshape(B, -1).contiguous().float()
+        xf = x.reshape(B, -1).contiguous().float()
+        lib, d = hip.load(), self.net_desc()
+        flat, pk = self.flat_params(), self.packed(self.prec, self.n_time)
+        out = torch.empty(B, Ta * Da, dtype=torch.float32, device=x.device)
+        wsb = lib.dppo_mlp_forward_workspace_bytes(C.byref(d), self.prec, B)
+        ws = self._ws.get(wsb, x.device)
+        hip.check(lib.dppo_actor_forward(C.byref(d), self.prec, flat.data_ptr(), pk.data_ptr(), xf.data_ptr(),
+                                         t.data_ptr(), state.data_ptr(), B, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         hip.stream()), "dppo_actor_forward")
+        return out.view(B, Ta, Da)

@@ -1,0 +1,47 @@
+"""Fused AdamW on a flat fp32 buffer (torch.optim.AdamW + clip_grad_norm_ semantics; reference
+agent/finetune/train_ppo_agent.py:34-62, train_ppo_diffusion_agent.py:360-373)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from dppo_amd import hip
+
+
+class FlatAdamW:
+    """One kernel per step over the whole parameter image; optional global-norm clipping without a host sync."""
+
+    def __init__(self, flat_params: torch.Tensor, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 1e-2):
+        hip.require_gpu(flat_params, "FlatAdamW")
+        assert flat_params.dtype == torch.float32 and flat_params.is_contiguous()
+        self.p = flat_params
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros_like(flat_params)
+        self.exp_avg_sq = torch.zeros_like(flat_params)
+        self.step_count = 0
+        self._norm = torch.zeros(1, dtype=torch.float64, device=flat_params.device)
+        self._scratch = torch.zeros(1024, dtype=torch.float64, device=flat_params.device)
+        # torch-optimizer look-alike for LR schedulers
+        self.param_groups = [{"lr": lr}]
+
+    def sq_norm(self, grad: torch.Tensor) -> torch.Tensor:
+        hip.check(hip.load().dppo_grad_sq_norm(grad.data_ptr(), grad.numel(), self._scratch.data_ptr(),
+                                               self._norm.data_ptr(), hip.stream()), "dppo_grad_sq_norm")
+        return self._norm
+
+    def step(self, grad: torch.Tensor, max_norm: Optional[float] = None, sq_norm: Optional[torch.Tensor] = None):
+        """grad: flat fp32 like the params.  max_norm: clip_grad_norm_ threshold (norm computed on device unless
+        ``sq_norm`` -- e.g. an all-reduced value -- is given)."""
+        assert grad.numel() == self.p.numel() and grad.is_contiguous()
+        self.step_count += 1
+        lr = self.param_groups[0]["lr"]
+        norm_ptr = None
+        if max_norm is not None:
+            norm_ptr = (sq_norm if sq_norm is not None else self.sq_norm(grad)).data_ptr()
+        hip.check(hip.load().dppo_adamw_step(self.p.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(),
+                                             self.exp_avg_sq.data_ptr(), self.p.numel(), self.step_count, float(lr),
+                                             float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                             float(self.weight_decay), norm_ptr, float(max_norm or 0.0),
+                                             hip.stream()), "dppo_adamw_step")

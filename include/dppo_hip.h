@@ -1,0 +1,198 @@
+/* dppo_hip.h -- C ABI of libdppo_hip.so: the MI355X (gfx950) DPPO hot path.
+ *
+ * The reference (enyen/dppo) has no FFI layer; its seam is Hydra `_target_` + nn.Module duck typing
+ * (SURVEY.md 8b).  This header is the boundary a native replacement exports so that the Python
+ * module `dppo_amd` (a mirror of the reference's PPODiffusion / DiffusionMLP / CriticObs classes)
+ * is a thin ctypes shim.  Each entry point names the reference code it replaces
+ * (paths relative to /root/reference/dppo).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in _host; plain C types only;
+ *  - no entry point allocates, frees or synchronises; callers pass workspaces (sizes from the
+ *    *_workspace_bytes queries) and the HIP stream (hipStream_t passed as void*);
+ *  - return 0 = ok, <0 = bad argument / unsupported shape (dppo_last_error() has the text),
+ *    >0 = hipError_t from a launch;
+ *  - re-entrant across streams: no global mutable state besides the thread-local error string.
+ *
+ * Networks are the reference's residual MLP family: Linear(in,H) -> n_blocks x
+ * [h + l2(act(l1(act(h))))] -> Linear(H,out)  (model/common/mlp.py:84-154), for the actor preceded
+ * by the sinusoidal time embedding MLP and concat [x, t_emb, state]
+ * (model/diffusion/mlp_diffusion.py:191-196,246).  Parameters live in ONE flat fp32 buffer in
+ * state-dict order:
+ *   actor : time_embedding.1.{weight(2td x td),bias}, time_embedding.3.{weight(td x 2td),bias},
+ *           layers.0.{weight(H x in),bias}, [layers.b.l1.{w,b}, layers.b.l2.{w,b}] x n_blocks,
+ *           layers.last.{weight(out x H),bias}
+ *   critic: the same without the time embedding (Q1.layers.*).
+ * nn.Linear layout (out,in) row-major.  Gradients use the same flat layout.
+ */
+#ifndef DPPO_HIP_H
+#define DPPO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPPO_PREC_F32 0  /* v_mfma_f32_16x16x4_f32 : exact fp32 products (parity mode)      */
+#define DPPO_PREC_BF16 1 /* v_mfma_f32_16x16x32_bf16: bf16 operands, fp32 accumulate         */
+
+#define DPPO_ACT_RELU 0
+#define DPPO_ACT_MISH 1
+
+typedef void* dppo_stream_t; /* hipStream_t */
+
+typedef struct dppo_net_desc {
+  int32_t kind;     /* 0 = actor (DiffusionMLP), 1 = critic (CriticObs)                     */
+  int32_t in_dim;   /* actor: Ta*Da + time_dim + cond_dim ; critic: cond_dim                 */
+  int32_t hidden;   /* H, multiple of 128                                                    */
+  int32_t n_blocks; /* residual blocks = (len(mlp_dims)-1)/2                                  */
+  int32_t out_dim;  /* actor: Ta*Da ; critic: 1                                              */
+  int32_t act;      /* DPPO_ACT_*                                                            */
+  int32_t time_dim; /* actor: td (even, >= 4) ; critic: 0                                    */
+  int32_t act_flat; /* actor: Ta*Da ; critic: 0                                              */
+  int32_t cond_dim; /* To*Do                                                                 */
+} dppo_net_desc;
+
+/* One denoising step, host-prepared in fp32 exactly as the reference computes its tables
+ * (model/diffusion/diffusion.py:98-196, diffusion_vpg.py:168-223,279-293).
+ *   DDPM: c0 = sqrt(1/abar_t), c1 = sqrt(1/abar_t - 1), c2 = mu_coef1, c3 = mu_coef2
+ *   DDIM: c0 = sqrt(alpha), c1 = sqrt(1 - alpha), c2 = sqrt(alpha_prev), c3 = sqrt(clamp(1-alpha_prev-sigma^2, 0))
+ *   std : the noise scale used at this step (sampling: after the min-std / deterministic rule;
+ *         log-prob tables: max(exp(.5 logvar), min_logprob_denoising_std))                      */
+typedef struct dppo_step {
+  int32_t net;        /* 0 = frozen base actor, 1 = fine-tuned actor                         */
+  int32_t t;          /* row of the time-embedding table (the diffusion time)                 */
+  int32_t chain_slot; /* sampler: chain position that receives x AFTER this step, or -1       */
+  int32_t final_clip; /* sampler: 1 = clamp x to +-final_action_clip_value after this step    */
+  float c0, c1, c2, c3;
+  float std;
+  float pad;
+} dppo_step;
+
+typedef struct dppo_diffusion_cfg {
+  int32_t use_ddim;
+  int32_t has_denoised_clip; /* denoised_clip_value is not None */
+  int32_t has_eps_clip;      /* eps_clip_value is not None (DDIM only) */
+  int32_t has_final_clip;
+  float denoised_clip, eps_clip, randn_clip, final_clip;
+} dppo_diffusion_cfg;
+
+typedef struct dppo_ppo_cfg {
+  int32_t ft_denoising_steps; /* Kft                                                         */
+  int32_t horizon_steps;      /* Ta                                                          */
+  int32_t action_dim;         /* Da                                                          */
+  int32_t reward_horizon;     /* chunk steps whose log-probs enter the loss                  */
+  int32_t norm_adv;
+  int32_t has_adv_clip;       /* quantile thresholds below are active                        */
+  int32_t has_vclip;
+  int32_t pad;
+  /* Python floats of the reference's constructor, kept as doubles: the denoising discount is
+   * float32(pow(double gamma, Kft-k-1)) and the clip schedule mixes double scalars into fp32 math
+   * (diffusion_ppo.py:138-159) */
+  double gamma_denoising, clip_ploss_coef, clip_ploss_coef_base, clip_ploss_coef_rate, clip_vloss_coef;
+  float adv_clip_lo, adv_clip_hi; /* torch.quantile thresholds of the normalised advantages */
+} dppo_ppo_cfg;
+
+/* index of each statistic in the `stats` output of dppo_ppo_loss_fwd_bwd (device doubles) */
+enum {
+  DPPO_STAT_PG_LOSS = 0,
+  DPPO_STAT_V_LOSS = 1,
+  DPPO_STAT_APPROX_KL = 2,
+  DPPO_STAT_CLIPFRAC = 3,
+  DPPO_STAT_RATIO = 4,
+  DPPO_STAT_ADV_MEAN = 5,
+  DPPO_STAT_ADV_STD = 6,
+  DPPO_STAT_COUNT = 8
+};
+
+int dppo_version(void);
+const char* dppo_last_error(void);
+
+/* ---- parameters ------------------------------------------------------------------------ */
+/* number of fp32 values in the flat parameter buffer of `net` */
+int64_t dppo_net_param_count(const dppo_net_desc* net);
+/* bytes of the packed (kernel-ready) image of `net`: time-embedding table for n_time diffusion
+ * times, GEMM operand copies (W and W^T) and the sampler's per-wave fragment streams */
+int64_t dppo_packed_bytes(const dppo_net_desc* net, int prec, int n_time);
+/* build the packed image from the fp32 master parameters; call again after every optimiser step */
+int dppo_pack_net(const dppo_net_desc* net, int prec, int n_time, const float* params, void* packed,
+                  dppo_stream_t stream);
+
+/* ---- A2-A5: network forwards ------------------------------------------------------------- */
+/* DiffusionMLP.forward (model/diffusion/mlp_diffusion.py:218-250): x (B,Ta*Da), t (B,) int64,
+ * state (B,cond) -> eps (B,Ta*Da) */
+int64_t dppo_mlp_forward_workspace_bytes(const dppo_net_desc* net, int prec, int64_t rows);
+int dppo_actor_forward(const dppo_net_desc* net, int prec, const float* params, const void* packed,
+                       const float* x, const int64_t* t, const float* state, int64_t rows, float* eps,
+                       void* workspace, int64_t workspace_bytes, dppo_stream_t stream);
+/* CriticObs.forward (model/common/critic.py:40-54): state (B,cond) -> value (B,) */
+int dppo_critic_forward(const dppo_net_desc* net, int prec, const float* params, const void* packed,
+                        const float* state, int64_t rows, float* values, void* workspace,
+                        int64_t workspace_bytes, dppo_stream_t stream);
+
+/* ---- A6-A7: VPGDiffusion.forward (model/diffusion/diffusion_vpg.py:227-315) --------------- */
+/* obs (B,cond); noise (n_steps+1,B,Ta*Da): noise[0] is x_K, noise[i+1] the draw of step i (clamped
+ * to +-randn_clip inside); sched: n_steps device entries; traj (B,Ta*Da); chains (B,chain_len,Ta*Da)
+ * (may be NULL when chain_len == 0); init_slot: chain position of x_K or -1. */
+int dppo_sample_chain(const dppo_net_desc* actor, int prec, const float* params_base, const void* packed_base,
+                      const float* params_ft, const void* packed_ft, const dppo_diffusion_cfg* cfg,
+                      const dppo_step* sched, int n_steps, const float* obs, const float* noise, int64_t B,
+                      float* traj, float* chains, int chain_len, int init_slot, dppo_stream_t stream);
+
+/* ---- A8: VPGDiffusion.get_logprobs (diffusion_vpg.py:319-396) ----------------------------- */
+/* obs (B,cond), chains (B,Kft+1,Ta*Da) -> logprobs (B,Kft,Ta*Da).  ksteps: Kft device entries,
+ * entry k describes chain position k (t = Kft-1-k for DDPM); all rows use the network passed in. */
+int64_t dppo_chain_logprob_workspace_bytes(const dppo_net_desc* actor, int prec, int64_t B, int Kft);
+int dppo_chain_logprob(const dppo_net_desc* actor, int prec, const float* params, const void* packed,
+                       const dppo_diffusion_cfg* cfg, const dppo_step* ksteps, int Kft, const float* obs,
+                       const float* chains, int64_t B, float* logprobs, void* workspace,
+                       int64_t workspace_bytes, dppo_stream_t stream);
+
+/* ---- A10: GAE (agent/finetune/train_ppo_diffusion_agent.py:255-279) ----------------------- */
+/* reward (S,E) float64 (already scaled by the host-side running scaler), values (S,E) fp32,
+ * terminated (S,E) fp32 0/1, last_values (E,) fp32.  Float64 arithmetic like the reference's numpy
+ * holders.  Outputs (any may be NULL): adv64/ret64 (S,E) float64, adv32/ret32 (S,E) fp32. */
+int dppo_gae(const double* reward, const float* values, const float* terminated, const float* last_values,
+             int n_steps, int n_envs, double gamma, double gae_lambda, double reward_scale_const, double* adv64,
+             double* ret64, float* adv32, float* ret32, dppo_stream_t stream);
+
+/* ---- A9 + A11: PPODiffusion.loss fused with the minibatch gather, forward AND backward ----- */
+/* (model/diffusion/diffusion_ppo.py:57-199; agent/finetune/train_ppo_diffusion_agent.py:316-327)
+ * Rollout buffer, R = n_steps*n_envs rows: obs_k (R,cond), chains_k (R,Kft+1,Ta*Da), returns_k,
+ * values_k, adv_k (R,), logprobs_k (R,Kft,Ta*Da).  inds (N,) int64 in [0, R*Kft): sample n is
+ * (row = ind / Kft, k = ind % Kft); kinds must be NULL.
+ * Pre-gathered mode (the reference's loss() signature): inds == NULL, kinds (N,) int64 = denoising_inds,
+ * obs_k (N,cond), chains_k (N,2,Ta*Da) = (chains_prev, chains_next), returns_k/values_k/adv_k (N,),
+ * logprobs_k (N,Ta*Da).
+ * Data parallel: global_moments (3 doubles: sum adv, sum adv^2, sample count over the GLOBAL minibatch,
+ * all-reduced by the caller) or NULL for a single-process minibatch.  With it, advantages are normalised
+ * by the global mean/std and every mean uses the global count, so SUM-all-reducing the gradients and
+ * statistics of all ranks reproduces the single-process result.
+ * Writes d(pg_loss)/d(actor params) to actor_grad and
+ * d(v_loss)/d(critic params) to critic_grad (flat layouts, overwritten), and the statistics
+ * (means over the minibatch) to stats[DPPO_STAT_*]. */
+int64_t dppo_ppo_workspace_bytes(const dppo_net_desc* actor, const dppo_net_desc* critic, int prec, int64_t N);
+int dppo_ppo_loss_fwd_bwd(const dppo_net_desc* actor, const dppo_net_desc* critic, int prec,
+                          const float* actor_params, const void* actor_packed, const float* critic_params,
+                          const void* critic_packed, const dppo_diffusion_cfg* dcfg, const dppo_ppo_cfg* pcfg,
+                          const dppo_step* ksteps, const float* obs_k, const float* chains_k,
+                          const float* returns_k, const float* values_k, const float* adv_k,
+                          const float* logprobs_k, const int64_t* inds, const int64_t* kinds, int64_t N,
+                          const double* global_moments, float* actor_grad, float* critic_grad, double* stats,
+                          void* workspace, int64_t workspace_bytes, dppo_stream_t stream);
+
+/* ---- A12: optimiser (torch.optim.AdamW + clip_grad_norm_ semantics) ----------------------- */
+/* out[0] = sum g^2 (float64), deterministic two-stage reduction; scratch >= 1024 doubles */
+int dppo_grad_sq_norm(const float* grad, int64_t n, double* scratch, double* out, dppo_stream_t stream);
+/* One AdamW step on a flat buffer.  If sq_norm != NULL the gradient is first scaled by
+ * min(1, max_norm / (sqrt(*sq_norm) + 1e-6)).  `step` counts from 1. */
+int dppo_adamw_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
+                    double lr, double beta1, double beta2, double eps, double weight_decay, const double* sq_norm,
+                    double max_norm, dppo_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPPO_HIP_H */

@@ -1,0 +1,94 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol the header declares,
+argument validation works without a GPU, and the product path refuses to run on CPU (no silent fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from dppo_amd import hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "dppo_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dppo_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = hip.load()
+    names = header_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"libdppo_hip.so does not export {n}"
+    assert sorted(hip.SYMBOLS) == names, "ctypes table and header disagree"
+    assert lib.dppo_version() == 1
+
+
+def hopper_desc():
+    return hip.NetDesc(kind=0, in_dim=39, hidden=512, n_blocks=1, out_dim=12, act=hip.ACT_RELU, time_dim=16,
+                       act_flat=12, cond_dim=11)
+
+
+def test_param_count_matches_reference_sizes():
+    lib = hip.load()
+    assert lib.dppo_net_param_count(C.byref(hopper_desc())) == 553020
+    critic = hip.NetDesc(kind=1, in_dim=11, hidden=256, n_blocks=1, out_dim=1, act=hip.ACT_MISH, time_dim=0,
+                         act_flat=0, cond_dim=11)
+    assert lib.dppo_net_param_count(C.byref(critic)) == 134913
+    for prec in (hip.PREC_F32, hip.PREC_BF16):
+        assert lib.dppo_packed_bytes(C.byref(hopper_desc()), prec, 20) > 553020
+        assert lib.dppo_ppo_workspace_bytes(C.byref(hopper_desc()), C.byref(critic), prec, 50000) > 0
+
+
+def test_bad_arguments_are_rejected_with_a_message():
+    lib = hip.load()
+    d = hopper_desc()
+    d.hidden = 100
+    assert lib.dppo_net_param_count(C.byref(d)) == -1
+    assert b"hidden" in lib.dppo_last_error()
+    d = hopper_desc()
+    d.in_dim = 40
+    assert lib.dppo_packed_bytes(C.byref(d), hip.PREC_BF16, 20) == -1
+    assert lib.dppo_packed_bytes(C.byref(hopper_desc()), 7, 20) == -1
+    assert lib.dppo_gae(None, None, None, None, 1, 1, 0.99, 0.95, 1.0, None, None, None, None, None) == -1
+
+
+def test_python_layout_matches_c_abi_and_reference_names():
+    from dppo_amd.model.common.critic import CriticObs
+    from dppo_amd.model.diffusion.mlp_diffusion import DiffusionMLP
+    a = DiffusionMLP(3, 4, 11, mlp_dims=[512, 512, 512], activation_type="ReLU", residual_style=True)
+    c = CriticObs(11, [256, 256, 256], residual_style=True)
+    assert list(dict(a.named_parameters())) == [
+        "time_embedding.1.weight", "time_embedding.1.bias", "time_embedding.3.weight", "time_embedding.3.bias",
+        "mlp_mean.layers.0.weight", "mlp_mean.layers.0.bias", "mlp_mean.layers.1.l1.weight",
+        "mlp_mean.layers.1.l1.bias", "mlp_mean.layers.1.l2.weight", "mlp_mean.layers.1.l2.bias",
+        "mlp_mean.layers.2.weight", "mlp_mean.layers.2.bias"]
+    assert list(dict(c.named_parameters()))[:2] == ["Q1.layers.0.weight", "Q1.layers.0.bias"]
+    lib = hip.load()
+    assert a.flat_params().numel() == lib.dppo_net_param_count(C.byref(a.net_desc()))
+    assert c.flat_params().numel() == lib.dppo_net_param_count(C.byref(c.net_desc()))
+    # parameters are views of the flat image, in state-dict order
+    f = a.flat_params()
+    off = 0
+    for p in a.parameters():
+        assert p.data_ptr() == f.data_ptr() + 4 * off
+        off += p.numel()
+
+
+def test_no_cpu_fallback():
+    from dppo_amd.model.common.critic import CriticObs
+    c = CriticObs(11, [256, 256, 256], residual_style=True)
+    with pytest.raises(hip.DppoHipError):
+        c({"state": torch.zeros(2, 1, 11)})
+
+
+def test_unsupported_variants_fail_loudly():
+    from dppo_amd.model.diffusion.mlp_diffusion import DiffusionMLP
+    with pytest.raises(NotImplementedError):
+        DiffusionMLP(3, 4, 11, mlp_dims=[512, 512, 512], residual_style=True, use_layernorm=True)
+    with pytest.raises(NotImplementedError):
+        DiffusionMLP(3, 4, 11, mlp_dims=[512, 512, 512], residual_style=True, cond_mlp_dims=[64, 16])
