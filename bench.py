@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""DPPO hot-path benchmark on MI355X: hopper-medium-v2 shapes, K=20 denoising steps, n_envs=512 per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input:
+  (a) one K=20 DDPM sampling call for 512 envs (obs -> action chunk + denoising chain), and
+  (b) one PPO minibatch update of 50,000 samples drawn from the device-resident rollout buffer: fused gather,
+      actor_ft + critic forward, loss, backward, [gradient all-reduce over ranks], AdamW on both networks and
+      re-packing of the updated weights for the next step.
+Both are timed over EXACTLY `steps` steps each, bracketed by barrier + torch.cuda.synchronize(), MAX over ranks.
+`value` is the headline the north star puts the target on -- PPO-update samples/s, whole job -- and the sampler's
+env-steps/s is reported beside it (BASELINE.json's metric names both).  Weak scaling: per-GPU load is fixed.
+
+Synthetic data (seed 42): random-init networks of the reference architecture, obs ~ U(-1,1),
+N(0,1) noise clipped at +-3, the rollout buffer is the sampler's own chains over 500 obs batches, rewards ~ N(0,1),
+terminated ~ Bernoulli(0.002), values from the random critic.
+
+The line also carries `roofline` (dominant kernel: the 128x128-tile bf16 MFMA GEMM on the 512x512 hidden layers,
+timed live with HIP events on its launch stream) and `cpu_baseline` (the CPU oracle = op-for-op restatement of the
+reference's PyTorch path, timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# hopper-medium-v2 ft_ppo_diffusion_mlp (reference cfg/gym/finetune/hopper-v2/ft_ppo_diffusion_mlp.yaml)
+OBS_DIM, ACT_DIM, TA, K, KFT, ACT_STEPS = 11, 3, 4, 20, 10, 4
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # MI355X_MICROARCH.md chip table (dense)
+FLOP_PER_SAMPLE = 4.11e6   # actor_ft 3 x 1.103 + critic 3 x 0.268 MFLOP
+FLOP_PER_CHUNK = 22.06e6   # 20 necessary network evaluations x 1.103 MFLOP
+
+
+def build_model(device, prec):
+    from dppo_amd.model.common.critic import CriticObs
+    from dppo_amd.model.diffusion.diffusion_ppo import PPODiffusion
+    from dppo_amd.model.diffusion.mlp_diffusion import DiffusionMLP
+    torch.manual_seed(42)
+    actor = DiffusionMLP(action_dim=ACT_DIM, horizon_steps=TA, cond_dim=OBS_DIM, time_dim=16,
+                         mlp_dims=[512, 512, 512], activation_type="ReLU", residual_style=True, precision=prec)
+    critic = CriticObs(cond_dim=OBS_DIM, mlp_dims=[256, 256, 256], activation_type="Mish", residual_style=True,
+                       precision=prec)
+    model = PPODiffusion(actor=actor, critic=critic, ft_denoising_steps=KFT, horizon_steps=TA, obs_dim=OBS_DIM,
+                         action_dim=ACT_DIM, denoising_steps=K, device=device, gamma_denoising=0.99,
+                         clip_ploss_coef=0.01, clip_ploss_coef_base=0.01, clip_ploss_coef_rate=3, randn_clip_value=3,
+                         min_sampling_denoising_std=0.1, min_logprob_denoising_std=0.1)
+    return model
+
+
+def make_rollout(model, n_envs, n_steps, device, gen):
+    """Device-resident rollout buffer produced by the sampler itself (R = n_steps * n_envs rows)."""
+    from dppo_amd.util.rollout import gae_device
+    AF = TA * ACT_DIM
+    R = n_steps * n_envs
+    obs = torch.empty(R, OBS_DIM, device=device)
+    chains = torch.empty(R, KFT + 1, AF, device=device)
+    for s in range(n_steps):
+        o = torch.rand(n_envs, 1, OBS_DIM, device=device, generator=gen) * 2 - 1
+        smp = model(cond={"state": o}, deterministic=False, return_chain=True)
+        obs[s * n_envs:(s + 1) * n_envs] = o.reshape(n_envs, -1)
+        chains[s * n_envs:(s + 1) * n_envs] = smp.chains.reshape(n_envs, KFT + 1, AF)
+    values = torch.empty(R, device=device)
+    logp = torch.empty(R, KFT, AF, device=device)
+    split = 20 * n_envs  # logprob_batch_size must be a multiple of n_envs (reference train_ppo_agent.py:22-25)
+    for lo in range(0, R, split):
+        hi = min(R, lo + split)
+        st = {"state": obs[lo:hi].reshape(hi - lo, 1, OBS_DIM)}
+        values[lo:hi] = model.critic(st).reshape(-1)
+        logp[lo:hi] = model.get_logprobs(st, chains[lo:hi].reshape(hi - lo, KFT + 1, TA, ACT_DIM)).reshape(
+            hi - lo, KFT, AF)
+    reward = torch.randn(n_steps, n_envs, device=device, generator=gen, dtype=torch.float64)
+    term = (torch.rand(n_steps, n_envs, device=device, generator=gen) < 0.002).float()
+    last_v = model.critic({"state": torch.rand(n_envs, 1, OBS_DIM, device=device, generator=gen) * 2 - 1}).reshape(-1)
+    _, _, adv, ret = gae_device(reward, values.reshape(n_steps, n_envs), term, last_v, 0.99, 0.95, 1.0)
+    return obs, chains, ret.reshape(-1).contiguous(), values, adv.reshape(-1).contiguous(), logp
+
+
+def cpu_baseline(n_envs, batch, budget_s=25.0):
+    """The CPU oracle (a validated op-for-op restatement of the reference's PyTorch path, incl. the discarded base-net
+    pass and the Python-list discount) on this box's host cores.  Bounded sample, see `sample` in the result."""
+    from oracle import dppo_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    a, c = O.named_specs("hopper")
+    cfg = O.DiffusionCfg(denoising_steps=K, ft_denoising_steps=KFT, horizon_steps=TA, action_dim=ACT_DIM,
+                         randn_clip_value=3, gamma_denoising=0.99, clip_ploss_coef=0.01, clip_ploss_coef_base=0.01)
+    base, ft, cr = O.init_params(a, 42), O.init_params(a, 43), O.init_params(c, 44)
+    rs = np.random.RandomState(42)
+    state = torch.from_numpy(rs.uniform(-1, 1, size=(n_envs, 1, OBS_DIM)).astype(np.float32))
+    noise = torch.from_numpy(rs.randn(K + 1, n_envs, TA, ACT_DIM).astype(np.float32))
+    O.sample_chain(cfg, a, base, ft, state, noise)  # warm-up
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        _, chains = O.sample_chain(cfg, a, base, ft, state, noise)
+        ts.append(time.perf_counter() - t0)
+    t_sample = float(np.median(ts))
+    # one PPO minibatch: loss forward + backward + 2 x AdamW (torch.optim, like the reference agent)
+    for p in list(ft.values()) + list(cr.values()):
+        p.requires_grad_(True)
+    opt_a = torch.optim.AdamW(list(ft.values()), lr=1e-4, weight_decay=0)
+    opt_c = torch.optim.AdamW(list(cr.values()), lr=1e-3, weight_decay=0)
+    reps = (batch + n_envs - 1) // n_envs
+    kinds = torch.from_numpy(rs.randint(0, KFT, size=(batch,)).astype(np.int64))
+    rows = torch.from_numpy(rs.randint(0, n_envs, size=(batch,)).astype(np.int64))
+    obs_b, prev, nxt = state[rows], chains[rows, kinds], chains[rows, kinds + 1]
+    with torch.no_grad():
+        oldlp = O.chain_logprob(cfg, a, base, ft, state, chains).reshape(n_envs, KFT, TA, ACT_DIM)[rows, kinds]
+    ret = torch.from_numpy(rs.normal(size=batch).astype(np.float32))
+    adv = torch.from_numpy(rs.normal(size=batch).astype(np.float32))
+    oldv = torch.zeros(batch)
+    tu, n_done, t_begin = [], 0, time.perf_counter()
+    while n_done < 3 and (n_done < 1 or time.perf_counter() - t_begin < budget_s):
+        t0 = time.perf_counter()
+        res = O.ppo_loss(cfg, a, c, base, ft, cr, obs_b, prev, nxt, kinds, ret, oldv, adv, oldlp)
+        opt_a.zero_grad()
+        opt_c.zero_grad()
+        (res[0] + 0.5 * res[2]).backward()
+        opt_a.step()
+        opt_c.step()
+        tu.append(time.perf_counter() - t0)
+        n_done += 1
+    t_update = float(np.median(tu))
+    return {"value": batch / t_update, "unit": "PPO-update samples/s", "cores": cores, "kind": "port",
+            "env_steps_per_sec": n_envs * ACT_STEPS / t_sample,
+            "sample": f"median of 5 sampling calls (B={n_envs}, K={K}) and of {n_done} minibatch updates "
+                      f"(N={batch}: loss fwd + bwd + 2x AdamW), torch {torch.__version__} CPU, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--prec", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--n-envs", type=int, default=512)
+    ap.add_argument("--n-steps", type=int, default=500, help="rollout length behind the update buffer")
+    ap.add_argument("--batch", type=int, default=50000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    from dppo_amd import hip
+    from dppo_amd.parallel import DataParallel
+    from dppo_amd.util.optim import FlatAdamW
+    lib = hip.load()
+
+    model = build_model(str(device), args.prec)  # same seed on every rank => identical initial weights
+    gen = torch.Generator(device=device).manual_seed(42 + rank)  # env shards differ per rank
+    torch.manual_seed(42 + rank)
+    dp = DataParallel(model, world)
+    obs_k, chains_k, ret_k, val_k, adv_k, logp_k = make_rollout(model, args.n_envs, args.n_steps, device, gen)
+    R = args.n_envs * args.n_steps
+    opt_a = FlatAdamW(model.actor_ft.flat_params(), lr=1e-4, weight_decay=0.0)
+    opt_c = FlatAdamW(model.critic.flat_params(), lr=1e-3, weight_decay=0.0)
+    n_total = args.steps + args.warmup
+    perm = torch.randperm(R * KFT, device=device, generator=gen)
+    n_mb = (R * KFT) // args.batch
+    minibatches = [perm[(i % n_mb) * args.batch:(i % n_mb + 1) * args.batch].contiguous() for i in range(n_total)]
+    moments = dp.minibatch_moments(adv_k, minibatches, KFT)  # ONE small collective for all steps (None if world == 1)
+    obs_batches = [torch.rand(args.n_envs, 1, OBS_DIM, device=device, generator=gen) * 2 - 1 for _ in range(4)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def update_step(i):
+        model.ppo_update(obs_k, chains_k, ret_k, val_k, adv_k, logp_k, minibatches[i], reward_horizon=ACT_STEPS,
+                         global_moments=None if moments is None else moments[i])
+        dp.allreduce_grads()  # one RCCL all-reduce of [actor grads | critic grads | stats]; no-op when world == 1
+        opt_a.step(model.actor_ft.flat_grads())
+        opt_c.step(model.critic.flat_grads())
+        model.actor_ft.mark_updated()
+        model.critic.mark_updated()
+        # re-pack so the next sampling / update call sees the new weights (part of the step's cost)
+        model.actor_ft.packed(model.prec, K)
+        model.critic.packed(model.prec, 0)
+
+    def sample_step(i):
+        return model(cond={"state": obs_batches[i % 4]}, deterministic=False, return_chain=True)
+
+    def timed(fn, probe=False):
+        for i in range(args.warmup):
+            fn(i)
+        barrier()
+        if probe:
+            hip.check(lib.dppo_probe_arm(8 * args.steps), "dppo_probe_arm")
+        t0 = time.perf_counter()
+        for i in range(args.warmup, n_total):
+            fn(i)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    dt_sample = timed(sample_step)
+    dt_update = timed(update_step, probe=(rank == 0))
+    probe = None
+    if rank == 0:
+        ms, cnt, fl = C.c_double(), C.c_int(), C.c_double()
+        hip.check(lib.dppo_probe_collect(C.byref(ms), C.byref(cnt), C.byref(fl)), "dppo_probe_collect")
+        if cnt.value > 0:
+            avg_ms = ms.value / cnt.value
+            tf = fl.value / cnt.value / (avg_ms * 1e-3) / 1e12
+            peak = MFMA_PEAK_TFLOPS[args.prec]
+            probe = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                     "traffic": None, "kernel": f"gemm_nt_kernel<{args.prec},128x128> M={args.batch} N=K=512",
+                     "avg_launch_ms": avg_ms, "launches": cnt.value}
+    stats = model._stats.tolist()
+    if rank == 0:
+        ms_update = dt_update / args.steps * 1e3
+        ms_sample = dt_sample / args.steps * 1e3
+        samples_per_s = args.batch * world / (dt_update / args.steps)
+        env_steps_per_s = args.n_envs * ACT_STEPS * world / (dt_sample / args.steps)
+        peak = MFMA_PEAK_TFLOPS[args.prec] * 1e12 * world
+        out = {
+            "metric": "PPO-update samples/sec (+ env-steps/sec of the K=20 sampler), hopper K=20 n_envs=512",
+            "value": samples_per_s, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_update, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.prec, "data": "synthetic",
+            "config": {"workload": "hopper-medium-v2 ft_ppo_diffusion_mlp K=20 Kft=10 Ta=4 (BASELINE configs[1])",
+                       "n_envs_per_gpu": args.n_envs, "minibatch_per_gpu": args.batch,
+                       "rollout_rows_per_gpu": R, "parallelism": f"dp{world} (env-sharded, RCCL grad all-reduce)"},
+            "env_steps_per_sec": env_steps_per_s, "sampler_ms_per_call": ms_sample,
+            "chunks_per_sec": args.n_envs * world / (dt_sample / args.steps),
+            "path_mfma_frac": {"update": samples_per_s * FLOP_PER_SAMPLE / peak,
+                               "sampler": args.n_envs * world / (dt_sample / args.steps) * FLOP_PER_CHUNK / peak},
+            "last_stats": {"pg_loss": stats[0], "v_loss": stats[1], "approx_kl": stats[2], "ratio": stats[4]},
+            "roofline": probe,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.n_envs, args.batch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

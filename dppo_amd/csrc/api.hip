@@ -665,3 +665,14 @@ int dppo_adamw_step(float* params, const float* grad, float* exp_avg, float* exp
   return check_launch();
 }
 
+
+// ---- measurement hook ----------------------------------------------------------------------------------
+int dppo_probe_arm(int max_launches) {
+  if (probe_arm(max_launches)) return fail(-1, "probe already armed or bad size");
+  return 0;
+}
+int dppo_probe_collect(double* total_ms_host, int* launches_host, double* flops_host) {
+  if (!total_ms_host || !launches_host || !flops_host) return fail(-1, "null pointer");
+  if (probe_collect(total_ms_host, launches_host, flops_host)) return fail(-1, "probe not armed / event error");
+  return 0;
+}

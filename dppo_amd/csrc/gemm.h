@@ -42,6 +42,12 @@ struct GemmTN {
 
 template <class P>
 void launch_gemm_nt(const GemmNT& a, hipStream_t s);
+
+// Measurement hook (bench.py's roofline): while armed, every 128x128-tile gemm_nt launch with N == Kp (the
+// H x H hidden layers: forward l1/l2 and both backward-data GEMMs) is bracketed by HIP events recorded on the
+// launch stream.  Process-wide, not thread-safe, off by default; never armed by the product path.
+int probe_arm(int max_launches);
+int probe_collect(double* total_ms, int* launches, double* flops);
 template <class P>
 void launch_gemm_tn(const GemmTN& a, hipStream_t s);
 

@@ -175,12 +175,50 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_nt_kernel(const GemmNT a) {
   }
 }
 
+struct Probe {
+  bool armed = false;
+  int cap = 0, used = 0;
+  hipEvent_t* ev = nullptr;  // 2 per launch
+  double flops = 0;
+};
+static Probe g_probe;
+int probe_arm(int max_launches) {
+  if (g_probe.armed || max_launches < 1) return -1;
+  g_probe.ev = new hipEvent_t[2 * max_launches];
+  for (int i = 0; i < 2 * max_launches; ++i)
+    if (hipEventCreate(&g_probe.ev[i]) != hipSuccess) return -1;
+  g_probe.cap = max_launches, g_probe.used = 0, g_probe.flops = 0, g_probe.armed = true;
+  return 0;
+}
+int probe_collect(double* total_ms, int* launches, double* flops) {
+  if (!g_probe.armed) return -1;
+  double tot = 0;
+  for (int i = 0; i < g_probe.used; ++i) {
+    float ms = 0;
+    if (hipEventSynchronize(g_probe.ev[2 * i + 1]) != hipSuccess) return -1;
+    if (hipEventElapsedTime(&ms, g_probe.ev[2 * i], g_probe.ev[2 * i + 1]) != hipSuccess) return -1;
+    tot += ms;
+  }
+  *total_ms = tot, *launches = g_probe.used, *flops = g_probe.flops;
+  for (int i = 0; i < 2 * g_probe.cap; ++i) (void)hipEventDestroy(g_probe.ev[i]);
+  delete[] g_probe.ev;
+  g_probe = Probe();
+  return 0;
+}
+
 template <class P, int WN, int WM, int TN, int TM>
 static void launch_nt_cfg(const GemmNT& a, hipStream_t s) {
   constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
   dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
   const size_t lds = 2 * (BN + BM) * 128;
+  const bool probe = g_probe.armed && BN == 128 && a.N == a.Kp && g_probe.used < g_probe.cap;
+  if (probe) (void)hipEventRecord(g_probe.ev[2 * g_probe.used], s);
   hipLaunchKernelGGL((gemm_nt_kernel<P, WN, WM, TN, TM>), grid, dim3(WN * WM * 64), lds, s, a);
+  if (probe) {
+    (void)hipEventRecord(g_probe.ev[2 * g_probe.used + 1], s);
+    g_probe.flops += 2.0 * a.M * a.N * a.Kp;
+    ++g_probe.used;
+  }
 }
 
 template <class P>

@@ -1,0 +1,70 @@
+"""A dependency-free vectorised environment with the interface the agent drives.
+
+The reference's env layer (env/gym_utils: AsyncVectorEnv + MultiStep + MuJoCo / Robomimic wrappers) stays on
+host CPU and is out of scope for this build; gym / mujoco / d4rl are not installed here.
+This stand-in exposes the same calls the agent makes -- ``reset_arg``, ``step`` on (n_envs, act_steps, act_dim)
+action chunks returning multi-step-summed rewards, ``seed`` -- over a stable linear system, so the training loop
+can be exercised end to end on synthetic data.
+"""
+import numpy as np
+
+
+class SyntheticVecEnv:
+    def __init__(self, n_envs, obs_dim, action_dim, n_obs_steps=1, n_action_steps=4, max_episode_steps=1000, seed=0):
+        self.n_envs, self.obs_dim, self.action_dim = n_envs, obs_dim, action_dim
+        self.n_obs_steps, self.n_action_steps, self.max_episode_steps = n_obs_steps, n_action_steps, max_episode_steps
+        rs = np.random.RandomState(1234)
+        q, _ = np.linalg.qr(rs.normal(size=(obs_dim, obs_dim)))
+        self.A = 0.97 * q
+        self.Bm = 0.2 * rs.normal(size=(obs_dim, action_dim))
+        self.seed([seed + i for i in range(n_envs)])
+        self.x = np.zeros((n_envs, obs_dim))
+        self.t = np.zeros(n_envs, dtype=np.int64)
+
+    def seed(self, seeds):
+        self.rngs = [np.random.RandomState(s) for s in seeds]
+
+    def _obs(self):
+        o = np.clip(self.x, -1, 1).astype(np.float32)
+        return {"state": np.repeat(o[:, None], self.n_obs_steps, axis=1)}
+
+    def _reset(self, i):
+        self.x[i] = self.rngs[i].uniform(-0.5, 0.5, size=self.obs_dim)
+        self.t[i] = 0
+
+    def reset_arg(self, options_list=None):
+        for i in range(self.n_envs):
+            self._reset(i)
+        return self._obs()
+
+    def step(self, action):
+        action = np.asarray(action, dtype=np.float64).reshape(self.n_envs, -1, self.action_dim)
+        reward = np.zeros(self.n_envs)
+        for s in range(action.shape[1]):
+            a = np.clip(action[:, s], -1, 1)
+            self.x = self.x @ self.A.T + a @ self.Bm.T
+            reward += -np.square(self.x).sum(-1) - 0.01 * np.square(a).sum(-1) + 1.0
+            self.t += 1
+        terminated = np.abs(self.x).max(-1) > 5.0
+        truncated = self.t >= self.max_episode_steps
+        for i in np.where(terminated | truncated)[0]:  # reset_within_step semantics of the reference MultiStep
+            self._reset(i)
+        return self._obs(), reward, terminated, truncated, [{} for _ in range(self.n_envs)]
+
+
+def make_venv(cfg):
+    """cfg.env.name == 'synthetic' -> SyntheticVecEnv; anything else needs the reference's env stack."""
+    env = cfg.env
+    if str(env.name).startswith("synthetic"):
+        return SyntheticVecEnv(env.n_envs, cfg.obs_dim, cfg.action_dim, cfg.cond_steps, cfg.act_steps,
+                               env.get("max_episode_steps", 1000), cfg.get("seed", 42))
+    try:  # the reference's un-namespaced import (agent/finetune/train_agent.py:16), if the user has that stack
+        from env.gym_utils import make_async
+    except ImportError as e:
+        raise ImportError(
+            f"environment {env.name!r} needs the reference's host-side env stack (gym, mujoco-py, d4rl / robomimic), "
+            "which is out of scope for dppo_amd and not installed here; pass a vectorised env to the agent "
+            "(venv=...) or use env.name=synthetic") from e
+    return make_async(env.name, env_type=env.get("env_type", None), num_envs=env.n_envs, asynchronous=True,
+                      max_episode_steps=env.max_episode_steps, wrappers=env.get("wrappers", None),
+                      obs_dim=cfg.obs_dim, action_dim=cfg.action_dim)

@@ -192,6 +192,14 @@ int dppo_adamw_step(float* params, const float* grad, float* exp_avg, float* exp
                     double lr, double beta1, double beta2, double eps, double weight_decay, const double* sq_norm,
                     double max_norm, dppo_stream_t stream);
 
+/* ---- measurement hook (bench.py only; process-wide, not thread-safe, off by default) ----------- */
+/* While armed, each launch of the dominant kernel -- the 128x128-tile MFMA gemm_nt on an H x H layer
+ * (forward l1/l2, backward-data) -- is bracketed by HIP events on its launch stream.  dppo_probe_collect
+ * waits for them, returns the summed kernel time, the launch count and the algorithmic FLOPs (2*M*N*K
+ * per launch), and disarms. */
+int dppo_probe_arm(int max_launches);
+int dppo_probe_collect(double* total_ms_host, int* launches_host, double* flops_host);
+
 #ifdef __cplusplus
 }
 #endif

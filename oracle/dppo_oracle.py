@@ -519,11 +519,15 @@ def ppo_loss(cfg: DiffusionCfg, aspec: NetSpec, cspec: NetSpec, base: Params, ft
              obs: torch.Tensor, chains_prev: torch.Tensor, chains_next: torch.Tensor,
              denoising_inds: torch.Tensor, returns: torch.Tensor, oldvalues: torch.Tensor,
              advantages: torch.Tensor, oldlogprobs: torch.Tensor, reward_horizon: int = 4,
-             python_list_discount: bool = True):
+             python_list_discount: bool = True, global_moments=None):
     """PPODiffusion.loss without the BC term, diffusion_ppo.py:57-199.
 
     Returns (pg_loss, entropy_loss, v_loss, clipfrac, approx_kl, ratio_mean, bc_loss(=0), eta_mean);
     the first three are tensors carrying grad when ``ft`` / ``critic`` require it.
+
+    ``global_moments = (sum adv, sum adv^2, count)`` of the GLOBAL minibatch switches to the data-parallel form
+    (new in this build): advantages are normalised with the pooled mean / unbiased std and every
+    mean becomes sum / global count, so that summing the per-rank results over ranks gives the single-process loss.
     """
     newlp, eta = logprob_subsample(cfg, aspec, base, ft, obs, chains_prev, chains_next, denoising_inds)
     entropy_loss = -eta.mean()
@@ -532,7 +536,14 @@ def ppo_loss(cfg: DiffusionCfg, aspec: NetSpec, cspec: NetSpec, base: Params, ft
     newlp = newlp.mean(dim=(-1, -2)).view(-1)
     oldlp = oldlp.mean(dim=(-1, -2)).view(-1)
     adv = advantages
-    if cfg.norm_adv:
+    n_glob = float(advantages.numel())
+    if global_moments is not None:
+        g_sum, g_sq, n_glob = (float(v) for v in global_moments)
+        g_mean = g_sum / n_glob
+        g_std = math.sqrt(max((g_sq - n_glob * g_mean * g_mean) / (n_glob - 1.0), 0.0))
+        if cfg.norm_adv:
+            adv = (adv - float(np.float32(g_mean))) / (float(np.float32(g_std)) + 1e-8)
+    elif cfg.norm_adv:
         adv = (adv - adv.mean()) / (adv.std() + 1e-8)
     lo = torch.quantile(adv, cfg.clip_advantage_lower_quantile)
     hi = torch.quantile(adv, cfg.clip_advantage_upper_quantile)
@@ -547,17 +558,18 @@ def ppo_loss(cfg: DiffusionCfg, aspec: NetSpec, cspec: NetSpec, base: Params, ft
     logratio = newlp - oldlp
     ratio = logratio.exp()
     eps_k = clip_coef_schedule(cfg, denoising_inds)
+    mean_ = (lambda x: x.mean()) if global_moments is None else (lambda x: x.sum() / n_glob)
     with torch.no_grad():
-        approx_kl = ((ratio - 1) - logratio).mean()
-        clipfrac = ((ratio - 1.0).abs() > eps_k).float().mean().item()
-    pg = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1 - eps_k, 1 + eps_k)).mean()
+        approx_kl = mean_((ratio - 1) - logratio)
+        clipfrac = mean_(((ratio - 1.0).abs() > eps_k).float()).item()
+    pg = mean_(torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1 - eps_k, 1 + eps_k)))
     newv = critic_forward(critic, cspec, obs).view(-1)
     if cfg.clip_vloss_coef is not None:
         vcl = oldvalues + torch.clamp(newv - oldvalues, -cfg.clip_vloss_coef, cfg.clip_vloss_coef)
-        v_loss = 0.5 * torch.max((newv - returns) ** 2, (vcl - returns) ** 2).mean()
+        v_loss = 0.5 * mean_(torch.max((newv - returns) ** 2, (vcl - returns) ** 2))
     else:
-        v_loss = 0.5 * ((newv - returns) ** 2).mean()
-    return (pg, entropy_loss, v_loss, clipfrac, approx_kl.item(), ratio.mean().item(), 0, eta.mean().item())
+        v_loss = 0.5 * mean_((newv - returns) ** 2)
+    return (pg, entropy_loss, v_loss, clipfrac, approx_kl.item(), mean_(ratio).item(), 0, eta.mean().item())
 
 
 # --------------------------------------------------------------------------

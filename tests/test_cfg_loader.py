@@ -1,0 +1,94 @@
+"""The YAML surface: a cfg written in the reference's style (same keys as
+cfg/gym/finetune/hopper-v2/ft_ppo_diffusion_mlp.yaml, typed in here -- not a copy of the file) resolves and
+instantiates the dppo_amd classes through `_target_` strings that still name the reference package."""
+import os
+import textwrap
+
+import pytest
+
+from dppo_amd.cfg.loader import get_class, instantiate, load_config
+
+YAML = textwrap.dedent("""
+    defaults:
+      - _self_
+    _target_: dppo.agent.finetune.train_ppo_diffusion_agent.TrainPPODiffusionAgent
+    name: ${env_name}_ppo_diffusion_mlp_ta${horizon_steps}_td${denoising_steps}_tdf${ft_denoising_steps}
+    logdir: ${oc.env:DPPO_LOG_DIR}/gym-finetune/${name}/${now:%Y-%m-%d}_${seed}
+    seed: 42
+    device: cuda:0
+    env_name: hopper-medium-v2
+    obs_dim: 11
+    action_dim: 3
+    denoising_steps: 20
+    ft_denoising_steps: 10
+    cond_steps: 1
+    horizon_steps: 4
+    act_steps: 4
+    train:
+      n_steps: 500
+      batch_size: 50000
+      actor_lr: 1e-4
+    model:
+      _target_: dppo.model.diffusion.diffusion_ppo.PPODiffusion
+      gamma_denoising: 0.99
+      clip_ploss_coef: 0.01
+      randn_clip_value: 3
+      network_path: null
+      actor:
+        _target_: dppo.model.diffusion.mlp_diffusion.DiffusionMLP
+        time_dim: 16
+        mlp_dims: [512, 512, 512]
+        activation_type: ReLU
+        residual_style: True
+        cond_dim: ${eval:'${obs_dim} * ${cond_steps}'}
+        horizon_steps: ${horizon_steps}
+        action_dim: ${action_dim}
+      critic:
+        _target_: dppo.model.common.critic.CriticObs
+        cond_dim: ${eval:'${obs_dim} * ${cond_steps}'}
+        mlp_dims: [256, 256, 256]
+        activation_type: Mish
+        residual_style: True
+      ft_denoising_steps: ${ft_denoising_steps}
+      horizon_steps: ${horizon_steps}
+      obs_dim: ${obs_dim}
+      action_dim: ${action_dim}
+      denoising_steps: ${denoising_steps}
+      device: ${device}
+""")
+
+
+def test_resolve_and_override(tmp_path, monkeypatch):
+    monkeypatch.setenv("DPPO_LOG_DIR", "/tmp/logs")
+    p = tmp_path / "cfg.yaml"
+    p.write_text(YAML)
+    cfg = load_config(str(p), overrides=["train.n_steps=7", "device=cpu", "cond_steps=2"])
+    assert cfg.name == "hopper-medium-v2_ppo_diffusion_mlp_ta4_td20_tdf10"
+    assert cfg.logdir.startswith("/tmp/logs/gym-finetune/hopper-medium-v2_ppo") and cfg.logdir.endswith("_42")
+    assert cfg.train.n_steps == 7 and cfg.train.get("gae_lambda", 0.95) == 0.95
+    assert cfg.model.actor.cond_dim == 22 and isinstance(cfg.model.actor.cond_dim, int)
+    assert cfg.train.actor_lr == pytest.approx(1e-4)
+    assert cfg.model.network_path is None
+
+
+def test_missing_env_var_is_an_error(tmp_path, monkeypatch):
+    monkeypatch.delenv("DPPO_LOG_DIR", raising=False)
+    p = tmp_path / "cfg.yaml"
+    p.write_text(YAML)
+    with pytest.raises(KeyError):
+        load_config(str(p))
+
+
+def test_targets_map_onto_this_package(tmp_path, monkeypatch):
+    monkeypatch.setenv("DPPO_LOG_DIR", "/tmp/logs")
+    p = tmp_path / "cfg.yaml"
+    p.write_text(YAML)
+    cfg = load_config(str(p), overrides=["device=cpu"])
+    model = instantiate(cfg.model)  # parameters only; no kernel runs on CPU
+    from dppo_amd.model.diffusion.diffusion_ppo import PPODiffusion
+    assert isinstance(model, PPODiffusion)
+    assert sum(p.numel() for p in model.actor_ft.parameters()) == 553020
+    keys = list(model.state_dict())
+    assert keys[0] == "network.time_embedding.1.weight" and "actor_ft.mlp_mean.layers.1.l2.bias" in keys
+    assert "critic.Q1.layers.2.weight" in keys
+    assert get_class(cfg._target_).__name__ == "TrainPPODiffusionAgent"
