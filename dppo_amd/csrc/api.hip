@@ -331,9 +331,11 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
     g.M = (int)M, g.N = td, g.Kp = H, g.ldx = H, g.ldw = H;
     g.X = B.dh, g.W = pk + L.W0tT, g.out_f32 = B.dtemb, g.ldo32 = L.tdp;
     launch_gemm_nt<P>(g, s);
-    launch_temb_segsum(B.dtemb, L.tdp, krow, M, Kft, td, B.part, REDUCE_BLOCKS, s);
-    float* G = B.part + (size_t)REDUCE_BLOCKS * Kft * td;
-    launch_slab_reduce(B.part, REDUCE_BLOCKS, (size_t)Kft * td, G, 1.f, s);
+    int sblocks = (int)(B.part_floats / ((size_t)Kft * td)) - 1;  // partial[sblocks][Kft*td] + G[Kft*td] must fit
+    sblocks = sblocks > REDUCE_BLOCKS ? REDUCE_BLOCKS : (sblocks < 1 ? 1 : sblocks);
+    launch_temb_segsum(B.dtemb, L.tdp, krow, M, Kft, td, B.part, sblocks, s);
+    float* G = B.part + (size_t)sblocks * Kft * td;
+    launch_slab_reduce(B.part, sblocks, (size_t)Kft * td, G, 1.f, s);
     launch_time_backward(prm + pl.te1_w, prm + pl.te1_b, prm + pl.te2_w, G, ksteps, Kft, td, grad + pl.te1_w,
                          grad + pl.te1_b, grad + pl.te2_w, grad + pl.te2_b, s);
   }
@@ -637,6 +639,7 @@ int dppo_ppo_loss_fwd_bwd(const dppo_net_desc* actor, const dppo_net_desc* criti
   if ((inds == nullptr) == (kinds == nullptr)) return fail(-1, "pass exactly one of inds (rollout mode) / kinds (gathered mode)");
   if (N < 2 || N > 0x7fffffff) return fail(-1, "N out of range");
   if (pcfg->ft_denoising_steps < 1 || pcfg->ft_denoising_steps > 1024) return fail(-1, "Kft out of range");
+  if ((int64_t)pcfg->ft_denoising_steps * actor->time_dim > 65536) return fail(-1, "Kft * time_dim too large");
   if (pcfg->horizon_steps * pcfg->action_dim != actor->act_flat) return fail(-1, "Ta*Da != act_flat");
   if (pcfg->reward_horizon < 1) return fail(-1, "reward_horizon must be >= 1");
 #define CALL(P)                                                                                                        \

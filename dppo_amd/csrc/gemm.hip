@@ -211,6 +211,14 @@ static void launch_nt_cfg(const GemmNT& a, hipStream_t s) {
   constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
   dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
   const size_t lds = 2 * (BN + BM) * 128;
+  if constexpr (2 * (BN + BM) * 128 > 65536) {  // the 16 x 256 tile needs 68 KiB: raise the dynamic-LDS cap once
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<P, WN, WM, TN, TM>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+  }
   const bool probe = g_probe.armed && BN == 128 && a.N == a.Kp && g_probe.used < g_probe.cap;
   if (probe) (void)hipEventRecord(g_probe.ev[2 * g_probe.used], s);
   hipLaunchKernelGGL((gemm_nt_kernel<P, WN, WM, TN, TM>), grid, dim3(WN * WM * 64), lds, s, a);
