@@ -14,7 +14,9 @@ namespace dppo {
 // LDS weight row q is NOT feature feat0+q: rows are permuted so that MFMA output row i = 4g+e of
 // tile tn is feature 4*TN*g + 4*tn + e of the wave's slice, which gives each lane 4*TN consecutive
 // features of one batch row in its accumulators.
-template <class P, int WN, int WM, int TN, int TM>
+// TAG only names the instantiation: TAG = 1 is used for the square hidden layers (N == Kp: forward l1 / l2 and both
+// backward-data GEMMs), so that profiles list the dominant launches under their own symbol.
+template <class P, int WN, int WM, int TN, int TM, int TAG>
 __global__ __launch_bounds__(WN* WM * 64) void gemm_nt_kernel(const GemmNT a) {
   typedef typename P::elem_t E;
   constexpr int BN = WN * TN * 16, BM = WM * TM * 16, T = WN * WM * 64, ES = P::ESIZE;
@@ -206,7 +208,7 @@ int probe_collect(double* total_ms, int* launches, double* flops) {
   return 0;
 }
 
-template <class P, int WN, int WM, int TN, int TM>
+template <class P, int WN, int WM, int TN, int TM, int TAG>
 static void launch_nt_cfg(const GemmNT& a, hipStream_t s) {
   constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
   dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
@@ -214,14 +216,14 @@ static void launch_nt_cfg(const GemmNT& a, hipStream_t s) {
   if constexpr (2 * (BN + BM) * 128 > 65536) {  // the 16 x 256 tile needs 68 KiB: raise the dynamic-LDS cap once
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<P, WN, WM, TN, TM>,
+      (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<P, WN, WM, TN, TM, TAG>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_set = true;
     }
   }
-  const bool probe = g_probe.armed && BN == 128 && a.N == a.Kp && g_probe.used < g_probe.cap;
+  const bool probe = g_probe.armed && TAG == 1 && g_probe.used < g_probe.cap;
   if (probe) (void)hipEventRecord(g_probe.ev[2 * g_probe.used], s);
-  hipLaunchKernelGGL((gemm_nt_kernel<P, WN, WM, TN, TM>), grid, dim3(WN * WM * 64), lds, s, a);
+  hipLaunchKernelGGL((gemm_nt_kernel<P, WN, WM, TN, TM, TAG>), grid, dim3(WN * WM * 64), lds, s, a);
   if (probe) {
     (void)hipEventRecord(g_probe.ev[2 * g_probe.used + 1], s);
     g_probe.flops += 2.0 * a.M * a.N * a.Kp;
@@ -233,11 +235,13 @@ template <class P>
 void launch_gemm_nt(const GemmNT& a, hipStream_t s) {
   if (a.M <= 0) return;
   if (a.N <= 16)
-    launch_nt_cfg<P, 1, 4, 1, 4>(a, s);  // 16 features x 256 rows
+    launch_nt_cfg<P, 1, 4, 1, 4, 0>(a, s);  // 16 features x 256 rows
   else if (a.N <= 64)
-    launch_nt_cfg<P, 1, 4, 4, 2>(a, s);  // 64 x 128
+    launch_nt_cfg<P, 1, 4, 4, 2, 0>(a, s);  // 64 x 128
+  else if (a.N == a.Kp)
+    launch_nt_cfg<P, 2, 2, 4, 4, 1>(a, s);  // 128 x 128, square hidden layer (the dominant launches)
   else
-    launch_nt_cfg<P, 2, 2, 4, 4>(a, s);  // 128 x 128
+    launch_nt_cfg<P, 2, 2, 4, 4, 0>(a, s);  // 128 x 128
 }
 template void launch_gemm_nt<F32>(const GemmNT&, hipStream_t);
 template void launch_gemm_nt<BF16>(const GemmNT&, hipStream_t);
