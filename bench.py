@@ -87,11 +87,24 @@ def make_rollout(model, n_envs, n_steps, device, gen):
     return obs, chains, ret.reshape(-1).contiguous(), values, adv.reshape(-1).contiguous(), logp
 
 
+def usable_cores():
+    """CPU threads this process may really use: cgroup quota if set, else the affinity mask (os.cpu_count() reports
+    the whole host, which oversubscribes a container that owns a slice of it)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, 64)
+
+
 def cpu_baseline(n_envs, batch, budget_s=25.0):
     """The CPU oracle (a validated op-for-op restatement of the reference's PyTorch path, incl. the discarded base-net
     pass and the Python-list discount) on this box's host cores.  Bounded sample, see `sample` in the result."""
     from oracle import dppo_oracle as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     a, c = O.named_specs("hopper")
     cfg = O.DiffusionCfg(denoising_steps=K, ft_denoising_steps=KFT, horizon_steps=TA, action_dim=ACT_DIM,

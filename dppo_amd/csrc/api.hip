@@ -679,3 +679,46 @@ int dppo_probe_collect(double* total_ms_host, int* launches_host, double* flops_
   if (probe_collect(total_ms_host, launches_host, flops_host)) return fail(-1, "probe not armed / event error");
   return 0;
 }
+
+// ---- tuning / micro-benchmark hooks -------------------------------------------------------------------
+int dppo_tune_set(int knob, int value) {
+  if (knob == 0) {
+    set_gemm_nt_variant(value);
+    return 0;
+  }
+  return fail(-1, "unknown tuning knob %d", knob);
+}
+
+int dppo_gemm_nt_raw(int prec, const void* X, const void* W, const float* bias, int64_t M, int N, int Kp, float* out_f32,
+                     void* out_elem, int ldo, int act, dppo_stream_t stream) {
+  if (int e = check_prec(prec)) return e;
+  if (!X || !W || M < 1 || M > 0x7fffffff || N < 1) return fail(-1, "bad argument");
+  const int es = prec == DPPO_PREC_F32 ? 4 : 2;
+  if (Kp < 1 || (Kp * es) % 128) return fail(-1, "Kp must be a multiple of %d", 128 / es);
+  if (ldo < ((N + 15) & ~15)) return fail(-1, "ldo too small");
+  GemmNT g;
+  memset(&g, 0, sizeof(g));
+  g.X = X, g.W = W, g.bias = bias, g.M = (int)M, g.N = N, g.Kp = Kp, g.ldx = Kp, g.ldw = Kp;
+  g.out_f32 = out_f32, g.ldo32 = ldo, g.out_act = out_elem, g.ldo = ldo, g.act = act;
+  if (prec == DPPO_PREC_F32)
+    launch_gemm_nt<F32>(g, (hipStream_t)stream);
+  else
+    launch_gemm_nt<BF16>(g, (hipStream_t)stream);
+  return check_launch();
+}
+
+int dppo_gemm_tn_raw(int prec, const void* A, int lda, int N1, const void* B, int ldb, int N2, int64_t M,
+                     int rows_per_split, float* slab, float* C, dppo_stream_t stream) {
+  if (int e = check_prec(prec)) return e;
+  if (!A || !B || !slab || !C || M < 1 || M > 0x7fffffff || N1 < 1 || N2 < 1) return fail(-1, "bad argument");
+  if (rows_per_split < 64 || rows_per_split % 64) return fail(-1, "rows_per_split must be a multiple of 64");
+  GemmTN t;
+  t.A = A, t.B = B, t.M = (int)M, t.N1 = N1, t.N2 = N2, t.lda = lda, t.ldb = ldb, t.slab = slab, t.ldc = N2;
+  t.rows_per_split = rows_per_split, t.splits = (int)((M + rows_per_split - 1) / rows_per_split);
+  if (prec == DPPO_PREC_F32)
+    launch_gemm_tn<F32>(t, (hipStream_t)stream);
+  else
+    launch_gemm_tn<BF16>(t, (hipStream_t)stream);
+  launch_slab_reduce_2d(slab, t.splits, N1, N2, N2, C, N2, 1.f, (hipStream_t)stream);
+  return check_launch();
+}

@@ -46,6 +46,7 @@ void launch_gemm_nt(const GemmNT& a, hipStream_t s);
 // Measurement hook (bench.py's roofline): while armed, every 128x128-tile gemm_nt launch with N == Kp (the
 // H x H hidden layers: forward l1/l2 and both backward-data GEMMs) is bracketed by HIP events recorded on the
 // launch stream.  Process-wide, not thread-safe, off by default; never armed by the product path.
+void set_gemm_nt_variant(int v);  // 0 register staging, 1 LDS-DMA staging where legal (default)
 int probe_arm(int max_launches);
 int probe_collect(double* total_ms, int* launches, double* flops);
 template <class P>

@@ -16,7 +16,11 @@ namespace dppo {
 // features of one batch row in its accumulators.
 // TAG only names the instantiation: TAG = 1 is used for the square hidden layers (N == Kp: forward l1 / l2 and both
 // backward-data GEMMs), so that profiles list the dominant launches under their own symbol.
-template <class P, int WN, int WM, int TN, int TM, int TAG>
+// DMA = 1 stages both operands with global_load_lds (LDS-DMA, 16 B per lane, no VGPR round trip).  The LDS write
+// of a wave instruction is wave-uniform base + lane * 16, i.e. linear, so the XOR swizzle moves to the per-lane
+// SOURCE address: LDS chunk position p of tile row q receives source chunk p ^ (q & 7) (the involution the
+// fragment reads apply).  Needs every weight row of the tile to exist (N % BN == 0: no zero fill in a DMA).
+template <class P, int WN, int WM, int TN, int TM, int TAG, int DMA>
 __global__ __launch_bounds__(WN* WM * 64) void gemm_nt_kernel(const GemmNT a) {
   typedef typename P::elem_t E;
   constexpr int BN = WN * TN * 16, BM = WM * TM * 16, T = WN * WM * 64, ES = P::ESIZE;
@@ -70,18 +74,51 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_nt_kernel(const GemmNT a) {
     }
   };
 
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  auto dma = [&](int kt, int st) {
+    char* Ws = smem + st * STAGE;
+    char* Xs = Ws + BN * 128;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int q = tid + i * T;  // LDS chunk slot: row q>>3, position q&7 (requires BN*8 % T == 0)
+      const int rho = q >> 3, c = (q & 7) ^ (rho & 7);
+      const int w_ = rho / (16 * TN), tn = (rho >> 4) % TN, ii = rho & 15;
+      const int feat = feat0 + w_ * 16 * TN + 4 * TN * (ii >> 2) + 4 * tn + (ii & 3);
+      __builtin_amdgcn_global_load_lds((glb_ptr)(Wb + (size_t)feat * a.ldw * ES + (size_t)kt * 128 + c * 16),
+                                       (lds_ptr)(Ws + (size_t)(i * T + (tid & ~63)) * 16), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int q = tid + i * T;
+      const int rr = q >> 3, c = (q & 7) ^ (rr & 7);
+      int row = row0 + rr;
+      row = row < a.M ? row : a.M - 1;
+      __builtin_amdgcn_global_load_lds((glb_ptr)(Xb + (size_t)row * a.ldx * ES + (size_t)kt * 128 + c * 16),
+                                       (lds_ptr)(Xs + (size_t)(i * T + (tid & ~63)) * 16), 16, 0, 0);
+    }
+  };
+
   f32x4 acc[TN][TM];
 #pragma unroll
   for (int i = 0; i < TN; ++i)
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  gload(0);
-  sstore(0);
-  __syncthreads();
+  if constexpr (DMA) {
+    dma(0, 0);
+  } else {
+    gload(0);
+    sstore(0);
+  }
+  __syncthreads();  // with an LDS-DMA outstanding the barrier's fence waits vmcnt(0): the stage has landed
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
+    if constexpr (DMA) {
+      if (kt + 1 < nk) dma(kt + 1, cur ^ 1);  // the other stage was last read before the previous barrier
+    } else {
+      if (kt + 1 < nk) gload(kt + 1);
+    }
     const char* Ws = smem + cur * STAGE;
     const char* Xs = Ws + BN * 128;
 #pragma unroll
@@ -102,7 +139,9 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_nt_kernel(const GemmNT a) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = P::mma(af[tn], bf[tm], acc[tn][tm]);
     }
-    if (kt + 1 < nk) sstore(cur ^ 1);
+    if constexpr (!DMA) {
+      if (kt + 1 < nk) sstore(cur ^ 1);
+    }
     __syncthreads();
   }
 
@@ -208,7 +247,10 @@ int probe_collect(double* total_ms, int* launches, double* flops) {
   return 0;
 }
 
-template <class P, int WN, int WM, int TN, int TM, int TAG>
+static int g_nt_variant = 1;  // 0 = register staging everywhere, 1 = LDS-DMA staging where legal (bench A/B knob)
+void set_gemm_nt_variant(int v) { g_nt_variant = v; }
+
+template <class P, int WN, int WM, int TN, int TM, int TAG, int DMA>
 static void launch_nt_cfg(const GemmNT& a, hipStream_t s) {
   constexpr int BN = WN * TN * 16, BM = WM * TM * 16;
   dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
@@ -216,14 +258,14 @@ static void launch_nt_cfg(const GemmNT& a, hipStream_t s) {
   if constexpr (2 * (BN + BM) * 128 > 65536) {  // the 16 x 256 tile needs 68 KiB: raise the dynamic-LDS cap once
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<P, WN, WM, TN, TM, TAG>,
+      (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<P, WN, WM, TN, TM, TAG, DMA>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_set = true;
     }
   }
   const bool probe = g_probe.armed && TAG == 1 && g_probe.used < g_probe.cap;
   if (probe) (void)hipEventRecord(g_probe.ev[2 * g_probe.used], s);
-  hipLaunchKernelGGL((gemm_nt_kernel<P, WN, WM, TN, TM, TAG>), grid, dim3(WN * WM * 64), lds, s, a);
+  hipLaunchKernelGGL((gemm_nt_kernel<P, WN, WM, TN, TM, TAG, DMA>), grid, dim3(WN * WM * 64), lds, s, a);
   if (probe) {
     (void)hipEventRecord(g_probe.ev[2 * g_probe.used + 1], s);
     g_probe.flops += 2.0 * a.M * a.N * a.Kp;
@@ -234,14 +276,19 @@ static void launch_nt_cfg(const GemmNT& a, hipStream_t s) {
 template <class P>
 void launch_gemm_nt(const GemmNT& a, hipStream_t s) {
   if (a.M <= 0) return;
+  const bool dma = g_nt_variant == 1 && a.N % 128 == 0;
   if (a.N <= 16)
-    launch_nt_cfg<P, 1, 4, 1, 4, 0>(a, s);  // 16 features x 256 rows
+    launch_nt_cfg<P, 1, 4, 1, 4, 0, 0>(a, s);  // 16 features x 256 rows
   else if (a.N <= 64)
-    launch_nt_cfg<P, 1, 4, 4, 2, 0>(a, s);  // 64 x 128
+    launch_nt_cfg<P, 1, 4, 4, 2, 0, 0>(a, s);  // 64 x 128
+  else if (a.N == a.Kp && dma)
+    launch_nt_cfg<P, 2, 2, 4, 4, 1, 1>(a, s);  // 128 x 128, square hidden layer (the dominant launches)
   else if (a.N == a.Kp)
-    launch_nt_cfg<P, 2, 2, 4, 4, 1>(a, s);  // 128 x 128, square hidden layer (the dominant launches)
+    launch_nt_cfg<P, 2, 2, 4, 4, 1, 0>(a, s);
+  else if (dma)
+    launch_nt_cfg<P, 2, 2, 4, 4, 0, 1>(a, s);  // 128 x 128
   else
-    launch_nt_cfg<P, 2, 2, 4, 4, 0>(a, s);  // 128 x 128
+    launch_nt_cfg<P, 2, 2, 4, 4, 0, 0>(a, s);
 }
 template void launch_gemm_nt<F32>(const GemmNT&, hipStream_t);
 template void launch_gemm_nt<BF16>(const GemmNT&, hipStream_t);
@@ -401,9 +448,15 @@ template void launch_gemm_tn<BF16>(const GemmTN&, hipStream_t);
 __global__ void slab_reduce_kernel(const float* slab, int splits, size_t n, float* out, float scale) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += slab[(size_t)k * n + i];
-  out[i] = s * scale;
+  // fixed summation tree (reproducible): 8 independent chains keep 8 loads in flight instead of one
+  float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 8 <= splits; k += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) p[u] += slab[(size_t)(k + u) * n + i];
+  }
+  for (; k < splits; ++k) p[k & 7] += slab[(size_t)k * n + i];
+  out[i] = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) * scale;
 }
 void launch_slab_reduce(const float* slab, int splits, size_t n, float* out, float scale, hipStream_t s) {
   if (n == 0) return;

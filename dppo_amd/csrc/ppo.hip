@@ -464,9 +464,14 @@ __global__ void slab_reduce_2d_kernel(const float* slab, int splits, int rows, i
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)rows * cols) return;
   const int r = (int)(i / cols), c = (int)(i % cols);
-  float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += slab[((size_t)k * rows + r) * lds + c];
-  out[(size_t)r * ldo + c] = s * scale;
+  float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 8 <= splits; k += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) p[u] += slab[((size_t)(k + u) * rows + r) * lds + c];
+  }
+  for (; k < splits; ++k) p[k & 7] += slab[((size_t)k * rows + r) * lds + c];
+  out[(size_t)r * ldo + c] = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) * scale;
 }
 void launch_slab_reduce_2d(const float* slab, int splits, int rows, int cols, int lds, float* out, int ldo,
                            float scale, hipStream_t s) {

@@ -200,6 +200,18 @@ int dppo_adamw_step(float* params, const float* grad, float* exp_avg, float* exp
 int dppo_probe_arm(int max_launches);
 int dppo_probe_collect(double* total_ms_host, int* launches_host, double* flops_host);
 
+/* ---- tuning / micro-benchmark hooks (tools/ and tests only; never used by the product path) ----- */
+/* knob 0: gemm_nt operand staging, 0 = through registers, 1 = global_load_lds (LDS-DMA, default) */
+int dppo_tune_set(int knob, int value);
+/* one bare layer GEMM: out[M][ldo] = act(X[M][Kp] . W[N][Kp]^T + bias) with elem = prec operands;
+ * out_f32 and/or out_elem may be NULL; ldo >= round_up(N,16) */
+int dppo_gemm_nt_raw(int prec, const void* X, const void* W, const float* bias, int64_t M, int N, int Kp,
+                     float* out_f32, void* out_elem, int ldo, int act, dppo_stream_t stream);
+/* one bare weight-gradient GEMM: C[N1][N2] = A[M][N1]^T . B[M][N2] (elem operands, leading dims lda/ldb);
+ * slab: scratch of at least splits*N1*N2 floats, splits = ceil(M / rows_per_split) */
+int dppo_gemm_tn_raw(int prec, const void* A, int lda, int N1, const void* B, int ldb, int N2, int64_t M,
+                     int rows_per_split, float* slab, float* C, dppo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
