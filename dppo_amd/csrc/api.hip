@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include "fused.h"
 #include "gemm.h"
 #include "ppo.h"
 #include "sampler.h"
@@ -60,7 +61,7 @@ static ParamLayout param_layout(const dppo_net_desc& d) {
 struct PackLayout {  // byte offsets into the packed image
   // every offset depends on (net, prec) only; the time table sits last so that only `total` grows with n_time
   size_t W0, W1[MAX_BLOCKS], W2[MAX_BLOCKS], Wout, W1T[MAX_BLOCKS], W2T[MAX_BLOCKS], WoutT, W0tT, sstream, ostream,
-      temb, total;
+      bstream, temb, total;
   int Kp0, Kpo, tdp;
 };
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -83,11 +84,13 @@ static PackLayout pack_layout(const dppo_net_desc& d, int n_time) {
   }
   L.Wout = o, o = al256(o + (size_t)d.out_dim * H * ES);
   L.WoutT = o, o = al256(o + (size_t)H * L.Kpo * ES);
-  if (d.kind == 0) {
-    L.W0tT = o, o = al256(o + (size_t)d.time_dim * H * ES);
+  if (d.kind == 0) L.W0tT = o, o = al256(o + (size_t)d.time_dim * H * ES);
+  {  // per-wave fragment streams: forward (sampler + fused forward), out layer, backward (fused backward)
     const SamplerGeom g = sampler_geom<P>(d);
+    const FusedGeom fg = fused_geom<P>(d);
     L.sstream = o, o = al256(o + (size_t)SAMPLER_WAVES * g.hidden_frags_per_wave * 64 * 16);
     L.ostream = o, o = al256(o + (size_t)SAMPLER_WAVES * g.out_frags_per_wave * 64 * 16);
+    L.bstream = o, o = al256(o + (size_t)SAMPLER_WAVES * fg.frags_per_wave * 64 * 16);
   }
   L.temb = o, o = al256(o + (size_t)n_time * (d.time_dim > 0 ? d.time_dim : 0) * 4);
   L.total = o;
@@ -140,9 +143,9 @@ static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char*
   launch_cast_pad<P>(prm + pl.Wout, d.out_dim, H, H, pk + L.Wout, H, s);
   // WoutT[h][o] = Wout[o][h] : src rows = out_dim, cols = H  -> dst [H][Kpo]
   launch_transpose_cast<P>(prm + pl.Wout, d.out_dim, H, H, 0, pk + L.WoutT, L.Kpo, s);
-  if (d.kind == 0) {
-    // W0tT[j][h] = W0[h][act_flat + j]
-    launch_transpose_cast<P>(prm + pl.W0, H, d.time_dim, d.in_dim, d.act_flat, pk + L.W0tT, H, s);
+  // W0tT[j][h] = W0[h][act_flat + j]
+  if (d.kind == 0) launch_transpose_cast<P>(prm + pl.W0, H, d.time_dim, d.in_dim, d.act_flat, pk + L.W0tT, H, s);
+  {
     const SamplerGeom g = sampler_geom<P>(d);
     u32x4* ss = (u32x4*)(pk + L.sstream);
     launch_pack_hidden<P>(prm + pl.W0, H, d.in_dim, d.in_dim, g.KS0, g.TPW, 0, g.total_pos, ss, s);
@@ -151,6 +154,15 @@ static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char*
       launch_pack_hidden<P>(prm + pl.l2w[b], H, H, H, g.KSH, g.TPW, g.KS0 + (2 * b + 1) * g.KSH, g.total_pos, ss, s);
     }
     launch_pack_out<P>(prm + pl.Wout, d.out_dim, H, g.OT, g.CNT, (u32x4*)(pk + L.ostream), s);
+    // backward stream, top down: [dh = d_out . Wout][block nb-1: W2^T, W1^T] ... [block 0: W2^T, W1^T];
+    // "feature f, contraction index k" of a transposed layer is W[k][f] = W[k*H + f]
+    const FusedGeom fg = fused_geom<P>(d);
+    u32x4* bs = (u32x4*)(pk + L.bstream);
+    launch_pack_hidden_strided<P>(prm + pl.Wout, 1, H, d.out_dim, fg.KSB0, g.TPW, 0, fg.total_pos, bs, s);
+    for (int b = d.n_blocks - 1, pos = fg.KSB0; b >= 0; --b, pos += 2 * g.KSH) {
+      launch_pack_hidden_strided<P>(prm + pl.l2w[b], 1, H, H, g.KSH, g.TPW, pos, fg.total_pos, bs, s);
+      launch_pack_hidden_strided<P>(prm + pl.l1w[b], 1, H, H, g.KSH, g.TPW, pos + g.KSH, fg.total_pos, bs, s);
+    }
   }
   return check_launch();
 }
@@ -176,6 +188,7 @@ struct MlpBufs {  // activations of one network for M rows
   void* a1[MAX_BLOCKS];        // act(h[b])
   void* z1[MAX_BLOCKS];        // l1 pre-activation (elem)
   void* a2[MAX_BLOCKS];        // act(z1)
+  void* hpre[MAX_BLOCKS + 1];  // elem(h[b]); hpre[nb] = hE (out-layer input)
   void* hE;                    // elem(h[nb])
   float* out;                  // [M][ldout] f32
   int ldout;
@@ -184,6 +197,10 @@ struct MlpBufs {  // activations of one network for M rows
   void* dh;     // [M][H] elem
   void* dz1;    // [M][H] elem
   float* dtemb; // [M][tdp] f32 (actor)
+  void* dh_all[MAX_BLOCKS + 1];  // fused backward: dh[b] = d loss / d h_b, elem [M][H]
+  void* dz1_all[MAX_BLOCKS];
+  float* tile_colsum;            // [(2nb+1)][tiles][H]
+  int tiles;
   float* slab;  // split-M partial weight gradients
   float* part;  // column-sum / segment-sum partials
   size_t slab_floats, part_floats;
@@ -214,12 +231,21 @@ static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, b
     B.z1[b] = keep ? c.take((size_t)M * H * ES) : nullptr;
   }
   B.hE = c.take((size_t)M * H * ES);
+  for (int b = 0; b <= nb; ++b) B.hpre[b] = b == nb ? B.hE : (keep ? c.take((size_t)M * H * ES) : nullptr);
   B.ldout = round_up(d.out_dim, 16);
   B.out = (float*)c.take((size_t)M * B.ldout * 4);
   if (bwd) {
     B.d_out = c.take((size_t)M * Kpo * ES);
     B.dh = c.take((size_t)M * H * ES);
     B.dz1 = c.take((size_t)M * H * ES);
+    B.dh_all[nb] = B.dh;
+    for (int b = 0; b < nb; ++b) {
+      B.dh_all[b] = c.take((size_t)M * H * ES);
+      B.dz1_all[b] = b == 0 ? B.dz1 : c.take((size_t)M * H * ES);
+    }
+    const int mt = fused_rows_per_tile<P>(d);
+    B.tiles = mt > 0 ? (int)((M + mt - 1) / mt) : 0;
+    B.tile_colsum = (float*)c.take((size_t)(2 * nb + 1) * (B.tiles > 0 ? B.tiles : 1) * H * 4);
     const int tdp = round_up(d.time_dim > 0 ? d.time_dim : 1, 16);
     B.dtemb = d.kind == 0 ? (float*)c.take((size_t)M * tdp * 4) : nullptr;
     // largest slab: H x max(H, Kp0) with up to 64 splits of a <=4-tile output, or 16+ splits of H x H
@@ -234,11 +260,40 @@ static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, b
   }
 }
 
+static int g_use_fused = 1;  // tuning knob 1: 1 = fused row-tile kernels where the shape is covered, 0 = layered GEMMs
+
+static void fill_bias_off(const dppo_net_desc& d, const ParamLayout& pl, int* off) {
+  off[0] = (int)pl.b0;
+  for (int b = 0; b < d.n_blocks; ++b) off[1 + 2 * b] = (int)pl.l1b[b], off[2 + 2 * b] = (int)pl.l2b[b];
+  off[1 + 2 * d.n_blocks] = (int)pl.bout;
+}
+
+template <class P>
+static bool fused_ok(const dppo_net_desc& d) {
+  return g_use_fused && fused_rows_per_tile<P>(d) > 0 && d.out_dim <= 64 && d.hidden <= 512;
+}
+
 template <class P>
 static void mlp_forward(const dppo_net_desc& d, const float* prm, const char* pk, const PackLayout& L, int64_t M,
                         MlpBufs<P>& B, bool keep, hipStream_t s) {
   const ParamLayout pl = param_layout(d);
   const int H = d.hidden, nb = d.n_blocks;
+  if (fused_ok<P>(d)) {
+    FusedFwdArgs f;
+    memset(&f, 0, sizeof(f));
+    f.wstream = (const u32x4*)(pk + L.sstream), f.ostream = (const u32x4*)(pk + L.ostream), f.params = prm;
+    fill_bias_off(d, pl, f.bias_off);
+    f.in = B.in, f.ld_in = L.Kp0, f.M = (int)M, f.Kp0 = sampler_geom<P>(d).Kp0, f.nb = nb, f.act = d.act;
+    f.out_dim = d.out_dim, f.out = B.out, f.ldout = B.ldout;
+    if (keep) {
+      for (int b = 0; b < nb; ++b) {
+        f.a1[b] = B.a1[b], f.a2[b] = B.a2[b];
+        if (d.act != DPPO_ACT_RELU) f.z1[b] = B.z1[b], f.hpre[b] = B.hpre[b];  // Mish' needs the pre-activations
+      }
+      f.hpre[nb] = B.hE;
+    }
+    if (launch_fused_forward<P>(d, f, s) == 0) return;
+  }
   GemmNT g;
   memset(&g, 0, sizeof(g));
   g.M = (int)M;
@@ -286,6 +341,27 @@ static void weight_grad(const void* A, int lda, int N1, const void* Bm, int ldb,
   launch_slab_reduce_2d(B.slab, (int)splits, N1, N2, N2, gw, ldgw, 1.f, s);
 }
 
+// d temb = dh0 . W0[:, temb columns]; summed per fine-tuned step; back through the tiny time MLP
+template <class P>
+static void time_embedding_grad(const dppo_net_desc& d, const float* prm, const char* pk, const PackLayout& L, int64_t M,
+                                MlpBufs<P>& B, const void* dh0, float* grad, const int32_t* krow, const dppo_step* ksteps,
+                                int Kft, hipStream_t s) {
+  const ParamLayout pl = param_layout(d);
+  const int H = d.hidden, td = d.time_dim;
+  GemmNT g;
+  memset(&g, 0, sizeof(g));
+  g.M = (int)M, g.N = td, g.Kp = H, g.ldx = H, g.ldw = H;
+  g.X = dh0, g.W = pk + L.W0tT, g.out_f32 = B.dtemb, g.ldo32 = L.tdp;
+  launch_gemm_nt<P>(g, s);
+  int sblocks = (int)(B.part_floats / ((size_t)Kft * td)) - 1;  // partial[sblocks][Kft*td] + G[Kft*td] must fit
+  sblocks = sblocks > REDUCE_BLOCKS ? REDUCE_BLOCKS : (sblocks < 1 ? 1 : sblocks);
+  launch_temb_segsum(B.dtemb, L.tdp, krow, M, Kft, td, B.part, sblocks, s);
+  float* G = B.part + (size_t)sblocks * Kft * td;
+  launch_slab_reduce(B.part, sblocks, (size_t)Kft * td, G, 1.f, s);
+  launch_time_backward(prm + pl.te1_w, prm + pl.te1_b, prm + pl.te2_w, G, ksteps, Kft, td, grad + pl.te1_w,
+                       grad + pl.te1_b, grad + pl.te2_w, grad + pl.te2_b, s);
+}
+
 // d_out (B.d_out, [M][Kpo] elem) -> gradients of every parameter of the network into `grad`
 template <class P>
 static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* pk, const PackLayout& L, int64_t M,
@@ -293,6 +369,37 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
                          hipStream_t s) {
   const ParamLayout pl = param_layout(d);
   const int H = d.hidden, nb = d.n_blocks;
+  if (fused_ok<P>(d) && B.tiles > 0) {
+    // one kernel produces every data gradient (dh[nb..0], dz1[..]) and their per-tile column sums
+    FusedBwdArgs f;
+    memset(&f, 0, sizeof(f));
+    const FusedGeom fg = fused_geom<P>(d);
+    f.bstream = (const u32x4*)(pk + L.bstream), f.d_out = B.d_out, f.ld_dout = L.Kpo, f.M = (int)M, f.KpB0 = fg.KpB0;
+    f.nb = nb, f.act = d.act, f.colsum = B.tile_colsum;
+    const bool relu = d.act == DPPO_ACT_RELU;
+    for (int b = 0; b < nb; ++b) {
+      f.m1[b] = relu ? B.a2[b] : B.z1[b];
+      f.m0[b] = relu ? B.a1[b] : B.hpre[b];
+      f.dz1[b] = B.dz1_all[b];
+    }
+    for (int b = 0; b <= nb; ++b) f.dh[b] = B.dh_all[b];
+    if (launch_fused_backward<P>(d, f, s) == 0) {
+      const size_t tsz = (size_t)B.tiles * H;
+      auto bias_grad = [&](int slot, float* out) { launch_slab_reduce(B.tile_colsum + slot * tsz, B.tiles, (size_t)H, out, 1.f, s); };
+      weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.hE, H, H, M, B, grad + pl.Wout, H, s);
+      launch_colsum<P>(B.d_out, (int)M, d.out_dim, L.Kpo, B.part, REDUCE_BLOCKS, grad + pl.bout, 1.f, s);
+      for (int b = nb - 1; b >= 0; --b) {
+        weight_grad<P>(B.dh_all[b + 1], H, H, B.a2[b], H, H, M, B, grad + pl.l2w[b], H, s);
+        bias_grad(nb - (b + 1), grad + pl.l2b[b]);
+        weight_grad<P>(B.dz1_all[b], H, H, B.a1[b], H, H, M, B, grad + pl.l1w[b], H, s);
+        bias_grad((nb + 1) + (nb - 1 - b), grad + pl.l1b[b]);
+      }
+      weight_grad<P>(B.dh_all[0], H, H, B.in, L.Kp0, d.in_dim, M, B, grad + pl.W0, d.in_dim, s);
+      bias_grad(nb, grad + pl.b0);
+      if (d.kind == 0) time_embedding_grad<P>(d, prm, pk, L, M, B, B.dh_all[0], grad, krow, ksteps, Kft, s);
+      return;
+    }
+  }
   // output layer parameters
   weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.hE, H, H, M, B, grad + pl.Wout, H, s);
   launch_colsum<P>(B.d_out, (int)M, d.out_dim, L.Kpo, B.part, REDUCE_BLOCKS, grad + pl.bout, 1.f, s);
@@ -324,21 +431,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
   // layer 0: dW0[h][c] = sum_m dh[m][h] in[m][c]
   weight_grad<P>(B.dh, H, H, B.in, L.Kp0, d.in_dim, M, B, grad + pl.W0, d.in_dim, s);
   launch_colsum<P>(B.dh, (int)M, H, H, B.part, REDUCE_BLOCKS, grad + pl.b0, 1.f, s);
-  if (d.kind == 0) {
-    // d temb = dh . W0[:, temb columns]; summed per fine-tuned step; back through the tiny time MLP
-    const int td = d.time_dim;
-    memset(&g, 0, sizeof(g));
-    g.M = (int)M, g.N = td, g.Kp = H, g.ldx = H, g.ldw = H;
-    g.X = B.dh, g.W = pk + L.W0tT, g.out_f32 = B.dtemb, g.ldo32 = L.tdp;
-    launch_gemm_nt<P>(g, s);
-    int sblocks = (int)(B.part_floats / ((size_t)Kft * td)) - 1;  // partial[sblocks][Kft*td] + G[Kft*td] must fit
-    sblocks = sblocks > REDUCE_BLOCKS ? REDUCE_BLOCKS : (sblocks < 1 ? 1 : sblocks);
-    launch_temb_segsum(B.dtemb, L.tdp, krow, M, Kft, td, B.part, sblocks, s);
-    float* G = B.part + (size_t)sblocks * Kft * td;
-    launch_slab_reduce(B.part, sblocks, (size_t)Kft * td, G, 1.f, s);
-    launch_time_backward(prm + pl.te1_w, prm + pl.te1_b, prm + pl.te2_w, G, ksteps, Kft, td, grad + pl.te1_w,
-                         grad + pl.te1_b, grad + pl.te2_w, grad + pl.te2_b, s);
-  }
+  if (d.kind == 0) time_embedding_grad<P>(d, prm, pk, L, M, B, B.dh, grad, krow, ksteps, Kft, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -684,6 +777,10 @@ int dppo_probe_collect(double* total_ms_host, int* launches_host, double* flops_
 int dppo_tune_set(int knob, int value) {
   if (knob == 0) {
     set_gemm_nt_variant(value);
+    return 0;
+  }
+  if (knob == 1) {
+    g_use_fused = value;
     return 0;
   }
   return fail(-1, "unknown tuning knob %d", knob);

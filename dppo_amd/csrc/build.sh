@@ -17,9 +17,10 @@ build() { # src extra-flags...
 }
 cd "$HERE"
 build "$HERE/gemm.hip"
+build "$HERE/fused.hip"
 build "$HERE/sampler.hip" -ffp-contract=off
 build "$HERE/ppo.hip" -ffp-contract=off
 build "$HERE/api.hip"
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libdppo_hip.so" "$HERE"/obj/gemm.o "$HERE"/obj/sampler.o "$HERE"/obj/ppo.o "$HERE"/obj/api.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libdppo_hip.so" "$HERE"/obj/gemm.o "$HERE"/obj/fused.o "$HERE"/obj/sampler.o "$HERE"/obj/ppo.o "$HERE"/obj/api.o
 echo "built $OUT/libdppo_hip.so"

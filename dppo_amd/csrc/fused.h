@@ -1,0 +1,72 @@
+// Fused row-tile MLP kernels for the big-batch side of the path (log-prob precompute, PPO update).
+//
+// Same engine as the sampler (sampler.hip), widened to MR row sub-tiles of 16 rows per workgroup: a persistent
+// 512-thread workgroup walks 16*MR-row tiles; the whole residual MLP runs with the activations resident in LDS
+// (XOR-swizzled [rows][H] images) and the residual stream in registers, the weights arrive as per-wave
+// fragment streams from L2 through a register ring that keeps prefetching across layers AND across tiles.
+// Only what the weight-gradient GEMMs need is written to HBM (training: act(h_b), act(z1_b), elem(h_nb);
+// inference: nothing but the network output).  The layer-by-layer gemm_nt path remains as the general fallback
+// and as an independent cross-check (tuning knob 1).
+//
+//  fused_forward : in [M][ld_in] -> out [M][ldout] (+ stored activations)
+//  fused_backward: d_out [M][Kpo] + stored activations -> dh_b (b = nb..0), dz1_b, per-tile column sums
+#pragma once
+#include "common.h"
+#include "sampler.h"
+
+namespace dppo {
+
+struct FusedGeom {  // backward stream geometry (the forward one is SamplerGeom)
+  int KSB0;         // k-step positions of the dh = d_out . Wout layer (Kpo padded to PD*KB)
+  int KpB0;         // its padded K in elements
+  int total_pos;    // KSB0 + 2*nb*KSH
+  size_t frags_per_wave;
+};
+template <class P>
+FusedGeom fused_geom(const dppo_net_desc& d);
+
+struct FusedFwdArgs {
+  const u32x4* wstream;  // forward hidden-layer stream of the net (same image the sampler uses)
+  const u32x4* ostream;  // out-layer fragments, [ks][to][lane]
+  const float* params;
+  int bias_off[2 + 2 * MAX_BLOCKS];
+  const void* in;  // [M][ld_in] elem ; columns >= ld_in are zero
+  int ld_in;
+  int M, Kp0, nb, act, out_dim;
+  // training-mode stores, each [M][H] elem (null = skip)
+  void* a1[MAX_BLOCKS];        // act(h_b)
+  void* a2[MAX_BLOCKS];        // act(z1_b)
+  void* z1[MAX_BLOCKS];        // z1_b          (needed for Mish')
+  void* hpre[MAX_BLOCKS + 1];  // elem(h_b)     (needed for Mish'; hpre[nb] = hE is always the out-layer input)
+  float* out;  // [M][ldout]
+  int ldout;
+};
+
+struct FusedBwdArgs {
+  const u32x4* bstream;  // backward stream: [dh layer (Wout^T)][per block, top down: W2^T, W1^T]
+  const void* d_out;     // [M][Kpo] elem, zero padded
+  int ld_dout;
+  int M, KpB0, nb, act;
+  // derivative sources, [M][H] elem: ReLU uses the activated copies (a > 0), Mish the pre-activations
+  const void* m1[MAX_BLOCKS];  // for act'(z1_b): a2_b (ReLU) or z1_b (Mish)
+  const void* m0[MAX_BLOCKS];  // for act'(h_b) : a1_b (ReLU) or hpre_b (Mish)
+  // outputs, [M][H] elem
+  void* dh[MAX_BLOCKS + 1];  // dh[b] = d loss / d h_b  (dh[nb] = d_out . Wout)
+  void* dz1[MAX_BLOCKS];
+  // per-tile column sums (bias gradients): [(nb+1) + nb tensors][tiles][H] f32, tensor order dh[nb..0] then dz1[nb-1..0]
+  float* colsum;
+};
+
+template <class P>
+int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStream_t s);   // <0: shape not covered
+template <class P>
+int launch_fused_backward(const dppo_net_desc& d, const FusedBwdArgs& a, hipStream_t s);
+template <class P>
+int fused_rows_per_tile(const dppo_net_desc& d);  // 16*MR for this (hidden, precision), 0 if not covered
+
+// generalised fragment packing: element (feature f, k) of the layer's weight matrix is W[f*rs + k*cs]
+template <class P>
+void launch_pack_hidden_strided(const float* W, long rs, long cs, int in_valid, int KS, int TPW, int pos0,
+                                int total_pos, u32x4* stream, hipStream_t s);
+
+}  // namespace dppo

@@ -1,0 +1,482 @@
+// See fused.h.  gfx950 only.
+#include "fused.h"
+
+namespace dppo {
+
+namespace {
+
+__device__ __forceinline__ int kmask16(int rb) {
+  const int n = rb >> 4;
+  const int p = n & (-n);
+  return (p > 16 ? 16 : p) - 1;
+}
+
+// ring depth (k-step positions in flight per wave): 4 unless the accumulators already fill the register file
+template <int TPW, int MR>
+constexpr int ring_depth() {
+  return TPW * MR > 16 ? 2 : 4;
+}
+
+// rows of a [rows][ld] elem matrix -> swizzled LDS image [MT][rb bytes]; 16-byte chunks, zero fill outside
+template <int MT>
+__device__ __forceinline__ void load_tile(char* dst, int rb, int km, const char* src, int ld_bytes, int row0, int M) {
+  const int nch = rb >> 4, vch = ld_bytes >> 4;
+  for (int q = threadIdx.x; q < MT * nch; q += 512) {
+    const int row = q / nch, c = q - row * nch;
+    const int grow = row0 + row;
+    u32x4 v = (u32x4){0, 0, 0, 0};
+    if (c < vch && grow < M) v = *(const u32x4*)(src + (size_t)grow * ld_bytes + c * 16);
+    *(u32x4*)(dst + row * rb + ((c ^ (row & km)) << 4)) = v;
+  }
+}
+
+// The engine shared by both kernels: per-wave accumulators acc[TPW][MR] (16 features x 16 rows each), one
+// k-step position = one B fragment per row sub-tile from LDS + TPW weight fragments from the ring.
+template <class P, int TPW, int MR, int PD>
+struct Engine {
+  u32x4 ring[PD][TPW];
+  const u32x4* stream;  // this wave's stream + lane
+  int total, pos;
+
+  __device__ __forceinline__ void prime(const u32x4* s, int total_pos) {
+    stream = s;
+    total = total_pos;
+    pos = 0;
+#pragma unroll
+    for (int p = 0; p < PD; ++p)
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp) ring[p][tp] = s[(p * TPW + tp) * 64];
+  }
+  // acc += W(layer at stream position pos .. pos+nks) . src^T ; src: swizzled LDS image with row bytes rb
+  __device__ __forceinline__ void run(f32x4 (&acc)[TPW][MR], const char* src, int rb, int km, int nks, int r, int g) {
+    for (int k0 = 0; k0 < nks; k0 += PD) {
+#pragma unroll
+      for (int p = 0; p < PD; ++p) {
+        const int ks = k0 + p;
+        u32x4 xb[MR];
+#pragma unroll
+        for (int m = 0; m < MR; ++m) xb[m] = *(const u32x4*)(src + (16 * m + r) * rb + (((ks * 4 + g) ^ (r & km)) << 4));
+#pragma unroll
+        for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+          for (int m = 0; m < MR; ++m) acc[tp][m] = P::mma(ring[p][tp], xb[m], acc[tp][m]);
+        int np = pos + ks + PD;
+        np = np < total ? np : np - total;  // wrap: the next tile walks the same stream
+        const u32x4* w = stream + (size_t)np * TPW * 64;
+#pragma unroll
+        for (int tp = 0; tp < TPW; ++tp) ring[p][tp] = w[tp * 64];
+      }
+    }
+    pos += nks;
+    if (pos >= total) pos -= total;
+  }
+};
+
+// v[tp][m] (features fb + 4tp + e of row 16m + r) -> activated elem chunks, written to the LDS image `lds`
+// (may be null) and to the global [M][H] tensor `glb` (may be null)
+template <class P, int TPW, int MR>
+__device__ __forceinline__ void emit(const f32x4 (&v)[TPW][MR], int actk, char* lds, void* glb, int H, int fb, int r,
+                                     int row0, int M) {
+  constexpr int ES = P::ESIZE;
+  const int HRB = H * ES;
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    const int grow = row0 + 16 * m + r;
+    char* gp = glb != nullptr && grow < M ? (char*)glb + ((size_t)grow * H + fb) * ES : nullptr;
+    char* lp = lds != nullptr ? lds + (16 * m + r) * HRB : nullptr;
+    if constexpr (ES == 4) {
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp) {
+        u32x4 o;
+        o.x = __float_as_uint(act_f(actk, v[tp][m][0]));
+        o.y = __float_as_uint(act_f(actk, v[tp][m][1]));
+        o.z = __float_as_uint(act_f(actk, v[tp][m][2]));
+        o.w = __float_as_uint(act_f(actk, v[tp][m][3]));
+        const int c = ((fb + 4 * tp) * 4) >> 4;
+        if (lp) *(u32x4*)(lp + ((c ^ (r & 15)) << 4)) = o;
+        if (gp) *(u32x4*)(gp + tp * 16) = o;
+      }
+    } else {
+#pragma unroll
+      for (int tp = 0; tp < TPW; tp += 2) {
+        u32x4 o;
+        o.x = (uint32_t)f2bf(act_f(actk, v[tp][m][0])) | ((uint32_t)f2bf(act_f(actk, v[tp][m][1])) << 16);
+        o.y = (uint32_t)f2bf(act_f(actk, v[tp][m][2])) | ((uint32_t)f2bf(act_f(actk, v[tp][m][3])) << 16);
+        o.z = (uint32_t)f2bf(act_f(actk, v[tp + 1][m][0])) | ((uint32_t)f2bf(act_f(actk, v[tp + 1][m][1])) << 16);
+        o.w = (uint32_t)f2bf(act_f(actk, v[tp + 1][m][2])) | ((uint32_t)f2bf(act_f(actk, v[tp + 1][m][3])) << 16);
+        const int c = ((fb + 4 * tp) * 2) >> 4;
+        if (lp) *(u32x4*)(lp + ((c ^ (r & 15)) << 4)) = o;
+        if (gp) *(u32x4*)(gp + (tp / 2) * 16) = o;
+      }
+    }
+  }
+}
+
+// this lane's 4*TPW values of row (16m + r) of a global [M][H] elem tensor, kept packed as loaded
+// (CH 16-byte chunks per row sub-tile); grad_at() decodes one element and returns act'(.)
+template <class P, int TPW>
+struct Chunks {
+  static constexpr int CH = P::ESIZE == 4 ? TPW : TPW / 2;
+};
+template <class P, int MR, int CH>
+__device__ __forceinline__ void fetch(u32x4 (&d)[MR][CH], const void* glb, int H, int fb, int r, int row0, int M) {
+  constexpr int ES = P::ESIZE;
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    const int grow = row0 + 16 * m + r;
+    const char* gp = (const char*)glb + ((size_t)(grow < M ? grow : M - 1) * H + fb) * ES;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) d[m][c] = *(const u32x4*)(gp + c * 16);
+  }
+}
+template <class P, int MR, int CH>
+__device__ __forceinline__ float grad_at(const u32x4 (&d)[MR][CH], int actk, int tp, int m, int e) {
+  if constexpr (P::ESIZE == 4) {
+    return act_grad_f(actk, __uint_as_float(d[m][tp][e]));
+  } else {
+    const uint32_t w = d[m][tp >> 1][(tp & 1) * 2 + (e >> 1)];
+    return act_grad_f(actk, bf2f((e & 1) ? (w >> 16) : (w & 0xffff)));
+  }
+}
+
+}  // namespace
+
+// =================================================================================================
+// forward
+// =================================================================================================
+template <class P, int TPW, int MR, int OT>
+__global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a) {
+  constexpr int PD = ring_depth<TPW, MR>(), ES = P::ESIZE, KB = P::KB;
+  constexpr int H = 128 * TPW, KSH = H / KB, HRB = H * ES, MT = 16 * MR;
+  constexpr int KSPLIT = MR * OT >= 8 ? 1 : 8 / (MR * OT);
+  constexpr int KPER = KSH / KSPLIT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int Kp0 = a.Kp0, nb = a.nb, M = a.M;
+  const int in_rb = Kp0 * ES, in_km = kmask16(in_rb), KS0 = Kp0 / KB;
+  const int total = KS0 + 2 * nb * KSH;
+  char* xin = smem;
+  char* bufA = xin + MT * in_rb;
+  char* bufB = bufA + MT * HRB;
+  float* part = (float*)(bufB + MT * HRB);  // [KSPLIT][MR][OT*16 features][16 rows]
+  const int fb = wid * 16 * TPW + 4 * TPW * g;
+  const u32x4* os = a.ostream + lane;
+
+  Engine<P, TPW, MR, PD> eng;
+  eng.prime(a.wstream + (size_t)wid * total * TPW * 64 + lane, total);
+
+  const int ntiles = (M + MT - 1) / MT;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row0 = tile * MT;
+    load_tile<MT>(xin, in_rb, in_km, (const char*)a.in, a.ld_in * ES, row0, M);
+    __syncthreads();
+
+    f32x4 h[TPW][MR], acc[TPW][MR];
+    auto bias_init = [&](int boff) {
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp) {
+        f32x4 b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = a.params[boff + fb + 4 * tp + e];
+#pragma unroll
+        for (int m = 0; m < MR; ++m) acc[tp][m] = b;
+      }
+    };
+    // ---- layer 0
+    bias_init(a.bias_off[0]);
+    eng.run(acc, xin, in_rb, in_km, KS0, r, g);
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+      for (int m = 0; m < MR; ++m) h[tp][m] = acc[tp][m];
+    if (nb > 0) {
+      if (a.hpre[0] != nullptr) emit<P, TPW, MR>(h, ACT_NONE, nullptr, a.hpre[0], H, fb, r, row0, M);
+      emit<P, TPW, MR>(h, a.act, bufA, a.a1[0], H, fb, r, row0, M);
+    } else {
+      emit<P, TPW, MR>(h, ACT_NONE, bufA, a.hpre[0], H, fb, r, row0, M);
+    }
+    __syncthreads();
+    // ---- residual blocks
+    for (int b = 0; b < nb; ++b) {
+      bias_init(a.bias_off[1 + 2 * b]);
+      eng.run(acc, bufA, HRB, 15, KSH, r, g);
+      if (a.z1[b] != nullptr) emit<P, TPW, MR>(acc, ACT_NONE, nullptr, a.z1[b], H, fb, r, row0, M);
+      emit<P, TPW, MR>(acc, a.act, bufB, a.a2[b], H, fb, r, row0, M);
+      __syncthreads();
+      bias_init(a.bias_off[2 + 2 * b]);
+      eng.run(acc, bufB, HRB, 15, KSH, r, g);
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+        for (int m = 0; m < MR; ++m) h[tp][m] += acc[tp][m];
+      if (b + 1 < nb) {
+        if (a.hpre[b + 1] != nullptr) emit<P, TPW, MR>(h, ACT_NONE, nullptr, a.hpre[b + 1], H, fb, r, row0, M);
+        emit<P, TPW, MR>(h, a.act, bufA, a.a1[b + 1], H, fb, r, row0, M);
+      } else {
+        emit<P, TPW, MR>(h, ACT_NONE, bufA, a.hpre[nb], H, fb, r, row0, M);
+      }
+      __syncthreads();
+    }
+    // ---- output layer: work items (row sub-tile m, out tile to, K slice kh) dealt to the 8 waves
+    for (int it = wid; it < MR * OT * KSPLIT; it += SAMPLER_WAVES) {
+      const int m = it % MR, to = (it / MR) % OT, kh = it / (MR * OT);
+      f32x4 oacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < KPER; ++c) {
+        const int ks = kh * KPER + c;
+        const u32x4 wf = os[(size_t)(ks * OT + to) * 64];
+        const u32x4 xb = *(const u32x4*)(bufA + (16 * m + r) * HRB + (((ks * 4 + g) ^ (r & 15)) << 4));
+        oacc = P::mma(wf, xb, oacc);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part[(((kh * MR + m) * OT + to) * 16 + 4 * g + e) * 16 + r] = oacc[e];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < MT * a.out_dim; idx += 512) {
+      const int row = idx / a.out_dim, j = idx - row * a.out_dim;
+      const int m = row >> 4, rr = row & 15, to = j >> 4, jj = j & 15;
+      float s = a.params[a.bias_off[1 + 2 * nb] + j];
+#pragma unroll
+      for (int kh = 0; kh < KSPLIT; ++kh) s += part[(((kh * MR + m) * OT + to) * 16 + jj) * 16 + rr];
+      if (row0 + row < M) a.out[(size_t)(row0 + row) * a.ldout + j] = s;
+    }
+    // the next tile's barriers (after its input load) order these reads before `part` is rewritten
+  }
+}
+
+// =================================================================================================
+// backward (data gradients + column sums)
+// =================================================================================================
+template <class P, int TPW, int MR>
+__global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs a) {
+  constexpr int PD = 2, ES = P::ESIZE, KB = P::KB;
+  constexpr int H = 128 * TPW, KSH = H / KB, HRB = H * ES, MT = 16 * MR;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int nb = a.nb, M = a.M;
+  const int in_rb = a.KpB0 * ES, in_km = kmask16(in_rb), KSB0 = a.KpB0 / KB;
+  const int total = KSB0 + 2 * nb * KSH;
+  char* xin = smem;
+  char* bufA = xin + MT * in_rb;
+  char* bufB = bufA + MT * HRB;
+  const int fb = wid * 16 * TPW + 4 * TPW * g;
+  const int ntiles = (M + MT - 1) / MT;
+
+  Engine<P, TPW, MR, PD> eng;
+  eng.prime(a.bstream + (size_t)wid * total * TPW * 64 + lane, total);
+
+  // column sums over this tile's rows of v -> colsum[slot][tile][H]; rows past M hold exact zeros
+  auto colsum = [&](const f32x4 (&v)[TPW][MR], int slot, int tile) {
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) {
+      f32x4 s = v[tp][0];
+#pragma unroll
+      for (int m = 1; m < MR; ++m) s += v[tp][m];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = s[e];
+        x += __shfl_xor(x, 1);
+        x += __shfl_xor(x, 2);
+        x += __shfl_xor(x, 4);
+        x += __shfl_xor(x, 8);
+        s[e] = x;
+      }
+      if (r == 0) *(f32x4*)(a.colsum + ((size_t)slot * ntiles + tile) * H + fb + 4 * tp) = s;
+    }
+  };
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row0 = tile * MT;
+    load_tile<MT>(xin, in_rb, in_km, (const char*)a.d_out, a.ld_dout * ES, row0, M);
+    __syncthreads();
+    f32x4 dh[TPW][MR], acc[TPW][MR];
+    auto zero_acc = [&]() {
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+        for (int m = 0; m < MR; ++m) acc[tp][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    // ---- dh[nb] = d_out . Wout
+    zero_acc();
+    eng.run(acc, xin, in_rb, in_km, KSB0, r, g);
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+      for (int m = 0; m < MR; ++m) dh[tp][m] = acc[tp][m];
+    emit<P, TPW, MR>(dh, ACT_NONE, bufA, a.dh[nb], H, fb, r, row0, M);
+    colsum(dh, 0, tile);
+    __syncthreads();
+    for (int b = nb - 1; b >= 0; --b) {
+      // ---- dz1 = (dh . W2) * act'(z1)
+      u32x4 d[MR][Chunks<P, TPW>::CH];
+      fetch<P>(d, a.m1[b], H, fb, r, row0, M);  // issued ahead of the layer: latency hides under it
+      zero_acc();
+      eng.run(acc, bufA, HRB, 15, KSH, r, g);
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[tp][m][e] *= grad_at<P>(d, a.act, tp, m, e);
+      emit<P, TPW, MR>(acc, ACT_NONE, bufB, a.dz1[b], H, fb, r, row0, M);
+      colsum(acc, (nb + 1) + (nb - 1 - b), tile);
+      __syncthreads();
+      // ---- dh[b] = dh[b+1] + (dz1 . W1) * act'(h_b)
+      fetch<P>(d, a.m0[b], H, fb, r, row0, M);
+      zero_acc();
+      eng.run(acc, bufB, HRB, 15, KSH, r, g);
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dh[tp][m][e] += acc[tp][m][e] * grad_at<P>(d, a.act, tp, m, e);
+      emit<P, TPW, MR>(dh, ACT_NONE, bufA, a.dh[b], H, fb, r, row0, M);
+      colsum(dh, nb - b, tile);
+      __syncthreads();
+    }
+  }
+}
+
+// =================================================================================================
+// host side
+// =================================================================================================
+template <class P>
+static int pick_mr(int hidden) {
+  const int tpw = hidden / 128;
+  if (hidden % 128) return 0;
+  if (P::ESIZE == 2) return tpw == 2 || tpw == 4 ? 4 : (tpw == 8 ? 2 : 0);
+  return tpw == 2 ? 4 : (tpw == 4 ? 2 : (tpw == 8 ? 1 : 0));
+}
+template <class P>
+int fused_rows_per_tile(const dppo_net_desc& d) {
+  return 16 * pick_mr<P>(d.hidden);
+}
+template int fused_rows_per_tile<F32>(const dppo_net_desc&);
+template int fused_rows_per_tile<BF16>(const dppo_net_desc&);
+
+template <class P>
+FusedGeom fused_geom(const dppo_net_desc& d) {
+  FusedGeom g;
+  const int pd = sampler_pd(d.hidden);
+  g.KpB0 = round_up(round_up(d.out_dim, 64), pd * P::KB);
+  g.KSB0 = g.KpB0 / P::KB;
+  g.total_pos = g.KSB0 + 2 * d.n_blocks * (d.hidden / P::KB);
+  g.frags_per_wave = (size_t)g.total_pos * (d.hidden / 128);
+  return g;
+}
+template FusedGeom fused_geom<F32>(const dppo_net_desc&);
+template FusedGeom fused_geom<BF16>(const dppo_net_desc&);
+
+constexpr int NUM_CUS = 256;
+
+template <class K>
+static void raise_lds(K kern, bool& done) {
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done = true;
+  }
+}
+
+template <class P, int TPW, int MR, int OT>
+static int launch_fwd_cfg(const FusedFwdArgs& a, hipStream_t s) {
+  constexpr int ES = P::ESIZE, MT = 16 * MR, H = 128 * TPW;
+  constexpr int KSPLIT = MR * OT >= 8 ? 1 : 8 / (MR * OT);
+  const size_t lds = (size_t)MT * a.Kp0 * ES + 2 * (size_t)MT * H * ES + (size_t)KSPLIT * MR * OT * 16 * 16 * 4;
+  if (lds > 160 * 1024) return -2;
+  static bool attr = false;
+  raise_lds(fused_forward_kernel<P, TPW, MR, OT>, attr);
+  const int ntiles = (a.M + MT - 1) / MT;
+  hipLaunchKernelGGL((fused_forward_kernel<P, TPW, MR, OT>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512), lds, s,
+                     a);
+  return 0;
+}
+
+template <class P>
+int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStream_t s) {
+  const int tpw = d.hidden / 128, mr = pick_mr<P>(d.hidden);
+  const int ot = (d.out_dim + 15) / 16 <= 1 ? 1 : ((d.out_dim + 15) / 16 <= 4 ? 4 : 0);
+  if (mr == 0 || ot == 0 || a.M <= 0) return -1;
+#define DPPO_FWD(T, R, O) \
+  if (tpw == T && mr == R && ot == O) return launch_fwd_cfg<P, T, R, O>(a, s);
+  if constexpr (P::ESIZE == 2) {
+    DPPO_FWD(2, 4, 1) DPPO_FWD(2, 4, 4) DPPO_FWD(4, 4, 1) DPPO_FWD(4, 4, 4) DPPO_FWD(8, 2, 1) DPPO_FWD(8, 2, 4)
+  } else {
+    DPPO_FWD(2, 4, 1) DPPO_FWD(2, 4, 4) DPPO_FWD(4, 2, 1) DPPO_FWD(4, 2, 4) DPPO_FWD(8, 1, 1) DPPO_FWD(8, 1, 4)
+  }
+#undef DPPO_FWD
+  return -1;
+}
+template int launch_fused_forward<F32>(const dppo_net_desc&, const FusedFwdArgs&, hipStream_t);
+template int launch_fused_forward<BF16>(const dppo_net_desc&, const FusedFwdArgs&, hipStream_t);
+
+template <class P, int TPW, int MR>
+static int launch_bwd_cfg(const FusedBwdArgs& a, hipStream_t s) {
+  constexpr int ES = P::ESIZE, MT = 16 * MR, H = 128 * TPW;
+  const size_t lds = (size_t)MT * a.KpB0 * ES + 2 * (size_t)MT * H * ES;
+  if (lds > 160 * 1024) return -2;
+  static bool attr = false;
+  raise_lds(fused_backward_kernel<P, TPW, MR>, attr);
+  const int ntiles = (a.M + MT - 1) / MT;
+  hipLaunchKernelGGL((fused_backward_kernel<P, TPW, MR>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512), lds, s, a);
+  return 0;
+}
+
+template <class P>
+int launch_fused_backward(const dppo_net_desc& d, const FusedBwdArgs& a, hipStream_t s) {
+  const int tpw = d.hidden / 128, mr = pick_mr<P>(d.hidden);
+  if (mr == 0 || a.M <= 0) return -1;
+#define DPPO_BWD(T, R) \
+  if (tpw == T && mr == R) return launch_bwd_cfg<P, T, R>(a, s);
+  if constexpr (P::ESIZE == 2) {
+    DPPO_BWD(2, 4) DPPO_BWD(4, 4) DPPO_BWD(8, 2)
+  } else {
+    DPPO_BWD(2, 4) DPPO_BWD(4, 2) DPPO_BWD(8, 1)
+  }
+#undef DPPO_BWD
+  return -1;
+}
+template int launch_fused_backward<F32>(const dppo_net_desc&, const FusedBwdArgs&, hipStream_t);
+template int launch_fused_backward<BF16>(const dppo_net_desc&, const FusedBwdArgs&, hipStream_t);
+
+// fragment packing with arbitrary strides (W^T streams of the backward pass)
+template <class P>
+__global__ void pack_hidden_strided_kernel(const float* W, long rs, long cs, int in_valid, int KS, int TPW, int pos0,
+                                           int total_pos, u32x4* stream) {
+  const int lane = threadIdx.x & 63;
+  const int tp = blockIdx.x % TPW;
+  const int ks = (blockIdx.x / TPW) % KS;
+  const int w = blockIdx.x / (TPW * KS);
+  const int r = lane & 15, g = lane >> 4;
+  const int feat = w * 16 * TPW + 4 * TPW * (r >> 2) + 4 * tp + (r & 3);
+  constexpr int EPL = 16 / P::ESIZE;
+  const int k0 = ks * P::KB + EPL * g;
+  uint32_t out[4];
+  if constexpr (P::ESIZE == 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = __float_as_uint(k0 + j < in_valid ? W[feat * rs + (k0 + j) * cs] : 0.f);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + 2 * j;
+      const float lo = k < in_valid ? W[feat * rs + k * cs] : 0.f;
+      const float hi = k + 1 < in_valid ? W[feat * rs + (k + 1) * cs] : 0.f;
+      out[j] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    }
+  }
+  stream[(((size_t)w * total_pos + pos0 + ks) * TPW + tp) * 64 + lane] = (u32x4){out[0], out[1], out[2], out[3]};
+}
+template <class P>
+void launch_pack_hidden_strided(const float* W, long rs, long cs, int in_valid, int KS, int TPW, int pos0,
+                                int total_pos, u32x4* stream, hipStream_t s) {
+  hipLaunchKernelGGL((pack_hidden_strided_kernel<P>), dim3(SAMPLER_WAVES * KS * TPW), dim3(64), 0, s, W, rs, cs, in_valid,
+                     KS, TPW, pos0, total_pos, stream);
+}
+template void launch_pack_hidden_strided<F32>(const float*, long, long, int, int, int, int, int, u32x4*, hipStream_t);
+template void launch_pack_hidden_strided<BF16>(const float*, long, long, int, int, int, int, int, u32x4*, hipStream_t);
+
+}  // namespace dppo

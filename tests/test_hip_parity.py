@@ -261,3 +261,48 @@ def test_adamw_and_clip_match_torch(golden):
     FlatAdamW(q1, lr=1e-2, weight_decay=0.0).step(T(g["clip_in"]).to(DEV), max_norm=1.5)
     FlatAdamW(q2, lr=1e-2, weight_decay=0.0).step(T(g["clip_out"]).to(DEV))
     np.testing.assert_allclose(q1.cpu().numpy(), q2.cpu().numpy(), rtol=1e-5, atol=1e-8)
+
+
+# ------------------------------------------------------------------ fused row-tile kernels vs layered GEMM chain
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("sname", ["hopper", "can"])
+def test_fused_path_matches_layered_path(prec, tol, sname):
+    """Two independent implementations of the big-batch MLP (fused row-tile kernels / layer-by-layer gemm_nt
+    chain, tuning knob 1) must agree on log-probs, loss statistics and every gradient."""
+    from dppo_amd import hip
+    lib = hip.load()
+    kw = dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01, randn_clip_value=3)
+    m, a, c = build_model(sname, kw, 71, prec)
+    R, N, Kft = 200, 1000, 10  # 200 rows: not a multiple of the 64/32-row tiles
+    AF = a.horizon_steps * a.action_dim
+    torch.manual_seed(3)
+    out = {}
+    try:
+        for fused in (1, 0):
+            lib.dppo_tune_set(1, fused)
+            gen = torch.Generator(device="cpu").manual_seed(5)
+            obs = (torch.rand(R, 1, a.cond_dim, generator=gen) * 2 - 1).to(DEV)
+            noise = torch.randn(21, R, AF, generator=gen).to(DEV)
+            chains = m(cond={"state": obs}, noise=noise).chains
+            logp = m.get_logprobs({"state": obs}, chains).reshape(R, Kft, AF)
+            val = m.critic({"state": obs}).reshape(R)
+            ret = val + torch.randn(R, generator=gen).to(DEV)
+            adv = torch.randn(R, generator=gen).to(DEV)
+            inds = torch.randperm(R * Kft, generator=gen)[:N].to(DEV).contiguous()
+            st = m.ppo_update(obs.reshape(R, -1).contiguous(), chains.reshape(R, Kft + 1, AF).contiguous(), ret, val,
+                              adv, logp + 0.01, inds).cpu().numpy().copy()
+            out[fused] = (logp.cpu().numpy(), val.cpu().numpy(), st, m.actor_ft.flat_grads().cpu().numpy().copy(),
+                          m.critic.flat_grads().cpu().numpy().copy())
+    finally:
+        lib.dppo_tune_set(1, 1)
+    lp1, v1, s1, ga1, gc1 = out[1]
+    lp0, v0, s0, ga0, gc0 = out[0]
+    lp_tol = tol * 30  # d logp = (z / sigma) d mu, sigma >= 0.1
+    np.testing.assert_allclose(lp1, lp0, rtol=lp_tol, atol=lp_tol)
+    np.testing.assert_allclose(v1, v0, rtol=tol, atol=tol)
+    np.testing.assert_allclose(s1[:5], s0[:5], rtol=max(tol * 50, 1e-4), atol=max(tol * 5, 1e-5))
+    cos = lambda x, y: float(np.dot(x, y) / (np.linalg.norm(x) * np.linalg.norm(y) + 1e-30))
+    lim = 1 - 1e-6 if prec == "fp32" else 0.995
+    assert cos(ga1, ga0) >= lim and cos(gc1, gc0) >= lim
+    assert np.linalg.norm(ga1) == pytest.approx(np.linalg.norm(ga0), rel=max(tol * 5, 1e-4))
+    assert np.linalg.norm(gc1) == pytest.approx(np.linalg.norm(gc0), rel=max(tol * 5, 1e-4))
