@@ -162,6 +162,8 @@ def main():
     ap.add_argument("--n-steps", type=int, default=500, help="rollout length behind the update buffer")
     ap.add_argument("--batch", type=int, default=50000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--probe", type=int, default=2,
+                    help="kernel timed live for `roofline`: 2 gemm_tn (weight grads), 3 fused fwd, 4 fused bwd, 5 sampler")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -219,7 +221,7 @@ def main():
             fn(i)
         barrier()
         if probe:
-            hip.check(lib.dppo_probe_arm(8 * args.steps), "dppo_probe_arm")
+            hip.check(lib.dppo_probe_arm(args.probe, 16 * args.steps), "dppo_probe_arm")
         t0 = time.perf_counter()
         for i in range(args.warmup, n_total):
             fn(i)
@@ -231,8 +233,8 @@ def main():
             dt = float(t.item())
         return dt
 
-    dt_sample = timed(sample_step)
-    dt_update = timed(update_step, probe=(rank == 0))
+    dt_sample = timed(sample_step, probe=(rank == 0 and args.probe == 5))
+    dt_update = timed(update_step, probe=(rank == 0 and args.probe != 5))
     probe = None
     if rank == 0:
         ms, cnt, fl = C.c_double(), C.c_int(), C.c_double()
@@ -241,9 +243,12 @@ def main():
             avg_ms = ms.value / cnt.value
             tf = fl.value / cnt.value / (avg_ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.prec]
+            names = {1: "gemm_nt_kernel (H x H layers, layered path)", 2: "gemm_tn_kernel (H x H weight gradients)",
+                     3: "fused_forward_kernel (actor_ft + critic)", 4: "fused_backward_kernel (actor_ft + critic)",
+                     5: "sample_chain_kernel"}
             probe = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
-                     "traffic": None, "kernel": f"gemm_nt_kernel<{args.prec},128x128> M={args.batch} N=K=512",
-                     "avg_launch_ms": avg_ms, "launches": cnt.value}
+                     "traffic": None, "kernel": f"{names[args.probe]}, {args.prec}", "avg_launch_ms": avg_ms,
+                     "launches": cnt.value, "algorithmic_gflop_per_launch": fl.value / cnt.value / 1e9}
     stats = model._stats.tolist()
     if rank == 0:
         ms_update = dt_update / args.steps * 1e3

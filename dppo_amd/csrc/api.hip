@@ -284,7 +284,7 @@ static void mlp_forward(const dppo_net_desc& d, const float* prm, const char* pk
     f.wstream = (const u32x4*)(pk + L.sstream), f.ostream = (const u32x4*)(pk + L.ostream), f.params = prm;
     fill_bias_off(d, pl, f.bias_off);
     f.in = B.in, f.ld_in = L.Kp0, f.M = (int)M, f.Kp0 = sampler_geom<P>(d).Kp0, f.nb = nb, f.act = d.act;
-    f.out_dim = d.out_dim, f.out = B.out, f.ldout = B.ldout;
+    f.out_dim = d.out_dim, f.out = B.out, f.ldout = B.ldout, f.in_valid = d.in_dim;
     if (keep) {
       for (int b = 0; b < nb; ++b) {
         f.a1[b] = B.a1[b], f.a2[b] = B.a2[b];
@@ -375,7 +375,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
     memset(&f, 0, sizeof(f));
     const FusedGeom fg = fused_geom<P>(d);
     f.bstream = (const u32x4*)(pk + L.bstream), f.d_out = B.d_out, f.ld_dout = L.Kpo, f.M = (int)M, f.KpB0 = fg.KpB0;
-    f.nb = nb, f.act = d.act, f.colsum = B.tile_colsum;
+    f.nb = nb, f.act = d.act, f.colsum = B.tile_colsum, f.out_valid = d.out_dim;
     const bool relu = d.act == DPPO_ACT_RELU;
     for (int b = 0; b < nb; ++b) {
       f.m1[b] = relu ? B.a2[b] : B.z1[b];
@@ -763,8 +763,8 @@ int dppo_adamw_step(float* params, const float* grad, float* exp_avg, float* exp
 
 
 // ---- measurement hook ----------------------------------------------------------------------------------
-int dppo_probe_arm(int max_launches) {
-  if (probe_arm(max_launches)) return fail(-1, "probe already armed or bad size");
+int dppo_probe_arm(int kernel_id, int max_launches) {
+  if (probe_arm(kernel_id, max_launches)) return fail(-1, "probe already armed or bad size");
   return 0;
 }
 int dppo_probe_collect(double* total_ms_host, int* launches_host, double* flops_host) {

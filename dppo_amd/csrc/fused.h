@@ -33,6 +33,7 @@ struct FusedFwdArgs {
   const void* in;  // [M][ld_in] elem ; columns >= ld_in are zero
   int ld_in;
   int M, Kp0, nb, act, out_dim;
+  int in_valid;  // true input width (algorithmic FLOP accounting only)
   // training-mode stores, each [M][H] elem (null = skip)
   void* a1[MAX_BLOCKS];        // act(h_b)
   void* a2[MAX_BLOCKS];        // act(z1_b)
@@ -47,6 +48,7 @@ struct FusedBwdArgs {
   const void* d_out;     // [M][Kpo] elem, zero padded
   int ld_dout;
   int M, KpB0, nb, act;
+  int out_valid;  // true output width of the network (algorithmic FLOP accounting only)
   // derivative sources, [M][H] elem: ReLU uses the activated copies (a > 0), Mish the pre-activations
   const void* m1[MAX_BLOCKS];  // for act'(z1_b): a2_b (ReLU) or z1_b (Mish)
   const void* m0[MAX_BLOCKS];  // for act'(h_b) : a1_b (ReLU) or hpre_b (Mish)

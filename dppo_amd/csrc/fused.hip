@@ -1,5 +1,6 @@
 // See fused.h.  gfx950 only.
 #include "fused.h"
+#include "gemm.h"
 
 namespace dppo {
 
@@ -391,8 +392,10 @@ static int launch_fwd_cfg(const FusedFwdArgs& a, hipStream_t s) {
   static bool attr = false;
   raise_lds(fused_forward_kernel<P, TPW, MR, OT>, attr);
   const int ntiles = (a.M + MT - 1) / MT;
+  const bool probe = probe_begin(PROBE_FUSED_FWD, s);
   hipLaunchKernelGGL((fused_forward_kernel<P, TPW, MR, OT>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512), lds, s,
                      a);
+  if (probe) probe_end(s, 2.0 * a.M * ((double)a.in_valid * H + 2.0 * a.nb * H * H + (double)H * a.out_dim));
   return 0;
 }
 
@@ -422,7 +425,9 @@ static int launch_bwd_cfg(const FusedBwdArgs& a, hipStream_t s) {
   static bool attr = false;
   raise_lds(fused_backward_kernel<P, TPW, MR>, attr);
   const int ntiles = (a.M + MT - 1) / MT;
+  const bool probe = probe_begin(PROBE_FUSED_BWD, s);
   hipLaunchKernelGGL((fused_backward_kernel<P, TPW, MR>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512), lds, s, a);
+  if (probe) probe_end(s, 2.0 * a.M * ((double)a.out_valid * H + 2.0 * a.nb * H * H));
   return 0;
 }
 

@@ -43,12 +43,15 @@ struct GemmTN {
 template <class P>
 void launch_gemm_nt(const GemmNT& a, hipStream_t s);
 
-// Measurement hook (bench.py's roofline): while armed, every 128x128-tile gemm_nt launch with N == Kp (the
-// H x H hidden layers: forward l1/l2 and both backward-data GEMMs) is bracketed by HIP events recorded on the
-// launch stream.  Process-wide, not thread-safe, off by default; never armed by the product path.
+// Measurement hook (bench.py's roofline): while armed for a kernel id, every launch of that kernel is bracketed by
+// HIP events recorded on its launch stream.  Process-wide, not thread-safe, off by default; never armed by the
+// product path.
+enum { PROBE_GEMM_NT_HIDDEN = 1, PROBE_GEMM_TN = 2, PROBE_FUSED_FWD = 3, PROBE_FUSED_BWD = 4, PROBE_SAMPLER = 5 };
 void set_gemm_nt_variant(int v);  // 0 register staging, 1 LDS-DMA staging where legal (default)
-int probe_arm(int max_launches);
+int probe_arm(int kernel_id, int max_launches);
 int probe_collect(double* total_ms, int* launches, double* flops);
+bool probe_begin(int kernel_id, hipStream_t s);  // true if this launch is being timed
+void probe_end(hipStream_t s, double flops);     // call right after the launch when probe_begin returned true
 template <class P>
 void launch_gemm_tn(const GemmTN& a, hipStream_t s);
 

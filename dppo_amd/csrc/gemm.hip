@@ -218,17 +218,17 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_nt_kernel(const GemmNT a) {
 
 struct Probe {
   bool armed = false;
-  int cap = 0, used = 0;
+  int id = 0, cap = 0, used = 0;
   hipEvent_t* ev = nullptr;  // 2 per launch
   double flops = 0;
 };
 static Probe g_probe;
-int probe_arm(int max_launches) {
+int probe_arm(int kernel_id, int max_launches) {
   if (g_probe.armed || max_launches < 1) return -1;
   g_probe.ev = new hipEvent_t[2 * max_launches];
   for (int i = 0; i < 2 * max_launches; ++i)
     if (hipEventCreate(&g_probe.ev[i]) != hipSuccess) return -1;
-  g_probe.cap = max_launches, g_probe.used = 0, g_probe.flops = 0, g_probe.armed = true;
+  g_probe.id = kernel_id, g_probe.cap = max_launches, g_probe.used = 0, g_probe.flops = 0, g_probe.armed = true;
   return 0;
 }
 int probe_collect(double* total_ms, int* launches, double* flops) {
@@ -245,6 +245,16 @@ int probe_collect(double* total_ms, int* launches, double* flops) {
   delete[] g_probe.ev;
   g_probe = Probe();
   return 0;
+}
+bool probe_begin(int kernel_id, hipStream_t s) {
+  if (!g_probe.armed || g_probe.id != kernel_id || g_probe.used >= g_probe.cap) return false;
+  (void)hipEventRecord(g_probe.ev[2 * g_probe.used], s);
+  return true;
+}
+void probe_end(hipStream_t s, double flops) {
+  (void)hipEventRecord(g_probe.ev[2 * g_probe.used + 1], s);
+  g_probe.flops += flops;
+  ++g_probe.used;
 }
 
 static int g_nt_variant = 1;  // 0 = register staging everywhere, 1 = LDS-DMA staging where legal (bench A/B knob)
@@ -263,14 +273,9 @@ static void launch_nt_cfg(const GemmNT& a, hipStream_t s) {
       attr_set = true;
     }
   }
-  const bool probe = g_probe.armed && TAG == 1 && g_probe.used < g_probe.cap;
-  if (probe) (void)hipEventRecord(g_probe.ev[2 * g_probe.used], s);
+  const bool probe = TAG == 1 && probe_begin(PROBE_GEMM_NT_HIDDEN, s);
   hipLaunchKernelGGL((gemm_nt_kernel<P, WN, WM, TN, TM, TAG, DMA>), grid, dim3(WN * WM * 64), lds, s, a);
-  if (probe) {
-    (void)hipEventRecord(g_probe.ev[2 * g_probe.used + 1], s);
-    g_probe.flops += 2.0 * a.M * a.N * a.Kp;
-    ++g_probe.used;
-  }
+  if (probe) probe_end(s, 2.0 * a.M * a.N * a.Kp);
 }
 
 template <class P>
@@ -437,7 +442,9 @@ void launch_gemm_tn(const GemmTN& a, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
     attr_set = true;
   }
+  const bool probe = a.N1 >= 128 && a.N2 >= 128 && probe_begin(PROBE_GEMM_TN, s);  // the H x H weight gradients
   hipLaunchKernelGGL((gemm_tn_kernel<P>), grid, dim3(256), 73728, s, a);
+  if (probe) probe_end(s, 2.0 * a.M * a.N1 * a.N2);
 }
 template void launch_gemm_tn<F32>(const GemmTN&, hipStream_t);
 template void launch_gemm_tn<BF16>(const GemmTN&, hipStream_t);

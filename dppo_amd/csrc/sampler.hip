@@ -1,6 +1,7 @@
 // See sampler.h.  gfx950 only.  Compiled with -ffp-contract=off so the posterior arithmetic is
 // the reference's op sequence (separate multiplies/adds, no fused contraction).
 #include "sampler.h"
+#include "gemm.h"
 
 namespace dppo {
 
@@ -266,7 +267,9 @@ static int launch_cfg(const SamplerGeom& g, const SampleArgs& a, hipStream_t s) 
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
+  const bool probe = probe_begin(PROBE_SAMPLER, s);
   hipLaunchKernelGGL(kern, dim3((a.B + 15) / 16), dim3(512), lds, s, a);
+  if (probe) probe_end(s, 2.0 * a.B * a.n_steps * ((double)g.in_dim * g.H + 2.0 * g.nb * g.H * g.H + (double)g.H * g.out_dim));
   return 0;
 }
 

@@ -193,11 +193,12 @@ int dppo_adamw_step(float* params, const float* grad, float* exp_avg, float* exp
                     double max_norm, dppo_stream_t stream);
 
 /* ---- measurement hook (bench.py only; process-wide, not thread-safe, off by default) ----------- */
-/* While armed, each launch of the dominant kernel -- the 128x128-tile MFMA gemm_nt on an H x H layer
- * (forward l1/l2, backward-data) -- is bracketed by HIP events on its launch stream.  dppo_probe_collect
- * waits for them, returns the summed kernel time, the launch count and the algorithmic FLOPs (2*M*N*K
- * per launch), and disarms. */
-int dppo_probe_arm(int max_launches);
+/* While armed for a kernel, each of its launches is bracketed by HIP events on the launch stream.
+ * kernel_id: 1 = gemm_nt on an H x H layer (layered path), 2 = gemm_tn weight gradient (N1,N2 >= 128),
+ * 3 = fused row-tile forward, 4 = fused row-tile backward, 5 = K-step sampler.  dppo_probe_collect waits for the
+ * events, returns the summed kernel time, the launch count and the summed ALGORITHMIC FLOPs (2 x MACs of the true,
+ * unpadded shapes), and disarms. */
+int dppo_probe_arm(int kernel_id, int max_launches);
 int dppo_probe_collect(double* total_ms_host, int* launches_host, double* flops_host);
 
 /* ---- tuning / micro-benchmark hooks (tools/ and tests only; never used by the product path) ----- */
