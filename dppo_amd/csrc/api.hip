@@ -122,6 +122,13 @@ static int check_prec(int prec) {
 #define DPPO_DISPATCH(prec, CALL)        \
   ((prec) == DPPO_PREC_F32 ? CALL(F32) : CALL(BF16))
 
+static int g_use_fused = 1;  // tuning knob 1: 1 = fused row-tile kernels where the shape is covered, 0 = layered GEMMs
+
+template <class P>
+static bool fused_ok(const dppo_net_desc& d) {
+  return g_use_fused && fused_rows_per_tile<P>(d) > 0 && d.out_dim <= 64 && d.hidden <= 512;
+}
+
 // ------------------------------------------------------------------------------------------------
 // pack
 // ------------------------------------------------------------------------------------------------
@@ -133,16 +140,18 @@ static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char*
   if (d.kind == 0)
     launch_time_table(prm + pl.te1_w, prm + pl.te1_b, prm + pl.te2_w, prm + pl.te2_b, d.time_dim, n_time,
                       (float*)(pk + L.temb), s);
-  launch_cast_pad<P>(prm + pl.W0, H, d.in_dim, d.in_dim, pk + L.W0, L.Kp0, s);
-  for (int b = 0; b < d.n_blocks; ++b) {
-    launch_cast_pad<P>(prm + pl.l1w[b], H, H, H, pk + L.W1[b], H, s);
-    launch_cast_pad<P>(prm + pl.l2w[b], H, H, H, pk + L.W2[b], H, s);
-    launch_transpose_cast<P>(prm + pl.l1w[b], H, H, H, 0, pk + L.W1T[b], H, s);
-    launch_transpose_cast<P>(prm + pl.l2w[b], H, H, H, 0, pk + L.W2T[b], H, s);
+  if (!fused_ok<P>(d)) {  // row-major operand copies of the layer-by-layer gemm_nt path (unused by the fused kernels)
+    launch_cast_pad<P>(prm + pl.W0, H, d.in_dim, d.in_dim, pk + L.W0, L.Kp0, s);
+    for (int b = 0; b < d.n_blocks; ++b) {
+      launch_cast_pad<P>(prm + pl.l1w[b], H, H, H, pk + L.W1[b], H, s);
+      launch_cast_pad<P>(prm + pl.l2w[b], H, H, H, pk + L.W2[b], H, s);
+      launch_transpose_cast<P>(prm + pl.l1w[b], H, H, H, 0, pk + L.W1T[b], H, s);
+      launch_transpose_cast<P>(prm + pl.l2w[b], H, H, H, 0, pk + L.W2T[b], H, s);
+    }
+    launch_cast_pad<P>(prm + pl.Wout, d.out_dim, H, H, pk + L.Wout, H, s);
+    // WoutT[h][o] = Wout[o][h] : src rows = out_dim, cols = H  -> dst [H][Kpo]
+    launch_transpose_cast<P>(prm + pl.Wout, d.out_dim, H, H, 0, pk + L.WoutT, L.Kpo, s);
   }
-  launch_cast_pad<P>(prm + pl.Wout, d.out_dim, H, H, pk + L.Wout, H, s);
-  // WoutT[h][o] = Wout[o][h] : src rows = out_dim, cols = H  -> dst [H][Kpo]
-  launch_transpose_cast<P>(prm + pl.Wout, d.out_dim, H, H, 0, pk + L.WoutT, L.Kpo, s);
   // W0tT[j][h] = W0[h][act_flat + j]
   if (d.kind == 0) launch_transpose_cast<P>(prm + pl.W0, H, d.time_dim, d.in_dim, d.act_flat, pk + L.W0tT, H, s);
   {
@@ -260,17 +269,10 @@ static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, b
   }
 }
 
-static int g_use_fused = 1;  // tuning knob 1: 1 = fused row-tile kernels where the shape is covered, 0 = layered GEMMs
-
 static void fill_bias_off(const dppo_net_desc& d, const ParamLayout& pl, int* off) {
   off[0] = (int)pl.b0;
   for (int b = 0; b < d.n_blocks; ++b) off[1 + 2 * b] = (int)pl.l1b[b], off[2 + 2 * b] = (int)pl.l2b[b];
   off[1 + 2 * d.n_blocks] = (int)pl.bout;
-}
-
-template <class P>
-static bool fused_ok(const dppo_net_desc& d) {
-  return g_use_fused && fused_rows_per_tile<P>(d) > 0 && d.out_dim <= 64 && d.hidden <= 512;
 }
 
 template <class P>

@@ -158,9 +158,9 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
   const int Kp0 = a.Kp0, nb = a.nb, M = a.M;
   const int in_rb = Kp0 * ES, in_km = kmask16(in_rb), KS0 = Kp0 / KB;
   const int total = KS0 + 2 * nb * KSH;
-  char* xin = smem;
-  char* bufA = xin + MT * in_rb;
+  char* bufA = smem;
   char* bufB = bufA + MT * HRB;
+  char* xin = bufB;  // the input tile is dead once layer 0 has run, before the first block writes bufB
   float* part = (float*)(bufB + MT * HRB);  // [KSPLIT][MR][OT*16 features][16 rows]
   const int fb = wid * 16 * TPW + 4 * TPW * g;
   const u32x4* os = a.ostream + lane;
@@ -261,9 +261,9 @@ __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs 
   const int nb = a.nb, M = a.M;
   const int in_rb = a.KpB0 * ES, in_km = kmask16(in_rb), KSB0 = a.KpB0 / KB;
   const int total = KSB0 + 2 * nb * KSH;
-  char* xin = smem;
-  char* bufA = xin + MT * in_rb;
+  char* bufA = smem;
   char* bufB = bufA + MT * HRB;
+  char* xin = bufB;  // d_out tile: consumed by the first layer, which emits into bufA
   const int fb = wid * 16 * TPW + 4 * TPW * g;
   const int ntiles = (M + MT - 1) / MT;
 
@@ -350,7 +350,9 @@ template <class P>
 static int pick_mr(int hidden) {
   const int tpw = hidden / 128;
   if (hidden % 128) return 0;
-  if (P::ESIZE == 2) return tpw == 2 || tpw == 4 ? 4 : (tpw == 8 ? 2 : 0);
+  // rows per tile = 16*MR: as many as the two [rows][H] LDS images (<= 64 KiB each) and 256 VGPRs allow --
+  // the per-tile weight stream is a fixed cost, so fewer, taller tiles win
+  if (P::ESIZE == 2) return tpw == 2 ? 8 : (tpw == 4 ? 4 : (tpw == 8 ? 2 : 0));
   return tpw == 2 ? 4 : (tpw == 4 ? 2 : (tpw == 8 ? 1 : 0));
 }
 template <class P>
@@ -387,8 +389,8 @@ template <class P, int TPW, int MR, int OT>
 static int launch_fwd_cfg(const FusedFwdArgs& a, hipStream_t s) {
   constexpr int ES = P::ESIZE, MT = 16 * MR, H = 128 * TPW;
   constexpr int KSPLIT = MR * OT >= 8 ? 1 : 8 / (MR * OT);
-  const size_t lds = (size_t)MT * a.Kp0 * ES + 2 * (size_t)MT * H * ES + (size_t)KSPLIT * MR * OT * 16 * 16 * 4;
-  if (lds > 160 * 1024) return -2;
+  const size_t lds = 2 * (size_t)MT * H * ES + (size_t)KSPLIT * MR * OT * 16 * 16 * 4;
+  if (lds > 160 * 1024 || a.Kp0 > H) return -2;
   static bool attr = false;
   raise_lds(fused_forward_kernel<P, TPW, MR, OT>, attr);
   const int ntiles = (a.M + MT - 1) / MT;
@@ -407,7 +409,7 @@ int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStrea
 #define DPPO_FWD(T, R, O) \
   if (tpw == T && mr == R && ot == O) return launch_fwd_cfg<P, T, R, O>(a, s);
   if constexpr (P::ESIZE == 2) {
-    DPPO_FWD(2, 4, 1) DPPO_FWD(2, 4, 4) DPPO_FWD(4, 4, 1) DPPO_FWD(4, 4, 4) DPPO_FWD(8, 2, 1) DPPO_FWD(8, 2, 4)
+    DPPO_FWD(2, 8, 1) DPPO_FWD(2, 8, 4) DPPO_FWD(4, 4, 1) DPPO_FWD(4, 4, 4) DPPO_FWD(8, 2, 1) DPPO_FWD(8, 2, 4)
   } else {
     DPPO_FWD(2, 4, 1) DPPO_FWD(2, 4, 4) DPPO_FWD(4, 2, 1) DPPO_FWD(4, 2, 4) DPPO_FWD(8, 1, 1) DPPO_FWD(8, 1, 4)
   }
@@ -420,8 +422,8 @@ template int launch_fused_forward<BF16>(const dppo_net_desc&, const FusedFwdArgs
 template <class P, int TPW, int MR>
 static int launch_bwd_cfg(const FusedBwdArgs& a, hipStream_t s) {
   constexpr int ES = P::ESIZE, MT = 16 * MR, H = 128 * TPW;
-  const size_t lds = (size_t)MT * a.KpB0 * ES + 2 * (size_t)MT * H * ES;
-  if (lds > 160 * 1024) return -2;
+  const size_t lds = 2 * (size_t)MT * H * ES;
+  if (lds > 160 * 1024 || a.KpB0 > H) return -2;
   static bool attr = false;
   raise_lds(fused_backward_kernel<P, TPW, MR>, attr);
   const int ntiles = (a.M + MT - 1) / MT;
@@ -438,7 +440,7 @@ int launch_fused_backward(const dppo_net_desc& d, const FusedBwdArgs& a, hipStre
 #define DPPO_BWD(T, R) \
   if (tpw == T && mr == R) return launch_bwd_cfg<P, T, R>(a, s);
   if constexpr (P::ESIZE == 2) {
-    DPPO_BWD(2, 4) DPPO_BWD(4, 4) DPPO_BWD(8, 2)
+    DPPO_BWD(2, 8) DPPO_BWD(4, 4) DPPO_BWD(8, 2)
   } else {
     DPPO_BWD(2, 4) DPPO_BWD(4, 2) DPPO_BWD(8, 1)
   }

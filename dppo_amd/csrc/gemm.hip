@@ -465,8 +465,37 @@ __global__ void slab_reduce_kernel(const float* slab, int splits, size_t n, floa
   for (; k < splits; ++k) p[k & 7] += slab[(size_t)k * n + i];
   out[i] = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) * scale;
 }
+// few columns, many partial rows (bias gradients over hundreds of tiles): 64 columns x 16 row-lanes per block,
+// 4 independent chains per lane, fixed combine order => reproducible
+__global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* in, int rows, size_t n, float* out, float scale) {
+  __shared__ float red[16][65];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const size_t c = (size_t)blockIdx.x * 64 + cl;
+  float p[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < n) {
+    int r = rl;
+    for (; r + 48 < rows; r += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) p[u] += in[(size_t)(r + 16 * u) * n + c];
+    }
+    for (; r < rows; r += 16) p[0] += in[(size_t)r * n + c];
+  }
+  red[rl][cl] = (p[0] + p[1]) + (p[2] + p[3]);
+  __syncthreads();
+  if (rl == 0 && c < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[i][cl];
+    out[c] = s * scale;
+  }
+}
+
 void launch_slab_reduce(const float* slab, int splits, size_t n, float* out, float scale, hipStream_t s) {
   if (n == 0) return;
+  if (n <= 16384 && splits >= 32) {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, s, slab, splits, n, out, scale);
+    return;
+  }
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slab, splits, n, out,
                      scale);
 }

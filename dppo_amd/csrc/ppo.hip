@@ -246,33 +246,43 @@ void launch_adv_moments(const float* adv_k, const int32_t* brow, int64_t N, doub
   hipLaunchKernelGGL(adv_moments_kernel, dim3(blocks), dim3(256), 0, s, adv_k, brow, N, moments);
 }
 
+// 16 lanes per sample (lane j owns chunk elements j, j+16, ...): every global access of a sample is one contiguous
+// segment; the two log-prob sums are reduced with 4 shuffles; scalar per-sample math is done redundantly by the 16 lanes
 template <class P>
 __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
   typedef typename P::elem_t E;
   __shared__ double sh[4];
-  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int sub = threadIdx.x & 15;
+  const int64_t n = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   const dppo_ppo_cfg& pc = a.pcfg;
   const int Kft = pc.ft_denoising_steps, AF = a.AF, Da = pc.action_dim;
   const int rh = pc.reward_horizon < pc.horizon_steps ? pc.reward_horizon : pc.horizon_steps;
   const int cnt = rh * Da;
   double s_pg = 0, s_v = 0, s_kl = 0, s_cf = 0, s_ratio = 0;
   const double Nn = a.moments[2];  // samples in the (global) minibatch: means and 1/N scaling use this count
-  if (n < a.N) {
-    const int b = a.brow[n], k = a.krow[n];
+  const bool live = n < a.N;
+  const int64_t nn = live ? n : a.N - 1;  // out-of-range lanes shadow the last sample (shuffles need all lanes) and write nothing
+  {
+    const int b = a.brow[nn], k = a.krow[nn];
     const dppo_step st = a.ksteps[k];
     const float* ch = a.gathered ? a.chains + (size_t)b * 2 * AF : a.chains + ((size_t)b * (Kft + 1) + k) * AF;
     const float* olp = a.gathered ? a.logprobs_k + (size_t)b * AF : a.logprobs_k + ((size_t)b * Kft + k) * AF;
-    const float* ep = a.eps + (size_t)n * a.lde;
+    const float* ep = a.eps + (size_t)nn * a.lde;
     const float var = st.std * st.std, lstd = logf(st.std);
     // ---- new / old log-probs, clamped to [-5, 2], averaged over the first `rh` chunk steps (:93-102)
     float sum_new = 0.f, sum_old = 0.f;
-    for (int j = 0; j < cnt; ++j) {
+    for (int j = sub; j < cnt; j += 16) {
       float mu, dmu;
       posterior(a.dcfg, st, ch[j], ep[j], mu, dmu);
       const float d = ch[AF + j] - mu;
       const float lp = -(d * d) / (2.f * var) - lstd - DPPO_LOG_SQRT_2PI;
       sum_new += fminf(fmaxf(lp, -5.f), 2.f);
       sum_old += fminf(fmaxf(olp[j], -5.f), 2.f);
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      sum_new += __shfl_xor(sum_new, o);
+      sum_old += __shfl_xor(sum_old, o);
     }
     const float newlp = sum_new / (float)cnt, oldlp = sum_old / (float)cnt;
     // ---- advantage: normalise over the minibatch, quantile clip, denoising discount (:129-144)
@@ -297,51 +307,65 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
     } else {
       eps_k = (float)k / (float)(Kft - 1);
     }
-    s_kl = (double)((ratio - 1.f) - logratio);
-    s_cf = fabsf(ratio - 1.f) > eps_k ? 1.0 : 0.0;
-    s_ratio = ratio;
     // ---- clipped surrogate (:170-174) and d L / d ratio with torch.max / clamp sub-gradients
     const float lo = 1.f - eps_k, hi = 1.f + eps_k;
     const float rc = fminf(fmaxf(ratio, lo), hi);
     const float pg1 = -adv * ratio, pg2 = -adv * rc;
-    s_pg = fmaxf(pg1, pg2);
     const float w1 = pg1 > pg2 ? 1.f : (pg1 == pg2 ? 0.5f : 0.f);
     const float within = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
     const float dL_dratio = -adv * (w1 + (1.f - w1) * within);
     const float coef = dL_dratio * ratio / ((float)Nn * (float)cnt);  // d mean(L) / d lp_j (before clamp mask)
-    E* de = (E*)a.d_eps + (size_t)n * a.ldde;
-    for (int j = 0; j < a.ldde; ++j) {
-      float gj = 0.f;
-      if (j < cnt) {
-        float mu, dmu;
-        posterior(a.dcfg, st, ch[j], ep[j], mu, dmu);
-        const float d = ch[AF + j] - mu;
-        const float lp = -(d * d) / (2.f * var) - lstd - DPPO_LOG_SQRT_2PI;
-        if (lp >= -5.f && lp <= 2.f) gj = coef * (d / var) * dmu;
-      }
-      de[j] = P::from_f32(gj);
-    }
     // ---- value loss (:177-189)
-    const float v = a.vnew[(size_t)n * a.ldv];
+    const float v = a.vnew[(size_t)nn * a.ldv];
     const float ret = a.returns_k[b];
-    float dv;
+    float dv, lv;
     if (pc.has_vclip) {
       const float ov = a.values_k[b];
       const float c = (float)pc.clip_vloss_coef;
       const float dlt = v - ov;
       const float vc = ov + fminf(fmaxf(dlt, -c), c);
       const float lu = (v - ret) * (v - ret), lc = (vc - ret) * (vc - ret);
-      s_v = 0.5 * (double)fmaxf(lu, lc);
+      lv = 0.5f * fmaxf(lu, lc);
       const float inr = (dlt >= -c && dlt <= c) ? 1.f : 0.f;
       const float wu = lu > lc ? 1.f : (lu == lc ? 0.5f : 0.f);
       dv = wu * (v - ret) + (1.f - wu) * (vc - ret) * inr;
     } else {
-      s_v = 0.5 * (double)((v - ret) * (v - ret));
+      lv = 0.5f * ((v - ret) * (v - ret));
       dv = v - ret;
     }
-    E* dvp = (E*)a.d_v + (size_t)n * a.lddv;
-    dvp[0] = P::from_f32(dv / (float)Nn);
-    for (int j = 1; j < a.lddv; ++j) dvp[j] = P::from_f32(0.f);
+    if (live) {
+      if (sub == 0) {
+        s_kl = (double)((ratio - 1.f) - logratio);
+        s_cf = fabsf(ratio - 1.f) > eps_k ? 1.0 : 0.0;
+        s_ratio = ratio;
+        s_pg = fmaxf(pg1, pg2);
+        s_v = lv;
+      }
+      // ---- d loss / d eps and d loss / d v, zero padded to the GEMM K width, 16 lanes x 4 elements per pass
+      E* de = (E*)a.d_eps + (size_t)n * a.ldde;
+      for (int j0 = 4 * sub; j0 < a.ldde; j0 += 64) {
+        float gq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j = j0 + q;
+          float gj = 0.f;
+          if (j < cnt) {
+            float mu, dmu;
+            posterior(a.dcfg, st, ch[j], ep[j], mu, dmu);
+            const float d = ch[AF + j] - mu;
+            const float lp = -(d * d) / (2.f * var) - lstd - DPPO_LOG_SQRT_2PI;
+            if (lp >= -5.f && lp <= 2.f) gj = coef * (d / var) * dmu;
+          }
+          gq[q] = gj;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) de[j0 + q] = P::from_f32(gq[q]);
+      }
+      E* dvp = (E*)a.d_v + (size_t)n * a.lddv;
+      for (int j0 = 4 * sub; j0 < a.lddv; j0 += 64)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dvp[j0 + q] = P::from_f32(j0 + q == 0 ? dv / (float)Nn : 0.f);
+    }
   }
   const double inv = 1.0 / Nn;
   s_pg = block_sum(s_pg, sh);
@@ -366,7 +390,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
 template <class P>
 void launch_ppo_loss(const LossArgs& a, hipStream_t s) {
   if (a.N <= 0) return;
-  hipLaunchKernelGGL((ppo_loss_kernel<P>), dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((ppo_loss_kernel<P>), dim3((unsigned)((a.N + 15) / 16)), dim3(256), 0, s, a);
 }
 template void launch_ppo_loss<F32>(const LossArgs&, hipStream_t);
 template void launch_ppo_loss<BF16>(const LossArgs&, hipStream_t);
