@@ -57,15 +57,24 @@ struct BF16 {
   static __device__ __forceinline__ float to_f32(elem_t x) { return bf2f(x); }
 };
 
-// nn.Mish = x * tanh(softplus(x)), softplus threshold 20 (torch default)
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
-__device__ __forceinline__ float mish_f(float x) { return x * tanhf(softplus_f(x)); }
+// nn.Mish = x * tanh(softplus(x)).  With e = exp(x): tanh(log(1 + e)) = ((1+e)^2 - 1) / ((1+e)^2 + 1)
+// = n / (n + 2), n = e (e + 2) -- exact algebra, no cancellation, one exp + one division instead of
+// expf + log1pf + tanhf (which made the Mish critic cost more than the 4x larger ReLU actor).  x is clamped at 20
+// for the exponential only (n / (n + 2) == 1 in fp32 from x ~ 9, matching torch's softplus threshold behaviour).
+__device__ __forceinline__ float mish_tanh_sp(float x, float& e) {
+  e = __expf(fminf(x, 20.f));
+  const float n = e * (e + 2.f);
+  return n / (n + 2.f);
+}
+__device__ __forceinline__ float mish_f(float x) {
+  float e;
+  return x * mish_tanh_sp(x, e);
+}
 __device__ __forceinline__ float mish_grad_f(float x) {
-  // d/dx [x tanh(sp(x))] = tanh(sp) + x (1 - tanh(sp)^2) sigmoid(x)   (sp' = sigmoid; =1 above the threshold)
-  float sp = softplus_f(x);
-  float th = tanhf(sp);
-  float sg = x > 20.f ? 1.f : 1.f / (1.f + expf(-x));
-  return th + x * (1.f - th * th) * sg;
+  // d/dx [x tanh(sp(x))] = tanh(sp) + x (1 - tanh(sp)^2) sigmoid(x)
+  float e;
+  const float th = mish_tanh_sp(x, e);
+  return th + x * (1.f - th * th) * (e / (1.f + e));
 }
 __device__ __forceinline__ float act_f(int act, float x) {
   return act == ACT_RELU ? fmaxf(x, 0.f) : (act == ACT_MISH ? mish_f(x) : x);
@@ -75,5 +84,15 @@ __device__ __forceinline__ float act_grad_f(int act, float x) {
 }
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Which features of its wave's 16*TPW-feature slice a lane owns in the streamed-weight kernels (sampler, fused):
+// MFMA output row i = 4g + e of tile tp is feature feat_off(g, tp) + e.  Tiles are grouped so that one 16-byte chunk
+// (EPC = 16 / ESIZE elements) holds consecutive features of ONE lane and the four lanes g = 0..3 own four consecutive
+// chunks: a store / load instruction of chunk group c then covers 64 contiguous bytes per batch row.
+template <class P>
+__host__ __device__ __forceinline__ constexpr int feat_off(int g, int tp) {
+  constexpr int EPC = 16 / P::ESIZE, TPC = EPC / 4;
+  return (tp / TPC) * (4 * EPC) + EPC * g + 4 * (tp % TPC);
+}
 
 }  // namespace dppo

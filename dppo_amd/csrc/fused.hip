@@ -76,14 +76,14 @@ struct Engine {
 // v[tp][m] (features fb + 4tp + e of row 16m + r) -> activated elem chunks, written to the LDS image `lds`
 // (may be null) and to the global [M][H] tensor `glb` (may be null)
 template <class P, int TPW, int MR>
-__device__ __forceinline__ void emit(const f32x4 (&v)[TPW][MR], int actk, char* lds, void* glb, int H, int fb, int r,
-                                     int row0, int M) {
+__device__ __forceinline__ void emit(const f32x4 (&v)[TPW][MR], int actk, char* lds, void* glb, int H, int wbase, int g,
+                                     int r, int row0, int M) {
   constexpr int ES = P::ESIZE;
   const int HRB = H * ES;
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
     const int grow = row0 + 16 * m + r;
-    char* gp = glb != nullptr && grow < M ? (char*)glb + ((size_t)grow * H + fb) * ES : nullptr;
+    char* gp = glb != nullptr && grow < M ? (char*)glb + (size_t)grow * HRB : nullptr;
     char* lp = lds != nullptr ? lds + (16 * m + r) * HRB : nullptr;
     if constexpr (ES == 4) {
 #pragma unroll
@@ -93,9 +93,9 @@ __device__ __forceinline__ void emit(const f32x4 (&v)[TPW][MR], int actk, char* 
         o.y = __float_as_uint(act_f(actk, v[tp][m][1]));
         o.z = __float_as_uint(act_f(actk, v[tp][m][2]));
         o.w = __float_as_uint(act_f(actk, v[tp][m][3]));
-        const int c = ((fb + 4 * tp) * 4) >> 4;
+        const int c = ((wbase + feat_off<P>(g, tp)) * 4) >> 4;
         if (lp) *(u32x4*)(lp + ((c ^ (r & 15)) << 4)) = o;
-        if (gp) *(u32x4*)(gp + tp * 16) = o;
+        if (gp) *(u32x4*)(gp + c * 16) = o;
       }
     } else {
 #pragma unroll
@@ -105,9 +105,9 @@ __device__ __forceinline__ void emit(const f32x4 (&v)[TPW][MR], int actk, char* 
         o.y = (uint32_t)f2bf(act_f(actk, v[tp][m][2])) | ((uint32_t)f2bf(act_f(actk, v[tp][m][3])) << 16);
         o.z = (uint32_t)f2bf(act_f(actk, v[tp + 1][m][0])) | ((uint32_t)f2bf(act_f(actk, v[tp + 1][m][1])) << 16);
         o.w = (uint32_t)f2bf(act_f(actk, v[tp + 1][m][2])) | ((uint32_t)f2bf(act_f(actk, v[tp + 1][m][3])) << 16);
-        const int c = ((fb + 4 * tp) * 2) >> 4;
+        const int c = ((wbase + feat_off<P>(g, tp)) * 2) >> 4;
         if (lp) *(u32x4*)(lp + ((c ^ (r & 15)) << 4)) = o;
-        if (gp) *(u32x4*)(gp + (tp / 2) * 16) = o;
+        if (gp) *(u32x4*)(gp + c * 16) = o;
       }
     }
   }
@@ -120,14 +120,15 @@ struct Chunks {
   static constexpr int CH = P::ESIZE == 4 ? TPW : TPW / 2;
 };
 template <class P, int MR, int CH>
-__device__ __forceinline__ void fetch(u32x4 (&d)[MR][CH], const void* glb, int H, int fb, int r, int row0, int M) {
-  constexpr int ES = P::ESIZE;
+__device__ __forceinline__ void fetch(u32x4 (&d)[MR][CH], const void* glb, int H, int wbase, int g, int r, int row0,
+                                      int M) {
+  constexpr int ES = P::ESIZE, TPC = ES == 4 ? 1 : 2;  // MFMA tiles per 16-byte chunk
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
     const int grow = row0 + 16 * m + r;
-    const char* gp = (const char*)glb + ((size_t)(grow < M ? grow : M - 1) * H + fb) * ES;
+    const char* gp = (const char*)glb + (size_t)(grow < M ? grow : M - 1) * H * ES;
 #pragma unroll
-    for (int c = 0; c < CH; ++c) d[m][c] = *(const u32x4*)(gp + c * 16);
+    for (int c = 0; c < CH; ++c) d[m][c] = *(const u32x4*)(gp + (size_t)(wbase + feat_off<P>(g, c * TPC)) * ES);
   }
 }
 template <class P, int MR, int CH>
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
   char* bufB = bufA + MT * HRB;
   char* xin = bufB;  // the input tile is dead once layer 0 has run, before the first block writes bufB
   float* part = (float*)(bufB + MT * HRB);  // [KSPLIT][MR][OT*16 features][16 rows]
-  const int fb = wid * 16 * TPW + 4 * TPW * g;
+  const int wbase = wid * 16 * TPW;  // lane features: wbase + feat_off<P>(g, tp) + e
   const u32x4* os = a.ostream + lane;
 
   Engine<P, TPW, MR, PD> eng;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
       for (int tp = 0; tp < TPW; ++tp) {
         f32x4 b;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) b[e] = a.params[boff + fb + 4 * tp + e];
+        for (int e = 0; e < 4; ++e) b[e] = a.params[boff + wbase + feat_off<P>(g, tp) + e];
 #pragma unroll
         for (int m = 0; m < MR; ++m) acc[tp][m] = b;
       }
@@ -193,18 +194,18 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
 #pragma unroll
       for (int m = 0; m < MR; ++m) h[tp][m] = acc[tp][m];
     if (nb > 0) {
-      if (a.hpre[0] != nullptr) emit<P, TPW, MR>(h, ACT_NONE, nullptr, a.hpre[0], H, fb, r, row0, M);
-      emit<P, TPW, MR>(h, a.act, bufA, a.a1[0], H, fb, r, row0, M);
+      if (a.hpre[0] != nullptr) emit<P, TPW, MR>(h, ACT_NONE, nullptr, a.hpre[0], H, wbase, g, r, row0, M);
+      emit<P, TPW, MR>(h, a.act, bufA, a.a1[0], H, wbase, g, r, row0, M);
     } else {
-      emit<P, TPW, MR>(h, ACT_NONE, bufA, a.hpre[0], H, fb, r, row0, M);
+      emit<P, TPW, MR>(h, ACT_NONE, bufA, a.hpre[0], H, wbase, g, r, row0, M);
     }
     __syncthreads();
     // ---- residual blocks
     for (int b = 0; b < nb; ++b) {
       bias_init(a.bias_off[1 + 2 * b]);
       eng.run(acc, bufA, HRB, 15, KSH, r, g);
-      if (a.z1[b] != nullptr) emit<P, TPW, MR>(acc, ACT_NONE, nullptr, a.z1[b], H, fb, r, row0, M);
-      emit<P, TPW, MR>(acc, a.act, bufB, a.a2[b], H, fb, r, row0, M);
+      if (a.z1[b] != nullptr) emit<P, TPW, MR>(acc, ACT_NONE, nullptr, a.z1[b], H, wbase, g, r, row0, M);
+      emit<P, TPW, MR>(acc, a.act, bufB, a.a2[b], H, wbase, g, r, row0, M);
       __syncthreads();
       bias_init(a.bias_off[2 + 2 * b]);
       eng.run(acc, bufB, HRB, 15, KSH, r, g);
@@ -213,10 +214,10 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
 #pragma unroll
         for (int m = 0; m < MR; ++m) h[tp][m] += acc[tp][m];
       if (b + 1 < nb) {
-        if (a.hpre[b + 1] != nullptr) emit<P, TPW, MR>(h, ACT_NONE, nullptr, a.hpre[b + 1], H, fb, r, row0, M);
-        emit<P, TPW, MR>(h, a.act, bufA, a.a1[b + 1], H, fb, r, row0, M);
+        if (a.hpre[b + 1] != nullptr) emit<P, TPW, MR>(h, ACT_NONE, nullptr, a.hpre[b + 1], H, wbase, g, r, row0, M);
+        emit<P, TPW, MR>(h, a.act, bufA, a.a1[b + 1], H, wbase, g, r, row0, M);
       } else {
-        emit<P, TPW, MR>(h, ACT_NONE, bufA, a.hpre[nb], H, fb, r, row0, M);
+        emit<P, TPW, MR>(h, ACT_NONE, bufA, a.hpre[nb], H, wbase, g, r, row0, M);
       }
       __syncthreads();
     }
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs 
   char* bufA = smem;
   char* bufB = bufA + MT * HRB;
   char* xin = bufB;  // d_out tile: consumed by the first layer, which emits into bufA
-  const int fb = wid * 16 * TPW + 4 * TPW * g;
+  const int wbase = wid * 16 * TPW;  // lane features: wbase + feat_off<P>(g, tp) + e
   const int ntiles = (M + MT - 1) / MT;
 
   Engine<P, TPW, MR, PD> eng;
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs 
         x += __shfl_xor(x, 8);
         s[e] = x;
       }
-      if (r == 0) *(f32x4*)(a.colsum + ((size_t)slot * ntiles + tile) * H + fb + 4 * tp) = s;
+      if (r == 0) *(f32x4*)(a.colsum + ((size_t)slot * ntiles + tile) * H + wbase + feat_off<P>(g, tp)) = s;
     }
   };
 
@@ -308,13 +309,13 @@ __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs 
     for (int tp = 0; tp < TPW; ++tp)
 #pragma unroll
       for (int m = 0; m < MR; ++m) dh[tp][m] = acc[tp][m];
-    emit<P, TPW, MR>(dh, ACT_NONE, bufA, a.dh[nb], H, fb, r, row0, M);
+    emit<P, TPW, MR>(dh, ACT_NONE, bufA, a.dh[nb], H, wbase, g, r, row0, M);
     colsum(dh, 0, tile);
     __syncthreads();
     for (int b = nb - 1; b >= 0; --b) {
       // ---- dz1 = (dh . W2) * act'(z1)
       u32x4 d[MR][Chunks<P, TPW>::CH];
-      fetch<P>(d, a.m1[b], H, fb, r, row0, M);  // issued ahead of the layer: latency hides under it
+      fetch<P>(d, a.m1[b], H, wbase, g, r, row0, M);  // issued ahead of the layer: latency hides under it
       zero_acc();
       eng.run(acc, bufA, HRB, 15, KSH, r, g);
 #pragma unroll
@@ -323,11 +324,11 @@ __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs 
         for (int m = 0; m < MR; ++m)
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[tp][m][e] *= grad_at<P>(d, a.act, tp, m, e);
-      emit<P, TPW, MR>(acc, ACT_NONE, bufB, a.dz1[b], H, fb, r, row0, M);
+      emit<P, TPW, MR>(acc, ACT_NONE, bufB, a.dz1[b], H, wbase, g, r, row0, M);
       colsum(acc, (nb + 1) + (nb - 1 - b), tile);
       __syncthreads();
       // ---- dh[b] = dh[b+1] + (dz1 . W1) * act'(h_b)
-      fetch<P>(d, a.m0[b], H, fb, r, row0, M);
+      fetch<P>(d, a.m0[b], H, wbase, g, r, row0, M);
       zero_acc();
       eng.run(acc, bufB, HRB, 15, KSH, r, g);
 #pragma unroll
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs 
         for (int m = 0; m < MR; ++m)
 #pragma unroll
           for (int e = 0; e < 4; ++e) dh[tp][m][e] += acc[tp][m][e] * grad_at<P>(d, a.act, tp, m, e);
-      emit<P, TPW, MR>(dh, ACT_NONE, bufA, a.dh[b], H, fb, r, row0, M);
+      emit<P, TPW, MR>(dh, ACT_NONE, bufA, a.dh[b], H, wbase, g, r, row0, M);
       colsum(dh, nb - b, tile);
       __syncthreads();
     }
@@ -459,7 +460,7 @@ __global__ void pack_hidden_strided_kernel(const float* W, long rs, long cs, int
   const int ks = (blockIdx.x / TPW) % KS;
   const int w = blockIdx.x / (TPW * KS);
   const int r = lane & 15, g = lane >> 4;
-  const int feat = w * 16 * TPW + 4 * TPW * (r >> 2) + 4 * tp + (r & 3);
+  const int feat = w * 16 * TPW + feat_off<P>(r >> 2, tp) + (r & 3);
   constexpr int EPL = 16 / P::ESIZE;
   const int k0 = ks * P::KB + EPL * g;
   uint32_t out[4];

@@ -252,10 +252,33 @@ template <class P>
 __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
   typedef typename P::elem_t E;
   __shared__ double sh[4];
-  const int sub = threadIdx.x & 15;
-  const int64_t n = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  // per-k constants (only Kft distinct values exist): denoising discount and clip range, built once per block in
+  // the reference's precision recipe (double pow / exp, then fp32) instead of per lane
+  extern __shared__ float tab[];  // [Kft] discount, [Kft] eps_k, [2] adv mean / std
   const dppo_ppo_cfg& pc = a.pcfg;
   const int Kft = pc.ft_denoising_steps, AF = a.AF, Da = pc.action_dim;
+  for (int k = threadIdx.x; k < Kft; k += 256) {
+    tab[k] = (float)pow(pc.gamma_denoising, (double)(Kft - k - 1));
+    float ek;
+    if (Kft > 1) {
+      const float t = (float)k / (float)(Kft - 1);
+      const float num = expf((float)pc.clip_ploss_coef_rate * t) - 1.f;
+      ek = (float)pc.clip_ploss_coef_base +
+           (float)(pc.clip_ploss_coef - pc.clip_ploss_coef_base) * num / (float)(exp(pc.clip_ploss_coef_rate) - 1.0);
+    } else {
+      ek = (float)k / (float)(Kft - 1);
+    }
+    tab[Kft + k] = ek;
+  }
+  if (threadIdx.x == 0) {
+    const double Nm = a.moments[2], mean = a.moments[0] / Nm;
+    const double varu = (a.moments[1] - Nm * mean * mean) / (Nm - 1.0);  // unbiased (torch.std)
+    tab[2 * Kft] = (float)mean;
+    tab[2 * Kft + 1] = (float)sqrt(varu > 0 ? varu : 0);
+  }
+  __syncthreads();
+  const int sub = threadIdx.x & 15;
+  const int64_t n = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   const int rh = pc.reward_horizon < pc.horizon_steps ? pc.reward_horizon : pc.horizon_steps;
   const int cnt = rh * Da;
   double s_pg = 0, s_v = 0, s_kl = 0, s_cf = 0, s_ratio = 0;
@@ -287,26 +310,13 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
     const float newlp = sum_new / (float)cnt, oldlp = sum_old / (float)cnt;
     // ---- advantage: normalise over the minibatch, quantile clip, denoising discount (:129-144)
     float adv = a.adv_k[b];
-    const double mean = a.moments[0] / Nn;
-    if (pc.norm_adv) {
-      const double varu = (a.moments[1] - Nn * mean * mean) / (Nn - 1.0);  // unbiased (torch.std)
-      const float sd = (float)sqrt(varu > 0 ? varu : 0);
-      adv = (adv - (float)mean) / (sd + 1e-8f);
-    }
+    if (pc.norm_adv) adv = (adv - tab[2 * Kft]) / (tab[2 * Kft + 1] + 1e-8f);
     if (pc.has_adv_clip) adv = fminf(fmaxf(adv, pc.adv_clip_lo), pc.adv_clip_hi);
-    adv *= (float)pow(pc.gamma_denoising, (double)(Kft - k - 1));
+    adv *= tab[k];
     // ---- ratio, per-step clip range (:147-159)
     const float logratio = newlp - oldlp;
     const float ratio = expf(logratio);
-    float eps_k;
-    if (Kft > 1) {
-      const float t = (float)k / (float)(Kft - 1);
-      const float num = expf((float)pc.clip_ploss_coef_rate * t) - 1.f;
-      eps_k = (float)pc.clip_ploss_coef_base +
-              (float)(pc.clip_ploss_coef - pc.clip_ploss_coef_base) * num / (float)(exp(pc.clip_ploss_coef_rate) - 1.0);
-    } else {
-      eps_k = (float)k / (float)(Kft - 1);
-    }
+    const float eps_k = tab[Kft + k];
     // ---- clipped surrogate (:170-174) and d L / d ratio with torch.max / clamp sub-gradients
     const float lo = 1.f - eps_k, hi = 1.f + eps_k;
     const float rc = fminf(fmaxf(ratio, lo), hi);
@@ -390,7 +400,8 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
 template <class P>
 void launch_ppo_loss(const LossArgs& a, hipStream_t s) {
   if (a.N <= 0) return;
-  hipLaunchKernelGGL((ppo_loss_kernel<P>), dim3((unsigned)((a.N + 15) / 16)), dim3(256), 0, s, a);
+  const size_t lds = (size_t)(2 * a.pcfg.ft_denoising_steps + 2) * sizeof(float);
+  hipLaunchKernelGGL((ppo_loss_kernel<P>), dim3((unsigned)((a.N + 15) / 16)), dim3(256), lds, s, a);
 }
 template void launch_ppo_loss<F32>(const LossArgs&, hipStream_t);
 template void launch_ppo_loss<BF16>(const LossArgs&, hipStream_t);

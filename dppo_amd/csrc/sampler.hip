@@ -72,7 +72,7 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
   const u32x4* ws[2] = {a.wstream[0] + wid * wave_stride + lane, a.wstream[1] + wid * wave_stride + lane};
   const u32x4* os[2] = {a.ostream[0] + (size_t)wid * CNT * OT * 64 + lane,
                         a.ostream[1] + (size_t)wid * CNT * OT * 64 + lane};
-  const int fb = wid * 16 * TPW + 4 * TPW * g;  // first of this lane's 4*TPW consecutive hidden features
+  const int wbase = wid * 16 * TPW;  // this wave's feature slice; the lane's features: wbase + feat_off<P>(g, tp) + e
 
   u32x4 ring[PD][TPW];
   {
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
 #pragma unroll
       for (int tp = 0; tp < TPW; ++tp)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[tp][e] = prm[boff + fb + 4 * tp + e];
+        for (int e = 0; e < 4; ++e) acc[tp][e] = prm[boff + wbase + feat_off<P>(g, tp) + e];
       for (int k0 = 0; k0 < nks; k0 += PD) {
 #pragma unroll
         for (int p = 0; p < PD; ++p) {
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
       if constexpr (ES == 4) {
 #pragma unroll
         for (int tp = 0; tp < TPW; ++tp) {
-          const int c = ((fb + 4 * tp) * 4) >> 4;
+          const int c = ((wbase + feat_off<P>(g, tp)) * 4) >> 4;
           float4 o = make_float4(act_f(actk, v[tp][0]), act_f(actk, v[tp][1]), act_f(actk, v[tp][2]),
                                  act_f(actk, v[tp][3]));
           *(float4*)(dst + r * HRB + ((c ^ (r & 15)) << 4)) = o;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
       } else {
 #pragma unroll
         for (int tp = 0; tp < TPW; tp += 2) {
-          const int c = ((fb + 4 * tp) * 2) >> 4;
+          const int c = ((wbase + feat_off<P>(g, tp)) * 2) >> 4;
           u32x4 o;
           o.x = (uint32_t)f2bf(act_f(actk, v[tp][0])) | ((uint32_t)f2bf(act_f(actk, v[tp][1])) << 16);
           o.y = (uint32_t)f2bf(act_f(actk, v[tp][2])) | ((uint32_t)f2bf(act_f(actk, v[tp][3])) << 16);
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
             o.w = (uint32_t)f2bf(act_f(actk, v[tp + 1][2])) | ((uint32_t)f2bf(act_f(actk, v[tp + 1][3])) << 16);
             *(u32x4*)(dst + r * HRB + ((c ^ (r & 15)) << 4)) = o;
           } else {
-            *(u32x2*)(dst + r * HRB + ((c ^ (r & 15)) << 4) + (((fb * 2) & 15))) = (u32x2){o.x, o.y};
+            *(u32x2*)(dst + r * HRB + ((c ^ (r & 15)) << 4)) = (u32x2){o.x, o.y};
           }
         }
       }
@@ -293,7 +293,7 @@ template int launch_sample_chain<BF16>(const SamplerGeom&, const SampleArgs&, hi
 // fragment-stream packing
 // ------------------------------------------------------------------------------------------------
 // hidden stream: [wave w][position][tp][lane] u32x4.  Lane (r,g) of tile tp holds
-// W[feature(w,tp,r)][ks*KB + (16/ES)*g + 0..], feature(w,tp,i) = w*16*TPW + 4*TPW*(i>>2) + 4*tp + (i&3).
+// W[feature(w,tp,r)][ks*KB + (16/ES)*g + 0..], feature(w,tp,i) = w*16*TPW + feat_off(i>>2, tp) + (i&3)  (common.h).
 template <class P>
 __global__ void pack_hidden_kernel(const float* W, int in_valid, int ld, int KS, int TPW, int pos0, int total_pos,
                                    u32x4* stream) {
@@ -302,7 +302,7 @@ __global__ void pack_hidden_kernel(const float* W, int in_valid, int ld, int KS,
   const int ks = (blockIdx.x / TPW) % KS;
   const int w = blockIdx.x / (TPW * KS);
   const int r = lane & 15, g = lane >> 4;
-  const int feat = w * 16 * TPW + 4 * TPW * (r >> 2) + 4 * tp + (r & 3);
+  const int feat = w * 16 * TPW + feat_off<P>(r >> 2, tp) + (r & 3);
   constexpr int EPL = 16 / P::ESIZE;  // elements per lane
   const int k0 = ks * P::KB + EPL * g;
   uint32_t out[4];
