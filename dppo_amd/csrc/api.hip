@@ -156,22 +156,27 @@ static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char*
   if (d.kind == 0) launch_transpose_cast<P>(prm + pl.W0, H, d.time_dim, d.in_dim, d.act_flat, pk + L.W0tT, H, s);
   {
     const SamplerGeom g = sampler_geom<P>(d);
-    u32x4* ss = (u32x4*)(pk + L.sstream);
-    launch_pack_hidden<P>(prm + pl.W0, H, d.in_dim, d.in_dim, g.KS0, g.TPW, 0, g.total_pos, ss, s);
-    for (int b = 0; b < d.n_blocks; ++b) {
-      launch_pack_hidden<P>(prm + pl.l1w[b], H, H, H, g.KSH, g.TPW, g.KS0 + 2 * b * g.KSH, g.total_pos, ss, s);
-      launch_pack_hidden<P>(prm + pl.l2w[b], H, H, H, g.KSH, g.TPW, g.KS0 + (2 * b + 1) * g.KSH, g.total_pos, ss, s);
-    }
-    launch_pack_out<P>(prm + pl.Wout, d.out_dim, H, g.OT, g.CNT, (u32x4*)(pk + L.ostream), s);
-    // backward stream, top down: [dh = d_out . Wout][block nb-1: W2^T, W1^T] ... [block 0: W2^T, W1^T];
-    // "feature f, contraction index k" of a transposed layer is W[k][f] = W[k*H + f]
     const FusedGeom fg = fused_geom<P>(d);
-    u32x4* bs = (u32x4*)(pk + L.bstream);
-    launch_pack_hidden_strided<P>(prm + pl.Wout, 1, H, d.out_dim, fg.KSB0, g.TPW, 0, fg.total_pos, bs, s);
-    for (int b = d.n_blocks - 1, pos = fg.KSB0; b >= 0; --b, pos += 2 * g.KSH) {
-      launch_pack_hidden_strided<P>(prm + pl.l2w[b], 1, H, H, g.KSH, g.TPW, pos, fg.total_pos, bs, s);
-      launch_pack_hidden_strided<P>(prm + pl.l1w[b], 1, H, H, g.KSH, g.TPW, pos + g.KSH, fg.total_pos, bs, s);
+    // forward stream [L0][b: l1, l2]... and backward stream, top down: [dh = d_out . Wout][b = nb-1..0: W2^T, W1^T]
+    // ("feature f, contraction index k" of a transposed layer is W[k][f] = W[k*H + f]); one launch each
+    PackStream fs, bs;
+    memset(&fs, 0, sizeof(fs));
+    memset(&bs, 0, sizeof(bs));
+    fs.TPW = bs.TPW = g.TPW, fs.total_pos = g.total_pos, bs.total_pos = fg.total_pos;
+    fs.stream = (u32x4*)(pk + L.sstream), bs.stream = (u32x4*)(pk + L.bstream);
+    fs.layer[fs.n_layers++] = PackLayer{prm + pl.W0, d.in_dim, 1, d.in_dim, g.KS0, 0};
+    for (int b = 0; b < d.n_blocks; ++b) {
+      fs.layer[fs.n_layers++] = PackLayer{prm + pl.l1w[b], H, 1, H, g.KSH, g.KS0 + 2 * b * g.KSH};
+      fs.layer[fs.n_layers++] = PackLayer{prm + pl.l2w[b], H, 1, H, g.KSH, g.KS0 + (2 * b + 1) * g.KSH};
     }
+    bs.layer[bs.n_layers++] = PackLayer{prm + pl.Wout, 1, H, d.out_dim, fg.KSB0, 0};
+    for (int b = d.n_blocks - 1, pos = fg.KSB0; b >= 0; --b, pos += 2 * g.KSH) {
+      bs.layer[bs.n_layers++] = PackLayer{prm + pl.l2w[b], 1, H, H, g.KSH, pos};
+      bs.layer[bs.n_layers++] = PackLayer{prm + pl.l1w[b], 1, H, H, g.KSH, pos + g.KSH};
+    }
+    launch_pack_stream<P>(fs, s);
+    launch_pack_stream<P>(bs, s);
+    launch_pack_out<P>(prm + pl.Wout, d.out_dim, H, g.OT, g.CNT, (u32x4*)(pk + L.ostream), s);
   }
   return check_launch();
 }
@@ -386,18 +391,23 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
     }
     for (int b = 0; b <= nb; ++b) f.dh[b] = B.dh_all[b];
     if (launch_fused_backward<P>(d, f, s) == 0) {
-      const size_t tsz = (size_t)B.tiles * H;
-      auto bias_grad = [&](int slot, float* out) { launch_slab_reduce(B.tile_colsum + slot * tsz, B.tiles, (size_t)H, out, 1.f, s); };
+      // bias gradients = column sums, reduced over tiles in one launch; slot order: dh[nb..0], then dz1[nb-1..0]
+      SlotOuts so;
+      memset(&so, 0, sizeof(so));
+      so.n_slots = 2 * nb + 1;
+      for (int b = nb - 1; b >= 0; --b) {
+        so.out[nb - (b + 1)] = grad + pl.l2b[b];
+        so.out[(nb + 1) + (nb - 1 - b)] = grad + pl.l1b[b];
+      }
+      so.out[nb] = grad + pl.b0;
+      launch_reduce_slots(B.tile_colsum, B.tiles, H, so, s);
       weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.hE, H, H, M, B, grad + pl.Wout, H, s);
       launch_colsum<P>(B.d_out, (int)M, d.out_dim, L.Kpo, B.part, REDUCE_BLOCKS, grad + pl.bout, 1.f, s);
       for (int b = nb - 1; b >= 0; --b) {
         weight_grad<P>(B.dh_all[b + 1], H, H, B.a2[b], H, H, M, B, grad + pl.l2w[b], H, s);
-        bias_grad(nb - (b + 1), grad + pl.l2b[b]);
         weight_grad<P>(B.dz1_all[b], H, H, B.a1[b], H, H, M, B, grad + pl.l1w[b], H, s);
-        bias_grad((nb + 1) + (nb - 1 - b), grad + pl.l1b[b]);
       }
       weight_grad<P>(B.dh_all[0], H, H, B.in, L.Kp0, d.in_dim, M, B, grad + pl.W0, d.in_dim, s);
-      bias_grad(nb, grad + pl.b0);
       if (d.kind == 0) time_embedding_grad<P>(d, prm, pk, L, M, B, B.dh_all[0], grad, krow, ksteps, Kft, s);
       return;
     }
@@ -655,10 +665,12 @@ struct PpoWs {
   MlpBufs<P> A, C;
   int32_t *brow, *krow;
   double* moments;
+  double* loss_partial;
 };
 template <class P>
 static size_t carve_ppo(Carver& c, const dppo_net_desc& a, const dppo_net_desc& cr, int64_t N, PpoWs<P>& W) {
   W.moments = (double*)c.take(256);
+  W.loss_partial = (double*)c.take((size_t)loss_blocks(N) * 8 * sizeof(double));
   W.brow = (int32_t*)c.take((size_t)N * 4);
   W.krow = (int32_t*)c.take((size_t)N * 4);
   carve_mlp<P>(c, a, N, true, true, W.A);
@@ -709,6 +721,7 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   la.ksteps = ksteps, la.dcfg = dcfg, la.pcfg = pcfg, la.AF = a.act_flat, la.N = N;
   la.moments = gmom ? gmom : W.moments;
   la.d_eps = W.A.d_out, la.ldde = LA.Kpo, la.d_v = W.C.d_out, la.lddv = LC.Kpo, la.stats = stats;
+  la.partial = W.loss_partial;
   launch_ppo_loss<P>(la, s);
   mlp_backward<P>(a, ap, ak, LA, N, W.A, agrad, W.krow, ksteps, Kft, s);
   mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s);

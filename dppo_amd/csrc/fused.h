@@ -66,9 +66,26 @@ int launch_fused_backward(const dppo_net_desc& d, const FusedBwdArgs& a, hipStre
 template <class P>
 int fused_rows_per_tile(const dppo_net_desc& d);  // 16*MR for this (hidden, precision), 0 if not covered
 
-// generalised fragment packing: element (feature f, k) of the layer's weight matrix is W[f*rs + k*cs]
+// Fragment packing of a whole stream in ONE launch: layer l occupies positions [pos0, pos0 + KS); element
+// (feature f, contraction index k) of its weight matrix is W[f*rs + k*cs] (rs = ld, cs = 1 for W; rs = 1, cs = ld for W^T)
+struct PackLayer {
+  const float* W;
+  long rs, cs;
+  int in_valid, KS, pos0;
+};
+struct PackStream {
+  PackLayer layer[1 + 2 * MAX_BLOCKS];
+  int n_layers, TPW, total_pos;
+  u32x4* stream;
+};
 template <class P>
-void launch_pack_hidden_strided(const float* W, long rs, long cs, int in_valid, int KS, int TPW, int pos0,
-                                int total_pos, u32x4* stream, hipStream_t s);
+void launch_pack_stream(const PackStream& d, hipStream_t s);
+
+// out[slot][c] = sum_t in[slot][t][c]  for c < n, one launch for all slots (bias gradients from per-tile column sums)
+struct SlotOuts {
+  float* out[2 * MAX_BLOCKS + 1];
+  int n_slots;
+};
+void launch_reduce_slots(const float* in, int tiles, int n, const SlotOuts& o, hipStream_t s);
 
 }  // namespace dppo

@@ -451,40 +451,70 @@ int launch_fused_backward(const dppo_net_desc& d, const FusedBwdArgs& a, hipStre
 template int launch_fused_backward<F32>(const dppo_net_desc&, const FusedBwdArgs&, hipStream_t);
 template int launch_fused_backward<BF16>(const dppo_net_desc&, const FusedBwdArgs&, hipStream_t);
 
-// fragment packing with arbitrary strides (W^T streams of the backward pass)
+// fragment packing of a whole stream: blockIdx.y = layer, blockIdx.x = (wave, k-step, tile)
 template <class P>
-__global__ void pack_hidden_strided_kernel(const float* W, long rs, long cs, int in_valid, int KS, int TPW, int pos0,
-                                           int total_pos, u32x4* stream) {
+__global__ void pack_stream_kernel(const PackStream d) {
+  const PackLayer L = d.layer[blockIdx.y];
+  const int TPW = d.TPW;
+  if ((int)blockIdx.x >= SAMPLER_WAVES * L.KS * TPW) return;
   const int lane = threadIdx.x & 63;
   const int tp = blockIdx.x % TPW;
-  const int ks = (blockIdx.x / TPW) % KS;
-  const int w = blockIdx.x / (TPW * KS);
+  const int ks = (blockIdx.x / TPW) % L.KS;
+  const int w = blockIdx.x / (TPW * L.KS);
   const int r = lane & 15, g = lane >> 4;
-  const int feat = w * 16 * TPW + feat_off<P>(r >> 2, tp) + (r & 3);
+  const long feat = w * 16 * TPW + feat_off<P>(r >> 2, tp) + (r & 3);
   constexpr int EPL = 16 / P::ESIZE;
   const int k0 = ks * P::KB + EPL * g;
   uint32_t out[4];
   if constexpr (P::ESIZE == 4) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) out[j] = __float_as_uint(k0 + j < in_valid ? W[feat * rs + (k0 + j) * cs] : 0.f);
+    for (int j = 0; j < 4; ++j) out[j] = __float_as_uint(k0 + j < L.in_valid ? L.W[feat * L.rs + (k0 + j) * L.cs] : 0.f);
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = k0 + 2 * j;
-      const float lo = k < in_valid ? W[feat * rs + k * cs] : 0.f;
-      const float hi = k + 1 < in_valid ? W[feat * rs + (k + 1) * cs] : 0.f;
+      const float lo = k < L.in_valid ? L.W[feat * L.rs + k * L.cs] : 0.f;
+      const float hi = k + 1 < L.in_valid ? L.W[feat * L.rs + (k + 1) * L.cs] : 0.f;
       out[j] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
     }
   }
-  stream[(((size_t)w * total_pos + pos0 + ks) * TPW + tp) * 64 + lane] = (u32x4){out[0], out[1], out[2], out[3]};
+  d.stream[(((size_t)w * d.total_pos + L.pos0 + ks) * TPW + tp) * 64 + lane] = (u32x4){out[0], out[1], out[2], out[3]};
 }
 template <class P>
-void launch_pack_hidden_strided(const float* W, long rs, long cs, int in_valid, int KS, int TPW, int pos0,
-                                int total_pos, u32x4* stream, hipStream_t s) {
-  hipLaunchKernelGGL((pack_hidden_strided_kernel<P>), dim3(SAMPLER_WAVES * KS * TPW), dim3(64), 0, s, W, rs, cs, in_valid,
-                     KS, TPW, pos0, total_pos, stream);
+void launch_pack_stream(const PackStream& d, hipStream_t s) {
+  int maxks = 0;
+  for (int l = 0; l < d.n_layers; ++l) maxks = d.layer[l].KS > maxks ? d.layer[l].KS : maxks;
+  hipLaunchKernelGGL((pack_stream_kernel<P>), dim3(SAMPLER_WAVES * maxks * d.TPW, d.n_layers), dim3(64), 0, s, d);
 }
-template void launch_pack_hidden_strided<F32>(const float*, long, long, int, int, int, int, int, u32x4*, hipStream_t);
-template void launch_pack_hidden_strided<BF16>(const float*, long, long, int, int, int, int, int, u32x4*, hipStream_t);
+template void launch_pack_stream<F32>(const PackStream&, hipStream_t);
+template void launch_pack_stream<BF16>(const PackStream&, hipStream_t);
+
+// bias gradients: out[slot][c] = sum over tiles; 64 columns x 16 tile-lanes per block, blockIdx.y = slot
+__global__ __launch_bounds__(1024) void reduce_slots_kernel(const float* in, int tiles, int n, const SlotOuts o) {
+  __shared__ float red[16][65];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const float* src = in + (size_t)blockIdx.y * tiles * n;
+  float p[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < n) {
+    int r = rl;
+    for (; r + 48 < tiles; r += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) p[u] += src[(size_t)(r + 16 * u) * n + c];
+    }
+    for (; r < tiles; r += 16) p[0] += src[(size_t)r * n + c];
+  }
+  red[rl][cl] = (p[0] + p[1]) + (p[2] + p[3]);
+  __syncthreads();
+  if (rl == 0 && c < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[i][cl];
+    o.out[blockIdx.y][c] = s;
+  }
+}
+void launch_reduce_slots(const float* in, int tiles, int n, const SlotOuts& o, hipStream_t s) {
+  hipLaunchKernelGGL(reduce_slots_kernel, dim3((n + 63) / 64, o.n_slots), dim3(1024), 0, s, in, tiles, n, o);
+}
 
 }  // namespace dppo

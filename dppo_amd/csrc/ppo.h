@@ -84,8 +84,10 @@ struct LossArgs {
   int ldde;
   void* d_v;  // [N][lddv] elem, column 0, zero padded
   int lddv;
-  double* stats;  // [DPPO_STAT_COUNT], zeroed by the caller
+  double* stats;    // [DPPO_STAT_COUNT], zeroed by the caller
+  double* partial;  // [loss_blocks(N)][8] scratch
 };
+int loss_blocks(int64_t N);
 template <class P>
 void launch_ppo_loss(const LossArgs& a, hipStream_t s);
 // moments[0] += sum adv_k[brow[n]], [1] += sum of squares, [2] += N (float64; zeroed by the caller)

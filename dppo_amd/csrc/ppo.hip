@@ -248,6 +248,8 @@ void launch_adv_moments(const float* adv_k, const int32_t* brow, int64_t N, doub
 
 // 16 lanes per sample (lane j owns chunk elements j, j+16, ...): every global access of a sample is one contiguous
 // segment; the two log-prob sums are reduced with 4 shuffles; scalar per-sample math is done redundantly by the 16 lanes
+constexpr int LOSS_PASSES = 8;  // samples per block = 16 * LOSS_PASSES
+
 template <class P>
 __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
   typedef typename P::elem_t E;
@@ -278,14 +280,14 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
   }
   __syncthreads();
   const int sub = threadIdx.x & 15;
-  const int64_t n = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   const int rh = pc.reward_horizon < pc.horizon_steps ? pc.reward_horizon : pc.horizon_steps;
   const int cnt = rh * Da;
   double s_pg = 0, s_v = 0, s_kl = 0, s_cf = 0, s_ratio = 0;
   const double Nn = a.moments[2];  // samples in the (global) minibatch: means and 1/N scaling use this count
-  const bool live = n < a.N;
-  const int64_t nn = live ? n : a.N - 1;  // out-of-range lanes shadow the last sample (shuffles need all lanes) and write nothing
-  {
+  for (int pass = 0; pass < LOSS_PASSES; ++pass) {
+    const int64_t n = ((int64_t)blockIdx.x * LOSS_PASSES + pass) * 16 + (threadIdx.x >> 4);
+    const bool live = n < a.N;
+    const int64_t nn = live ? n : a.N - 1;  // out-of-range lanes shadow the last sample (shuffles need all lanes), write nothing
     const int b = a.brow[nn], k = a.krow[nn];
     const dppo_step st = a.ksteps[k];
     const float* ch = a.gathered ? a.chains + (size_t)b * 2 * AF : a.chains + ((size_t)b * (Kft + 1) + k) * AF;
@@ -345,11 +347,11 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
     }
     if (live) {
       if (sub == 0) {
-        s_kl = (double)((ratio - 1.f) - logratio);
-        s_cf = fabsf(ratio - 1.f) > eps_k ? 1.0 : 0.0;
-        s_ratio = ratio;
-        s_pg = fmaxf(pg1, pg2);
-        s_v = lv;
+        s_kl += (double)((ratio - 1.f) - logratio);
+        s_cf += fabsf(ratio - 1.f) > eps_k ? 1.0 : 0.0;
+        s_ratio += ratio;
+        s_pg += fmaxf(pg1, pg2);
+        s_v += lv;
       }
       // ---- d loss / d eps and d loss / d v, zero padded to the GEMM K width, 16 lanes x 4 elements per pass
       E* de = (E*)a.d_eps + (size_t)n * a.ldde;
@@ -377,31 +379,46 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
         for (int q = 0; q < 4; ++q) dvp[j0 + q] = P::from_f32(j0 + q == 0 ? dv / (float)Nn : 0.f);
     }
   }
-  const double inv = 1.0 / Nn;
+  // per-block partial sums; loss_finalize_kernel adds them in block order (no atomics: reproducible, and thousands of
+  // double atomics on five addresses serialise in L2)
   s_pg = block_sum(s_pg, sh);
   s_v = block_sum(s_v, sh);
   s_kl = block_sum(s_kl, sh);
   s_cf = block_sum(s_cf, sh);
   s_ratio = block_sum(s_ratio, sh);
   if (threadIdx.x == 0) {
-    atomicAdd(&a.stats[DPPO_STAT_PG_LOSS], s_pg * inv);
-    atomicAdd(&a.stats[DPPO_STAT_V_LOSS], s_v * inv);
-    atomicAdd(&a.stats[DPPO_STAT_APPROX_KL], s_kl * inv);
-    atomicAdd(&a.stats[DPPO_STAT_CLIPFRAC], s_cf * inv);
-    atomicAdd(&a.stats[DPPO_STAT_RATIO], s_ratio * inv);
-    if (blockIdx.x == 0) {
-      const double mean = a.moments[0] / Nn;
-      const double varu = Nn > 1 ? (a.moments[1] - Nn * mean * mean) / (Nn - 1.0) : 0.0;
-      a.stats[DPPO_STAT_ADV_MEAN] = mean;
-      a.stats[DPPO_STAT_ADV_STD] = sqrt(varu > 0 ? varu : 0);
-    }
+    double* o = a.partial + (size_t)blockIdx.x * 8;
+    o[DPPO_STAT_PG_LOSS] = s_pg, o[DPPO_STAT_V_LOSS] = s_v, o[DPPO_STAT_APPROX_KL] = s_kl;
+    o[DPPO_STAT_CLIPFRAC] = s_cf, o[DPPO_STAT_RATIO] = s_ratio;
   }
 }
+
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const double* partial, int blocks, const double* moments,
+                                                            double* stats) {
+  __shared__ double sh[4];
+  const double Nn = moments[2];
+  for (int k = 0; k < 5; ++k) {
+    double s = 0;
+    for (int b = threadIdx.x; b < blocks; b += 256) s += partial[(size_t)b * 8 + k];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) stats[k] += s / Nn;
+  }
+  if (threadIdx.x == 0) {
+    const double mean = moments[0] / Nn;
+    const double varu = Nn > 1 ? (moments[1] - Nn * mean * mean) / (Nn - 1.0) : 0.0;
+    stats[DPPO_STAT_ADV_MEAN] = mean;
+    stats[DPPO_STAT_ADV_STD] = sqrt(varu > 0 ? varu : 0);
+  }
+}
+int loss_blocks(int64_t N) { return (int)((N + 16 * LOSS_PASSES - 1) / (16 * LOSS_PASSES)); }
+
 template <class P>
 void launch_ppo_loss(const LossArgs& a, hipStream_t s) {
   if (a.N <= 0) return;
   const size_t lds = (size_t)(2 * a.pcfg.ft_denoising_steps + 2) * sizeof(float);
-  hipLaunchKernelGGL((ppo_loss_kernel<P>), dim3((unsigned)((a.N + 15) / 16)), dim3(256), lds, s, a);
+  const int blocks = loss_blocks(a.N);
+  hipLaunchKernelGGL((ppo_loss_kernel<P>), dim3(blocks), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, a.partial, blocks, a.moments, a.stats);
 }
 template void launch_ppo_loss<F32>(const LossArgs&, hipStream_t);
 template void launch_ppo_loss<BF16>(const LossArgs&, hipStream_t);
