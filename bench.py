@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--n-steps", type=int, default=500, help="rollout length behind the update buffer")
     ap.add_argument("--batch", type=int, default=50000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --share-gpu rehearses the data-parallel path with several ranks on ONE GPU")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     ap.add_argument("--probe", type=int, default=2,
                     help="kernel timed live for `roofline`: 2 gemm_tn (weight grads), 3 fused fwd, 4 fused bwd, 5 sampler")
     args = ap.parse_args()
@@ -169,10 +172,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_gpu:
+        local = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)

@@ -329,14 +329,25 @@ static void mlp_forward(const dppo_net_desc& d, const float* prm, const char* pk
   launch_gemm_nt<P>(g, s);
 }
 
+// gw[N1][N2] (ld ldgw) = A[M][N1]^T . B[M][N2].  A thin N1 (the out layer) is computed transposed, B^T . A, so that the
+// 512 x 64 block shape of gemm_tn covers it in one output tile; the slab reduce transposes back.
 template <class P>
 static void weight_grad(const void* A, int lda, int N1, const void* Bm, int ldb, int N2, int64_t M, MlpBufs<P>& B,
                         float* gw, int ldgw, hipStream_t s) {
-  const size_t tiles = (size_t)((N1 + 127) / 128) * ((N2 + 127) / 128);
+  const bool swap = N1 <= 64 && N2 > 64;
+  if (swap) {
+    const void* tp = A;
+    A = Bm, Bm = tp;
+    int ti = lda;
+    lda = ldb, ldb = ti;
+    ti = N1, N1 = N2, N2 = ti;
+  }
+  const bool thin = gemm_tn_thin(N1, N2);
+  const size_t tiles = thin ? (size_t)((N1 + 511) / 512) : (size_t)((N1 + 127) / 128) * ((N2 + 127) / 128);
   int64_t splits = (512 + tiles - 1) / tiles;
   const int64_t max_splits = (M + 63) / 64;
   if (splits > max_splits) splits = max_splits;
-  if (splits > 128) splits = 128;
+  if (splits > 256) splits = 256;
   while (splits > 1 && (size_t)splits * N1 * N2 > B.slab_floats) --splits;
   int64_t rps = (M + splits - 1) / splits;
   rps = (rps + 63) / 64 * 64;
@@ -345,7 +356,7 @@ static void weight_grad(const void* A, int lda, int N1, const void* Bm, int ldb,
   t.A = A, t.B = Bm, t.M = (int)M, t.N1 = N1, t.N2 = N2, t.lda = lda, t.ldb = ldb;
   t.slab = B.slab, t.ldc = N2, t.splits = (int)splits, t.rows_per_split = (int)rps;
   launch_gemm_tn<P>(t, s);
-  launch_slab_reduce_2d(B.slab, (int)splits, N1, N2, N2, gw, ldgw, 1.f, s);
+  launch_slab_reduce_2d(B.slab, (int)splits, N1, N2, N2, gw, ldgw, 1.f, s, swap ? 1 : 0);
 }
 
 // d temb = dh0 . W0[:, temb columns]; summed per fine-tuned step; back through the tiny time MLP
@@ -373,7 +384,7 @@ static void time_embedding_grad(const dppo_net_desc& d, const float* prm, const 
 template <class P>
 static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* pk, const PackLayout& L, int64_t M,
                          MlpBufs<P>& B, float* grad, const int32_t* krow, const dppo_step* ksteps, int Kft,
-                         hipStream_t s) {
+                         hipStream_t s, bool bout_done = false) {
   const ParamLayout pl = param_layout(d);
   const int H = d.hidden, nb = d.n_blocks;
   if (fused_ok<P>(d) && B.tiles > 0) {
@@ -402,7 +413,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       so.out[nb] = grad + pl.b0;
       launch_reduce_slots(B.tile_colsum, B.tiles, H, so, s);
       weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.hE, H, H, M, B, grad + pl.Wout, H, s);
-      launch_colsum<P>(B.d_out, (int)M, d.out_dim, L.Kpo, B.part, REDUCE_BLOCKS, grad + pl.bout, 1.f, s);
+      if (!bout_done) launch_colsum<P>(B.d_out, (int)M, d.out_dim, L.Kpo, B.part, REDUCE_BLOCKS, grad + pl.bout, 1.f, s);
       for (int b = nb - 1; b >= 0; --b) {
         weight_grad<P>(B.dh_all[b + 1], H, H, B.a2[b], H, H, M, B, grad + pl.l2w[b], H, s);
         weight_grad<P>(B.dz1_all[b], H, H, B.a1[b], H, H, M, B, grad + pl.l1w[b], H, s);
@@ -666,11 +677,13 @@ struct PpoWs {
   int32_t *brow, *krow;
   double* moments;
   double* loss_partial;
+  float* loss_partial_cs;
 };
 template <class P>
 static size_t carve_ppo(Carver& c, const dppo_net_desc& a, const dppo_net_desc& cr, int64_t N, PpoWs<P>& W) {
   W.moments = (double*)c.take(256);
   W.loss_partial = (double*)c.take((size_t)loss_blocks(N) * 8 * sizeof(double));
+  W.loss_partial_cs = (float*)c.take((size_t)loss_blocks(N) * 65 * sizeof(float));
   W.brow = (int32_t*)c.take((size_t)N * 4);
   W.krow = (int32_t*)c.take((size_t)N * 4);
   carve_mlp<P>(c, a, N, true, true, W.A);
@@ -722,9 +735,14 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   la.moments = gmom ? gmom : W.moments;
   la.d_eps = W.A.d_out, la.ldde = LA.Kpo, la.d_v = W.C.d_out, la.lddv = LC.Kpo, la.stats = stats;
   la.partial = W.loss_partial;
+  const bool fuse_bout = LA.Kpo == 64 && fused_ok<P>(a) && fused_ok<P>(cr);  // the fused backward skips its own colsum then
+  if (fuse_bout) {
+    la.partial_cs = W.loss_partial_cs, la.out_dim = a.out_dim;
+    la.gb_actor = agrad + param_layout(a).bout, la.gb_critic = cgrad + param_layout(cr).bout;
+  }
   launch_ppo_loss<P>(la, s);
-  mlp_backward<P>(a, ap, ak, LA, N, W.A, agrad, W.krow, ksteps, Kft, s);
-  mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s);
+  mlp_backward<P>(a, ap, ak, LA, N, W.A, agrad, W.krow, ksteps, Kft, s, fuse_bout);
+  mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s, fuse_bout);
   return check_launch();
 }
 

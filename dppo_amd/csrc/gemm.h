@@ -54,6 +54,7 @@ bool probe_begin(int kernel_id, hipStream_t s);  // true if this launch is being
 void probe_end(hipStream_t s, double flops);     // call right after the launch when probe_begin returned true
 template <class P>
 void launch_gemm_tn(const GemmTN& a, hipStream_t s);
+bool gemm_tn_thin(int N1, int N2);  // true: the 512 x 64 block shape is used (one output tile covers <= 64 columns)
 
 // out[n] (+)= sum_s slab[s][n]  (fixed order => reproducible)
 void launch_slab_reduce(const float* slab, int splits, size_t n, float* out, float scale, hipStream_t s);

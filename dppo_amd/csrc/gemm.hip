@@ -309,57 +309,71 @@ template void launch_gemm_nt<BF16>(const GemmNT&, hipStream_t);
 //         swap the two halves (a k-permutation common to A and B) so that with a 288-byte row
 //         stride the 8 rows touched by a 32-lane half are distinct mod 8: conflict-free.
 //   fp32: one dword per lane per MFMA, read straight down the column (stride 576 B, conflict-free).
-template <class P>
+// Block tile = (WA*TA*16) A-features x (WB*TB*16) B-features, WA x WB = 4 waves.  Two shapes are built:
+//   <2,2,4,4> 128 x 128 : the H x H gradients
+//   <4,1,8,4> 512 x  64 : thin outputs (dW0: H x in_dim; dWout computed transposed as H x out_dim) -- one block
+//                         covers the whole output, all parallelism comes from the split over batch rows
+template <class P, int WA, int WB, int TA, int TB>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN a) {
   constexpr int ES = P::ESIZE;
-  constexpr int ROWS = (ES == 2) ? 64 : 32;     // batch rows per LDS stage (two k-steps)
-  constexpr int RSTR = (ES == 2) ? 288 : 576;   // LDS row stride in bytes (128 features + pad)
-  constexpr int CPR = 128 * ES / 16;            // 16-byte chunks per tile row
-  constexpr int NCH = ROWS * CPR / 256;         // chunks per thread per operand (= 4)
-  constexpr int OPB = ROWS * RSTR;              // bytes per operand tile
+  constexpr int BA = WA * TA * 16, BB = WB * TB * 16;
+  constexpr int ROWS = (ES == 2) ? 64 : 32;  // batch rows per LDS stage (two k-steps)
+  constexpr int RSA = BA * ES + 32, RSB = BB * ES + 32;  // LDS row strides: +8 dwords => 8 rows hit 8 bank groups
+  constexpr int CPA = BA * ES / 16, CPB = BB * ES / 16;  // 16-byte chunks per tile row
+  constexpr int NCA = (ROWS * CPA + 255) / 256, NCB = (ROWS * CPB + 255) / 256;
+  constexpr int OPA = ROWS * RSA, OPB = ROWS * RSB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int wa = wid & 1, wb = wid >> 1;
-  const int fa0 = blockIdx.x * 128, fb0 = blockIdx.y * 128;
+  const int wa = wid % WA, wb = wid / WA;
+  const int fa0 = blockIdx.x * BA, fb0 = blockIdx.y * BB;
   const int m_begin = blockIdx.z * a.rows_per_split;
   const int m_end = min(a.M, m_begin + a.rows_per_split);
   const char* Ab = (const char*)a.A;
   const char* Bb = (const char*)a.B;
 
-  u32x4 areg[NCH], breg[NCH];
+  u32x4 areg[NCA], breg[NCB];
   auto gload = [&](int m0) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int q = tid + i * 256;
-      const int rr = q / CPR, c = q % CPR;
-      const int row = m0 + rr;
-      const int ca = fa0 + c * (16 / ES), cb = fb0 + c * (16 / ES);
-      const bool oka = row < m_end && ca < a.lda, okb = row < m_end && cb < a.ldb;
-      const u32x4 va = *(const u32x4*)(Ab + ((size_t)(oka ? row : 0) * a.lda + (oka ? ca : 0)) * ES);
-      const u32x4 vb = *(const u32x4*)(Bb + ((size_t)(okb ? row : 0) * a.ldb + (okb ? cb : 0)) * ES);
-      areg[i] = oka ? va : (u32x4){0, 0, 0, 0};
-      breg[i] = okb ? vb : (u32x4){0, 0, 0, 0};
+    for (int i = 0; i < NCA; ++i) {
+      const int q = (tid + i * 256) % (ROWS * CPA);
+      const int rr = q / CPA, c = q % CPA;
+      const int row = m0 + rr, ca = fa0 + c * (16 / ES);
+      const bool ok = row < m_end && ca < a.lda;
+      const u32x4 v = *(const u32x4*)(Ab + ((size_t)(ok ? row : 0) * a.lda + (ok ? ca : 0)) * ES);
+      areg[i] = ok ? v : (u32x4){0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+      const int q = (tid + i * 256) % (ROWS * CPB);
+      const int rr = q / CPB, c = q % CPB;
+      const int row = m0 + rr, cb = fb0 + c * (16 / ES);
+      const bool ok = row < m_end && cb < a.ldb;
+      const u32x4 v = *(const u32x4*)(Bb + ((size_t)(ok ? row : 0) * a.ldb + (ok ? cb : 0)) * ES);
+      breg[i] = ok ? v : (u32x4){0, 0, 0, 0};
     }
   };
   auto sstore = [&](int st) {
-    char* As = smem + st * 2 * OPB;
-    char* Bs = As + OPB;
+    char* As = smem + st * (OPA + OPB);
+    char* Bs = As + OPA;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int q = tid + i * 256;
-      const int rr = q / CPR, c = q % CPR;
-      *(u32x4*)(As + rr * RSTR + c * 16) = areg[i];
-      *(u32x4*)(Bs + rr * RSTR + c * 16) = breg[i];
+    for (int i = 0; i < NCA; ++i) {
+      const int q = (tid + i * 256) % (ROWS * CPA);
+      *(u32x4*)(As + (q / CPA) * RSA + (q % CPA) * 16) = areg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+      const int q = (tid + i * 256) % (ROWS * CPB);
+      *(u32x4*)(Bs + (q / CPB) * RSB + (q % CPB) * 16) = breg[i];
     }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[TA][TB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TA; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nst = (m_end - m_begin + ROWS - 1) / ROWS;
   if (nst > 0) {
@@ -370,50 +384,55 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN a) {
   for (int st = 0; st < nst; ++st) {
     const int cur = st & 1;
     if (st + 1 < nst) gload(m_begin + (st + 1) * ROWS);
-    const char* As = smem + cur * 2 * OPB;
-    const char* Bs = As + OPB;
+    const char* As = smem + cur * (OPA + OPB);
+    const char* Bs = As + OPA;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      u32x4 af[4], bf[4];
+      u32x4 af[TA], bf[TB];
       if constexpr (ES == 2) {
-        // rows of this k-step: 32s .. 32s+31 ; lane group g: 32s + 8g + {0..7}
+        // rows of this k-step: 32s .. 32s+31 ; lane group g: 32s + 8g + {0..7}; odd g swap the two 4-row halves
+        // (a k-permutation common to A and B) so a 32-lane half touches 8 rows that are distinct mod 8
+        typedef __attribute__((address_space(3))) i16x4 lds_v;
         const int q = r >> 2, p = r & 3;
         const int rbase = 32 * s + 8 * g;
-        const int rA = rbase + ((g & 1) ? 4 : 0) + q;  // first read
-        const int rB = rbase + ((g & 1) ? 0 : 4) + q;  // second read
+        const int r0 = rbase + ((g & 1) ? 4 : 0) + q, r1 = rbase + ((g & 1) ? 0 : 4) + q;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int ca = (wa * 64 + t * 16 + 4 * p) * 2, cb = (wb * 64 + t * 16 + 4 * p) * 2;
-          typedef __attribute__((address_space(3))) i16x4 lds_v;
-          i16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(As + rA * RSTR + ca));
-          i16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(As + rB * RSTR + ca));
-          i16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(Bs + rA * RSTR + cb));
-          i16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(Bs + rB * RSTR + cb));
-          const u32x2 ua0 = __builtin_bit_cast(u32x2, a0), ua1 = __builtin_bit_cast(u32x2, a1);
-          const u32x2 ub0 = __builtin_bit_cast(u32x2, b0), ub1 = __builtin_bit_cast(u32x2, b1);
-          af[t] = (u32x4){ua0.x, ua0.y, ua1.x, ua1.y};
-          bf[t] = (u32x4){ub0.x, ub0.y, ub1.x, ub1.y};
+        for (int t = 0; t < TA; ++t) {
+          const int ca = (wa * TA * 16 + t * 16 + 4 * p) * 2;
+          const u32x2 u0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(As + r0 * RSA + ca)));
+          const u32x2 u1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(As + r1 * RSA + ca)));
+          af[t] = (u32x4){u0.x, u0.y, u1.x, u1.y};
+        }
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+          const int cb = (wb * TB * 16 + t * 16 + 4 * p) * 2;
+          const u32x2 u0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(Bs + r0 * RSB + cb)));
+          const u32x2 u1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(Bs + r1 * RSB + cb)));
+          bf[t] = (u32x4){u0.x, u0.y, u1.x, u1.y};
         }
       } else {
         // rows of this k-step: 16s .. 16s+15 ; MFMA j of the step uses row 16s + 4j + g
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int ca = (wa * 64 + t * 16 + r) * 4, cb = (wb * 64 + t * 16 + r) * 4;
-          uint32_t va[4], vb[4];
+        for (int t = 0; t < TA; ++t) {
+          const int ca = (wa * TA * 16 + t * 16 + r) * 4;
+          uint32_t v[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int row = 16 * s + 4 * j + g;
-            va[j] = *(const uint32_t*)(As + row * RSTR + ca);
-            vb[j] = *(const uint32_t*)(Bs + row * RSTR + cb);
-          }
-          af[t] = (u32x4){va[0], va[1], va[2], va[3]};
-          bf[t] = (u32x4){vb[0], vb[1], vb[2], vb[3]};
+          for (int j = 0; j < 4; ++j) v[j] = *(const uint32_t*)(As + (16 * s + 4 * j + g) * RSA + ca);
+          af[t] = (u32x4){v[0], v[1], v[2], v[3]};
+        }
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+          const int cb = (wb * TB * 16 + t * 16 + r) * 4;
+          uint32_t v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = *(const uint32_t*)(Bs + (16 * s + 4 * j + g) * RSB + cb);
+          bf[t] = (u32x4){v[0], v[1], v[2], v[3]};
         }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TA; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = P::mma(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < TB; ++j) acc[i][j] = P::mma(af[i], bf[j], acc[i][j]);
     }
     if (st + 1 < nst) sstore(cur ^ 1);
     __syncthreads();
@@ -421,30 +440,43 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN a) {
 
   float* out = a.slab + (size_t)blockIdx.z * a.N1 * a.ldc;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TA; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int n1 = fa0 + wa * 64 + i * 16 + 4 * g + e;
+      const int n1 = fa0 + wa * TA * 16 + i * 16 + 4 * g + e;
       if (n1 >= a.N1) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n2 = fb0 + wb * 64 + j * 16 + r;
+      for (int j = 0; j < TB; ++j) {
+        const int n2 = fb0 + wb * TB * 16 + j * 16 + r;
         if (n2 < a.N2) out[(size_t)n1 * a.ldc + n2] = acc[i][j][e];
       }
     }
 }
 
-template <class P>
-void launch_gemm_tn(const GemmTN& a, hipStream_t s) {
-  dim3 grid((a.N1 + 127) / 128, (a.N2 + 127) / 128, a.splits);
-  static bool attr_set = false;  // 72 KiB of dynamic LDS needs the cap raised once per kernel
+template <class P, int WA, int WB, int TA, int TB>
+static void launch_tn_cfg(const GemmTN& a, hipStream_t s) {
+  constexpr int ES = P::ESIZE, BA = WA * TA * 16, BB = WB * TB * 16, ROWS = (ES == 2) ? 64 : 32;
+  constexpr int LDS = 2 * ROWS * ((BA * ES + 32) + (BB * ES + 32));
+  dim3 grid((a.N1 + BA - 1) / BA, (a.N2 + BB - 1) / BB, a.splits);
+  static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the cap raised once per kernel
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<P, WA, WB, TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              LDS);
     attr_set = true;
   }
-  const bool probe = a.N1 >= 128 && a.N2 >= 128 && probe_begin(PROBE_GEMM_TN, s);  // the H x H weight gradients
-  hipLaunchKernelGGL((gemm_tn_kernel<P>), grid, dim3(256), 73728, s, a);
+  const bool probe = BA == 128 && a.N1 >= 128 && a.N2 >= 128 && probe_begin(PROBE_GEMM_TN, s);  // H x H gradients
+  hipLaunchKernelGGL((gemm_tn_kernel<P, WA, WB, TA, TB>), grid, dim3(256), LDS, s, a);
   if (probe) probe_end(s, 2.0 * a.M * a.N1 * a.N2);
+}
+
+bool gemm_tn_thin(int N1, int N2) { return N2 <= 64 && N1 > 64; }
+
+template <class P>
+void launch_gemm_tn(const GemmTN& a, hipStream_t s) {
+  if (gemm_tn_thin(a.N1, a.N2))
+    launch_tn_cfg<P, 4, 1, 8, 4>(a, s);
+  else
+    launch_tn_cfg<P, 2, 2, 4, 4>(a, s);
 }
 template void launch_gemm_tn<F32>(const GemmTN&, hipStream_t);
 template void launch_gemm_tn<BF16>(const GemmTN&, hipStream_t);

@@ -86,6 +86,11 @@ struct LossArgs {
   int lddv;
   double* stats;    // [DPPO_STAT_COUNT], zeroed by the caller
   double* partial;  // [loss_blocks(N)][8] scratch
+  // optional fused out-layer bias gradients (needs ldde == 64): column sums of d_eps -> gb_actor[out_dim], of d_v -> gb_critic[0]
+  float* partial_cs;  // [loss_blocks(N)][65] scratch, or null
+  float* gb_actor;
+  float* gb_critic;
+  int out_dim;
 };
 int loss_blocks(int64_t N);
 template <class P>
@@ -101,9 +106,9 @@ void launch_temb_segsum(const float* dtemb, int ld, const int32_t* krow, int64_t
 void launch_time_backward(const float* w1, const float* b1, const float* w2, const float* G, const dppo_step* ksteps,
                           int Kft, int td, float* gw1, float* gb1, float* gw2, float* gb2, hipStream_t s);
 
-// out[r][c] (ldo) = scale * sum_s slab[s][r][c] (lds) for r < rows, c < cols
+// out[r][c] (ldo) = scale * sum_s slab[s][r][c] (lds) for r < rows, c < cols ; transpose: out[c][r] instead
 void launch_slab_reduce_2d(const float* slab, int splits, int rows, int cols, int lds, float* out, int ldo,
-                           float scale, hipStream_t s);
+                           float scale, hipStream_t s, int transpose = 0);
 
 // ---- GAE / optimiser -----------------------------------------------------------------------------
 void launch_gae(const double* reward, const float* values, const float* terminated, const float* last_values, int S,

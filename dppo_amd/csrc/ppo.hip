@@ -283,6 +283,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
   const int rh = pc.reward_horizon < pc.horizon_steps ? pc.reward_horizon : pc.horizon_steps;
   const int cnt = rh * Da;
   double s_pg = 0, s_v = 0, s_kl = 0, s_cf = 0, s_ratio = 0;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cs_v = 0.f;  // column sums of d_eps (this lane's 4 columns) and of d_v
   const double Nn = a.moments[2];  // samples in the (global) minibatch: means and 1/N scaling use this count
   for (int pass = 0; pass < LOSS_PASSES; ++pass) {
     const int64_t n = ((int64_t)blockIdx.x * LOSS_PASSES + pass) * 16 + (threadIdx.x >> 4);
@@ -372,7 +373,12 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) de[j0 + q] = P::from_f32(gq[q]);
+        if (j0 < 64) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) cs[q] += gq[q];
+        }
       }
+      if (sub == 0) cs_v += dv / (float)Nn;
       E* dvp = (E*)a.d_v + (size_t)n * a.lddv;
       for (int j0 = 4 * sub; j0 < a.lddv; j0 += 64)
 #pragma unroll
@@ -391,12 +397,35 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
     o[DPPO_STAT_PG_LOSS] = s_pg, o[DPPO_STAT_V_LOSS] = s_v, o[DPPO_STAT_APPROX_KL] = s_kl;
     o[DPPO_STAT_CLIPFRAC] = s_cf, o[DPPO_STAT_RATIO] = s_ratio;
   }
+  // out-layer bias gradients: sum this block's 16 sample groups -> partial_cs[block][65] (64 d_eps columns, d_v)
+  if (a.partial_cs != nullptr) {
+    __shared__ float cred[16][65];
+    const int grp = threadIdx.x >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cred[grp][4 * sub + q] = cs[q];
+    if (sub == 0) cred[grp][64] = cs_v;
+    __syncthreads();
+    if (threadIdx.x < 65) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t += cred[i][threadIdx.x];
+      a.partial_cs[(size_t)blockIdx.x * 65 + threadIdx.x] = t;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const double* partial, int blocks, const double* moments,
-                                                            double* stats) {
+                                                            double* stats, const float* partial_cs, float* gb_actor,
+                                                            int out_dim, float* gb_critic) {
   __shared__ double sh[4];
   const double Nn = moments[2];
+  if (partial_cs != nullptr && threadIdx.x < 65) {  // fixed block order => reproducible
+    const int j = threadIdx.x;
+    float t = 0.f;
+    for (int b = 0; b < blocks; ++b) t += partial_cs[(size_t)b * 65 + j];
+    if (j < out_dim) gb_actor[j] = t;
+    if (j == 64) gb_critic[0] = t;
+  }
   for (int k = 0; k < 5; ++k) {
     double s = 0;
     for (int b = threadIdx.x; b < blocks; b += 256) s += partial[(size_t)b * 8 + k];
@@ -418,7 +447,8 @@ void launch_ppo_loss(const LossArgs& a, hipStream_t s) {
   const size_t lds = (size_t)(2 * a.pcfg.ft_denoising_steps + 2) * sizeof(float);
   const int blocks = loss_blocks(a.N);
   hipLaunchKernelGGL((ppo_loss_kernel<P>), dim3(blocks), dim3(256), lds, s, a);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, a.partial, blocks, a.moments, a.stats);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, a.partial, blocks, a.moments, a.stats, a.partial_cs,
+                     a.gb_actor, a.out_dim, a.gb_critic);
 }
 template void launch_ppo_loss<F32>(const LossArgs&, hipStream_t);
 template void launch_ppo_loss<BF16>(const LossArgs&, hipStream_t);
@@ -512,7 +542,7 @@ void launch_time_backward(const float* w1, const float* b1, const float* w2, con
 }
 
 __global__ void slab_reduce_2d_kernel(const float* slab, int splits, int rows, int cols, int lds, float* out, int ldo,
-                                      float scale) {
+                                      float scale, int transpose) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)rows * cols) return;
   const int r = (int)(i / cols), c = (int)(i % cols);
@@ -523,14 +553,18 @@ __global__ void slab_reduce_2d_kernel(const float* slab, int splits, int rows, i
     for (int u = 0; u < 8; ++u) p[u] += slab[((size_t)(k + u) * rows + r) * lds + c];
   }
   for (; k < splits; ++k) p[k & 7] += slab[((size_t)k * rows + r) * lds + c];
-  out[(size_t)r * ldo + c] = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) * scale;
+  const float v = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) * scale;
+  if (transpose)
+    out[(size_t)c * ldo + r] = v;
+  else
+    out[(size_t)r * ldo + c] = v;
 }
 void launch_slab_reduce_2d(const float* slab, int splits, int rows, int cols, int lds, float* out, int ldo,
-                           float scale, hipStream_t s) {
+                           float scale, hipStream_t s, int transpose) {
   const size_t n = (size_t)rows * cols;
   if (n == 0) return;
   hipLaunchKernelGGL(slab_reduce_2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slab, splits, rows,
-                     cols, lds, out, ldo, scale);
+                     cols, lds, out, ldo, scale, transpose);
 }
 
 // =================================================================================================
