@@ -347,7 +347,7 @@ static void weight_grad(const void* A, int lda, int N1, const void* Bm, int ldb,
   int64_t splits = (512 + tiles - 1) / tiles;
   const int64_t max_splits = (M + 63) / 64;
   if (splits > max_splits) splits = max_splits;
-  if (splits > 256) splits = 256;
+  if (splits > 128) splits = 128;
   while (splits > 1 && (size_t)splits * N1 * N2 > B.slab_floats) --splits;
   int64_t rps = (M + splits - 1) / splits;
   rps = (rps + 63) / 64 * 64;

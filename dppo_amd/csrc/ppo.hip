@@ -414,31 +414,60 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void loss_finalize_kernel(const double* partial, int blocks, const double* moments,
-                                                            double* stats, const float* partial_cs, float* gb_actor,
-                                                            int out_dim, float* gb_critic) {
-  __shared__ double sh[4];
+// one block of 1024 threads: statistics (5 doubles over the blocks) and the 65 out-layer bias-gradient columns
+// (64 column lanes x 16 block lanes, 4 independent chains each); fixed order => reproducible
+__global__ __launch_bounds__(1024) void loss_finalize_kernel(const double* partial, int blocks, const double* moments,
+                                                             double* stats, const float* partial_cs, float* gb_actor,
+                                                             int out_dim, float* gb_critic) {
+  __shared__ double shd[16];
+  __shared__ float red[16][65];
   const double Nn = moments[2];
-  if (partial_cs != nullptr && threadIdx.x < 65) {  // fixed block order => reproducible
-    const int j = threadIdx.x;
-    float t = 0.f;
-    for (int b = 0; b < blocks; ++b) t += partial_cs[(size_t)b * 65 + j];
-    if (j < out_dim) gb_actor[j] = t;
-    if (j == 64) gb_critic[0] = t;
-  }
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int k = 0; k < 5; ++k) {
     double s = 0;
-    for (int b = threadIdx.x; b < blocks; b += 256) s += partial[(size_t)b * 8 + k];
-    s = block_sum(s, sh);
-    if (threadIdx.x == 0) stats[k] += s / Nn;
+    for (int b = tid; b < blocks; b += 1024) s += partial[(size_t)b * 8 + k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    __syncthreads();
+    if (lane == 0) shd[w] = s;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0;
+      for (int i = 0; i < 16; ++i) t += shd[i];
+      stats[k] += t / Nn;
+    }
   }
-  if (threadIdx.x == 0) {
+  if (partial_cs != nullptr) {
+    for (int c0 = 0; c0 < 65; c0 += 64) {  // columns 0..63, then column 64 (d_v)
+      const int c = c0 + lane;
+      float p[4] = {0.f, 0.f, 0.f, 0.f};
+      if (c < 65) {
+        int b = w;
+        for (; b + 48 < blocks; b += 64) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) p[u] += partial_cs[(size_t)(b + 16 * u) * 65 + c];
+        }
+        for (; b < blocks; b += 16) p[0] += partial_cs[(size_t)b * 65 + c];
+      }
+      __syncthreads();
+      red[w][lane] = (p[0] + p[1]) + (p[2] + p[3]);
+      __syncthreads();
+      if (w == 0 && c < 65) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][lane];
+        if (c < out_dim) gb_actor[c] = t;
+        if (c == 64) gb_critic[0] = t;
+      }
+    }
+  }
+  if (tid == 0) {
     const double mean = moments[0] / Nn;
     const double varu = Nn > 1 ? (moments[1] - Nn * mean * mean) / (Nn - 1.0) : 0.0;
     stats[DPPO_STAT_ADV_MEAN] = mean;
     stats[DPPO_STAT_ADV_STD] = sqrt(varu > 0 ? varu : 0);
   }
 }
+
 int loss_blocks(int64_t N) { return (int)((N + 16 * LOSS_PASSES - 1) / (16 * LOSS_PASSES)); }
 
 template <class P>
@@ -447,7 +476,7 @@ void launch_ppo_loss(const LossArgs& a, hipStream_t s) {
   const size_t lds = (size_t)(2 * a.pcfg.ft_denoising_steps + 2) * sizeof(float);
   const int blocks = loss_blocks(a.N);
   hipLaunchKernelGGL((ppo_loss_kernel<P>), dim3(blocks), dim3(256), lds, s, a);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, a.partial, blocks, a.moments, a.stats, a.partial_cs,
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, s, a.partial, blocks, a.moments, a.stats, a.partial_cs,
                      a.gb_actor, a.out_dim, a.gb_critic);
 }
 template void launch_ppo_loss<F32>(const LossArgs&, hipStream_t);
