@@ -254,8 +254,12 @@ def main():
             names = {1: "gemm_nt_kernel (H x H layers, layered path)", 2: "gemm_tn_kernel (H x H weight gradients)",
                      3: "fused_forward_kernel (actor_ft + critic)", 4: "fused_backward_kernel (actor_ft + critic)",
                      5: "sample_chain_kernel"}
+            traffic = None  # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)
+            tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_probe{args.probe}_{args.prec}.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             probe = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
-                     "traffic": None, "kernel": f"{names[args.probe]}, {args.prec}", "avg_launch_ms": avg_ms,
+                     "traffic": traffic, "kernel": f"{names[args.probe]}, {args.prec}", "avg_launch_ms": avg_ms,
                      "launches": cnt.value, "algorithmic_gflop_per_launch": fl.value / cnt.value / 1e9}
     stats = model._stats.tolist()
     if rank == 0:

@@ -349,9 +349,11 @@ static void weight_grad(const void* A, int lda, int N1, const void* Bm, int ldb,
   if (splits > max_splits) splits = max_splits;
   if (splits > 128) splits = 128;
   while (splits > 1 && (size_t)splits * N1 * N2 > B.slab_floats) --splits;
+  if (splits >= 8) splits = splits / 8 * 8;  // a multiple of the XCD count keeps one split's tiles on one XCD
   int64_t rps = (M + splits - 1) / splits;
   rps = (rps + 63) / 64 * 64;
-  splits = (M + rps - 1) / rps;
+  const int64_t need = (M + rps - 1) / rps;
+  if (need < splits) splits = need >= 8 ? (need + 7) / 8 * 8 : need;  // surplus splits see no rows and store zeros
   GemmTN t;
   t.A = A, t.B = Bm, t.M = (int)M, t.N1 = N1, t.N2 = N2, t.lda = lda, t.ldb = ldb;
   t.slab = B.slab, t.ldc = N2, t.splits = (int)splits, t.rows_per_split = (int)rps;

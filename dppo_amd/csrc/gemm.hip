@@ -327,8 +327,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN a) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int wa = wid % WA, wb = wid / WA;
-  const int fa0 = blockIdx.x * BA, fb0 = blockIdx.y * BB;
-  const int m_begin = blockIdx.z * a.rows_per_split;
+  // blockIdx.x = row split: workgroups are dealt round-robin to the 8 XCDs, so with splits % 8 == 0 every output tile
+  // of one split runs on the same XCD and its A/B row tiles are fetched into that XCD's L2 once, not once per XCD
+  const int fa0 = blockIdx.y * BA, fb0 = blockIdx.z * BB;
+  const int m_begin = blockIdx.x * a.rows_per_split;
   const int m_end = min(a.M, m_begin + a.rows_per_split);
   const char* Ab = (const char*)a.A;
   const char* Bb = (const char*)a.B;
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN a) {
     __syncthreads();
   }
 
-  float* out = a.slab + (size_t)blockIdx.z * a.N1 * a.ldc;
+  float* out = a.slab + (size_t)blockIdx.x * a.N1 * a.ldc;
 #pragma unroll
   for (int i = 0; i < TA; ++i)
 #pragma unroll
@@ -457,7 +459,7 @@ template <class P, int WA, int WB, int TA, int TB>
 static void launch_tn_cfg(const GemmTN& a, hipStream_t s) {
   constexpr int ES = P::ESIZE, BA = WA * TA * 16, BB = WB * TB * 16, ROWS = (ES == 2) ? 64 : 32;
   constexpr int LDS = 2 * ROWS * ((BA * ES + 32) + (BB * ES + 32));
-  dim3 grid((a.N1 + BA - 1) / BA, (a.N2 + BB - 1) / BB, a.splits);
+  dim3 grid(a.splits, (a.N1 + BA - 1) / BA, (a.N2 + BB - 1) / BB);
   static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the cap raised once per kernel
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<P, WA, WB, TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize,
