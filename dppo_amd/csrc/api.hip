@@ -30,7 +30,7 @@ static int check_launch() {
 // layouts
 // ------------------------------------------------------------------------------------------------
 struct ParamLayout {  // float offsets into the flat fp32 parameter / gradient buffer (state-dict order)
-  int64_t te1_w, te1_b, te2_w, te2_b, W0, b0, l1w[MAX_BLOCKS], l1b[MAX_BLOCKS], l2w[MAX_BLOCKS], l2b[MAX_BLOCKS], Wout,
+  int64_t te1_w, te1_b, te2_w, te2_b, c1w, c1b, c2w, c2b, W0, b0, l1w[MAX_BLOCKS], l1b[MAX_BLOCKS], l2w[MAX_BLOCKS], l2b[MAX_BLOCKS], Wout,
       bout, total;
 };
 static ParamLayout param_layout(const dppo_net_desc& d) {
@@ -43,6 +43,12 @@ static ParamLayout param_layout(const dppo_net_desc& d) {
     L.te1_b = o, o += 2 * td;
     L.te2_w = o, o += td * 2 * td;
     L.te2_b = o, o += td;
+    if (d.cond_hidden > 0) {
+      L.c1w = o, o += (int64_t)d.cond_hidden * d.cond_dim;
+      L.c1b = o, o += d.cond_hidden;
+      L.c2w = o, o += (int64_t)d.cond_out * d.cond_hidden;
+      L.c2b = o, o += d.cond_out;
+    }
   }
   L.W0 = o, o += (int64_t)H * d.in_dim;
   L.b0 = o, o += H;
@@ -61,8 +67,9 @@ static ParamLayout param_layout(const dppo_net_desc& d) {
 struct PackLayout {  // byte offsets into the packed image
   // every offset depends on (net, prec) only; the time table sits last so that only `total` grows with n_time
   size_t W0, W1[MAX_BLOCKS], W2[MAX_BLOCKS], Wout, W1T[MAX_BLOCKS], W2T[MAX_BLOCKS], WoutT, W0tT, sstream, ostream,
-      bstream, temb, total;
+      bstream, Wc1, Wc2, Wc2T, W0eT, temb, total;
   int Kp0, Kpo, tdp;
+  int Kpc, C1p, Ep;  // cond_mlp: padded K of the encoder layers (cond, hidden) and padded encoder width
 };
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 template <class P>
@@ -92,6 +99,14 @@ static PackLayout pack_layout(const dppo_net_desc& d, int n_time) {
     L.ostream = o, o = al256(o + (size_t)SAMPLER_WAVES * g.out_frags_per_wave * 64 * 16);
     L.bstream = o, o = al256(o + (size_t)SAMPLER_WAVES * fg.frags_per_wave * 64 * 16);
   }
+  L.Kpc = round_up(d.cond_dim > 0 ? d.cond_dim : 1, 64);
+  if (d.cond_hidden > 0) {  // observation encoder: row-major GEMM operands (small), W2^T and the encoder columns of W0
+    L.C1p = round_up(d.cond_hidden, 64), L.Ep = round_up(d.cond_out, 64);
+    L.Wc1 = o, o = al256(o + (size_t)d.cond_hidden * L.Kpc * ES);
+    L.Wc2 = o, o = al256(o + (size_t)d.cond_out * L.C1p * ES);
+    L.Wc2T = o, o = al256(o + (size_t)d.cond_hidden * L.Ep * ES);
+    L.W0eT = o, o = al256(o + (size_t)d.cond_out * H * ES);
+  }
   L.temb = o, o = al256(o + (size_t)n_time * (d.time_dim > 0 ? d.time_dim : 0) * 4);
   L.total = o;
   return L;
@@ -107,9 +122,14 @@ static int check_net(const dppo_net_desc* d) {
   if (d->kind == 0) {
     if (d->time_dim < 4 || d->time_dim % 2) return fail(-1, "time_dim=%d must be even and >= 4", d->time_dim);
     if (d->act_flat != d->out_dim) return fail(-1, "actor out_dim must equal act_flat");
-    if (d->in_dim != d->act_flat + d->time_dim + d->cond_dim) return fail(-1, "actor in_dim mismatch");
+    if ((d->cond_hidden > 0) != (d->cond_out > 0)) return fail(-1, "cond_hidden / cond_out must both be set or both 0");
+    if (d->cond_hidden < 0 || d->cond_hidden > 1024 || d->cond_out > 256) return fail(-1, "cond_mlp dims out of range");
+    if (d->cond_out > 0 && (d->act_flat + d->time_dim) % 4) return fail(-1, "cond_mlp needs Ta*Da + time_dim to be a multiple of 4");
+    if (d->in_dim != d->act_flat + d->time_dim + (d->cond_out > 0 ? d->cond_out : d->cond_dim))
+      return fail(-1, "actor in_dim mismatch");
   } else {
     if (d->in_dim != d->cond_dim) return fail(-1, "critic in_dim must equal cond_dim");
+    if (d->cond_hidden || d->cond_out) return fail(-1, "critic has no cond_mlp");
     if (d->out_dim != 1) return fail(-1, "critic out_dim must be 1");
   }
   if (d->in_dim < 1 || d->in_dim > 1024) return fail(-1, "in_dim=%d out of [1,1024]", d->in_dim);
@@ -154,6 +174,13 @@ static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char*
   }
   // W0tT[j][h] = W0[h][act_flat + j]
   if (d.kind == 0) launch_transpose_cast<P>(prm + pl.W0, H, d.time_dim, d.in_dim, d.act_flat, pk + L.W0tT, H, s);
+  if (d.cond_hidden > 0) {
+    launch_cast_pad<P>(prm + pl.c1w, d.cond_hidden, d.cond_dim, d.cond_dim, pk + L.Wc1, L.Kpc, s);
+    launch_cast_pad<P>(prm + pl.c2w, d.cond_out, d.cond_hidden, d.cond_hidden, pk + L.Wc2, L.C1p, s);
+    // Wc2T[c][e] = Wc2[e][c] -> [cond_hidden][Ep] ; W0eT[e][h] = W0[h][act_flat + td + e] -> [cond_out][H]
+    launch_transpose_cast<P>(prm + pl.c2w, d.cond_out, d.cond_hidden, d.cond_hidden, 0, pk + L.Wc2T, L.Ep, s);
+    launch_transpose_cast<P>(prm + pl.W0, H, d.cond_out, d.in_dim, d.act_flat + d.time_dim, pk + L.W0eT, H, s);
+  }
   {
     const SamplerGeom g = sampler_geom<P>(d);
     const FusedGeom fg = fused_geom<P>(d);
@@ -211,8 +238,15 @@ struct MlpBufs {  // activations of one network for M rows
   void* dh;     // [M][H] elem
   void* dz1;    // [M][H] elem
   float* dtemb; // [M][tdp] f32 (actor)
+  // cond_mlp (observation encoder) activations / gradients
+  void* cin;     // [M][Kpc] elem : [obs | 0]
+  void* ca;      // [M][C1p] act(z_c)
+  void* cz;      // [M][C1p] z_c (Mish')
+  void* d_enc;   // [M][Ep]
+  void* d_cz;    // [M][C1p]
   void* dh_all[MAX_BLOCKS + 1];  // fused backward: dh[b] = d loss / d h_b, elem [M][H]
   void* dz1_all[MAX_BLOCKS];
+  const void* dh0_final;         // where the last backward left d loss / d h_0
   float* tile_colsum;            // [(2nb+1)][tiles][H]
   int tiles;
   float* slab;  // split-M partial weight gradients
@@ -243,6 +277,16 @@ static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, b
     B.a1[b] = a1s;
     B.a2[b] = a2s;
     B.z1[b] = keep ? c.take((size_t)M * H * ES) : nullptr;
+  }
+  if (d.cond_hidden > 0) {
+    const int Kpc = round_up(d.cond_dim, 64), C1p = round_up(d.cond_hidden, 64), Ep = round_up(d.cond_out, 64);
+    B.cin = c.take((size_t)M * Kpc * ES);
+    B.ca = c.take((size_t)M * C1p * ES);
+    B.cz = keep ? c.take((size_t)M * C1p * ES) : nullptr;
+    if (bwd) {
+      B.d_enc = c.take((size_t)M * Ep * ES);
+      B.d_cz = c.take((size_t)M * C1p * ES);
+    }
   }
   B.hE = c.take((size_t)M * H * ES);
   for (int b = 0; b <= nb; ++b) B.hpre[b] = b == nb ? B.hE : (keep ? c.take((size_t)M * H * ES) : nullptr);
@@ -278,6 +322,26 @@ static void fill_bias_off(const dppo_net_desc& d, const ParamLayout& pl, int* of
   off[0] = (int)pl.b0;
   for (int b = 0; b < d.n_blocks; ++b) off[1 + 2 * b] = (int)pl.l1b[b], off[2 + 2 * b] = (int)pl.l2b[b];
   off[1 + 2 * d.n_blocks] = (int)pl.bout;
+}
+
+// cond_mlp (mlp_diffusion.py:201-207,240-241): enc = Linear2(act(Linear1(obs))), written as elem straight into the
+// encoder columns [act_flat + time_dim, +cond_out) of the trunk's input rows `in` (ld Kp0).  cin: [M][Kpc] elem obs.
+template <class P>
+static void cond_encode(const dppo_net_desc& d, const float* prm, const char* pk, const PackLayout& L, int64_t M,
+                        const void* cin, MlpBufs<P>& B, void* in, float* enc_f32, int ld_enc, bool keep, hipStream_t s) {
+  const ParamLayout pl = param_layout(d);
+  GemmNT g;
+  memset(&g, 0, sizeof(g));
+  g.M = (int)M, g.N = d.cond_hidden, g.Kp = L.Kpc, g.ldx = L.Kpc, g.ldw = L.Kpc, g.ldo = L.C1p, g.act = d.act;
+  g.X = cin, g.W = pk + L.Wc1, g.bias = prm + pl.c1b, g.out_act = B.ca, g.out_pre = keep ? B.cz : nullptr;
+  launch_gemm_nt<P>(g, s);
+  if (L.C1p > round_up(d.cond_hidden, 16)) launch_zero_cols<P>(B.ca, (int)M, round_up(d.cond_hidden, 16), L.C1p, L.C1p, s);
+  memset(&g, 0, sizeof(g));
+  g.M = (int)M, g.N = d.cond_out, g.Kp = L.C1p, g.ldx = L.C1p, g.ldw = L.C1p;
+  g.X = B.ca, g.W = pk + L.Wc2, g.bias = prm + pl.c2b;
+  if (in != nullptr) g.out_pre = (char*)in + (size_t)(d.act_flat + d.time_dim) * P::ESIZE, g.ldo = L.Kp0;
+  if (enc_f32 != nullptr) g.out_f32 = enc_f32, g.ldo32 = ld_enc;
+  launch_gemm_nt<P>(g, s);
 }
 
 template <class P>
@@ -382,6 +446,30 @@ static void time_embedding_grad(const dppo_net_desc& d, const float* prm, const 
                        grad + pl.te1_b, grad + pl.te2_w, grad + pl.te2_b, s);
 }
 
+// gradients of the encoder from dh0 (= d loss / d h_0 of the trunk)
+template <class P>
+static void cond_backward(const dppo_net_desc& d, const float* prm, const char* pk, const PackLayout& L, int64_t M,
+                          MlpBufs<P>& B, const void* dh0, const void* cin, float* grad, hipStream_t s) {
+  const ParamLayout pl = param_layout(d);
+  const int H = d.hidden;
+  GemmNT g;
+  memset(&g, 0, sizeof(g));  // d_enc = dh0 . W0[:, enc columns]
+  g.M = (int)M, g.N = d.cond_out, g.Kp = H, g.ldx = H, g.ldw = H, g.ldo = L.Ep;
+  g.X = dh0, g.W = pk + L.W0eT, g.out_pre = B.d_enc;
+  launch_gemm_nt<P>(g, s);
+  if (L.Ep > round_up(d.cond_out, 16))  // columns the epilogue does not store must be zero: they are the next GEMM's K padding
+    launch_zero_cols<P>(B.d_enc, (int)M, round_up(d.cond_out, 16), L.Ep, L.Ep, s);
+  weight_grad<P>(B.d_enc, L.Ep, d.cond_out, B.ca, L.C1p, d.cond_hidden, M, B, grad + pl.c2w, d.cond_hidden, s);
+  launch_colsum<P>(B.d_enc, (int)M, d.cond_out, L.Ep, B.part, REDUCE_BLOCKS, grad + pl.c2b, 1.f, s);
+  memset(&g, 0, sizeof(g));  // d_zc = (d_enc . Wc2) * act'(z_c)
+  g.M = (int)M, g.N = d.cond_hidden, g.Kp = L.Ep, g.ldx = L.Ep, g.ldw = L.Ep, g.ldo = L.C1p;
+  g.X = B.d_enc, g.W = pk + L.Wc2T, g.out_pre = B.d_cz, g.dsrc_kind = 2, g.dsrc_ld = L.C1p, g.dact = d.act;
+  g.dsrc = d.act == DPPO_ACT_RELU ? B.ca : B.cz;
+  launch_gemm_nt<P>(g, s);
+  weight_grad<P>(B.d_cz, L.C1p, d.cond_hidden, cin, L.Kpc, d.cond_dim, M, B, grad + pl.c1w, d.cond_dim, s);
+  launch_colsum<P>(B.d_cz, (int)M, d.cond_hidden, L.C1p, B.part, REDUCE_BLOCKS, grad + pl.c1b, 1.f, s);
+}
+
 // d_out (B.d_out, [M][Kpo] elem) -> gradients of every parameter of the network into `grad`
 template <class P>
 static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* pk, const PackLayout& L, int64_t M,
@@ -422,6 +510,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       }
       weight_grad<P>(B.dh_all[0], H, H, B.in, L.Kp0, d.in_dim, M, B, grad + pl.W0, d.in_dim, s);
       if (d.kind == 0) time_embedding_grad<P>(d, prm, pk, L, M, B, B.dh_all[0], grad, krow, ksteps, Kft, s);
+      B.dh0_final = B.dh_all[0];
       return;
     }
   }
@@ -457,6 +546,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
   weight_grad<P>(B.dh, H, H, B.in, L.Kp0, d.in_dim, M, B, grad + pl.W0, d.in_dim, s);
   launch_colsum<P>(B.dh, (int)M, H, H, B.part, REDUCE_BLOCKS, grad + pl.b0, 1.f, s);
   if (d.kind == 0) time_embedding_grad<P>(d, prm, pk, L, M, B, B.dh, grad, krow, ksteps, Kft, s);
+  B.dh0_final = B.dh;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -516,8 +606,14 @@ static int net_forward_impl(const dppo_net_desc& d, const float* prm, const char
   carve_mlp<P>(c, d, M, false, false, B);
   if ((int64_t)c.off > wsb) return fail(-1, "workspace too small: need %zu bytes, got %lld", c.off, (long long)wsb);
   const PackLayout L = pack_layout<P>(d, 0);
-  launch_build_direct<P>(x, t, state, (const float*)(pk + L.temb), d.act_flat, d.time_dim, d.cond_dim, M, B.in, L.Kp0,
-                         s);
+  if (d.cond_hidden > 0) {  // [x | temb | 0] rows, then the encoder writes its columns
+    launch_build_direct<P>(x, t, nullptr, (const float*)(pk + L.temb), d.act_flat, d.time_dim, 0, M, B.in, L.Kp0, s);
+    launch_build_direct<P>(nullptr, nullptr, state, nullptr, 0, 0, d.cond_dim, M, B.cin, L.Kpc, s);
+    cond_encode<P>(d, prm, pk, L, M, B.cin, B, B.in, nullptr, 0, false, s);
+  } else {
+    launch_build_direct<P>(x, t, state, (const float*)(pk + L.temb), d.act_flat, d.time_dim, d.cond_dim, M, B.in,
+                           L.Kp0, s);
+  }
   mlp_forward<P>(d, prm, pk, L, M, B, false, s);
   launch_slab_reduce_2d(B.out, 1, (int)M, d.out_dim, B.ldout, out, d.out_dim, 1.f, s);
   return check_launch();
@@ -554,10 +650,29 @@ int dppo_critic_forward(const dppo_net_desc* net, int prec, const float* params,
 
 // ---- sampler -----------------------------------------------------------------------------------------
 template <class P>
+static size_t sample_carve(Carver& c, const dppo_net_desc& d, int64_t B, MlpBufs<P>& Bz, float*& enc) {
+  memset(&Bz, 0, sizeof(Bz));
+  enc = nullptr;
+  if (d.cond_hidden <= 0) return 0;
+  const size_t ES = P::ESIZE;
+  Bz.cin = c.take((size_t)B * round_up(d.cond_dim, 64) * ES);
+  Bz.ca = c.take((size_t)B * round_up(d.cond_hidden, 64) * ES);
+  enc = (float*)c.take((size_t)2 * B * round_up(d.cond_out, 16) * 4);
+  return al256(c.off);
+}
+template <class P>
+static size_t sample_ws(const dppo_net_desc& d, int64_t B) {
+  Carver c{nullptr, 0, 0};
+  MlpBufs<P> Bz;
+  float* enc;
+  return sample_carve<P>(c, d, B, Bz, enc);
+}
+
+template <class P>
 static int sample_impl(const dppo_net_desc& d, const float* pb, const char* kb, const float* pf, const char* kf,
                        const dppo_diffusion_cfg& cfg, const dppo_step* sched, int n_steps, const float* obs,
-                       const float* noise, int64_t B, float* traj, float* chains, int chain_len, int init_slot,
-                       hipStream_t s) {
+                       const float* noise, int64_t B, float* traj, float* chains, int chain_len, int init_slot, void* ws,
+                       int64_t wsb, hipStream_t s) {
   const SamplerGeom g = sampler_geom<P>(d);
   const PackLayout L = pack_layout<P>(d, 0);
   const ParamLayout pl = param_layout(d);
@@ -567,11 +682,22 @@ static int sample_impl(const dppo_net_desc& d, const float* pb, const char* kb, 
   a.ostream[0] = (const u32x4*)(kb + L.ostream), a.ostream[1] = (const u32x4*)(kf + L.ostream);
   a.params[0] = pb, a.params[1] = pf;
   a.temb[0] = (const float*)(kb + L.temb), a.temb[1] = (const float*)(kf + L.temb);
-  a.bias_off[0] = (int)pl.b0;
-  for (int b = 0; b < d.n_blocks; ++b) a.bias_off[1 + 2 * b] = (int)pl.l1b[b], a.bias_off[2 + 2 * b] = (int)pl.l2b[b];
-  a.bias_off[1 + 2 * d.n_blocks] = (int)pl.bout;
-  a.obs = obs, a.noise = noise, a.traj = traj, a.chains = chains, a.sched = sched;
-  a.B = (int)B, a.AF = d.act_flat, a.td = d.time_dim, a.cond = d.cond_dim, a.Kp0 = g.Kp0, a.nb = d.n_blocks;
+  fill_bias_off(d, pl, a.bias_off);
+  a.obs[0] = a.obs[1] = obs, a.cond = d.cond_dim, a.ld_obs = d.cond_dim;
+  if (d.cond_hidden > 0) {  // per-network encoded observation, computed once per call (constant over the K steps)
+    MlpBufs<P> Bz;
+    float* enc = nullptr;
+    if (!ws || (int64_t)sample_ws<P>(d, B) > wsb) return fail(-1, "sampler workspace too small: need %zu bytes", sample_ws<P>(d, B));
+    Carver c{(char*)ws, 0, (size_t)wsb};
+    sample_carve<P>(c, d, B, Bz, enc);
+    const int lde = round_up(d.cond_out, 16);
+    launch_build_direct<P>(nullptr, nullptr, obs, nullptr, 0, 0, d.cond_dim, B, Bz.cin, L.Kpc, s);
+    cond_encode<P>(d, pb, kb, L, B, Bz.cin, Bz, nullptr, enc, lde, false, s);
+    cond_encode<P>(d, pf, kf, L, B, Bz.cin, Bz, nullptr, enc + (size_t)B * lde, lde, false, s);
+    a.obs[0] = enc, a.obs[1] = enc + (size_t)B * lde, a.cond = d.cond_out, a.ld_obs = lde;
+  }
+  a.noise = noise, a.traj = traj, a.chains = chains, a.sched = sched;
+  a.B = (int)B, a.AF = d.act_flat, a.td = d.time_dim, a.Kp0 = g.Kp0, a.nb = d.n_blocks;
   a.n_steps = n_steps, a.chain_len = chain_len, a.init_slot = init_slot, a.act = d.act, a.use_ddim = cfg.use_ddim;
   a.has_dclip = cfg.has_denoised_clip, a.has_eclip = cfg.has_eps_clip, a.has_fclip = cfg.has_final_clip;
   a.dclip = cfg.denoised_clip, a.eclip = cfg.eps_clip, a.rclip = cfg.randn_clip, a.fclip = cfg.final_clip;
@@ -581,10 +707,17 @@ static int sample_impl(const dppo_net_desc& d, const float* pb, const char* kb, 
   return check_launch();
 }
 
+int64_t dppo_sample_chain_workspace_bytes(const dppo_net_desc* actor, int prec, int64_t B) {
+  if (check_net(actor) || check_prec(prec)) return -1;
+  if (B < 1) return fail(-1, "B out of range");
+  return prec == DPPO_PREC_F32 ? (int64_t)sample_ws<F32>(*actor, B) : (int64_t)sample_ws<BF16>(*actor, B);
+}
+
 int dppo_sample_chain(const dppo_net_desc* actor, int prec, const float* params_base, const void* packed_base,
                       const float* params_ft, const void* packed_ft, const dppo_diffusion_cfg* cfg,
                       const dppo_step* sched, int n_steps, const float* obs, const float* noise, int64_t B, float* traj,
-                      float* chains, int chain_len, int init_slot, dppo_stream_t stream) {
+                      float* chains, int chain_len, int init_slot, void* workspace, int64_t workspace_bytes,
+                      dppo_stream_t stream) {
   if (int e = check_net(actor)) return e;
   if (int e = check_prec(prec)) return e;
   if (actor->kind != 0) return fail(-1, "dppo_sample_chain needs an actor descriptor");
@@ -596,7 +729,7 @@ int dppo_sample_chain(const dppo_net_desc* actor, int prec, const float* params_
   if (init_slot >= chain_len) return fail(-1, "init_slot outside the chain");
 #define CALL(P)                                                                                                   \
   sample_impl<P>(*actor, params_base, (const char*)packed_base, params_ft, (const char*)packed_ft, *cfg, sched, n_steps, obs, \
-                 noise, B, traj, chains, chain_len, init_slot, (hipStream_t)stream)
+                 noise, B, traj, chains, chain_len, init_slot, workspace, workspace_bytes, (hipStream_t)stream)
   return DPPO_DISPATCH(prec, CALL);
 #undef CALL
 }
@@ -634,9 +767,11 @@ static int logprob_impl(const dppo_net_desc& d, const float* prm, const char* pk
   BuildRows br;
   memset(&br, 0, sizeof(br));
   br.chains = chains, br.obs = obs, br.temb = (const float*)(pk + L.temb), br.ksteps = ksteps;
-  br.Kft = Kft, br.AF = d.act_flat, br.td = d.time_dim, br.cond = d.cond_dim, br.M = M;
+  br.Kft = Kft, br.AF = d.act_flat, br.td = d.time_dim, br.cond = d.cond_dim, br.M = M, br.obs_in_a = 1;
   br.inA = B.in, br.KpA = L.Kp0, br.brow = brow, br.krow = krow;
+  if (d.cond_hidden > 0) br.obs_in_a = 0, br.inC = B.cin, br.KpC = L.Kpc;
   launch_build_rows<P>(br, s);
+  if (d.cond_hidden > 0) cond_encode<P>(d, prm, pk, L, M, B.cin, B, B.in, nullptr, 0, false, s);
   mlp_forward<P>(d, prm, pk, L, M, B, false, s);
   LogprobArgs la;
   la.eps = B.out, la.lde = B.ldout, la.chains = chains, la.ksteps = ksteps, la.cfg = cfg, la.Kft = Kft;
@@ -724,7 +859,9 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   br.ksteps = ksteps;
   br.Kft = Kft, br.AF = a.act_flat, br.td = a.time_dim, br.cond = a.cond_dim, br.M = N;
   br.inA = W.A.in, br.KpA = LA.Kp0, br.inC = W.C.in, br.KpC = LC.Kp0, br.brow = W.brow, br.krow = W.krow;
+  br.obs_in_a = a.cond_hidden > 0 ? 0 : 1;  // with cond_mlp the encoder fills the state columns (from the critic's obs rows)
   launch_build_rows<P>(br, s);
+  if (a.cond_hidden > 0) cond_encode<P>(a, ap, ak, LA, N, W.C.in, W.A, W.A.in, nullptr, 0, true, s);
   if (gmom == nullptr) launch_adv_moments(adv_k, W.brow, N, W.moments, s);
   mlp_forward<P>(a, ap, ak, LA, N, W.A, true, s);
   mlp_forward<P>(cr, cp, ck, LC, N, W.C, true, s);
@@ -744,6 +881,7 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   }
   launch_ppo_loss<P>(la, s);
   mlp_backward<P>(a, ap, ak, LA, N, W.A, agrad, W.krow, ksteps, Kft, s, fuse_bout);
+  if (a.cond_hidden > 0) cond_backward<P>(a, ap, ak, LA, N, W.A, W.A.dh0_final, W.C.in, agrad, s);
   mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s, fuse_bout);
   return check_launch();
 }

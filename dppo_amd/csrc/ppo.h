@@ -31,6 +31,7 @@ struct BuildRows {
   const float* temb;    // [n_time][td]
   const dppo_step* ksteps;
   int Kft, AF, td, cond;
+  int obs_in_a;  // 1: the observation goes into inA's state columns; 0: zeros there (a cond_mlp encoder fills them)
   int64_t M;
   void* inA;  // [M][KpA] elem : [x_k | temb(t_k) | obs | 0]
   int KpA;
@@ -46,6 +47,10 @@ void launch_build_rows(const BuildRows& a, hipStream_t s);
 template <class P>
 void launch_build_direct(const float* x, const int64_t* t, const float* state, const float* temb, int AF, int td,
                          int cond, int64_t M, void* in, int Kp, hipStream_t s);
+
+// zero columns [c0, c1) of an [M][ld] elem matrix (K padding the GEMM epilogues do not write)
+template <class P>
+void launch_zero_cols(void* X, int M, int c0, int c1, int ld, hipStream_t s);
 
 // ---- log-prob epilogue (diffusion_vpg.py:381-396) -------------------------------------------------
 struct LogprobArgs {

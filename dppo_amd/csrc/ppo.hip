@@ -106,7 +106,7 @@ __global__ void build_rows_kernel(const BuildRows a) {
       v = xk[c];
     else if (c < a.AF + a.td)
       v = a.temb[(size_t)t * a.td + (c - a.AF)];
-    else if (c < a.AF + a.td + a.cond)
+    else if (c < a.AF + a.td + a.cond && a.obs_in_a)
       v = ob[c - a.AF - a.td];
     ia[c] = P::from_f32(v);
   }
@@ -151,6 +151,23 @@ template void launch_build_direct<F32>(const float*, const int64_t*, const float
                                        void*, int, hipStream_t);
 template void launch_build_direct<BF16>(const float*, const int64_t*, const float*, const float*, int, int, int,
                                         int64_t, void*, int, hipStream_t);
+
+template <class P>
+__global__ void zero_cols_kernel(typename P::elem_t* X, int M, int c0, int c1, int ld) {
+  const int w = c1 - c0;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * w) return;
+  X[(i / w) * ld + c0 + (i % w)] = P::from_f32(0.f);
+}
+template <class P>
+void launch_zero_cols(void* X, int M, int c0, int c1, int ld, hipStream_t s) {
+  const size_t n = (size_t)M * (c1 - c0);
+  if (n == 0) return;
+  hipLaunchKernelGGL((zero_cols_kernel<P>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (typename P::elem_t*)X, M,
+                     c0, c1, ld);
+}
+template void launch_zero_cols<F32>(void*, int, int, int, int, hipStream_t);
+template void launch_zero_cols<BF16>(void*, int, int, int, int, hipStream_t);
 
 // =================================================================================================
 // posterior mean (VPGDiffusion.p_mean_var, diffusion_vpg.py:165-223) and its derivative wrt eps

@@ -32,7 +32,8 @@ struct SampleArgs {
   const float* params[2];
   const float* temb[2];  // [n_time][td]
   int bias_off[2 + 2 * MAX_BLOCKS];  // L0, (l1,l2) x nb, out  -- float offsets into params
-  const float* obs;     // [B][cond]
+  const float* obs[2];  // per network: [B][ld_obs] state columns (raw observation, or its cond_mlp encoding)
+  int ld_obs;
   const float* noise;   // [n_steps+1][B][AF]
   float* traj;          // [B][AF]
   float* chains;        // [B][chain_len][AF]

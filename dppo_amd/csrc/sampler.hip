@@ -43,15 +43,20 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
   float* xcur = (float*)(bufB + 16 * HRB);            // [16][AF]
   float* part = xcur + ((16 * AF + 3) & ~3);          // [8 waves][OT*16 features][16 rows]
 
-  // ---- one-time: observation + zero padding of the input image, x_K, time embedding of step 0
-  for (int idx = tid; idx < 16 * Kp0; idx += 512) {
-    const int row = idx / Kp0, c = idx - row * Kp0;
-    if (c >= AF + td) {
-      const int j = c - AF - td;
-      const int grow = min(grow0 + row, B - 1);
-      lds_put<P>(xin, in_rb, in_km, row, c, j < cond ? a.obs[(size_t)grow * cond + j] : 0.f);
+  // ---- one-time: state columns (of the first step's network) + zero padding of the input image, x_K, time
+  // embedding of step 0
+  auto put_state = [&](int net) {
+    const float* ob = a.obs[net];
+    for (int idx = tid; idx < 16 * Kp0; idx += 512) {
+      const int row = idx / Kp0, c = idx - row * Kp0;
+      if (c >= AF + td) {
+        const int j = c - AF - td;
+        const int grow = min(grow0 + row, B - 1);
+        lds_put<P>(xin, in_rb, in_km, row, c, j < cond ? ob[(size_t)grow * a.ld_obs + j] : 0.f);
+      }
     }
-  }
+  };
+  put_state(a.sched[0].net);
   {
     const dppo_step s0 = a.sched[0];
     for (int idx = tid; idx < 16 * AF; idx += 512) {
@@ -228,6 +233,8 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
         const int row = idx / td, j = idx - row * td;
         lds_put<P>(xin, in_rb, in_km, row, AF + j, a.temb[sn.net][sn.t * td + j]);
       }
+      // a cond_mlp encodes the observation per network: swap the state columns when the next step switches network
+      if (sn.net != st.net && a.obs[0] != a.obs[1]) put_state(sn.net);
     }
     __syncthreads();
   }

@@ -25,7 +25,8 @@ PREC_BY_NAME = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": 
 
 class NetDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("kind", "in_dim", "hidden", "n_blocks", "out_dim", "act", "time_dim", "act_flat", "cond_dim")]
+                ("kind", "in_dim", "hidden", "n_blocks", "out_dim", "act", "time_dim", "act_flat", "cond_dim",
+                 "cond_hidden", "cond_out")]
 
 
 class DiffusionCfg(C.Structure):
@@ -60,8 +61,9 @@ SYMBOLS = {
     "dppo_mlp_forward_workspace_bytes": (_L, [_ND, _I, _L]),
     "dppo_actor_forward": (_I, [_ND, _I, _P, _P, _P, _P, _P, _L, _P, _P, _L, _P]),
     "dppo_critic_forward": (_I, [_ND, _I, _P, _P, _P, _L, _P, _P, _L, _P]),
+    "dppo_sample_chain_workspace_bytes": (_L, [_ND, _I, _L]),
     "dppo_sample_chain": (_I, [_ND, _I, _P, _P, _P, _P, C.POINTER(DiffusionCfg), _P, _I, _P, _P, _L, _P, _P, _I, _I,
-                               _P]),
+                               _P, _L, _P]),
     "dppo_chain_logprob_workspace_bytes": (_L, [_ND, _I, _L, _I]),
     "dppo_chain_logprob": (_I, [_ND, _I, _P, _P, C.POINTER(DiffusionCfg), _P, _I, _P, _P, _L, _P, _P, _L, _P]),
     "dppo_gae": (_I, [_P, _P, _P, _P, _I, _I, _D, _D, _D, _P, _P, _P, _P, _P]),

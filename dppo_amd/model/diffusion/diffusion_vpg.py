@@ -53,6 +53,7 @@ class VPGDiffusion(DiffusionModel):
                 self.load_state_dict(checkpoint["model"], strict=False)
         object.__setattr__(self, "_sched_cache", {})
         object.__setattr__(self, "_ws_logprob", hip.Workspace())
+        object.__setattr__(self, "_ws_sample", hip.Workspace())
 
     # ------------------------------------------------------------------ annealing (reference :102-136)
     def step(self):
@@ -183,12 +184,15 @@ class VPGDiffusion(DiffusionModel):
         d = self.actor.net_desc()
         K = self.denoising_steps
         cfg = self.diffusion_cfg()
+        wsb = lib.dppo_sample_chain_workspace_bytes(C.byref(d), self.prec, B)
+        ws = self._ws_sample.get(wsb, dev) if wsb > 0 else None
         hip.check(lib.dppo_sample_chain(
             C.byref(d), self.prec, self.actor.flat_params().data_ptr(), self.actor.packed(self.prec, K).data_ptr(),
             self.actor_ft.flat_params().data_ptr(), self.actor_ft.packed(self.prec, K).data_ptr(), C.byref(cfg),
             sched.data_ptr(), n_steps, obs.data_ptr(), noise.data_ptr(), B, traj.data_ptr(),
             chains.data_ptr() if return_chain else None, chain_len if return_chain else 0,
-            init_slot if return_chain else -1, hip.stream()), "dppo_sample_chain")
+            init_slot if return_chain else -1, ws.data_ptr() if ws is not None else None, wsb, hip.stream()),
+            "dppo_sample_chain")
         traj = traj.view(B, self.horizon_steps, self.action_dim)
         if return_chain:
             chains = chains.view(B, chain_len, self.horizon_steps, self.action_dim)

@@ -14,6 +14,18 @@ class _NoParams(nn.Module):
     """Placeholder for the parameter-free stages of the reference's nn.Sequential (keeps indices 1 and 3)."""
 
 
+class _PlainMLP(nn.Module):
+    """Parameter container with the reference MLP's names: ``moduleList.{i}.linear_1.{weight,bias}`` (mlp.py:46-74)."""
+
+    def __init__(self, dims):
+        super().__init__()
+        self.moduleList = nn.ModuleList()
+        for i in range(len(dims) - 1):
+            layer = nn.Module()
+            layer.linear_1 = nn.Linear(dims[i], dims[i + 1])
+            self.moduleList.append(layer)
+
+
 class DiffusionMLP(HipNet):
     """eps(x, t, state) = ResidualMLP(cat[x, time_mlp(sinusoid(t)), state]).
 
@@ -24,14 +36,19 @@ class DiffusionMLP(HipNet):
                  activation_type="Mish", out_activation_type="Identity", use_layernorm=False, residual_style=False,
                  precision="bf16"):
         super().__init__()
-        if cond_mlp_dims is not None:
-            raise NotImplementedError("dppo_amd: cond_mlp (obs encoder) is not built yet (SURVEY.md 8f)")
+        if cond_mlp_dims is not None and len(cond_mlp_dims) != 2:
+            raise NotImplementedError("dppo_amd: cond_mlp is built for two layers (every shipped cfg: [hidden, out])")
         if not residual_style:
             raise NotImplementedError("dppo_amd: DiffusionMLP needs residual_style=True (plain MLP not built yet)")
         self.time_embedding = nn.Sequential(_NoParams(), nn.Linear(time_dim, time_dim * 2), _NoParams(),
                                             nn.Linear(time_dim * 2, time_dim))
         out_dim = action_dim * horizon_steps
-        in_dim = time_dim + out_dim + cond_dim
+        self.cond_mlp_dims = list(cond_mlp_dims) if cond_mlp_dims is not None else None
+        if cond_mlp_dims is not None:  # reference mlp_diffusion.py:201-207: MLP([cond_dim] + dims), same activation, Identity out
+            if activation_type not in ("ReLU", "Mish"):
+                raise NotImplementedError(f"dppo_amd: activation {activation_type!r} not built (ReLU, Mish are)")
+            self.cond_mlp = _PlainMLP([cond_dim] + list(cond_mlp_dims))
+        in_dim = time_dim + out_dim + (cond_mlp_dims[-1] if cond_mlp_dims is not None else cond_dim)
         self.mlp_mean = ResidualMLP([in_dim] + list(mlp_dims) + [out_dim], activation_type=activation_type,
                                     out_activation_type=out_activation_type, use_layernorm=use_layernorm)
         self.time_dim, self.action_dim, self.horizon_steps, self.cond_dim = time_dim, action_dim, horizon_steps, cond_dim
@@ -41,8 +58,10 @@ class DiffusionMLP(HipNet):
 
     def net_desc(self) -> hip.NetDesc:
         m = self.mlp_mean
+        ch, co = self.cond_mlp_dims if self.cond_mlp_dims is not None else (0, 0)
         return hip.NetDesc(kind=0, in_dim=m.in_dim, hidden=m.hidden, n_blocks=m.n_blocks, out_dim=m.out_dim, act=m.act,
-                           time_dim=self.time_dim, act_flat=m.out_dim, cond_dim=self.cond_dim)
+                           time_dim=self.time_dim, act_flat=m.out_dim, cond_dim=self.cond_dim, cond_hidden=ch,
+                           cond_out=co)
 
     @torch.no_grad()
     def forward(self, x, time, cond, **kwargs):

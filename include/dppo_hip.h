@@ -20,6 +20,7 @@
  * (model/diffusion/mlp_diffusion.py:191-196,246).  Parameters live in ONE flat fp32 buffer in
  * state-dict order:
  *   actor : time_embedding.1.{weight(2td x td),bias}, time_embedding.3.{weight(td x 2td),bias},
+ *           [cond_mlp.moduleList.0.linear_1.{weight(ch x cond),bias}, cond_mlp.moduleList.1.linear_1.{weight(co x ch),bias}],
  *           layers.0.{weight(H x in),bias}, [layers.b.l1.{w,b}, layers.b.l2.{w,b}] x n_blocks,
  *           layers.last.{weight(out x H),bias}
  *   critic: the same without the time embedding (Q1.layers.*).
@@ -53,6 +54,11 @@ typedef struct dppo_net_desc {
   int32_t time_dim; /* actor: td (even, >= 4) ; critic: 0                                    */
   int32_t act_flat; /* actor: Ta*Da ; critic: 0                                              */
   int32_t cond_dim; /* To*Do                                                                 */
+  /* optional observation encoder of the actor (DiffusionMLP cond_mlp_dims = [cond_hidden, cond_out],
+   * model/diffusion/mlp_diffusion.py:201-207,240-241): state' = Linear(act(Linear(state))).  0/0 = none.
+   * With it, in_dim = Ta*Da + time_dim + cond_out. */
+  int32_t cond_hidden;
+  int32_t cond_out;
 } dppo_net_desc;
 
 /* One denoising step, host-prepared in fp32 exactly as the reference computes its tables
@@ -136,10 +142,12 @@ int dppo_critic_forward(const dppo_net_desc* net, int prec, const float* params,
 /* obs (B,cond); noise (n_steps+1,B,Ta*Da): noise[0] is x_K, noise[i+1] the draw of step i (clamped
  * to +-randn_clip inside); sched: n_steps device entries; traj (B,Ta*Da); chains (B,chain_len,Ta*Da)
  * (may be NULL when chain_len == 0); init_slot: chain position of x_K or -1. */
+int64_t dppo_sample_chain_workspace_bytes(const dppo_net_desc* actor, int prec, int64_t B); /* 0 without cond_mlp */
 int dppo_sample_chain(const dppo_net_desc* actor, int prec, const float* params_base, const void* packed_base,
                       const float* params_ft, const void* packed_ft, const dppo_diffusion_cfg* cfg,
                       const dppo_step* sched, int n_steps, const float* obs, const float* noise, int64_t B,
-                      float* traj, float* chains, int chain_len, int init_slot, dppo_stream_t stream);
+                      float* traj, float* chains, int chain_len, int init_slot, void* workspace,
+                      int64_t workspace_bytes, dppo_stream_t stream);
 
 /* ---- A8: VPGDiffusion.get_logprobs (diffusion_vpg.py:319-396) ----------------------------- */
 /* obs (B,cond), chains (B,Kft+1,Ta*Da) -> logprobs (B,Kft,Ta*Da).  ksteps: Kft device entries,

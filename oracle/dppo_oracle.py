@@ -168,6 +168,10 @@ def named_specs(name: str) -> Tuple[NetSpec, NetSpec]:
                           cond_mlp_dims=[64, 16]),
                 NetSpec("critic", cond_dim=20, mlp_dims=[64, 64, 64], activation="Mish", residual=True,
                           use_layernorm=True))
+    if name == "kitchen_like":  # cond_mlp obs encoder, Mish, H=256 (cfg/gym/finetune/kitchen-complete-v0/ft_ppo_diffusion_mlp.yaml:88-101)
+        return (NetSpec("actor", cond_dim=60, mlp_dims=[256, 256, 256], activation="Mish", residual=True,
+                        action_dim=9, horizon_steps=4, time_dim=16, cond_mlp_dims=[128, 32]),
+                NetSpec("critic", cond_dim=60, mlp_dims=[256, 256, 256], activation="Mish", residual=True))
     if name == "plain_mlp":
         return (NetSpec("actor", cond_dim=11, mlp_dims=[64, 64], activation="Mish", residual=False,
                           action_dim=3, horizon_steps=4, time_dim=16),

@@ -121,7 +121,7 @@ def g1_tables():
 def g2_forward():
     rs = np.random.RandomState(100)
     out = {}
-    for name in ("hopper", "can", "halfcheetah", "furniture_like", "plain_mlp"):
+    for name in ("hopper", "can", "halfcheetah", "furniture_like", "plain_mlp", "kitchen_like"):
         a, c = specs(name)
         B = 8
         pa, pc = O.init_params(a, 11), O.init_params(c, 12)
@@ -154,6 +154,8 @@ def g3_g4_chains():
                                                   ddim_steps=10, randn_clip_value=3), False),
         "furniture_like": ("furniture_like", 4, dict(denoising_steps=20, ft_denoising_steps=5,
                                                      randn_clip_value=3), False),
+        "kitchen_like": ("kitchen_like", 5, dict(denoising_steps=20, ft_denoising_steps=10,
+                                                 randn_clip_value=3), False),
     }
     out = {}
     rs = np.random.RandomState(200)
@@ -187,6 +189,7 @@ def g5_loss():
         "ddim": ("hopper", dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
                                 clip_ploss_coef=0.01), 4),
         "furniture_like": ("furniture_like", dict(denoising_steps=20, ft_denoising_steps=5, clip_ploss_coef=0.01), 4),
+        "kitchen_like": ("kitchen_like", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01), 4),
     }
     out = {}
     rs = np.random.RandomState(300)

@@ -30,14 +30,14 @@ def test_library_exports_every_declared_symbol():
 
 def hopper_desc():
     return hip.NetDesc(kind=0, in_dim=39, hidden=512, n_blocks=1, out_dim=12, act=hip.ACT_RELU, time_dim=16,
-                       act_flat=12, cond_dim=11)
+                       act_flat=12, cond_dim=11, cond_hidden=0, cond_out=0)
 
 
 def test_param_count_matches_reference_sizes():
     lib = hip.load()
     assert lib.dppo_net_param_count(C.byref(hopper_desc())) == 553020
     critic = hip.NetDesc(kind=1, in_dim=11, hidden=256, n_blocks=1, out_dim=1, act=hip.ACT_MISH, time_dim=0,
-                         act_flat=0, cond_dim=11)
+                         act_flat=0, cond_dim=11, cond_hidden=0, cond_out=0)
     assert lib.dppo_net_param_count(C.byref(critic)) == 134913
     for prec in (hip.PREC_F32, hip.PREC_BF16):
         assert lib.dppo_packed_bytes(C.byref(hopper_desc()), prec, 20) > 553020
@@ -91,4 +91,15 @@ def test_unsupported_variants_fail_loudly():
     with pytest.raises(NotImplementedError):
         DiffusionMLP(3, 4, 11, mlp_dims=[512, 512, 512], residual_style=True, use_layernorm=True)
     with pytest.raises(NotImplementedError):
-        DiffusionMLP(3, 4, 11, mlp_dims=[512, 512, 512], residual_style=True, cond_mlp_dims=[64, 16])
+        DiffusionMLP(3, 4, 11, mlp_dims=[512, 512, 512], residual_style=False)
+
+
+def test_cond_mlp_layout_matches_reference_names():
+    from dppo_amd.model.diffusion.mlp_diffusion import DiffusionMLP
+    a = DiffusionMLP(9, 4, 60, mlp_dims=[256, 256, 256], residual_style=True, cond_mlp_dims=[128, 32])
+    names = list(dict(a.named_parameters()))
+    assert names[4:8] == ["cond_mlp.moduleList.0.linear_1.weight", "cond_mlp.moduleList.0.linear_1.bias",
+                          "cond_mlp.moduleList.1.linear_1.weight", "cond_mlp.moduleList.1.linear_1.bias"]
+    assert names[8] == "mlp_mean.layers.0.weight" and tuple(a.mlp_mean.layers[0].weight.shape) == (256, 36 + 16 + 32)
+    lib = hip.load()
+    assert a.flat_params().numel() == lib.dppo_net_param_count(C.byref(a.net_desc()))

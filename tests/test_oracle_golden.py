@@ -43,7 +43,7 @@ def test_survey_check_values():
 
 
 # ------------------------------------------------------------------ G2
-@pytest.mark.parametrize("name", ["hopper", "can", "halfcheetah", "furniture_like", "plain_mlp"])
+@pytest.mark.parametrize("name", ["hopper", "can", "halfcheetah", "furniture_like", "plain_mlp", "kitchen_like"])
 def test_network_forward(golden, name):
     g = golden("g2_forward")
     a, c = O.named_specs(name)
@@ -75,6 +75,7 @@ CHAIN_CASES = {
     "ddim100_10_ft4": ("halfcheetah", dict(denoising_steps=100, ft_denoising_steps=4, use_ddim=True,
                                            ddim_steps=10, randn_clip_value=3), False),
     "furniture_like": ("furniture_like", dict(denoising_steps=20, ft_denoising_steps=5, randn_clip_value=3), False),
+    "kitchen_like": ("kitchen_like", dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3), False),
 }
 
 
@@ -115,6 +116,7 @@ LOSS_CASES = {
     "ddim": ("hopper", dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
                             clip_ploss_coef=0.01)),
     "furniture_like": ("furniture_like", dict(denoising_steps=20, ft_denoising_steps=5, clip_ploss_coef=0.01)),
+    "kitchen_like": ("kitchen_like", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01)),
 }
 
 
