@@ -146,7 +146,7 @@ static int g_use_fused = 1;  // tuning knob 1: 1 = fused row-tile kernels where 
 
 template <class P>
 static bool fused_ok(const dppo_net_desc& d) {
-  return g_use_fused && fused_rows_per_tile<P>(d) > 0 && d.out_dim <= 64 && d.hidden <= 512;
+  return g_use_fused && fused_rows_per_tile<P>(d) > 0 && d.out_dim <= 64 && d.hidden <= 1024;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -64,7 +64,7 @@ int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStrea
 template <class P>
 int launch_fused_backward(const dppo_net_desc& d, const FusedBwdArgs& a, hipStream_t s);
 template <class P>
-int fused_rows_per_tile(const dppo_net_desc& d);  // 16*MR for this (hidden, precision), 0 if not covered
+int fused_rows_per_tile(const dppo_net_desc& d);  // rows per tile of the BACKWARD kernel (sizes the per-tile column sums), 0 if not covered
 
 // Fragment packing of a whole stream in ONE launch: layer l occupies positions [pos0, pos0 + KS); element
 // (feature f, contraction index k) of its weight matrix is W[f*rs + k*cs] (rs = ld, cs = 1 for W; rs = 1, cs = ld for W^T)

@@ -15,7 +15,7 @@ __device__ __forceinline__ int kmask16(int rb) {
 // ring depth (k-step positions in flight per wave): 4 unless the accumulators already fill the register file
 template <int TPW, int MR>
 constexpr int ring_depth() {
-  return TPW * MR > 16 ? 2 : 4;
+  return (TPW >= 8 || TPW * MR > 16) ? 2 : 4;
 }
 
 // rows of a [rows][ld] elem matrix -> swizzled LDS image [MT][rb bytes]; 16-byte chunks, zero fill outside
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
     for (int it = wid; it < MR * OT * KSPLIT; it += SAMPLER_WAVES) {
       const int m = it % MR, to = (it / MR) % OT, kh = it / (MR * OT);
       f32x4 oacc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 8
       for (int c = 0; c < KPER; ++c) {
         const int ks = kh * KPER + c;
         const u32x4 wf = os[(size_t)(ks * OT + to) * 64];
@@ -356,9 +356,15 @@ static int pick_mr(int hidden) {
   if (P::ESIZE == 2) return tpw == 2 ? 8 : (tpw == 4 ? 4 : (tpw == 8 ? 2 : 0));
   return tpw == 2 ? 4 : (tpw == 4 ? 2 : (tpw == 8 ? 1 : 0));
 }
+// the backward kernel also holds the running dh and the packed derivative sources: one size smaller at H = 1024
+template <class P>
+static int pick_mr_bwd(int hidden) {
+  const int mr = pick_mr<P>(hidden);
+  return hidden >= 1024 && mr > 1 ? mr / 2 : mr;
+}
 template <class P>
 int fused_rows_per_tile(const dppo_net_desc& d) {
-  return 16 * pick_mr<P>(d.hidden);
+  return 16 * pick_mr_bwd<P>(d.hidden);
 }
 template int fused_rows_per_tile<F32>(const dppo_net_desc&);
 template int fused_rows_per_tile<BF16>(const dppo_net_desc&);
@@ -436,12 +442,12 @@ static int launch_bwd_cfg(const FusedBwdArgs& a, hipStream_t s) {
 
 template <class P>
 int launch_fused_backward(const dppo_net_desc& d, const FusedBwdArgs& a, hipStream_t s) {
-  const int tpw = d.hidden / 128, mr = pick_mr<P>(d.hidden);
+  const int tpw = d.hidden / 128, mr = pick_mr_bwd<P>(d.hidden);
   if (mr == 0 || a.M <= 0) return -1;
 #define DPPO_BWD(T, R) \
   if (tpw == T && mr == R) return launch_bwd_cfg<P, T, R>(a, s);
   if constexpr (P::ESIZE == 2) {
-    DPPO_BWD(2, 8) DPPO_BWD(4, 4) DPPO_BWD(8, 2)
+    DPPO_BWD(2, 8) DPPO_BWD(4, 4) DPPO_BWD(8, 1)
   } else {
     DPPO_BWD(2, 4) DPPO_BWD(4, 2) DPPO_BWD(8, 1)
   }

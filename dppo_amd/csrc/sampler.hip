@@ -97,11 +97,14 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
     const u32x4* nxt = ws[nnet];
     const float* prm = a.params[net];
 
+    // out-layer fragments: prefetched at the top of the step, except at H = 1024 where the registers are needed
     u32x4 of[CNT][OT];
+    if constexpr (TPW < 8) {
 #pragma unroll
-    for (int c = 0; c < CNT; ++c)
+      for (int c = 0; c < CNT; ++c)
 #pragma unroll
-      for (int to = 0; to < OT; ++to) of[c][to] = os[net][(c * OT + to) * 64];
+        for (int to = 0; to < OT; ++to) of[c][to] = os[net][(c * OT + to) * 64];
+    }
 
     f32x4 h[TPW], acc[TPW];
     int pos = 0;
@@ -175,6 +178,12 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
     }
     // ---- output layer: K split over the 8 waves, partial tiles reduced through LDS
     {
+      if constexpr (TPW >= 8) {
+#pragma unroll
+        for (int c = 0; c < CNT; ++c)
+#pragma unroll
+          for (int to = 0; to < OT; ++to) of[c][to] = os[net][(c * OT + to) * 64];
+      }
       f32x4 oacc[OT];
 #pragma unroll
       for (int to = 0; to < OT; ++to) oacc[to] = (f32x4){0.f, 0.f, 0.f, 0.f};

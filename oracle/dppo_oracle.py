@@ -172,6 +172,10 @@ def named_specs(name: str) -> Tuple[NetSpec, NetSpec]:
         return (NetSpec("actor", cond_dim=60, mlp_dims=[256, 256, 256], activation="Mish", residual=True,
                         action_dim=9, horizon_steps=4, time_dim=16, cond_mlp_dims=[128, 32]),
                 NetSpec("critic", cond_dim=60, mlp_dims=[256, 256, 256], activation="Mish", residual=True))
+    if name == "square_like":  # H=1024 + cond_mlp + time_dim 32, Mish (cfg/robomimic/finetune/square/ft_ppo_diffusion_mlp.yaml:92-105)
+        return (NetSpec("actor", cond_dim=23, mlp_dims=[1024, 1024, 1024], activation="Mish", residual=True,
+                        action_dim=7, horizon_steps=4, time_dim=32, cond_mlp_dims=[512, 64]),
+                NetSpec("critic", cond_dim=23, mlp_dims=[256, 256, 256], activation="Mish", residual=True))
     if name == "plain_mlp":
         return (NetSpec("actor", cond_dim=11, mlp_dims=[64, 64], activation="Mish", residual=False,
                           action_dim=3, horizon_steps=4, time_dim=16),

@@ -121,7 +121,7 @@ def g1_tables():
 def g2_forward():
     rs = np.random.RandomState(100)
     out = {}
-    for name in ("hopper", "can", "halfcheetah", "furniture_like", "plain_mlp", "kitchen_like"):
+    for name in ("hopper", "can", "halfcheetah", "furniture_like", "plain_mlp", "kitchen_like", "square_like"):
         a, c = specs(name)
         B = 8
         pa, pc = O.init_params(a, 11), O.init_params(c, 12)
@@ -156,6 +156,8 @@ def g3_g4_chains():
                                                      randn_clip_value=3), False),
         "kitchen_like": ("kitchen_like", 5, dict(denoising_steps=20, ft_denoising_steps=10,
                                                  randn_clip_value=3), False),
+        "square_like": ("square_like", 3, dict(denoising_steps=20, ft_denoising_steps=10,
+                                               randn_clip_value=3), False),
     }
     out = {}
     rs = np.random.RandomState(200)
@@ -190,6 +192,7 @@ def g5_loss():
                                 clip_ploss_coef=0.01), 4),
         "furniture_like": ("furniture_like", dict(denoising_steps=20, ft_denoising_steps=5, clip_ploss_coef=0.01), 4),
         "kitchen_like": ("kitchen_like", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01), 4),
+        "square_like": ("square_like", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01), 4),
     }
     out = {}
     rs = np.random.RandomState(300)

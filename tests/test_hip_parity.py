@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 T = torch.from_numpy
 DEV = "cuda:0"
-HIP_SUPPORTED = {"hopper", "can", "halfcheetah", "kitchen_like"}  # LayerNorm / plain-MLP variants are "next" rows
+HIP_SUPPORTED = {"hopper", "can", "halfcheetah", "kitchen_like", "square_like"}  # LayerNorm / plain-MLP variants are "next" rows
 
 
 def build_model(sname, kw, seed, precision):
@@ -54,15 +54,15 @@ def test_library_loads_and_versions():
 
 # ------------------------------------------------------------------ G2 network forwards
 @pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16", 3e-2)])
-@pytest.mark.parametrize("name", ["hopper", "can", "halfcheetah", "kitchen_like"])
+@pytest.mark.parametrize("name", ["hopper", "can", "halfcheetah", "kitchen_like", "square_like"])
 def test_network_forward(golden, name, prec, tol):
     from dppo_amd.model.common.critic import CriticObs
     from dppo_amd.model.diffusion.mlp_diffusion import DiffusionMLP
     g = golden("g2_forward")
     a, c = O.named_specs(name)
     actor = DiffusionMLP(action_dim=a.action_dim, horizon_steps=a.horizon_steps, cond_dim=a.cond_dim,
-                         mlp_dims=list(a.mlp_dims), activation_type=a.activation, cond_mlp_dims=a.cond_mlp_dims,
-                         residual_style=True, precision=prec).to(DEV)
+                         time_dim=a.time_dim, mlp_dims=list(a.mlp_dims), activation_type=a.activation,
+                         cond_mlp_dims=a.cond_mlp_dims, residual_style=True, precision=prec).to(DEV)
     critic = CriticObs(cond_dim=c.cond_dim, mlp_dims=list(c.mlp_dims), activation_type=c.activation,
                        residual_style=True, precision=prec).to(DEV)
     actor.load_state_dict(O.init_params(a, 11))
@@ -265,7 +265,7 @@ def test_adamw_and_clip_match_torch(golden):
 
 # ------------------------------------------------------------------ fused row-tile kernels vs layered GEMM chain
 @pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
-@pytest.mark.parametrize("sname", ["hopper", "can", "kitchen_like"])
+@pytest.mark.parametrize("sname", ["hopper", "can", "kitchen_like", "square_like"])
 def test_fused_path_matches_layered_path(prec, tol, sname):
     """Two independent implementations of the big-batch MLP (fused row-tile kernels / layer-by-layer gemm_nt
     chain, tuning knob 1) must agree on log-probs, loss statistics and every gradient."""

@@ -43,7 +43,7 @@ def test_survey_check_values():
 
 
 # ------------------------------------------------------------------ G2
-@pytest.mark.parametrize("name", ["hopper", "can", "halfcheetah", "furniture_like", "plain_mlp", "kitchen_like"])
+@pytest.mark.parametrize("name", ["hopper", "can", "halfcheetah", "furniture_like", "plain_mlp", "kitchen_like", "square_like"])
 def test_network_forward(golden, name):
     g = golden("g2_forward")
     a, c = O.named_specs(name)
@@ -76,6 +76,7 @@ CHAIN_CASES = {
                                            ddim_steps=10, randn_clip_value=3), False),
     "furniture_like": ("furniture_like", dict(denoising_steps=20, ft_denoising_steps=5, randn_clip_value=3), False),
     "kitchen_like": ("kitchen_like", dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3), False),
+    "square_like": ("square_like", dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3), False),
 }
 
 
@@ -117,6 +118,7 @@ LOSS_CASES = {
                             clip_ploss_coef=0.01)),
     "furniture_like": ("furniture_like", dict(denoising_steps=20, ft_denoising_steps=5, clip_ploss_coef=0.01)),
     "kitchen_like": ("kitchen_like", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01)),
+    "square_like": ("square_like", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01)),
 }
 
 
