@@ -41,7 +41,9 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
   char* bufA = xin + 16 * in_rb;
   char* bufB = bufA + 16 * HRB;
   float* xcur = (float*)(bufB + 16 * HRB);            // [16][AF]
-  float* part = xcur + ((16 * AF + 3) & ~3);          // [8 waves][OT*16 features][16 rows]
+  // out-layer partials [8 waves][OT*16 features][16 rows]: bufB is idle while the out layer reads bufA, reuse it when it fits
+  constexpr bool PART_IN_B = SAMPLER_WAVES * OT * 16 * 16 * 4 <= 16 * HRB;
+  float* part = PART_IN_B ? (float*)bufB : xcur + ((16 * AF + 3) & ~3);
 
   // ---- one-time: state columns (of the first step's network) + zero padding of the input image, x_K, time
   // embedding of step 0
@@ -274,8 +276,9 @@ template SamplerGeom sampler_geom<BF16>(const dppo_net_desc&);
 template <class P, int TPW, int OT>
 static int launch_cfg(const SamplerGeom& g, const SampleArgs& a, hipStream_t s) {
   const int ES = P::ESIZE;
+  const size_t part_bytes = (size_t)SAMPLER_WAVES * OT * 16 * 16 * 4;
   size_t lds = (size_t)16 * a.Kp0 * ES + 2 * (size_t)16 * g.H * ES + (size_t)((16 * a.AF + 3) & ~3) * 4 +
-               (size_t)SAMPLER_WAVES * OT * 16 * 16 * 4;
+               (part_bytes <= (size_t)16 * g.H * ES ? 0 : part_bytes);
   if (lds > 160 * 1024) return -2;
   static bool attr_set = false;  // raising the dynamic-LDS cap is idempotent; racing setters are harmless
   auto kern = sample_chain_kernel<P, TPW, OT>;
