@@ -30,8 +30,8 @@ static int check_launch() {
 // layouts
 // ------------------------------------------------------------------------------------------------
 struct ParamLayout {  // float offsets into the flat fp32 parameter / gradient buffer (state-dict order)
-  int64_t te1_w, te1_b, te2_w, te2_b, c1w, c1b, c2w, c2b, W0, b0, l1w[MAX_BLOCKS], l1b[MAX_BLOCKS], l2w[MAX_BLOCKS], l2b[MAX_BLOCKS], Wout,
-      bout, total;
+  int64_t te1_w, te1_b, te2_w, te2_b, c1w, c1b, c2w, c2b, W0, b0, l1w[MAX_BLOCKS], l1b[MAX_BLOCKS], l2w[MAX_BLOCKS], l2b[MAX_BLOCKS],
+      n1w[MAX_BLOCKS], n1b[MAX_BLOCKS], n2w[MAX_BLOCKS], n2b[MAX_BLOCKS], Wout, bout, total;
 };
 static ParamLayout param_layout(const dppo_net_desc& d) {
   ParamLayout L;
@@ -57,6 +57,12 @@ static ParamLayout param_layout(const dppo_net_desc& d) {
     L.l1b[b] = o, o += H;
     L.l2w[b] = o, o += (int64_t)H * H;
     L.l2b[b] = o, o += H;
+    if (d.use_layernorm) {
+      L.n1w[b] = o, o += H;
+      L.n1b[b] = o, o += H;
+      L.n2w[b] = o, o += H;
+      L.n2b[b] = o, o += H;
+    }
   }
   L.Wout = o, o += (int64_t)d.out_dim * H;
   L.bout = o, o += d.out_dim;
@@ -133,6 +139,9 @@ static int check_net(const dppo_net_desc* d) {
     if (d->out_dim != 1) return fail(-1, "critic out_dim must be 1");
   }
   if (d->in_dim < 1 || d->in_dim > 1024) return fail(-1, "in_dim=%d out of [1,1024]", d->in_dim);
+  if (d->use_layernorm != 0 && d->use_layernorm != 1) return fail(-1, "use_layernorm must be 0 or 1");
+  if (d->use_layernorm && !(d->hidden == 256 || d->hidden == 512 || d->hidden == 1024))
+    return fail(-1, "LayerNorm blocks need hidden in {256, 512, 1024} (fused kernels only), got %d", d->hidden);
   return 0;
 }
 static int check_prec(int prec) {
@@ -146,7 +155,7 @@ static int g_use_fused = 1;  // tuning knob 1: 1 = fused row-tile kernels where 
 
 template <class P>
 static bool fused_ok(const dppo_net_desc& d) {
-  return g_use_fused && fused_rows_per_tile<P>(d) > 0 && d.out_dim <= 64 && d.hidden <= 1024;
+  return (g_use_fused || d.use_layernorm) && fused_rows_per_tile<P>(d) > 0 && d.out_dim <= 64 && d.hidden <= 1024;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -246,6 +255,7 @@ struct MlpBufs {  // activations of one network for M rows
   void* d_cz;    // [M][C1p]
   void* dh_all[MAX_BLOCKS + 1];  // fused backward: dh[b] = d loss / d h_b, elem [M][H]
   void* dz1_all[MAX_BLOCKS];
+  float* ln_stats;               // [nb][2][M][2] LayerNorm row statistics (training)
   const void* dh0_final;         // where the last backward left d loss / d h_0
   float* tile_colsum;            // [(2nb+1)][tiles][H]
   int tiles;
@@ -288,6 +298,7 @@ static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, b
       B.d_cz = c.take((size_t)M * C1p * ES);
     }
   }
+  if (d.use_layernorm && keep) B.ln_stats = (float*)c.take((size_t)nb * 2 * M * 2 * 4);
   B.hE = c.take((size_t)M * H * ES);
   for (int b = 0; b <= nb; ++b) B.hpre[b] = b == nb ? B.hE : (keep ? c.take((size_t)M * H * ES) : nullptr);
   B.ldout = round_up(d.out_dim, 16);
@@ -303,7 +314,7 @@ static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, b
     }
     const int mt = fused_rows_per_tile<P>(d);
     B.tiles = mt > 0 ? (int)((M + mt - 1) / mt) : 0;
-    B.tile_colsum = (float*)c.take((size_t)(2 * nb + 1) * (B.tiles > 0 ? B.tiles : 1) * H * 4);
+    B.tile_colsum = (float*)c.take((size_t)(2 * nb + 1 + (d.use_layernorm ? 4 * nb : 0)) * (B.tiles > 0 ? B.tiles : 1) * H * 4);
     const int tdp = round_up(d.time_dim > 0 ? d.time_dim : 1, 16);
     B.dtemb = d.kind == 0 ? (float*)c.take((size_t)M * tdp * 4) : nullptr;
     // largest slab: H x max(H, Kp0) with up to 64 splits of a <=4-tile output, or 16+ splits of H x H
@@ -322,6 +333,10 @@ static void fill_bias_off(const dppo_net_desc& d, const ParamLayout& pl, int* of
   off[0] = (int)pl.b0;
   for (int b = 0; b < d.n_blocks; ++b) off[1 + 2 * b] = (int)pl.l1b[b], off[2 + 2 * b] = (int)pl.l2b[b];
   off[1 + 2 * d.n_blocks] = (int)pl.bout;
+}
+static void fill_ln_off(const dppo_net_desc& d, const ParamLayout& pl, int* off) {
+  for (int b = 0; b < d.n_blocks; ++b)
+    off[4 * b] = (int)pl.n1w[b], off[4 * b + 1] = (int)pl.n1b[b], off[4 * b + 2] = (int)pl.n2w[b], off[4 * b + 3] = (int)pl.n2b[b];
 }
 
 // cond_mlp (mlp_diffusion.py:201-207,240-241): enc = Linear2(act(Linear1(obs))), written as elem straight into the
@@ -356,12 +371,16 @@ static void mlp_forward(const dppo_net_desc& d, const float* prm, const char* pk
     fill_bias_off(d, pl, f.bias_off);
     f.in = B.in, f.ld_in = L.Kp0, f.M = (int)M, f.Kp0 = sampler_geom<P>(d).Kp0, f.nb = nb, f.act = d.act;
     f.out_dim = d.out_dim, f.out = B.out, f.ldout = B.ldout, f.in_valid = d.in_dim;
+    f.use_ln = d.use_layernorm;
+    if (d.use_layernorm) fill_ln_off(d, pl, f.ln_off);
     if (keep) {
       for (int b = 0; b < nb; ++b) {
         f.a1[b] = B.a1[b], f.a2[b] = B.a2[b];
-        if (d.act != DPPO_ACT_RELU) f.z1[b] = B.z1[b], f.hpre[b] = B.hpre[b];  // Mish' needs the pre-activations
+        // Mish' needs the pre-activations; LayerNorm's backward needs its inputs
+        if (d.act != DPPO_ACT_RELU || d.use_layernorm) f.z1[b] = B.z1[b], f.hpre[b] = B.hpre[b];
       }
       f.hpre[nb] = B.hE;
+      f.ln_stats = d.use_layernorm ? B.ln_stats : nullptr;
     }
     if (launch_fused_forward<P>(d, f, s) == 0) return;
   }
@@ -484,10 +503,12 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
     const FusedGeom fg = fused_geom<P>(d);
     f.bstream = (const u32x4*)(pk + L.bstream), f.d_out = B.d_out, f.ld_dout = L.Kpo, f.M = (int)M, f.KpB0 = fg.KpB0;
     f.nb = nb, f.act = d.act, f.colsum = B.tile_colsum, f.out_valid = d.out_dim;
-    const bool relu = d.act == DPPO_ACT_RELU;
+    const bool post = d.act == DPPO_ACT_RELU && !d.use_layernorm;  // ReLU': the activated copy suffices
+    f.params = prm, f.use_ln = d.use_layernorm, f.ln_stats = B.ln_stats;
+    if (d.use_layernorm) fill_ln_off(d, pl, f.ln_off);
     for (int b = 0; b < nb; ++b) {
-      f.m1[b] = relu ? B.a2[b] : B.z1[b];
-      f.m0[b] = relu ? B.a1[b] : B.hpre[b];
+      f.m1[b] = post ? B.a2[b] : B.z1[b];
+      f.m0[b] = post ? B.a1[b] : B.hpre[b];
       f.dz1[b] = B.dz1_all[b];
     }
     for (int b = 0; b <= nb; ++b) f.dh[b] = B.dh_all[b];
@@ -501,6 +522,14 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
         so.out[(nb + 1) + (nb - 1 - b)] = grad + pl.l1b[b];
       }
       so.out[nb] = grad + pl.b0;
+      if (d.use_layernorm) {  // 4 more slots per block, top block first: d gamma1, d beta1, d gamma2, d beta2
+        for (int b = nb - 1; b >= 0; --b) {
+          const int ls = (2 * nb + 1) + 4 * (nb - 1 - b);
+          so.out[ls] = grad + pl.n1w[b], so.out[ls + 1] = grad + pl.n1b[b];
+          so.out[ls + 2] = grad + pl.n2w[b], so.out[ls + 3] = grad + pl.n2b[b];
+        }
+        so.n_slots += 4 * nb;
+      }
       launch_reduce_slots(B.tile_colsum, B.tiles, H, so, s);
       weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.hE, H, H, M, B, grad + pl.Wout, H, s);
       if (!bout_done) launch_colsum<P>(B.d_out, (int)M, d.out_dim, L.Kpo, B.part, REDUCE_BLOCKS, grad + pl.bout, 1.f, s);
@@ -683,6 +712,8 @@ static int sample_impl(const dppo_net_desc& d, const float* pb, const char* kb, 
   a.params[0] = pb, a.params[1] = pf;
   a.temb[0] = (const float*)(kb + L.temb), a.temb[1] = (const float*)(kf + L.temb);
   fill_bias_off(d, pl, a.bias_off);
+  a.use_ln = d.use_layernorm;
+  if (d.use_layernorm) fill_ln_off(d, pl, a.ln_off);
   a.obs[0] = a.obs[1] = obs, a.cond = d.cond_dim, a.ld_obs = d.cond_dim;
   if (d.cond_hidden > 0) {  // per-network encoded observation, computed once per call (constant over the K steps)
     MlpBufs<P> Bz;

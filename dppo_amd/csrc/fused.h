@@ -30,6 +30,9 @@ struct FusedFwdArgs {
   const u32x4* ostream;  // out-layer fragments, [ks][to][lane]
   const float* params;
   int bias_off[2 + 2 * MAX_BLOCKS];
+  int ln_off[4 * MAX_BLOCKS];  // per block: norm1.weight, norm1.bias, norm2.weight, norm2.bias (use_ln only)
+  int use_ln;
+  float* ln_stats;  // training + use_ln: [nb][2 norms][M][2] (mean, rstd) of every LayerNorm input row, else null
   const void* in;  // [M][ld_in] elem ; columns >= ld_in are zero
   int ld_in;
   int M, Kp0, nb, act, out_dim;
@@ -49,13 +52,19 @@ struct FusedBwdArgs {
   int ld_dout;
   int M, KpB0, nb, act;
   int out_valid;  // true output width of the network (algorithmic FLOP accounting only)
+  // LayerNorm blocks: parameters (gamma/beta), saved row statistics; m1/m0 then hold the PRE-LayerNorm tensors z1_b / h_b
+  const float* params;
+  int ln_off[4 * MAX_BLOCKS];
+  int use_ln;
+  const float* ln_stats;  // [nb][2][M][2] (mean, rstd) from the forward
   // derivative sources, [M][H] elem: ReLU uses the activated copies (a > 0), Mish the pre-activations
   const void* m1[MAX_BLOCKS];  // for act'(z1_b): a2_b (ReLU) or z1_b (Mish)
   const void* m0[MAX_BLOCKS];  // for act'(h_b) : a1_b (ReLU) or hpre_b (Mish)
   // outputs, [M][H] elem
   void* dh[MAX_BLOCKS + 1];  // dh[b] = d loss / d h_b  (dh[nb] = d_out . Wout)
   void* dz1[MAX_BLOCKS];
-  // per-tile column sums (bias gradients): [(nb+1) + nb tensors][tiles][H] f32, tensor order dh[nb..0] then dz1[nb-1..0]
+  // per-tile column sums: [slots][tiles][H] f32.  Slots 0..nb: dh[nb..0]; nb+1..2nb: dz1[nb-1..0] (bias gradients);
+  // with LayerNorm 4 more per block, top block first: d gamma1, d beta1, d gamma2, d beta2
   float* colsum;
 };
 
@@ -83,7 +92,7 @@ void launch_pack_stream(const PackStream& d, hipStream_t s);
 
 // out[slot][c] = sum_t in[slot][t][c]  for c < n, one launch for all slots (bias gradients from per-tile column sums)
 struct SlotOuts {
-  float* out[2 * MAX_BLOCKS + 1];
+  float* out[6 * MAX_BLOCKS + 1];
   int n_slots;
 };
 void launch_reduce_slots(const float* in, int tiles, int n, const SlotOuts& o, hipStream_t s);

@@ -1,6 +1,7 @@
 // See fused.h.  gfx950 only.
 #include "fused.h"
 #include "gemm.h"
+#include "tile_ln.h"
 
 namespace dppo {
 
@@ -146,7 +147,7 @@ __device__ __forceinline__ float grad_at(const u32x4 (&d)[MR][CH], int actk, int
 // =================================================================================================
 // forward
 // =================================================================================================
-template <class P, int TPW, int MR, int OT>
+template <class P, int TPW, int MR, int OT, bool LN>
 __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a) {
   constexpr int PD = ring_depth<TPW, MR>(), ES = P::ESIZE, KB = P::KB;
   constexpr int H = 128 * TPW, KSH = H / KB, HRB = H * ES, MT = 16 * MR;
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
   char* bufB = bufA + MT * HRB;
   char* xin = bufB;  // the input tile is dead once layer 0 has run, before the first block writes bufB
   float* part = (float*)(bufB + MT * HRB);  // [KSPLIT][MR][OT*16 features][16 rows]
+  float* lnred = part + KSPLIT * MR * OT * 16 * 16;  // [8 waves][MR][16] LayerNorm row-reduction table
   const int wbase = wid * 16 * TPW;  // lane features: wbase + feat_off<P>(g, tp) + e
   const u32x4* os = a.ostream + lane;
 
@@ -186,6 +188,24 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
         for (int m = 0; m < MR; ++m) acc[tp][m] = b;
       }
     };
+    // block input: bufA <- act([LN1_b] h), with the tensors the backward needs (training only)
+    auto put_block_input = [&](int b) {
+      if (a.hpre[b] != nullptr) emit<P, TPW, MR>(h, ACT_NONE, nullptr, a.hpre[b], H, wbase, g, r, row0, M);
+      if constexpr (LN) {
+        float mean[MR], rstd[MR];
+        ln_forward<P, TPW, MR>(h, acc, a.params + a.ln_off[4 * b], a.params + a.ln_off[4 * b + 1], H, wbase, g, r, wid,
+                               lnred, mean, rstd);
+        if (a.ln_stats != nullptr && wid == 0 && g == 0) {
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+            if (row0 + 16 * m + r < M)
+              *(float2*)(a.ln_stats + (((size_t)(2 * b) * M) + row0 + 16 * m + r) * 2) = make_float2(mean[m], rstd[m]);
+        }
+        emit<P, TPW, MR>(acc, a.act, bufA, a.a1[b], H, wbase, g, r, row0, M);
+      } else {
+        emit<P, TPW, MR>(h, a.act, bufA, a.a1[b], H, wbase, g, r, row0, M);
+      }
+    };
     // ---- layer 0
     bias_init(a.bias_off[0]);
     eng.run(acc, xin, in_rb, in_km, KS0, r, g);
@@ -193,18 +213,27 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
     for (int tp = 0; tp < TPW; ++tp)
 #pragma unroll
       for (int m = 0; m < MR; ++m) h[tp][m] = acc[tp][m];
-    if (nb > 0) {
-      if (a.hpre[0] != nullptr) emit<P, TPW, MR>(h, ACT_NONE, nullptr, a.hpre[0], H, wbase, g, r, row0, M);
-      emit<P, TPW, MR>(h, a.act, bufA, a.a1[0], H, wbase, g, r, row0, M);
-    } else {
+    if (nb > 0)
+      put_block_input(0);
+    else
       emit<P, TPW, MR>(h, ACT_NONE, bufA, a.hpre[0], H, wbase, g, r, row0, M);
-    }
     __syncthreads();
     // ---- residual blocks
     for (int b = 0; b < nb; ++b) {
       bias_init(a.bias_off[1 + 2 * b]);
       eng.run(acc, bufA, HRB, 15, KSH, r, g);
       if (a.z1[b] != nullptr) emit<P, TPW, MR>(acc, ACT_NONE, nullptr, a.z1[b], H, wbase, g, r, row0, M);
+      if constexpr (LN) {
+        float mean[MR], rstd[MR];
+        ln_forward<P, TPW, MR>(acc, acc, a.params + a.ln_off[4 * b + 2], a.params + a.ln_off[4 * b + 3], H, wbase, g, r,
+                               wid, lnred, mean, rstd);
+        if (a.ln_stats != nullptr && wid == 0 && g == 0) {
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+            if (row0 + 16 * m + r < M)
+              *(float2*)(a.ln_stats + (((size_t)(2 * b + 1) * M) + row0 + 16 * m + r) * 2) = make_float2(mean[m], rstd[m]);
+        }
+      }
       emit<P, TPW, MR>(acc, a.act, bufB, a.a2[b], H, wbase, g, r, row0, M);
       __syncthreads();
       bias_init(a.bias_off[2 + 2 * b]);
@@ -213,12 +242,10 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
       for (int tp = 0; tp < TPW; ++tp)
 #pragma unroll
         for (int m = 0; m < MR; ++m) h[tp][m] += acc[tp][m];
-      if (b + 1 < nb) {
-        if (a.hpre[b + 1] != nullptr) emit<P, TPW, MR>(h, ACT_NONE, nullptr, a.hpre[b + 1], H, wbase, g, r, row0, M);
-        emit<P, TPW, MR>(h, a.act, bufA, a.a1[b + 1], H, wbase, g, r, row0, M);
-      } else {
+      if (b + 1 < nb)
+        put_block_input(b + 1);
+      else
         emit<P, TPW, MR>(h, ACT_NONE, bufA, a.hpre[nb], H, wbase, g, r, row0, M);
-      }
       __syncthreads();
     }
     // ---- output layer: work items (row sub-tile m, out tile to, K slice kh) dealt to the 8 waves
@@ -251,7 +278,7 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
 // =================================================================================================
 // backward (data gradients + column sums)
 // =================================================================================================
-template <class P, int TPW, int MR>
+template <class P, int TPW, int MR, bool LN>
 __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs a) {
   constexpr int PD = 2, ES = P::ESIZE, KB = P::KB;
   constexpr int H = 128 * TPW, KSH = H / KB, HRB = H * ES, MT = 16 * MR;
@@ -265,6 +292,7 @@ __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs 
   char* bufA = smem;
   char* bufB = bufA + MT * HRB;
   char* xin = bufB;  // d_out tile: consumed by the first layer, which emits into bufA
+  float* lnred = (float*)(bufB + MT * HRB);  // [8 waves][2][MR][16] LayerNorm row-reduction table (LN only)
   const int wbase = wid * 16 * TPW;  // lane features: wbase + feat_off<P>(g, tp) + e
   const int ntiles = (M + MT - 1) / MT;
 
@@ -290,6 +318,31 @@ __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs 
       if (r == 0) *(f32x4*)(a.colsum + ((size_t)slot * ntiles + tile) * H + wbase + feat_off<P>(g, tp)) = s;
     }
   };
+  // same for per-lane sums that are already reduced over the row sub-tiles (LayerNorm d gamma / d beta)
+  auto colsum1 = [&](const f32x4 (&v)[TPW], int slot, int tile) {
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) {
+      f32x4 s = v[tp];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = s[e];
+        x += __shfl_xor(x, 1);
+        x += __shfl_xor(x, 2);
+        x += __shfl_xor(x, 4);
+        x += __shfl_xor(x, 8);
+        s[e] = x;
+      }
+      if (r == 0) *(f32x4*)(a.colsum + ((size_t)slot * ntiles + tile) * H + wbase + feat_off<P>(g, tp)) = s;
+    }
+  };
+  auto load_stats = [&](int which, int row0, float (&mean)[MR], float (&rstd)[MR]) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      const int grow = row0 + 16 * m + r;
+      const float2 st = *(const float2*)(a.ln_stats + ((size_t)which * M + (grow < M ? grow : M - 1)) * 2);
+      mean[m] = st.x, rstd[m] = st.y;
+    }
+  };
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int row0 = tile * MT;
@@ -313,30 +366,56 @@ __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs 
     colsum(dh, 0, tile);
     __syncthreads();
     for (int b = nb - 1; b >= 0; --b) {
-      // ---- dz1 = (dh . W2) * act'(z1)
+      // ---- dz1 = (dh . W2) * act'(z1)       [LayerNorm: back through act(LN2(z1))]
       u32x4 d[MR][Chunks<P, TPW>::CH];
       fetch<P>(d, a.m1[b], H, wbase, g, r, row0, M);  // issued ahead of the layer: latency hides under it
       zero_acc();
       eng.run(acc, bufA, HRB, 15, KSH, r, g);
+      if constexpr (LN) {
+        float mean[MR], rstd[MR];
+        f32x4 dga[TPW], dbe[TPW];
+        load_stats(2 * b + 1, row0, mean, rstd);
+        ln_backward<P, TPW, MR>(acc, d, a.params + a.ln_off[4 * b + 2], a.params + a.ln_off[4 * b + 3], mean, rstd, a.act, H,
+                                wbase, g, r, wid, lnred, dga, dbe);
+        const int ls = (2 * nb + 1) + 4 * (nb - 1 - b);
+        colsum1(dga, ls + 2, tile);
+        colsum1(dbe, ls + 3, tile);
+      } else {
 #pragma unroll
-      for (int tp = 0; tp < TPW; ++tp)
+        for (int tp = 0; tp < TPW; ++tp)
 #pragma unroll
-        for (int m = 0; m < MR; ++m)
+          for (int m = 0; m < MR; ++m)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[tp][m][e] *= grad_at<P>(d, a.act, tp, m, e);
+            for (int e = 0; e < 4; ++e) acc[tp][m][e] *= grad_at<P>(d, a.act, tp, m, e);
+      }
       emit<P, TPW, MR>(acc, ACT_NONE, bufB, a.dz1[b], H, wbase, g, r, row0, M);
       colsum(acc, (nb + 1) + (nb - 1 - b), tile);
       __syncthreads();
-      // ---- dh[b] = dh[b+1] + (dz1 . W1) * act'(h_b)
+      // ---- dh[b] = dh[b+1] + (dz1 . W1) * act'(h_b)       [LayerNorm: back through act(LN1(h_b))]
       fetch<P>(d, a.m0[b], H, wbase, g, r, row0, M);
       zero_acc();
       eng.run(acc, bufB, HRB, 15, KSH, r, g);
+      if constexpr (LN) {
+        float mean[MR], rstd[MR];
+        f32x4 dga[TPW], dbe[TPW];
+        load_stats(2 * b, row0, mean, rstd);
+        ln_backward<P, TPW, MR>(acc, d, a.params + a.ln_off[4 * b], a.params + a.ln_off[4 * b + 1], mean, rstd, a.act, H,
+                                wbase, g, r, wid, lnred, dga, dbe);
+        const int ls = (2 * nb + 1) + 4 * (nb - 1 - b);
+        colsum1(dga, ls, tile);
+        colsum1(dbe, ls + 1, tile);
 #pragma unroll
-      for (int tp = 0; tp < TPW; ++tp)
+        for (int tp = 0; tp < TPW; ++tp)
 #pragma unroll
-        for (int m = 0; m < MR; ++m)
+          for (int m = 0; m < MR; ++m) dh[tp][m] += acc[tp][m];
+      } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) dh[tp][m][e] += acc[tp][m][e] * grad_at<P>(d, a.act, tp, m, e);
+        for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dh[tp][m][e] += acc[tp][m][e] * grad_at<P>(d, a.act, tp, m, e);
+      }
       emit<P, TPW, MR>(dh, ACT_NONE, bufA, a.dh[b], H, wbase, g, r, row0, M);
       colsum(dh, nb - b, tile);
       __syncthreads();
@@ -357,14 +436,17 @@ static int pick_mr(int hidden) {
   return tpw == 2 ? 4 : (tpw == 4 ? 2 : (tpw == 8 ? 1 : 0));
 }
 // the backward kernel also holds the running dh and the packed derivative sources: one size smaller at H = 1024
+// (and once more with LayerNorm, whose backward keeps two more row-statistics / gradient sets live)
 template <class P>
-static int pick_mr_bwd(int hidden) {
-  const int mr = pick_mr<P>(hidden);
-  return hidden >= 1024 && mr > 1 ? mr / 2 : mr;
+static int pick_mr_bwd(int hidden, int ln) {
+  int mr = pick_mr<P>(hidden);
+  if (hidden >= 1024 && mr > 1) mr /= 2;
+  if (ln && mr > 1) mr /= 2;
+  return mr;
 }
 template <class P>
 int fused_rows_per_tile(const dppo_net_desc& d) {
-  return 16 * pick_mr_bwd<P>(d.hidden);
+  return 16 * pick_mr_bwd<P>(d.hidden, d.use_layernorm);
 }
 template int fused_rows_per_tile<F32>(const dppo_net_desc&);
 template int fused_rows_per_tile<BF16>(const dppo_net_desc&);
@@ -392,17 +474,17 @@ static void raise_lds(K kern, bool& done) {
   }
 }
 
-template <class P, int TPW, int MR, int OT>
+template <class P, int TPW, int MR, int OT, bool LN>
 static int launch_fwd_cfg(const FusedFwdArgs& a, hipStream_t s) {
   constexpr int ES = P::ESIZE, MT = 16 * MR, H = 128 * TPW;
   constexpr int KSPLIT = MR * OT >= 8 ? 1 : 8 / (MR * OT);
-  const size_t lds = 2 * (size_t)MT * H * ES + (size_t)KSPLIT * MR * OT * 16 * 16 * 4;
+  const size_t lds = 2 * (size_t)MT * H * ES + (size_t)KSPLIT * MR * OT * 16 * 16 * 4 + (size_t)LN_WAVES * MR * 16 * 4;
   if (lds > 160 * 1024 || a.Kp0 > H) return -2;
   static bool attr = false;
-  raise_lds(fused_forward_kernel<P, TPW, MR, OT>, attr);
+  raise_lds(fused_forward_kernel<P, TPW, MR, OT, LN>, attr);
   const int ntiles = (a.M + MT - 1) / MT;
   const bool probe = probe_begin(PROBE_FUSED_FWD, s);
-  hipLaunchKernelGGL((fused_forward_kernel<P, TPW, MR, OT>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512), lds, s,
+  hipLaunchKernelGGL((fused_forward_kernel<P, TPW, MR, OT, LN>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512), lds, s,
                      a);
   if (probe) probe_end(s, 2.0 * a.M * ((double)a.in_valid * H + 2.0 * a.nb * H * H + (double)H * a.out_dim));
   return 0;
@@ -414,7 +496,7 @@ int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStrea
   const int ot = (d.out_dim + 15) / 16 <= 1 ? 1 : ((d.out_dim + 15) / 16 <= 4 ? 4 : 0);
   if (mr == 0 || ot == 0 || a.M <= 0) return -1;
 #define DPPO_FWD(T, R, O) \
-  if (tpw == T && mr == R && ot == O) return launch_fwd_cfg<P, T, R, O>(a, s);
+  if (tpw == T && mr == R && ot == O) return a.use_ln ? launch_fwd_cfg<P, T, R, O, true>(a, s) : launch_fwd_cfg<P, T, R, O, false>(a, s);
   if constexpr (P::ESIZE == 2) {
     DPPO_FWD(2, 8, 1) DPPO_FWD(2, 8, 4) DPPO_FWD(4, 4, 1) DPPO_FWD(4, 4, 4) DPPO_FWD(8, 2, 1) DPPO_FWD(8, 2, 4)
   } else {
@@ -426,30 +508,32 @@ int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStrea
 template int launch_fused_forward<F32>(const dppo_net_desc&, const FusedFwdArgs&, hipStream_t);
 template int launch_fused_forward<BF16>(const dppo_net_desc&, const FusedFwdArgs&, hipStream_t);
 
-template <class P, int TPW, int MR>
+template <class P, int TPW, int MR, bool LN>
 static int launch_bwd_cfg(const FusedBwdArgs& a, hipStream_t s) {
   constexpr int ES = P::ESIZE, MT = 16 * MR, H = 128 * TPW;
-  const size_t lds = 2 * (size_t)MT * H * ES;
+  const size_t lds = 2 * (size_t)MT * H * ES + (LN ? (size_t)LN_WAVES * 2 * MR * 16 * 4 : 0);
   if (lds > 160 * 1024 || a.KpB0 > H) return -2;
   static bool attr = false;
-  raise_lds(fused_backward_kernel<P, TPW, MR>, attr);
+  raise_lds(fused_backward_kernel<P, TPW, MR, LN>, attr);
   const int ntiles = (a.M + MT - 1) / MT;
   const bool probe = probe_begin(PROBE_FUSED_BWD, s);
-  hipLaunchKernelGGL((fused_backward_kernel<P, TPW, MR>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((fused_backward_kernel<P, TPW, MR, LN>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512), lds, s, a);
   if (probe) probe_end(s, 2.0 * a.M * ((double)a.out_valid * H + 2.0 * a.nb * H * H));
   return 0;
 }
 
 template <class P>
 int launch_fused_backward(const dppo_net_desc& d, const FusedBwdArgs& a, hipStream_t s) {
-  const int tpw = d.hidden / 128, mr = pick_mr_bwd<P>(d.hidden);
+  const int tpw = d.hidden / 128, mr = pick_mr_bwd<P>(d.hidden, a.use_ln);
   if (mr == 0 || a.M <= 0) return -1;
-#define DPPO_BWD(T, R) \
-  if (tpw == T && mr == R) return launch_bwd_cfg<P, T, R>(a, s);
+#define DPPO_BWD(T, R, L) \
+  if (tpw == T && mr == R && (a.use_ln != 0) == L) return launch_bwd_cfg<P, T, R, L>(a, s);
   if constexpr (P::ESIZE == 2) {
-    DPPO_BWD(2, 8) DPPO_BWD(4, 4) DPPO_BWD(8, 1)
+    DPPO_BWD(2, 8, false) DPPO_BWD(2, 4, true) DPPO_BWD(4, 4, false) DPPO_BWD(4, 2, true) DPPO_BWD(8, 1, false)
+    DPPO_BWD(8, 1, true)
   } else {
-    DPPO_BWD(2, 4) DPPO_BWD(4, 2) DPPO_BWD(8, 1)
+    DPPO_BWD(2, 4, false) DPPO_BWD(2, 2, true) DPPO_BWD(4, 2, false) DPPO_BWD(4, 1, true) DPPO_BWD(8, 1, false)
+    DPPO_BWD(8, 1, true)
   }
 #undef DPPO_BWD
   return -1;

@@ -32,6 +32,8 @@ struct SampleArgs {
   const float* params[2];
   const float* temb[2];  // [n_time][td]
   int bias_off[2 + 2 * MAX_BLOCKS];  // L0, (l1,l2) x nb, out  -- float offsets into params
+  int ln_off[4 * MAX_BLOCKS];        // per block: norm1.weight, norm1.bias, norm2.weight, norm2.bias (use_ln only)
+  int use_ln;
   const float* obs[2];  // per network: [B][ld_obs] state columns (raw observation, or its cond_mlp encoding)
   int ld_obs;
   const float* noise;   // [n_steps+1][B][AF]

@@ -2,6 +2,7 @@
 // the reference's op sequence (separate multiplies/adds, no fused contraction).
 #include "sampler.h"
 #include "gemm.h"
+#include "tile_ln.h"
 
 namespace dppo {
 
@@ -21,7 +22,7 @@ __device__ __forceinline__ void lds_put(char* buf, int rb, int kmask, int row, i
   *(typename P::elem_t*)p = P::from_f32(v);
 }
 
-template <class P, int TPW, int OT>
+template <class P, int TPW, int OT, bool LN>
 __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
   constexpr int PD = sampler_pd(128 * TPW), ES = P::ESIZE, KB = P::KB;
   constexpr int H = 128 * TPW, KSH = H / KB, CNT = (KSH + SAMPLER_WAVES - 1) / SAMPLER_WAVES;
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
   // out-layer partials [8 waves][OT*16 features][16 rows]: bufB is idle while the out layer reads bufA, reuse it when it fits
   constexpr bool PART_IN_B = SAMPLER_WAVES * OT * 16 * 16 * 4 <= 16 * HRB;
   float* part = PART_IN_B ? (float*)bufB : xcur + ((16 * AF + 3) & ~3);
+  float* lnred = (PART_IN_B ? xcur + ((16 * AF + 3) & ~3) : part + SAMPLER_WAVES * OT * 16 * 16);  // [8][16]
 
   // ---- one-time: state columns (of the first step's network) + zero padding of the input image, x_K, time
   // embedding of step 0
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
         for (int to = 0; to < OT; ++to) of[c][to] = os[net][(c * OT + to) * 64];
     }
 
-    f32x4 h[TPW], acc[TPW];
+    f32x4 h[TPW][1], acc[TPW][1];
     int pos = 0;
 
     // one hidden layer: nks k-step positions starting at stream position `pos`, B operand from `src`
@@ -116,14 +118,14 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
 #pragma unroll
       for (int tp = 0; tp < TPW; ++tp)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[tp][e] = prm[boff + wbase + feat_off<P>(g, tp) + e];
+        for (int e = 0; e < 4; ++e) acc[tp][0][e] = prm[boff + wbase + feat_off<P>(g, tp) + e];
       for (int k0 = 0; k0 < nks; k0 += PD) {
 #pragma unroll
         for (int p = 0; p < PD; ++p) {
           const int ks = k0 + p;
           const u32x4 xb = *(const u32x4*)(src + r * rb + (((ks * 4 + g) ^ (r & km)) << 4));
 #pragma unroll
-          for (int tp = 0; tp < TPW; ++tp) acc[tp] = P::mma(ring[p][tp], xb, acc[tp]);
+          for (int tp = 0; tp < TPW; ++tp) acc[tp][0] = P::mma(ring[p][tp], xb, acc[tp][0]);
           // refill the slot just consumed with the fragments PD positions ahead (next layer / next step included)
           const int np = pos + ks + PD;
           const u32x4* src_w = np < total ? cur + (size_t)np * TPW * 64 : nxt + (size_t)(np - total) * TPW * 64;
@@ -134,13 +136,13 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
       pos += nks;
     };
     // write this lane's 4*TPW features of batch row r (optionally activated) into an LDS image
-    auto put_hidden = [&](char* dst, const f32x4 (&v)[TPW], int actk) {
+    auto put_hidden = [&](char* dst, const f32x4 (&v)[TPW][1], int actk) {
       if constexpr (ES == 4) {
 #pragma unroll
         for (int tp = 0; tp < TPW; ++tp) {
           const int c = ((wbase + feat_off<P>(g, tp)) * 4) >> 4;
-          float4 o = make_float4(act_f(actk, v[tp][0]), act_f(actk, v[tp][1]), act_f(actk, v[tp][2]),
-                                 act_f(actk, v[tp][3]));
+          float4 o = make_float4(act_f(actk, v[tp][0][0]), act_f(actk, v[tp][0][1]), act_f(actk, v[tp][0][2]),
+                                 act_f(actk, v[tp][0][3]));
           *(float4*)(dst + r * HRB + ((c ^ (r & 15)) << 4)) = o;
         }
       } else {
@@ -148,11 +150,11 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
         for (int tp = 0; tp < TPW; tp += 2) {
           const int c = ((wbase + feat_off<P>(g, tp)) * 2) >> 4;
           u32x4 o;
-          o.x = (uint32_t)f2bf(act_f(actk, v[tp][0])) | ((uint32_t)f2bf(act_f(actk, v[tp][1])) << 16);
-          o.y = (uint32_t)f2bf(act_f(actk, v[tp][2])) | ((uint32_t)f2bf(act_f(actk, v[tp][3])) << 16);
+          o.x = (uint32_t)f2bf(act_f(actk, v[tp][0][0])) | ((uint32_t)f2bf(act_f(actk, v[tp][0][1])) << 16);
+          o.y = (uint32_t)f2bf(act_f(actk, v[tp][0][2])) | ((uint32_t)f2bf(act_f(actk, v[tp][0][3])) << 16);
           if constexpr (TPW >= 2) {
-            o.z = (uint32_t)f2bf(act_f(actk, v[tp + 1][0])) | ((uint32_t)f2bf(act_f(actk, v[tp + 1][1])) << 16);
-            o.w = (uint32_t)f2bf(act_f(actk, v[tp + 1][2])) | ((uint32_t)f2bf(act_f(actk, v[tp + 1][3])) << 16);
+            o.z = (uint32_t)f2bf(act_f(actk, v[tp + 1][0][0])) | ((uint32_t)f2bf(act_f(actk, v[tp + 1][0][1])) << 16);
+            o.w = (uint32_t)f2bf(act_f(actk, v[tp + 1][0][2])) | ((uint32_t)f2bf(act_f(actk, v[tp + 1][0][3])) << 16);
             *(u32x4*)(dst + r * HRB + ((c ^ (r & 15)) << 4)) = o;
           } else {
             *(u32x2*)(dst + r * HRB + ((c ^ (r & 15)) << 4)) = (u32x2){o.x, o.y};
@@ -161,21 +163,41 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
       }
     };
 
+    // LayerNorm variant of a block input: bufA <- act(LN1_b(h)) (acc is scratch here)
+    float ln_m[1], ln_r[1];
+    auto put_block_input = [&](int b) {
+      if constexpr (LN) {
+        ln_forward<P, TPW, 1>(h, acc, prm + a.ln_off[4 * b], prm + a.ln_off[4 * b + 1], H, wbase, g, r, wid, lnred, ln_m,
+                              ln_r);
+        put_hidden(bufA, acc, a.act);
+      } else {
+        put_hidden(bufA, h, a.act);
+      }
+    };
     // ---- layer 0
     run_layer(xin, in_rb, in_km, KS0, a.bias_off[0]);
 #pragma unroll
-    for (int tp = 0; tp < TPW; ++tp) h[tp] = acc[tp];
-    put_hidden(bufA, h, nb > 0 ? a.act : ACT_NONE);
+    for (int tp = 0; tp < TPW; ++tp) h[tp][0] = acc[tp][0];
+    if (nb > 0)
+      put_block_input(0);
+    else
+      put_hidden(bufA, h, ACT_NONE);
     __syncthreads();
-    // ---- residual blocks: h += l2(act(l1(act(h))))
+    // ---- residual blocks: h += l2(act([LN2] l1(act([LN1] h))))
     for (int b = 0; b < nb; ++b) {
       run_layer(bufA, HRB, 15, KSH, a.bias_off[1 + 2 * b]);
+      if constexpr (LN)
+        ln_forward<P, TPW, 1>(acc, acc, prm + a.ln_off[4 * b + 2], prm + a.ln_off[4 * b + 3], H, wbase, g, r, wid, lnred,
+                              ln_m, ln_r);
       put_hidden(bufB, acc, a.act);
       __syncthreads();
       run_layer(bufB, HRB, 15, KSH, a.bias_off[2 + 2 * b]);
 #pragma unroll
-      for (int tp = 0; tp < TPW; ++tp) h[tp] += acc[tp];
-      put_hidden(bufA, h, b + 1 < nb ? a.act : ACT_NONE);
+      for (int tp = 0; tp < TPW; ++tp) h[tp][0] += acc[tp][0];
+      if (b + 1 < nb)
+        put_block_input(b + 1);
+      else
+        put_hidden(bufA, h, ACT_NONE);
       __syncthreads();
     }
     // ---- output layer: K split over the 8 waves, partial tiles reduced through LDS
@@ -273,15 +295,15 @@ SamplerGeom sampler_geom(const dppo_net_desc& d) {
 template SamplerGeom sampler_geom<F32>(const dppo_net_desc&);
 template SamplerGeom sampler_geom<BF16>(const dppo_net_desc&);
 
-template <class P, int TPW, int OT>
+template <class P, int TPW, int OT, bool LN>
 static int launch_cfg(const SamplerGeom& g, const SampleArgs& a, hipStream_t s) {
   const int ES = P::ESIZE;
   const size_t part_bytes = (size_t)SAMPLER_WAVES * OT * 16 * 16 * 4;
   size_t lds = (size_t)16 * a.Kp0 * ES + 2 * (size_t)16 * g.H * ES + (size_t)((16 * a.AF + 3) & ~3) * 4 +
-               (part_bytes <= (size_t)16 * g.H * ES ? 0 : part_bytes);
+               (part_bytes <= (size_t)16 * g.H * ES ? 0 : part_bytes) + (size_t)LN_WAVES * 16 * 4;
   if (lds > 160 * 1024) return -2;
   static bool attr_set = false;  // raising the dynamic-LDS cap is idempotent; racing setters are harmless
-  auto kern = sample_chain_kernel<P, TPW, OT>;
+  auto kern = sample_chain_kernel<P, TPW, OT, LN>;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
@@ -295,7 +317,7 @@ static int launch_cfg(const SamplerGeom& g, const SampleArgs& a, hipStream_t s) 
 template <class P>
 int launch_sample_chain(const SamplerGeom& g, const SampleArgs& a, hipStream_t s) {
 #define DPPO_CASE(T, O) \
-  if (g.TPW == T && g.OT == O) return launch_cfg<P, T, O>(g, a, s);
+  if (g.TPW == T && g.OT == O) return a.use_ln ? launch_cfg<P, T, O, true>(g, a, s) : launch_cfg<P, T, O, false>(g, a, s);
   DPPO_CASE(2, 1)
   DPPO_CASE(2, 4)
   DPPO_CASE(4, 1)

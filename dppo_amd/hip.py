@@ -26,7 +26,7 @@ PREC_BY_NAME = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": 
 class NetDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("kind", "in_dim", "hidden", "n_blocks", "out_dim", "act", "time_dim", "act_flat", "cond_dim",
-                 "cond_hidden", "cond_out")]
+                 "cond_hidden", "cond_out", "use_layernorm")]
 
 
 class DiffusionCfg(C.Structure):

@@ -19,12 +19,16 @@ SUPPORTED_ACT = {"ReLU": hip.ACT_RELU, "Mish": hip.ACT_MISH}
 
 
 class TwoLayerPreActivationResNetLinear(nn.Module):
-    """h + l2(act(l1(act(h))))  (reference mlp.py:128-154, LayerNorm variant not built yet)."""
+    """h + l2(act(norm2(l1(act(norm1(h))))))  (reference mlp.py:128-154); the norms exist only with
+    ``use_layernorm`` (nn.LayerNorm(H, eps=1e-6)), registered after l1/l2 like the reference's state dict."""
 
-    def __init__(self, hidden_dim: int):
+    def __init__(self, hidden_dim: int, use_layernorm: bool = False):
         super().__init__()
         self.l1 = nn.Linear(hidden_dim, hidden_dim)
         self.l2 = nn.Linear(hidden_dim, hidden_dim)
+        if use_layernorm:
+            self.norm1 = nn.LayerNorm(hidden_dim, eps=1e-6)
+            self.norm2 = nn.LayerNorm(hidden_dim, eps=1e-6)
 
 
 class ResidualMLP(nn.Module):
@@ -33,8 +37,10 @@ class ResidualMLP(nn.Module):
     def __init__(self, dim_list: List[int], activation_type: str = "Mish", out_activation_type: str = "Identity",
                  use_layernorm: bool = False, use_layernorm_final: bool = False, dropout: float = 0):
         super().__init__()
-        if use_layernorm or use_layernorm_final:
-            raise NotImplementedError("dppo_amd: LayerNorm in ResidualMLP is not built yet (SURVEY.md 8f)")
+        if use_layernorm_final:
+            raise NotImplementedError("dppo_amd: use_layernorm_final is not built (no shipped cfg sets it)")
+        if use_layernorm and dim_list[1] not in (256, 512, 1024):
+            raise NotImplementedError("dppo_amd: LayerNorm blocks need a hidden width of 256, 512 or 1024")
         if dropout:
             raise NotImplementedError("Dropout not implemented for residual MLP!")  # same as the reference
         if out_activation_type != "Identity":
@@ -46,11 +52,12 @@ class ResidualMLP(nn.Module):
         assert n_hidden % 2 == 0
         assert all(d == hidden for d in dim_list[1:-1]), "residual MLP needs one hidden width"
         self.layers = nn.ModuleList([nn.Linear(dim_list[0], hidden)])
-        self.layers.extend([TwoLayerPreActivationResNetLinear(hidden) for _ in range(1, n_hidden, 2)])
+        self.layers.extend([TwoLayerPreActivationResNetLinear(hidden, use_layernorm) for _ in range(1, n_hidden, 2)])
         self.layers.append(nn.Linear(hidden, dim_list[-1]))
         self.hidden, self.n_blocks = hidden, n_hidden // 2
         self.in_dim, self.out_dim = dim_list[0], dim_list[-1]
         self.act = SUPPORTED_ACT[activation_type]
+        self.use_layernorm = int(bool(use_layernorm))
 
 
 class HipNet(nn.Module):

@@ -61,7 +61,7 @@ class DiffusionMLP(HipNet):
         ch, co = self.cond_mlp_dims if self.cond_mlp_dims is not None else (0, 0)
         return hip.NetDesc(kind=0, in_dim=m.in_dim, hidden=m.hidden, n_blocks=m.n_blocks, out_dim=m.out_dim, act=m.act,
                            time_dim=self.time_dim, act_flat=m.out_dim, cond_dim=self.cond_dim, cond_hidden=ch,
-                           cond_out=co)
+                           cond_out=co, use_layernorm=m.use_layernorm)
 
     @torch.no_grad()
     def forward(self, x, time, cond, **kwargs):

@@ -21,7 +21,7 @@
  * state-dict order:
  *   actor : time_embedding.1.{weight(2td x td),bias}, time_embedding.3.{weight(td x 2td),bias},
  *           [cond_mlp.moduleList.0.linear_1.{weight(ch x cond),bias}, cond_mlp.moduleList.1.linear_1.{weight(co x ch),bias}],
- *           layers.0.{weight(H x in),bias}, [layers.b.l1.{w,b}, layers.b.l2.{w,b}] x n_blocks,
+ *           layers.0.{weight(H x in),bias}, [layers.b.l1.{w,b}, layers.b.l2.{w,b} (, norm1.{w,b}, norm2.{w,b})] x n_blocks,
  *           layers.last.{weight(out x H),bias}
  *   critic: the same without the time embedding (Q1.layers.*).
  * nn.Linear layout (out,in) row-major.  Gradients use the same flat layout.
@@ -59,6 +59,10 @@ typedef struct dppo_net_desc {
    * With it, in_dim = Ta*Da + time_dim + cond_out. */
   int32_t cond_hidden;
   int32_t cond_out;
+  /* 1: the residual blocks are LayerNorm blocks, x + l2(act(norm2(l1(act(norm1(x)))))) with eps 1e-6
+   * (model/common/mlp.py:139-154); parameters norm1.{weight,bias}, norm2.{weight,bias} follow l2 in each block.
+   * Needs a fused-kernel shape: hidden in {256, 512, 1024}. */
+  int32_t use_layernorm;
 } dppo_net_desc;
 
 /* One denoising step, host-prepared in fp32 exactly as the reference computes its tables

@@ -176,6 +176,16 @@ def named_specs(name: str) -> Tuple[NetSpec, NetSpec]:
         return (NetSpec("actor", cond_dim=23, mlp_dims=[1024, 1024, 1024], activation="Mish", residual=True,
                         action_dim=7, horizon_steps=4, time_dim=32, cond_mlp_dims=[512, 64]),
                 NetSpec("critic", cond_dim=23, mlp_dims=[256, 256, 256], activation="Mish", residual=True))
+    if name == "furniture_256":  # furniture one_leg_low style at a kernel-covered width: LayerNorm blocks x3, cond_mlp, Mish,
+        # time_dim 32 (cfg/furniture/finetune/one_leg_low/ft_ppo_diffusion_mlp.yaml:98-113; critic without LayerNorm as there)
+        return (NetSpec("actor", cond_dim=58, mlp_dims=[256] * 7, activation="Mish", residual=True,
+                        use_layernorm=True, action_dim=10, horizon_steps=4, time_dim=32, cond_mlp_dims=[128, 64]),
+                NetSpec("critic", cond_dim=58, mlp_dims=[256, 256, 256], activation="Mish", residual=True))
+    if name == "ln_relu":  # LayerNorm + ReLU actor and LayerNorm critic, no encoder
+        return (NetSpec("actor", cond_dim=11, mlp_dims=[512, 512, 512], activation="ReLU", residual=True,
+                        use_layernorm=True, action_dim=3, horizon_steps=4, time_dim=16),
+                NetSpec("critic", cond_dim=11, mlp_dims=[256, 256, 256], activation="Mish", residual=True,
+                        use_layernorm=True))
     if name == "plain_mlp":
         return (NetSpec("actor", cond_dim=11, mlp_dims=[64, 64], activation="Mish", residual=False,
                           action_dim=3, horizon_steps=4, time_dim=16),

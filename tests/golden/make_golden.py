@@ -121,7 +121,7 @@ def g1_tables():
 def g2_forward():
     rs = np.random.RandomState(100)
     out = {}
-    for name in ("hopper", "can", "halfcheetah", "furniture_like", "plain_mlp", "kitchen_like", "square_like"):
+    for name in ("hopper", "can", "halfcheetah", "furniture_like", "plain_mlp", "kitchen_like", "square_like", "furniture_256", "ln_relu"):
         a, c = specs(name)
         B = 8
         pa, pc = O.init_params(a, 11), O.init_params(c, 12)
@@ -158,6 +158,9 @@ def g3_g4_chains():
                                                  randn_clip_value=3), False),
         "square_like": ("square_like", 3, dict(denoising_steps=20, ft_denoising_steps=10,
                                                randn_clip_value=3), False),
+        "furniture_256": ("furniture_256", 4, dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True,
+                                                   ddim_steps=5, randn_clip_value=3), False),
+        "ln_relu": ("ln_relu", 5, dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3), False),
     }
     out = {}
     rs = np.random.RandomState(200)
@@ -193,6 +196,9 @@ def g5_loss():
         "furniture_like": ("furniture_like", dict(denoising_steps=20, ft_denoising_steps=5, clip_ploss_coef=0.01), 4),
         "kitchen_like": ("kitchen_like", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01), 4),
         "square_like": ("square_like", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01), 4),
+        "furniture_256": ("furniture_256", dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
+                                                clip_ploss_coef=0.001), 4),
+        "ln_relu": ("ln_relu", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01), 4),
     }
     out = {}
     rs = np.random.RandomState(300)

@@ -88,10 +88,21 @@ def test_no_cpu_fallback():
 
 def test_unsupported_variants_fail_loudly():
     from dppo_amd.model.diffusion.mlp_diffusion import DiffusionMLP
-    with pytest.raises(NotImplementedError):
-        DiffusionMLP(3, 4, 11, mlp_dims=[512, 512, 512], residual_style=True, use_layernorm=True)
+    with pytest.raises(NotImplementedError):  # LayerNorm blocks exist only on the fused kernels' widths
+        DiffusionMLP(3, 4, 11, mlp_dims=[384, 384, 384], residual_style=True, use_layernorm=True)
     with pytest.raises(NotImplementedError):
         DiffusionMLP(3, 4, 11, mlp_dims=[512, 512, 512], residual_style=False)
+    d = hopper_desc()
+    d.use_layernorm, d.hidden = 1, 384
+    assert hip.load().dppo_net_param_count(C.byref(d)) < 0
+
+
+def test_layernorm_layout_matches_reference_names():
+    from dppo_amd.model.diffusion.mlp_diffusion import DiffusionMLP
+    a = DiffusionMLP(3, 4, 11, mlp_dims=[512, 512, 512], residual_style=True, use_layernorm=True)
+    names = [n for n in dict(a.named_parameters()) if n.startswith("mlp_mean.layers.1.")]
+    assert names == [f"mlp_mean.layers.1.{m}.{w}" for m in ("l1", "l2", "norm1", "norm2") for w in ("weight", "bias")]
+    assert a.flat_params().numel() == hip.load().dppo_net_param_count(C.byref(a.net_desc())) == 553020 + 4 * 512
 
 
 def test_cond_mlp_layout_matches_reference_names():

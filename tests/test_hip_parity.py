@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 T = torch.from_numpy
 DEV = "cuda:0"
-HIP_SUPPORTED = {"hopper", "can", "halfcheetah", "kitchen_like", "square_like"}  # LayerNorm / plain-MLP variants are "next" rows
+HIP_SUPPORTED = {"hopper", "can", "halfcheetah", "kitchen_like", "square_like", "furniture_256", "ln_relu"}  # plain (non-residual) MLPs: "next" row
 
 
 def build_model(sname, kw, seed, precision):
@@ -31,9 +31,10 @@ def build_model(sname, kw, seed, precision):
     a, c = O.named_specs(sname)
     actor = DiffusionMLP(action_dim=a.action_dim, horizon_steps=a.horizon_steps, cond_dim=a.cond_dim,
                          time_dim=a.time_dim, mlp_dims=list(a.mlp_dims), activation_type=a.activation,
-                         cond_mlp_dims=a.cond_mlp_dims, residual_style=True, precision=precision)
+                         cond_mlp_dims=a.cond_mlp_dims, residual_style=True, use_layernorm=a.use_layernorm,
+                         precision=precision)
     critic = CriticObs(cond_dim=c.cond_dim, mlp_dims=list(c.mlp_dims), activation_type=c.activation,
-                       residual_style=True, precision=precision)
+                       residual_style=True, use_layernorm=c.use_layernorm, precision=precision)
     actor.load_state_dict(O.init_params(a, seed), strict=True)
     critic.load_state_dict(O.init_params(c, seed + 2), strict=True)
     kw = dict(kw)
@@ -54,7 +55,7 @@ def test_library_loads_and_versions():
 
 # ------------------------------------------------------------------ G2 network forwards
 @pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16", 3e-2)])
-@pytest.mark.parametrize("name", ["hopper", "can", "halfcheetah", "kitchen_like", "square_like"])
+@pytest.mark.parametrize("name", ["hopper", "can", "halfcheetah", "kitchen_like", "square_like", "furniture_256", "ln_relu"])
 def test_network_forward(golden, name, prec, tol):
     from dppo_amd.model.common.critic import CriticObs
     from dppo_amd.model.diffusion.mlp_diffusion import DiffusionMLP
@@ -62,9 +63,10 @@ def test_network_forward(golden, name, prec, tol):
     a, c = O.named_specs(name)
     actor = DiffusionMLP(action_dim=a.action_dim, horizon_steps=a.horizon_steps, cond_dim=a.cond_dim,
                          time_dim=a.time_dim, mlp_dims=list(a.mlp_dims), activation_type=a.activation,
-                         cond_mlp_dims=a.cond_mlp_dims, residual_style=True, precision=prec).to(DEV)
+                         cond_mlp_dims=a.cond_mlp_dims, residual_style=True, use_layernorm=a.use_layernorm,
+                         precision=prec).to(DEV)
     critic = CriticObs(cond_dim=c.cond_dim, mlp_dims=list(c.mlp_dims), activation_type=c.activation,
-                       residual_style=True, precision=prec).to(DEV)
+                       residual_style=True, use_layernorm=c.use_layernorm, precision=prec).to(DEV)
     actor.load_state_dict(O.init_params(a, 11))
     critic.load_state_dict(O.init_params(c, 12))
     st = T(g[f"{name}_state"]).to(DEV)

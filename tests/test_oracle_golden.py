@@ -43,7 +43,7 @@ def test_survey_check_values():
 
 
 # ------------------------------------------------------------------ G2
-@pytest.mark.parametrize("name", ["hopper", "can", "halfcheetah", "furniture_like", "plain_mlp", "kitchen_like", "square_like"])
+@pytest.mark.parametrize("name", ["hopper", "can", "halfcheetah", "furniture_like", "plain_mlp", "kitchen_like", "square_like", "furniture_256", "ln_relu"])
 def test_network_forward(golden, name):
     g = golden("g2_forward")
     a, c = O.named_specs(name)
@@ -77,6 +77,9 @@ CHAIN_CASES = {
     "furniture_like": ("furniture_like", dict(denoising_steps=20, ft_denoising_steps=5, randn_clip_value=3), False),
     "kitchen_like": ("kitchen_like", dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3), False),
     "square_like": ("square_like", dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3), False),
+    "furniture_256": ("furniture_256", dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
+                                            randn_clip_value=3), False),
+    "ln_relu": ("ln_relu", dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3), False),
 }
 
 
@@ -119,6 +122,9 @@ LOSS_CASES = {
     "furniture_like": ("furniture_like", dict(denoising_steps=20, ft_denoising_steps=5, clip_ploss_coef=0.01)),
     "kitchen_like": ("kitchen_like", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01)),
     "square_like": ("square_like", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01)),
+    "furniture_256": ("furniture_256", dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
+                                            clip_ploss_coef=0.001)),
+    "ln_relu": ("ln_relu", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01)),
 }
 
 
