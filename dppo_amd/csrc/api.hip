@@ -20,7 +20,15 @@ static int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+// A fused kernel refused a shape that fused_ok() admitted: the packed image then holds no layered operands to fall back
+// on, so the call must fail (reported by the check_launch() that ends every entry point).
+static int g_fused_fault = 0;
 static int check_launch() {
+  if (g_fused_fault) {
+    const int rc = g_fused_fault;
+    g_fused_fault = 0;
+    return fail(-1, "fused MLP kernel refused the launch (code %d): shape admitted by the packer but not by the kernel", rc);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail((int)e, "HIP launch failed: %s", hipGetErrorString(e));
   return 0;
@@ -382,7 +390,8 @@ static void mlp_forward(const dppo_net_desc& d, const float* prm, const char* pk
       f.hpre[nb] = B.hE;
       f.ln_stats = d.use_layernorm ? B.ln_stats : nullptr;
     }
-    if (launch_fused_forward<P>(d, f, s) == 0) return;
+    g_fused_fault = launch_fused_forward<P>(d, f, s);
+    return;
   }
   GemmNT g;
   memset(&g, 0, sizeof(g));
@@ -512,7 +521,9 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       f.dz1[b] = B.dz1_all[b];
     }
     for (int b = 0; b <= nb; ++b) f.dh[b] = B.dh_all[b];
-    if (launch_fused_backward<P>(d, f, s) == 0) {
+    g_fused_fault = launch_fused_backward<P>(d, f, s);
+    if (g_fused_fault != 0) return;
+    {
       // bias gradients = column sums, reduced over tiles in one launch; slot order: dh[nb..0], then dz1[nb-1..0]
       SlotOuts so;
       memset(&so, 0, sizeof(so));

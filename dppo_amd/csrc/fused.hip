@@ -164,7 +164,7 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
   char* bufB = bufA + MT * HRB;
   char* xin = bufB;  // the input tile is dead once layer 0 has run, before the first block writes bufB
   float* part = (float*)(bufB + MT * HRB);  // [KSPLIT][MR][OT*16 features][16 rows]
-  float* lnred = part + KSPLIT * MR * OT * 16 * 16;  // [8 waves][MR][16] LayerNorm row-reduction table
+  float* lnred = part;  // [8 waves][MR][16] LayerNorm row-reduction table: the out-layer partials are idle while the blocks run
   const int wbase = wid * 16 * TPW;  // lane features: wbase + feat_off<P>(g, tp) + e
   const u32x4* os = a.ostream + lane;
 
@@ -478,7 +478,8 @@ template <class P, int TPW, int MR, int OT, bool LN>
 static int launch_fwd_cfg(const FusedFwdArgs& a, hipStream_t s) {
   constexpr int ES = P::ESIZE, MT = 16 * MR, H = 128 * TPW;
   constexpr int KSPLIT = MR * OT >= 8 ? 1 : 8 / (MR * OT);
-  const size_t lds = 2 * (size_t)MT * H * ES + (size_t)KSPLIT * MR * OT * 16 * 16 * 4 + (size_t)LN_WAVES * MR * 16 * 4;
+  const size_t lds = 2 * (size_t)MT * H * ES + (size_t)KSPLIT * MR * OT * 16 * 16 * 4;
+  static_assert(KSPLIT * MR * OT * 16 * 16 >= LN_WAVES * MR * 16, "LayerNorm table must fit in the out-layer partials");
   if (lds > 160 * 1024 || a.Kp0 > H) return -2;
   static bool attr = false;
   raise_lds(fused_forward_kernel<P, TPW, MR, OT, LN>, attr);
