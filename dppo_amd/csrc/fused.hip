@@ -163,8 +163,11 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
   char* bufA = smem;
   char* bufB = bufA + MT * HRB;
   char* xin = bufB;  // the input tile is dead once layer 0 has run, before the first block writes bufB
-  float* part = (float*)(bufB + MT * HRB);  // [KSPLIT][MR][OT*16 features][16 rows]
-  float* lnred = part;  // [8 waves][MR][16] LayerNorm row-reduction table: the out-layer partials are idle while the blocks run
+  // out-layer partials [KSPLIT][MR][OT*16 features][16 rows]: the out layer reads bufA only, so they live in bufB
+  // (KSPLIT*OT <= 8 sub-tiles of 1 KB per 16 rows <= 16*H*ES always)
+  float* part = (float*)bufB;
+  static_assert(KSPLIT * OT * 16 * 16 * 4 <= 16 * HRB, "out-layer partials must fit in buffer B");
+  float* lnred = (float*)(bufB + MT * HRB);  // [8 waves][MR][16] LayerNorm row-reduction table (LN only)
   const int wbase = wid * 16 * TPW;  // lane features: wbase + feat_off<P>(g, tp) + e
   const u32x4* os = a.ostream + lane;
 
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
       for (int kh = 0; kh < KSPLIT; ++kh) s += part[(((kh * MR + m) * OT + to) * 16 + jj) * 16 + rr];
       if (row0 + row < M) a.out[(size_t)(row0 + row) * a.ldout + j] = s;
     }
-    // the next tile's barriers (after its input load) order these reads before `part` is rewritten
+    __syncthreads();  // the next tile's input lands in buffer B, where the partials were just read
   }
 }
 
@@ -477,9 +480,7 @@ static void raise_lds(K kern, bool& done) {
 template <class P, int TPW, int MR, int OT, bool LN>
 static int launch_fwd_cfg(const FusedFwdArgs& a, hipStream_t s) {
   constexpr int ES = P::ESIZE, MT = 16 * MR, H = 128 * TPW;
-  constexpr int KSPLIT = MR * OT >= 8 ? 1 : 8 / (MR * OT);
-  const size_t lds = 2 * (size_t)MT * H * ES + (size_t)KSPLIT * MR * OT * 16 * 16 * 4;
-  static_assert(KSPLIT * MR * OT * 16 * 16 >= LN_WAVES * MR * 16, "LayerNorm table must fit in the out-layer partials");
+  const size_t lds = 2 * (size_t)MT * H * ES + (LN ? (size_t)LN_WAVES * MR * 16 * 4 : 0);
   if (lds > 160 * 1024 || a.Kp0 > H) return -2;
   static bool attr = false;
   raise_lds(fused_forward_kernel<P, TPW, MR, OT, LN>, attr);
@@ -494,14 +495,16 @@ static int launch_fwd_cfg(const FusedFwdArgs& a, hipStream_t s) {
 template <class P>
 int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStream_t s) {
   const int tpw = d.hidden / 128, mr = pick_mr<P>(d.hidden);
-  const int ot = (d.out_dim + 15) / 16 <= 1 ? 1 : ((d.out_dim + 15) / 16 <= 4 ? 4 : 0);
+  const int nt = (d.out_dim + 15) / 16, ot = nt <= 1 ? 1 : (nt <= 4 ? 4 : (nt <= 8 ? 8 : 0));
   if (mr == 0 || ot == 0 || a.M <= 0) return -1;
 #define DPPO_FWD(T, R, O) \
   if (tpw == T && mr == R && ot == O) return a.use_ln ? launch_fwd_cfg<P, T, R, O, true>(a, s) : launch_fwd_cfg<P, T, R, O, false>(a, s);
   if constexpr (P::ESIZE == 2) {
     DPPO_FWD(2, 8, 1) DPPO_FWD(2, 8, 4) DPPO_FWD(4, 4, 1) DPPO_FWD(4, 4, 4) DPPO_FWD(8, 2, 1) DPPO_FWD(8, 2, 4)
+    DPPO_FWD(2, 8, 8) DPPO_FWD(4, 4, 8) DPPO_FWD(8, 2, 8)
   } else {
     DPPO_FWD(2, 4, 1) DPPO_FWD(2, 4, 4) DPPO_FWD(4, 2, 1) DPPO_FWD(4, 2, 4) DPPO_FWD(8, 1, 1) DPPO_FWD(8, 1, 4)
+    DPPO_FWD(2, 4, 8) DPPO_FWD(4, 2, 8) DPPO_FWD(8, 1, 8)
   }
 #undef DPPO_FWD
   return -1;

@@ -101,13 +101,16 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
     const u32x4* nxt = ws[nnet];
     const float* prm = a.params[net];
 
-    // out-layer fragments: prefetched at the top of the step, except at H = 1024 where the registers are needed
-    u32x4 of[CNT][OT];
-    if constexpr (TPW < 8) {
+    // out-layer fragments, in groups of OG out tiles: one group, prefetched at the top of the step, when it is small;
+    // loaded right before use at H = 1024 (the registers are needed) and for wide outputs (two groups)
+    constexpr int OG = OT < 4 ? OT : 4;
+    constexpr bool OF_EARLY = TPW < 8 && OT <= 4;
+    u32x4 of[CNT][OG];
+    if constexpr (OF_EARLY) {
 #pragma unroll
       for (int c = 0; c < CNT; ++c)
 #pragma unroll
-        for (int to = 0; to < OT; ++to) of[c][to] = os[net][(c * OT + to) * 64];
+        for (int to = 0; to < OG; ++to) of[c][to] = os[net][(c * OT + to) * 64];
     }
 
     f32x4 h[TPW][1], acc[TPW][1];
@@ -202,28 +205,31 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
     }
     // ---- output layer: K split over the 8 waves, partial tiles reduced through LDS
     {
-      if constexpr (TPW >= 8) {
 #pragma unroll
-        for (int c = 0; c < CNT; ++c)
+      for (int og = 0; og < OT; og += OG) {
+        if constexpr (!OF_EARLY) {
 #pragma unroll
-          for (int to = 0; to < OT; ++to) of[c][to] = os[net][(c * OT + to) * 64];
-      }
-      f32x4 oacc[OT];
+          for (int c = 0; c < CNT; ++c)
 #pragma unroll
-      for (int to = 0; to < OT; ++to) oacc[to] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int c = 0; c < CNT; ++c) {
-        const int ks = wid * CNT + c;
-        if (ks < KSH) {
-          const u32x4 xb = *(const u32x4*)(bufA + r * HRB + (((ks * 4 + g) ^ (r & 15)) << 4));
-#pragma unroll
-          for (int to = 0; to < OT; ++to) oacc[to] = P::mma(of[c][to], xb, oacc[to]);
+            for (int to = 0; to < OG; ++to) of[c][to] = os[net][(c * OT + og + to) * 64];
         }
+        f32x4 oacc[OG];
+#pragma unroll
+        for (int to = 0; to < OG; ++to) oacc[to] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < CNT; ++c) {
+          const int ks = wid * CNT + c;
+          if (ks < KSH) {
+            const u32x4 xb = *(const u32x4*)(bufA + r * HRB + (((ks * 4 + g) ^ (r & 15)) << 4));
+#pragma unroll
+            for (int to = 0; to < OG; ++to) oacc[to] = P::mma(of[c][to], xb, oacc[to]);
+          }
+        }
+#pragma unroll
+        for (int to = 0; to < OG; ++to)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) part[(wid * OT * 16 + (og + to) * 16 + 4 * g + e) * 16 + r] = oacc[to][e];
       }
-#pragma unroll
-      for (int to = 0; to < OT; ++to)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) part[(wid * OT * 16 + to * 16 + 4 * g + e) * 16 + r] = oacc[to][e];
     }
     __syncthreads();
     // ---- posterior + noise: diffusion_vpg.py:165-223 (p_mean_var) and :279-311 (sampling loop)
@@ -324,6 +330,9 @@ int launch_sample_chain(const SamplerGeom& g, const SampleArgs& a, hipStream_t s
   DPPO_CASE(4, 4)
   DPPO_CASE(8, 1)
   DPPO_CASE(8, 4)
+  DPPO_CASE(2, 8)
+  DPPO_CASE(4, 8)
+  DPPO_CASE(8, 8)
 #undef DPPO_CASE
   return -1;
 }

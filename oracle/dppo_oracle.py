@@ -186,6 +186,15 @@ def named_specs(name: str) -> Tuple[NetSpec, NetSpec]:
                         use_layernorm=True, action_dim=3, horizon_steps=4, time_dim=16),
                 NetSpec("critic", cond_dim=11, mlp_dims=[256, 256, 256], activation="Mish", residual=True,
                         use_layernorm=True))
+    if name == "transport":  # shipped shape, Ta*Da = 112 (cfg/robomimic/finetune/transport/ft_ppo_diffusion_mlp.yaml:17-23,80-93)
+        return (NetSpec("actor", cond_dim=59, mlp_dims=[1024, 1024, 1024], activation="Mish", residual=True,
+                        action_dim=14, horizon_steps=8, time_dim=32),
+                NetSpec("critic", cond_dim=59, mlp_dims=[256, 256, 256], activation="Mish", residual=True))
+    if name == "furniture_one_leg":  # shipped shape: 3 LayerNorm blocks of 1024, cond_mlp, Ta*Da = 80, critic 512 wide
+        # (cfg/furniture/finetune/one_leg_low/ft_ppo_diffusion_mlp.yaml:16-23,98-113)
+        return (NetSpec("actor", cond_dim=58, mlp_dims=[1024] * 7, activation="Mish", residual=True,
+                        use_layernorm=True, action_dim=10, horizon_steps=8, time_dim=32, cond_mlp_dims=[512, 64]),
+                NetSpec("critic", cond_dim=58, mlp_dims=[512, 512, 512], activation="Mish", residual=True))
     if name == "plain_mlp":
         return (NetSpec("actor", cond_dim=11, mlp_dims=[64, 64], activation="Mish", residual=False,
                           action_dim=3, horizon_steps=4, time_dim=16),

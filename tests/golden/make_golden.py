@@ -121,7 +121,8 @@ def g1_tables():
 def g2_forward():
     rs = np.random.RandomState(100)
     out = {}
-    for name in ("hopper", "can", "halfcheetah", "furniture_like", "plain_mlp", "kitchen_like", "square_like", "furniture_256", "ln_relu"):
+    for name in ("hopper", "can", "halfcheetah", "furniture_like", "plain_mlp", "kitchen_like", "square_like", "furniture_256", "ln_relu",
+                 "transport", "furniture_one_leg"):
         a, c = specs(name)
         B = 8
         pa, pc = O.init_params(a, 11), O.init_params(c, 12)
@@ -161,6 +162,11 @@ def g3_g4_chains():
         "furniture_256": ("furniture_256", 4, dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True,
                                                    ddim_steps=5, randn_clip_value=3), False),
         "ln_relu": ("ln_relu", 5, dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3), False),
+        "transport": ("transport", 3, dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3,
+                                           min_sampling_denoising_std=0.1, min_logprob_denoising_std=0.1), False),
+        "furniture_one_leg": ("furniture_one_leg", 3, dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True,
+                                                           ddim_steps=5, randn_clip_value=3,
+                                                           min_sampling_denoising_std=0.04), False),
     }
     out = {}
     rs = np.random.RandomState(200)
@@ -199,6 +205,12 @@ def g5_loss():
         "furniture_256": ("furniture_256", dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
                                                 clip_ploss_coef=0.001), 4),
         "ln_relu": ("ln_relu", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01), 4),
+        "transport": ("transport", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01,
+                                        clip_ploss_coef_base=0.001, min_sampling_denoising_std=0.1,
+                                        min_logprob_denoising_std=0.1), 8),
+        "furniture_one_leg": ("furniture_one_leg", dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True,
+                                                        ddim_steps=5, clip_ploss_coef=0.001, clip_ploss_coef_base=0.001,
+                                                        min_sampling_denoising_std=0.04), 8),
     }
     out = {}
     rs = np.random.RandomState(300)

@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 
 T = torch.from_numpy
 DEV = "cuda:0"
-HIP_SUPPORTED = {"hopper", "can", "halfcheetah", "kitchen_like", "square_like", "furniture_256", "ln_relu"}  # plain (non-residual) MLPs: "next" row
+HIP_SUPPORTED = {"hopper", "can", "halfcheetah", "kitchen_like", "square_like", "furniture_256", "ln_relu",
+                 "transport", "furniture_one_leg"}  # plain (non-residual) MLPs: "next" row
 
 
 def build_model(sname, kw, seed, precision):
@@ -55,7 +56,8 @@ def test_library_loads_and_versions():
 
 # ------------------------------------------------------------------ G2 network forwards
 @pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16", 3e-2)])
-@pytest.mark.parametrize("name", ["hopper", "can", "halfcheetah", "kitchen_like", "square_like", "furniture_256", "ln_relu"])
+@pytest.mark.parametrize("name", ["hopper", "can", "halfcheetah", "kitchen_like", "square_like", "furniture_256", "ln_relu",
+                                  "transport", "furniture_one_leg"])
 def test_network_forward(golden, name, prec, tol):
     from dppo_amd.model.common.critic import CriticObs
     from dppo_amd.model.diffusion.mlp_diffusion import DiffusionMLP
@@ -267,7 +269,7 @@ def test_adamw_and_clip_match_torch(golden):
 
 # ------------------------------------------------------------------ fused row-tile kernels vs layered GEMM chain
 @pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
-@pytest.mark.parametrize("sname", ["hopper", "can", "kitchen_like", "square_like"])
+@pytest.mark.parametrize("sname", ["hopper", "can", "kitchen_like", "square_like", "transport"])
 def test_fused_path_matches_layered_path(prec, tol, sname):
     """Two independent implementations of the big-batch MLP (fused row-tile kernels / layer-by-layer gemm_nt
     chain, tuning knob 1) must agree on log-probs, loss statistics and every gradient."""

@@ -43,7 +43,8 @@ def test_survey_check_values():
 
 
 # ------------------------------------------------------------------ G2
-@pytest.mark.parametrize("name", ["hopper", "can", "halfcheetah", "furniture_like", "plain_mlp", "kitchen_like", "square_like", "furniture_256", "ln_relu"])
+@pytest.mark.parametrize("name", ["hopper", "can", "halfcheetah", "furniture_like", "plain_mlp", "kitchen_like", "square_like", "furniture_256", "ln_relu",
+                                  "transport", "furniture_one_leg"])
 def test_network_forward(golden, name):
     g = golden("g2_forward")
     a, c = O.named_specs(name)
@@ -80,6 +81,10 @@ CHAIN_CASES = {
     "furniture_256": ("furniture_256", dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
                                             randn_clip_value=3), False),
     "ln_relu": ("ln_relu", dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3), False),
+    "transport": ("transport", dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3,
+                                    min_sampling_denoising_std=0.1, min_logprob_denoising_std=0.1), False),
+    "furniture_one_leg": ("furniture_one_leg", dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
+                                                    randn_clip_value=3, min_sampling_denoising_std=0.04), False),
 }
 
 
@@ -125,6 +130,12 @@ LOSS_CASES = {
     "furniture_256": ("furniture_256", dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
                                             clip_ploss_coef=0.001)),
     "ln_relu": ("ln_relu", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01)),
+    "transport": ("transport", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01,
+                                    clip_ploss_coef_base=0.001, min_sampling_denoising_std=0.1,
+                                    min_logprob_denoising_std=0.1)),
+    "furniture_one_leg": ("furniture_one_leg", dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
+                                                    clip_ploss_coef=0.001, clip_ploss_coef_base=0.001,
+                                                    min_sampling_denoising_std=0.04)),
 }
 
 
