@@ -167,6 +167,8 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     ap.add_argument("--probe", type=int, default=2,
                     help="kernel timed live for `roofline`: 2 gemm_tn (weight grads), 3 fused fwd, 4 fused bwd, 5 sampler")
+    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
+                    help="dppo_tune_set knob (include/dppo_hip.h), e.g. 2=0: critic half on the main stream (serial kernels)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -188,6 +190,9 @@ def main():
     from dppo_amd.parallel import DataParallel
     from dppo_amd.util.optim import FlatAdamW
     lib = hip.load()
+    for kv in args.tune:
+        k, v = kv.split("=")
+        hip.check(lib.dppo_tune_set(int(k), int(v)), "dppo_tune_set")
 
     model = build_model(str(device), args.prec)  # same seed on every rank => identical initial weights
     gen = torch.Generator(device=device).manual_seed(42 + rank)  # env shards differ per rank

@@ -852,6 +852,43 @@ int dppo_gae(const double* reward, const float* values, const float* terminated,
 }
 
 // ---- PPO update --------------------------------------------------------------------------------------
+// The actor and the critic halves of an update are independent between the row builder and the loss, and again after
+// it.  Their persistent row-tile kernels leave CUs idle in the last round of tiles (50,000 rows = 3.05 rounds of 64-row
+// tiles on 256 CUs), so the critic runs on a side stream and fills those gaps.  Fork / join through events: legal under
+// stream capture too.  Tuning knob 2 turns it off (serial, for per-kernel timing).
+static int g_overlap = 1;
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false;
+};
+static SideStream* side_stream() {
+  static SideStream tab[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  SideStream& t = tab[dev];
+  if (!t.ok) {
+    if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&t.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    t.ok = true;
+  }
+  return &t;
+}
+static hipStream_t fork_side(hipStream_t main) {  // returns the stream the independent half should use
+  SideStream* t = g_overlap ? side_stream() : nullptr;
+  if (t == nullptr) return main;
+  (void)hipEventRecord(t->fork, main);
+  (void)hipStreamWaitEvent(t->s, t->fork, 0);
+  return t->s;
+}
+static void join_side(hipStream_t main, hipStream_t sidestream) {
+  if (sidestream == main) return;
+  SideStream* t = side_stream();
+  (void)hipEventRecord(t->join, sidestream);
+  (void)hipStreamWaitEvent(main, t->join, 0);
+}
+
 template <class P>
 struct PpoWs {
   MlpBufs<P> A, C;
@@ -907,8 +944,10 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   launch_build_rows<P>(br, s);
   if (a.cond_hidden > 0) cond_encode<P>(a, ap, ak, LA, N, W.C.in, W.A, W.A.in, nullptr, 0, true, s);
   if (gmom == nullptr) launch_adv_moments(adv_k, W.brow, N, W.moments, s);
+  hipStream_t s2 = fork_side(s);
+  mlp_forward<P>(cr, cp, ck, LC, N, W.C, true, s2);
   mlp_forward<P>(a, ap, ak, LA, N, W.A, true, s);
-  mlp_forward<P>(cr, cp, ck, LC, N, W.C, true, s);
+  join_side(s, s2);
   LossArgs la;
   memset(&la, 0, sizeof(la));
   la.eps = W.A.out, la.lde = W.A.ldout, la.vnew = W.C.out, la.ldv = W.C.ldout, la.brow = W.brow, la.krow = W.krow;
@@ -924,9 +963,11 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
     la.gb_actor = agrad + param_layout(a).bout, la.gb_critic = cgrad + param_layout(cr).bout;
   }
   launch_ppo_loss<P>(la, s);
+  s2 = fork_side(s);
+  mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s2, fuse_bout);
   mlp_backward<P>(a, ap, ak, LA, N, W.A, agrad, W.krow, ksteps, Kft, s, fuse_bout);
   if (a.cond_hidden > 0) cond_backward<P>(a, ap, ak, LA, N, W.A, W.A.dh0_final, W.C.in, agrad, s);
-  mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s, fuse_bout);
+  join_side(s, s2);
   return check_launch();
 }
 
@@ -998,6 +1039,10 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 1) {
     g_use_fused = value;
+    return 0;
+  }
+  if (knob == 2) {
+    g_overlap = value;
     return 0;
   }
   return fail(-1, "unknown tuning knob %d", knob);

@@ -215,7 +215,8 @@ int dppo_probe_collect(double* total_ms_host, int* launches_host, double* flops_
 
 /* ---- tuning / micro-benchmark hooks (tools/ and tests only; never used by the product path) ----- */
 /* knob 0: gemm_nt operand staging, 0 = through registers, 1 = global_load_lds (LDS-DMA, default)
- * knob 1: big-batch MLP path, 1 = fused row-tile kernels (default), 0 = layer-by-layer gemm_nt chain */
+ * knob 1: big-batch MLP path, 1 = fused row-tile kernels (default), 0 = layer-by-layer gemm_nt chain
+ * knob 2: PPO update, 1 = critic half on a side stream, overlapping the actor half (default), 0 = one stream */
 int dppo_tune_set(int knob, int value);
 /* one bare layer GEMM: out[M][ldo] = act(X[M][Kp] . W[N][Kp]^T + bias) with elem = prec operands;
  * out_f32 and/or out_elem may be NULL; ldo >= round_up(N,16) */

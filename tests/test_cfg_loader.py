@@ -92,3 +92,31 @@ def test_targets_map_onto_this_package(tmp_path, monkeypatch):
     assert keys[0] == "network.time_embedding.1.weight" and "actor_ft.mlp_mean.layers.1.l2.bias" in keys
     assert "critic.Q1.layers.2.weight" in keys
     assert get_class(cfg._target_).__name__ == "TrainPPODiffusionAgent"
+
+
+REF_CFG = "/root/reference/dppo/cfg"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason="reference checkout not present (GPU box)")
+def test_every_shipped_diffusion_mlp_cfg_builds():
+    """Each ft_ppo_diffusion_mlp.yaml the reference ships resolves through the loader, its actor / critic build as
+    dppo_amd containers, and the C ABI accepts both descriptors (parameter count == the containers' flat size)."""
+    import ctypes as C
+    import glob
+
+    from dppo_amd import hip
+    os.environ.setdefault("DPPO_LOG_DIR", "/tmp/log")
+    os.environ.setdefault("DPPO_DATA_DIR", "/tmp/data")
+    os.environ.setdefault("DPPO_WANDB_ENTITY", "none")
+    paths = sorted(glob.glob(os.path.join(REF_CFG, "*", "finetune", "*", "ft_ppo_diffusion_mlp.yaml")))
+    assert len(paths) >= 19
+    lib = hip.load()
+    for p in paths:
+        cfg = load_config(p)
+        actor = instantiate(cfg.model.actor)
+        critic = instantiate(cfg.model.critic)
+        for net in (actor, critic):
+            n = lib.dppo_net_param_count(C.byref(net.net_desc()))
+            assert n == net.flat_params().numel(), (p, hip.last_error())
+            for prec in (hip.PREC_F32, hip.PREC_BF16):
+                assert lib.dppo_packed_bytes(C.byref(net.net_desc()), prec, int(cfg.denoising_steps)) > 0, p
