@@ -3,13 +3,19 @@
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="$HERE/../lib"
-mkdir -p "$OUT" "$HERE/obj"
+OBJ="$HERE/obj"
+LIB="libdppo_hip.so"
+EXTRA=""
+if [ -n "${DPPO_STAMPS:-}" ]; then  # debug variant with in-kernel phase stamps (tools/fused_bench.py --stamps)
+  OBJ="$HERE/obj_stamps"; LIB="libdppo_hip_stamps.so"; EXTRA="-DDPPO_STAMPS"
+fi
+mkdir -p "$OUT" "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I$HERE/../../include"
+COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I$HERE/../../include $EXTRA"
 pids=()
 build() { # src extra-flags...
   local src="$1"; shift
-  local obj="$HERE/obj/$(basename "${src%.hip}").o"
+  local obj="$OBJ/$(basename "${src%.hip}").o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ -n "$(find "$HERE" ../../include -maxdepth 1 -name '*.h' -newer "$obj" 2>/dev/null)" ]; then
     $HIPCC $COMMON "$@" -c "$src" -o "$obj" &
     pids+=($!)
@@ -22,5 +28,5 @@ build "$HERE/sampler.hip" -ffp-contract=off
 build "$HERE/ppo.hip" -ffp-contract=off
 build "$HERE/api.hip"
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libdppo_hip.so" "$HERE"/obj/gemm.o "$HERE"/obj/fused.o "$HERE"/obj/sampler.o "$HERE"/obj/ppo.o "$HERE"/obj/api.o
-echo "built $OUT/libdppo_hip.so"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/$LIB" "$OBJ"/gemm.o "$OBJ"/fused.o "$OBJ"/sampler.o "$OBJ"/ppo.o "$OBJ"/api.o
+echo "built $OUT/$LIB"

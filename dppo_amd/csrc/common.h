@@ -61,10 +61,12 @@ struct BF16 {
 // = n / (n + 2), n = e (e + 2) -- exact algebra, no cancellation, one exp + one division instead of
 // expf + log1pf + tanhf (which made the Mish critic cost more than the 4x larger ReLU actor).  x is clamped at 20
 // for the exponential only (n / (n + 2) == 1 in fp32 from x ~ 9, matching torch's softplus threshold behaviour).
+// The divisions are v_rcp_f32 (1 ulp): an IEEE divide is ~10 instructions, and the activation of a 64-row tile is
+// as long as one of its 512 x 512 layers on the matrix cores if it is not kept to exp + rcp + a few multiplies.
 __device__ __forceinline__ float mish_tanh_sp(float x, float& e) {
   e = __expf(fminf(x, 20.f));
   const float n = e * (e + 2.f);
-  return n / (n + 2.f);
+  return n * __builtin_amdgcn_rcpf(n + 2.f);
 }
 __device__ __forceinline__ float mish_f(float x) {
   float e;
@@ -74,13 +76,41 @@ __device__ __forceinline__ float mish_grad_f(float x) {
   // d/dx [x tanh(sp(x))] = tanh(sp) + x (1 - tanh(sp)^2) sigmoid(x)
   float e;
   const float th = mish_tanh_sp(x, e);
-  return th + x * (1.f - th * th) * (e / (1.f + e));
+  return th + x * (1.f - th * th) * (e * __builtin_amdgcn_rcpf(1.f + e));
 }
 __device__ __forceinline__ float act_f(int act, float x) {
   return act == ACT_RELU ? fmaxf(x, 0.f) : (act == ACT_MISH ? mish_f(x) : x);
 }
 __device__ __forceinline__ float act_grad_f(int act, float x) {
   return act == ACT_RELU ? (x > 0.f ? 1.f : 0.f) : (act == ACT_MISH ? mish_grad_f(x) : 1.f);
+}
+// The same with the kind a compile-time constant, and with_act() to get there from the runtime kind ONCE per tile
+// instead of once per element (the per-element form made a ReLU emit cost as much as a Mish one: measured 8k of a
+// 52k-cycle tile, twice).
+template <int ACT>
+__device__ __forceinline__ float act_c(float x) {
+  if constexpr (ACT == ACT_RELU) return fmaxf(x, 0.f);
+  if constexpr (ACT == ACT_MISH) return mish_f(x);
+  return x;
+}
+template <int ACT>
+__device__ __forceinline__ float act_grad_c(float x) {
+  if constexpr (ACT == ACT_RELU) return x > 0.f ? 1.f : 0.f;
+  if constexpr (ACT == ACT_MISH) return mish_grad_f(x);
+  return 1.f;
+}
+template <int ACT>
+struct ActTag {
+  static constexpr int value = ACT;
+};
+template <class F>
+__device__ __forceinline__ void with_act(int actk, F&& body) {
+  if (actk == ACT_RELU)
+    body(ActTag<ACT_RELU>{});
+  else if (actk == ACT_MISH)
+    body(ActTag<ACT_MISH>{});
+  else
+    body(ActTag<ACT_NONE>{});
 }
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }

@@ -5,6 +5,20 @@
 
 namespace dppo {
 
+// Phase stamps (debug build only: DPPO_STAMPS=1 build.sh -> libdppo_hip_stamps.so, tools/fused_bench.py --stamps):
+// s_memtime of every wave of workgroup 0 at the phase boundaries of its second tile.
+#ifdef DPPO_STAMPS
+__device__ unsigned long long g_stamps[8][32];
+#define STAMP(i)                                                                   \
+  do {                                                                             \
+    if (blockIdx.x == 0 && lane == 0 && tile == (int)gridDim.x) g_stamps[wid][i] = clock64(); \
+  } while (0)
+#else
+#define STAMP(i) \
+  do {           \
+  } while (0)
+#endif
+
 namespace {
 
 __device__ __forceinline__ int kmask16(int rb) {
@@ -81,37 +95,40 @@ __device__ __forceinline__ void emit(const f32x4 (&v)[TPW][MR], int actk, char* 
                                      int r, int row0, int M) {
   constexpr int ES = P::ESIZE;
   const int HRB = H * ES;
+  with_act(actk, [&](auto tag) {
+    constexpr int ACT = decltype(tag)::value;
 #pragma unroll
-  for (int m = 0; m < MR; ++m) {
-    const int grow = row0 + 16 * m + r;
-    char* gp = glb != nullptr && grow < M ? (char*)glb + (size_t)grow * HRB : nullptr;
-    char* lp = lds != nullptr ? lds + (16 * m + r) * HRB : nullptr;
-    if constexpr (ES == 4) {
+    for (int m = 0; m < MR; ++m) {
+      const int grow = row0 + 16 * m + r;
+      char* gp = glb != nullptr && grow < M ? (char*)glb + (size_t)grow * HRB : nullptr;
+      char* lp = lds != nullptr ? lds + (16 * m + r) * HRB : nullptr;
+      if constexpr (ES == 4) {
 #pragma unroll
-      for (int tp = 0; tp < TPW; ++tp) {
-        u32x4 o;
-        o.x = __float_as_uint(act_f(actk, v[tp][m][0]));
-        o.y = __float_as_uint(act_f(actk, v[tp][m][1]));
-        o.z = __float_as_uint(act_f(actk, v[tp][m][2]));
-        o.w = __float_as_uint(act_f(actk, v[tp][m][3]));
-        const int c = ((wbase + feat_off<P>(g, tp)) * 4) >> 4;
-        if (lp) *(u32x4*)(lp + ((c ^ (r & 15)) << 4)) = o;
-        if (gp) *(u32x4*)(gp + c * 16) = o;
-      }
-    } else {
+        for (int tp = 0; tp < TPW; ++tp) {
+          u32x4 o;
+          o.x = __float_as_uint(act_c<ACT>(v[tp][m][0]));
+          o.y = __float_as_uint(act_c<ACT>(v[tp][m][1]));
+          o.z = __float_as_uint(act_c<ACT>(v[tp][m][2]));
+          o.w = __float_as_uint(act_c<ACT>(v[tp][m][3]));
+          const int c = ((wbase + feat_off<P>(g, tp)) * 4) >> 4;
+          if (lp) *(u32x4*)(lp + ((c ^ (r & 15)) << 4)) = o;
+          if (gp) *(u32x4*)(gp + c * 16) = o;
+        }
+      } else {
 #pragma unroll
-      for (int tp = 0; tp < TPW; tp += 2) {
-        u32x4 o;
-        o.x = (uint32_t)f2bf(act_f(actk, v[tp][m][0])) | ((uint32_t)f2bf(act_f(actk, v[tp][m][1])) << 16);
-        o.y = (uint32_t)f2bf(act_f(actk, v[tp][m][2])) | ((uint32_t)f2bf(act_f(actk, v[tp][m][3])) << 16);
-        o.z = (uint32_t)f2bf(act_f(actk, v[tp + 1][m][0])) | ((uint32_t)f2bf(act_f(actk, v[tp + 1][m][1])) << 16);
-        o.w = (uint32_t)f2bf(act_f(actk, v[tp + 1][m][2])) | ((uint32_t)f2bf(act_f(actk, v[tp + 1][m][3])) << 16);
-        const int c = ((wbase + feat_off<P>(g, tp)) * 2) >> 4;
-        if (lp) *(u32x4*)(lp + ((c ^ (r & 15)) << 4)) = o;
-        if (gp) *(u32x4*)(gp + c * 16) = o;
+        for (int tp = 0; tp < TPW; tp += 2) {
+          u32x4 o;
+          o.x = (uint32_t)f2bf(act_c<ACT>(v[tp][m][0])) | ((uint32_t)f2bf(act_c<ACT>(v[tp][m][1])) << 16);
+          o.y = (uint32_t)f2bf(act_c<ACT>(v[tp][m][2])) | ((uint32_t)f2bf(act_c<ACT>(v[tp][m][3])) << 16);
+          o.z = (uint32_t)f2bf(act_c<ACT>(v[tp + 1][m][0])) | ((uint32_t)f2bf(act_c<ACT>(v[tp + 1][m][1])) << 16);
+          o.w = (uint32_t)f2bf(act_c<ACT>(v[tp + 1][m][2])) | ((uint32_t)f2bf(act_c<ACT>(v[tp + 1][m][3])) << 16);
+          const int c = ((wbase + feat_off<P>(g, tp)) * 2) >> 4;
+          if (lp) *(u32x4*)(lp + ((c ^ (r & 15)) << 4)) = o;
+          if (gp) *(u32x4*)(gp + c * 16) = o;
+        }
       }
     }
-  }
+  });
 }
 
 // this lane's 4*TPW values of row (16m + r) of a global [M][H] elem tensor, kept packed as loaded
@@ -132,13 +149,13 @@ __device__ __forceinline__ void fetch(u32x4 (&d)[MR][CH], const void* glb, int H
     for (int c = 0; c < CH; ++c) d[m][c] = *(const u32x4*)(gp + (size_t)(wbase + feat_off<P>(g, c * TPC)) * ES);
   }
 }
-template <class P, int MR, int CH>
-__device__ __forceinline__ float grad_at(const u32x4 (&d)[MR][CH], int actk, int tp, int m, int e) {
+template <class P, int ACT, int MR, int CH>
+__device__ __forceinline__ float grad_at(const u32x4 (&d)[MR][CH], int tp, int m, int e) {
   if constexpr (P::ESIZE == 4) {
-    return act_grad_f(actk, __uint_as_float(d[m][tp][e]));
+    return act_grad_c<ACT>(__uint_as_float(d[m][tp][e]));
   } else {
     const uint32_t w = d[m][tp >> 1][(tp & 1) * 2 + (e >> 1)];
-    return act_grad_f(actk, bf2f((e & 1) ? (w >> 16) : (w & 0xffff)));
+    return act_grad_c<ACT>(bf2f((e & 1) ? (w >> 16) : (w & 0xffff)));
   }
 }
 
@@ -147,7 +164,7 @@ __device__ __forceinline__ float grad_at(const u32x4 (&d)[MR][CH], int actk, int
 // =================================================================================================
 // forward
 // =================================================================================================
-template <class P, int TPW, int MR, int OT, bool LN>
+template <class P, int TPW, int MR, int OT, bool LN, int ACT>
 __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a) {
   constexpr int PD = ring_depth<TPW, MR>(), ES = P::ESIZE, KB = P::KB;
   constexpr int H = 128 * TPW, KSH = H / KB, HRB = H * ES, MT = 16 * MR;
@@ -177,8 +194,10 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
   const int ntiles = (M + MT - 1) / MT;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int row0 = tile * MT;
+    STAMP(0);
     load_tile<MT>(xin, in_rb, in_km, (const char*)a.in, a.ld_in * ES, row0, M);
     __syncthreads();
+    STAMP(1);
 
     f32x4 h[TPW][MR], acc[TPW][MR];
     auto bias_init = [&](int boff) {
@@ -204,14 +223,15 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
             if (row0 + 16 * m + r < M)
               *(float2*)(a.ln_stats + (((size_t)(2 * b) * M) + row0 + 16 * m + r) * 2) = make_float2(mean[m], rstd[m]);
         }
-        emit<P, TPW, MR>(acc, a.act, bufA, a.a1[b], H, wbase, g, r, row0, M);
+        emit<P, TPW, MR>(acc, ACT, bufA, a.a1[b], H, wbase, g, r, row0, M);
       } else {
-        emit<P, TPW, MR>(h, a.act, bufA, a.a1[b], H, wbase, g, r, row0, M);
+        emit<P, TPW, MR>(h, ACT, bufA, a.a1[b], H, wbase, g, r, row0, M);
       }
     };
     // ---- layer 0
     bias_init(a.bias_off[0]);
     eng.run(acc, xin, in_rb, in_km, KS0, r, g);
+    STAMP(2);
 #pragma unroll
     for (int tp = 0; tp < TPW; ++tp)
 #pragma unroll
@@ -220,11 +240,14 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
       put_block_input(0);
     else
       emit<P, TPW, MR>(h, ACT_NONE, bufA, a.hpre[0], H, wbase, g, r, row0, M);
+    STAMP(3);
     __syncthreads();
+    STAMP(4);
     // ---- residual blocks
     for (int b = 0; b < nb; ++b) {
       bias_init(a.bias_off[1 + 2 * b]);
       eng.run(acc, bufA, HRB, 15, KSH, r, g);
+      STAMP(5);
       if (a.z1[b] != nullptr) emit<P, TPW, MR>(acc, ACT_NONE, nullptr, a.z1[b], H, wbase, g, r, row0, M);
       if constexpr (LN) {
         float mean[MR], rstd[MR];
@@ -237,10 +260,13 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
               *(float2*)(a.ln_stats + (((size_t)(2 * b + 1) * M) + row0 + 16 * m + r) * 2) = make_float2(mean[m], rstd[m]);
         }
       }
-      emit<P, TPW, MR>(acc, a.act, bufB, a.a2[b], H, wbase, g, r, row0, M);
+      emit<P, TPW, MR>(acc, ACT, bufB, a.a2[b], H, wbase, g, r, row0, M);
+      STAMP(6);
       __syncthreads();
+      STAMP(7);
       bias_init(a.bias_off[2 + 2 * b]);
       eng.run(acc, bufB, HRB, 15, KSH, r, g);
+      STAMP(8);
 #pragma unroll
       for (int tp = 0; tp < TPW; ++tp)
 #pragma unroll
@@ -249,7 +275,9 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
         put_block_input(b + 1);
       else
         emit<P, TPW, MR>(h, ACT_NONE, bufA, a.hpre[nb], H, wbase, g, r, row0, M);
+      STAMP(9);
       __syncthreads();
+      STAMP(10);
     }
     // ---- output layer: work items (row sub-tile m, out tile to, K slice kh) dealt to the 8 waves
     for (int it = wid; it < MR * OT * KSPLIT; it += SAMPLER_WAVES) {
@@ -265,7 +293,9 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
 #pragma unroll
       for (int e = 0; e < 4; ++e) part[(((kh * MR + m) * OT + to) * 16 + 4 * g + e) * 16 + r] = oacc[e];
     }
+    STAMP(11);
     __syncthreads();
+    STAMP(12);
     for (int idx = tid; idx < MT * a.out_dim; idx += 512) {
       const int row = idx / a.out_dim, j = idx - row * a.out_dim;
       const int m = row >> 4, rr = row & 15, to = j >> 4, jj = j & 15;
@@ -274,14 +304,16 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
       for (int kh = 0; kh < KSPLIT; ++kh) s += part[(((kh * MR + m) * OT + to) * 16 + jj) * 16 + rr];
       if (row0 + row < M) a.out[(size_t)(row0 + row) * a.ldout + j] = s;
     }
+    STAMP(13);
     __syncthreads();  // the next tile's input lands in buffer B, where the partials were just read
+    STAMP(14);
   }
 }
 
 // =================================================================================================
 // backward (data gradients + column sums)
 // =================================================================================================
-template <class P, int TPW, int MR, bool LN>
+template <class P, int TPW, int MR, bool LN, int ACT>
 __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs a) {
   constexpr int PD = 2, ES = P::ESIZE, KB = P::KB;
   constexpr int H = 128 * TPW, KSH = H / KB, HRB = H * ES, MT = 16 * MR;
@@ -378,7 +410,7 @@ __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs 
         float mean[MR], rstd[MR];
         f32x4 dga[TPW], dbe[TPW];
         load_stats(2 * b + 1, row0, mean, rstd);
-        ln_backward<P, TPW, MR>(acc, d, a.params + a.ln_off[4 * b + 2], a.params + a.ln_off[4 * b + 3], mean, rstd, a.act, H,
+        ln_backward<P, TPW, MR>(acc, d, a.params + a.ln_off[4 * b + 2], a.params + a.ln_off[4 * b + 3], mean, rstd, ACT, H,
                                 wbase, g, r, wid, lnred, dga, dbe);
         const int ls = (2 * nb + 1) + 4 * (nb - 1 - b);
         colsum1(dga, ls + 2, tile);
@@ -389,7 +421,7 @@ __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs 
 #pragma unroll
           for (int m = 0; m < MR; ++m)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[tp][m][e] *= grad_at<P>(d, a.act, tp, m, e);
+            for (int e = 0; e < 4; ++e) acc[tp][m][e] *= grad_at<P, ACT>(d, tp, m, e);
       }
       emit<P, TPW, MR>(acc, ACT_NONE, bufB, a.dz1[b], H, wbase, g, r, row0, M);
       colsum(acc, (nb + 1) + (nb - 1 - b), tile);
@@ -402,7 +434,7 @@ __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs 
         float mean[MR], rstd[MR];
         f32x4 dga[TPW], dbe[TPW];
         load_stats(2 * b, row0, mean, rstd);
-        ln_backward<P, TPW, MR>(acc, d, a.params + a.ln_off[4 * b], a.params + a.ln_off[4 * b + 1], mean, rstd, a.act, H,
+        ln_backward<P, TPW, MR>(acc, d, a.params + a.ln_off[4 * b], a.params + a.ln_off[4 * b + 1], mean, rstd, ACT, H,
                                 wbase, g, r, wid, lnred, dga, dbe);
         const int ls = (2 * nb + 1) + 4 * (nb - 1 - b);
         colsum1(dga, ls, tile);
@@ -417,7 +449,7 @@ __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs 
 #pragma unroll
           for (int m = 0; m < MR; ++m)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dh[tp][m][e] += acc[tp][m][e] * grad_at<P>(d, a.act, tp, m, e);
+            for (int e = 0; e < 4; ++e) dh[tp][m][e] += acc[tp][m][e] * grad_at<P, ACT>(d, tp, m, e);
       }
       emit<P, TPW, MR>(dh, ACT_NONE, bufA, a.dh[b], H, wbase, g, r, row0, M);
       colsum(dh, nb - b, tile);
@@ -425,6 +457,12 @@ __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs 
     }
   }
 }
+
+#ifdef DPPO_STAMPS
+extern "C" int dppo_debug_stamps(unsigned long long* out) {  // out: [8 waves][32]
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8 * 32);
+}
+#endif
 
 // =================================================================================================
 // host side
@@ -477,16 +515,16 @@ static void raise_lds(K kern, bool& done) {
   }
 }
 
-template <class P, int TPW, int MR, int OT, bool LN>
+template <class P, int TPW, int MR, int OT, bool LN, int ACT>
 static int launch_fwd_cfg(const FusedFwdArgs& a, hipStream_t s) {
   constexpr int ES = P::ESIZE, MT = 16 * MR, H = 128 * TPW;
   const size_t lds = 2 * (size_t)MT * H * ES + (LN ? (size_t)LN_WAVES * MR * 16 * 4 : 0);
   if (lds > 160 * 1024 || a.Kp0 > H) return -2;
   static bool attr = false;
-  raise_lds(fused_forward_kernel<P, TPW, MR, OT, LN>, attr);
+  raise_lds(fused_forward_kernel<P, TPW, MR, OT, LN, ACT>, attr);
   const int ntiles = (a.M + MT - 1) / MT;
   const bool probe = probe_begin(PROBE_FUSED_FWD, s);
-  hipLaunchKernelGGL((fused_forward_kernel<P, TPW, MR, OT, LN>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512), lds, s,
+  hipLaunchKernelGGL((fused_forward_kernel<P, TPW, MR, OT, LN, ACT>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512), lds, s,
                      a);
   if (probe) probe_end(s, 2.0 * a.M * ((double)a.in_valid * H + 2.0 * a.nb * H * H + (double)H * a.out_dim));
   return 0;
@@ -497,8 +535,11 @@ int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStrea
   const int tpw = d.hidden / 128, mr = pick_mr<P>(d.hidden);
   const int nt = (d.out_dim + 15) / 16, ot = nt <= 1 ? 1 : (nt <= 4 ? 4 : (nt <= 8 ? 8 : 0));
   if (mr == 0 || ot == 0 || a.M <= 0) return -1;
+  const bool relu = a.act == ACT_RELU;  // check_net admits ReLU and Mish only
 #define DPPO_FWD(T, R, O) \
-  if (tpw == T && mr == R && ot == O) return a.use_ln ? launch_fwd_cfg<P, T, R, O, true>(a, s) : launch_fwd_cfg<P, T, R, O, false>(a, s);
+  if (tpw == T && mr == R && ot == O)                                                                                  \
+    return a.use_ln ? (relu ? launch_fwd_cfg<P, T, R, O, true, ACT_RELU>(a, s) : launch_fwd_cfg<P, T, R, O, true, ACT_MISH>(a, s)) \
+                    : (relu ? launch_fwd_cfg<P, T, R, O, false, ACT_RELU>(a, s) : launch_fwd_cfg<P, T, R, O, false, ACT_MISH>(a, s));
   if constexpr (P::ESIZE == 2) {
     DPPO_FWD(2, 8, 1) DPPO_FWD(2, 8, 4) DPPO_FWD(4, 4, 1) DPPO_FWD(4, 4, 4) DPPO_FWD(8, 2, 1) DPPO_FWD(8, 2, 4)
     DPPO_FWD(2, 8, 8) DPPO_FWD(4, 4, 8) DPPO_FWD(8, 2, 8)
@@ -512,16 +553,16 @@ int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStrea
 template int launch_fused_forward<F32>(const dppo_net_desc&, const FusedFwdArgs&, hipStream_t);
 template int launch_fused_forward<BF16>(const dppo_net_desc&, const FusedFwdArgs&, hipStream_t);
 
-template <class P, int TPW, int MR, bool LN>
+template <class P, int TPW, int MR, bool LN, int ACT>
 static int launch_bwd_cfg(const FusedBwdArgs& a, hipStream_t s) {
   constexpr int ES = P::ESIZE, MT = 16 * MR, H = 128 * TPW;
   const size_t lds = 2 * (size_t)MT * H * ES + (LN ? (size_t)LN_WAVES * 2 * MR * 16 * 4 : 0);
   if (lds > 160 * 1024 || a.KpB0 > H) return -2;
   static bool attr = false;
-  raise_lds(fused_backward_kernel<P, TPW, MR, LN>, attr);
+  raise_lds(fused_backward_kernel<P, TPW, MR, LN, ACT>, attr);
   const int ntiles = (a.M + MT - 1) / MT;
   const bool probe = probe_begin(PROBE_FUSED_BWD, s);
-  hipLaunchKernelGGL((fused_backward_kernel<P, TPW, MR, LN>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((fused_backward_kernel<P, TPW, MR, LN, ACT>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512), lds, s, a);
   if (probe) probe_end(s, 2.0 * a.M * ((double)a.out_valid * H + 2.0 * a.nb * H * H));
   return 0;
 }
@@ -530,8 +571,10 @@ template <class P>
 int launch_fused_backward(const dppo_net_desc& d, const FusedBwdArgs& a, hipStream_t s) {
   const int tpw = d.hidden / 128, mr = pick_mr_bwd<P>(d.hidden, a.use_ln);
   if (mr == 0 || a.M <= 0) return -1;
+  const bool relu = a.act == ACT_RELU;
 #define DPPO_BWD(T, R, L) \
-  if (tpw == T && mr == R && (a.use_ln != 0) == L) return launch_bwd_cfg<P, T, R, L>(a, s);
+  if (tpw == T && mr == R && (a.use_ln != 0) == L) \
+    return relu ? launch_bwd_cfg<P, T, R, L, ACT_RELU>(a, s) : launch_bwd_cfg<P, T, R, L, ACT_MISH>(a, s);
   if constexpr (P::ESIZE == 2) {
     DPPO_BWD(2, 8, false) DPPO_BWD(2, 4, true) DPPO_BWD(4, 4, false) DPPO_BWD(4, 2, true) DPPO_BWD(8, 1, false)
     DPPO_BWD(8, 1, true)

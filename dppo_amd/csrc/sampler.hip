@@ -22,7 +22,7 @@ __device__ __forceinline__ void lds_put(char* buf, int rb, int kmask, int row, i
   *(typename P::elem_t*)p = P::from_f32(v);
 }
 
-template <class P, int TPW, int OT, bool LN>
+template <class P, int TPW, int OT, bool LN, int ACT>
 __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
   constexpr int PD = sampler_pd(128 * TPW), ES = P::ESIZE, KB = P::KB;
   constexpr int H = 128 * TPW, KSH = H / KB, CNT = (KSH + SAMPLER_WAVES - 1) / SAMPLER_WAVES;
@@ -140,30 +140,33 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
     };
     // write this lane's 4*TPW features of batch row r (optionally activated) into an LDS image
     auto put_hidden = [&](char* dst, const f32x4 (&v)[TPW][1], int actk) {
-      if constexpr (ES == 4) {
+      with_act(actk, [&](auto tag) {  // the activation kind resolved once per call, not per element
+        constexpr int AK = decltype(tag)::value;
+        if constexpr (ES == 4) {
 #pragma unroll
-        for (int tp = 0; tp < TPW; ++tp) {
-          const int c = ((wbase + feat_off<P>(g, tp)) * 4) >> 4;
-          float4 o = make_float4(act_f(actk, v[tp][0][0]), act_f(actk, v[tp][0][1]), act_f(actk, v[tp][0][2]),
-                                 act_f(actk, v[tp][0][3]));
-          *(float4*)(dst + r * HRB + ((c ^ (r & 15)) << 4)) = o;
-        }
-      } else {
+          for (int tp = 0; tp < TPW; ++tp) {
+            const int c = ((wbase + feat_off<P>(g, tp)) * 4) >> 4;
+            float4 o = make_float4(act_c<AK>(v[tp][0][0]), act_c<AK>(v[tp][0][1]), act_c<AK>(v[tp][0][2]),
+                                   act_c<AK>(v[tp][0][3]));
+            *(float4*)(dst + r * HRB + ((c ^ (r & 15)) << 4)) = o;
+          }
+        } else {
 #pragma unroll
-        for (int tp = 0; tp < TPW; tp += 2) {
-          const int c = ((wbase + feat_off<P>(g, tp)) * 2) >> 4;
-          u32x4 o;
-          o.x = (uint32_t)f2bf(act_f(actk, v[tp][0][0])) | ((uint32_t)f2bf(act_f(actk, v[tp][0][1])) << 16);
-          o.y = (uint32_t)f2bf(act_f(actk, v[tp][0][2])) | ((uint32_t)f2bf(act_f(actk, v[tp][0][3])) << 16);
-          if constexpr (TPW >= 2) {
-            o.z = (uint32_t)f2bf(act_f(actk, v[tp + 1][0][0])) | ((uint32_t)f2bf(act_f(actk, v[tp + 1][0][1])) << 16);
-            o.w = (uint32_t)f2bf(act_f(actk, v[tp + 1][0][2])) | ((uint32_t)f2bf(act_f(actk, v[tp + 1][0][3])) << 16);
-            *(u32x4*)(dst + r * HRB + ((c ^ (r & 15)) << 4)) = o;
-          } else {
-            *(u32x2*)(dst + r * HRB + ((c ^ (r & 15)) << 4)) = (u32x2){o.x, o.y};
+          for (int tp = 0; tp < TPW; tp += 2) {
+            const int c = ((wbase + feat_off<P>(g, tp)) * 2) >> 4;
+            u32x4 o;
+            o.x = (uint32_t)f2bf(act_c<AK>(v[tp][0][0])) | ((uint32_t)f2bf(act_c<AK>(v[tp][0][1])) << 16);
+            o.y = (uint32_t)f2bf(act_c<AK>(v[tp][0][2])) | ((uint32_t)f2bf(act_c<AK>(v[tp][0][3])) << 16);
+            if constexpr (TPW >= 2) {
+              o.z = (uint32_t)f2bf(act_c<AK>(v[tp + 1][0][0])) | ((uint32_t)f2bf(act_c<AK>(v[tp + 1][0][1])) << 16);
+              o.w = (uint32_t)f2bf(act_c<AK>(v[tp + 1][0][2])) | ((uint32_t)f2bf(act_c<AK>(v[tp + 1][0][3])) << 16);
+              *(u32x4*)(dst + r * HRB + ((c ^ (r & 15)) << 4)) = o;
+            } else {
+              *(u32x2*)(dst + r * HRB + ((c ^ (r & 15)) << 4)) = (u32x2){o.x, o.y};
+            }
           }
         }
-      }
+      });
     };
 
     // LayerNorm variant of a block input: bufA <- act(LN1_b(h)) (acc is scratch here)
@@ -172,9 +175,9 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
       if constexpr (LN) {
         ln_forward<P, TPW, 1>(h, acc, prm + a.ln_off[4 * b], prm + a.ln_off[4 * b + 1], H, wbase, g, r, wid, lnred, ln_m,
                               ln_r);
-        put_hidden(bufA, acc, a.act);
+        put_hidden(bufA, acc, ACT);
       } else {
-        put_hidden(bufA, h, a.act);
+        put_hidden(bufA, h, ACT);
       }
     };
     // ---- layer 0
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
       if constexpr (LN)
         ln_forward<P, TPW, 1>(acc, acc, prm + a.ln_off[4 * b + 2], prm + a.ln_off[4 * b + 3], H, wbase, g, r, wid, lnred,
                               ln_m, ln_r);
-      put_hidden(bufB, acc, a.act);
+      put_hidden(bufB, acc, ACT);
       __syncthreads();
       run_layer(bufB, HRB, 15, KSH, a.bias_off[2 + 2 * b]);
 #pragma unroll
@@ -301,7 +304,7 @@ SamplerGeom sampler_geom(const dppo_net_desc& d) {
 template SamplerGeom sampler_geom<F32>(const dppo_net_desc&);
 template SamplerGeom sampler_geom<BF16>(const dppo_net_desc&);
 
-template <class P, int TPW, int OT, bool LN>
+template <class P, int TPW, int OT, bool LN, int ACT>
 static int launch_cfg(const SamplerGeom& g, const SampleArgs& a, hipStream_t s) {
   const int ES = P::ESIZE;
   const size_t part_bytes = (size_t)SAMPLER_WAVES * OT * 16 * 16 * 4;
@@ -309,7 +312,7 @@ static int launch_cfg(const SamplerGeom& g, const SampleArgs& a, hipStream_t s) 
                (part_bytes <= (size_t)16 * g.H * ES ? 0 : part_bytes) + (size_t)LN_WAVES * 16 * 4;
   if (lds > 160 * 1024) return -2;
   static bool attr_set = false;  // raising the dynamic-LDS cap is idempotent; racing setters are harmless
-  auto kern = sample_chain_kernel<P, TPW, OT, LN>;
+  auto kern = sample_chain_kernel<P, TPW, OT, LN, ACT>;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
@@ -322,8 +325,11 @@ static int launch_cfg(const SamplerGeom& g, const SampleArgs& a, hipStream_t s) 
 
 template <class P>
 int launch_sample_chain(const SamplerGeom& g, const SampleArgs& a, hipStream_t s) {
+  const bool relu = a.act == ACT_RELU;  // check_net admits ReLU and Mish only
 #define DPPO_CASE(T, O) \
-  if (g.TPW == T && g.OT == O) return a.use_ln ? launch_cfg<P, T, O, true>(g, a, s) : launch_cfg<P, T, O, false>(g, a, s);
+  if (g.TPW == T && g.OT == O)                                                                                      \
+    return a.use_ln ? (relu ? launch_cfg<P, T, O, true, ACT_RELU>(g, a, s) : launch_cfg<P, T, O, true, ACT_MISH>(g, a, s)) \
+                    : (relu ? launch_cfg<P, T, O, false, ACT_RELU>(g, a, s) : launch_cfg<P, T, O, false, ACT_MISH>(g, a, s));
   DPPO_CASE(2, 1)
   DPPO_CASE(2, 4)
   DPPO_CASE(4, 1)

@@ -108,28 +108,31 @@ __device__ __forceinline__ void ln_backward(f32x4 (&gacc)[TPW][MR], const u32x4 
   float s[2][MR];
 #pragma unroll
   for (int m = 0; m < MR; ++m) s[0][m] = s[1][m] = 0.f;
+  with_act(actk, [&](auto tag) {
+    constexpr int ACT = decltype(tag)::value;
 #pragma unroll
-  for (int tp = 0; tp < TPW; ++tp) {
-    const int f = wbase + feat_off<P>(g, tp);
-    f32x4 ga, be, dg = (f32x4){0.f, 0.f, 0.f, 0.f}, db = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int tp = 0; tp < TPW; ++tp) {
+      const int f = wbase + feat_off<P>(g, tp);
+      f32x4 ga, be, dg = (f32x4){0.f, 0.f, 0.f, 0.f}, db = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) ga[e] = gamma[f + e], be[e] = beta[f + e];
+      for (int e = 0; e < 4; ++e) ga[e] = gamma[f + e], be[e] = beta[f + e];
 #pragma unroll
-    for (int m = 0; m < MR; ++m)
+      for (int m = 0; m < MR; ++m)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float xh = (elem_at<P>(xraw, tp, m, e) - mean[m]) * rstd[m];
-        const float du = gacc[tp][m][e] * act_grad_f(actk, xh * ga[e] + be[e]);
-        dg[e] += du * xh;
-        db[e] += du;
-        const float dxh = du * ga[e];
-        gacc[tp][m][e] = dxh;
-        s[0][m] += dxh;
-        s[1][m] += dxh * xh;
-      }
-    dgamma[tp] = dg;
-    dbeta[tp] = db;
-  }
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (elem_at<P>(xraw, tp, m, e) - mean[m]) * rstd[m];
+          const float du = gacc[tp][m][e] * act_grad_c<ACT>(xh * ga[e] + be[e]);
+          dg[e] += du * xh;
+          db[e] += du;
+          const float dxh = du * ga[e];
+          gacc[tp][m][e] = dxh;
+          s[0][m] += dxh;
+          s[1][m] += dxh * xh;
+        }
+      dgamma[tp] = dg;
+      dbeta[tp] = db;
+    }
+  });
   row_reduce<2, MR>(s, lds, wid, r, g);
   const float inv = 1.f / (float)H;
 #pragma unroll

@@ -13,7 +13,9 @@ from typing import Optional
 import numpy as np
 import torch
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdppo_hip.so")
+# DPPO_HIP_LIB names another build of the same library (debug variants such as libdppo_hip_stamps.so); never a CPU path
+LIB_PATH = os.environ.get("DPPO_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                                                          "libdppo_hip.so")
 
 PREC_F32, PREC_BF16 = 0, 1
 ACT_RELU, ACT_MISH = 0, 1
