@@ -61,22 +61,28 @@ struct BF16 {
 // = n / (n + 2), n = e (e + 2) -- exact algebra, no cancellation, one exp + one division instead of
 // expf + log1pf + tanhf (which made the Mish critic cost more than the 4x larger ReLU actor).  x is clamped at 20
 // for the exponential only (n / (n + 2) == 1 in fp32 from x ~ 9, matching torch's softplus threshold behaviour).
-// The divisions are v_rcp_f32 (1 ulp): an IEEE divide is ~10 instructions, and the activation of a 64-row tile is
-// as long as one of its 512 x 512 layers on the matrix cores if it is not kept to exp + rcp + a few multiplies.
-__device__ __forceinline__ float mish_tanh_sp(float x, float& e) {
-  e = __expf(fminf(x, 20.f));
+// With w = n + 2: tanh(sp) = n / w, and since n + 1 = (1 + e)^2 the derivative
+// d/dx [x tanh(sp(x))] = tanh(sp) + x (1 - tanh(sp)^2) sigmoid(x) collapses to n/w + 4 x e (1 + e) / w^2: value and
+// derivative share ONE exp and ONE reciprocal.  The reciprocal is v_rcp_f32 (1 ulp): an IEEE divide is ~10
+// instructions, and the activation of a 64-row tile costs as much as one of its 512 x 512 layers on the matrix cores
+// unless it is kept to exp + rcp + a few multiplies.
+__device__ __forceinline__ void mish_both(float x, float& val, float& grad) {
+  const float e = __expf(fminf(x, 20.f));
   const float n = e * (e + 2.f);
-  return n * __builtin_amdgcn_rcpf(n + 2.f);
+  const float R = __builtin_amdgcn_rcpf(n + 2.f);
+  const float th = n * R;
+  val = x * th;
+  grad = th + 4.f * x * (e * (1.f + e)) * (R * R);
 }
 __device__ __forceinline__ float mish_f(float x) {
-  float e;
-  return x * mish_tanh_sp(x, e);
+  const float e = __expf(fminf(x, 20.f));
+  const float n = e * (e + 2.f);
+  return x * (n * __builtin_amdgcn_rcpf(n + 2.f));
 }
 __device__ __forceinline__ float mish_grad_f(float x) {
-  // d/dx [x tanh(sp(x))] = tanh(sp) + x (1 - tanh(sp)^2) sigmoid(x)
-  float e;
-  const float th = mish_tanh_sp(x, e);
-  return th + x * (1.f - th * th) * (e * __builtin_amdgcn_rcpf(1.f + e));
+  float v, g;
+  mish_both(x, v, g);
+  return g;
 }
 __device__ __forceinline__ float act_f(int act, float x) {
   return act == ACT_RELU ? fmaxf(x, 0.f) : (act == ACT_MISH ? mish_f(x) : x);

@@ -37,6 +37,7 @@ struct FusedFwdArgs {
   int ld_in;
   int M, Kp0, nb, act, out_dim;
   int in_valid;  // true input width (algorithmic FLOP accounting only)
+  int consts_lds;  // set by the launcher: bit 0 = biases staged in LDS, bit 1 = out-layer fragments staged in LDS
   // training-mode stores, each [M][H] elem (null = skip)
   void* a1[MAX_BLOCKS];        // act(h_b)
   void* a2[MAX_BLOCKS];        // act(z1_b)

@@ -1,4 +1,6 @@
 // See fused.h.  gfx950 only.
+#include <type_traits>
+
 #include "fused.h"
 #include "gemm.h"
 #include "tile_ln.h"
@@ -37,7 +39,9 @@ constexpr int ring_depth() {
 template <int MT>
 __device__ __forceinline__ void load_tile(char* dst, int rb, int km, const char* src, int ld_bytes, int row0, int M) {
   const int nch = rb >> 4, vch = ld_bytes >> 4;
-  for (int q = threadIdx.x; q < MT * nch; q += 512) {
+  int t0 = threadIdx.x;
+  asm volatile("" : "+v"(t0));  // addresses recomputed per tile, never hoisted out of the tile loop and spilled (see emit())
+  for (int q = t0; q < MT * nch; q += 512) {
     const int row = q / nch, c = q - row * nch;
     const int grow = row0 + row;
     u32x4 v = (u32x4){0, 0, 0, 0};
@@ -89,45 +93,65 @@ struct Engine {
 };
 
 // v[tp][m] (features fb + 4tp + e of row 16m + r) -> activated elem chunks, written to the LDS image `lds`
-// (may be null) and to the global [M][H] tensor `glb` (may be null)
+// (may be null) and to the global [M][H] tensor `glb` (may be null).  `dglb` (may be null, Mish only): a second global
+// [M][H] tensor that receives act'(v) -- the backward then multiplies by it instead of recomputing the derivative from the
+// pre-activation (value and derivative share one exp and one reciprocal here; a separate Mish' pass made the 128-row
+// critic tile VALU-bound).
 template <class P, int TPW, int MR>
 __device__ __forceinline__ void emit(const f32x4 (&v)[TPW][MR], int actk, char* lds, void* glb, int H, int wbase, int g,
-                                     int r, int row0, int M) {
+                                     int r, int row0, int M, void* dglb = nullptr) {
   constexpr int ES = P::ESIZE;
   const int HRB = H * ES;
+  // keep this phase's addresses from being hoisted out of the persistent tile loop and spilled: a scratch reload waits
+  // (vmcnt is in issue order) for every weight fragment the ring has in flight
+  asm volatile("" : "+v"(r), "+v"(g));
   with_act(actk, [&](auto tag) {
     constexpr int ACT = decltype(tag)::value;
+    auto body = [&](auto grad_tag) {  // resolved once per call, never per element
+    constexpr bool with_grad = decltype(grad_tag)::value;
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
       const int grow = row0 + 16 * m + r;
-      char* gp = glb != nullptr && grow < M ? (char*)glb + (size_t)grow * HRB : nullptr;
+      const bool live = grow < M;
+      char* gp = glb != nullptr && live ? (char*)glb + (size_t)grow * HRB : nullptr;
+      char* dp = with_grad && live ? (char*)dglb + (size_t)grow * HRB : nullptr;
       char* lp = lds != nullptr ? lds + (16 * m + r) * HRB : nullptr;
-      if constexpr (ES == 4) {
+      constexpr int TPC = ES == 4 ? 1 : 2;  // MFMA tiles per 16-byte chunk
 #pragma unroll
-        for (int tp = 0; tp < TPW; ++tp) {
-          u32x4 o;
-          o.x = __float_as_uint(act_c<ACT>(v[tp][m][0]));
-          o.y = __float_as_uint(act_c<ACT>(v[tp][m][1]));
-          o.z = __float_as_uint(act_c<ACT>(v[tp][m][2]));
-          o.w = __float_as_uint(act_c<ACT>(v[tp][m][3]));
-          const int c = ((wbase + feat_off<P>(g, tp)) * 4) >> 4;
-          if (lp) *(u32x4*)(lp + ((c ^ (r & 15)) << 4)) = o;
-          if (gp) *(u32x4*)(gp + c * 16) = o;
-        }
-      } else {
+      for (int tp = 0; tp < TPW; tp += TPC) {
+        float av[4 * TPC], dv[4 * TPC];
 #pragma unroll
-        for (int tp = 0; tp < TPW; tp += 2) {
-          u32x4 o;
-          o.x = (uint32_t)f2bf(act_c<ACT>(v[tp][m][0])) | ((uint32_t)f2bf(act_c<ACT>(v[tp][m][1])) << 16);
-          o.y = (uint32_t)f2bf(act_c<ACT>(v[tp][m][2])) | ((uint32_t)f2bf(act_c<ACT>(v[tp][m][3])) << 16);
-          o.z = (uint32_t)f2bf(act_c<ACT>(v[tp + 1][m][0])) | ((uint32_t)f2bf(act_c<ACT>(v[tp + 1][m][1])) << 16);
-          o.w = (uint32_t)f2bf(act_c<ACT>(v[tp + 1][m][2])) | ((uint32_t)f2bf(act_c<ACT>(v[tp + 1][m][3])) << 16);
-          const int c = ((wbase + feat_off<P>(g, tp)) * 2) >> 4;
-          if (lp) *(u32x4*)(lp + ((c ^ (r & 15)) << 4)) = o;
-          if (gp) *(u32x4*)(gp + c * 16) = o;
+        for (int q = 0; q < 4 * TPC; ++q) {
+          const float x = v[tp + q / 4][m][q % 4];
+          if constexpr (ACT == ACT_MISH && with_grad) {
+            mish_both(x, av[q], dv[q]);
+          } else {
+            av[q] = act_c<ACT>(x);
+            dv[q] = 0.f;
+          }
         }
+        const int c = ((wbase + feat_off<P>(g, tp)) * ES) >> 4;
+        u32x4 o, od;
+        if constexpr (ES == 4) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = __float_as_uint(av[q]), od[q] = __float_as_uint(dv[q]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            o[q] = (uint32_t)f2bf(av[2 * q]) | ((uint32_t)f2bf(av[2 * q + 1]) << 16);
+            od[q] = (uint32_t)f2bf(dv[2 * q]) | ((uint32_t)f2bf(dv[2 * q + 1]) << 16);
+          }
+        }
+        if (lp) *(u32x4*)(lp + ((c ^ (r & 15)) << 4)) = o;
+        if (gp) *(u32x4*)(gp + c * 16) = o;
+        if (dp) *(u32x4*)(dp + c * 16) = od;
       }
     }
+    };
+    if (ACT == ACT_MISH && dglb != nullptr)
+      body(std::true_type{});
+    else
+      body(std::false_type{});
   });
 }
 
@@ -141,6 +165,7 @@ template <class P, int MR, int CH>
 __device__ __forceinline__ void fetch(u32x4 (&d)[MR][CH], const void* glb, int H, int wbase, int g, int r, int row0,
                                       int M) {
   constexpr int ES = P::ESIZE, TPC = ES == 4 ? 1 : 2;  // MFMA tiles per 16-byte chunk
+  asm volatile("" : "+v"(r), "+v"(g));  // see emit()
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
     const int grow = row0 + 16 * m + r;
@@ -149,14 +174,18 @@ __device__ __forceinline__ void fetch(u32x4 (&d)[MR][CH], const void* glb, int H
     for (int c = 0; c < CH; ++c) d[m][c] = *(const u32x4*)(gp + (size_t)(wbase + feat_off<P>(g, c * TPC)) * ES);
   }
 }
+// ReLU: d holds the activated copy (a > 0 <=> x > 0); Mish: d holds act'(x) itself, stored by the forward's emit()
 template <class P, int ACT, int MR, int CH>
 __device__ __forceinline__ float grad_at(const u32x4 (&d)[MR][CH], int tp, int m, int e) {
+  float x;
   if constexpr (P::ESIZE == 4) {
-    return act_grad_c<ACT>(__uint_as_float(d[m][tp][e]));
+    x = __uint_as_float(d[m][tp][e]);
   } else {
     const uint32_t w = d[m][tp >> 1][(tp & 1) * 2 + (e >> 1)];
-    return act_grad_c<ACT>(bf2f((e & 1) ? (w >> 16) : (w & 0xffff)));
+    x = bf2f((e & 1) ? (w >> 16) : (w & 0xffff));
   }
+  if constexpr (ACT == ACT_MISH) return x;
+  return act_grad_c<ACT>(x);
 }
 
 }  // namespace
@@ -185,8 +214,21 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
   float* part = (float*)bufB;
   static_assert(KSPLIT * OT * 16 * 16 * 4 <= 16 * HRB, "out-layer partials must fit in buffer B");
   float* lnred = (float*)(bufB + MT * HRB);  // [8 waves][MR][16] LayerNorm row-reduction table (LN only)
+  // Constants of the whole launch, staged once per workgroup where LDS allows (the launcher decides, a.consts_lds):
+  // a global load issued at a layer's start waits behind every weight fragment the ring has in flight (vmcnt is in
+  // issue order) -- measured ~2k cycles per layer for the bias and ~6k for the out-layer fragments of a 48k-cycle tile.
+  float* biasL = lnred + (LN ? LN_WAVES * MR * 16 : 0);  // [1 + 2 nb][H] hidden-layer biases, then [OT*16] out bias
+  u32x4* woutL = (u32x4*)(biasL + (((1 + 2 * a.nb) * H + OT * 16 + 3) & ~3));  // [KSH][OT][64 lanes] out-layer fragments
   const int wbase = wid * 16 * TPW;  // lane features: wbase + feat_off<P>(g, tp) + e
-  const u32x4* os = a.ostream + lane;
+  const bool bias_lds = (a.consts_lds & 1) != 0, wout_lds = (a.consts_lds & 2) != 0;
+  if (bias_lds) {
+    for (int idx = tid; idx < (1 + 2 * a.nb) * H; idx += 512) biasL[idx] = a.params[a.bias_off[idx / H] + idx % H];
+    for (int idx = tid; idx < OT * 16; idx += 512)
+      biasL[(1 + 2 * a.nb) * H + idx] = idx < a.out_dim ? a.params[a.bias_off[1 + 2 * a.nb] + idx] : 0.f;
+  }
+  if (wout_lds)
+    for (int idx = tid; idx < KSH * OT * 64; idx += 512) woutL[idx] = a.ostream[idx];
+  // (visible after the first tile's barrier)
 
   Engine<P, TPW, MR, PD> eng;
   eng.prime(a.wstream + (size_t)wid * total * TPW * 64 + lane, total);
@@ -200,20 +242,25 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
     STAMP(1);
 
     f32x4 h[TPW][MR], acc[TPW][MR];
-    auto bias_init = [&](int boff) {
+    auto bias_init = [&](int layer) {  // layer: 0, then 1 + 2b / 2 + 2b
+      const float* src = bias_lds ? biasL + layer * H : a.params + a.bias_off[layer];
 #pragma unroll
       for (int tp = 0; tp < TPW; ++tp) {
         f32x4 b;
+        if (bias_lds) {
+          b = *(const f32x4*)(src + wbase + feat_off<P>(g, tp));
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) b[e] = a.params[boff + wbase + feat_off<P>(g, tp) + e];
+          for (int e = 0; e < 4; ++e) b[e] = src[wbase + feat_off<P>(g, tp) + e];
+        }
 #pragma unroll
         for (int m = 0; m < MR; ++m) acc[tp][m] = b;
       }
     };
     // block input: bufA <- act([LN1_b] h), with the tensors the backward needs (training only)
     auto put_block_input = [&](int b) {
-      if (a.hpre[b] != nullptr) emit<P, TPW, MR>(h, ACT_NONE, nullptr, a.hpre[b], H, wbase, g, r, row0, M);
       if constexpr (LN) {
+        if (a.hpre[b] != nullptr) emit<P, TPW, MR>(h, ACT_NONE, nullptr, a.hpre[b], H, wbase, g, r, row0, M);
         float mean[MR], rstd[MR];
         ln_forward<P, TPW, MR>(h, acc, a.params + a.ln_off[4 * b], a.params + a.ln_off[4 * b + 1], H, wbase, g, r, wid,
                                lnred, mean, rstd);
@@ -225,11 +272,11 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
         }
         emit<P, TPW, MR>(acc, ACT, bufA, a.a1[b], H, wbase, g, r, row0, M);
       } else {
-        emit<P, TPW, MR>(h, ACT, bufA, a.a1[b], H, wbase, g, r, row0, M);
+        emit<P, TPW, MR>(h, ACT, bufA, a.a1[b], H, wbase, g, r, row0, M, a.hpre[b]);  // hpre[b] <- act'(h_b) (Mish)
       }
     };
     // ---- layer 0
-    bias_init(a.bias_off[0]);
+    bias_init(0);
     eng.run(acc, xin, in_rb, in_km, KS0, r, g);
     STAMP(2);
 #pragma unroll
@@ -245,11 +292,11 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
     STAMP(4);
     // ---- residual blocks
     for (int b = 0; b < nb; ++b) {
-      bias_init(a.bias_off[1 + 2 * b]);
+      bias_init(1 + 2 * b);
       eng.run(acc, bufA, HRB, 15, KSH, r, g);
       STAMP(5);
-      if (a.z1[b] != nullptr) emit<P, TPW, MR>(acc, ACT_NONE, nullptr, a.z1[b], H, wbase, g, r, row0, M);
       if constexpr (LN) {
+        if (a.z1[b] != nullptr) emit<P, TPW, MR>(acc, ACT_NONE, nullptr, a.z1[b], H, wbase, g, r, row0, M);
         float mean[MR], rstd[MR];
         ln_forward<P, TPW, MR>(acc, acc, a.params + a.ln_off[4 * b + 2], a.params + a.ln_off[4 * b + 3], H, wbase, g, r,
                                wid, lnred, mean, rstd);
@@ -260,11 +307,11 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
               *(float2*)(a.ln_stats + (((size_t)(2 * b + 1) * M) + row0 + 16 * m + r) * 2) = make_float2(mean[m], rstd[m]);
         }
       }
-      emit<P, TPW, MR>(acc, ACT, bufB, a.a2[b], H, wbase, g, r, row0, M);
+      emit<P, TPW, MR>(acc, ACT, bufB, a.a2[b], H, wbase, g, r, row0, M, LN ? nullptr : a.z1[b]);  // z1[b] <- act'(z1_b) (Mish)
       STAMP(6);
       __syncthreads();
       STAMP(7);
-      bias_init(a.bias_off[2 + 2 * b]);
+      bias_init(2 + 2 * b);
       eng.run(acc, bufB, HRB, 15, KSH, r, g);
       STAMP(8);
 #pragma unroll
@@ -280,26 +327,45 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
       STAMP(10);
     }
     // ---- output layer: work items (row sub-tile m, out tile to, K slice kh) dealt to the 8 waves
-    for (int it = wid; it < MR * OT * KSPLIT; it += SAMPLER_WAVES) {
-      const int m = it % MR, to = (it / MR) % OT, kh = it / (MR * OT);
-      f32x4 oacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // (lane-derived indices pass through an empty asm here: otherwise the compiler hoists this phase's LDS addresses out
+    // of the persistent tile loop, spills them, and every scratch reload then waits -- vmcnt is in issue order -- for the
+    // whole ring of weight fragments in flight: measured 5k cycles of a 45k-cycle tile)
+    int r_ = r, g_ = g, lane_ = lane;
+    asm volatile("" : "+v"(r_), "+v"(g_), "+v"(lane_));
+    auto out_items = [&](auto from_lds) {
+      const int r = r_, g = g_, lane = lane_;
+      const u32x4* os = a.ostream + lane;
+      for (int it = wid; it < MR * OT * KSPLIT; it += SAMPLER_WAVES) {
+        const int m = it % MR, to = (it / MR) % OT, kh = it / (MR * OT);
+        f32x4 oacc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
-      for (int c = 0; c < KPER; ++c) {
-        const int ks = kh * KPER + c;
-        const u32x4 wf = os[(size_t)(ks * OT + to) * 64];
-        const u32x4 xb = *(const u32x4*)(bufA + (16 * m + r) * HRB + (((ks * 4 + g) ^ (r & 15)) << 4));
-        oacc = P::mma(wf, xb, oacc);
-      }
+        for (int c = 0; c < KPER; ++c) {
+          const int ks = kh * KPER + c;
+          u32x4 wf;
+          if constexpr (decltype(from_lds)::value)
+            wf = woutL[(ks * OT + to) * 64 + lane];
+          else
+            wf = os[(size_t)(ks * OT + to) * 64];
+          const u32x4 xb = *(const u32x4*)(bufA + (16 * m + r) * HRB + (((ks * 4 + g) ^ (r & 15)) << 4));
+          oacc = P::mma(wf, xb, oacc);
+        }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) part[(((kh * MR + m) * OT + to) * 16 + 4 * g + e) * 16 + r] = oacc[e];
-    }
+        for (int e = 0; e < 4; ++e) part[(((kh * MR + m) * OT + to) * 16 + 4 * g + e) * 16 + r] = oacc[e];
+      }
+    };
+    if (wout_lds)
+      out_items(std::true_type{});
+    else
+      out_items(std::false_type{});
     STAMP(11);
     __syncthreads();
     STAMP(12);
-    for (int idx = tid; idx < MT * a.out_dim; idx += 512) {
+    int tid_ = tid;
+    asm volatile("" : "+v"(tid_));  // see emit()
+    for (int idx = tid_; idx < MT * a.out_dim; idx += 512) {
       const int row = idx / a.out_dim, j = idx - row * a.out_dim;
       const int m = row >> 4, rr = row & 15, to = j >> 4, jj = j & 15;
-      float s = a.params[a.bias_off[1 + 2 * nb] + j];
+      float s = bias_lds ? biasL[(1 + 2 * nb) * H + j] : a.params[a.bias_off[1 + 2 * nb] + j];
 #pragma unroll
       for (int kh = 0; kh < KSPLIT; ++kh) s += part[(((kh * MR + m) * OT + to) * 16 + jj) * 16 + rr];
       if (row0 + row < M) a.out[(size_t)(row0 + row) * a.ldout + j] = s;
@@ -518,14 +584,22 @@ static void raise_lds(K kern, bool& done) {
 template <class P, int TPW, int MR, int OT, bool LN, int ACT>
 static int launch_fwd_cfg(const FusedFwdArgs& a, hipStream_t s) {
   constexpr int ES = P::ESIZE, MT = 16 * MR, H = 128 * TPW;
-  const size_t lds = 2 * (size_t)MT * H * ES + (LN ? (size_t)LN_WAVES * MR * 16 * 4 : 0);
+  size_t lds = 2 * (size_t)MT * H * ES + (LN ? (size_t)LN_WAVES * MR * 16 * 4 : 0);
   if (lds > 160 * 1024 || a.Kp0 > H) return -2;
+  FusedFwdArgs b = a;  // constants staged in LDS as far as it reaches: biases first, then the out-layer fragments
+  const size_t bias_bytes = ((size_t)((1 + 2 * a.nb) * H + OT * 16 + 3) & ~(size_t)3) * 4;
+  const size_t wout_bytes = (size_t)(H / P::KB) * OT * 64 * 16;
+  b.consts_lds = 0;
+  if (lds + bias_bytes <= 160 * 1024) {
+    b.consts_lds |= 1, lds += bias_bytes;
+    if (lds + wout_bytes <= 160 * 1024) b.consts_lds |= 2, lds += wout_bytes;
+  }
   static bool attr = false;
   raise_lds(fused_forward_kernel<P, TPW, MR, OT, LN, ACT>, attr);
   const int ntiles = (a.M + MT - 1) / MT;
   const bool probe = probe_begin(PROBE_FUSED_FWD, s);
   hipLaunchKernelGGL((fused_forward_kernel<P, TPW, MR, OT, LN, ACT>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512), lds, s,
-                     a);
+                     b);
   if (probe) probe_end(s, 2.0 * a.M * ((double)a.in_valid * H + 2.0 * a.nb * H * H + (double)H * a.out_dim));
   return 0;
 }

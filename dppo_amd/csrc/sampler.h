@@ -42,6 +42,7 @@ struct SampleArgs {
   const dppo_step* sched;
   int B, AF, td, cond, Kp0, nb, n_steps, chain_len, init_slot, act, use_ddim;
   int has_dclip, has_eclip, has_fclip;
+  int consts_lds;  // set by the launcher: 1 = both networks' biases staged in LDS
   float dclip, eclip, rclip, fclip;
 };
 

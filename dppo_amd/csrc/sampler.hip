@@ -46,6 +46,19 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
   constexpr bool PART_IN_B = SAMPLER_WAVES * OT * 16 * 16 * 4 <= 16 * HRB;
   float* part = PART_IN_B ? (float*)bufB : xcur + ((16 * AF + 3) & ~3);
   float* lnred = (PART_IN_B ? xcur + ((16 * AF + 3) & ~3) : part + SAMPLER_WAVES * OT * 16 * 16);  // [8][16]
+  // both networks' biases, staged once: [net][(1 + 2 nb) * H hidden | OT*16 out].  A global load at a layer's start
+  // would wait behind every weight fragment the ring has in flight (vmcnt is in issue order), 3 x 20 times per call.
+  float* biasL = lnred + LN_WAVES * 16;
+  const int bias_stride = (1 + 2 * nb) * H + OT * 16;
+  const bool bias_lds = a.consts_lds != 0;
+  if (bias_lds) {
+    for (int net = 0; net < 2; ++net) {
+      for (int idx = tid; idx < (1 + 2 * nb) * H; idx += 512)
+        biasL[net * bias_stride + idx] = a.params[net][a.bias_off[idx / H] + idx % H];
+      for (int idx = tid; idx < OT * 16; idx += 512)
+        biasL[net * bias_stride + (1 + 2 * nb) * H + idx] = idx < AF ? a.params[net][a.bias_off[1 + 2 * nb] + idx] : 0.f;
+    }
+  }
 
   // ---- one-time: state columns (of the first step's network) + zero padding of the input image, x_K, time
   // embedding of step 0
@@ -117,11 +130,18 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
     int pos = 0;
 
     // one hidden layer: nks k-step positions starting at stream position `pos`, B operand from `src`
-    auto run_layer = [&](const char* src, int rb, int km, int nks, int boff) {
+    auto run_layer = [&](const char* src, int rb, int km, int nks, int layer) {
+      if (bias_lds) {
 #pragma unroll
-      for (int tp = 0; tp < TPW; ++tp)
+        for (int tp = 0; tp < TPW; ++tp)
+          acc[tp][0] = *(const f32x4*)(biasL + net * bias_stride + layer * H + wbase + feat_off<P>(g, tp));
+      } else {
+        const int boff = a.bias_off[layer];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[tp][0][e] = prm[boff + wbase + feat_off<P>(g, tp) + e];
+        for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[tp][0][e] = prm[boff + wbase + feat_off<P>(g, tp) + e];
+      }
       for (int k0 = 0; k0 < nks; k0 += PD) {
 #pragma unroll
         for (int p = 0; p < PD; ++p) {
@@ -181,7 +201,7 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
       }
     };
     // ---- layer 0
-    run_layer(xin, in_rb, in_km, KS0, a.bias_off[0]);
+    run_layer(xin, in_rb, in_km, KS0, 0);
 #pragma unroll
     for (int tp = 0; tp < TPW; ++tp) h[tp][0] = acc[tp][0];
     if (nb > 0)
@@ -191,13 +211,13 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
     __syncthreads();
     // ---- residual blocks: h += l2(act([LN2] l1(act([LN1] h))))
     for (int b = 0; b < nb; ++b) {
-      run_layer(bufA, HRB, 15, KSH, a.bias_off[1 + 2 * b]);
+      run_layer(bufA, HRB, 15, KSH, 1 + 2 * b);
       if constexpr (LN)
         ln_forward<P, TPW, 1>(acc, acc, prm + a.ln_off[4 * b + 2], prm + a.ln_off[4 * b + 3], H, wbase, g, r, wid, lnred,
                               ln_m, ln_r);
       put_hidden(bufB, acc, ACT);
       __syncthreads();
-      run_layer(bufB, HRB, 15, KSH, a.bias_off[2 + 2 * b]);
+      run_layer(bufB, HRB, 15, KSH, 2 + 2 * b);
 #pragma unroll
       for (int tp = 0; tp < TPW; ++tp) h[tp][0] += acc[tp][0];
       if (b + 1 < nb)
@@ -242,7 +262,7 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
       for (int idx = tid; idx < 16 * AF; idx += 512) {
         const int row = idx / AF, j = idx - row * AF;
         const int grow = grow0 + row;
-        float eps = prm[a.bias_off[1 + 2 * nb] + j];
+        float eps = bias_lds ? biasL[net * bias_stride + (1 + 2 * nb) * H + j] : prm[a.bias_off[1 + 2 * nb] + j];
 #pragma unroll
         for (int w = 0; w < SAMPLER_WAVES; ++w) eps += part[(w * OT * 16 + j) * 16 + row];
         const float x = xcur[row * AF + j];
@@ -311,6 +331,10 @@ static int launch_cfg(const SamplerGeom& g, const SampleArgs& a, hipStream_t s) 
   size_t lds = (size_t)16 * a.Kp0 * ES + 2 * (size_t)16 * g.H * ES + (size_t)((16 * a.AF + 3) & ~3) * 4 +
                (part_bytes <= (size_t)16 * g.H * ES ? 0 : part_bytes) + (size_t)LN_WAVES * 16 * 4;
   if (lds > 160 * 1024) return -2;
+  SampleArgs b = a;
+  const size_t bias_bytes = 2 * ((size_t)(1 + 2 * a.nb) * g.H + OT * 16) * 4;
+  b.consts_lds = lds + bias_bytes <= 160 * 1024 ? 1 : 0;
+  if (b.consts_lds) lds += bias_bytes;
   static bool attr_set = false;  // raising the dynamic-LDS cap is idempotent; racing setters are harmless
   auto kern = sample_chain_kernel<P, TPW, OT, LN, ACT>;
   if (!attr_set) {
@@ -318,7 +342,7 @@ static int launch_cfg(const SamplerGeom& g, const SampleArgs& a, hipStream_t s) 
     attr_set = true;
   }
   const bool probe = probe_begin(PROBE_SAMPLER, s);
-  hipLaunchKernelGGL(kern, dim3((a.B + 15) / 16), dim3(512), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3((a.B + 15) / 16), dim3(512), lds, s, b);
   if (probe) probe_end(s, 2.0 * a.B * a.n_steps * ((double)g.in_dim * g.H + 2.0 * g.nb * g.H * g.H + (double)g.H * g.out_dim));
   return 0;
 }
