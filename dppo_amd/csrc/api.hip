@@ -423,6 +423,8 @@ static void mlp_forward(const dppo_net_desc& d, const float* prm, const char* pk
   launch_gemm_nt<P>(g, s);
 }
 
+static int g_tn_target = 512;      // tuning knob 3: workgroups a weight-gradient GEMM aims for (tiles x row splits)
+static int g_tn_max_splits = 128;  // tuning knob 4: cap on its row splits (each split costs one fp32 slab of the output)
 // gw[N1][N2] (ld ldgw) = A[M][N1]^T . B[M][N2].  A thin N1 (the out layer) is computed transposed, B^T . A, so that the
 // 512 x 64 block shape of gemm_tn covers it in one output tile; the slab reduce transposes back.
 template <class P>
@@ -438,10 +440,10 @@ static void weight_grad(const void* A, int lda, int N1, const void* Bm, int ldb,
   }
   const bool thin = gemm_tn_thin(N1, N2);
   const size_t tiles = thin ? (size_t)((N1 + 511) / 512) : (size_t)((N1 + 127) / 128) * ((N2 + 127) / 128);
-  int64_t splits = (512 + tiles - 1) / tiles;
+  int64_t splits = (g_tn_target + tiles - 1) / tiles;
   const int64_t max_splits = (M + 63) / 64;
   if (splits > max_splits) splits = max_splits;
-  if (splits > 128) splits = 128;
+  if (splits > g_tn_max_splits) splits = g_tn_max_splits;
   while (splits > 1 && (size_t)splits * N1 * N2 > B.slab_floats) --splits;
   if (splits >= 8) splits = splits / 8 * 8;  // a multiple of the XCD count keeps one split's tiles on one XCD
   int64_t rps = (M + splits - 1) / splits;
@@ -1043,6 +1045,18 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 2) {
     g_overlap = value;
+    return 0;
+  }
+  if (knob == 3 && value >= 1) {
+    g_tn_target = value;
+    return 0;
+  }
+  if (knob == 4 && value >= 1) {
+    g_tn_max_splits = value;
+    return 0;
+  }
+  if (knob == 5) {
+    set_gemm_tn_variant(value);
     return 0;
   }
   return fail(-1, "unknown tuning knob %d", knob);

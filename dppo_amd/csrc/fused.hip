@@ -548,6 +548,7 @@ template <class P>
 static int pick_mr_bwd(int hidden, int ln) {
   int mr = pick_mr<P>(hidden);
   if (hidden >= 1024 && mr > 1) mr /= 2;
+  if (P::ESIZE == 2 && hidden == 256) mr /= 2;  // 8 row sub-tiles of dh, acc, derivative chunks and B fragments do not fit 256 VGPRs
   if (ln && mr > 1) mr /= 2;
   return mr;
 }
@@ -650,7 +651,7 @@ int launch_fused_backward(const dppo_net_desc& d, const FusedBwdArgs& a, hipStre
   if (tpw == T && mr == R && (a.use_ln != 0) == L) \
     return relu ? launch_bwd_cfg<P, T, R, L, ACT_RELU>(a, s) : launch_bwd_cfg<P, T, R, L, ACT_MISH>(a, s);
   if constexpr (P::ESIZE == 2) {
-    DPPO_BWD(2, 8, false) DPPO_BWD(2, 4, true) DPPO_BWD(4, 4, false) DPPO_BWD(4, 2, true) DPPO_BWD(8, 1, false)
+    DPPO_BWD(2, 4, false) DPPO_BWD(2, 2, true) DPPO_BWD(4, 4, false) DPPO_BWD(4, 2, true) DPPO_BWD(8, 1, false)
     DPPO_BWD(8, 1, true)
   } else {
     DPPO_BWD(2, 4, false) DPPO_BWD(2, 2, true) DPPO_BWD(4, 2, false) DPPO_BWD(4, 1, true) DPPO_BWD(8, 1, false)

@@ -455,6 +455,174 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm_tn, LDS-DMA pipeline.  Same contraction and slab output as gemm_tn_kernel, but both operands go global -> LDS
+// with global_load_lds (16 B per lane, no VGPR round trip) into a ring of NST stages of ROWS batch rows, so that
+// NST - 1 stages (tens of KB per workgroup) are in flight while one is multiplied: the register-staged kernel has one
+// stage of lookahead and waits out an HBM latency per 64 rows.  One barrier per stage.  A DMA writes LDS linearly
+// (wave base + 16 * lane), so the XOR swizzle that keeps the transposed fragment reads conflict-free sits on the
+// SOURCE side: slot p of tile row q receives source chunk p ^ swz(q).  The transposed reads fetch 8 B per lane, 32
+// contiguous bytes per (row, 4 lanes), 8 rows per 32-lane half: the swizzle therefore permutes 32-byte units by the
+// row's low 3 bits, swz(q) = (q & 7) << 1 (rows of 16+ chunks; narrower rows use the bits they have).  A DMA cannot
+// zero-fill: lanes whose row or column does not exist read a 16-byte page of zeros instead.
+__device__ u32x4 g_zero_chunk[1];
+template <int CP>  // chunk-index XOR of tile row q (CP chunks of 16 B per row)
+__device__ __forceinline__ constexpr int swz(int q) {
+  return CP >= 16 ? (q & 7) << 1 : (CP >= 8 ? (q & 3) << 1 : 0);
+}
+
+template <class P, int WA, int WB, int TA, int TB, int NST, int KS>
+__global__ __launch_bounds__(WA* WB * 64) void gemm_tn_dma_kernel(const GemmTN a) {
+  constexpr int ES = P::ESIZE, NT = WA * WB * 64;
+  constexpr int BA = WA * TA * 16, BB = WB * TB * 16;
+  constexpr int ROWS = KS * ((ES == 2) ? 32 : 16);  // batch rows per stage (KS k-steps)
+  constexpr int RSA = BA * ES, RSB = BB * ES;  // dense rows
+  constexpr int CPA = RSA / 16, CPB = RSB / 16;  // 16-byte chunks per tile row (>= 8: the swizzle needs 3 bits)
+  static_assert(CPA >= 8 && CPB >= 8 && (ROWS * CPA) % NT == 0 && (ROWS * CPB) % NT == 0, "tile / thread-count mismatch");
+  constexpr int NCA = ROWS * CPA / NT, NCB = ROWS * CPB / NT, NLD = NCA + NCB;
+  constexpr int OPA = ROWS * RSA, STAGE = ROWS * (RSA + RSB);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int wa = wid % WA, wb = wid / WA;
+  const int fa0 = blockIdx.y * BA, fb0 = blockIdx.z * BB;  // blockIdx.x = row split: see gemm_tn_kernel
+  const int m_begin = blockIdx.x * a.rows_per_split;
+  const int m_end = min(a.M, m_begin + a.rows_per_split);
+  const char* Ab = (const char*)a.A;
+  const char* Bb = (const char*)a.B;
+  const char* zero = (const char*)g_zero_chunk;
+
+  auto dma = [&](int stage_idx, int buf) {
+    char* As = smem + buf * STAGE;
+    char* Bs = As + OPA;
+    const int m0 = m_begin + stage_idx * ROWS;
+#pragma unroll
+    for (int i = 0; i < NCA; ++i) {
+      const int q = tid + i * NT;  // LDS chunk slot
+      const int rr = q / CPA, c = (q % CPA) ^ swz<CPA>(rr);
+      const int row = m0 + rr, ca = fa0 + c * (16 / ES);
+      const char* src = (row < m_end && ca < a.lda) ? Ab + ((size_t)row * a.lda + ca) * ES : zero;
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(As + (size_t)(i * NT + (tid & ~63)) * 16), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+      const int q = tid + i * NT;
+      const int rr = q / CPB, c = (q % CPB) ^ swz<CPB>(rr);
+      const int row = m0 + rr, cb = fb0 + c * (16 / ES);
+      const char* src = (row < m_end && cb < a.ldb) ? Bb + ((size_t)row * a.ldb + cb) * ES : zero;
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(Bs + (size_t)(i * NT + (tid & ~63)) * 16), 16, 0, 0);
+    }
+  };
+  // byte offset of logical (row, byte column) in a swizzled tile
+  auto atA = [](int row, int byte_col) { return row * RSA + ((((byte_col >> 4) ^ swz<CPA>(row)) << 4) | (byte_col & 15)); };
+  auto atB = [](int row, int byte_col) { return row * RSB + ((((byte_col >> 4) ^ swz<CPB>(row)) << 4) | (byte_col & 15)); };
+
+  f32x4 acc[TA][TB];
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nst = (m_end - m_begin + ROWS - 1) / ROWS;
+#pragma unroll
+  for (int p = 0; p < NST - 1; ++p)
+    if (p < nst) dma(p, p);
+  for (int st = 0; st < nst; ++st) {
+    // this wave's share of stage st has landed once at most the DMAs of the NST - 2 younger stages are outstanding
+    // (vmcnt counts in issue order); near the end fewer are in flight: wait for all
+    if (st + NST - 2 < nst)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NLD) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // everyone's share landed, and everyone is done reading the buffer refilled next
+    if (st + NST - 1 < nst) dma(st + NST - 1, (st + NST - 1) % NST);
+    const char* As = smem + (st % NST) * STAGE;
+    const char* Bs = As + OPA;
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+      u32x4 af[TA], bf[TB];
+      if constexpr (ES == 2) {
+        // rows of this k-step: 32 s2 .. 32 s2 + 31; lane group g: 32 s2 + 8g + {0..7}; odd g swap the two 4-row halves
+        // (a k-permutation common to A and B)
+        typedef __attribute__((address_space(3))) i16x4 lds_v;
+        const int q = r >> 2, p = r & 3;
+        const int rbase = 32 * s2 + 8 * g;
+        const int r0 = rbase + ((g & 1) ? 4 : 0) + q, r1 = rbase + ((g & 1) ? 0 : 4) + q;
+#pragma unroll
+        for (int t = 0; t < TA; ++t) {
+          const int ca = (wa * TA * 16 + t * 16 + 4 * p) * 2;
+          const u32x2 u0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(As + atA(r0, ca))));
+          const u32x2 u1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(As + atA(r1, ca))));
+          af[t] = (u32x4){u0.x, u0.y, u1.x, u1.y};
+        }
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+          const int cb = (wb * TB * 16 + t * 16 + 4 * p) * 2;
+          const u32x2 u0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(Bs + atB(r0, cb))));
+          const u32x2 u1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(Bs + atB(r1, cb))));
+          bf[t] = (u32x4){u0.x, u0.y, u1.x, u1.y};
+        }
+      } else {
+        // rows of this k-step: 16 s2 .. 16 s2 + 15 ; MFMA j of the step uses row 16 s2 + 4j + g
+#pragma unroll
+        for (int t = 0; t < TA; ++t) {
+          const int ca = (wa * TA * 16 + t * 16 + r) * 4;
+          uint32_t v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = *(const uint32_t*)(As + atA(16 * s2 + 4 * j + g, ca));
+          af[t] = (u32x4){v[0], v[1], v[2], v[3]};
+        }
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+          const int cb = (wb * TB * 16 + t * 16 + r) * 4;
+          uint32_t v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = *(const uint32_t*)(Bs + atB(16 * s2 + 4 * j + g, cb));
+          bf[t] = (u32x4){v[0], v[1], v[2], v[3]};
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) acc[i][j] = P::mma(af[i], bf[j], acc[i][j]);
+    }
+  }
+
+  float* out = a.slab + (size_t)blockIdx.x * a.N1 * a.ldc;
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n1 = fa0 + wa * TA * 16 + i * 16 + 4 * g + e;
+      if (n1 >= a.N1) continue;
+#pragma unroll
+      for (int j = 0; j < TB; ++j) {
+        const int n2 = fb0 + wb * TB * 16 + j * 16 + r;
+        if (n2 < a.N2) out[(size_t)n1 * a.ldc + n2] = acc[i][j][e];
+      }
+    }
+}
+
+template <class P, int WA, int WB, int TA, int TB, int NST, int KS = 2>
+static void launch_tn_dma_cfg(const GemmTN& a, hipStream_t s) {
+  constexpr int ES = P::ESIZE, BA = WA * TA * 16, BB = WB * TB * 16, ROWS = KS * ((ES == 2) ? 32 : 16);
+  constexpr int LDS = NST * ROWS * (BA + BB) * ES;
+  static_assert(LDS <= 160 * 1024, "ring does not fit LDS");
+  dim3 grid(a.splits, (a.N1 + BA - 1) / BA, (a.N2 + BB - 1) / BB);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<P, WA, WB, TA, TB, NST, KS>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  const bool probe = a.N1 >= 128 && a.N2 >= 128 && probe_begin(PROBE_GEMM_TN, s);  // H x H gradients
+  hipLaunchKernelGGL((gemm_tn_dma_kernel<P, WA, WB, TA, TB, NST, KS>), grid, dim3(WA * WB * 64), LDS, s, a);
+  if (probe) probe_end(s, 2.0 * a.M * a.N1 * a.N2);
+}
+
 template <class P, int WA, int WB, int TA, int TB>
 static void launch_tn_cfg(const GemmTN& a, hipStream_t s) {
   constexpr int ES = P::ESIZE, BA = WA * TA * 16, BB = WB * TB * 16, ROWS = (ES == 2) ? 64 : 32;
@@ -473,12 +641,32 @@ static void launch_tn_cfg(const GemmTN& a, hipStream_t s) {
 
 bool gemm_tn_thin(int N1, int N2) { return N2 <= 64 && N1 > 64; }
 
+// 0 (default): register-staged kernel; 1..8: an LDS-DMA ring configuration (tools/gemm_bench.py sweeps them); -1: ring
+// variant 2 for outputs of 512 x 512 and more.  Alone on the chip the ring wins at 512 x 512 (43.8 vs 51.6 us incl. the
+// slab reduce, M = 50,000, bf16) and loses at 256 x 256 (34.7 vs 30.1); inside the update step, next to the other
+// stream's kernels, it does not pay (65.9 vs 66.9 M samples/s), so it stays an option.  Either way the contraction is
+// HBM-bound here (195 FLOP per byte of operand + slab traffic against a machine balance of ~310).
+static int g_tn_variant = 0;
+void set_gemm_tn_variant(int v) { g_tn_variant = v; }
+
 template <class P>
 void launch_gemm_tn(const GemmTN& a, hipStream_t s) {
-  if (gemm_tn_thin(a.N1, a.N2))
+  if (gemm_tn_thin(a.N1, a.N2)) {
     launch_tn_cfg<P, 4, 1, 8, 4>(a, s);
-  else
-    launch_tn_cfg<P, 2, 2, 4, 4>(a, s);
+    return;
+  }
+  const int variant = g_tn_variant >= 0 ? g_tn_variant : ((size_t)a.N1 * a.N2 >= 512 * 512 ? 2 : 0);
+  switch (variant) {
+    case 1: launch_tn_dma_cfg<P, 2, 2, 4, 4, 3>(a, s); break;  // 128 x 128, 4 waves, 3 stages (96 KB)
+    case 2: launch_tn_dma_cfg<P, 2, 2, 4, 4, 2>(a, s); break;  // 128 x 128, 4 waves, 2 stages (2 workgroups / CU)
+    case 3: launch_tn_dma_cfg<P, 4, 2, 4, 4, 3>(a, s); break;  // 256 x 128, 8 waves, 3 stages (144 KB)
+    case 4: launch_tn_dma_cfg<P, 2, 2, 4, 4, 4>(a, s); break;  // 128 x 128, 4 waves, 4 stages (128 KB)
+    case 5: launch_tn_dma_cfg<P, 2, 2, 8, 4, 2, 1>(a, s); break;  // 256 x 128, 4 waves of 128 x 64, 2 stages of 1 k-step (48 KB)
+    case 6: launch_tn_dma_cfg<P, 2, 2, 8, 4, 3, 1>(a, s); break;  // same, 3 stages (72 KB)
+    case 7: launch_tn_dma_cfg<P, 2, 4, 8, 4, 2, 2>(a, s); break;  // 256 x 256, 8 waves of 128 x 64, 2 stages of 2 k-steps (128 KB)
+    case 8: launch_tn_dma_cfg<P, 2, 2, 8, 4, 2, 2>(a, s); break;  // 256 x 128, 4 waves, 2 stages of 2 k-steps (96 KB)
+    default: launch_tn_cfg<P, 2, 2, 4, 4>(a, s);
+  }
 }
 template void launch_gemm_tn<F32>(const GemmTN&, hipStream_t);
 template void launch_gemm_tn<BF16>(const GemmTN&, hipStream_t);

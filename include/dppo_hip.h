@@ -216,7 +216,9 @@ int dppo_probe_collect(double* total_ms_host, int* launches_host, double* flops_
 /* ---- tuning / micro-benchmark hooks (tools/ and tests only; never used by the product path) ----- */
 /* knob 0: gemm_nt operand staging, 0 = through registers, 1 = global_load_lds (LDS-DMA, default)
  * knob 1: big-batch MLP path, 1 = fused row-tile kernels (default), 0 = layer-by-layer gemm_nt chain
- * knob 2: PPO update, 1 = critic half on a side stream, overlapping the actor half (default), 0 = one stream */
+ * knob 2: PPO update, 1 = critic half on a side stream, overlapping the actor half (default), 0 = one stream
+ * knob 3 / 4: weight-gradient GEMMs, workgroups aimed for (default 512) / cap on the row splits (default 128)
+ * knob 5: weight-gradient GEMM kernel, 0 = register-staged (default), 1..8 = an LDS-DMA ring configuration, -1 = by shape */
 int dppo_tune_set(int knob, int value);
 /* one bare layer GEMM: out[M][ldo] = act(X[M][Kp] . W[N][Kp]^T + bias) with elem = prec operands;
  * out_f32 and/or out_elem may be NULL; ldo >= round_up(N,16) */
