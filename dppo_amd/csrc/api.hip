@@ -204,24 +204,23 @@ static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char*
     const SamplerGeom g = sampler_geom<P>(d);
     const FusedGeom fg = fused_geom<P>(d);
     // forward stream [L0][b: l1, l2]... and backward stream, top down: [dh = d_out . Wout][b = nb-1..0: W2^T, W1^T]
-    // ("feature f, contraction index k" of a transposed layer is W[k][f] = W[k*H + f]); one launch each
-    PackStream fs, bs;
-    memset(&fs, 0, sizeof(fs));
-    memset(&bs, 0, sizeof(bs));
-    fs.TPW = bs.TPW = g.TPW, fs.total_pos = g.total_pos, bs.total_pos = fg.total_pos;
-    fs.stream = (u32x4*)(pk + L.sstream), bs.stream = (u32x4*)(pk + L.bstream);
-    fs.layer[fs.n_layers++] = PackLayer{prm + pl.W0, d.in_dim, 1, d.in_dim, g.KS0, 0};
+    // ("feature f, contraction index k" of a transposed layer is W[k][f] = W[k*H + f]); all in one launch
+    PackStream ps;
+    memset(&ps, 0, sizeof(ps));
+    ps.TPW = g.TPW;
+    u32x4* fwd = (u32x4*)(pk + L.sstream);
+    u32x4* bwd = (u32x4*)(pk + L.bstream);
+    ps.layer[ps.n_layers++] = PackLayer{prm + pl.W0, d.in_dim, 1, d.in_dim, g.KS0, 0, fwd, g.total_pos};
     for (int b = 0; b < d.n_blocks; ++b) {
-      fs.layer[fs.n_layers++] = PackLayer{prm + pl.l1w[b], H, 1, H, g.KSH, g.KS0 + 2 * b * g.KSH};
-      fs.layer[fs.n_layers++] = PackLayer{prm + pl.l2w[b], H, 1, H, g.KSH, g.KS0 + (2 * b + 1) * g.KSH};
+      ps.layer[ps.n_layers++] = PackLayer{prm + pl.l1w[b], H, 1, H, g.KSH, g.KS0 + 2 * b * g.KSH, fwd, g.total_pos};
+      ps.layer[ps.n_layers++] = PackLayer{prm + pl.l2w[b], H, 1, H, g.KSH, g.KS0 + (2 * b + 1) * g.KSH, fwd, g.total_pos};
     }
-    bs.layer[bs.n_layers++] = PackLayer{prm + pl.Wout, 1, H, d.out_dim, fg.KSB0, 0};
+    ps.layer[ps.n_layers++] = PackLayer{prm + pl.Wout, 1, H, d.out_dim, fg.KSB0, 0, bwd, fg.total_pos};
     for (int b = d.n_blocks - 1, pos = fg.KSB0; b >= 0; --b, pos += 2 * g.KSH) {
-      bs.layer[bs.n_layers++] = PackLayer{prm + pl.l2w[b], 1, H, H, g.KSH, pos};
-      bs.layer[bs.n_layers++] = PackLayer{prm + pl.l1w[b], 1, H, H, g.KSH, pos + g.KSH};
+      ps.layer[ps.n_layers++] = PackLayer{prm + pl.l2w[b], 1, H, H, g.KSH, pos, bwd, fg.total_pos};
+      ps.layer[ps.n_layers++] = PackLayer{prm + pl.l1w[b], 1, H, H, g.KSH, pos + g.KSH, bwd, fg.total_pos};
     }
-    launch_pack_stream<P>(fs, s);
-    launch_pack_stream<P>(bs, s);
+    launch_pack_stream<P>(ps, s);
     launch_pack_out<P>(prm + pl.Wout, d.out_dim, H, g.OT, g.CNT, (u32x4*)(pk + L.ostream), s);
   }
   return check_launch();
@@ -423,6 +422,44 @@ static void mlp_forward(const dppo_net_desc& d, const float* prm, const char* pk
   launch_gemm_nt<P>(g, s);
 }
 
+// ---- side streams ----------------------------------------------------------------------------------------
+// Independent parts of one call run on side streams so that their kernels fill each other's gaps (the persistent
+// row-tile kernels leave CUs idle in their last round of tiles; the small reductions are latency-bound).  Fork / join
+// through events: legal under stream capture too.  Tuning knob 2 turns it off (one stream, for per-kernel timing).
+//   side 0: the critic half of a PPO update;  side 1 / 2: the bias / time-embedding gradient tail of the actor / critic
+static int g_overlap = 1;
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false;
+};
+static SideStream* side_stream(int idx) {
+  static SideStream tab[16][3];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  SideStream& t = tab[dev][idx];
+  if (!t.ok) {
+    if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&t.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    t.ok = true;
+  }
+  return &t;
+}
+static hipStream_t fork_side(hipStream_t main, int idx = 0) {  // returns the stream the independent part should use
+  SideStream* t = g_overlap ? side_stream(idx) : nullptr;
+  if (t == nullptr) return main;
+  (void)hipEventRecord(t->fork, main);
+  (void)hipStreamWaitEvent(t->s, t->fork, 0);
+  return t->s;
+}
+static void join_side(hipStream_t main, hipStream_t sidestream, int idx = 0) {
+  if (sidestream == main) return;
+  SideStream* t = side_stream(idx);
+  (void)hipEventRecord(t->join, sidestream);
+  (void)hipStreamWaitEvent(main, t->join, 0);
+}
+
 static int g_tn_target = 512;      // tuning knob 3: workgroups a weight-gradient GEMM aims for (tiles x row splits)
 static int g_tn_max_splits = 128;  // tuning knob 4: cap on its row splits (each split costs one fp32 slab of the output)
 // gw[N1][N2] (ld ldgw) = A[M][N1]^T . B[M][N2].  A thin N1 (the out layer) is computed transposed, B^T . A, so that the
@@ -506,7 +543,7 @@ static void cond_backward(const dppo_net_desc& d, const float* prm, const char* 
 template <class P>
 static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* pk, const PackLayout& L, int64_t M,
                          MlpBufs<P>& B, float* grad, const int32_t* krow, const dppo_step* ksteps, int Kft,
-                         hipStream_t s, bool bout_done = false) {
+                         hipStream_t s, bool bout_done = false, int aux_idx = 1) {
   const ParamLayout pl = param_layout(d);
   const int H = d.hidden, nb = d.n_blocks;
   if (fused_ok<P>(d) && B.tiles > 0) {
@@ -545,15 +582,19 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
         }
         so.n_slots += 4 * nb;
       }
-      launch_reduce_slots(B.tile_colsum, B.tiles, H, so, s);
+      // the latency-bound tail (bias sums, time-embedding gradient; they share B.part) runs beside the weight-gradient
+      // GEMMs (which share B.slab and stay in order on s)
+      hipStream_t aux = fork_side(s, aux_idx);
+      launch_reduce_slots(B.tile_colsum, B.tiles, H, so, aux);
+      if (!bout_done) launch_colsum<P>(B.d_out, (int)M, d.out_dim, L.Kpo, B.part, REDUCE_BLOCKS, grad + pl.bout, 1.f, aux);
+      if (d.kind == 0) time_embedding_grad<P>(d, prm, pk, L, M, B, B.dh_all[0], grad, krow, ksteps, Kft, aux);
       weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.hE, H, H, M, B, grad + pl.Wout, H, s);
-      if (!bout_done) launch_colsum<P>(B.d_out, (int)M, d.out_dim, L.Kpo, B.part, REDUCE_BLOCKS, grad + pl.bout, 1.f, s);
       for (int b = nb - 1; b >= 0; --b) {
         weight_grad<P>(B.dh_all[b + 1], H, H, B.a2[b], H, H, M, B, grad + pl.l2w[b], H, s);
         weight_grad<P>(B.dz1_all[b], H, H, B.a1[b], H, H, M, B, grad + pl.l1w[b], H, s);
       }
       weight_grad<P>(B.dh_all[0], H, H, B.in, L.Kp0, d.in_dim, M, B, grad + pl.W0, d.in_dim, s);
-      if (d.kind == 0) time_embedding_grad<P>(d, prm, pk, L, M, B, B.dh_all[0], grad, krow, ksteps, Kft, s);
+      join_side(s, aux, aux_idx);
       B.dh0_final = B.dh_all[0];
       return;
     }
@@ -854,54 +895,19 @@ int dppo_gae(const double* reward, const float* values, const float* terminated,
 }
 
 // ---- PPO update --------------------------------------------------------------------------------------
-// The actor and the critic halves of an update are independent between the row builder and the loss, and again after
-// it.  Their persistent row-tile kernels leave CUs idle in the last round of tiles (50,000 rows = 3.05 rounds of 64-row
-// tiles on 256 CUs), so the critic runs on a side stream and fills those gaps.  Fork / join through events: legal under
-// stream capture too.  Tuning knob 2 turns it off (serial, for per-kernel timing).
-static int g_overlap = 1;
-struct SideStream {
-  hipStream_t s = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  bool ok = false;
-};
-static SideStream* side_stream() {
-  static SideStream tab[16];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  SideStream& t = tab[dev];
-  if (!t.ok) {
-    if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&t.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-    t.ok = true;
-  }
-  return &t;
-}
-static hipStream_t fork_side(hipStream_t main) {  // returns the stream the independent half should use
-  SideStream* t = g_overlap ? side_stream() : nullptr;
-  if (t == nullptr) return main;
-  (void)hipEventRecord(t->fork, main);
-  (void)hipStreamWaitEvent(t->s, t->fork, 0);
-  return t->s;
-}
-static void join_side(hipStream_t main, hipStream_t sidestream) {
-  if (sidestream == main) return;
-  SideStream* t = side_stream();
-  (void)hipEventRecord(t->join, sidestream);
-  (void)hipStreamWaitEvent(main, t->join, 0);
-}
-
 template <class P>
 struct PpoWs {
   MlpBufs<P> A, C;
   int32_t *brow, *krow;
   double* moments;
+  float* loss_tab;  // [2 Kft], Kft <= 1024
   double* loss_partial;
   float* loss_partial_cs;
 };
 template <class P>
 static size_t carve_ppo(Carver& c, const dppo_net_desc& a, const dppo_net_desc& cr, int64_t N, PpoWs<P>& W) {
   W.moments = (double*)c.take(256);
+  W.loss_tab = (float*)c.take(2 * 1024 * sizeof(float));
   W.loss_partial = (double*)c.take((size_t)loss_blocks(N) * 8 * sizeof(double));
   W.loss_partial_cs = (float*)c.take((size_t)loss_blocks(N) * 65 * sizeof(float));
   W.brow = (int32_t*)c.take((size_t)N * 4);
@@ -934,10 +940,10 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   if ((int64_t)need > wsb) return fail(-1, "workspace too small: need %zu bytes, got %lld", need, (long long)wsb);
   const PackLayout LA = pack_layout<P>(a, 0), LC = pack_layout<P>(cr, 0);
   const int Kft = pcfg.ft_denoising_steps;
-  (void)hipMemsetAsync(stats, 0, DPPO_STAT_COUNT * sizeof(double), s);
-  (void)hipMemsetAsync(W.moments, 0, 256, s);
   BuildRows br;
   memset(&br, 0, sizeof(br));
+  br.zero_a = stats, br.n_zero_a = DPPO_STAT_COUNT, br.zero_b = W.moments, br.n_zero_b = 32;  // zeroed by the row builder
+  if (Kft <= 1024) br.loss_tab = W.loss_tab, br.pcfg = pcfg;
   br.inds = inds, br.kinds = kinds, br.chains = chains_k, br.obs = obs_k, br.temb = (const float*)(ak + LA.temb);
   br.ksteps = ksteps;
   br.Kft = Kft, br.AF = a.act_flat, br.td = a.time_dim, br.cond = a.cond_dim, br.M = N;
@@ -957,16 +963,20 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   la.chains = chains_k, la.logprobs_k = logprobs_k, la.returns_k = returns_k, la.values_k = values_k, la.adv_k = adv_k;
   la.ksteps = ksteps, la.dcfg = dcfg, la.pcfg = pcfg, la.AF = a.act_flat, la.N = N;
   la.moments = gmom ? gmom : W.moments;
+  la.tab = Kft <= 1024 ? W.loss_tab : nullptr;
   la.d_eps = W.A.d_out, la.ldde = LA.Kpo, la.d_v = W.C.d_out, la.lddv = LC.Kpo, la.stats = stats;
   la.partial = W.loss_partial;
-  const bool fuse_bout = LA.Kpo == 64 && fused_ok<P>(a) && fused_ok<P>(cr);  // the fused backward skips its own colsum then
+  // Out-layer bias gradients (column sums of d_eps / d_v): the loss kernel can emit them (per-block partials, summed by
+  // loss_finalize), but both kernels sit on the critical path between forward and backward, while a column-sum pass over
+  // d_out runs beside the weight-gradient GEMMs on the tail stream for free.  Measured: finalize 21 -> 5 us.  Off.
+  const bool fuse_bout = false && LA.Kpo == 64 && fused_ok<P>(a) && fused_ok<P>(cr);
   if (fuse_bout) {
     la.partial_cs = W.loss_partial_cs, la.out_dim = a.out_dim;
     la.gb_actor = agrad + param_layout(a).bout, la.gb_critic = cgrad + param_layout(cr).bout;
   }
   launch_ppo_loss<P>(la, s);
   s2 = fork_side(s);
-  mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s2, fuse_bout);
+  mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s2, fuse_bout, 2);
   mlp_backward<P>(a, ap, ak, LA, N, W.A, agrad, W.krow, ksteps, Kft, s, fuse_bout);
   if (a.cond_hidden > 0) cond_backward<P>(a, ap, ak, LA, N, W.A, W.A.dh0_final, W.C.in, agrad, s);
   join_side(s, s2);
@@ -1057,6 +1067,10 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 5) {
     set_gemm_tn_variant(value);
+    return 0;
+  }
+  if (knob == 6) {
+    set_gemm_tn_thin(value);
     return 0;
   }
   return fail(-1, "unknown tuning knob %d", knob);

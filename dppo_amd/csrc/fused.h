@@ -82,11 +82,12 @@ struct PackLayer {
   const float* W;
   long rs, cs;
   int in_valid, KS, pos0;
+  u32x4* stream;  // destination stream and its length in k-step positions (forward and backward streams differ)
+  int total_pos;
 };
-struct PackStream {
-  PackLayer layer[1 + 2 * MAX_BLOCKS];
-  int n_layers, TPW, total_pos;
-  u32x4* stream;
+struct PackStream {  // every layer of both streams of a network: one launch
+  PackLayer layer[2 * (1 + 2 * MAX_BLOCKS)];
+  int n_layers, TPW;
 };
 template <class P>
 void launch_pack_stream(const PackStream& d, hipStream_t s);

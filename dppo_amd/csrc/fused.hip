@@ -690,7 +690,7 @@ __global__ void pack_stream_kernel(const PackStream d) {
       out[j] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
     }
   }
-  d.stream[(((size_t)w * d.total_pos + L.pos0 + ks) * TPW + tp) * 64 + lane] = (u32x4){out[0], out[1], out[2], out[3]};
+  L.stream[(((size_t)w * L.total_pos + L.pos0 + ks) * TPW + tp) * 64 + lane] = (u32x4){out[0], out[1], out[2], out[3]};
 }
 template <class P>
 void launch_pack_stream(const PackStream& d, hipStream_t s) {

@@ -43,6 +43,7 @@ struct GemmTN {
 template <class P>
 void launch_gemm_nt(const GemmNT& a, hipStream_t s);
 void set_gemm_tn_variant(int v);  // tuning knob 5
+void set_gemm_tn_thin(int v);     // tuning knob 6
 
 // Measurement hook (bench.py's roofline): while armed for a kernel id, every launch of that kernel is bracketed by
 // HIP events recorded on its launch stream.  Process-wide, not thread-safe, off by default; never armed by the

@@ -639,7 +639,9 @@ static void launch_tn_cfg(const GemmTN& a, hipStream_t s) {
   if (probe) probe_end(s, 2.0 * a.M * a.N1 * a.N2);
 }
 
-bool gemm_tn_thin(int N1, int N2) { return N2 <= 64 && N1 > 64; }
+static int g_tn_thin = 1;  // tuning knob 6: 0 = no one-tile 512 x 64 configuration for thin outputs
+void set_gemm_tn_thin(int v) { g_tn_thin = v; }
+bool gemm_tn_thin(int N1, int N2) { return g_tn_thin && N2 <= 64 && N1 > 64; }
 
 // 0 (default): register-staged kernel; 1..8: an LDS-DMA ring configuration (tools/gemm_bench.py sweeps them); -1: ring
 // variant 2 for outputs of 512 x 512 and more.  Alone on the chip the ring wins at 512 x 512 (43.8 vs 51.6 us incl. the

@@ -39,6 +39,13 @@ struct BuildRows {
   int KpC;
   int32_t* brow;  // [M]
   int32_t* krow;  // [M]
+  // side jobs of block 0 (all optional): the PPO loss's per-k table, [Kft] denoising discount then [Kft] clip range,
+  // in the reference's precision recipe (double pow / exp, then fp32), and two small double arrays to zero
+  float* loss_tab;
+  dppo_ppo_cfg pcfg;
+  double* zero_a;  // n <= 128 each; null / 0 = none
+  double* zero_b;
+  int n_zero_a, n_zero_b;
 };
 template <class P>
 void launch_build_rows(const BuildRows& a, hipStream_t s);
@@ -85,6 +92,7 @@ struct LossArgs {
   int AF;
   int64_t N;
   const double* moments;  // [3] sum(adv), sum(adv^2), count over the (global) minibatch
+  const float* tab;       // [2 Kft] per-k discount and clip range built by the row builder (null: built per block)
   void* d_eps;            // [N][ldde] elem, zero padded
   int ldde;
   void* d_v;  // [N][lddv] elem, column 0, zero padded

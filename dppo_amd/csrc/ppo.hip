@@ -77,48 +77,97 @@ void launch_time_table(const float* w1, const float* b1, const float* w2, const 
 // =================================================================================================
 // row building
 // =================================================================================================
-template <class P>
-__global__ void build_rows_kernel(const BuildRows a) {
-  typedef typename P::elem_t E;
-  const int64_t n = blockIdx.x;
-  if (n >= a.M) return;
-  int64_t b;
-  int k;
-  if (a.kinds != nullptr) {
-    b = n;
-    k = (int)a.kinds[n];
+// per-k constants of PPODiffusion.loss (only Kft distinct values exist): tab[k] = gamma_denoising^(Kft-k-1)
+// (diffusion_ppo.py:138-144), tab[Kft + k] = clip range eps_k (:151-159)
+__device__ __forceinline__ void loss_table_entry(const dppo_ppo_cfg& pc, int k, float* tab) {
+  const int Kft = pc.ft_denoising_steps;
+  tab[k] = (float)pow(pc.gamma_denoising, (double)(Kft - k - 1));
+  float ek;
+  if (Kft > 1) {
+    const float t = (float)k / (float)(Kft - 1);
+    const float num = expf((float)pc.clip_ploss_coef_rate * t) - 1.f;
+    ek = (float)pc.clip_ploss_coef_base +
+         (float)(pc.clip_ploss_coef - pc.clip_ploss_coef_base) * num / (float)(exp(pc.clip_ploss_coef_rate) - 1.0);
   } else {
-    const int64_t ind = a.inds ? a.inds[n] : n;
-    b = ind / a.Kft;
-    k = (int)(ind - b * a.Kft);
+    ek = (float)k / (float)(Kft - 1);
   }
-  if (threadIdx.x == 0) {
-    a.brow[n] = (int32_t)b;
-    a.krow[n] = k;
+  tab[Kft + k] = ek;
+}
+
+// One thread per 16-byte chunk of an output row (whole 128-byte rows per 8 lanes: coalesced stores), 256 threads per
+// block; blocks stride over the chunks of inA first, then of inC.  Block 0 also zeroes the step's accumulators
+// (zero_a, zero_b), which saves two memset packets and the pipeline bubble behind them.
+template <class P>
+__global__ __launch_bounds__(256) void build_rows_kernel(const BuildRows a) {
+  constexpr int EPC = 16 / P::ESIZE;  // elements per chunk
+  if (blockIdx.x == 0) {
+    if ((int)threadIdx.x < a.n_zero_a) a.zero_a[threadIdx.x] = 0.0;
+    if ((int)threadIdx.x >= 128 && (int)threadIdx.x - 128 < a.n_zero_b) a.zero_b[threadIdx.x - 128] = 0.0;
+    if (a.loss_tab != nullptr)
+      for (int k = threadIdx.x; k < a.pcfg.ft_denoising_steps; k += blockDim.x) loss_table_entry(a.pcfg, k, a.loss_tab);
   }
-  const int t = a.ksteps[k].t;
-  E* ia = (E*)a.inA + (size_t)n * a.KpA;
-  const float* xk = a.kinds != nullptr ? a.chains + (size_t)b * 2 * a.AF : a.chains + ((size_t)b * (a.Kft + 1) + k) * a.AF;
-  const float* ob = a.obs + (size_t)b * a.cond;
-  for (int c = threadIdx.x; c < a.KpA; c += blockDim.x) {
-    float v = 0.f;
-    if (c < a.AF)
-      v = xk[c];
-    else if (c < a.AF + a.td)
-      v = a.temb[(size_t)t * a.td + (c - a.AF)];
-    else if (c < a.AF + a.td + a.cond && a.obs_in_a)
-      v = ob[c - a.AF - a.td];
-    ia[c] = P::from_f32(v);
-  }
-  if (a.inC != nullptr) {
-    E* ic = (E*)a.inC + (size_t)n * a.KpC;
-    for (int c = threadIdx.x; c < a.KpC; c += blockDim.x) ic[c] = P::from_f32(c < a.cond ? ob[c] : 0.f);
+  const int ca = a.KpA / EPC, cc = a.inC != nullptr ? a.KpC / EPC : 0;
+  const int64_t total = a.M * (ca + cc);
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    const bool isA = q < a.M * ca;
+    const int64_t qq = isA ? q : q - a.M * ca;
+    const int cpr = isA ? ca : cc;
+    const int64_t n = qq / cpr;
+    const int c0 = (int)(qq - n * cpr) * EPC;
+    int64_t b;
+    int k;
+    if (a.kinds != nullptr) {
+      b = n;
+      k = (int)a.kinds[n];
+    } else {
+      const int64_t ind = a.inds ? a.inds[n] : n;
+      b = ind / a.Kft;
+      k = (int)(ind - b * a.Kft);
+    }
+    const float* ob = a.obs + (size_t)b * a.cond;
+    float v[EPC];
+    if (isA) {
+      if (c0 == 0) {
+        a.brow[n] = (int32_t)b;
+        a.krow[n] = k;
+      }
+      const int t = a.ksteps[k].t;
+      const float* xk = a.kinds != nullptr ? a.chains + (size_t)b * 2 * a.AF : a.chains + ((size_t)b * (a.Kft + 1) + k) * a.AF;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const int c = c0 + e;
+        float x = 0.f;
+        if (c < a.AF)
+          x = xk[c];
+        else if (c < a.AF + a.td)
+          x = a.temb[(size_t)t * a.td + (c - a.AF)];
+        else if (c < a.AF + a.td + a.cond && a.obs_in_a)
+          x = ob[c - a.AF - a.td];
+        v[e] = x;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v[e] = c0 + e < a.cond ? ob[c0 + e] : 0.f;
+    }
+    u32x4 o;
+    if constexpr (P::ESIZE == 4) {
+      o = (u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (uint32_t)f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
+    }
+    char* dst = isA ? (char*)a.inA + ((size_t)n * a.KpA + c0) * P::ESIZE : (char*)a.inC + ((size_t)n * a.KpC + c0) * P::ESIZE;
+    *(u32x4*)dst = o;
   }
 }
 template <class P>
 void launch_build_rows(const BuildRows& a, hipStream_t s) {
   if (a.M <= 0) return;
-  hipLaunchKernelGGL((build_rows_kernel<P>), dim3((unsigned)a.M), dim3(64), 0, s, a);
+  constexpr int EPC = 16 / P::ESIZE;
+  const int64_t total = a.M * (a.KpA / EPC + (a.inC != nullptr ? a.KpC / EPC : 0));
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL((build_rows_kernel<P>), dim3((unsigned)blocks), dim3(256), 0, s, a);
 }
 template void launch_build_rows<F32>(const BuildRows&, hipStream_t);
 template void launch_build_rows<BF16>(const BuildRows&, hipStream_t);
@@ -265,7 +314,7 @@ void launch_adv_moments(const float* adv_k, const int32_t* brow, int64_t N, doub
 
 // 16 lanes per sample (lane j owns chunk elements j, j+16, ...): every global access of a sample is one contiguous
 // segment; the two log-prob sums are reduced with 4 shuffles; scalar per-sample math is done redundantly by the 16 lanes
-constexpr int LOSS_PASSES = 8;  // samples per block = 16 * LOSS_PASSES
+constexpr int LOSS_PASSES = 2;  // samples per block = 16 * LOSS_PASSES: short blocks, many in flight (the gathers are latency-bound)
 
 template <class P>
 __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
@@ -276,18 +325,10 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
   extern __shared__ float tab[];  // [Kft] discount, [Kft] eps_k, [2] adv mean / std
   const dppo_ppo_cfg& pc = a.pcfg;
   const int Kft = pc.ft_denoising_steps, AF = a.AF, Da = pc.action_dim;
-  for (int k = threadIdx.x; k < Kft; k += 256) {
-    tab[k] = (float)pow(pc.gamma_denoising, (double)(Kft - k - 1));
-    float ek;
-    if (Kft > 1) {
-      const float t = (float)k / (float)(Kft - 1);
-      const float num = expf((float)pc.clip_ploss_coef_rate * t) - 1.f;
-      ek = (float)pc.clip_ploss_coef_base +
-           (float)(pc.clip_ploss_coef - pc.clip_ploss_coef_base) * num / (float)(exp(pc.clip_ploss_coef_rate) - 1.0);
-    } else {
-      ek = (float)k / (float)(Kft - 1);
-    }
-    tab[Kft + k] = ek;
+  if (a.tab != nullptr) {
+    for (int k = threadIdx.x; k < 2 * Kft; k += 256) tab[k] = a.tab[k];
+  } else {
+    for (int k = threadIdx.x; k < Kft; k += 256) loss_table_entry(pc, k, tab);
   }
   if (threadIdx.x == 0) {
     const double Nm = a.moments[2], mean = a.moments[0] / Nm;
