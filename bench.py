@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 # hopper-medium-v2 ft_ppo_diffusion_mlp (reference cfg/gym/finetune/hopper-v2/ft_ppo_diffusion_mlp.yaml)
 OBS_DIM, ACT_DIM, TA, K, KFT, ACT_STEPS = 11, 3, 4, 20, 10, 4
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md chip table
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # MI355X_MICROARCH.md chip table (dense)
 FLOP_PER_SAMPLE = 4.11e6   # actor_ft 3 x 1.103 + critic 3 x 0.268 MFLOP
 FLOP_PER_CHUNK = 22.06e6   # 20 necessary network evaluations x 1.103 MFLOP
@@ -266,6 +267,22 @@ def main():
             probe = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                      "traffic": traffic, "kernel": f"{names[args.probe]}, {args.prec}", "avg_launch_ms": avg_ms,
                      "launches": cnt.value, "algorithmic_gflop_per_launch": fl.value / cnt.value / 1e9}
+            if args.probe == 2:
+                # dW[N1 x N2] = A[M x N1]^T . B[M x N2]: algorithmic bytes = both operands once + the fp32 result.
+                # 253 (512^2) / 128 (256^2) FLOP per byte at bf16 against a machine balance of 2500 / 8 = 312: the
+                # contraction over 50,000 batch rows is HBM-bound, so that is the roof it is priced against.
+                es = 2 if args.prec == "bf16" else 4
+                shapes = [(model.actor_ft.mlp_mean.hidden, model.actor_ft.mlp_mean.n_blocks),
+                          (model.critic.Q1.hidden, model.critic.Q1.n_blocks)]
+                nbytes = sum(2 * nb * (args.batch * 2 * h * es + h * h * 4) for h, nb in shapes)
+                nlaunch = sum(2 * nb for _, nb in shapes)
+                b_per = nbytes / nlaunch
+                intensity = (fl.value / cnt.value) / b_per
+                if intensity < peak * 1e12 / (HBM_PEAK_GBS * 1e9):
+                    gbs = b_per / (avg_ms * 1e-3) / 1e9
+                    probe.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": gbs / HBM_PEAK_GBS, "algorithmic_mb_per_launch": b_per / 1e6,
+                                  "flop_per_byte": intensity, "mfma_tflops": tf, "mfma_frac": tf / peak})
     stats = model._stats.tolist()
     if rank == 0:
         ms_update = dt_update / args.steps * 1e3

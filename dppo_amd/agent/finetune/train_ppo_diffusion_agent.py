@@ -105,8 +105,8 @@ class TrainPPODiffusionAgent:
         if self.reward_scale_running:
             self.running_reward_scaler = RunningRewardScaler(self.n_envs, moments_hook=self._pool_return_moments)
         self.reward_scale_const = cfg.train.get("reward_scale_const", 1)
-        if cfg.train.get("use_bc_loss", False):
-            raise NotImplementedError("dppo_amd: use_bc_loss is not built yet")
+        self.use_bc_loss = cfg.train.get("use_bc_loss", False)
+        self.bc_loss_coeff = cfg.train.get("bc_loss_coeff", 0)
         # ---- TrainPPODiffusionAgent (:22-45)
         self.reward_horizon = cfg.get("reward_horizon", self.act_steps)
         self.learn_eta = self.model.learn_eta
@@ -265,6 +265,12 @@ class TrainPPODiffusionAgent:
                 st = model.ppo_update(obs_buf, chains_buf, ret_k, values_buf, adv_k, logp_buf, inds,
                                       reward_horizon=self.reward_horizon,
                                       global_moments=None if moments is None else moments[b])
+                if self.use_bc_loss:  # + bc_loss * bc_loss_coeff on the minibatch's observations (reference :329-357)
+                    rows = torch.div(inds, Kft, rounding_mode="floor")
+                    model.add_bc_gradient({"state": obs_buf[rows].reshape(rows.numel(), self.n_cond_step, -1)},
+                                          self.bc_loss_coeff / self.world)
+                if self.vf_coef != 1:  # loss = pg + ... + v_loss * vf_coef: the critic sees vf_coef * d v_loss
+                    model.critic.flat_grads().mul_(self.vf_coef)
                 self.dp.allreduce_grads()
                 if update_actor:
                     self.actor_optimizer.step(model.actor_ft.flat_grads(), max_norm=self.max_grad_norm)

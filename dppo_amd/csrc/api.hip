@@ -883,6 +883,75 @@ int dppo_chain_logprob(const dppo_net_desc* actor, int prec, const float* params
 #undef CALL
 }
 
+// ---- behaviour-cloning term ----------------------------------------------------------------------------
+template <class P>
+static size_t carve_bc(Carver& c, const dppo_net_desc& d, int64_t M, MlpBufs<P>& B, int32_t*& brow, int32_t*& krow) {
+  carve_mlp<P>(c, d, M, true, true, B);
+  brow = (int32_t*)c.take((size_t)M * 4);
+  krow = (int32_t*)c.take((size_t)M * 4);
+  return al256(c.off);
+}
+int64_t dppo_bc_loss_workspace_bytes(const dppo_net_desc* actor, int prec, int64_t B, int Kft) {
+  if (check_net(actor) || check_prec(prec)) return -1;
+  if (B < 1 || Kft < 1 || B * Kft > 0x7fffffff) return fail(-1, "B*Kft out of range");
+  Carver c{nullptr, 0, 0};
+  int32_t *br, *kr;
+  if (prec == DPPO_PREC_F32) {
+    MlpBufs<F32> W;
+    return (int64_t)carve_bc<F32>(c, *actor, B * Kft, W, br, kr);
+  }
+  MlpBufs<BF16> W;
+  return (int64_t)carve_bc<BF16>(c, *actor, B * Kft, W, br, kr);
+}
+template <class P>
+static int bc_impl(const dppo_net_desc& d, const float* prm, const char* pk, const dppo_diffusion_cfg& cfg,
+                   const dppo_step* ksteps, int Kft, const float* obs, const float* chains, int64_t Bn, float* grad,
+                   double* loss, void* ws, int64_t wsb, hipStream_t s) {
+  const int64_t M = Bn * Kft;
+  Carver c{(char*)ws, 0, (size_t)wsb};
+  MlpBufs<P> B;
+  int32_t *brow, *krow;
+  const size_t need = carve_bc<P>(c, d, M, B, brow, krow);
+  if ((int64_t)need > wsb) return fail(-1, "workspace too small: need %zu bytes, got %lld", need, (long long)wsb);
+  const PackLayout L = pack_layout<P>(d, 0);
+  BuildRows br;
+  memset(&br, 0, sizeof(br));
+  br.chains = chains, br.obs = obs, br.temb = (const float*)(pk + L.temb), br.ksteps = ksteps;
+  br.Kft = Kft, br.AF = d.act_flat, br.td = d.time_dim, br.cond = d.cond_dim, br.M = M, br.obs_in_a = 1;
+  br.inA = B.in, br.KpA = L.Kp0, br.brow = brow, br.krow = krow;
+  if (d.cond_hidden > 0) br.obs_in_a = 0, br.inC = B.cin, br.KpC = L.Kpc;
+  launch_build_rows<P>(br, s);
+  if (d.cond_hidden > 0) cond_encode<P>(d, prm, pk, L, M, B.cin, B, B.in, nullptr, 0, true, s);
+  mlp_forward<P>(d, prm, pk, L, M, B, true, s);
+  BcArgs ba;
+  ba.eps = B.out, ba.lde = B.ldout, ba.chains = chains, ba.ksteps = ksteps, ba.cfg = cfg, ba.Kft = Kft;
+  ba.AF = d.act_flat, ba.M = M, ba.d_eps = B.d_out, ba.ldde = L.Kpo, ba.loss = loss;
+  launch_bc_loss<P>(ba, s);
+  mlp_backward<P>(d, prm, pk, L, M, B, grad, krow, ksteps, Kft, s, false);
+  if (d.cond_hidden > 0) cond_backward<P>(d, prm, pk, L, M, B, B.dh0_final, B.cin, grad, s);
+  return check_launch();
+}
+int dppo_bc_loss_fwd_bwd(const dppo_net_desc* actor, int prec, const float* params, const void* packed,
+                         const dppo_diffusion_cfg* cfg, const dppo_step* ksteps, int Kft, const float* obs,
+                         const float* chains, int64_t B, float* grad, double* loss, void* workspace,
+                         int64_t workspace_bytes, dppo_stream_t stream) {
+  if (int e = check_net(actor)) return e;
+  if (int e = check_prec(prec)) return e;
+  if (actor->kind != 0) return fail(-1, "dppo_bc_loss_fwd_bwd needs an actor descriptor");
+  if (!params || !packed || !cfg || !ksteps || !obs || !chains || !grad || !loss || !workspace) return fail(-1, "null pointer");
+  if (B < 1 || Kft < 1 || B * Kft > 0x7fffffff) return fail(-1, "B*Kft out of range");
+#define CALL(P)                                                                                                       \
+  bc_impl<P>(*actor, params, (const char*)packed, *cfg, ksteps, Kft, obs, chains, B, grad, loss, workspace, workspace_bytes, \
+             (hipStream_t)stream)
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
+}
+int dppo_axpy(float* y, const float* x, double alpha, int64_t n, dppo_stream_t stream) {
+  if (!y || !x || n < 0) return fail(-1, "bad argument");
+  launch_axpy(y, x, (float)alpha, n, (hipStream_t)stream);
+  return check_launch();
+}
+
 // ---- GAE ---------------------------------------------------------------------------------------------
 int dppo_gae(const double* reward, const float* values, const float* terminated, const float* last_values, int n_steps,
              int n_envs, double gamma, double gae_lambda, double reward_scale_const, double* adv64, double* ret64,

@@ -72,6 +72,24 @@ struct LogprobArgs {
 };
 void launch_logprob(const LogprobArgs& a, hipStream_t s);
 
+// ---- behaviour-cloning term (diffusion_ppo.py:104-126): loss = -mean clamp(logp, -5, 2) over all (row, element);
+// d_eps [M][ldde] elem (zero padded) = d loss / d eps, loss accumulated into *loss (double, zeroed by the caller's launch)
+struct BcArgs {
+  const float* eps;  // [M][lde] network output on the base policy's chains
+  int lde;
+  const float* chains;  // [B][Kft+1][AF]
+  const dppo_step* ksteps;
+  dppo_diffusion_cfg cfg;
+  int Kft, AF;
+  int64_t M;
+  void* d_eps;
+  int ldde;
+  double* loss;
+};
+template <class P>
+void launch_bc_loss(const BcArgs& a, hipStream_t s);
+void launch_axpy(float* y, const float* x, float alpha, int64_t n, hipStream_t s);  // y += alpha * x
+
 // ---- fused PPO loss (diffusion_ppo.py:85-199) -----------------------------------------------------
 struct LossArgs {
   const float* eps;  // [N][lde] actor output

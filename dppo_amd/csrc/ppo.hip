@@ -278,6 +278,58 @@ void launch_logprob(const LogprobArgs& a, hipStream_t s) {
 }
 
 // =================================================================================================
+// behaviour-cloning term
+// =================================================================================================
+__device__ __forceinline__ double block_sum(double v, double* sh);
+
+// one thread per (row, padded column); the row's d_eps is written whole (zero padding included)
+template <class P>
+__global__ __launch_bounds__(256) void bc_loss_kernel(const BcArgs a) {
+  __shared__ double sh[4];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double part = 0.0;
+  if (i < a.M * a.ldde) {
+    const int64_t n = i / a.ldde;
+    const int j = (int)(i - n * a.ldde);
+    float g = 0.f;
+    if (j < a.AF) {
+      const int64_t b = n / a.Kft;
+      const int k = (int)(n - b * a.Kft);
+      const dppo_step st = a.ksteps[k];
+      const float* ch = a.chains + ((size_t)b * (a.Kft + 1) + k) * a.AF;
+      float mu, dmu;
+      posterior(a.cfg, st, ch[j], a.eps[(size_t)n * a.lde + j], mu, dmu);
+      const float var = st.std * st.std;
+      const float d = ch[a.AF + j] - mu;
+      const float lp = -(d * d) / (2.f * var) - logf(st.std) - DPPO_LOG_SQRT_2PI;
+      const float scale = 1.f / ((float)a.M * (float)a.AF);
+      part = -(double)fminf(fmaxf(lp, -5.f), 2.f) * (double)scale;
+      if (lp >= -5.f && lp <= 2.f) g = -scale * (d / var) * dmu;  // d(-lp)/d eps = -(d / var) * d mu / d eps
+    }
+    ((typename P::elem_t*)a.d_eps)[i] = P::from_f32(g);
+  }
+  part = block_sum(part, sh);
+  if (threadIdx.x == 0) atomicAdd(a.loss, part);
+}
+template <class P>
+void launch_bc_loss(const BcArgs& a, hipStream_t s) {
+  const int64_t n = a.M * a.ldde;
+  if (n <= 0) return;
+  (void)hipMemsetAsync(a.loss, 0, sizeof(double), s);
+  hipLaunchKernelGGL((bc_loss_kernel<P>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+}
+template void launch_bc_loss<F32>(const BcArgs&, hipStream_t);
+template void launch_bc_loss<BF16>(const BcArgs&, hipStream_t);
+
+__global__ void axpy_kernel(float* y, const float* x, float alpha, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += alpha * x[i];
+}
+void launch_axpy(float* y, const float* x, float alpha, int64_t n, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, x, alpha, n);
+}
+
+// =================================================================================================
 // fused PPO loss
 // =================================================================================================
 __device__ __forceinline__ double block_sum(double v, double* sh) {

@@ -43,6 +43,19 @@ class _FusedPPOLoss(torch.autograd.Function):
         return (None, None, None, None, *ga, *gc)
 
 
+class _FusedBCLoss(torch.autograd.Function):
+    """bc_loss with the gradient w.r.t. the actor_ft parameters precomputed by the HIP kernel."""
+
+    @staticmethod
+    def forward(ctx, value, grads, *params):
+        ctx.grads = grads
+        return value.float().clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None, *[x * g for x in ctx.grads])
+
+
 class PPODiffusion(VPGDiffusion):
     def __init__(self, gamma_denoising: float, clip_ploss_coef: float, clip_ploss_coef_base: float = 1e-3,
                  clip_ploss_coef_rate: float = 3, clip_vloss_coef: Optional[float] = None,
@@ -58,7 +71,10 @@ class PPODiffusion(VPGDiffusion):
         self.clip_advantage_lower_quantile = clip_advantage_lower_quantile
         self.clip_advantage_upper_quantile = clip_advantage_upper_quantile
         object.__setattr__(self, "_ws_ppo", hip.Workspace())
+        object.__setattr__(self, "_ws_bc", hip.Workspace())
         object.__setattr__(self, "_stats", None)
+        object.__setattr__(self, "_bc_grad", None)
+        object.__setattr__(self, "_bc_value", None)
 
     # ------------------------------------------------------------------ helpers
     def _ppo_cfg(self, reward_horizon: int, adv_gathered: Optional[torch.Tensor]) -> hip.PpoCfg:
@@ -108,12 +124,52 @@ class PPODiffusion(VPGDiffusion):
     def _eta_mean(self) -> float:
         return self._eta_value(False) if self.use_ddim else 1.0
 
+    # ------------------------------------------------------------------ behaviour-cloning term (reference :104-126)
+    def bc_loss_and_grad(self, cond, noise=None):
+        """-mean clamp(log p_ft(base policy's chains), -5, 2) and its gradient w.r.t. the flat ``actor_ft`` parameters.
+
+        Samples the chains with the base policy (``forward(use_base_policy=True)``, stochastic, as the reference) and
+        runs forward + backward of the fine-tuned network over the B*Kft rows in one library call.  Returns
+        (device float64[1], flat fp32 gradient); both buffers are reused by the next call.
+        """
+        state = cond["state"]
+        hip.require_gpu(state, "PPODiffusion.bc_loss_and_grad")
+        samples = self.forward(cond=cond, deterministic=False, return_chain=True, use_base_policy=True, noise=noise)
+        B, dev = state.shape[0], state.device
+        Kft, AF = self.ft_denoising_steps, self.horizon_steps * self.action_dim
+        net = self.actor_ft
+        lib, d = hip.load(), net.net_desc()
+        flat = net.flat_params()
+        if self._bc_grad is None or self._bc_grad.numel() != flat.numel() or self._bc_grad.device != dev:
+            object.__setattr__(self, "_bc_grad", torch.zeros_like(flat))
+            object.__setattr__(self, "_bc_value", torch.zeros(1, dtype=torch.float64, device=dev))
+        obs = state.reshape(B, -1).contiguous().float()
+        ch = samples.chains.reshape(B, Kft + 1, AF).contiguous().float()
+        ks = self._logprob_schedule(dev)
+        cfg = self.diffusion_cfg()
+        wsb = lib.dppo_bc_loss_workspace_bytes(C.byref(d), self.prec, B, Kft)
+        if wsb < 0:
+            hip.check(int(wsb), "dppo_bc_loss_workspace_bytes")
+        ws = self._ws_bc.get(wsb, dev)
+        hip.check(lib.dppo_bc_loss_fwd_bwd(
+            C.byref(d), self.prec, flat.data_ptr(), net.packed(self.prec, self.denoising_steps).data_ptr(), C.byref(cfg),
+            ks.data_ptr(), Kft, obs.data_ptr(), ch.data_ptr(), B, self._bc_grad.data_ptr(), self._bc_value.data_ptr(),
+            ws.data_ptr(), ws.numel(), hip.stream()), "dppo_bc_loss_fwd_bwd")
+        return self._bc_value, self._bc_grad
+
+    def add_bc_gradient(self, cond, coeff: float, noise=None):
+        """actor_ft.flat_grads() += coeff * d bc_loss / d theta (the ``bc_loss * bc_loss_coeff`` term of the agent's loss,
+        train_ppo_diffusion_agent.py:351-357); returns the device bc_loss."""
+        value, grad = self.bc_loss_and_grad(cond, noise)
+        ga = self.actor_ft.flat_grads()
+        hip.check(hip.load().dppo_axpy(ga.data_ptr(), grad.data_ptr(), float(coeff), ga.numel(), hip.stream()),
+                  "dppo_axpy")
+        return value
+
     # ------------------------------------------------------------------ drop-in loss (reference :57-199)
     def loss(self, obs, chains_prev, chains_next, denoising_inds, returns, oldvalues, advantages, oldlogprobs,
              use_bc_loss=False, reward_horizon=4):
         """Same arguments / 8-tuple as the reference.  pg_loss and v_loss carry grad."""
-        if use_bc_loss:
-            raise NotImplementedError("dppo_amd: use_bc_loss=True is not built yet (SURVEY.md 8f)")
         state = obs["state"]
         hip.require_gpu(state, "PPODiffusion.loss")
         N = state.shape[0]
@@ -133,8 +189,16 @@ class PPODiffusion(VPGDiffusion):
         host = stats.tolist()  # one D2H sync, like the reference's .item() calls
         eta = self._eta_mean()
         entropy_loss = torch.tensor(-eta, device=state.device)
+        bc_loss = 0
+        if use_bc_loss:  # reference :104-126
+            value, grad = self.bc_loss_and_grad(obs)
+            views, off = [], 0
+            for p in a_params:
+                views.append(grad[off:off + p.numel()].view(p.shape).clone())
+                off += p.numel()
+            bc_loss = _FusedBCLoss.apply(value[0], views, *a_params)
         return (pg_loss, entropy_loss, v_loss, host[hip.STAT_CLIPFRAC], host[hip.STAT_APPROX_KL],
-                host[hip.STAT_RATIO], 0, eta)
+                host[hip.STAT_RATIO], bc_loss, eta)
 
     # ------------------------------------------------------------------ fused-gather fast path
     def ppo_update(self, obs_k, chains_k, returns_k, values_k, adv_k, logprobs_k, inds, reward_horizon=4,

@@ -230,3 +230,47 @@ class VPGDiffusion(DiffusionModel):
                 (B * Kft, 1, 1), self._eta_value(False), device=dev)
             return out, eta
         return out
+
+    @torch.no_grad()
+    def get_logprobs_subsample(self, cond, chains_prev, chains_next, denoising_inds, get_ent: bool = False,
+                               use_base_policy: bool = False):
+        """log N(chains_next; mu(chains_prev, t_k, s), sigma_k) for one random denoising step per sample, (B,Ta,Da)
+        (reference diffusion_vpg.py:398-461; k = denoising_inds[b] indexes the chain position like there).
+
+        Inference only: inside ``PPODiffusion.loss`` the same evaluation runs fused and differentiable.  Here the
+        samples are grouped by k and each group goes through the chain kernel as a one-step chain.
+        """
+        state = cond["state"]
+        hip.require_gpu(state, "VPGDiffusion.get_logprobs_subsample")
+        B, dev = chains_prev.shape[0], chains_prev.device
+        AF = self.horizon_steps * self.action_dim
+        net = self.actor if use_base_policy else self.actor_ft
+        lib, d = hip.load(), net.net_desc()
+        obs = state.reshape(B, -1).contiguous().float()
+        pairs = torch.stack([chains_prev.reshape(B, AF), chains_next.reshape(B, AF)], dim=1).contiguous().float()
+        kinds = denoising_inds.reshape(B).to(torch.long)
+        ks = self._logprob_schedule(dev)
+        step_bytes = hip.STEP_DTYPE.itemsize
+        cfg = self.diffusion_cfg()
+        out = torch.empty((B, AF), device=dev, dtype=torch.float32)
+        packed = net.packed(self.prec, self.denoising_steps)
+        for k in torch.unique(kinds).tolist():
+            rows = torch.nonzero(kinds == k).reshape(-1)
+            n = rows.numel()
+            ob, ch = obs[rows].contiguous(), pairs[rows].contiguous()
+            lp = torch.empty((n, AF), device=dev, dtype=torch.float32)
+            ks_k = ks[k * step_bytes:(k + 1) * step_bytes].contiguous()
+            wsb = lib.dppo_chain_logprob_workspace_bytes(C.byref(d), self.prec, n, 1)
+            ws = self._ws_logprob.get(wsb, dev)
+            hip.check(lib.dppo_chain_logprob(
+                C.byref(d), self.prec, net.flat_params().data_ptr(), packed.data_ptr(), C.byref(cfg), ks_k.data_ptr(), 1,
+                ob.data_ptr(), ch.data_ptr(), n, lp.data_ptr(), ws.data_ptr(), ws.numel(), hip.stream()),
+                "dppo_chain_logprob")
+            out[rows] = lp
+        out = out.view(B, self.horizon_steps, self.action_dim)
+        if get_ent:
+            eta = torch.full_like(out, 1.0) if not self.use_ddim else torch.full(
+                (B, 1, 1), self._eta_value(False), device=dev)
+            return out, eta
+        return out
+

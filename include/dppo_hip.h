@@ -162,6 +162,19 @@ int dppo_chain_logprob(const dppo_net_desc* actor, int prec, const float* params
                        const float* chains, int64_t B, float* logprobs, void* workspace,
                        int64_t workspace_bytes, dppo_stream_t stream);
 
+/* ---- A9(3): behaviour-cloning term of PPODiffusion.loss (diffusion_ppo.py:104-126) ----------- */
+/* chains (B,Kft+1,Ta*Da): sampled by the caller with the BASE policy (dppo_sample_chain, base weights on both
+ * network slots).  Evaluates the fine-tuned network (params / packed) on them, writes
+ *   loss[0] = -mean over (b, k, Ta, Da) of clamp(log N(x_{k+1}; mu(x_k, t_k, s_b), sigma_k), -5, 2)   (double, device)
+ * and grad (dppo_net_param_count floats, overwritten) = d loss / d params.  dppo_axpy adds it to the PPO gradient
+ * with the caller's bc_loss_coeff (train_ppo_diffusion_agent.py:351-357). */
+int64_t dppo_bc_loss_workspace_bytes(const dppo_net_desc* actor, int prec, int64_t B, int Kft);
+int dppo_bc_loss_fwd_bwd(const dppo_net_desc* actor, int prec, const float* params, const void* packed,
+                         const dppo_diffusion_cfg* cfg, const dppo_step* ksteps, int Kft, const float* obs,
+                         const float* chains, int64_t B, float* grad, double* loss, void* workspace,
+                         int64_t workspace_bytes, dppo_stream_t stream);
+int dppo_axpy(float* y, const float* x, double alpha, int64_t n, dppo_stream_t stream); /* y += alpha * x */
+
 /* ---- A10: GAE (agent/finetune/train_ppo_diffusion_agent.py:255-279) ----------------------- */
 /* reward (S,E) float64 (already scaled by the host-side running scaler), values (S,E) fp32,
  * terminated (S,E) fp32 0/1, last_values (E,) fp32.  Float64 arithmetic like the reference's numpy

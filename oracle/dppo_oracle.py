@@ -542,6 +542,18 @@ def clip_coef_schedule(cfg: DiffusionCfg, denoising_inds: torch.Tensor) -> torch
         return denoising_inds.float() / (Kft - 1)
 
 
+def bc_loss(cfg: DiffusionCfg, spec: NetSpec, base: Params, ft: Params, state: torch.Tensor,
+            noise: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The behaviour-cloning term of PPODiffusion.loss, diffusion_ppo.py:104-126: sample chains with the BASE
+    policy (use_base_policy=True, stochastic), score them under the fine-tuned policy, clamp to [-5, 2], mean over
+    (Ta, Da) then over the B*Kft rows, negate.  Returns (bc_loss carrying grad w.r.t. ``ft``, base chains)."""
+    with torch.no_grad():
+        _, chains = sample_chain(cfg, spec, base, ft, state, noise, deterministic=False, use_base_policy=True)
+    lp = chain_logprob(cfg, spec, base, ft, state, chains, use_base_policy=False)
+    lp = lp.clamp(min=-5, max=2).mean(dim=(-1, -2)).view(-1)
+    return -lp.mean(), chains
+
+
 def ppo_loss(cfg: DiffusionCfg, aspec: NetSpec, cspec: NetSpec, base: Params, ft: Params, critic: Params,
              obs: torch.Tensor, chains_prev: torch.Tensor, chains_next: torch.Tensor,
              denoising_inds: torch.Tensor, returns: torch.Tensor, oldvalues: torch.Tensor,

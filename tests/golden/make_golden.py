@@ -253,6 +253,48 @@ def g5_loss():
     save("g5_loss", **out)
 
 
+# ---------------------------------------------------------------- G8 behaviour-cloning term of the loss
+BC_CASES = {
+    "bc_ddpm": ("hopper", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01)),
+    "bc_ddim_kitchen": ("kitchen_like", dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
+                                            clip_ploss_coef=0.01, min_sampling_denoising_std=0.08)),
+}
+
+
+def g8_bc():
+    out = {}
+    rs = np.random.RandomState(800)
+    N = 16
+    for cname, (sname, kw) in BC_CASES.items():
+        a, c = specs(sname)
+        if kw.get("use_ddim"):
+            kw = dict(kw, eta=EtaFixed(base_eta=1.0))
+        m = ref_model(a, c, 41, gamma_denoising=0.99, randn_clip_value=3, **kw)
+        Kft = kw["ft_denoising_steps"]
+        n_steps = kw["ddim_steps"] if kw.get("use_ddim") else kw["denoising_steps"]
+        state = torch.from_numpy(rs.uniform(-1, 1, size=(N, 1, a.cond_dim)).astype(np.float32))
+        noise = torch.from_numpy(rs.randn(n_steps + 1, N, a.horizon_steps, a.action_dim).astype(np.float32))
+        with recorded_noise(list(noise)):
+            base_chains = m(cond={"state": state}, deterministic=False, return_chain=True, use_base_policy=True).chains
+        # the PPO inputs only have to be valid: the recorded outputs are the BC term and its gradient alone
+        kinds = torch.from_numpy(rs.randint(0, Kft, size=(N,)).astype(np.int64))
+        rows = torch.arange(N)
+        prev, nxt = base_chains[rows, kinds], base_chains[rows, kinds + 1]
+        oldlp = torch.from_numpy(rs.normal(-1, 0.5, size=(N, a.horizon_steps, a.action_dim)).astype(np.float32))
+        ret = torch.from_numpy(rs.normal(0, 1, N).astype(np.float32))
+        adv = torch.from_numpy(rs.normal(0.3, 2.0, N).astype(np.float32))
+        with recorded_noise(list(noise)):
+            res = m.loss({"state": state}, prev, nxt, kinds, ret, ret.clone(), adv, oldlp, use_bc_loss=True,
+                         reward_horizon=4)
+        bc = res[6]
+        bc.backward()
+        out.update({f"{cname}_state": state, f"{cname}_noise": noise, f"{cname}_base_chains": base_chains,
+                    f"{cname}_bc_loss": np.float64(bc.item())})
+        for k, p in m.actor_ft.named_parameters():
+            put_grad(out, f"{cname}_gbc_{k}", p.grad)
+    save("g8_bc", **out)
+
+
 # ---------------------------------------------------------------- G6 reward scaler (GAE loop is not importable)
 def g6_reward_scaler():
     rs = np.random.RandomState(400)
@@ -292,9 +334,7 @@ def g7_adamw():
 
 
 if __name__ == "__main__":
-    g1_tables()
-    g2_forward()
-    g3_g4_chains()
-    g5_loss()
-    g6_reward_scaler()
-    g7_adamw()
+    only = sys.argv[1:]  # e.g. `make_golden.py g8_bc` regenerates one file (each generator owns its RNG stream)
+    for fn in (g1_tables, g2_forward, g3_g4_chains, g5_loss, g6_reward_scaler, g7_adamw, g8_bc):
+        if not only or fn.__name__ in only:
+            fn()

@@ -8,6 +8,9 @@ Tolerances (stated per SURVEY.md 8c):
                    mean error <= 0.06; loss parity is checked as bitwise self-consistency (ratio == 1) and
                    gradient direction vs the fp32 path (cosine >= 0.99).
 """
+import math
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -265,6 +268,73 @@ def test_adamw_and_clip_match_torch(golden):
     FlatAdamW(q1, lr=1e-2, weight_decay=0.0).step(T(g["clip_in"]).to(DEV), max_norm=1.5)
     FlatAdamW(q2, lr=1e-2, weight_decay=0.0).step(T(g["clip_out"]).to(DEV))
     np.testing.assert_allclose(q1.cpu().numpy(), q2.cpu().numpy(), rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("case", ["ddim100_5", "ddpm20_ft10"])
+def test_logprob_subsample_matches_chain_logprobs(golden, case):
+    """get_logprobs_subsample (reference diffusion_vpg.py:398-461) == the matching entries of get_logprobs and of the
+    reference's golden log-probs."""
+    g = golden("g3_chains")
+    sname, kw, _ = CHAIN_CASES[case]
+    m, a, _ = build_model(sname, kw, 21, "fp32")
+    state = T(g[f"{case}_state"]).to(DEV)
+    chains = T(g[f"{case}_chains"]).to(DEV)
+    B, Kft = chains.shape[0], m.ft_denoising_steps
+    full = m.get_logprobs({"state": state}, chains).reshape(B, Kft, a.horizon_steps, a.action_dim)
+    kinds = torch.tensor([(3 * i + 1) % Kft for i in range(B)], device=DEV)
+    rows = torch.arange(B, device=DEV)
+    sub = m.get_logprobs_subsample({"state": state}, chains[rows, kinds], chains[rows, kinds + 1], kinds)
+    np.testing.assert_allclose(sub.cpu().numpy(), full[rows, kinds].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    ref = g[f"{case}_logprobs"].reshape(B, Kft, a.horizon_steps, a.action_dim)[rows.cpu().numpy(), kinds.cpu().numpy()]
+    sel = ref > -50
+    np.testing.assert_allclose(sub.cpu().numpy()[sel], ref[sel], rtol=2e-4, atol=2e-4)
+
+
+# ------------------------------------------------------------------ G8 behaviour-cloning term
+@pytest.mark.parametrize("case", ["bc_ddpm", "bc_ddim_kitchen"])
+def test_bc_loss_and_gradient(golden, case):
+    """PPODiffusion.loss(use_bc_loss=True)'s BC term (reference diffusion_ppo.py:104-126): value and gradient against
+    the reference's golden vectors on the recorded noise (fp32 path), and the autograd hand-off of loss()."""
+    from tests.test_oracle_golden import BC_CASES, check_grad
+    g = golden("g8_bc")
+    sname, kw = BC_CASES[case]
+    m, a, _ = build_model(sname, dict(kw, clip_ploss_coef=0.01), 41, "fp32")
+    state, noise = T(g[f"{case}_state"]).to(DEV), T(g[f"{case}_noise"]).to(DEV)
+    value, grad = m.bc_loss_and_grad({"state": state}, noise=noise)
+    assert float(value.item()) == pytest.approx(float(g[f"{case}_bc_loss"]), rel=2e-4, abs=1e-5)
+    off = 0
+    for k, p in m.actor_ft.named_parameters():
+        check_grad(g, f"{case}_gbc_{k}", grad[off:off + p.numel()].view(p.shape).cpu(), 2e-3, 2e-6)
+        off += p.numel()
+    # accumulation into the PPO gradient
+    ga = m.actor_ft.flat_grads()
+    ga.fill_(1.0)
+    m.add_bc_gradient({"state": state}, 0.5, noise=noise)
+    np.testing.assert_allclose(ga.cpu().numpy(), 1.0 + 0.5 * grad.cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_loss_with_bc_term_hands_gradients_to_autograd():
+    m, a, c = build_model("hopper", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01,
+                                         randn_clip_value=3), 5, "fp32")
+    N, Kft = 32, 10
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    state = (torch.rand(N, 1, a.cond_dim, generator=gen) * 2 - 1).to(DEV)
+    chains = m(cond={"state": state}).chains
+    kinds = torch.randint(0, Kft, (N,), generator=gen).to(DEV)
+    rows = torch.arange(N, device=DEV)
+    oldlp = m.get_logprobs_subsample({"state": state}, chains[rows, kinds], chains[rows, kinds + 1], kinds)
+    ret, adv = torch.randn(N, generator=gen).to(DEV), torch.randn(N, generator=gen).to(DEV)
+    torch.manual_seed(11)
+    res = m.loss({"state": state}, chains[rows, kinds], chains[rows, kinds + 1], kinds, ret, ret.clone(), adv, oldlp,
+                 use_bc_loss=True, reward_horizon=4)
+    pg, vl, bc = res[0], res[2], res[6]
+    assert torch.is_tensor(bc) and bc.requires_grad and math.isfinite(float(bc.detach())) and -2 <= float(bc.detach()) <= 5
+    for p in m.actor_ft.parameters():
+        p.grad = None
+    (pg + 0.5 * vl + 0.25 * bc).backward()
+    g_all = torch.cat([p.grad.reshape(-1) for p in m.actor_ft.parameters()])
+    expect = m.actor_ft.flat_grads() + 0.25 * m._bc_grad
+    np.testing.assert_allclose(g_all.cpu().numpy(), expect.cpu().numpy(), rtol=1e-6, atol=1e-8)
 
 
 # ------------------------------------------------------------------ fused row-tile kernels vs layered GEMM chain

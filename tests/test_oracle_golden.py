@@ -228,3 +228,28 @@ def test_adamw_and_clip(golden):
     tot = O.clip_grad_norm([gr], 1.5)
     assert tot == pytest.approx(float(g["clip_total"]), rel=1e-6)
     close(gr, g["clip_out"], rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------ G8 behaviour-cloning term
+BC_CASES = {
+    "bc_ddpm": ("hopper", dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3)),
+    "bc_ddim_kitchen": ("kitchen_like", dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
+                                            randn_clip_value=3, min_sampling_denoising_std=0.08)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(BC_CASES))
+def test_bc_loss_matches_reference(golden, case):
+    g = golden("g8_bc")
+    sname, kw = BC_CASES[case]
+    a, _ = O.named_specs(sname)
+    cfg = make_cfg(a, kw)
+    base = O.init_params(a, 41)
+    ft = {k: v.clone().requires_grad_(True) for k, v in O.init_params(a, 42).items()}
+    bc, chains = O.bc_loss(cfg, a, base, ft, T(g[f"{case}_state"]), T(g[f"{case}_noise"]))
+    np.testing.assert_allclose(chains.numpy(), g[f"{case}_base_chains"], rtol=1e-5, atol=1e-5)
+    assert float(bc.detach()) == pytest.approx(float(g[f"{case}_bc_loss"]), rel=1e-5, abs=1e-6)
+    bc.backward()
+    for k, v in ft.items():
+        check_grad(g, f"{case}_gbc_{k}", v.grad if v.grad is not None else torch.zeros_like(v), 2e-4, 1e-7)
+
