@@ -248,7 +248,17 @@ def main():
         return dt
 
     dt_sample = timed(sample_step, probe=(rank == 0 and args.probe == 5))
-    dt_update = timed(update_step, probe=(rank == 0 and args.probe != 5))
+    dt_update = timed(update_step)
+    # Roofline pass: the same K update steps once more with the library's side streams off (knob 2 = 0).  In the timed
+    # region above the critic half and the gradient tails run beside the probed kernel, so an event-bracketed launch
+    # duration there includes its co-runners' share of the chip; serial, it is the kernel's own (rocprofv3 on
+    # `bench.py --tune 2=0` reports the same average).  `value` always comes from the default (overlapped) pass.
+    dt_serial = None
+    if args.probe != 5:
+        overlap = next((int(kv.split("=")[1]) for kv in args.tune if kv.split("=")[0] == "2"), 1)
+        hip.check(lib.dppo_tune_set(2, 0), "dppo_tune_set")
+        dt_serial = timed(update_step, probe=(rank == 0))
+        hip.check(lib.dppo_tune_set(2, overlap), "dppo_tune_set")
     probe = None
     if rank == 0:
         ms, cnt, fl = C.c_double(), C.c_int(), C.c_double()
@@ -266,7 +276,11 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             probe = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                      "traffic": traffic, "kernel": f"{names[args.probe]}, {args.prec}", "avg_launch_ms": avg_ms,
-                     "launches": cnt.value, "algorithmic_gflop_per_launch": fl.value / cnt.value / 1e9}
+                     "launches": cnt.value, "algorithmic_gflop_per_launch": fl.value / cnt.value / 1e9,
+                     "measured": "HIP events around every launch of the kernel" + (
+                         "" if dt_serial is None else
+                         f", in a second pass of the same {args.steps} steps with side streams off "
+                         f"({dt_serial / args.steps * 1e3:.3f} ms per step)")}
             if args.probe == 2:
                 # dW[N1 x N2] = A[M x N1]^T . B[M x N2]: algorithmic bytes = both operands once + the fp32 result.
                 # 253 (512^2) / 128 (256^2) FLOP per byte at bf16 against a machine balance of 2500 / 8 = 312: the

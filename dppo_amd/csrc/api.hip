@@ -323,7 +323,7 @@ static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, b
     }
     const int mt = fused_rows_per_tile<P>(d);
     B.tiles = mt > 0 ? (int)((M + mt - 1) / mt) : 0;
-    B.tile_colsum = (float*)c.take((size_t)(2 * nb + 1 + (d.use_layernorm ? 4 * nb : 0)) * (B.tiles > 0 ? B.tiles : 1) * H * 4);
+    B.tile_colsum = (float*)c.take((size_t)(2 * nb + 2 + (d.use_layernorm ? 4 * nb : 0)) * (B.tiles > 0 ? B.tiles : 1) * H * 4);
     const int tdp = round_up(d.time_dim > 0 ? d.time_dim : 1, 16);
     B.dtemb = d.kind == 0 ? (float*)c.take((size_t)M * tdp * 4) : nullptr;
     // largest slab: H x max(H, Kp0) with up to 64 splits of a <=4-tile output, or 16+ splits of H x H
@@ -553,6 +553,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
     const FusedGeom fg = fused_geom<P>(d);
     f.bstream = (const u32x4*)(pk + L.bstream), f.d_out = B.d_out, f.ld_dout = L.Kpo, f.M = (int)M, f.KpB0 = fg.KpB0;
     f.nb = nb, f.act = d.act, f.colsum = B.tile_colsum, f.out_valid = d.out_dim;
+    f.dout_slot = bout_done ? -1 : 2 * nb + 1 + (d.use_layernorm ? 4 * nb : 0);
     const bool post = d.act == DPPO_ACT_RELU && !d.use_layernorm;  // ReLU': the activated copy suffices
     f.params = prm, f.use_ln = d.use_layernorm, f.ln_stats = B.ln_stats;
     if (d.use_layernorm) fill_ln_off(d, pl, f.ln_off);
@@ -582,11 +583,12 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
         }
         so.n_slots += 4 * nb;
       }
+      for (int i = 0; i < so.n_slots; ++i) so.n[i] = H;
+      if (!bout_done) so.out[so.n_slots] = grad + pl.bout, so.n[so.n_slots] = d.out_dim, ++so.n_slots;  // the d_out slot
       // the latency-bound tail (bias sums, time-embedding gradient; they share B.part) runs beside the weight-gradient
       // GEMMs (which share B.slab and stay in order on s)
       hipStream_t aux = fork_side(s, aux_idx);
       launch_reduce_slots(B.tile_colsum, B.tiles, H, so, aux);
-      if (!bout_done) launch_colsum<P>(B.d_out, (int)M, d.out_dim, L.Kpo, B.part, REDUCE_BLOCKS, grad + pl.bout, 1.f, aux);
       if (d.kind == 0) time_embedding_grad<P>(d, prm, pk, L, M, B, B.dh_all[0], grad, krow, ksteps, Kft, aux);
       weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.hE, H, H, M, B, grad + pl.Wout, H, s);
       for (int b = nb - 1; b >= 0; --b) {

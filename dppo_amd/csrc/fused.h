@@ -65,8 +65,10 @@ struct FusedBwdArgs {
   void* dh[MAX_BLOCKS + 1];  // dh[b] = d loss / d h_b  (dh[nb] = d_out . Wout)
   void* dz1[MAX_BLOCKS];
   // per-tile column sums: [slots][tiles][H] f32.  Slots 0..nb: dh[nb..0]; nb+1..2nb: dz1[nb-1..0] (bias gradients);
-  // with LayerNorm 4 more per block, top block first: d gamma1, d beta1, d gamma2, d beta2
+  // with LayerNorm 4 more per block, top block first: d gamma1, d beta1, d gamma2, d beta2; then, when dout_slot >= 0,
+  // one slot with the column sums of d_out itself (the out-layer bias gradient; first KpB0 columns of the slot)
   float* colsum;
+  int dout_slot;
 };
 
 template <class P>
@@ -94,7 +96,8 @@ void launch_pack_stream(const PackStream& d, hipStream_t s);
 
 // out[slot][c] = sum_t in[slot][t][c]  for c < n, one launch for all slots (bias gradients from per-tile column sums)
 struct SlotOuts {
-  float* out[6 * MAX_BLOCKS + 1];
+  float* out[6 * MAX_BLOCKS + 2];
+  int n[6 * MAX_BLOCKS + 2];  // columns of each slot that are written (<= the slot width)
   int n_slots;
 };
 void launch_reduce_slots(const float* in, int tiles, int n, const SlotOuts& o, hipStream_t s);

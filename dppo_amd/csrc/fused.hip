@@ -449,6 +449,14 @@ __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs 
     const int row0 = tile * MT;
     load_tile<MT>(xin, in_rb, in_km, (const char*)a.d_out, a.ld_dout * ES, row0, M);
     __syncthreads();
+    if (a.dout_slot >= 0 && tid < a.KpB0) {  // out-layer bias gradient: column sums of the d_out tile (rows past M are zero)
+      typedef typename P::elem_t E;
+      float t = 0.f;
+      const int cb = tid * ES;
+      for (int row = 0; row < MT; ++row)
+        t += P::to_f32(*(const E*)(xin + row * in_rb + ((((cb >> 4) ^ (row & in_km)) << 4) | (cb & 15))));
+      a.colsum[((size_t)a.dout_slot * ntiles + tile) * H + tid] = t;
+    }
     f32x4 dh[TPW][MR], acc[TPW][MR];
     auto zero_acc = [&]() {
 #pragma unroll
@@ -722,7 +730,7 @@ __global__ __launch_bounds__(1024) void reduce_slots_kernel(const float* in, int
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += red[i][cl];
-    o.out[blockIdx.y][c] = s;
+    if (c < o.n[blockIdx.y]) o.out[blockIdx.y][c] = s;
   }
 }
 void launch_reduce_slots(const float* in, int tiles, int n, const SlotOuts& o, hipStream_t s) {
