@@ -460,6 +460,7 @@ static void join_side(hipStream_t main, hipStream_t sidestream, int idx = 0) {
   (void)hipStreamWaitEvent(main, t->join, 0);
 }
 
+static int g_dbg = 0;  // tuning knob 8: timing experiments on the fused backward (results are wrong while it is set)
 static int g_tn_target = 512;      // tuning knob 3: workgroups a weight-gradient GEMM aims for (tiles x row splits)
 static int g_tn_max_splits = 128;  // tuning knob 4: cap on its row splits (each split costs one fp32 slab of the output)
 // gw[N1][N2] (ld ldgw) = A[M][N1]^T . B[M][N2].  A thin N1 (the out layer) is computed transposed, B^T . A, so that the
@@ -563,6 +564,10 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       f.dz1[b] = B.dz1_all[b];
     }
     for (int b = 0; b <= nb; ++b) f.dh[b] = B.dh_all[b];
+    if (g_dbg & 1)  // timing experiment: no gradient stores (the weight-gradient GEMMs then read stale buffers)
+      for (int b = 0; b <= nb; ++b) f.dh[b] = nullptr, f.dz1[b < nb ? b : 0] = nullptr;
+    if (g_dbg & 2)  // timing experiment: no derivative-source fetch
+      for (int b = 0; b < nb; ++b) f.m1[b] = f.m0[b] = nullptr;
     g_fused_fault = launch_fused_backward<P>(d, f, s);
     if (g_fused_fault != 0) return;
     {
@@ -1142,6 +1147,14 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 6) {
     set_gemm_tn_thin(value);
+    return 0;
+  }
+  if (knob == 7) {
+    set_fused_short_tiles(value);
+    return 0;
+  }
+  if (knob == 8) {
+    g_dbg = value;
     return 0;
   }
   return fail(-1, "unknown tuning knob %d", knob);

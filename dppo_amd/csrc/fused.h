@@ -69,12 +69,14 @@ struct FusedBwdArgs {
   // one slot with the column sums of d_out itself (the out-layer bias gradient; first KpB0 columns of the slot)
   float* colsum;
   int dout_slot;
+  int dbg;  // timing experiments only (tuning knob 8): bit 1 = do not fetch the derivative sources (wrong results)
 };
 
 template <class P>
 int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStream_t s);   // <0: shape not covered
 template <class P>
 int launch_fused_backward(const dppo_net_desc& d, const FusedBwdArgs& a, hipStream_t s);
+void set_fused_short_tiles(int v);  // tuning knob 7
 template <class P>
 int fused_rows_per_tile(const dppo_net_desc& d);  // rows per tile of the BACKWARD kernel (sizes the per-tile column sums), 0 if not covered
 

@@ -5,6 +5,10 @@
 #include "gemm.h"
 #include "tile_ln.h"
 
+#ifndef DPPO_BWD_LATE
+#define DPPO_BWD_LATE 1
+#endif
+
 namespace dppo {
 
 // Phase stamps (debug build only: DPPO_STAMPS=1 build.sh -> libdppo_hip_stamps.so, tools/fused_bench.py --stamps):
@@ -166,6 +170,13 @@ __device__ __forceinline__ void fetch(u32x4 (&d)[MR][CH], const void* glb, int H
                                       int M) {
   constexpr int ES = P::ESIZE, TPC = ES == 4 ? 1 : 2;  // MFMA tiles per 16-byte chunk
   asm volatile("" : "+v"(r), "+v"(g));  // see emit()
+  if (glb == nullptr) {  // (timing experiments only)
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) d[m][c] = (u32x4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
     const int grow = row0 + 16 * m + r;
@@ -193,9 +204,12 @@ __device__ __forceinline__ float grad_at(const u32x4 (&d)[MR][CH], int tp, int m
 // =================================================================================================
 // forward
 // =================================================================================================
-template <class P, int TPW, int MR, int OT, bool LN, int ACT>
-__global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a) {
-  constexpr int PD = ring_depth<TPW, MR>(), ES = P::ESIZE, KB = P::KB;
+template <class P, int TPW, int MR, int OT, bool LN, int ACT, int OCC>
+__global__ __launch_bounds__(512, 2 * OCC) void fused_forward_kernel(const FusedFwdArgs a) {
+  // (HIP: the second launch bound is waves per SIMD: 2 per workgroup of 8 waves)
+  // OCC = 2: two workgroups per CU (128 VGPRs each): a shallower ring, the other workgroup's MFMAs fill this one's
+  // emit / barrier phases
+  constexpr int PD = OCC > 1 ? 2 : ring_depth<TPW, MR>(), ES = P::ESIZE, KB = P::KB;
   constexpr int H = 128 * TPW, KSH = H / KB, HRB = H * ES, MT = 16 * MR;
   constexpr int KSPLIT = MR * OT >= 8 ? 1 : 8 / (MR * OT);
   constexpr int KPER = KSH / KSPLIT;
@@ -379,9 +393,13 @@ __global__ __launch_bounds__(512) void fused_forward_kernel(const FusedFwdArgs a
 // =================================================================================================
 // backward (data gradients + column sums)
 // =================================================================================================
-template <class P, int TPW, int MR, bool LN, int ACT>
-__global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs a) {
-  constexpr int PD = 2, ES = P::ESIZE, KB = P::KB;
+template <class P, int TPW, int MR, bool LN, int ACT, int OCC>
+__global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const FusedBwdArgs a) {
+  constexpr int ES = P::ESIZE, KB = P::KB;
+  // derivative sources are fetched AFTER the layer's k-loop where the registers are needed for a 4-deep ring instead
+  // (16 accumulator tiles per wave), or cannot be carried at all (two workgroups per CU)
+  constexpr bool FETCH_LATE = OCC > 1 || (DPPO_BWD_LATE && TPW * MR >= 16 && ES == 2 && !LN);
+  constexpr int PD = (FETCH_LATE && OCC == 1) ? 4 : 2;
   constexpr int H = 128 * TPW, KSH = H / KB, HRB = H * ES, MT = 16 * MR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -394,6 +412,8 @@ __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs 
   char* bufB = bufA + MT * HRB;
   char* xin = bufB;  // d_out tile: consumed by the first layer, which emits into bufA
   float* lnred = (float*)(bufB + MT * HRB);  // [8 waves][2][MR][16] LayerNorm row-reduction table (LN only)
+  constexpr int DRED_COLS = 128;             // d_out is at most 128 columns wide
+  float* dred = lnred + (LN ? LN_WAVES * 2 * MR * 16 : 0);  // [8 waves][128] column sums of the d_out tile
   const int wbase = wid * 16 * TPW;  // lane features: wbase + feat_off<P>(g, tp) + e
   const int ntiles = (M + MT - 1) / MT;
 
@@ -447,15 +467,19 @@ __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs 
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int row0 = tile * MT;
+    STAMP(16);
     load_tile<MT>(xin, in_rb, in_km, (const char*)a.d_out, a.ld_dout * ES, row0, M);
     __syncthreads();
-    if (a.dout_slot >= 0 && tid < a.KpB0) {  // out-layer bias gradient: column sums of the d_out tile (rows past M are zero)
-      typedef typename P::elem_t E;
-      float t = 0.f;
-      const int cb = tid * ES;
-      for (int row = 0; row < MT; ++row)
-        t += P::to_f32(*(const E*)(xin + row * in_rb + ((((cb >> 4) ^ (row & in_km)) << 4) | (cb & 15))));
-      a.colsum[((size_t)a.dout_slot * ntiles + tile) * H + tid] = t;
+    STAMP(17);
+    if (a.dout_slot >= 0) {  // out-layer bias gradient: column sums of the d_out tile (rows past M are zero), part 1:
+      typedef typename P::elem_t E;  // wave w adds rows w, w + 8, ...; lane = column
+      for (int c = lane; c < a.KpB0; c += 64) {
+        const int cb = c * ES;
+        float t = 0.f;
+        for (int row = wid; row < MT; row += SAMPLER_WAVES)
+          t += P::to_f32(*(const E*)(xin + row * in_rb + ((((cb >> 4) ^ (row & in_km)) << 4) | (cb & 15))));
+        dred[wid * DRED_COLS + c] = t;
+      }
     }
     f32x4 dh[TPW][MR], acc[TPW][MR];
     auto zero_acc = [&]() {
@@ -467,19 +491,33 @@ __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs 
     // ---- dh[nb] = d_out . Wout
     zero_acc();
     eng.run(acc, xin, in_rb, in_km, KSB0, r, g);
+    STAMP(18);
 #pragma unroll
     for (int tp = 0; tp < TPW; ++tp)
 #pragma unroll
       for (int m = 0; m < MR; ++m) dh[tp][m] = acc[tp][m];
     emit<P, TPW, MR>(dh, ACT_NONE, bufA, a.dh[nb], H, wbase, g, r, row0, M);
+    STAMP(19);
     colsum(dh, 0, tile);
+    STAMP(20);
     __syncthreads();
+    STAMP(21);
+    if (a.dout_slot >= 0 && tid < a.KpB0) {  // part 2: the eight waves' partial sums
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < SAMPLER_WAVES; ++w) t += dred[w * DRED_COLS + tid];
+      a.colsum[((size_t)a.dout_slot * ntiles + tile) * H + tid] = t;
+    }
     for (int b = nb - 1; b >= 0; --b) {
       // ---- dz1 = (dh . W2) * act'(z1)       [LayerNorm: back through act(LN2(z1))]
       u32x4 d[MR][Chunks<P, TPW>::CH];
-      fetch<P>(d, a.m1[b], H, wbase, g, r, row0, M);  // issued ahead of the layer: latency hides under it
+      // derivative sources: issued ahead of the layer so the latency hides under it -- except at two workgroups per CU,
+      // where 128 VGPRs cannot carry them through the k-loop and the other workgroup hides the latency instead
+      if constexpr (!FETCH_LATE) fetch<P>(d, a.m1[b], H, wbase, g, r, row0, M);
       zero_acc();
       eng.run(acc, bufA, HRB, 15, KSH, r, g);
+      if constexpr (FETCH_LATE) fetch<P>(d, a.m1[b], H, wbase, g, r, row0, M);
+      STAMP(22);
       if constexpr (LN) {
         float mean[MR], rstd[MR];
         f32x4 dga[TPW], dbe[TPW];
@@ -498,12 +536,17 @@ __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs 
             for (int e = 0; e < 4; ++e) acc[tp][m][e] *= grad_at<P, ACT>(d, tp, m, e);
       }
       emit<P, TPW, MR>(acc, ACT_NONE, bufB, a.dz1[b], H, wbase, g, r, row0, M);
+      STAMP(23);
       colsum(acc, (nb + 1) + (nb - 1 - b), tile);
+      STAMP(24);
       __syncthreads();
+      STAMP(25);
       // ---- dh[b] = dh[b+1] + (dz1 . W1) * act'(h_b)       [LayerNorm: back through act(LN1(h_b))]
-      fetch<P>(d, a.m0[b], H, wbase, g, r, row0, M);
+      if constexpr (!FETCH_LATE) fetch<P>(d, a.m0[b], H, wbase, g, r, row0, M);
       zero_acc();
       eng.run(acc, bufB, HRB, 15, KSH, r, g);
+      if constexpr (FETCH_LATE) fetch<P>(d, a.m0[b], H, wbase, g, r, row0, M);
+      STAMP(26);
       if constexpr (LN) {
         float mean[MR], rstd[MR];
         f32x4 dga[TPW], dbe[TPW];
@@ -526,8 +569,11 @@ __global__ __launch_bounds__(512) void fused_backward_kernel(const FusedBwdArgs 
             for (int e = 0; e < 4; ++e) dh[tp][m][e] += acc[tp][m][e] * grad_at<P, ACT>(d, tp, m, e);
       }
       emit<P, TPW, MR>(dh, ACT_NONE, bufA, a.dh[b], H, wbase, g, r, row0, M);
+      STAMP(27);
       colsum(dh, nb - b, tile);
+      STAMP(28);
       __syncthreads();
+      STAMP(29);
     }
   }
 }
@@ -541,6 +587,13 @@ extern "C" int dppo_debug_stamps(unsigned long long* out) {  // out: [8 waves][3
 // =================================================================================================
 // host side
 // =================================================================================================
+// tuning knob 7: short tiles at two workgroups per CU (bf16, H = 512, no LayerNorm): bit 0 backward, bit 1 forward
+static int g_short_tiles = 0;
+void set_fused_short_tiles(int v) { g_short_tiles = v; }
+template <class P>
+static bool short_tiles(int hidden, int ln, int bit) {
+  return P::ESIZE == 2 && hidden == 512 && !ln && ((g_short_tiles >> bit) & 1);
+}
 template <class P>
 static int pick_mr(int hidden) {
   const int tpw = hidden / 128;
@@ -554,6 +607,7 @@ static int pick_mr(int hidden) {
 // (and once more with LayerNorm, whose backward keeps two more row-statistics / gradient sets live)
 template <class P>
 static int pick_mr_bwd(int hidden, int ln) {
+  if (short_tiles<P>(hidden, ln, 0)) return 2;
   int mr = pick_mr<P>(hidden);
   if (hidden >= 1024 && mr > 1) mr /= 2;
   if (P::ESIZE == 2 && hidden == 256) mr /= 2;  // 8 row sub-tiles of dh, acc, derivative chunks and B fragments do not fit 256 VGPRs
@@ -590,25 +644,26 @@ static void raise_lds(K kern, bool& done) {
   }
 }
 
-template <class P, int TPW, int MR, int OT, bool LN, int ACT>
+template <class P, int TPW, int MR, int OT, bool LN, int ACT, int OCC = 1>
 static int launch_fwd_cfg(const FusedFwdArgs& a, hipStream_t s) {
   constexpr int ES = P::ESIZE, MT = 16 * MR, H = 128 * TPW;
   size_t lds = 2 * (size_t)MT * H * ES + (LN ? (size_t)LN_WAVES * MR * 16 * 4 : 0);
-  if (lds > 160 * 1024 || a.Kp0 > H) return -2;
+  constexpr size_t cap = 160 * 1024 / OCC;  // OCC workgroups share a CU's LDS
+  if (lds > cap || a.Kp0 > H) return -2;
   FusedFwdArgs b = a;  // constants staged in LDS as far as it reaches: biases first, then the out-layer fragments
   const size_t bias_bytes = ((size_t)((1 + 2 * a.nb) * H + OT * 16 + 3) & ~(size_t)3) * 4;
   const size_t wout_bytes = (size_t)(H / P::KB) * OT * 64 * 16;
   b.consts_lds = 0;
-  if (lds + bias_bytes <= 160 * 1024) {
+  if (lds + bias_bytes <= cap) {
     b.consts_lds |= 1, lds += bias_bytes;
-    if (lds + wout_bytes <= 160 * 1024) b.consts_lds |= 2, lds += wout_bytes;
+    if (lds + wout_bytes <= cap) b.consts_lds |= 2, lds += wout_bytes;
   }
   static bool attr = false;
-  raise_lds(fused_forward_kernel<P, TPW, MR, OT, LN, ACT>, attr);
+  raise_lds(fused_forward_kernel<P, TPW, MR, OT, LN, ACT, OCC>, attr);
   const int ntiles = (a.M + MT - 1) / MT;
   const bool probe = probe_begin(PROBE_FUSED_FWD, s);
-  hipLaunchKernelGGL((fused_forward_kernel<P, TPW, MR, OT, LN, ACT>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512), lds, s,
-                     b);
+  hipLaunchKernelGGL((fused_forward_kernel<P, TPW, MR, OT, LN, ACT, OCC>),
+                     dim3(ntiles < NUM_CUS * OCC ? ntiles : NUM_CUS * OCC), dim3(512), lds, s, b);
   if (probe) probe_end(s, 2.0 * a.M * ((double)a.in_valid * H + 2.0 * a.nb * H * H + (double)H * a.out_dim));
   return 0;
 }
@@ -619,6 +674,10 @@ int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStrea
   const int nt = (d.out_dim + 15) / 16, ot = nt <= 1 ? 1 : (nt <= 4 ? 4 : (nt <= 8 ? 8 : 0));
   if (mr == 0 || ot == 0 || a.M <= 0) return -1;
   const bool relu = a.act == ACT_RELU;  // check_net admits ReLU and Mish only
+  if constexpr (P::ESIZE == 2) {
+    if (short_tiles<P>(d.hidden, a.use_ln, 1) && ot == 1)
+      return relu ? launch_fwd_cfg<P, 4, 2, 1, false, ACT_RELU, 2>(a, s) : launch_fwd_cfg<P, 4, 2, 1, false, ACT_MISH, 2>(a, s);
+  }
 #define DPPO_FWD(T, R, O) \
   if (tpw == T && mr == R && ot == O)                                                                                  \
     return a.use_ln ? (relu ? launch_fwd_cfg<P, T, R, O, true, ACT_RELU>(a, s) : launch_fwd_cfg<P, T, R, O, true, ACT_MISH>(a, s)) \
@@ -636,16 +695,17 @@ int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStrea
 template int launch_fused_forward<F32>(const dppo_net_desc&, const FusedFwdArgs&, hipStream_t);
 template int launch_fused_forward<BF16>(const dppo_net_desc&, const FusedFwdArgs&, hipStream_t);
 
-template <class P, int TPW, int MR, bool LN, int ACT>
+template <class P, int TPW, int MR, bool LN, int ACT, int OCC = 1>
 static int launch_bwd_cfg(const FusedBwdArgs& a, hipStream_t s) {
   constexpr int ES = P::ESIZE, MT = 16 * MR, H = 128 * TPW;
-  const size_t lds = 2 * (size_t)MT * H * ES + (LN ? (size_t)LN_WAVES * 2 * MR * 16 * 4 : 0);
-  if (lds > 160 * 1024 || a.KpB0 > H) return -2;
+  const size_t lds = 2 * (size_t)MT * H * ES + (LN ? (size_t)LN_WAVES * 2 * MR * 16 * 4 : 0) + SAMPLER_WAVES * 128 * 4;
+  if (lds > 160 * 1024 / OCC || a.KpB0 > H || a.KpB0 > 128) return -2;
   static bool attr = false;
-  raise_lds(fused_backward_kernel<P, TPW, MR, LN, ACT>, attr);
+  raise_lds(fused_backward_kernel<P, TPW, MR, LN, ACT, OCC>, attr);
   const int ntiles = (a.M + MT - 1) / MT;
   const bool probe = probe_begin(PROBE_FUSED_BWD, s);
-  hipLaunchKernelGGL((fused_backward_kernel<P, TPW, MR, LN, ACT>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((fused_backward_kernel<P, TPW, MR, LN, ACT, OCC>), dim3(ntiles < NUM_CUS * OCC ? ntiles : NUM_CUS * OCC),
+                     dim3(512), lds, s, a);
   if (probe) probe_end(s, 2.0 * a.M * ((double)a.out_valid * H + 2.0 * a.nb * H * H));
   return 0;
 }
@@ -655,6 +715,10 @@ int launch_fused_backward(const dppo_net_desc& d, const FusedBwdArgs& a, hipStre
   const int tpw = d.hidden / 128, mr = pick_mr_bwd<P>(d.hidden, a.use_ln);
   if (mr == 0 || a.M <= 0) return -1;
   const bool relu = a.act == ACT_RELU;
+  if constexpr (P::ESIZE == 2) {
+    if (short_tiles<P>(d.hidden, a.use_ln, 0))
+      return relu ? launch_bwd_cfg<P, 4, 2, false, ACT_RELU, 2>(a, s) : launch_bwd_cfg<P, 4, 2, false, ACT_MISH, 2>(a, s);
+  }
 #define DPPO_BWD(T, R, L) \
   if (tpw == T && mr == R && (a.use_ln != 0) == L) \
     return relu ? launch_bwd_cfg<P, T, R, L, ACT_RELU>(a, s) : launch_bwd_cfg<P, T, R, L, ACT_MISH>(a, s);

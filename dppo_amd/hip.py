@@ -103,6 +103,10 @@ def load() -> C.CDLL:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
             fn.restype, fn.argtypes = res, args
+        for kv in filter(None, os.environ.get("DPPO_TUNE", "").split(",")):  # e.g. DPPO_TUNE=2=0,7=1 (dppo_tune_set knobs)
+            k, v = kv.split("=")
+            if lib.dppo_tune_set(int(k), int(v)) != 0:
+                raise DppoHipError(f"DPPO_TUNE: bad knob {kv!r}: {lib.dppo_last_error().decode()}")
         _lib = lib
     return _lib
 

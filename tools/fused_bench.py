@@ -68,13 +68,18 @@ def main():
         raw = C.CDLL(hip.LIB_PATH)
         raw.dppo_debug_stamps.argtypes = [C.c_void_p]
         assert raw.dppo_debug_stamps(buf.ctypes.data) == 0
-        t = buf[:, :15].astype(np.int64)
-        t0 = t[:, 0].min()
-        names = ["start", "tile loaded", "L0 run", "L0 emit", "barrier", "l1 run", "l1 emit", "barrier", "l2 run",
-                 "l2 emit", "barrier", "out layer", "barrier", "reduce+store", "barrier"]
-        print(f"--- {title}: cycles since tile start, per wave (workgroup 0, its 2nd tile; last block only)")
-        for i, n in enumerate(names):
-            print(f"{n:14s} " + " ".join(f"{int(v - t0):7d}" for v in t[:, i]))
+        fwd = ["start", "tile loaded", "L0 run", "L0 emit", "barrier", "l1 run", "l1 emit", "barrier", "l2 run",
+               "l2 emit", "barrier", "out layer", "barrier", "reduce+store", "barrier"]
+        bwd = ["start", "tile loaded", "dh run", "dh emit", "dh colsum", "barrier", "W2T run", "x act' + emit",
+               "dz1 colsum", "barrier", "W1T run", "x act' + emit", "dh colsum", "barrier"]
+        for label, first, names in (("forward kernel", 0, fwd), ("backward kernel", 16, bwd)):
+            t = buf[:, first:first + len(names)].astype(np.int64)
+            if t.max() == 0:
+                continue
+            t0 = t[:, 0].min()
+            print(f"--- {title}, {label}: cycles since tile start, per wave (workgroup 0, its 2nd tile; last block only)")
+            for i, n in enumerate(names):
+                print(f"{n:14s} " + " ".join(f"{int(v - t0):7d}" for v in t[:, i]))
 
     lib.dppo_tune_set(2, 0)
     rows = R * KFT
