@@ -149,6 +149,9 @@ __device__ __forceinline__ void emit(const f32x4 (&v)[TPW][MR], int actk, char* 
         if (lp) *(u32x4*)(lp + ((c ^ (r & 15)) << 4)) = o;
         if (gp) *(u32x4*)(gp + c * 16) = o;
         if (dp) *(u32x4*)(dp + c * 16) = od;
+        // one chunk at a time: interleaving the exp / rcp chains of all 16 chunks keeps their temporaries live at once,
+        // on top of the accumulators, the residual stream and the weight ring
+        if constexpr (ACT == ACT_MISH) __builtin_amdgcn_sched_barrier(0);
       }
     }
     };
