@@ -268,7 +268,9 @@ struct MlpBufs {  // activations of one network for M rows
   const void* dh0_final;         // where the last backward left d loss / d h_0
   float* tile_colsum;            // [(2nb+1)][tiles][H]
   int tiles;
-  float* slab;  // split-M partial weight gradients
+  float* slab;  // split-M partial weight gradients: a pool, one sub-slab per pending weight-gradient GEMM
+  size_t slab_used;   // floats handed out since the last flush
+  SlabJobs slab_jobs; // reductions pending on the pool (flush_slabs)
   float* part;  // column-sum / segment-sum partials
   size_t slab_floats, part_floats;
 };
@@ -329,10 +331,11 @@ static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, b
     // largest slab: H x max(H, Kp0) with up to 64 splits of a <=4-tile output, or 16+ splits of H x H
     const size_t tiles_hh = (size_t)((H + 127) / 128) * ((H + 127) / 128);
     size_t splits_hh = (512 + tiles_hh - 1) / tiles_hh;
-    B.slab_floats = splits_hh * (size_t)H * H;
     const size_t alt = (size_t)128 * H * (size_t)(Kp0 > 128 ? Kp0 : 128);  // thin outputs, up to 128 splits
-    if (alt > B.slab_floats) B.slab_floats = alt;
+    // a pool for all of one backward's GEMMs (2 per block + first and out layer), reduced together at the end
+    B.slab_floats = (size_t)2 * (nb > 0 ? nb : 1) * splits_hh * (size_t)H * H + 2 * alt;
     B.slab = (float*)c.take(B.slab_floats * 4);
+    B.slab_used = 0, B.slab_jobs.n = 0;
     B.part_floats = (size_t)REDUCE_BLOCKS * (H > 1024 ? H : 1024);
     B.part = (float*)c.take(B.part_floats * 4);
   }
@@ -463,11 +466,16 @@ static void join_side(hipStream_t main, hipStream_t sidestream, int idx = 0) {
 static int g_dbg = 0;  // tuning knob 8: timing experiments on the fused backward (results are wrong while it is set)
 static int g_tn_target = 512;      // tuning knob 3: workgroups a weight-gradient GEMM aims for (tiles x row splits)
 static int g_tn_max_splits = 128;  // tuning knob 4: cap on its row splits (each split costs one fp32 slab of the output)
+template <class P>
+static void flush_slabs(MlpBufs<P>& B, hipStream_t s) {
+  launch_slab_reduce_batch(B.slab_jobs, s);
+  B.slab_jobs.n = 0, B.slab_used = 0;
+}
 // gw[N1][N2] (ld ldgw) = A[M][N1]^T . B[M][N2].  A thin N1 (the out layer) is computed transposed, B^T . A, so that the
 // 512 x 64 block shape of gemm_tn covers it in one output tile; the slab reduce transposes back.
 template <class P>
 static void weight_grad(const void* A, int lda, int N1, const void* Bm, int ldb, int N2, int64_t M, MlpBufs<P>& B,
-                        float* gw, int ldgw, hipStream_t s) {
+                        float* gw, int ldgw, hipStream_t s, bool defer = false) {
   const bool swap = N1 <= 64 && N2 > 64;
   if (swap) {
     const void* tp = A;
@@ -482,6 +490,7 @@ static void weight_grad(const void* A, int lda, int N1, const void* Bm, int ldb,
   const int64_t max_splits = (M + 63) / 64;
   if (splits > max_splits) splits = max_splits;
   if (splits > g_tn_max_splits) splits = g_tn_max_splits;
+  if ((size_t)splits * N1 * N2 > B.slab_floats - B.slab_used || B.slab_jobs.n == MAX_SLAB_JOBS) flush_slabs(B, s);
   while (splits > 1 && (size_t)splits * N1 * N2 > B.slab_floats) --splits;
   if (splits >= 8) splits = splits / 8 * 8;  // a multiple of the XCD count keeps one split's tiles on one XCD
   int64_t rps = (M + splits - 1) / splits;
@@ -490,9 +499,13 @@ static void weight_grad(const void* A, int lda, int N1, const void* Bm, int ldb,
   if (need < splits) splits = need >= 8 ? (need + 7) / 8 * 8 : need;  // surplus splits see no rows and store zeros
   GemmTN t;
   t.A = A, t.B = Bm, t.M = (int)M, t.N1 = N1, t.N2 = N2, t.lda = lda, t.ldb = ldb;
-  t.slab = B.slab, t.ldc = N2, t.splits = (int)splits, t.rows_per_split = (int)rps;
+  float* sub = B.slab + B.slab_used;
+  B.slab_used += (size_t)splits * N1 * N2;
+  t.slab = sub, t.ldc = N2, t.splits = (int)splits, t.rows_per_split = (int)rps;
   launch_gemm_tn<P>(t, s);
-  launch_slab_reduce_2d(B.slab, (int)splits, N1, N2, N2, gw, ldgw, 1.f, s, swap ? 1 : 0);
+  SlabJob& j = B.slab_jobs.j[B.slab_jobs.n++];
+  j.slab = sub, j.out = gw, j.splits = (int)splits, j.rows = N1, j.cols = N2, j.lds = N2, j.ldo = ldgw, j.transpose = swap ? 1 : 0;
+  if (!defer) flush_slabs(B, s);  // deferred: the caller flushes once after its last GEMM (same stream)
 }
 
 // d temb = dh0 . W0[:, temb columns]; summed per fine-tuned step; back through the tiny time MLP
@@ -595,12 +608,13 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       hipStream_t aux = fork_side(s, aux_idx);
       launch_reduce_slots(B.tile_colsum, B.tiles, H, so, aux);
       if (d.kind == 0) time_embedding_grad<P>(d, prm, pk, L, M, B, B.dh_all[0], grad, krow, ksteps, Kft, aux);
-      weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.hE, H, H, M, B, grad + pl.Wout, H, s);
+      weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.hE, H, H, M, B, grad + pl.Wout, H, s, true);
       for (int b = nb - 1; b >= 0; --b) {
-        weight_grad<P>(B.dh_all[b + 1], H, H, B.a2[b], H, H, M, B, grad + pl.l2w[b], H, s);
-        weight_grad<P>(B.dz1_all[b], H, H, B.a1[b], H, H, M, B, grad + pl.l1w[b], H, s);
+        weight_grad<P>(B.dh_all[b + 1], H, H, B.a2[b], H, H, M, B, grad + pl.l2w[b], H, s, true);
+        weight_grad<P>(B.dz1_all[b], H, H, B.a1[b], H, H, M, B, grad + pl.l1w[b], H, s, true);
       }
-      weight_grad<P>(B.dh_all[0], H, H, B.in, L.Kp0, d.in_dim, M, B, grad + pl.W0, d.in_dim, s);
+      weight_grad<P>(B.dh_all[0], H, H, B.in, L.Kp0, d.in_dim, M, B, grad + pl.W0, d.in_dim, s, true);
+      flush_slabs(B, s);  // every slab of this backward in one reduction launch
       join_side(s, aux, aux_idx);
       B.dh0_final = B.dh_all[0];
       return;

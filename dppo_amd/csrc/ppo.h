@@ -138,6 +138,19 @@ void launch_time_backward(const float* w1, const float* b1, const float* w2, con
                           int Kft, int td, float* gw1, float* gb1, float* gw2, float* gb2, hipStream_t s);
 
 // out[r][c] (ldo) = scale * sum_s slab[s][r][c] (lds) for r < rows, c < cols ; transpose: out[c][r] instead
+// several split-M slabs summed in ONE launch (blockIdx.y = job): the weight-gradient GEMMs of a network each write their
+// own slab, and their reductions -- latency-bound alone -- run together after the last GEMM
+struct SlabJob {
+  const float* slab;  // [splits][rows][lds]
+  float* out;         // [rows][ldo], or its transpose when `transpose`
+  int splits, rows, cols, lds, ldo, transpose;
+};
+constexpr int MAX_SLAB_JOBS = 24;
+struct SlabJobs {
+  SlabJob j[MAX_SLAB_JOBS];
+  int n;
+};
+void launch_slab_reduce_batch(const SlabJobs& jobs, hipStream_t s);
 void launch_slab_reduce_2d(const float* slab, int splits, int rows, int cols, int lds, float* out, int ldo,
                            float scale, hipStream_t s, int transpose = 0);
 

@@ -706,6 +706,36 @@ void launch_slab_reduce_2d(const float* slab, int splits, int rows, int cols, in
                      cols, lds, out, ldo, scale, transpose);
 }
 
+__global__ __launch_bounds__(256) void slab_reduce_batch_kernel(const SlabJobs jobs) {
+  const SlabJob J = jobs.j[blockIdx.y];
+  const size_t n = (size_t)J.rows * J.cols;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / J.cols), c = (int)(i % J.cols);
+    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // same summation tree as slab_reduce_2d_kernel
+    int k = 0;
+    for (; k + 8 <= J.splits; k += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p[u] += J.slab[((size_t)(k + u) * J.rows + r) * J.lds + c];
+    }
+    for (; k < J.splits; ++k) p[k & 7] += J.slab[((size_t)k * J.rows + r) * J.lds + c];
+    const float v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    if (J.transpose)
+      J.out[(size_t)c * J.ldo + r] = v;
+    else
+      J.out[(size_t)r * J.ldo + c] = v;
+  }
+}
+void launch_slab_reduce_batch(const SlabJobs& jobs, hipStream_t s) {
+  if (jobs.n <= 0) return;
+  size_t most = 0;
+  for (int i = 0; i < jobs.n; ++i) {
+    const size_t n = (size_t)jobs.j[i].rows * jobs.j[i].cols;
+    most = n > most ? n : most;
+  }
+  if (most == 0) return;
+  hipLaunchKernelGGL(slab_reduce_batch_kernel, dim3((unsigned)((most + 255) / 256), jobs.n), dim3(256), 0, s, jobs);
+}
+
 // =================================================================================================
 // GAE: one thread per env, float64 reverse scan (train_ppo_diffusion_agent.py:255-279)
 // =================================================================================================
