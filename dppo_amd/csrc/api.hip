@@ -388,8 +388,8 @@ static void mlp_forward(const dppo_net_desc& d, const float* prm, const char* pk
     if (keep) {
       for (int b = 0; b < nb; ++b) {
         f.a1[b] = B.a1[b], f.a2[b] = B.a2[b];
-        // Mish' needs the pre-activations; LayerNorm's backward needs its inputs
-        if (d.act != DPPO_ACT_RELU || d.use_layernorm) f.z1[b] = B.z1[b], f.hpre[b] = B.hpre[b];
+        // derivative sources: Mish' itself, ReLU sign words, or (LayerNorm) the pre-LayerNorm tensors
+        f.z1[b] = B.z1[b], f.hpre[b] = B.hpre[b];
       }
       f.hpre[nb] = B.hE;
       f.ln_stats = d.use_layernorm ? B.ln_stats : nullptr;
@@ -568,7 +568,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
     f.bstream = (const u32x4*)(pk + L.bstream), f.d_out = B.d_out, f.ld_dout = L.Kpo, f.M = (int)M, f.KpB0 = fg.KpB0;
     f.nb = nb, f.act = d.act, f.colsum = B.tile_colsum, f.out_valid = d.out_dim;
     f.dout_slot = bout_done ? -1 : 2 * nb + 1 + (d.use_layernorm ? 4 * nb : 0);
-    const bool post = d.act == DPPO_ACT_RELU && !d.use_layernorm;  // ReLU': the activated copy suffices
+    const bool post = false;  // the forward left the derivative sources in z1 / hpre (see emit())
     f.params = prm, f.use_ln = d.use_layernorm, f.ln_stats = B.ln_stats;
     if (d.use_layernorm) fill_ln_off(d, pl, f.ln_off);
     for (int b = 0; b < nb; ++b) {

@@ -96,11 +96,15 @@ struct Engine {
   }
 };
 
+// ReLU'(x) of a lane's 4*TPW features of one row is a bit mask: the forward stores it as one 32-bit word per (row, wave,
+// lane group g) -- [M][SIGN_WORDS] -- and the backward reads 128 bytes per row instead of the whole activated tensor.
+constexpr int SIGN_WORDS = 32;  // 8 waves x 4 lane groups
+
 // v[tp][m] (features fb + 4tp + e of row 16m + r) -> activated elem chunks, written to the LDS image `lds`
-// (may be null) and to the global [M][H] tensor `glb` (may be null).  `dglb` (may be null, Mish only): a second global
-// [M][H] tensor that receives act'(v) -- the backward then multiplies by it instead of recomputing the derivative from the
-// pre-activation (value and derivative share one exp and one reciprocal here; a separate Mish' pass made the 128-row
-// critic tile VALU-bound).
+// (may be null) and to the global [M][H] tensor `glb` (may be null).  `dglb` (may be null): the derivative source for the
+// backward -- Mish: a second [M][H] tensor that receives act'(v), so the backward multiplies by it instead of recomputing the
+// derivative from the pre-activation (value and derivative share one exp and one reciprocal here; a separate Mish' pass
+// made the 128-row critic tile VALU-bound); ReLU: the [M][SIGN_WORDS] sign-bit words.
 template <class P, int TPW, int MR>
 __device__ __forceinline__ void emit(const f32x4 (&v)[TPW][MR], int actk, char* lds, void* glb, int H, int wbase, int g,
                                      int r, int row0, int M, void* dglb = nullptr) {
@@ -113,12 +117,14 @@ __device__ __forceinline__ void emit(const f32x4 (&v)[TPW][MR], int actk, char* 
     constexpr int ACT = decltype(tag)::value;
     auto body = [&](auto grad_tag) {  // resolved once per call, never per element
     constexpr bool with_grad = decltype(grad_tag)::value;
+    constexpr bool with_mask = with_grad && ACT == ACT_RELU;  // ReLU: the derivative is one bit, see sign_mask_at()
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
       const int grow = row0 + 16 * m + r;
       const bool live = grow < M;
       char* gp = glb != nullptr && live ? (char*)glb + (size_t)grow * HRB : nullptr;
-      char* dp = with_grad && live ? (char*)dglb + (size_t)grow * HRB : nullptr;
+      char* dp = with_grad && !with_mask && live ? (char*)dglb + (size_t)grow * HRB : nullptr;
+      uint32_t bits = 0;
       char* lp = lds != nullptr ? lds + (16 * m + r) * HRB : nullptr;
       constexpr int TPC = ES == 4 ? 1 : 2;  // MFMA tiles per 16-byte chunk
 #pragma unroll
@@ -127,6 +133,7 @@ __device__ __forceinline__ void emit(const f32x4 (&v)[TPW][MR], int actk, char* 
 #pragma unroll
         for (int q = 0; q < 4 * TPC; ++q) {
           const float x = v[tp + q / 4][m][q % 4];
+          if constexpr (with_mask) bits |= (x > 0.f ? 1u : 0u) << (4 * tp + q);
           if constexpr (ACT == ACT_MISH && with_grad) {
             mish_both(x, av[q], dv[q]);
           } else {
@@ -153,9 +160,12 @@ __device__ __forceinline__ void emit(const f32x4 (&v)[TPW][MR], int actk, char* 
         // on top of the accumulators, the residual stream and the weight ring
         if constexpr (ACT == ACT_MISH) __builtin_amdgcn_sched_barrier(0);
       }
+      if constexpr (with_mask) {
+        if (live) ((uint32_t*)dglb)[(size_t)grow * SIGN_WORDS + (wbase / (16 * TPW)) * 4 + g] = bits;
+      }
     }
     };
-    if (ACT == ACT_MISH && dglb != nullptr)
+    if ((ACT == ACT_MISH || ACT == ACT_RELU) && dglb != nullptr)
       body(std::true_type{});
     else
       body(std::false_type{});
@@ -168,11 +178,21 @@ template <class P, int TPW>
 struct Chunks {
   static constexpr int CH = P::ESIZE == 4 ? TPW : TPW / 2;
 };
-template <class P, int MR, int CH>
+template <class P, bool MASK, int TPW, int MR, int CH>
 __device__ __forceinline__ void fetch(u32x4 (&d)[MR][CH], const void* glb, int H, int wbase, int g, int r, int row0,
                                       int M) {
   constexpr int ES = P::ESIZE, TPC = ES == 4 ? 1 : 2;  // MFMA tiles per 16-byte chunk
   asm volatile("" : "+v"(r), "+v"(g));  // see emit()
+  if constexpr (MASK) {  // ReLU sign words written by emit()
+    if (glb != nullptr) {
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        const int grow = row0 + 16 * m + r;
+        d[m][0][0] = ((const uint32_t*)glb)[(size_t)(grow < M ? grow : M - 1) * SIGN_WORDS + (wbase / (16 * TPW)) * 4 + g];
+      }
+      return;
+    }
+  }
   if (glb == nullptr) {  // (timing experiments only)
 #pragma unroll
     for (int m = 0; m < MR; ++m)
@@ -188,9 +208,10 @@ __device__ __forceinline__ void fetch(u32x4 (&d)[MR][CH], const void* glb, int H
     for (int c = 0; c < CH; ++c) d[m][c] = *(const u32x4*)(gp + (size_t)(wbase + feat_off<P>(g, c * TPC)) * ES);
   }
 }
-// ReLU: d holds the activated copy (a > 0 <=> x > 0); Mish: d holds act'(x) itself, stored by the forward's emit()
+// ReLU: d[m][0][0] holds the lane's sign bits; Mish: d holds act'(x) itself; both stored by the forward's emit()
 template <class P, int ACT, int MR, int CH>
 __device__ __forceinline__ float grad_at(const u32x4 (&d)[MR][CH], int tp, int m, int e) {
+  if constexpr (ACT == ACT_RELU) return (d[m][0][0] >> (4 * tp + e)) & 1u ? 1.f : 0.f;
   float x;
   if constexpr (P::ESIZE == 4) {
     x = __uint_as_float(d[m][tp][e]);
@@ -516,10 +537,10 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
       u32x4 d[MR][Chunks<P, TPW>::CH];
       // derivative sources: issued ahead of the layer so the latency hides under it -- except at two workgroups per CU,
       // where 128 VGPRs cannot carry them through the k-loop and the other workgroup hides the latency instead
-      if constexpr (!FETCH_LATE) fetch<P>(d, a.m1[b], H, wbase, g, r, row0, M);
+      if constexpr (!FETCH_LATE) fetch<P, ACT == ACT_RELU && !LN, TPW>(d, a.m1[b], H, wbase, g, r, row0, M);
       zero_acc();
       eng.run(acc, bufA, HRB, 15, KSH, r, g);
-      if constexpr (FETCH_LATE) fetch<P>(d, a.m1[b], H, wbase, g, r, row0, M);
+      if constexpr (FETCH_LATE) fetch<P, ACT == ACT_RELU && !LN, TPW>(d, a.m1[b], H, wbase, g, r, row0, M);
       STAMP(22);
       if constexpr (LN) {
         float mean[MR], rstd[MR];
@@ -545,10 +566,10 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
       __syncthreads();
       STAMP(25);
       // ---- dh[b] = dh[b+1] + (dz1 . W1) * act'(h_b)       [LayerNorm: back through act(LN1(h_b))]
-      if constexpr (!FETCH_LATE) fetch<P>(d, a.m0[b], H, wbase, g, r, row0, M);
+      if constexpr (!FETCH_LATE) fetch<P, ACT == ACT_RELU && !LN, TPW>(d, a.m0[b], H, wbase, g, r, row0, M);
       zero_acc();
       eng.run(acc, bufB, HRB, 15, KSH, r, g);
-      if constexpr (FETCH_LATE) fetch<P>(d, a.m0[b], H, wbase, g, r, row0, M);
+      if constexpr (FETCH_LATE) fetch<P, ACT == ACT_RELU && !LN, TPW>(d, a.m0[b], H, wbase, g, r, row0, M);
       STAMP(26);
       if constexpr (LN) {
         float mean[MR], rstd[MR];
