@@ -189,7 +189,7 @@ def main():
     torch.cuda.set_device(device)
     from dppo_amd import hip
     from dppo_amd.parallel import DataParallel
-    from dppo_amd.util.optim import FlatAdamW
+    from dppo_amd.util.optim import FlatAdamW, step_and_repack
     lib = hip.load()
     for kv in args.tune:
         k, v = kv.split("=")
@@ -219,13 +219,8 @@ def main():
         model.ppo_update(obs_k, chains_k, ret_k, val_k, adv_k, logp_k, minibatches[i], reward_horizon=ACT_STEPS,
                          global_moments=None if moments is None else moments[i])
         dp.allreduce_grads()  # one RCCL all-reduce of [actor grads | critic grads | stats]; no-op when world == 1
-        opt_a.step(model.actor_ft.flat_grads())
-        opt_c.step(model.critic.flat_grads())
-        model.actor_ft.mark_updated()
-        model.critic.mark_updated()
-        # re-pack so the next sampling / update call sees the new weights (part of the step's cost)
-        model.actor_ft.packed(model.prec, K)
-        model.critic.packed(model.prec, 0)
+        # 2 x AdamW, then re-pack so the next sampling / update call sees the new weights (part of the step's cost)
+        step_and_repack(model, opt_a, opt_c, n_time=K)
 
     def sample_step(i):
         return model(cond={"state": obs_batches[i % 4]}, deterministic=False, return_chain=True)

@@ -25,7 +25,7 @@ import torch.distributed as dist
 from dppo_amd.cfg.loader import instantiate
 from dppo_amd.env.synthetic import make_venv
 from dppo_amd.parallel import DataParallel
-from dppo_amd.util.optim import FlatAdamW
+from dppo_amd.util.optim import FlatAdamW, step_and_repack
 from dppo_amd.util.reward_scaling import RunningRewardScaler
 from dppo_amd.util.rollout import gae_device
 from dppo_amd.util.scheduler import CosineAnnealingWarmupRestarts
@@ -272,11 +272,8 @@ class TrainPPODiffusionAgent:
                 if self.vf_coef != 1:  # loss = pg + ... + v_loss * vf_coef: the critic sees vf_coef * d v_loss
                     model.critic.flat_grads().mul_(self.vf_coef)
                 self.dp.allreduce_grads()
-                if update_actor:
-                    self.actor_optimizer.step(model.actor_ft.flat_grads(), max_norm=self.max_grad_norm)
-                    model.actor_ft.mark_updated()
-                self.critic_optimizer.step(model.critic.flat_grads())
-                model.critic.mark_updated()
+                step_and_repack(model, self.actor_optimizer, self.critic_optimizer, update_actor=update_actor,
+                                max_norm=self.max_grad_norm)
                 stats = st.tolist()  # D2H sync once per minibatch, as the reference's .item() calls
                 clipfracs.append(stats[hip.STAT_CLIPFRAC])
                 if self.target_kl is not None and stats[hip.STAT_APPROX_KL] > self.target_kl:

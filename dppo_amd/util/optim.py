@@ -45,3 +45,32 @@ class FlatAdamW:
                                              float(self.betas[0]), float(self.betas[1]), float(self.eps),
                                              float(self.weight_decay), norm_ptr, float(max_norm or 0.0),
                                              hip.stream()), "dppo_adamw_step")
+
+
+_side_streams = {}
+
+
+def step_and_repack(model, actor_opt: "FlatAdamW", critic_opt: "FlatAdamW", update_actor: bool = True,
+                    max_norm: Optional[float] = None, n_time: Optional[int] = None):
+    """Optimiser step + kernel-image repack of both networks (reference train_ppo_diffusion_agent.py:360-373).
+
+    The two chains (AdamW -> 2-4 pack launches) are a handful of launch-latency-bound kernels each and independent of
+    one another, so the critic's runs on a side stream beside the actor's and the caller's stream waits for both.
+    """
+    main = torch.cuda.current_stream()
+    dev = actor_opt.p.device
+    side = _side_streams.get(dev)
+    if side is None:
+        side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    n_time = model.denoising_steps if n_time is None else n_time
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        critic_opt.step(model.critic.flat_grads())
+        model.critic.mark_updated()
+        model.critic.packed(model.prec, 0)
+    if update_actor:
+        actor_opt.step(model.actor_ft.flat_grads(), max_norm=max_norm)
+        model.actor_ft.mark_updated()
+        model.actor_ft.packed(model.prec, n_time)
+    main.wait_stream(side)
+
