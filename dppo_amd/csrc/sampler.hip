@@ -113,6 +113,16 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
     const u32x4* cur = ws[net];
     const u32x4* nxt = ws[nnet];
     const float* prm = a.params[net];
+    // this step's noise draw and the next step's time embedding are needed at the very end of the step, right behind the
+    // ring's prefetches: issued here, they have a whole step to land; issued there, they would wait for every weight
+    // fragment in flight (vmcnt is in issue order) -- 20 times per call
+    const dppo_step sn = a.sched[min(i + 1, a.n_steps - 1)];
+    float z_pre = 0.f, te_pre = 0.f;
+    if (tid < 16 * AF) {
+      const int row = tid / AF, j = tid - row * AF;
+      z_pre = a.noise[(size_t)(i + 1) * B * AF + (size_t)min(grow0 + row, B - 1) * AF + j];
+    }
+    if (tid < 16 * td) te_pre = a.temb[sn.net][sn.t * td + tid % td];
 
     // out-layer fragments, in groups of OG out tiles: one group, prefetched at the top of the step, when it is small;
     // loaded right before use at H = 1024 (the registers are needed) and for wide outputs (two groups)
@@ -257,7 +267,6 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
     __syncthreads();
     // ---- posterior + noise: diffusion_vpg.py:165-223 (p_mean_var) and :279-311 (sampling loop)
     {
-      const dppo_step sn = a.sched[min(i + 1, a.n_steps - 1)];
       const float* nz = a.noise + (size_t)(i + 1) * B * AF;
       for (int idx = tid; idx < 16 * AF; idx += 512) {
         const int row = idx / AF, j = idx - row * AF;
@@ -280,7 +289,7 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
           if (a.has_eclip) eps = fminf(fmaxf(eps, -a.eclip), a.eclip);
           mu = st.c2 * x0 + st.c3 * eps;
         }
-        float z = nz[(size_t)min(grow, B - 1) * AF + j];
+        float z = idx == tid ? z_pre : nz[(size_t)min(grow, B - 1) * AF + j];  // first pass: prefetched at the step's top
         z = fminf(fmaxf(z, -a.rclip), a.rclip);
         float xn = mu + st.std * z;
         if (st.final_clip) xn = fminf(fmaxf(xn, -a.fclip), a.fclip);
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
       }
       for (int idx = tid; idx < 16 * td; idx += 512) {
         const int row = idx / td, j = idx - row * td;
-        lds_put<P>(xin, in_rb, in_km, row, AF + j, a.temb[sn.net][sn.t * td + j]);
+        lds_put<P>(xin, in_rb, in_km, row, AF + j, idx == tid ? te_pre : a.temb[sn.net][sn.t * td + j]);
       }
       // a cond_mlp encodes the observation per network: swap the state columns when the next step switches network
       if (sn.net != st.net && a.obs[0] != a.obs[1]) put_state(sn.net);
