@@ -992,6 +992,7 @@ struct PpoWs {
   double* moments;
   float* loss_tab;  // [2 Kft], Kft <= 1024
   double* loss_partial;
+  double* loss_partial_v;  // the value half's, when it runs on the critic's stream
   float* loss_partial_cs;
 };
 template <class P>
@@ -999,6 +1000,7 @@ static size_t carve_ppo(Carver& c, const dppo_net_desc& a, const dppo_net_desc& 
   W.moments = (double*)c.take(256);
   W.loss_tab = (float*)c.take(2 * 1024 * sizeof(float));
   W.loss_partial = (double*)c.take((size_t)loss_blocks(N) * 8 * sizeof(double));
+  W.loss_partial_v = (double*)c.take((size_t)loss_blocks(N) * 8 * sizeof(double));
   W.loss_partial_cs = (float*)c.take((size_t)loss_blocks(N) * 65 * sizeof(float));
   W.brow = (int32_t*)c.take((size_t)N * 4);
   W.krow = (int32_t*)c.take((size_t)N * 4);
@@ -1042,10 +1044,11 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   launch_build_rows<P>(br, s);
   if (a.cond_hidden > 0) cond_encode<P>(a, ap, ak, LA, N, W.C.in, W.A, W.A.in, nullptr, 0, true, s);
   if (gmom == nullptr) launch_adv_moments(adv_k, W.brow, N, W.moments, s);
+  // The critic half (forward -> value loss -> backward -> weight gradients) and the actor half (forward -> policy
+  // loss -> ...) share only the row builder's outputs and the advantage moments: one fork here, one join at the end
+  // (a cross-stream event hop costs ~10 us of idle device time, so the loss is evaluated as two launches rather than
+  // joining the streams in the middle of the call).
   hipStream_t s2 = fork_side(s);
-  mlp_forward<P>(cr, cp, ck, LC, N, W.C, true, s2);
-  mlp_forward<P>(a, ap, ak, LA, N, W.A, true, s);
-  join_side(s, s2);
   LossArgs la;
   memset(&la, 0, sizeof(la));
   la.eps = W.A.out, la.lde = W.A.ldout, la.vnew = W.C.out, la.ldv = W.C.ldout, la.brow = W.brow, la.krow = W.krow;
@@ -1055,18 +1058,20 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   la.moments = gmom ? gmom : W.moments;
   la.tab = Kft <= 1024 ? W.loss_tab : nullptr;
   la.d_eps = W.A.d_out, la.ldde = LA.Kpo, la.d_v = W.C.d_out, la.lddv = LC.Kpo, la.stats = stats;
-  la.partial = W.loss_partial;
-  // Out-layer bias gradients (column sums of d_eps / d_v): the loss kernel can emit them (per-block partials, summed by
-  // loss_finalize), but both kernels sit on the critical path between forward and backward, while a column-sum pass over
-  // d_out runs beside the weight-gradient GEMMs on the tail stream for free.  Measured: finalize 21 -> 5 us.  Off.
-  const bool fuse_bout = false && LA.Kpo == 64 && fused_ok<P>(a) && fused_ok<P>(cr);
-  if (fuse_bout) {
-    la.partial_cs = W.loss_partial_cs, la.out_dim = a.out_dim;
-    la.gb_actor = agrad + param_layout(a).bout, la.gb_critic = cgrad + param_layout(cr).bout;
+  const bool fuse_bout = false;  // out-layer bias gradients come from the fused backward's d_out column sums
+  const bool split = s2 != s;
+  // critic half
+  mlp_forward<P>(cr, cp, ck, LC, N, W.C, true, s2);
+  if (split) {
+    la.part = 2, la.partial = W.loss_partial_v;
+    launch_ppo_loss<P>(la, s2);
+    mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s2, fuse_bout, 2);
   }
+  // actor half
+  mlp_forward<P>(a, ap, ak, LA, N, W.A, true, s);
+  la.part = split ? 1 : 3, la.partial = W.loss_partial;
   launch_ppo_loss<P>(la, s);
-  s2 = fork_side(s);
-  mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s2, fuse_bout, 2);
+  if (!split) mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s, fuse_bout, 2);
   mlp_backward<P>(a, ap, ak, LA, N, W.A, agrad, W.krow, ksteps, Kft, s, fuse_bout);
   if (a.cond_hidden > 0) cond_backward<P>(a, ap, ak, LA, N, W.A, W.A.dh0_final, W.C.in, agrad, s);
   join_side(s, s2);

@@ -405,9 +405,10 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
     const float* olp = a.gathered ? a.logprobs_k + (size_t)b * AF : a.logprobs_k + ((size_t)b * Kft + k) * AF;
     const float* ep = a.eps + (size_t)nn * a.lde;
     const float var = st.std * st.std, lstd = logf(st.std);
+    const bool pol = (a.part & 1) != 0, val = (a.part & 2) != 0;
     // ---- new / old log-probs, clamped to [-5, 2], averaged over the first `rh` chunk steps (:93-102)
     float sum_new = 0.f, sum_old = 0.f;
-    for (int j = sub; j < cnt; j += 16) {
+    for (int j = sub; pol && j < cnt; j += 16) {
       float mu, dmu;
       posterior(a.dcfg, st, ch[j], ep[j], mu, dmu);
       const float d = ch[AF + j] - mu;
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
     const float dL_dratio = -adv * (w1 + (1.f - w1) * within);
     const float coef = dL_dratio * ratio / ((float)Nn * (float)cnt);  // d mean(L) / d lp_j (before clamp mask)
     // ---- value loss (:177-189)
-    const float v = a.vnew[(size_t)nn * a.ldv];
+    const float v = val ? a.vnew[(size_t)nn * a.ldv] : 0.f;
     const float ret = a.returns_k[b];
     float dv, lv;
     if (pc.has_vclip) {
@@ -457,16 +458,16 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
       dv = v - ret;
     }
     if (live) {
-      if (sub == 0) {
+      if (sub == 0 && pol) {
         s_kl += (double)((ratio - 1.f) - logratio);
         s_cf += fabsf(ratio - 1.f) > eps_k ? 1.0 : 0.0;
         s_ratio += ratio;
         s_pg += fmaxf(pg1, pg2);
-        s_v += lv;
       }
+      if (sub == 0 && val) s_v += lv;
       // ---- d loss / d eps and d loss / d v, zero padded to the GEMM K width, 16 lanes x 4 elements per pass
       E* de = (E*)a.d_eps + (size_t)n * a.ldde;
-      for (int j0 = 4 * sub; j0 < a.ldde; j0 += 64) {
+      for (int j0 = 4 * sub; pol && j0 < a.ldde; j0 += 64) {
         float gq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
       }
       if (sub == 0) cs_v += dv / (float)Nn;
       E* dvp = (E*)a.d_v + (size_t)n * a.lddv;
-      for (int j0 = 4 * sub; j0 < a.lddv; j0 += 64)
+      for (int j0 = 4 * sub; val && j0 < a.lddv; j0 += 64)
 #pragma unroll
         for (int q = 0; q < 4; ++q) dvp[j0 + q] = P::from_f32(j0 + q == 0 ? dv / (float)Nn : 0.f);
     }
@@ -528,12 +529,13 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
 // (64 column lanes x 16 block lanes, 4 independent chains each); fixed order => reproducible
 __global__ __launch_bounds__(1024) void loss_finalize_kernel(const double* partial, int blocks, const double* moments,
                                                              double* stats, const float* partial_cs, float* gb_actor,
-                                                             int out_dim, float* gb_critic) {
+                                                             int out_dim, float* gb_critic, int part) {
   __shared__ double shd[16];
   __shared__ float red[16][65];
   const double Nn = moments[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int k = 0; k < 5; ++k) {
+    if (!((k == DPPO_STAT_V_LOSS ? 2 : 1) & part)) continue;  // the other half's launch owns this entry
     double s = 0;
     for (int b = tid; b < blocks; b += 1024) s += partial[(size_t)b * 8 + k];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
@@ -587,7 +589,7 @@ void launch_ppo_loss(const LossArgs& a, hipStream_t s) {
   const int blocks = loss_blocks(a.N);
   hipLaunchKernelGGL((ppo_loss_kernel<P>), dim3(blocks), dim3(256), lds, s, a);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, s, a.partial, blocks, a.moments, a.stats, a.partial_cs,
-                     a.gb_actor, a.out_dim, a.gb_critic);
+                     a.gb_actor, a.out_dim, a.gb_critic, a.part);
 }
 template void launch_ppo_loss<F32>(const LossArgs&, hipStream_t);
 template void launch_ppo_loss<BF16>(const LossArgs&, hipStream_t);

@@ -1,10 +1,17 @@
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01d; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01e; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 echo "[1] bench full"; timeout -k 10 400 python3 $R/bench.py > $O/bench.json 2> $O/bench.err && tail -c 600 $O/bench.json && echo
 echo "[2] rocprof stats"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/stats.log 2>&1 && echo ok
 echo "[3] pmc fetch"; timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 4 --warmup 1 --n-steps 60 --no-cpu-baseline > $O/pmc_fetch.log 2>&1 && echo ok
 echo "[4] pmc write"; timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 4 --warmup 1 --n-steps 60 --no-cpu-baseline > $O/pmc_write.log 2>&1 && echo ok
 cd $R
+echo "[4b] mfma util"; cd /tmp; timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -- python3 $R/bench.py --steps 4 --warmup 1 --n-steps 60 --no-cpu-baseline > $O/pmc_mfma.log 2>&1 && echo ok
+echo "[4c] timeline"; timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/trace.log 2>&1 && echo ok
+cd $R
+python3 tools/mfma_util.py $(ls $O/pmc_mfma/*/*counter_collection.csv) $O/mfma_util.json > $O/mfma_util.txt
+python3 tools/trace_step.py $(ls $O/trace/*/*kernel_trace.csv) v 5 > $O/step_overlapped.txt
+python3 tools/trace_step.py $(ls $O/trace/*/*kernel_trace.csv) v > $O/step_serial.txt
 echo "[5] fused bench"; timeout -k 10 200 python3 tools/fused_bench.py > $O/fused_bench.txt 2>&1 && tail -6 $O/fused_bench.txt
+echo "[5b] stamps"; DPPO_HIP_LIB=$R/dppo_amd/lib/libdppo_hip_stamps.so timeout -k 10 200 python3 tools/fused_bench.py --stamps > $O/stamps.txt 2>&1 && echo ok
 echo "[6] dp2 rehearsal"; HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --share-gpu --no-cpu-baseline --n-steps 50 > $O/dp2.log 2>&1 && tail -1 $O/dp2.log | cut -c1-300

@@ -1,5 +1,10 @@
 #!/usr/bin/env python3
-"""Break one PPO update step out of a rocprofv3 kernel trace CSV: python tools/trace_step.py <kernel_trace.csv>"""
+"""Break one PPO update step out of a rocprofv3 kernel trace CSV:
+
+    python tools/trace_step.py <kernel_trace.csv> [v] [step index]
+
+`v` also lists the step's kernels on a time line.  Step index counts the loss kernels of the trace (default -2, a
+step of bench.py's last pass -- the serial roofline pass; use e.g. 5 for a step of the first, overlapped, pass)."""
 import collections
 import csv
 import sys
@@ -8,7 +13,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 ts = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in rows)
 loss_idx = [i for i, t in enumerate(ts) if 'ppo_loss_kernel' in t[2]]
 build_idx = [i for i, t in enumerate(ts) if 'build_rows_kernel' in t[2]]
-li = loss_idx[-2]
+li = loss_idx[int(sys.argv[3]) if len(sys.argv) > 3 else -2]
 start = max(i for i in build_idx if i < li)
 end = min(i for i in build_idx if i > li)
 seg = ts[start:end]
