@@ -3,6 +3,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01e; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 echo "[1] bench full"; timeout -k 10 400 python3 $R/bench.py > $O/bench.json 2> $O/bench.err && tail -c 600 $O/bench.json && echo
 echo "[2] rocprof stats"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/stats.log 2>&1 && echo ok
+echo "[2b] rocprof stats, side streams off (the setting of bench.py's roofline pass)"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_serial -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --tune 2=0 > $O/stats_serial.log 2>&1 && echo ok
 echo "[3] pmc fetch"; timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 4 --warmup 1 --n-steps 60 --no-cpu-baseline > $O/pmc_fetch.log 2>&1 && echo ok
 echo "[4] pmc write"; timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 4 --warmup 1 --n-steps 60 --no-cpu-baseline > $O/pmc_write.log 2>&1 && echo ok
 cd $R
