@@ -290,6 +290,51 @@ def test_logprob_subsample_matches_chain_logprobs(golden, case):
     np.testing.assert_allclose(sub.cpu().numpy()[sel], ref[sel], rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("N", [2, 3, 65, 129])
+def test_tiny_and_ragged_minibatches_match_oracle(N):
+    """Edge sizes of the update: fewer samples than one row tile, one past a tile, ... against the CPU oracle (fp32)."""
+    kw = dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01, randn_clip_value=3)
+    m, a, c = build_model("hopper", kw, 9, "fp32")
+    cfg = make_cfg(a, kw)
+    R, Kft, AF = 40, 10, a.horizon_steps * a.action_dim
+    gen = torch.Generator(device="cpu").manual_seed(N)
+    obs = (torch.rand(R, 1, a.cond_dim, generator=gen) * 2 - 1)
+    chains = m(cond={"state": obs.to(DEV)}).chains.cpu()
+    logp = m.get_logprobs({"state": obs.to(DEV)}, chains.to(DEV)).reshape(R, Kft, a.horizon_steps, a.action_dim).cpu()
+    ret, val, adv = (torch.randn(R, generator=gen) for _ in range(3))
+    inds = torch.randperm(R * Kft, generator=gen)[:N]
+    st = m.ppo_update(obs.reshape(R, -1).to(DEV), chains.reshape(R, Kft + 1, AF).to(DEV), ret.to(DEV), val.to(DEV),
+                      adv.to(DEV), (logp + 0.01).reshape(R, Kft, AF).to(DEV), inds.to(DEV)).cpu().numpy().copy()
+    rows, kk = inds // Kft, inds % Kft
+    base, ft, cr = O.init_params(a, 9), O.init_params(a, 10), O.init_params(c, 11)
+    ft = {k: v.clone().requires_grad_(True) for k, v in ft.items()}
+    cr = {k: v.clone().requires_grad_(True) for k, v in cr.items()}
+    res = O.ppo_loss(cfg, a, c, base, ft, cr, obs[rows], chains[rows, kk], chains[rows, kk + 1], kk, ret[rows], val[rows],
+                     adv[rows].clone(), logp[rows, kk] + 0.01, reward_horizon=4)
+    assert st[0] == pytest.approx(float(res[0].detach()), rel=2e-4, abs=2e-6)
+    assert st[1] == pytest.approx(float(res[2].detach()), rel=2e-4, abs=2e-6)
+    (res[0] + res[2]).backward()
+    ga = torch.cat([ft[k].grad.reshape(-1) if ft[k].grad is not None else torch.zeros(ft[k].numel())
+                    for k, _ in m.actor_ft.named_parameters()])
+    gc = torch.cat([cr[k].grad.reshape(-1) for k, _ in m.critic.named_parameters()])
+    np.testing.assert_allclose(m.actor_ft.flat_grads().cpu().numpy(), ga.numpy(), rtol=2e-3, atol=2e-6)
+    np.testing.assert_allclose(m.critic.flat_grads().cpu().numpy(), gc.numpy(), rtol=2e-3, atol=2e-6)
+
+
+def test_sampler_single_env_and_ragged_batches():
+    m, a, _ = build_model("hopper", dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3), 3, "fp32")
+    base, ft = O.init_params(a, 3), O.init_params(a, 4)
+    cfg = make_cfg(a, dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3))
+    for B in (1, 15, 17, 33):
+        gen = torch.Generator(device="cpu").manual_seed(B)
+        st = torch.rand(B, 1, a.cond_dim, generator=gen) * 2 - 1
+        noise = torch.randn(21, B, a.horizon_steps, a.action_dim, generator=gen)
+        got = m(cond={"state": st.to(DEV)}, noise=noise.to(DEV))
+        traj, chains = O.sample_chain(cfg, a, base, ft, st, noise)
+        np.testing.assert_allclose(got.chains.cpu().numpy(), chains.numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(got.trajectories.cpu().numpy(), traj.numpy(), rtol=1e-4, atol=1e-4)
+
+
 # ------------------------------------------------------------------ G8 behaviour-cloning term
 @pytest.mark.parametrize("case", ["bc_ddpm", "bc_ddim_kitchen"])
 def test_bc_loss_and_gradient(golden, case):
