@@ -989,6 +989,7 @@ template <class P>
 struct PpoWs {
   MlpBufs<P> A, C;
   int32_t *brow, *krow;
+  int32_t* brow_c;  // the critic pipeline's own copy of brow (it builds its rows on its own stream)
   double* moments;
   float* loss_tab;  // [2 Kft], Kft <= 1024
   double* loss_partial;
@@ -1003,6 +1004,7 @@ static size_t carve_ppo(Carver& c, const dppo_net_desc& a, const dppo_net_desc& 
   W.loss_partial_v = (double*)c.take((size_t)loss_blocks(N) * 8 * sizeof(double));
   W.loss_partial_cs = (float*)c.take((size_t)loss_blocks(N) * 65 * sizeof(float));
   W.brow = (int32_t*)c.take((size_t)N * 4);
+  W.brow_c = (int32_t*)c.take((size_t)N * 4);
   W.krow = (int32_t*)c.take((size_t)N * 4);
   carve_mlp<P>(c, a, N, true, true, W.A);
   carve_mlp<P>(c, cr, N, true, true, W.C);
@@ -1032,23 +1034,34 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   if ((int64_t)need > wsb) return fail(-1, "workspace too small: need %zu bytes, got %lld", need, (long long)wsb);
   const PackLayout LA = pack_layout<P>(a, 0), LC = pack_layout<P>(cr, 0);
   const int Kft = pcfg.ft_denoising_steps;
+  // The critic pipeline (rows -> forward -> value loss -> backward -> weight gradients) and the actor pipeline (rows ->
+  // advantage moments -> forward -> policy loss -> ...) share nothing but the call's inputs: one fork at entry, one join
+  // at the end.  A cross-stream event hop costs 10-17 us of device idle time; at entry it hides behind the actor's row
+  // builder, and the loss is evaluated as two launches rather than joining the streams in the middle of the call.
+  // (With a cond_mlp the actor's encoder reads the critic's observation rows: the row builder then stays one launch.)
+  const bool own_rows = a.cond_hidden == 0;
+  hipStream_t s2 = own_rows ? fork_side(s) : s;
   BuildRows br;
   memset(&br, 0, sizeof(br));
-  br.zero_a = stats, br.n_zero_a = DPPO_STAT_COUNT, br.zero_b = W.moments, br.n_zero_b = 32;  // zeroed by the row builder
+  br.zero_b = W.moments, br.n_zero_b = 32;  // zeroed by the row builder (every statistic has one owner launch that writes it)
   if (Kft <= 1024) br.loss_tab = W.loss_tab, br.pcfg = pcfg;
   br.inds = inds, br.kinds = kinds, br.chains = chains_k, br.obs = obs_k, br.temb = (const float*)(ak + LA.temb);
   br.ksteps = ksteps;
   br.Kft = Kft, br.AF = a.act_flat, br.td = a.time_dim, br.cond = a.cond_dim, br.M = N;
   br.inA = W.A.in, br.KpA = LA.Kp0, br.inC = W.C.in, br.KpC = LC.Kp0, br.brow = W.brow, br.krow = W.krow;
   br.obs_in_a = a.cond_hidden > 0 ? 0 : 1;  // with cond_mlp the encoder fills the state columns (from the critic's obs rows)
+  const bool split = s2 != s;
+  if (split) {
+    BuildRows bc = br;  // critic rows only, on the critic's stream
+    bc.zero_a = bc.zero_b = nullptr, bc.n_zero_a = bc.n_zero_b = 0, bc.loss_tab = nullptr;
+    bc.inA = nullptr, bc.brow = W.brow_c, bc.krow = nullptr;
+    launch_build_rows<P>(bc, s2);
+    br.inC = nullptr;
+  }
   launch_build_rows<P>(br, s);
   if (a.cond_hidden > 0) cond_encode<P>(a, ap, ak, LA, N, W.C.in, W.A, W.A.in, nullptr, 0, true, s);
   if (gmom == nullptr) launch_adv_moments(adv_k, W.brow, N, W.moments, s);
-  // The critic half (forward -> value loss -> backward -> weight gradients) and the actor half (forward -> policy
-  // loss -> ...) share only the row builder's outputs and the advantage moments: one fork here, one join at the end
-  // (a cross-stream event hop costs ~10 us of idle device time, so the loss is evaluated as two launches rather than
-  // joining the streams in the middle of the call).
-  hipStream_t s2 = fork_side(s);
+  if (!own_rows) s2 = fork_side(s);
   LossArgs la;
   memset(&la, 0, sizeof(la));
   la.eps = W.A.out, la.lde = W.A.ldout, la.vnew = W.C.out, la.ldv = W.C.ldout, la.brow = W.brow, la.krow = W.krow;
@@ -1059,19 +1072,22 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   la.tab = Kft <= 1024 ? W.loss_tab : nullptr;
   la.d_eps = W.A.d_out, la.ldde = LA.Kpo, la.d_v = W.C.d_out, la.lddv = LC.Kpo, la.stats = stats;
   const bool fuse_bout = false;  // out-layer bias gradients come from the fused backward's d_out column sums
-  const bool split = s2 != s;
+  const bool two_streams = s2 != s;
   // critic half
   mlp_forward<P>(cr, cp, ck, LC, N, W.C, true, s2);
-  if (split) {
+  if (two_streams) {
     la.part = 2, la.partial = W.loss_partial_v;
+    if (split) la.brow = W.brow_c;
+    if (gmom == nullptr) la.n_count = (double)N;  // = what adv_moments leaves in moments[2], without waiting for it
     launch_ppo_loss<P>(la, s2);
+    la.brow = W.brow, la.n_count = 0;
     mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s2, fuse_bout, 2);
   }
   // actor half
   mlp_forward<P>(a, ap, ak, LA, N, W.A, true, s);
-  la.part = split ? 1 : 3, la.partial = W.loss_partial;
+  la.part = two_streams ? 1 : 3, la.partial = W.loss_partial;
   launch_ppo_loss<P>(la, s);
-  if (!split) mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s, fuse_bout, 2);
+  if (!two_streams) mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s, fuse_bout, 2);
   mlp_backward<P>(a, ap, ak, LA, N, W.A, agrad, W.krow, ksteps, Kft, s, fuse_bout);
   if (a.cond_hidden > 0) cond_backward<P>(a, ap, ak, LA, N, W.A, W.A.dh0_final, W.C.in, agrad, s);
   join_side(s, s2);

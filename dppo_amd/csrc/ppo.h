@@ -111,6 +111,8 @@ struct LossArgs {
   int64_t N;
   const double* moments;  // [3] sum(adv), sum(adv^2), count over the (global) minibatch
   const float* tab;       // [2 Kft] per-k discount and clip range built by the row builder (null: built per block)
+  double n_count;  // > 0: the (global) minibatch sample count, instead of moments[2] (the value half must not wait for
+                   // the advantage-moment kernel on the other stream)
   int part;  // bit 0: the policy half (log-probs, surrogate, d_eps; needs eps), bit 1: the value half (v loss, d_v; needs
              // vnew) -- the two halves of one update can then run on the actor's and the critic's stream, no join
   void* d_eps;            // [N][ldde] elem, zero padded

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void build_rows_kernel(const BuildRows a) {
     if (a.loss_tab != nullptr)
       for (int k = threadIdx.x; k < a.pcfg.ft_denoising_steps; k += blockDim.x) loss_table_entry(a.pcfg, k, a.loss_tab);
   }
-  const int ca = a.KpA / EPC, cc = a.inC != nullptr ? a.KpC / EPC : 0;
+  const int ca = a.inA != nullptr ? a.KpA / EPC : 0, cc = a.inC != nullptr ? a.KpC / EPC : 0;
   const int64_t total = a.M * (ca + cc);
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
     const bool isA = q < a.M * ca;
@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256) void build_rows_kernel(const BuildRows a) {
         v[e] = x;
       }
     } else {
+      if (ca == 0 && c0 == 0 && a.brow != nullptr) a.brow[n] = (int32_t)b;  // critic-only launch: its own row index
 #pragma unroll
       for (int e = 0; e < EPC; ++e) v[e] = c0 + e < a.cond ? ob[c0 + e] : 0.f;
     }
@@ -164,7 +165,7 @@ template <class P>
 void launch_build_rows(const BuildRows& a, hipStream_t s) {
   if (a.M <= 0) return;
   constexpr int EPC = 16 / P::ESIZE;
-  const int64_t total = a.M * (a.KpA / EPC + (a.inC != nullptr ? a.KpC / EPC : 0));
+  const int64_t total = a.M * ((a.inA != nullptr ? a.KpA / EPC : 0) + (a.inC != nullptr ? a.KpC / EPC : 0));
   int64_t blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL((build_rows_kernel<P>), dim3((unsigned)blocks), dim3(256), 0, s, a);
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
   } else {
     for (int k = threadIdx.x; k < Kft; k += 256) loss_table_entry(pc, k, tab);
   }
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && (a.part & 1)) {
     const double Nm = a.moments[2], mean = a.moments[0] / Nm;
     const double varu = (a.moments[1] - Nm * mean * mean) / (Nm - 1.0);  // unbiased (torch.std)
     tab[2 * Kft] = (float)mean;
@@ -394,12 +395,12 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
   const int cnt = rh * Da;
   double s_pg = 0, s_v = 0, s_kl = 0, s_cf = 0, s_ratio = 0;
   float cs[4] = {0.f, 0.f, 0.f, 0.f}, cs_v = 0.f;  // column sums of d_eps (this lane's 4 columns) and of d_v
-  const double Nn = a.moments[2];  // samples in the (global) minibatch: means and 1/N scaling use this count
+  const double Nn = a.n_count > 0 ? a.n_count : a.moments[2];  // samples in the (global) minibatch: means and 1/N scaling
   for (int pass = 0; pass < LOSS_PASSES; ++pass) {
     const int64_t n = ((int64_t)blockIdx.x * LOSS_PASSES + pass) * 16 + (threadIdx.x >> 4);
     const bool live = n < a.N;
     const int64_t nn = live ? n : a.N - 1;  // out-of-range lanes shadow the last sample (shuffles need all lanes), write nothing
-    const int b = a.brow[nn], k = a.krow[nn];
+    const int b = a.brow[nn], k = (a.part & 1) ? a.krow[nn] : 0;  // the value half never looks at the denoising step
     const dppo_step st = a.ksteps[k];
     const float* ch = a.gathered ? a.chains + (size_t)b * 2 * AF : a.chains + ((size_t)b * (Kft + 1) + k) * AF;
     const float* olp = a.gathered ? a.logprobs_k + (size_t)b * AF : a.logprobs_k + ((size_t)b * Kft + k) * AF;
@@ -529,10 +530,10 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
 // (64 column lanes x 16 block lanes, 4 independent chains each); fixed order => reproducible
 __global__ __launch_bounds__(1024) void loss_finalize_kernel(const double* partial, int blocks, const double* moments,
                                                              double* stats, const float* partial_cs, float* gb_actor,
-                                                             int out_dim, float* gb_critic, int part) {
+                                                             int out_dim, float* gb_critic, int part, double n_count) {
   __shared__ double shd[16];
   __shared__ float red[16][65];
-  const double Nn = moments[2];
+  const double Nn = n_count > 0 ? n_count : moments[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int k = 0; k < 5; ++k) {
     if (!((k == DPPO_STAT_V_LOSS ? 2 : 1) & part)) continue;  // the other half's launch owns this entry
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const double* parti
     if (tid == 0) {
       double t = 0;
       for (int i = 0; i < 16; ++i) t += shd[i];
-      stats[k] += t / Nn;
+      stats[k] = t / Nn;  // each entry has exactly one owner launch
     }
   }
   if (partial_cs != nullptr) {
@@ -589,7 +590,7 @@ void launch_ppo_loss(const LossArgs& a, hipStream_t s) {
   const int blocks = loss_blocks(a.N);
   hipLaunchKernelGGL((ppo_loss_kernel<P>), dim3(blocks), dim3(256), lds, s, a);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, s, a.partial, blocks, a.moments, a.stats, a.partial_cs,
-                     a.gb_actor, a.out_dim, a.gb_critic, a.part);
+                     a.gb_actor, a.out_dim, a.gb_critic, a.part, a.n_count);
 }
 template void launch_ppo_loss<F32>(const LossArgs&, hipStream_t);
 template void launch_ppo_loss<BF16>(const LossArgs&, hipStream_t);
