@@ -1090,7 +1090,13 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   const bool two_streams = s2 != s;
   // critic half.  (Knob 10 gates its first persistent kernel so that it becomes eligible together with the actor's instead
   // of starting alone and taking every CU first; measured worse, off.)
-  if (split && g_gate_critic) gate_side(s, s2);
+  const bool actor_first = split && g_gate_critic == 2;  // experiment: the critic's forward waits for the actor's
+  if (actor_first) {
+    mlp_forward<P>(a, ap, ak, LA, N, W.A, true, s);
+    gate_side(s, s2);
+  } else if (split && g_gate_critic) {
+    gate_side(s, s2);
+  }
   mlp_forward<P>(cr, cp, ck, LC, N, W.C, true, s2);
   if (two_streams) {
     la.part = 2, la.partial = W.loss_partial_v;
@@ -1101,7 +1107,7 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
     mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s2, fuse_bout, 2);
   }
   // actor half
-  mlp_forward<P>(a, ap, ak, LA, N, W.A, true, s);
+  if (!actor_first) mlp_forward<P>(a, ap, ak, LA, N, W.A, true, s);
   la.part = two_streams ? 1 : 3, la.partial = W.loss_partial;
   launch_ppo_loss<P>(la, s);
   if (!two_streams) mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s, fuse_bout, 2);
