@@ -819,7 +819,7 @@ static int sample_impl(const dppo_net_desc& d, const float* pb, const char* kb, 
     cond_encode<P>(d, pf, kf, L, B, Bz.cin, Bz, nullptr, enc + (size_t)B * lde, lde, false, s);
     a.obs[0] = enc, a.obs[1] = enc + (size_t)B * lde, a.cond = d.cond_out, a.ld_obs = lde;
   }
-  a.noise = noise, a.traj = traj, a.chains = chains, a.sched = sched;
+  a.noise = noise, a.seed_lo = cfg.seed_lo, a.seed_hi = cfg.seed_hi, a.traj = traj, a.chains = chains, a.sched = sched;
   a.B = (int)B, a.AF = d.act_flat, a.td = d.time_dim, a.Kp0 = g.Kp0, a.nb = d.n_blocks;
   a.n_steps = n_steps, a.chain_len = chain_len, a.init_slot = init_slot, a.act = d.act, a.use_ddim = cfg.use_ddim;
   a.has_dclip = cfg.has_denoised_clip, a.has_eclip = cfg.has_eps_clip, a.has_fclip = cfg.has_final_clip;
@@ -844,7 +844,7 @@ int dppo_sample_chain(const dppo_net_desc* actor, int prec, const float* params_
   if (int e = check_net(actor)) return e;
   if (int e = check_prec(prec)) return e;
   if (actor->kind != 0) return fail(-1, "dppo_sample_chain needs an actor descriptor");
-  if (!params_base || !packed_base || !params_ft || !packed_ft || !cfg || !sched || !obs || !noise || !traj)
+  if (!params_base || !packed_base || !params_ft || !packed_ft || !cfg || !sched || !obs || !traj)  // noise may be NULL
     return fail(-1, "null pointer");
   if (n_steps < 1) return fail(-1, "n_steps must be >= 1");
   if (B < 1 || B > (1 << 24)) return fail(-1, "B out of range");

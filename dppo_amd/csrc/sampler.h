@@ -36,7 +36,8 @@ struct SampleArgs {
   int use_ln;
   const float* obs[2];  // per network: [B][ld_obs] state columns (raw observation, or its cond_mlp encoding)
   int ld_obs;
-  const float* noise;   // [n_steps+1][B][AF]
+  const float* noise;   // [n_steps+1][B][AF], or null: drawn in the kernel (Philox4x32-10 keyed by seed_lo / seed_hi)
+  uint32_t seed_lo, seed_hi;
   float* traj;          // [B][AF]
   float* chains;        // [B][chain_len][AF]
   const dppo_step* sched;

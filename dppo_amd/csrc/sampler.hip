@@ -22,6 +22,22 @@ __device__ __forceinline__ void lds_put(char* buf, int rb, int kmask, int row, i
   *(typename P::elem_t*)p = P::from_f32(v);
 }
 
+// N(0,1) draw number `idx` of the stream keyed by (k0, k1): Philox4x32-10 on counter (idx, 0), Box-Muller on two of its
+// four words.  The counter is the element's index in the (n_steps+1, B, AF) noise tensor the host would have drawn.
+__device__ __forceinline__ float philox_normal(uint64_t idx, uint32_t k0, uint32_t k1) {
+  uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = 0, c3 = 0;
+#pragma unroll
+  for (int rnd = 0; rnd < 10; ++rnd) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0, c1 = lo1, c2 = hi0 ^ c3 ^ k1, c3 = lo0;
+    k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+  }
+  const float u1 = ((float)c0 + 1.f) * 2.3283064365386963e-10f;  // (0, 1]
+  const float u2 = (float)c1 * 2.3283064365386963e-10f;          // [0, 1)
+  return sqrtf(-2.f * __logf(u1)) * __cosf(6.283185307179586f * u2);
+}
+
 template <class P, int TPW, int OT, bool LN, int ACT>
 __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
   constexpr int PD = sampler_pd(128 * TPW), ES = P::ESIZE, KB = P::KB;
@@ -79,7 +95,8 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
     for (int idx = tid; idx < 16 * AF; idx += 512) {
       const int row = idx / AF, j = idx - row * AF;
       const int grow = grow0 + row;
-      const float v = a.noise[(size_t)min(grow, B - 1) * AF + j];
+      const size_t ni = (size_t)min(grow, B - 1) * AF + j;
+      const float v = a.noise != nullptr ? a.noise[ni] : philox_normal(ni, a.seed_lo, a.seed_hi);
       xcur[row * AF + j] = v;
       lds_put<P>(xin, in_rb, in_km, row, j, v);
       if (a.init_slot >= 0 && a.chains != nullptr && grow < B) a.chains[((size_t)grow * a.chain_len + a.init_slot) * AF + j] = v;
@@ -120,7 +137,8 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
     float z_pre = 0.f, te_pre = 0.f;
     if (tid < 16 * AF) {
       const int row = tid / AF, j = tid - row * AF;
-      z_pre = a.noise[(size_t)(i + 1) * B * AF + (size_t)min(grow0 + row, B - 1) * AF + j];
+      const size_t ni = (size_t)(i + 1) * B * AF + (size_t)min(grow0 + row, B - 1) * AF + j;
+      z_pre = a.noise != nullptr ? a.noise[ni] : philox_normal(ni, a.seed_lo, a.seed_hi);
     }
     if (tid < 16 * td) te_pre = a.temb[sn.net][sn.t * td + tid % td];
 
@@ -267,7 +285,7 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
     __syncthreads();
     // ---- posterior + noise: diffusion_vpg.py:165-223 (p_mean_var) and :279-311 (sampling loop)
     {
-      const float* nz = a.noise + (size_t)(i + 1) * B * AF;
+      const size_t nz0 = (size_t)(i + 1) * B * AF;
       for (int idx = tid; idx < 16 * AF; idx += 512) {
         const int row = idx / AF, j = idx - row * AF;
         const int grow = grow0 + row;
@@ -289,7 +307,11 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
           if (a.has_eclip) eps = fminf(fmaxf(eps, -a.eclip), a.eclip);
           mu = st.c2 * x0 + st.c3 * eps;
         }
-        float z = idx == tid ? z_pre : nz[(size_t)min(grow, B - 1) * AF + j];  // first pass: prefetched at the step's top
+        float z = z_pre;  // first pass: prefetched / drawn at the step's top
+        if (idx != tid) {
+          const size_t ni = nz0 + (size_t)min(grow, B - 1) * AF + j;
+          z = a.noise != nullptr ? a.noise[ni] : philox_normal(ni, a.seed_lo, a.seed_hi);
+        }
         z = fminf(fmaxf(z, -a.rclip), a.rclip);
         float xn = mu + st.std * z;
         if (st.final_clip) xn = fminf(fmaxf(xn, -a.fclip), a.fclip);

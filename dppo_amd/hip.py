@@ -34,7 +34,7 @@ class NetDesc(C.Structure):
 class DiffusionCfg(C.Structure):
     _fields_ = [("use_ddim", C.c_int32), ("has_denoised_clip", C.c_int32), ("has_eps_clip", C.c_int32),
                 ("has_final_clip", C.c_int32), ("denoised_clip", C.c_float), ("eps_clip", C.c_float),
-                ("randn_clip", C.c_float), ("final_clip", C.c_float)]
+                ("randn_clip", C.c_float), ("final_clip", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32)]
 
 
 class PpoCfg(C.Structure):

@@ -165,8 +165,10 @@ class VPGDiffusion(DiffusionModel):
     def forward(self, cond, deterministic=False, return_chain=True, use_base_policy=False, noise=None):
         """cond {"state": (B,To,Do)} -> Sample(trajectories (B,Ta,Da), chains (B,Kft+1,Ta,Da)).
 
-        ``noise`` (n_steps+1,B,Ta,Da) replaces the internal ``torch.randn`` draw (parity tests): noise[0] is the
-        initial x, noise[i+1] the draw of step i.
+        ``noise`` (n_steps+1,B,Ta,Da) replaces the internal draw (parity tests): noise[0] is the initial x, noise[i+1]
+        the draw of step i.  Without it the kernel draws N(0,1) itself (Philox keyed by a 64-bit value taken from
+        torch's CPU generator, so ``torch.manual_seed`` reproduces a run) -- the reference's ``torch.randn`` /
+        ``randn_like`` (:271, :303) in distribution, without a separate noise launch and tensor.
         """
         state = cond["state"]
         hip.require_gpu(state, "VPGDiffusion.forward")
@@ -174,22 +176,24 @@ class VPGDiffusion(DiffusionModel):
         dev = state.device
         AF = self.horizon_steps * self.action_dim
         sched, n_steps, chain_len, init_slot = self._sampling_schedule(deterministic, use_base_policy, dev)
+        cfg = self.diffusion_cfg()
         if noise is None:
-            noise = torch.randn((n_steps + 1, B, AF), device=dev, dtype=torch.float32)
-        noise = noise.reshape(n_steps + 1, B, AF).contiguous().float()
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: no device sync
+            cfg.seed_lo, cfg.seed_hi = seed & 0xFFFFFFFF, seed >> 32
+        else:
+            noise = noise.reshape(n_steps + 1, B, AF).contiguous().float()
         obs = state.reshape(B, -1).contiguous().float()
         traj = torch.empty((B, AF), device=dev, dtype=torch.float32)
         chains = torch.empty((B, chain_len, AF), device=dev, dtype=torch.float32) if return_chain else None
         lib = hip.load()
         d = self.actor.net_desc()
         K = self.denoising_steps
-        cfg = self.diffusion_cfg()
         wsb = lib.dppo_sample_chain_workspace_bytes(C.byref(d), self.prec, B)
         ws = self._ws_sample.get(wsb, dev) if wsb > 0 else None
         hip.check(lib.dppo_sample_chain(
             C.byref(d), self.prec, self.actor.flat_params().data_ptr(), self.actor.packed(self.prec, K).data_ptr(),
             self.actor_ft.flat_params().data_ptr(), self.actor_ft.packed(self.prec, K).data_ptr(), C.byref(cfg),
-            sched.data_ptr(), n_steps, obs.data_ptr(), noise.data_ptr(), B, traj.data_ptr(),
+            sched.data_ptr(), n_steps, obs.data_ptr(), noise.data_ptr() if noise is not None else None, B, traj.data_ptr(),
             chains.data_ptr() if return_chain else None, chain_len if return_chain else 0,
             init_slot if return_chain else -1, ws.data_ptr() if ws is not None else None, wsb, hip.stream()),
             "dppo_sample_chain")

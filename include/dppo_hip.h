@@ -87,6 +87,7 @@ typedef struct dppo_diffusion_cfg {
   int32_t has_eps_clip;      /* eps_clip_value is not None (DDIM only) */
   int32_t has_final_clip;
   float denoised_clip, eps_clip, randn_clip, final_clip;
+  uint32_t seed_lo, seed_hi; /* dppo_sample_chain with noise == NULL: key of the in-kernel Philox4x32-10 generator */
 } dppo_diffusion_cfg;
 
 typedef struct dppo_ppo_cfg {
@@ -145,7 +146,10 @@ int dppo_critic_forward(const dppo_net_desc* net, int prec, const float* params,
 /* ---- A6-A7: VPGDiffusion.forward (model/diffusion/diffusion_vpg.py:227-315) --------------- */
 /* obs (B,cond); noise (n_steps+1,B,Ta*Da): noise[0] is x_K, noise[i+1] the draw of step i (clamped
  * to +-randn_clip inside); sched: n_steps device entries; traj (B,Ta*Da); chains (B,chain_len,Ta*Da)
- * (may be NULL when chain_len == 0); init_slot: chain position of x_K or -1. */
+ * (may be NULL when chain_len == 0); init_slot: chain position of x_K or -1.
+ * noise: (n_steps+1, B, Ta*Da) pre-drawn N(0,1) (noise[0] = x_K, noise[i+1] = the draw of step i; parity runs), or NULL:
+ * the kernel then draws them itself (Philox4x32-10 keyed by cfg->seed_*, counter = the element's index in that tensor,
+ * Box-Muller) -- same distribution as the reference's torch.randn / randn_like, one launch instead of two. */
 int64_t dppo_sample_chain_workspace_bytes(const dppo_net_desc* actor, int prec, int64_t B); /* 0 without cond_mlp */
 int dppo_sample_chain(const dppo_net_desc* actor, int prec, const float* params_base, const void* packed_base,
                       const float* params_ft, const void* packed_ft, const dppo_diffusion_cfg* cfg,

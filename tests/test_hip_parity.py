@@ -133,6 +133,30 @@ def test_sampler_without_chain_and_internal_noise():
     assert torch.isfinite(s2.chains).all()
 
 
+def test_in_kernel_noise_is_standard_normal_and_seeded():
+    """Without a noise tensor the sampler draws N(0,1) itself (Philox4x32-10 + Box-Muller): check the moments of x_K
+    (chain slot 0 when Kft == K), reproducibility under torch.manual_seed and independence of seeds."""
+    m, a, _ = build_model("hopper", dict(denoising_steps=20, ft_denoising_steps=20, randn_clip_value=3), 3, "bf16")
+    st = torch.rand(4096, 1, a.cond_dim, device=DEV) * 2 - 1
+    torch.manual_seed(123)
+    s1 = m(cond={"state": st})
+    torch.manual_seed(123)
+    s2 = m(cond={"state": st})
+    s3 = m(cond={"state": st})
+    assert torch.equal(s1.chains, s2.chains) and not torch.equal(s1.chains, s3.chains)
+    x = s1.chains[:, 0].double().reshape(-1)  # x_K = the initial draw, unclipped
+    n = x.numel()
+    assert abs(x.mean().item()) < 4 / n ** 0.5
+    assert abs(x.var().item() - 1.0) < 0.03
+    assert abs((x ** 4).mean().item() - 3.0) < 0.15
+    assert abs((x.abs() > 1.1503).double().mean().item() - 0.25) < 0.01  # P(|z| > 1.1503) = 0.25
+    # rows / columns / steps are not correlated with each other
+    y = s3.chains[:, 0].double().reshape(-1)
+    assert abs((x * y).mean().item()) < 4 / n ** 0.5
+    c = s1.chains[:, 0].double()
+    assert abs((c[:, 0, 0] * c[:, 1, 1]).mean().item()) < 4 / c.shape[0] ** 0.5
+
+
 # ------------------------------------------------------------------ G5 PPO loss + gradients
 def flat_of(params, spec):
     return np.concatenate([params[n].detach().numpy().reshape(-1) for n, _, _ in O.param_shapes(spec)])
