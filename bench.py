@@ -168,6 +168,9 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     ap.add_argument("--probe", type=int, default=2,
                     help="kernel timed live for `roofline`: 2 gemm_tn (weight grads), 3 fused fwd, 4 fused bwd, 5 sampler")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the update step as captured hipGraphs (dppo_amd.util.graphed) instead of issuing its ~38 "
+                         "launches one by one; pays at small minibatches, not at this workload (0.69 vs 0.65 ms)")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
                     help="dppo_tune_set knob (include/dppo_hip.h), e.g. 2=0: critic half on the main stream (serial kernels)")
     args = ap.parse_args()
@@ -215,7 +218,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from dppo_amd.util.graphed import GraphedUpdate
+    graphed = None
+    if args.graph:
+        graphed = GraphedUpdate(model, opt_a, opt_c, dp, (obs_k, chains_k, ret_k, val_k, adv_k, logp_k), args.batch,
+                                ACT_STEPS, n_time=K)
+
+    eager = [False]  # the roofline pass issues the launches one by one (per-launch HIP events cannot be captured)
+
     def update_step(i):
+        if graphed is not None and not eager[0]:  # same work as below, launched as hipGraph replays (captured in warm-up)
+            graphed.step(minibatches[i], None if moments is None else moments[i])
+            return
         model.ppo_update(obs_k, chains_k, ret_k, val_k, adv_k, logp_k, minibatches[i], reward_horizon=ACT_STEPS,
                          global_moments=None if moments is None else moments[i])
         dp.allreduce_grads()  # one RCCL all-reduce of [actor grads | critic grads | stats]; no-op when world == 1
@@ -252,7 +266,9 @@ def main():
     if args.probe != 5:
         overlap = next((int(kv.split("=")[1]) for kv in args.tune if kv.split("=")[0] == "2"), 1)
         hip.check(lib.dppo_tune_set(2, 0), "dppo_tune_set")
+        eager[0] = True
         dt_serial = timed(update_step, probe=(rank == 0))
+        eager[0] = False
         hip.check(lib.dppo_tune_set(2, overlap), "dppo_tune_set")
     probe = None
     if rank == 0:
@@ -304,6 +320,7 @@ def main():
             "value": samples_per_s, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_update, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.prec, "data": "synthetic",
+            "launch": "eager" if graphed is None else "hipGraph replay of the update step (captured once in warm-up)",
             "config": {"workload": "hopper-medium-v2 ft_ppo_diffusion_mlp K=20 Kft=10 Ta=4 (BASELINE configs[1])",
                        "n_envs_per_gpu": args.n_envs, "minibatch_per_gpu": args.batch,
                        "rollout_rows_per_gpu": R, "parallelism": f"dp{world} (env-sharded, RCCL grad all-reduce)"},

@@ -429,7 +429,7 @@ static void mlp_forward(const dppo_net_desc& d, const float* prm, const char* pk
 // Independent parts of one call run on side streams so that their kernels fill each other's gaps (the persistent
 // row-tile kernels leave CUs idle in their last round of tiles; the small reductions are latency-bound).  Fork / join
 // through events: legal under stream capture too.  Tuning knob 2 turns it off (one stream, for per-kernel timing).
-//   side 0: the critic half of a PPO update;  side 1 / 2: the bias / time-embedding gradient tail of the actor / critic
+//   side 0: the critic pipeline of a PPO update;  side 1: the bias / time-embedding gradient tail of the actor
 static int g_overlap = 1;
 static int g_gate_critic = 0;  // tuning knob 10: measured 77 -> 74 M samples/s when on (letting the critic run ahead alone is better)
 static int g_side_low_priority = 0;  // read when a side stream is first created
@@ -449,7 +449,11 @@ static SideStream* side_stream(int idx) {
     // beyond the intent, so the default is equal priority and first come, first served.
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    if (hipStreamCreateWithPriority(&t.s, hipStreamNonBlocking, g_side_low_priority ? least : 0) != hipSuccess) return nullptr;
+    if (g_side_low_priority) {
+      if (hipStreamCreateWithPriority(&t.s, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
+    } else if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) {
+      return nullptr;
+    }
     if (hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&t.join, hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&t.gate, hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -458,7 +462,10 @@ static SideStream* side_stream(int idx) {
   return &t;
 }
 static hipStream_t fork_side(hipStream_t main, int idx = 0) {  // returns the stream the independent part should use
-  SideStream* t = g_overlap ? side_stream(idx) : nullptr;
+  // g_overlap: 0 = none, 1 = every side stream, other values = bit mask over the side-stream indices, shifted by one
+  // (e.g. 2 = the critic pipeline's only)
+  const int mask = g_overlap == 1 ? 7 : g_overlap >> 1;
+  SideStream* t = ((mask >> idx) & 1) ? side_stream(idx) : nullptr;
   if (t == nullptr) return main;
   (void)hipEventRecord(t->fork, main);
   (void)hipStreamWaitEvent(t->s, t->fork, 0);
@@ -620,7 +627,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       if (!bout_done) so.out[so.n_slots] = grad + pl.bout, so.n[so.n_slots] = d.out_dim, ++so.n_slots;  // the d_out slot
       // the latency-bound tail (bias sums, time-embedding gradient; they share B.part) runs beside the weight-gradient
       // GEMMs (which share B.slab and stay in order on s)
-      hipStream_t aux = fork_side(s, aux_idx);
+      hipStream_t aux = aux_idx >= 0 ? fork_side(s, aux_idx) : s;
       launch_reduce_slots(B.tile_colsum, B.tiles, H, so, aux);
       if (d.kind == 0) time_embedding_grad<P>(d, prm, pk, L, M, B, B.dh_all[0], grad, krow, ksteps, Kft, aux);
       weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.hE, H, H, M, B, grad + pl.Wout, H, s, true);
@@ -630,7 +637,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       }
       weight_grad<P>(B.dh_all[0], H, H, B.in, L.Kp0, d.in_dim, M, B, grad + pl.W0, d.in_dim, s, true);
       flush_slabs(B, s);  // every slab of this backward in one reduction launch
-      join_side(s, aux, aux_idx);
+      if (aux_idx >= 0) join_side(s, aux, aux_idx);
       B.dh0_final = B.dh_all[0];
       return;
     }
@@ -1104,13 +1111,15 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
     if (gmom == nullptr) la.n_count = (double)N;  // = what adv_moments leaves in moments[2], without waiting for it
     launch_ppo_loss<P>(la, s2);
     la.brow = W.brow, la.n_count = 0;
-    mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s2, fuse_bout, 2);
+    // (no tail stream of its own: a fork from a forked stream crashes hipGraph capture on ROCm 7.0 at capture end, and
+    // the critic's tail is one 10-us reduction)
+    mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s2, fuse_bout, -1);
   }
   // actor half
   if (!actor_first) mlp_forward<P>(a, ap, ak, LA, N, W.A, true, s);
   la.part = two_streams ? 1 : 3, la.partial = W.loss_partial;
   launch_ppo_loss<P>(la, s);
-  if (!two_streams) mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s, fuse_bout, 2);
+  if (!two_streams) mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s, fuse_bout, -1);
   mlp_backward<P>(a, ap, ak, LA, N, W.A, agrad, W.krow, ksteps, Kft, s, fuse_bout);
   if (a.cond_hidden > 0) cond_backward<P>(a, ap, ak, LA, N, W.A, W.A.dh0_final, W.C.in, agrad, s);
   join_side(s, s2);
@@ -1165,6 +1174,15 @@ int dppo_adamw_step(float* params, const float* grad, float* exp_avg, float* exp
   return check_launch();
 }
 
+
+int dppo_adamw_step_dev(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t* step_dev,
+                        const float* lr_dev, double beta1, double beta2, double eps, double weight_decay,
+                        const double* sq_norm, double max_norm, dppo_stream_t stream) {
+  if (!params || !grad || !exp_avg || !exp_avg_sq || !step_dev || !lr_dev || n < 1) return fail(-1, "bad argument");
+  launch_adamw_dev(params, grad, exp_avg, exp_avg_sq, n, step_dev, lr_dev, beta1, beta2, (float)eps, weight_decay, sq_norm,
+                   (float)max_norm, (hipStream_t)stream);
+  return check_launch();
+}
 
 // ---- measurement hook ----------------------------------------------------------------------------------
 int dppo_probe_arm(int kernel_id, int max_launches) {

@@ -163,6 +163,9 @@ void launch_gae(const double* reward, const float* values, const float* terminat
                 int E, double gamma, double lam, double rconst, double* adv64, double* ret64, float* adv32,
                 float* ret32, hipStream_t s);
 void launch_sq_norm(const float* g, int64_t n, double* scratch, double* out, hipStream_t s);
+void launch_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, int32_t* step_dev, const float* lr_dev,
+                      double beta1, double beta2, float eps, double weight_decay, const double* sq_norm, float max_norm,
+                      hipStream_t s);
 void launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr_wd_mul, float one_m_b1, float b2,
                   float one_m_b2, float step_size, float bc2_sqrt, float eps, const double* sq_norm, float max_norm,
                   hipStream_t s);

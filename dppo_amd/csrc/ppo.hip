@@ -820,6 +820,44 @@ __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, int64
   m[i] = mi;
   v[i] = vi;
 }
+// The same with the step count and the learning rate read from device memory, so that a captured graph of the update
+// replays correctly: step t = *step_dev + 1 (adamw_tick_kernel increments it after the launch), lr = *lr_dev.
+__global__ __launch_bounds__(256) void adamw_dev_kernel(float* p, const float* g, float* m, float* v, int64_t n,
+                                                        const int32_t* step_dev, const float* lr_dev, double beta1,
+                                                        double beta2, float eps, double weight_decay, const double* sq_norm,
+                                                        float max_norm) {
+  __shared__ float c[4];
+  if (threadIdx.x == 0) {
+    const double t = (double)(step_dev[0] + 1), lr = (double)lr_dev[0];
+    const double bc1 = 1.0 - pow(beta1, t), bc2 = 1.0 - pow(beta2, t);
+    c[0] = (float)(1.0 - lr * weight_decay), c[1] = (float)(lr / bc1), c[2] = (float)sqrt(bc2);
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float gi = g[i];
+  if (sq_norm != nullptr) {
+    const float total = (float)sqrt(sq_norm[0]);
+    gi *= fminf(max_norm / (total + 1e-6f), 1.0f);
+  }
+  const float one_m_b1 = (float)(1.0 - beta1), b2 = (float)beta2, one_m_b2 = (float)(1.0 - beta2);
+  float pi = p[i] * c[0];
+  float mi = m[i];
+  mi = mi + one_m_b1 * (gi - mi);
+  const float vi = v[i] * b2 + one_m_b2 * (gi * gi);
+  pi = pi - c[1] * (mi / (sqrtf(vi) / c[2] + eps));
+  p[i] = pi, m[i] = mi, v[i] = vi;
+}
+__global__ void adamw_tick_kernel(int32_t* step_dev) { step_dev[0] += 1; }
+void launch_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, int32_t* step_dev, const float* lr_dev,
+                      double beta1, double beta2, float eps, double weight_decay, const double* sq_norm, float max_norm,
+                      hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(adamw_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, step_dev, lr_dev,
+                     beta1, beta2, eps, weight_decay, sq_norm, max_norm);
+  hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, s, step_dev);
+}
+
 void launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr_wd_mul, float one_m_b1, float b2,
                   float one_m_b2, float step_size, float bc2_sqrt, float eps, const double* sq_norm, float max_norm,
                   hipStream_t s) {

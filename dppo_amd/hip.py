@@ -77,6 +77,7 @@ SYMBOLS = {
                                    _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P]),
     "dppo_grad_sq_norm": (_I, [_P, _L, _P, _P, _P]),
     "dppo_adamw_step": (_I, [_P, _P, _P, _P, _L, _I, _D, _D, _D, _D, _D, _P, _D, _P]),
+    "dppo_adamw_step_dev": (_I, [_P, _P, _P, _P, _L, _P, _P, _D, _D, _D, _D, _P, _D, _P]),
     "dppo_probe_arm": (_I, [_I, _I]),
     "dppo_probe_collect": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "dppo_tune_set": (_I, [_I, _I]),

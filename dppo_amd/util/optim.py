@@ -21,6 +21,11 @@ class FlatAdamW:
         self.exp_avg = torch.zeros_like(flat_params)
         self.exp_avg_sq = torch.zeros_like(flat_params)
         self.step_count = 0
+        # step count and learning rate also live on the device (dppo_adamw_step_dev): a captured graph of the update
+        # replays without any argument changing from step to step
+        self._step_dev = torch.zeros(1, dtype=torch.int32, device=flat_params.device)
+        self._lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=flat_params.device)
+        self._lr_host = float(lr)
         self._norm = torch.zeros(1, dtype=torch.float64, device=flat_params.device)
         self._scratch = torch.zeros(1024, dtype=torch.float64, device=flat_params.device)
         # torch-optimizer look-alike for LR schedulers
@@ -36,15 +41,22 @@ class FlatAdamW:
         ``sq_norm`` -- e.g. an all-reduced value -- is given)."""
         assert grad.numel() == self.p.numel() and grad.is_contiguous()
         self.step_count += 1
-        lr = self.param_groups[0]["lr"]
+        self.sync_lr()
         norm_ptr = None
         if max_norm is not None:
             norm_ptr = (sq_norm if sq_norm is not None else self.sq_norm(grad)).data_ptr()
-        hip.check(hip.load().dppo_adamw_step(self.p.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(),
-                                             self.exp_avg_sq.data_ptr(), self.p.numel(), self.step_count, float(lr),
-                                             float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                                             float(self.weight_decay), norm_ptr, float(max_norm or 0.0),
-                                             hip.stream()), "dppo_adamw_step")
+        hip.check(hip.load().dppo_adamw_step_dev(
+            self.p.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.p.numel(),
+            self._step_dev.data_ptr(), self._lr_dev.data_ptr(), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+            float(self.weight_decay), norm_ptr, float(max_norm or 0.0), hip.stream()), "dppo_adamw_step_dev")
+
+    def sync_lr(self):
+        """Push a changed ``param_groups[0]['lr']`` (LR schedulers) to the device copy.  Never inside a graph capture: a
+        captured fill would pin the old value; callers that replay graphs call this before the replay."""
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_host and not torch.cuda.is_current_stream_capturing():
+            self._lr_dev.fill_(lr)
+            self._lr_host = lr
 
 
 _side_streams = {}

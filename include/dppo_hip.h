@@ -220,6 +220,12 @@ int dppo_grad_sq_norm(const float* grad, int64_t n, double* scratch, double* out
 int dppo_adamw_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
                     double lr, double beta1, double beta2, double eps, double weight_decay, const double* sq_norm,
                     double max_norm, dppo_stream_t stream);
+/* The same with the step count and the learning rate in device memory (step_dev[0] = steps taken so far, incremented by
+ * the call; lr_dev[0]): nothing in the argument list changes from step to step, so a captured hipGraph of the update can
+ * be replayed. */
+int dppo_adamw_step_dev(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t* step_dev,
+                        const float* lr_dev, double beta1, double beta2, double eps, double weight_decay,
+                        const double* sq_norm, double max_norm, dppo_stream_t stream);
 
 /* ---- measurement hook (bench.py only; process-wide, not thread-safe, off by default) ----------- */
 /* While armed for a kernel, each of its launches is bracketed by HIP events on the launch stream.

@@ -104,3 +104,41 @@ def test_agent_runs_and_learns_something(tmp_path, monkeypatch):
     assert ck["itr"] == 2 and "actor_ft.mlp_mean.layers.1.l1.weight" in ck["model"]
     assert torch.equal(ck["model"]["actor_ft.mlp_mean.layers.0.weight"].cpu(),
                        agent.model.actor_ft.mlp_mean.layers[0].weight.detach().cpu())
+
+
+def test_graph_replayed_update_equals_eager_update():
+    """dppo_amd.util.graphed.GraphedUpdate: three minibatch updates replayed from captured hipGraphs leave the same
+    parameters and statistics as the same three updates issued launch by launch (device-resident AdamW step / lr)."""
+    import copy
+
+    import bench
+    from dppo_amd.parallel import DataParallel
+    from dppo_amd.util.graphed import GraphedUpdate
+    from dppo_amd.util.optim import FlatAdamW, step_and_repack
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    torch.manual_seed(7)
+    m0 = bench.build_model(str(dev), "bf16")
+    R, N = 1200, 6000
+    ro = bench.make_rollout(m0, R, 1, dev, gen)
+    mbs = [torch.randperm(R * bench.KFT, device=dev, generator=gen)[:N].contiguous() for _ in range(5)]
+    out = []
+    for graphed in (False, True):
+        m = copy.deepcopy(m0)
+        oa = FlatAdamW(m.actor_ft.flat_params(), lr=1e-4, weight_decay=0.0)
+        oc = FlatAdamW(m.critic.flat_params(), lr=1e-3, weight_decay=0.0)
+        g = GraphedUpdate(m, oa, oc, DataParallel(m, 1), ro, N, bench.ACT_STEPS, n_time=bench.K, warmup=0) if graphed else None
+        for i, inds in enumerate(mbs):
+            if i == 3:  # an LR scheduler steps between iterations
+                oa.param_groups[0]["lr"] = 5e-5
+            if graphed and i >= 2:  # the first two steps are the helper's eager warm-up on these very minibatches
+                g.step(inds)
+            else:
+                if graphed:
+                    g.inds.copy_(inds)
+                m.ppo_update(*ro, inds, reward_horizon=bench.ACT_STEPS)
+                step_and_repack(m, oa, oc, n_time=bench.K)
+        out.append((m.actor_ft.flat_params().clone(), m.critic.flat_params().clone(), m._stats.clone()))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+

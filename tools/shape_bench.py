@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--prec", default="bf16")
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--graph", action="store_true", help="replay the update as captured hipGraphs")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     for name in args.shapes.split(","):
@@ -59,7 +60,16 @@ def main():
         oa = FlatAdamW(m.actor_ft.flat_params(), lr=1e-5, weight_decay=0.0)
         oc = FlatAdamW(m.critic.flat_params(), lr=1e-4, weight_decay=0.0)
 
+        graphed = None
+        if args.graph:
+            from dppo_amd.parallel import DataParallel
+            from dppo_amd.util.graphed import GraphedUpdate
+            graphed = GraphedUpdate(m, oa, oc, DataParallel(m, 1), (obs.reshape(R, -1), chains, ret, val, adv, logp), N, c["ta"])
+
         def update():
+            if graphed is not None:
+                graphed.step(inds)
+                return
             m.ppo_update(obs.reshape(R, -1), chains, ret, val, adv, logp, inds, reward_horizon=c["ta"])
             step_and_repack(m, oa, oc)
 
