@@ -488,6 +488,17 @@ static void join_side(hipStream_t main, hipStream_t sidestream, int idx = 0) {
 static int g_dbg = 0;  // tuning knob 8: timing experiments on the fused backward (results are wrong while it is set)
 static int g_tn_target = 512;      // tuning knob 3: workgroups a weight-gradient GEMM aims for (tiles x row splits)
 static int g_tn_max_splits = 128;  // tuning knob 4: cap on its row splits (each split costs one fp32 slab of the output)
+// Time-embedding gradient through the first layer's weight-gradient GEMM: with a one-hot of the row's denoising step k in
+// the K padding of the input rows, dW0's extra columns are S[h][k] = sum over the rows of step k of dh0[row][h], and
+// d loss / d temb[k] = W0[:, temb columns]^T S[:, k] -- no second pass over dh0, no segmented reduction (tuning knob 11).
+static int g_temb_onehot = 1;
+template <class P>
+static int temb_onehot_col(const dppo_net_desc& d, const PackLayout& L, int Kft, const MlpBufs<P>& B) {
+  if (!g_temb_onehot || d.kind != 0 || !fused_ok<P>(d) || Kft < 1) return -1;
+  if (d.cond_out > 0 && d.cond_out % 16) return -1;  // the encoder's epilogue zero-fills up to a multiple of 16 columns
+  if (L.Kp0 - d.in_dim < Kft || (size_t)(d.hidden + d.time_dim) * Kft > B.part_floats) return -1;
+  return d.in_dim;
+}
 template <class P>
 static void flush_slabs(MlpBufs<P>& B, hipStream_t s) {
   launch_slab_reduce_batch(B.slab_jobs, s);
@@ -497,7 +508,8 @@ static void flush_slabs(MlpBufs<P>& B, hipStream_t s) {
 // 512 x 64 block shape of gemm_tn covers it in one output tile; the slab reduce transposes back.
 template <class P>
 static void weight_grad(const void* A, int lda, int N1, const void* Bm, int ldb, int N2, int64_t M, MlpBufs<P>& B,
-                        float* gw, int ldgw, hipStream_t s, bool defer = false) {
+                        float* gw, int ldgw, hipStream_t s, bool defer = false, int n2a = -1, float* gw2 = nullptr,
+                        int ldgw2 = 0) {  // n2a >= 0: columns [n2a, N2) of the result go to gw2 instead (never with a thin N1)
   const bool swap = N1 <= 64 && N2 > 64;
   if (swap) {
     const void* tp = A;
@@ -512,7 +524,7 @@ static void weight_grad(const void* A, int lda, int N1, const void* Bm, int ldb,
   const int64_t max_splits = (M + 63) / 64;
   if (splits > max_splits) splits = max_splits;
   if (splits > g_tn_max_splits) splits = g_tn_max_splits;
-  if ((size_t)splits * N1 * N2 > B.slab_floats - B.slab_used || B.slab_jobs.n == MAX_SLAB_JOBS) flush_slabs(B, s);
+  if ((size_t)splits * N1 * N2 > B.slab_floats - B.slab_used || B.slab_jobs.n + 2 > MAX_SLAB_JOBS) flush_slabs(B, s);
   while (splits > 1 && (size_t)splits * N1 * N2 > B.slab_floats) --splits;
   if (splits >= 8) splits = splits / 8 * 8;  // a multiple of the XCD count keeps one split's tiles on one XCD
   int64_t rps = (M + splits - 1) / splits;
@@ -527,6 +539,13 @@ static void weight_grad(const void* A, int lda, int N1, const void* Bm, int ldb,
   launch_gemm_tn<P>(t, s);
   SlabJob& j = B.slab_jobs.j[B.slab_jobs.n++];
   j.slab = sub, j.out = gw, j.splits = (int)splits, j.rows = N1, j.cols = N2, j.lds = N2, j.ldo = ldgw, j.transpose = swap ? 1 : 0;
+  j.c0 = 0;
+  if (n2a >= 0 && !swap) {
+    j.cols = n2a;
+    SlabJob& j2 = B.slab_jobs.j[B.slab_jobs.n++];
+    j2 = j;
+    j2.out = gw2, j2.ldo = ldgw2, j2.c0 = n2a, j2.cols = N2 - n2a;
+  }
   if (!defer) flush_slabs(B, s);  // deferred: the caller flushes once after its last GEMM (same stream)
 }
 
@@ -629,14 +648,23 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       // GEMMs (which share B.slab and stay in order on s)
       hipStream_t aux = aux_idx >= 0 ? fork_side(s, aux_idx) : s;
       launch_reduce_slots(B.tile_colsum, B.tiles, H, so, aux);
-      if (d.kind == 0) time_embedding_grad<P>(d, prm, pk, L, M, B, B.dh_all[0], grad, krow, ksteps, Kft, aux);
+      const int oh = d.kind == 0 ? temb_onehot_col<P>(d, L, Kft, B) : -1;  // must match what the row builder was told
+      if (d.kind == 0 && oh < 0) time_embedding_grad<P>(d, prm, pk, L, M, B, B.dh_all[0], grad, krow, ksteps, Kft, aux);
       weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.hE, H, H, M, B, grad + pl.Wout, H, s, true);
       for (int b = nb - 1; b >= 0; --b) {
         weight_grad<P>(B.dh_all[b + 1], H, H, B.a2[b], H, H, M, B, grad + pl.l2w[b], H, s, true);
         weight_grad<P>(B.dz1_all[b], H, H, B.a1[b], H, H, M, B, grad + pl.l1w[b], H, s, true);
       }
-      weight_grad<P>(B.dh_all[0], H, H, B.in, L.Kp0, d.in_dim, M, B, grad + pl.W0, d.in_dim, s, true);
+      if (oh >= 0)  // + Kft one-hot columns: their block of the result is S[h][k] (B.part), see temb_onehot_col()
+        weight_grad<P>(B.dh_all[0], H, H, B.in, L.Kp0, d.in_dim + Kft, M, B, grad + pl.W0, d.in_dim, s, true, d.in_dim, B.part,
+                       Kft);
+      else
+        weight_grad<P>(B.dh_all[0], H, H, B.in, L.Kp0, d.in_dim, M, B, grad + pl.W0, d.in_dim, s, true);
       flush_slabs(B, s);  // every slab of this backward in one reduction launch
+      if (oh >= 0)
+        launch_time_backward_from_sums(prm + pl.te1_w, prm + pl.te1_b, prm + pl.te2_w, B.part, prm + pl.W0, d.in_dim,
+                                       d.act_flat, H, B.part + (size_t)H * Kft, ksteps, Kft, d.time_dim, grad + pl.te1_w,
+                                       grad + pl.te1_b, grad + pl.te2_w, grad + pl.te2_b, s);
       if (aux_idx >= 0) join_side(s, aux, aux_idx);
       B.dh0_final = B.dh_all[0];
       return;
@@ -898,7 +926,7 @@ static int logprob_impl(const dppo_net_desc& d, const float* prm, const char* pk
   memset(&br, 0, sizeof(br));
   br.chains = chains, br.obs = obs, br.temb = (const float*)(pk + L.temb), br.ksteps = ksteps;
   br.Kft = Kft, br.AF = d.act_flat, br.td = d.time_dim, br.cond = d.cond_dim, br.M = M, br.obs_in_a = 1;
-  br.inA = B.in, br.KpA = L.Kp0, br.brow = brow, br.krow = krow;
+  br.inA = B.in, br.KpA = L.Kp0, br.brow = brow, br.krow = krow, br.onehot0 = -1;
   if (d.cond_hidden > 0) br.obs_in_a = 0, br.inC = B.cin, br.KpC = L.Kpc;
   launch_build_rows<P>(br, s);
   if (d.cond_hidden > 0) cond_encode<P>(d, prm, pk, L, M, B.cin, B, B.in, nullptr, 0, false, s);
@@ -961,7 +989,7 @@ static int bc_impl(const dppo_net_desc& d, const float* prm, const char* pk, con
   memset(&br, 0, sizeof(br));
   br.chains = chains, br.obs = obs, br.temb = (const float*)(pk + L.temb), br.ksteps = ksteps;
   br.Kft = Kft, br.AF = d.act_flat, br.td = d.time_dim, br.cond = d.cond_dim, br.M = M, br.obs_in_a = 1;
-  br.inA = B.in, br.KpA = L.Kp0, br.brow = brow, br.krow = krow;
+  br.inA = B.in, br.KpA = L.Kp0, br.brow = brow, br.krow = krow, br.onehot0 = temb_onehot_col<P>(d, L, Kft, B);
   if (d.cond_hidden > 0) br.obs_in_a = 0, br.inC = B.cin, br.KpC = L.Kpc;
   launch_build_rows<P>(br, s);
   if (d.cond_hidden > 0) cond_encode<P>(d, prm, pk, L, M, B.cin, B, B.in, nullptr, 0, true, s);
@@ -1072,6 +1100,7 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   br.Kft = Kft, br.AF = a.act_flat, br.td = a.time_dim, br.cond = a.cond_dim, br.M = N;
   br.inA = W.A.in, br.KpA = LA.Kp0, br.inC = W.C.in, br.KpC = LC.Kp0, br.brow = W.brow, br.krow = W.krow;
   br.obs_in_a = a.cond_hidden > 0 ? 0 : 1;  // with cond_mlp the encoder fills the state columns (from the critic's obs rows)
+  br.onehot0 = temb_onehot_col<P>(a, LA, Kft, W.A);
   const bool split = s2 != s;
   if (split) {
     BuildRows bc = br;  // critic rows only, on the critic's stream
@@ -1239,6 +1268,10 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 10) {
     g_gate_critic = value;
+    return 0;
+  }
+  if (knob == 11) {
+    g_temb_onehot = value;
     return 0;
   }
   return fail(-1, "unknown tuning knob %d", knob);

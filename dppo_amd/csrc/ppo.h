@@ -32,6 +32,9 @@ struct BuildRows {
   const dppo_step* ksteps;
   int Kft, AF, td, cond;
   int obs_in_a;  // 1: the observation goes into inA's state columns; 0: zeros there (a cond_mlp encoder fills them)
+  int onehot0;   // >= 0: column onehot0 + k of inA is set to 1 (one-hot of the row's denoising step in the K padding: the
+                 // first layer's weight-gradient GEMM then returns sum_{rows of step k} dh0 as extra columns, which is
+                 // all the time-embedding gradient needs); -1: off.  The forward never sees these columns (zero weights).
   int64_t M;
   void* inA;  // [M][KpA] elem : [x_k | temb(t_k) | obs | 0]
   int KpA;
@@ -138,6 +141,11 @@ void launch_adv_moments(const float* adv_k, const int32_t* brow, int64_t N, doub
 void launch_temb_segsum(const float* dtemb, int ld, const int32_t* krow, int64_t M, int Kft, int td, float* partial,
                         int blocks, hipStream_t s);
 // G[k][td] (already reduced) -> grads of time_embedding.{1,3}.{weight,bias}; ksteps[k].t gives the time
+// G[k][j] = sum_h W0[h*ldw0 + AF + j] * S[h*Kft + k] (S = per-step column sums of dh0; G: Kft*td floats of scratch), then
+// the time MLP's backward
+void launch_time_backward_from_sums(const float* w1, const float* b1, const float* w2, const float* S, const float* W0,
+                                    int ldw0, int AF, int H, float* G, const dppo_step* ksteps, int Kft, int td, float* gw1,
+                                    float* gb1, float* gw2, float* gb2, hipStream_t s);
 void launch_time_backward(const float* w1, const float* b1, const float* w2, const float* G, const dppo_step* ksteps,
                           int Kft, int td, float* gw1, float* gb1, float* gw2, float* gb2, hipStream_t s);
 
@@ -145,9 +153,9 @@ void launch_time_backward(const float* w1, const float* b1, const float* w2, con
 // several split-M slabs summed in ONE launch (blockIdx.y = job): the weight-gradient GEMMs of a network each write their
 // own slab, and their reductions -- latency-bound alone -- run together after the last GEMM
 struct SlabJob {
-  const float* slab;  // [splits][rows][lds]
+  const float* slab;  // [splits][rows][lds]; columns c0 .. c0 + cols of every row are reduced
   float* out;         // [rows][ldo], or its transpose when `transpose`
-  int splits, rows, cols, lds, ldo, transpose;
+  int splits, rows, cols, lds, ldo, transpose, c0;
 };
 constexpr int MAX_SLAB_JOBS = 24;
 struct SlabJobs {

@@ -143,6 +143,8 @@ __global__ __launch_bounds__(256) void build_rows_kernel(const BuildRows a) {
           x = a.temb[(size_t)t * a.td + (c - a.AF)];
         else if (c < a.AF + a.td + a.cond && a.obs_in_a)
           x = ob[c - a.AF - a.td];
+        else if (a.onehot0 >= 0 && c == a.onehot0 + k)
+          x = 1.f;
         v[e] = x;
       }
     } else {
@@ -629,11 +631,12 @@ void launch_temb_segsum(const float* dtemb, int ld, const int32_t* krow, int64_t
 
 // single block: recompute the tiny time MLP per fine-tuned step and back-propagate G[k][td] through it
 __global__ __launch_bounds__(256) void time_backward_kernel(const float* w1, const float* b1, const float* w2,
-                                                            const float* G, const dppo_step* ksteps, int Kft, int td,
+                                                            const float* G_in, const dppo_step* ksteps, int Kft, int td,
                                                             float* gw1, float* gb1, float* gw2, float* gb2) {
   extern __shared__ float sh[];  // per k: e0[td], z1[2td], a1[2td], dz1[2td]
   const int per = 7 * td;
   const int tid = threadIdx.x;
+  const float* G = G_in;
   for (int i = tid; i < Kft * td; i += 256) {
     const int k = i / td, j = i % td;
     sh[k * per + j] = sinus_feat(ksteps[k].t, j, td);
@@ -682,6 +685,22 @@ void launch_time_backward(const float* w1, const float* b1, const float* w2, con
   hipLaunchKernelGGL(time_backward_kernel, dim3(1), dim3(256), (size_t)Kft * 7 * td * sizeof(float), s, w1, b1, w2, G,
                      ksteps, Kft, td, gw1, gb1, gw2, gb2);
 }
+// G[k][j] = sum_h W0[h*ldw0 + AF + j] * S[h*Kft + k]: one wave per output, lanes over h (a single block looping over h
+// costs 512 dependent L2 latencies: measured 150 us on the critical path)
+__global__ __launch_bounds__(64) void temb_from_sums_kernel(const float* S, const float* W0, int ldw0, int AF, int H, int Kft,
+                                                            int td, float* G) {
+  const int k = blockIdx.x / td, j = blockIdx.x % td;
+  float acc = 0.f;
+  for (int h = threadIdx.x; h < H; h += 64) acc += W0[(size_t)h * ldw0 + AF + j] * S[(size_t)h * Kft + k];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if (threadIdx.x == 0) G[blockIdx.x] = acc;
+}
+void launch_time_backward_from_sums(const float* w1, const float* b1, const float* w2, const float* S, const float* W0,
+                                    int ldw0, int AF, int H, float* G, const dppo_step* ksteps, int Kft, int td, float* gw1,
+                                    float* gb1, float* gw2, float* gb2, hipStream_t s) {
+  hipLaunchKernelGGL(temb_from_sums_kernel, dim3(Kft * td), dim3(64), 0, s, S, W0, ldw0, AF, H, Kft, td, G);
+  launch_time_backward(w1, b1, w2, G, ksteps, Kft, td, gw1, gb1, gw2, gb2, s);
+}
 
 __global__ void slab_reduce_2d_kernel(const float* slab, int splits, int rows, int cols, int lds, float* out, int ldo,
                                       float scale, int transpose) {
@@ -718,9 +737,9 @@ __global__ __launch_bounds__(256) void slab_reduce_batch_kernel(const SlabJobs j
     int k = 0;
     for (; k + 8 <= J.splits; k += 8) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) p[u] += J.slab[((size_t)(k + u) * J.rows + r) * J.lds + c];
+      for (int u = 0; u < 8; ++u) p[u] += J.slab[((size_t)(k + u) * J.rows + r) * J.lds + J.c0 + c];
     }
-    for (; k < J.splits; ++k) p[k & 7] += J.slab[((size_t)k * J.rows + r) * J.lds + c];
+    for (; k < J.splits; ++k) p[k & 7] += J.slab[((size_t)k * J.rows + r) * J.lds + J.c0 + c];
     const float v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
     if (J.transpose)
       J.out[(size_t)c * J.ldo + r] = v;

@@ -243,7 +243,11 @@ int dppo_probe_collect(double* total_ms_host, int* launches_host, double* flops_
  * knob 3 / 4: weight-gradient GEMMs, workgroups aimed for (default 512) / cap on the row splits (default 128)
  * knob 7: fused kernels, bit 0 / 1 = 32-row tiles at two workgroups per CU in the backward / forward (default 0)
  * knob 8: timing experiments on the fused backward (results are wrong while set); knob 9: side streams at low priority
- * knob 5: weight-gradient GEMM kernel, 0 = register-staged (default), 1..8 = an LDS-DMA ring configuration, -1 = by shape */
+ * knob 5: weight-gradient GEMM kernel, 0 = register-staged (default), 1..8 = an LDS-DMA ring configuration, -1 = by shape
+ * knob 6: thin (512 x 64) weight-gradient tiles on / off; knob 10: critic side stream gated on the actor's forward (0 off)
+ * knob 11: time-embedding gradient from a one-hot of the denoising step in the K padding of the actor's input rows, so
+ *          the first layer's weight-gradient GEMM also yields the per-step sums of dh0 (default 1); 0 = separate
+ *          gemm_nt + segmented sum on the tail stream */
 int dppo_tune_set(int knob, int value);
 /* one bare layer GEMM: out[M][ldo] = act(X[M][Kp] . W[N][Kp]^T + bias) with elem = prec operands;
  * out_f32 and/or out_elem may be NULL; ldo >= round_up(N,16) */
