@@ -272,17 +272,21 @@ def main():
         hip.check(lib.dppo_tune_set(2, overlap), "dppo_tune_set")
     probe = None
     if rank == 0:
-        ms, cnt, fl = C.c_double(), C.c_int(), C.c_double()
-        hip.check(lib.dppo_probe_collect(C.byref(ms), C.byref(cnt), C.byref(fl)), "dppo_probe_collect")
+        ms, cnt, fl, nb_lib = C.c_double(), C.c_int(), C.c_double(), C.c_double()
+        hip.check(lib.dppo_probe_collect_bytes(C.byref(ms), C.byref(cnt), C.byref(fl), C.byref(nb_lib)),
+                  "dppo_probe_collect_bytes")
         if cnt.value > 0:
             avg_ms = ms.value / cnt.value
             tf = fl.value / cnt.value / (avg_ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.prec]
-            names = {1: "gemm_nt_kernel (H x H layers, layered path)", 2: "gemm_tn_kernel (H x H weight gradients)",
+            grouped = nb_lib.value > 0  # knob 12: every weight gradient of a backward pass in one launch
+            names = {1: "gemm_nt_kernel (H x H layers, layered path)",
+                     2: "gemm_tn_group_kernel (all weight gradients of one network's backward pass, one launch)"
+                     if grouped else "gemm_tn_kernel (H x H weight gradients)",
                      3: "fused_forward_kernel (actor_ft + critic)", 4: "fused_backward_kernel (actor_ft + critic)",
                      5: "sample_chain_kernel"}
             traffic = None  # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)
-            tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_probe{args.probe}_{args.prec}.json")
+            tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_probe{args.probe}{'g' if grouped else ''}_{args.prec}.json")
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             probe = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
@@ -302,6 +306,8 @@ def main():
                 nbytes = sum(2 * nb * (args.batch * 2 * h * es + h * h * 4) for h, nb in shapes)
                 nlaunch = sum(2 * nb for _, nb in shapes)
                 b_per = nbytes / nlaunch
+                if grouped:  # the library's own count: per GEMM of the group, M (N1 + N2) elements + N1 N2 floats
+                    b_per = nb_lib.value / cnt.value
                 intensity = (fl.value / cnt.value) / b_per
                 if intensity < peak * 1e12 / (HBM_PEAK_GBS * 1e9):
                     gbs = b_per / (avg_ms * 1e-3) / 1e9

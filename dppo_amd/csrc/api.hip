@@ -171,12 +171,14 @@ static bool fused_ok(const dppo_net_desc& d) {
 // ------------------------------------------------------------------------------------------------
 // pack
 // ------------------------------------------------------------------------------------------------
+static int g_pack_one = 1;  // tuning knob 13: one launch per network for all of its kernel-ready images
 template <class P>
 static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char* pk, hipStream_t s) {
   const ParamLayout pl = param_layout(d);
   const PackLayout L = pack_layout<P>(d, n_time);
   const int H = d.hidden;
-  if (d.kind == 0)
+  const bool one_launch = fused_ok<P>(d) && g_pack_one && pack_net_supports(d.time_dim);
+  if (d.kind == 0 && !one_launch)
     launch_time_table(prm + pl.te1_w, prm + pl.te1_b, prm + pl.te2_w, prm + pl.te2_b, d.time_dim, n_time,
                       (float*)(pk + L.temb), s);
   if (!fused_ok<P>(d)) {  // row-major operand copies of the layer-by-layer gemm_nt path (unused by the fused kernels)
@@ -192,7 +194,8 @@ static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char*
     launch_transpose_cast<P>(prm + pl.Wout, d.out_dim, H, H, 0, pk + L.WoutT, L.Kpo, s);
   }
   // W0tT[j][h] = W0[h][act_flat + j]
-  if (d.kind == 0) launch_transpose_cast<P>(prm + pl.W0, H, d.time_dim, d.in_dim, d.act_flat, pk + L.W0tT, H, s);
+  if (d.kind == 0 && !one_launch)
+    launch_transpose_cast<P>(prm + pl.W0, H, d.time_dim, d.in_dim, d.act_flat, pk + L.W0tT, H, s);
   if (d.cond_hidden > 0) {
     launch_cast_pad<P>(prm + pl.c1w, d.cond_hidden, d.cond_dim, d.cond_dim, pk + L.Wc1, L.Kpc, s);
     launch_cast_pad<P>(prm + pl.c2w, d.cond_out, d.cond_hidden, d.cond_hidden, pk + L.Wc2, L.C1p, s);
@@ -205,8 +208,9 @@ static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char*
     const FusedGeom fg = fused_geom<P>(d);
     // forward stream [L0][b: l1, l2]... and backward stream, top down: [dh = d_out . Wout][b = nb-1..0: W2^T, W1^T]
     // ("feature f, contraction index k" of a transposed layer is W[k][f] = W[k*H + f]); all in one launch
-    PackStream ps;
-    memset(&ps, 0, sizeof(ps));
+    PackNet pn;
+    memset(&pn, 0, sizeof(pn));
+    PackStream& ps = pn.ps;
     ps.TPW = g.TPW;
     u32x4* fwd = (u32x4*)(pk + L.sstream);
     u32x4* bwd = (u32x4*)(pk + L.bstream);
@@ -220,8 +224,23 @@ static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char*
       ps.layer[ps.n_layers++] = PackLayer{prm + pl.l2w[b], 1, H, H, g.KSH, pos, bwd, fg.total_pos};
       ps.layer[ps.n_layers++] = PackLayer{prm + pl.l1w[b], 1, H, H, g.KSH, pos + g.KSH, bwd, fg.total_pos};
     }
-    launch_pack_stream<P>(ps, s);
-    launch_pack_out<P>(prm + pl.Wout, d.out_dim, H, g.OT, g.CNT, (u32x4*)(pk + L.ostream), s);
+    if (one_launch) {  // + out-layer stream, time-embedding table and W0tT, all in the same launch
+      int maxks = 0;
+      for (int l = 0; l < ps.n_layers; ++l) maxks = ps.layer[l].KS > maxks ? ps.layer[l].KS : maxks;
+      pn.ps_x = SAMPLER_WAVES * maxks * ps.TPW;
+      pn.Wout = prm + pl.Wout, pn.out_dim = d.out_dim, pn.H = H, pn.OT = g.OT, pn.CNT = g.CNT;
+      pn.ostream = (u32x4*)(pk + L.ostream);
+      if (d.kind == 0) {
+        pn.te_w1 = prm + pl.te1_w, pn.te_b1 = prm + pl.te1_b, pn.te_w2 = prm + pl.te2_w, pn.te_b2 = prm + pl.te2_b;
+        pn.td = d.time_dim, pn.n_time = n_time, pn.temb = (float*)(pk + L.temb);
+        pn.tsrc = prm + pl.W0, pn.t_rows = H, pn.t_cols = d.time_dim, pn.t_lds = d.in_dim, pn.t_coff = d.act_flat;
+        pn.t_ldd = H, pn.tdst = pk + L.W0tT;
+      }
+      launch_pack_net<P>(pn, s);
+    } else {
+      launch_pack_stream<P>(ps, s);
+      launch_pack_out<P>(prm + pl.Wout, d.out_dim, H, g.OT, g.CNT, (u32x4*)(pk + L.ostream), s);
+    }
   }
   return check_launch();
 }
@@ -271,6 +290,7 @@ struct MlpBufs {  // activations of one network for M rows
   float* slab;  // split-M partial weight gradients: a pool, one sub-slab per pending weight-gradient GEMM
   size_t slab_used;   // floats handed out since the last flush
   SlabJobs slab_jobs; // reductions pending on the pool (flush_slabs)
+  GemmTNGroup tn_group;  // weight-gradient GEMMs pending on the pool: launched together by flush_slabs
   float* part;  // column-sum / segment-sum partials
   size_t slab_floats, part_floats;
 };
@@ -335,7 +355,7 @@ static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, b
     // a pool for all of one backward's GEMMs (2 per block + first and out layer), reduced together at the end
     B.slab_floats = (size_t)2 * (nb > 0 ? nb : 1) * splits_hh * (size_t)H * H + 2 * alt;
     B.slab = (float*)c.take(B.slab_floats * 4);
-    B.slab_used = 0, B.slab_jobs.n = 0;
+    B.slab_used = 0, B.slab_jobs.n = 0, B.tn_group.n = 0;
     B.part_floats = (size_t)REDUCE_BLOCKS * (H > 1024 ? H : 1024);
     B.part = (float*)c.take(B.part_floats * 4);
   }
@@ -486,7 +506,8 @@ static void join_side(hipStream_t main, hipStream_t sidestream, int idx = 0) {
 }
 
 static int g_dbg = 0;  // tuning knob 8: timing experiments on the fused backward (results are wrong while it is set)
-static int g_tn_target = 512;      // tuning knob 3: workgroups a weight-gradient GEMM aims for (tiles x row splits)
+static int g_tn_group = 1;         // tuning knob 12: one launch for all weight-gradient GEMMs of a backward pass
+static int g_tn_target = 256;      // tuning knob 3: workgroups a weight-gradient GEMM aims for (tiles x row splits)
 static int g_tn_max_splits = 128;  // tuning knob 4: cap on its row splits (each split costs one fp32 slab of the output)
 // Time-embedding gradient through the first layer's weight-gradient GEMM: with a one-hot of the row's denoising step k in
 // the K padding of the input rows, dW0's extra columns are S[h][k] = sum over the rows of step k of dh0[row][h], and
@@ -501,6 +522,19 @@ static int temb_onehot_col(const dppo_net_desc& d, const PackLayout& L, int Kft,
 }
 template <class P>
 static void flush_slabs(MlpBufs<P>& B, hipStream_t s) {
+  if (B.tn_group.n > 0) {
+    GemmTNGroup& gr = B.tn_group;
+    for (int i = 1; i < gr.n; ++i)  // longest row ranges first (insertion sort: the short jobs fill the last round)
+      for (int k = i; k > 0 && gr.j[k].rows_per_split > gr.j[k - 1].rows_per_split; --k) {
+        const GemmTN t = gr.j[k];
+        gr.j[k] = gr.j[k - 1], gr.j[k - 1] = t;
+      }
+    gr.base[0] = 0;
+    for (int i = 0; i < gr.n; ++i)
+      gr.base[i + 1] = gr.base[i] + gr.j[i].splits * ((gr.j[i].N1 + 127) / 128) * ((gr.j[i].N2 + 127) / 128);
+    launch_gemm_tn_group<P>(gr, s);
+    gr.n = 0;
+  }
   launch_slab_reduce_batch(B.slab_jobs, s);
   B.slab_jobs.n = 0, B.slab_used = 0;
 }
@@ -518,13 +552,16 @@ static void weight_grad(const void* A, int lda, int N1, const void* Bm, int ldb,
     lda = ldb, ldb = ti;
     ti = N1, N1 = N2, N2 = ti;
   }
-  const bool thin = gemm_tn_thin(N1, N2);
+  const bool group = defer && g_tn_group;  // launched with the caller's other GEMMs, 128 x 128 tiles throughout
+  const bool thin = !group && gemm_tn_thin(N1, N2);
   const size_t tiles = thin ? (size_t)((N1 + 511) / 512) : (size_t)((N1 + 127) / 128) * ((N2 + 127) / 128);
   int64_t splits = (g_tn_target + tiles - 1) / tiles;
   const int64_t max_splits = (M + 63) / 64;
   if (splits > max_splits) splits = max_splits;
   if (splits > g_tn_max_splits) splits = g_tn_max_splits;
-  if ((size_t)splits * N1 * N2 > B.slab_floats - B.slab_used || B.slab_jobs.n + 2 > MAX_SLAB_JOBS) flush_slabs(B, s);
+  if ((size_t)splits * N1 * N2 > B.slab_floats - B.slab_used || B.slab_jobs.n + 2 > MAX_SLAB_JOBS ||
+      B.tn_group.n >= MAX_TN_JOBS)
+    flush_slabs(B, s);
   while (splits > 1 && (size_t)splits * N1 * N2 > B.slab_floats) --splits;
   if (splits >= 8) splits = splits / 8 * 8;  // a multiple of the XCD count keeps one split's tiles on one XCD
   int64_t rps = (M + splits - 1) / splits;
@@ -536,7 +573,10 @@ static void weight_grad(const void* A, int lda, int N1, const void* Bm, int ldb,
   float* sub = B.slab + B.slab_used;
   B.slab_used += (size_t)splits * N1 * N2;
   t.slab = sub, t.ldc = N2, t.splits = (int)splits, t.rows_per_split = (int)rps;
-  launch_gemm_tn<P>(t, s);
+  if (group)
+    B.tn_group.j[B.tn_group.n++] = t;
+  else
+    launch_gemm_tn<P>(t, s);
   SlabJob& j = B.slab_jobs.j[B.slab_jobs.n++];
   j.slab = sub, j.out = gw, j.splits = (int)splits, j.rows = N1, j.cols = N2, j.lds = N2, j.ldo = ldgw, j.transpose = swap ? 1 : 0;
   j.c0 = 0;
@@ -1048,7 +1088,7 @@ struct PpoWs {
 };
 template <class P>
 static size_t carve_ppo(Carver& c, const dppo_net_desc& a, const dppo_net_desc& cr, int64_t N, PpoWs<P>& W) {
-  W.moments = (double*)c.take(256);
+  W.moments = (double*)c.take((8 + 2 * ADV_MOMENT_BLOCKS) * sizeof(double));
   W.loss_tab = (float*)c.take(2 * 1024 * sizeof(float));
   W.loss_partial = (double*)c.take((size_t)loss_blocks(N) * 8 * sizeof(double));
   W.loss_partial_v = (double*)c.take((size_t)loss_blocks(N) * 8 * sizeof(double));
@@ -1213,6 +1253,24 @@ int dppo_adamw_step_dev(float* params, const float* grad, float* exp_avg, float*
   return check_launch();
 }
 
+int dppo_adamw_step_multi(const dppo_adamw_slot* slots, int n_slots, dppo_stream_t stream) {
+  if (!slots || n_slots < 1 || n_slots > 4) return fail(-1, "1..4 slots");
+  AdamwSlots a;
+  memset(&a, 0, sizeof(a));
+  for (int i = 0; i < n_slots; ++i) {
+    const dppo_adamw_slot& q = slots[i];
+    if (!q.params || !q.grad || !q.exp_avg || !q.exp_avg_sq || !q.step_dev || !q.lr_dev || q.n < 1)
+      return fail(-1, "bad argument in slot %d", i);
+    AdamwSlot& t = a.s[i];
+    t.p = q.params, t.g = q.grad, t.m = q.exp_avg, t.v = q.exp_avg_sq, t.n = q.n, t.step_dev = q.step_dev;
+    t.lr_dev = q.lr_dev, t.beta1 = q.beta1, t.beta2 = q.beta2, t.weight_decay = q.weight_decay, t.eps = (float)q.eps;
+    t.max_norm = (float)q.max_norm, t.sq_norm = q.sq_norm;
+  }
+  a.n = n_slots;
+  launch_adamw_multi(a, (hipStream_t)stream);
+  return check_launch();
+}
+
 // ---- measurement hook ----------------------------------------------------------------------------------
 int dppo_probe_arm(int kernel_id, int max_launches) {
   if (probe_arm(kernel_id, max_launches)) return fail(-1, "probe already armed or bad size");
@@ -1221,6 +1279,11 @@ int dppo_probe_arm(int kernel_id, int max_launches) {
 int dppo_probe_collect(double* total_ms_host, int* launches_host, double* flops_host) {
   if (!total_ms_host || !launches_host || !flops_host) return fail(-1, "null pointer");
   if (probe_collect(total_ms_host, launches_host, flops_host)) return fail(-1, "probe not armed / event error");
+  return 0;
+}
+int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* flops_host, double* bytes_host) {
+  if (!total_ms_host || !launches_host || !flops_host || !bytes_host) return fail(-1, "null pointer");
+  if (probe_collect(total_ms_host, launches_host, flops_host, bytes_host)) return fail(-1, "probe not armed / event error");
   return 0;
 }
 
@@ -1272,6 +1335,14 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 11) {
     g_temb_onehot = value;
+    return 0;
+  }
+  if (knob == 12) {
+    g_tn_group = value;
+    return 0;
+  }
+  if (knob == 13) {
+    g_pack_one = value;
     return 0;
   }
   return fail(-1, "unknown tuning knob %d", knob);

@@ -4,6 +4,7 @@
 #include "fused.h"
 #include "gemm.h"
 #include "tile_ln.h"
+#include "pack_dev.h"
 
 #ifndef DPPO_BWD_LATE
 #define DPPO_BWD_LATE 1
@@ -762,31 +763,7 @@ template int launch_fused_backward<BF16>(const dppo_net_desc&, const FusedBwdArg
 // fragment packing of a whole stream: blockIdx.y = layer, blockIdx.x = (wave, k-step, tile)
 template <class P>
 __global__ void pack_stream_kernel(const PackStream d) {
-  const PackLayer L = d.layer[blockIdx.y];
-  const int TPW = d.TPW;
-  if ((int)blockIdx.x >= SAMPLER_WAVES * L.KS * TPW) return;
-  const int lane = threadIdx.x & 63;
-  const int tp = blockIdx.x % TPW;
-  const int ks = (blockIdx.x / TPW) % L.KS;
-  const int w = blockIdx.x / (TPW * L.KS);
-  const int r = lane & 15, g = lane >> 4;
-  const long feat = w * 16 * TPW + feat_off<P>(r >> 2, tp) + (r & 3);
-  constexpr int EPL = 16 / P::ESIZE;
-  const int k0 = ks * P::KB + EPL * g;
-  uint32_t out[4];
-  if constexpr (P::ESIZE == 4) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) out[j] = __float_as_uint(k0 + j < L.in_valid ? L.W[feat * L.rs + (k0 + j) * L.cs] : 0.f);
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = k0 + 2 * j;
-      const float lo = k < L.in_valid ? L.W[feat * L.rs + k * L.cs] : 0.f;
-      const float hi = k + 1 < L.in_valid ? L.W[feat * L.rs + (k + 1) * L.cs] : 0.f;
-      out[j] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
-    }
-  }
-  L.stream[(((size_t)w * L.total_pos + L.pos0 + ks) * TPW + tp) * 64 + lane] = (u32x4){out[0], out[1], out[2], out[3]};
+  pack_stream_block<P>(d.layer[blockIdx.y], d.TPW, blockIdx.x);
 }
 template <class P>
 void launch_pack_stream(const PackStream& d, hipStream_t s) {

@@ -40,8 +40,17 @@ struct GemmTN {
   int ldc, splits, rows_per_split;  // rows_per_split multiple of 64
 };
 
+constexpr int MAX_TN_JOBS = 8;
+struct GemmTNGroup {  // one launch over the 128 x 128 tiles of n weight-gradient GEMMs (gemm_tn_group_kernel)
+  GemmTN j[MAX_TN_JOBS];
+  int base[MAX_TN_JOBS + 1];  // first workgroup of job i; base[n] = grid size
+  int n;
+};
+
 template <class P>
 void launch_gemm_nt(const GemmNT& a, hipStream_t s);
+template <class P>
+void launch_gemm_tn_group(const GemmTNGroup& gr, hipStream_t s);
 void set_gemm_tn_variant(int v);  // tuning knob 5
 void set_gemm_tn_thin(int v);     // tuning knob 6
 
@@ -51,9 +60,9 @@ void set_gemm_tn_thin(int v);     // tuning knob 6
 enum { PROBE_GEMM_NT_HIDDEN = 1, PROBE_GEMM_TN = 2, PROBE_FUSED_FWD = 3, PROBE_FUSED_BWD = 4, PROBE_SAMPLER = 5 };
 void set_gemm_nt_variant(int v);  // 0 register staging, 1 LDS-DMA staging where legal (default)
 int probe_arm(int kernel_id, int max_launches);
-int probe_collect(double* total_ms, int* launches, double* flops);
+int probe_collect(double* total_ms, int* launches, double* flops, double* bytes = nullptr);
 bool probe_begin(int kernel_id, hipStream_t s);  // true if this launch is being timed
-void probe_end(hipStream_t s, double flops);     // call right after the launch when probe_begin returned true
+void probe_end(hipStream_t s, double flops, double bytes = 0);  // right after the launch when probe_begin returned true
 template <class P>
 void launch_gemm_tn(const GemmTN& a, hipStream_t s);
 bool gemm_tn_thin(int N1, int N2);  // true: the 512 x 64 block shape is used (one output tile covers <= 64 columns)

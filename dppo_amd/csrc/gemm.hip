@@ -220,7 +220,7 @@ struct Probe {
   bool armed = false;
   int id = 0, cap = 0, used = 0;
   hipEvent_t* ev = nullptr;  // 2 per launch
-  double flops = 0;
+  double flops = 0, bytes = 0;
 };
 static Probe g_probe;
 int probe_arm(int kernel_id, int max_launches) {
@@ -228,10 +228,10 @@ int probe_arm(int kernel_id, int max_launches) {
   g_probe.ev = new hipEvent_t[2 * max_launches];
   for (int i = 0; i < 2 * max_launches; ++i)
     if (hipEventCreate(&g_probe.ev[i]) != hipSuccess) return -1;
-  g_probe.id = kernel_id, g_probe.cap = max_launches, g_probe.used = 0, g_probe.flops = 0, g_probe.armed = true;
+  g_probe.id = kernel_id, g_probe.cap = max_launches, g_probe.used = 0, g_probe.flops = 0, g_probe.bytes = 0, g_probe.armed = true;
   return 0;
 }
-int probe_collect(double* total_ms, int* launches, double* flops) {
+int probe_collect(double* total_ms, int* launches, double* flops, double* bytes) {
   if (!g_probe.armed) return -1;
   double tot = 0;
   for (int i = 0; i < g_probe.used; ++i) {
@@ -241,6 +241,7 @@ int probe_collect(double* total_ms, int* launches, double* flops) {
     tot += ms;
   }
   *total_ms = tot, *launches = g_probe.used, *flops = g_probe.flops;
+  if (bytes) *bytes = g_probe.bytes;
   for (int i = 0; i < 2 * g_probe.cap; ++i) (void)hipEventDestroy(g_probe.ev[i]);
   delete[] g_probe.ev;
   g_probe = Probe();
@@ -251,9 +252,9 @@ bool probe_begin(int kernel_id, hipStream_t s) {
   (void)hipEventRecord(g_probe.ev[2 * g_probe.used], s);
   return true;
 }
-void probe_end(hipStream_t s, double flops) {
+void probe_end(hipStream_t s, double flops, double bytes) {
   (void)hipEventRecord(g_probe.ev[2 * g_probe.used + 1], s);
-  g_probe.flops += flops;
+  g_probe.flops += flops, g_probe.bytes += bytes;
   ++g_probe.used;
 }
 
@@ -314,7 +315,7 @@ template void launch_gemm_nt<BF16>(const GemmNT&, hipStream_t);
 //   <4,1,8,4> 512 x  64 : thin outputs (dW0: H x in_dim; dWout computed transposed as H x out_dim) -- one block
 //                         covers the whole output, all parallelism comes from the split over batch rows
 template <class P, int WA, int WB, int TA, int TB>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN a) {
+__device__ __forceinline__ void tn_tile(const GemmTN& a, const int split, const int fa0, const int fb0) {
   constexpr int ES = P::ESIZE;
   constexpr int BA = WA * TA * 16, BB = WB * TB * 16;
   constexpr int ROWS = (ES == 2) ? 64 : 32;  // batch rows per LDS stage (two k-steps)
@@ -327,10 +328,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN a) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int wa = wid % WA, wb = wid / WA;
-  // blockIdx.x = row split: workgroups are dealt round-robin to the 8 XCDs, so with splits % 8 == 0 every output tile
-  // of one split runs on the same XCD and its A/B row tiles are fetched into that XCD's L2 once, not once per XCD
-  const int fa0 = blockIdx.y * BA, fb0 = blockIdx.z * BB;
-  const int m_begin = blockIdx.x * a.rows_per_split;
+  const int m_begin = split * a.rows_per_split;
   const int m_end = min(a.M, m_begin + a.rows_per_split);
   const char* Ab = (const char*)a.A;
   const char* Bb = (const char*)a.B;
@@ -342,18 +340,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN a) {
       const int q = (tid + i * 256) % (ROWS * CPA);
       const int rr = q / CPA, c = q % CPA;
       const int row = m0 + rr, ca = fa0 + c * (16 / ES);
-      const bool ok = row < m_end && ca < a.lda;
-      const u32x4 v = *(const u32x4*)(Ab + ((size_t)(ok ? row : 0) * a.lda + (ok ? ca : 0)) * ES);
-      areg[i] = ok ? v : (u32x4){0, 0, 0, 0};
+      areg[i] = (u32x4){0, 0, 0, 0};
+      if (row < m_end && ca < a.lda) areg[i] = *(const u32x4*)(Ab + ((size_t)row * a.lda + ca) * ES);
     }
 #pragma unroll
     for (int i = 0; i < NCB; ++i) {
       const int q = (tid + i * 256) % (ROWS * CPB);
       const int rr = q / CPB, c = q % CPB;
       const int row = m0 + rr, cb = fb0 + c * (16 / ES);
-      const bool ok = row < m_end && cb < a.ldb;
-      const u32x4 v = *(const u32x4*)(Bb + ((size_t)(ok ? row : 0) * a.ldb + (ok ? cb : 0)) * ES);
-      breg[i] = ok ? v : (u32x4){0, 0, 0, 0};
+      breg[i] = (u32x4){0, 0, 0, 0};
+      if (row < m_end && cb < a.ldb) breg[i] = *(const u32x4*)(Bb + ((size_t)row * a.ldb + cb) * ES);
     }
   };
   auto sstore = [&](int st) {
@@ -440,7 +436,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN a) {
     __syncthreads();
   }
 
-  float* out = a.slab + (size_t)blockIdx.x * a.N1 * a.ldc;
+  float* out = a.slab + (size_t)split * a.N1 * a.ldc;
 #pragma unroll
   for (int i = 0; i < TA; ++i)
 #pragma unroll
@@ -453,6 +449,29 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN a) {
         if (n2 < a.N2) out[(size_t)n1 * a.ldc + n2] = acc[i][j][e];
       }
     }
+}
+
+// blockIdx.x = row split: workgroups are dealt round-robin to the 8 XCDs, so with splits % 8 == 0 every output tile
+// of one split runs on the same XCD and its A/B row tiles are fetched into that XCD's L2 once, not once per XCD
+template <class P, int WA, int WB, int TA, int TB>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN a) {
+  tn_tile<P, WA, WB, TA, TB>(a, blockIdx.x, blockIdx.y * (WA * TA * 16), blockIdx.z * (WB * TB * 16));
+}
+
+// Every weight gradient of one backward pass in one launch: 128 x 128 tiles of all jobs, job after job (long ones
+// first), within a job the split index fastest (bases and split counts are multiples of 8: one split's tiles share an
+// XCD, as above).  No inter-kernel gaps, and the last round of one GEMM is filled by the first of the next.
+template <class P>
+__global__ __launch_bounds__(256) void gemm_tn_group_kernel(const GemmTNGroup gr) {
+  int j = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_TN_JOBS; ++i)
+    if (i < gr.n && (int)blockIdx.x >= gr.base[i]) j = i;
+  const GemmTN& a = gr.j[j];
+  const int local = blockIdx.x - gr.base[j];
+  const int split = local % a.splits, tile = local / a.splits;
+  const int tb = (a.N2 + 127) / 128;
+  tn_tile<P, 2, 2, 4, 4>(a, split, (tile / tb) * 128, (tile % tb) * 128);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -638,6 +657,29 @@ static void launch_tn_cfg(const GemmTN& a, hipStream_t s) {
   hipLaunchKernelGGL((gemm_tn_kernel<P, WA, WB, TA, TB>), grid, dim3(256), LDS, s, a);
   if (probe) probe_end(s, 2.0 * a.M * a.N1 * a.N2);
 }
+
+template <class P>
+void launch_gemm_tn_group(const GemmTNGroup& gr, hipStream_t s) {
+  if (gr.n <= 0) return;
+  constexpr int ES = P::ESIZE, ROWS = (ES == 2) ? 64 : 32;
+  constexpr int LDS = 2 * ROWS * 2 * (128 * ES + 32);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_group_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  double flops = 0, bytes = 0;
+  for (int i = 0; i < gr.n; ++i) {
+    const GemmTN& a = gr.j[i];
+    flops += 2.0 * a.M * a.N1 * a.N2;
+    bytes += (double)a.M * (a.N1 + a.N2) * ES + 4.0 * a.N1 * a.N2;  // both operands once + the fp32 result
+  }
+  const bool probe = probe_begin(PROBE_GEMM_TN, s);
+  hipLaunchKernelGGL((gemm_tn_group_kernel<P>), dim3(gr.base[gr.n]), dim3(256), LDS, s, gr);
+  if (probe) probe_end(s, flops, bytes);
+}
+template void launch_gemm_tn_group<F32>(const GemmTNGroup&, hipStream_t);
+template void launch_gemm_tn_group<BF16>(const GemmTNGroup&, hipStream_t);
 
 static int g_tn_thin = 1;  // tuning knob 6: 0 = no one-tile 512 x 64 configuration for thin outputs
 void set_gemm_tn_thin(int v) { g_tn_thin = v; }

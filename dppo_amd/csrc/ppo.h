@@ -3,6 +3,7 @@
 // GAE scan, AdamW, parameter packing for the GEMM path.
 #pragma once
 #include "common.h"
+#include "fused.h"
 #include "../../include/dppo_hip.h"
 
 namespace dppo {
@@ -134,6 +135,8 @@ int loss_blocks(int64_t N);
 template <class P>
 void launch_ppo_loss(const LossArgs& a, hipStream_t s);
 // moments[0] += sum adv_k[brow[n]], [1] += sum of squares, [2] += N (float64; zeroed by the caller)
+// moments: 8 + 2 * ADV_MOMENT_BLOCKS doubles; [3] must be zero on entry (see the kernel)
+constexpr int ADV_MOMENT_BLOCKS = 256;
 void launch_adv_moments(const float* adv_k, const int32_t* brow, int64_t N, double* moments, hipStream_t s);
 
 // ---- time-embedding backward ---------------------------------------------------------------------
@@ -177,5 +180,44 @@ void launch_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, i
 void launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr_wd_mul, float one_m_b1, float b2,
                   float one_m_b2, float step_size, float bc2_sqrt, float eps, const double* sq_norm, float max_norm,
                   hipStream_t s);
+
+// Every kernel-ready image of one network in ONE launch of 64-lane blocks: the streamed fragments of all layers (both
+// streams), the out-layer stream, the (n_time x td) time-embedding table, and one transposed operand copy.
+struct PackNet {
+  PackStream ps;
+  int ps_x;  // blocks per layer of the stream part (the widest layer's count)
+  const float* Wout;
+  int out_dim, H, OT, CNT;
+  u32x4* ostream;
+  const float *te_w1, *te_b1, *te_w2, *te_b2;  // n_time = 0: no table
+  int td, n_time;
+  float* temb;
+  const float* tsrc;  // t_cols = 0: no transpose (dst[c][r] = src[r][coff + c], zero for r >= rows)
+  int t_rows, t_cols, t_lds, t_coff, t_ldd;
+  void* tdst;
+};
+template <class P>
+void launch_pack_net(const PackNet& n, hipStream_t s);
+bool pack_net_supports(int time_dim);
+
+// AdamW on up to four flat parameter vectors in one launch; step counts / learning rates in device memory.
+// step_dev: int32[2] = {steps taken, 0}: the slot's last block to finish advances [0] (no tick launch).
+struct AdamwSlot {
+  float* p;
+  const float* g;
+  float *m, *v;
+  int64_t n;
+  int32_t* step_dev;
+  const float* lr_dev;
+  double beta1, beta2, weight_decay;
+  float eps, max_norm;
+  const double* sq_norm;  // null: no clipping
+  int block0, blocks;
+};
+struct AdamwSlots {
+  AdamwSlot s[4];
+  int n;
+};
+void launch_adamw_multi(AdamwSlots& a, hipStream_t s);
 
 }  // namespace dppo

@@ -1,6 +1,7 @@
 // See ppo.h.  gfx950 only.  Compiled with -ffp-contract=off: the loss / posterior arithmetic keeps
 // the reference's op sequence.
 #include "ppo.h"
+#include "pack_dev.h"
 
 namespace dppo {
 
@@ -49,12 +50,10 @@ __device__ __forceinline__ float sinus_feat(int t, int j, int td) {
   const float ang = (float)t * expf((float)jj * step);
   return j < half ? sinf(ang) : cosf(ang);
 }
-__global__ void time_table_kernel(const float* w1, const float* b1, const float* w2, const float* b2, int td,
-                                  float* temb) {
-  extern __shared__ float sh[];  // [td] sinusoid, [2td] hidden
-  float* e0 = sh;
+__device__ __forceinline__ void time_table_block(const float* w1, const float* b1, const float* w2, const float* b2,
+                                                 int td, float* temb, const int t, float* sh) {
+  float* e0 = sh;  // [td] sinusoid, [2td] hidden
   float* a1 = sh + td;
-  const int t = blockIdx.x;
   for (int j = threadIdx.x; j < td; j += blockDim.x) e0[j] = sinus_feat(t, j, td);
   __syncthreads();
   for (int o = threadIdx.x; o < 2 * td; o += blockDim.x) {
@@ -69,10 +68,53 @@ __global__ void time_table_kernel(const float* w1, const float* b1, const float*
     temb[(size_t)t * td + o] = s;
   }
 }
+__global__ void time_table_kernel(const float* w1, const float* b1, const float* w2, const float* b2, int td,
+                                  float* temb) {
+  extern __shared__ float sh[];
+  time_table_block(w1, b1, w2, b2, td, temb, blockIdx.x, sh);
+}
 void launch_time_table(const float* w1, const float* b1, const float* w2, const float* b2, int td, int n_time,
                        float* temb, hipStream_t s) {
   hipLaunchKernelGGL(time_table_kernel, dim3(n_time), dim3(64), 3 * td * sizeof(float), s, w1, b1, w2, b2, td, temb);
 }
+
+constexpr int PACK_TD_MAX = 128;  // time_dim bound of the one-launch packer (3 * td floats of LDS)
+template <class P>
+__global__ __launch_bounds__(64) void pack_net_kernel(const PackNet n) {
+  __shared__ float sh[3 * PACK_TD_MAX];
+  int b = blockIdx.x;
+  const int n_stream = n.ps_x * n.ps.n_layers;
+  if (b < n_stream) {
+    pack_stream_block<P>(n.ps.layer[b / n.ps_x], n.ps.TPW, b % n.ps_x);
+    return;
+  }
+  b -= n_stream;
+  const int n_out = SAMPLER_WAVES * n.CNT * n.OT;
+  if (b < n_out) {
+    pack_out_block<P>(n.Wout, n.out_dim, n.H, n.OT, n.CNT, n.ostream, b);
+    return;
+  }
+  b -= n_out;
+  if (b < n.n_time) {
+    time_table_block(n.te_w1, n.te_b1, n.te_w2, n.te_b2, n.td, n.temb, b, sh);
+    return;
+  }
+  b -= n.n_time;
+  typename P::elem_t* dst = (typename P::elem_t*)n.tdst;
+  const size_t i = (size_t)b * 64 + threadIdx.x;
+  if (i >= (size_t)n.t_cols * n.t_ldd) return;
+  const int c = (int)(i / n.t_ldd), r = (int)(i % n.t_ldd);
+  dst[i] = P::from_f32(r < n.t_rows ? n.tsrc[(size_t)r * n.t_lds + n.t_coff + c] : 0.f);
+}
+template <class P>
+void launch_pack_net(const PackNet& n, hipStream_t s) {
+  const size_t tblocks = ((size_t)n.t_cols * n.t_ldd + 63) / 64;
+  const size_t blocks = (size_t)n.ps_x * n.ps.n_layers + (size_t)SAMPLER_WAVES * n.CNT * n.OT + n.n_time + tblocks;
+  hipLaunchKernelGGL((pack_net_kernel<P>), dim3((unsigned)blocks), dim3(64), 0, s, n);
+}
+template void launch_pack_net<F32>(const PackNet&, hipStream_t);
+template void launch_pack_net<BF16>(const PackNet&, hipStream_t);
+bool pack_net_supports(int time_dim) { return time_dim <= PACK_TD_MAX; }
 
 // =================================================================================================
 // row building
@@ -345,9 +387,14 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// moments[0..2] = (sum, sum of squares, N) of the minibatch's advantages.  Each block leaves its partial sums in
+// moments[8 + 2 * block ..]; the block that finishes last (counter in moments[3], zeroed by the row builder) adds them
+// in block order: no floating-point atomics, so the result is the same in every run (an atomic sum changed the last
+// bit of the std from run to run)
 __global__ __launch_bounds__(256) void adv_moments_kernel(const float* adv_k, const int32_t* brow, int64_t N,
                                                           double* moments) {
   __shared__ double sh[4];
+  __shared__ bool last;
   double s = 0, q = 0;
   for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
     const double v = adv_k[brow[n]];
@@ -357,13 +404,21 @@ __global__ __launch_bounds__(256) void adv_moments_kernel(const float* adv_k, co
   s = block_sum(s, sh);
   q = block_sum(q, sh);
   if (threadIdx.x == 0) {
-    atomicAdd(&moments[0], s);
-    atomicAdd(&moments[1], q);
-    if (blockIdx.x == 0) atomicAdd(&moments[2], (double)N);
+    moments[8 + 2 * blockIdx.x] = s, moments[9 + 2 * blockIdx.x] = q;
+    __threadfence();
+    last = atomicAdd((unsigned long long*)&moments[3], 1ull) == gridDim.x - 1;
   }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  s = threadIdx.x < gridDim.x ? __builtin_nontemporal_load(&moments[8 + 2 * threadIdx.x]) : 0.0;
+  q = threadIdx.x < gridDim.x ? __builtin_nontemporal_load(&moments[9 + 2 * threadIdx.x]) : 0.0;
+  s = block_sum(s, sh);
+  q = block_sum(q, sh);
+  if (threadIdx.x == 0) moments[0] = s, moments[1] = q, moments[2] = (double)N;
 }
 void launch_adv_moments(const float* adv_k, const int32_t* brow, int64_t N, double* moments, hipStream_t s) {
-  const int blocks = (int)min((int64_t)256, (N + 255) / 256);
+  const int blocks = (int)min((int64_t)ADV_MOMENT_BLOCKS, (N + 255) / 256);
   hipLaunchKernelGGL(adv_moments_kernel, dim3(blocks), dim3(256), 0, s, adv_k, brow, N, moments);
 }
 
@@ -575,7 +630,7 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const double* parti
       }
     }
   }
-  if (tid == 0) {
+  if (tid == 0 && (part & 1)) {  // the policy half owns these (its stream is the one the moments were pooled on)
     const double mean = moments[0] / Nn;
     const double varu = Nn > 1 ? (moments[1] - Nn * mean * mean) / (Nn - 1.0) : 0.0;
     stats[DPPO_STAT_ADV_MEAN] = mean;
@@ -875,6 +930,50 @@ void launch_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, i
   hipLaunchKernelGGL(adamw_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, step_dev, lr_dev,
                      beta1, beta2, eps, weight_decay, sq_norm, max_norm);
   hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, s, step_dev);
+}
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwSlots a) {
+  int si = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i < a.n && (int)blockIdx.x >= a.s[i].block0) si = i;
+  const AdamwSlot& sl = a.s[si];
+  __shared__ float c[4];
+  if (threadIdx.x == 0) {
+    const double t = (double)(sl.step_dev[0] + 1), lr = (double)sl.lr_dev[0];
+    const double bc1 = 1.0 - pow(sl.beta1, t), bc2 = 1.0 - pow(sl.beta2, t);
+    c[0] = (float)(1.0 - lr * sl.weight_decay), c[1] = (float)(lr / bc1), c[2] = (float)sqrt(bc2);
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)(blockIdx.x - sl.block0) * 256 + threadIdx.x;
+  if (i < sl.n) {
+    float gi = sl.g[i];
+    if (sl.sq_norm != nullptr) {
+      const float total = (float)sqrt(sl.sq_norm[0]);
+      gi *= fminf(sl.max_norm / (total + 1e-6f), 1.0f);
+    }
+    const float one_m_b1 = (float)(1.0 - sl.beta1), b2 = (float)sl.beta2, one_m_b2 = (float)(1.0 - sl.beta2);
+    float pi = sl.p[i] * c[0];
+    float mi = sl.m[i];
+    mi = mi + one_m_b1 * (gi - mi);
+    const float vi = sl.v[i] * b2 + one_m_b2 * (gi * gi);
+    pi = pi - c[1] * (mi / (sqrtf(vi) / c[2] + sl.eps));
+    sl.p[i] = pi, sl.m[i] = mi, sl.v[i] = vi;
+  }
+  // every block of the slot has read step_dev[0] before it arrives here: the last one to arrive advances the count
+  if (threadIdx.x == 0 && atomicAdd(&sl.step_dev[1], 1) == sl.blocks - 1) {
+    sl.step_dev[0] += 1;
+    sl.step_dev[1] = 0;
+  }
+}
+void launch_adamw_multi(AdamwSlots& a, hipStream_t s) {
+  int blocks = 0;
+  for (int i = 0; i < a.n; ++i) {
+    a.s[i].block0 = blocks;
+    a.s[i].blocks = (int)((a.s[i].n + 255) / 256);
+    blocks += a.s[i].blocks;
+  }
+  if (blocks > 0) hipLaunchKernelGGL(adamw_multi_kernel, dim3(blocks), dim3(256), 0, s, a);
 }
 
 void launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr_wd_mul, float one_m_b1, float b2,

@@ -3,6 +3,7 @@
 #include "sampler.h"
 #include "gemm.h"
 #include "tile_ln.h"
+#include "pack_dev.h"
 
 namespace dppo {
 
@@ -446,29 +447,7 @@ template void launch_pack_hidden<BF16>(const float*, int, int, int, int, int, in
 // out stream: [wave w][c][to][lane]; wave w owns k-steps w*CNT + c; rows >= out_dim are zero.
 template <class P>
 __global__ void pack_out_kernel(const float* W, int out_dim, int H, int OT, int CNT, u32x4* stream) {
-  const int lane = threadIdx.x & 63;
-  const int to = blockIdx.x % OT;
-  const int c = (blockIdx.x / OT) % CNT;
-  const int w = blockIdx.x / (OT * CNT);
-  const int r = lane & 15, g = lane >> 4;
-  const int o = to * 16 + r;
-  const int ks = w * CNT + c;
-  constexpr int EPL = 16 / P::ESIZE;
-  const int k0 = ks * P::KB + EPL * g;
-  const bool ok = o < out_dim && k0 < H;
-  uint32_t out[4];
-  if constexpr (P::ESIZE == 4) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) out[j] = __float_as_uint(ok ? W[(size_t)o * H + k0 + j] : 0.f);
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float lo = ok ? W[(size_t)o * H + k0 + 2 * j] : 0.f;
-      const float hi = ok ? W[(size_t)o * H + k0 + 2 * j + 1] : 0.f;
-      out[j] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
-    }
-  }
-  stream[(((size_t)w * CNT + c) * OT + to) * 64 + lane] = (u32x4){out[0], out[1], out[2], out[3]};
+  pack_out_block<P>(W, out_dim, H, OT, CNT, stream, blockIdx.x);
 }
 template <class P>
 void launch_pack_out(const float* W, int out_dim, int H, int OT, int CNT, u32x4* stream, hipStream_t s) {

@@ -37,6 +37,13 @@ class DiffusionCfg(C.Structure):
                 ("randn_clip", C.c_float), ("final_clip", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32)]
 
 
+class AdamwSlot(C.Structure):  # struct dppo_adamw_slot
+    _fields_ = [("params", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_int64), ("step_dev", C.c_void_p), ("lr_dev", C.c_void_p), ("beta1", C.c_double),
+                ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double), ("sq_norm", C.c_void_p),
+                ("max_norm", C.c_double)]
+
+
 class PpoCfg(C.Structure):
     _fields_ = [("ft_denoising_steps", C.c_int32), ("horizon_steps", C.c_int32), ("action_dim", C.c_int32),
                 ("reward_horizon", C.c_int32), ("norm_adv", C.c_int32), ("has_adv_clip", C.c_int32),
@@ -78,8 +85,11 @@ SYMBOLS = {
     "dppo_grad_sq_norm": (_I, [_P, _L, _P, _P, _P]),
     "dppo_adamw_step": (_I, [_P, _P, _P, _P, _L, _I, _D, _D, _D, _D, _D, _P, _D, _P]),
     "dppo_adamw_step_dev": (_I, [_P, _P, _P, _P, _L, _P, _P, _D, _D, _D, _D, _P, _D, _P]),
+    "dppo_adamw_step_multi": (_I, [_P, _I, _P]),
     "dppo_probe_arm": (_I, [_I, _I]),
     "dppo_probe_collect": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "dppo_probe_collect_bytes": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                      C.POINTER(C.c_double)]),
     "dppo_tune_set": (_I, [_I, _I]),
     "dppo_gemm_nt_raw": (_I, [_I, _P, _P, _P, _L, _I, _I, _P, _P, _I, _I, _P]),
     "dppo_gemm_tn_raw": (_I, [_I, _P, _I, _I, _P, _I, _I, _L, _I, _P, _P, _P]),

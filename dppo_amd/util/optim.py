@@ -23,7 +23,7 @@ class FlatAdamW:
         self.step_count = 0
         # step count and learning rate also live on the device (dppo_adamw_step_dev): a captured graph of the update
         # replays without any argument changing from step to step
-        self._step_dev = torch.zeros(1, dtype=torch.int32, device=flat_params.device)
+        self._step_dev = torch.zeros(2, dtype=torch.int32, device=flat_params.device)  # {steps taken, scratch}
         self._lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=flat_params.device)
         self._lr_host = float(lr)
         self._norm = torch.zeros(1, dtype=torch.float64, device=flat_params.device)
@@ -50,6 +50,20 @@ class FlatAdamW:
             self._step_dev.data_ptr(), self._lr_dev.data_ptr(), float(self.betas[0]), float(self.betas[1]), float(self.eps),
             float(self.weight_decay), norm_ptr, float(max_norm or 0.0), hip.stream()), "dppo_adamw_step_dev")
 
+    def slot(self, grad: torch.Tensor, max_norm: Optional[float] = None,
+             sq_norm: Optional[torch.Tensor] = None) -> "hip.AdamwSlot":
+        """This optimiser's step as one slot of ``dppo_adamw_step_multi`` (see ``step_many``)."""
+        assert grad.numel() == self.p.numel() and grad.is_contiguous()
+        self.step_count += 1
+        self.sync_lr()
+        norm_ptr = None
+        if max_norm is not None:
+            norm_ptr = (sq_norm if sq_norm is not None else self.sq_norm(grad)).data_ptr()
+        return hip.AdamwSlot(self.p.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                             self.p.numel(), self._step_dev.data_ptr(), self._lr_dev.data_ptr(), float(self.betas[0]),
+                             float(self.betas[1]), float(self.eps), float(self.weight_decay), norm_ptr,
+                             float(max_norm or 0.0))
+
     def sync_lr(self):
         """Push a changed ``param_groups[0]['lr']`` (LR schedulers) to the device copy.  Never inside a graph capture: a
         captured fill would pin the old value; callers that replay graphs call this before the replay."""
@@ -59,30 +73,29 @@ class FlatAdamW:
             self._lr_host = lr
 
 
-_side_streams = {}
+def step_many(slots) -> None:
+    """One launch for the AdamW steps of several optimisers (``FlatAdamW.slot`` each)."""
+    import ctypes as C
+    arr = (hip.AdamwSlot * len(slots))(*slots)
+    hip.check(hip.load().dppo_adamw_step_multi(C.cast(arr, C.c_void_p), len(slots), hip.stream()),
+              "dppo_adamw_step_multi")
 
 
 def step_and_repack(model, actor_opt: "FlatAdamW", critic_opt: "FlatAdamW", update_actor: bool = True,
                     max_norm: Optional[float] = None, n_time: Optional[int] = None):
     """Optimiser step + kernel-image repack of both networks (reference train_ppo_diffusion_agent.py:360-373).
 
-    The two chains (AdamW -> 2-4 pack launches) are a handful of launch-latency-bound kernels each and independent of
-    one another, so the critic's runs on a side stream beside the actor's and the caller's stream waits for both.
+    The tail of an update is a chain of launch-latency-bound kernels, so it is kept short: one AdamW launch for both
+    networks, then one pack launch per network, all on the caller's stream (a side stream for the critic's chain costs
+    a cross-stream hop of 10-20 us, more than the two launches it hides).
     """
-    main = torch.cuda.current_stream()
-    dev = actor_opt.p.device
-    side = _side_streams.get(dev)
-    if side is None:
-        side = _side_streams[dev] = torch.cuda.Stream(device=dev)
     n_time = model.denoising_steps if n_time is None else n_time
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        critic_opt.step(model.critic.flat_grads())
-        model.critic.mark_updated()
-        model.critic.packed(model.prec, 0)
+    slots = [critic_opt.slot(model.critic.flat_grads())]
     if update_actor:
-        actor_opt.step(model.actor_ft.flat_grads(), max_norm=max_norm)
+        slots.append(actor_opt.slot(model.actor_ft.flat_grads(), max_norm=max_norm))
+    step_many(slots)
+    model.critic.mark_updated()
+    model.critic.packed(model.prec, 0)
+    if update_actor:
         model.actor_ft.mark_updated()
         model.actor_ft.packed(model.prec, n_time)
-    main.wait_stream(side)
-

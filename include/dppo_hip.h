@@ -227,6 +227,23 @@ int dppo_adamw_step_dev(float* params, const float* grad, float* exp_avg, float*
                         const float* lr_dev, double beta1, double beta2, double eps, double weight_decay,
                         const double* sq_norm, double max_norm, dppo_stream_t stream);
 
+/* The same for up to four parameter vectors in ONE launch (actor_ft and critic: the optimiser tail of an update is a
+ * chain of latency-bound launches).  step_dev points at int32[2] = {steps taken, 0}: the slot's last workgroup to finish
+ * advances [0], so there is no separate tick launch; sq_norm NULL = no clipping. */
+typedef struct dppo_adamw_slot {
+  float* params;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t n;
+  int32_t* step_dev;
+  const float* lr_dev;
+  double beta1, beta2, eps, weight_decay;
+  const double* sq_norm;
+  double max_norm;
+} dppo_adamw_slot;
+int dppo_adamw_step_multi(const dppo_adamw_slot* slots, int n_slots, dppo_stream_t stream);
+
 /* ---- measurement hook (bench.py only; process-wide, not thread-safe, off by default) ----------- */
 /* While armed for a kernel, each of its launches is bracketed by HIP events on the launch stream.
  * kernel_id: 1 = gemm_nt on an H x H layer (layered path), 2 = gemm_tn weight gradient (N1,N2 >= 128),
@@ -235,19 +252,25 @@ int dppo_adamw_step_dev(float* params, const float* grad, float* exp_avg, float*
  * unpadded shapes), and disarms. */
 int dppo_probe_arm(int kernel_id, int max_launches);
 int dppo_probe_collect(double* total_ms_host, int* launches_host, double* flops_host);
+/* same, plus the algorithmic bytes of the timed launches where the library knows them (kernel id 2 with knob 12: both
+ * operands of every GEMM of the group once + its fp32 result), else 0 */
+int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* flops_host, double* bytes_host);
 
 /* ---- tuning / micro-benchmark hooks (tools/ and tests only; never used by the product path) ----- */
 /* knob 0: gemm_nt operand staging, 0 = through registers, 1 = global_load_lds (LDS-DMA, default)
  * knob 1: big-batch MLP path, 1 = fused row-tile kernels (default), 0 = layer-by-layer gemm_nt chain
  * knob 2: PPO update, 1 = critic half on a side stream, overlapping the actor half (default), 0 = one stream
- * knob 3 / 4: weight-gradient GEMMs, workgroups aimed for (default 512) / cap on the row splits (default 128)
+ * knob 3 / 4: weight-gradient GEMMs, workgroups aimed for (default 256) / cap on the row splits (default 128)
  * knob 7: fused kernels, bit 0 / 1 = 32-row tiles at two workgroups per CU in the backward / forward (default 0)
  * knob 8: timing experiments on the fused backward (results are wrong while set); knob 9: side streams at low priority
  * knob 5: weight-gradient GEMM kernel, 0 = register-staged (default), 1..8 = an LDS-DMA ring configuration, -1 = by shape
  * knob 6: thin (512 x 64) weight-gradient tiles on / off; knob 10: critic side stream gated on the actor's forward (0 off)
  * knob 11: time-embedding gradient from a one-hot of the denoising step in the K padding of the actor's input rows, so
  *          the first layer's weight-gradient GEMM also yields the per-step sums of dh0 (default 1); 0 = separate
- *          gemm_nt + segmented sum on the tail stream */
+ *          gemm_nt + segmented sum on the tail stream
+ * knob 12: all weight-gradient GEMMs of one backward pass in one grouped launch of 128 x 128 tiles (default 1); 0 = one
+ *          launch per GEMM (thin outputs then use the 512 x 64 tile of knob 6)
+ * knob 13: dppo_pack_net writes all images of a network in one launch (default 1); 0 = one launch per image */
 int dppo_tune_set(int knob, int value);
 /* one bare layer GEMM: out[M][ldo] = act(X[M][Kp] . W[N][Kp]^T + bias) with elem = prec operands;
  * out_f32 and/or out_elem may be NULL; ldo >= round_up(N,16) */

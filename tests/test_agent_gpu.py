@@ -139,6 +139,6 @@ def test_graph_replayed_update_equals_eager_update():
                 m.ppo_update(*ro, inds, reward_horizon=bench.ACT_STEPS)
                 step_and_repack(m, oa, oc, n_time=bench.K)
         out.append((m.actor_ft.flat_params().clone(), m.critic.flat_params().clone(), m._stats.clone()))
-    for a, b in zip(*out):
-        assert torch.equal(a, b)
+    for name, a, b in zip(("actor_ft", "critic", "stats"), *out):
+        assert torch.equal(a, b), f"{name}: {(a - b).abs().max().item():.3e} at {(a != b).nonzero().flatten().tolist()[:8]}"
 

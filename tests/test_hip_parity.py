@@ -294,6 +294,34 @@ def test_adamw_and_clip_match_torch(golden):
     np.testing.assert_allclose(q1.cpu().numpy(), q2.cpu().numpy(), rtol=1e-5, atol=1e-8)
 
 
+def test_adamw_multi_equals_single_steps(golden):
+    """dppo_adamw_step_multi (one launch, step count advanced by the slot's last workgroup) == the same steps taken one
+    optimiser at a time, bit for bit, over several steps, with clipping on one slot."""
+    from dppo_amd.util.optim import FlatAdamW, step_many
+    g = golden("g7_adamw")
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    sizes = (g["p0"].size, 1000, 257)
+    ref = [torch.randn(n, generator=gen).to(DEV) for n in sizes]
+    ref[0] = T(g["p0"].copy()).to(DEV)
+    multi = [r.clone() for r in ref]
+    o_ref = [FlatAdamW(p, lr=1e-3 * (i + 1), weight_decay=0.01 * i) for i, p in enumerate(ref)]
+    o_mul = [FlatAdamW(p, lr=1e-3 * (i + 1), weight_decay=0.01 * i) for i, p in enumerate(multi)]
+    for it in range(4):
+        grads = [torch.randn(n, generator=gen).to(DEV) for n in sizes]
+        for i, (o, gr) in enumerate(zip(o_ref, grads)):
+            o.step(gr, max_norm=0.7 if i == 1 else None)
+        step_many([o.slot(gr, max_norm=0.7 if i == 1 else None) for i, (o, gr) in enumerate(zip(o_mul, grads))])
+        for a, b, o in zip(ref, multi, o_mul):
+            assert torch.equal(a, b)
+            assert o._step_dev.tolist() == [it + 1, 0]
+    # and the first vector still follows torch.optim.AdamW's trajectory
+    p = T(g["p0"].copy()).to(DEV)
+    opt = FlatAdamW(p, lr=1e-3, weight_decay=0.01)
+    for i in range(3):
+        step_many([opt.slot(T(g[f"g{i}"]).to(DEV))])
+        np.testing.assert_allclose(p.cpu().numpy(), g[f"p{i + 1}"], rtol=1e-6, atol=1e-7)
+
+
 @pytest.mark.parametrize("case", ["ddim100_5", "ddpm20_ft10"])
 def test_logprob_subsample_matches_chain_logprobs(golden, case):
     """get_logprobs_subsample (reference diffusion_vpg.py:398-461) == the matching entries of get_logprobs and of the
