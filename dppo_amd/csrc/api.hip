@@ -638,7 +638,8 @@ static void cond_backward(const dppo_net_desc& d, const float* prm, const char* 
 template <class P>
 static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* pk, const PackLayout& L, int64_t M,
                          MlpBufs<P>& B, float* grad, const int32_t* krow, const dppo_step* ksteps, int Kft,
-                         hipStream_t s, bool bout_done = false, int aux_idx = 1) {
+                         hipStream_t s, bool bout_done = false, int aux_idx = 1, const LossArgs* fin = nullptr) {
+  // fin: the loss's statistics are finalised off the critical path (on the tail stream, or after the GEMMs)
   const ParamLayout pl = param_layout(d);
   const int H = d.hidden, nb = d.n_blocks;
   if (fused_ok<P>(d) && B.tiles > 0) {
@@ -687,6 +688,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       // the latency-bound tail (bias sums, time-embedding gradient; they share B.part) runs beside the weight-gradient
       // GEMMs (which share B.slab and stay in order on s)
       hipStream_t aux = aux_idx >= 0 ? fork_side(s, aux_idx) : s;
+      if (fin && aux != s) launch_loss_finalize(*fin, aux);
       launch_reduce_slots(B.tile_colsum, B.tiles, H, so, aux);
       const int oh = d.kind == 0 ? temb_onehot_col<P>(d, L, Kft, B) : -1;  // must match what the row builder was told
       if (d.kind == 0 && oh < 0) time_embedding_grad<P>(d, prm, pk, L, M, B, B.dh_all[0], grad, krow, ksteps, Kft, aux);
@@ -705,11 +707,13 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
         launch_time_backward_from_sums(prm + pl.te1_w, prm + pl.te1_b, prm + pl.te2_w, B.part, prm + pl.W0, d.in_dim,
                                        d.act_flat, H, B.part + (size_t)H * Kft, ksteps, Kft, d.time_dim, grad + pl.te1_w,
                                        grad + pl.te1_b, grad + pl.te2_w, grad + pl.te2_b, s);
+      if (fin && aux == s) launch_loss_finalize(*fin, s);
       if (aux_idx >= 0) join_side(s, aux, aux_idx);
       B.dh0_final = B.dh_all[0];
       return;
     }
   }
+  if (fin) launch_loss_finalize(*fin, s);
   // output layer parameters
   weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.hE, H, H, M, B, grad + pl.Wout, H, s);
   launch_colsum<P>(B.d_out, (int)M, d.out_dim, L.Kpo, B.part, REDUCE_BLOCKS, grad + pl.bout, 1.f, s);
@@ -1179,17 +1183,18 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
     if (split) la.brow = W.brow_c;
     if (gmom == nullptr) la.n_count = (double)N;  // = what adv_moments leaves in moments[2], without waiting for it
     launch_ppo_loss<P>(la, s2);
+    const LossArgs lv = la;
     la.brow = W.brow, la.n_count = 0;
     // (no tail stream of its own: a fork from a forked stream crashes hipGraph capture on ROCm 7.0 at capture end, and
     // the critic's tail is one 10-us reduction)
-    mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s2, fuse_bout, -1);
+    mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s2, fuse_bout, -1, &lv);
   }
   // actor half
   if (!actor_first) mlp_forward<P>(a, ap, ak, LA, N, W.A, true, s);
   la.part = two_streams ? 1 : 3, la.partial = W.loss_partial;
   launch_ppo_loss<P>(la, s);
   if (!two_streams) mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s, fuse_bout, -1);
-  mlp_backward<P>(a, ap, ak, LA, N, W.A, agrad, W.krow, ksteps, Kft, s, fuse_bout);
+  mlp_backward<P>(a, ap, ak, LA, N, W.A, agrad, W.krow, ksteps, Kft, s, fuse_bout, 1, &la);
   if (a.cond_hidden > 0) cond_backward<P>(a, ap, ak, LA, N, W.A, W.A.dh0_final, W.C.in, agrad, s);
   join_side(s, s2);
   return check_launch();

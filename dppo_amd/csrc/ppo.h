@@ -133,7 +133,8 @@ struct LossArgs {
 };
 int loss_blocks(int64_t N);
 template <class P>
-void launch_ppo_loss(const LossArgs& a, hipStream_t s);
+void launch_ppo_loss(const LossArgs& a, hipStream_t s);  // the loss kernel: d_out + per-block partial sums
+void launch_loss_finalize(const LossArgs& a, hipStream_t s);  // partial sums -> stats
 // moments[0] += sum adv_k[brow[n]], [1] += sum of squares, [2] += N (float64; zeroed by the caller)
 // moments: 8 + 2 * ADV_MOMENT_BLOCKS doubles; [3] must be zero on entry (see the kernel)
 constexpr int ADV_MOMENT_BLOCKS = 256;

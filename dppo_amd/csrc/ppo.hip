@@ -646,8 +646,12 @@ void launch_ppo_loss(const LossArgs& a, hipStream_t s) {
   const size_t lds = (size_t)(2 * a.pcfg.ft_denoising_steps + 2) * sizeof(float);
   const int blocks = loss_blocks(a.N);
   hipLaunchKernelGGL((ppo_loss_kernel<P>), dim3(blocks), dim3(256), lds, s, a);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, s, a.partial, blocks, a.moments, a.stats, a.partial_cs,
-                     a.gb_actor, a.out_dim, a.gb_critic, a.part, a.n_count);
+}
+// the statistics (and nothing the backward pass reads): any stream ordered after the loss kernel will do
+void launch_loss_finalize(const LossArgs& a, hipStream_t s) {
+  if (a.N <= 0) return;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, s, a.partial, loss_blocks(a.N), a.moments, a.stats,
+                     a.partial_cs, a.gb_actor, a.out_dim, a.gb_critic, a.part, a.n_count);
 }
 template void launch_ppo_loss<F32>(const LossArgs&, hipStream_t);
 template void launch_ppo_loss<BF16>(const LossArgs&, hipStream_t);
@@ -932,6 +936,7 @@ void launch_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, i
   hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, s, step_dev);
 }
 
+constexpr int ADAMW_MULTI_EPT = 8;  // elements per thread
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwSlots a) {
   int si = 0;
 #pragma unroll
@@ -945,14 +950,16 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwSlots a) {
     c[0] = (float)(1.0 - lr * sl.weight_decay), c[1] = (float)(lr / bc1), c[2] = (float)sqrt(bc2);
   }
   __syncthreads();
-  const int64_t i = (int64_t)(blockIdx.x - sl.block0) * 256 + threadIdx.x;
-  if (i < sl.n) {
+  float clip = 1.f;
+  if (sl.sq_norm != nullptr) clip = fminf(sl.max_norm / ((float)sqrt(sl.sq_norm[0]) + 1e-6f), 1.0f);
+  const float one_m_b1 = (float)(1.0 - sl.beta1), b2 = (float)sl.beta2, one_m_b2 = (float)(1.0 - sl.beta2);
+  const int64_t i0 = (int64_t)(blockIdx.x - sl.block0) * (256 * ADAMW_MULTI_EPT) + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < ADAMW_MULTI_EPT; ++u) {  // few, fat blocks: the arrival counter below is one contended address
+    const int64_t i = i0 + u * 256;
+    if (i >= sl.n) break;
     float gi = sl.g[i];
-    if (sl.sq_norm != nullptr) {
-      const float total = (float)sqrt(sl.sq_norm[0]);
-      gi *= fminf(sl.max_norm / (total + 1e-6f), 1.0f);
-    }
-    const float one_m_b1 = (float)(1.0 - sl.beta1), b2 = (float)sl.beta2, one_m_b2 = (float)(1.0 - sl.beta2);
+    if (sl.sq_norm != nullptr) gi *= clip;
     float pi = sl.p[i] * c[0];
     float mi = sl.m[i];
     mi = mi + one_m_b1 * (gi - mi);
@@ -970,7 +977,7 @@ void launch_adamw_multi(AdamwSlots& a, hipStream_t s) {
   int blocks = 0;
   for (int i = 0; i < a.n; ++i) {
     a.s[i].block0 = blocks;
-    a.s[i].blocks = (int)((a.s[i].n + 255) / 256);
+    a.s[i].blocks = (int)((a.s[i].n + 256 * ADAMW_MULTI_EPT - 1) / (256 * ADAMW_MULTI_EPT));
     blocks += a.s[i].blocks;
   }
   if (blocks > 0) hipLaunchKernelGGL(adamw_multi_kernel, dim3(blocks), dim3(256), 0, s, a);
