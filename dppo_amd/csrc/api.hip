@@ -291,6 +291,10 @@ struct MlpBufs {  // activations of one network for M rows
   size_t slab_used;   // floats handed out since the last flush
   SlabJobs slab_jobs; // reductions pending on the pool (flush_slabs)
   GemmTNGroup tn_group;  // weight-gradient GEMMs pending on the pool: launched together by flush_slabs
+  // side streams to join into the flushing stream right behind the GEMM launch: the barrier packets (~10 us each even when
+  // the event fired long ago) are then processed while the GEMMs run instead of at the end of the call
+  hipStream_t join_s[2];
+  int join_idx[2], n_join;
   float* part;  // column-sum / segment-sum partials
   size_t slab_floats, part_floats;
 };
@@ -355,7 +359,7 @@ static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, b
     // a pool for all of one backward's GEMMs (2 per block + first and out layer), reduced together at the end
     B.slab_floats = (size_t)2 * (nb > 0 ? nb : 1) * splits_hh * (size_t)H * H + 2 * alt;
     B.slab = (float*)c.take(B.slab_floats * 4);
-    B.slab_used = 0, B.slab_jobs.n = 0, B.tn_group.n = 0;
+    B.slab_used = 0, B.slab_jobs.n = 0, B.tn_group.n = 0, B.n_join = 0;
     B.part_floats = (size_t)REDUCE_BLOCKS * (H > 1024 ? H : 1024);
     B.part = (float*)c.take(B.part_floats * 4);
   }
@@ -506,6 +510,7 @@ static void join_side(hipStream_t main, hipStream_t sidestream, int idx = 0) {
 }
 
 static int g_dbg = 0;  // tuning knob 8: timing experiments on the fused backward (results are wrong while it is set)
+static int g_early_join = 1;       // tuning knob 14: side streams joined right behind the weight-gradient GEMM launch
 static int g_tn_group = 1;         // tuning knob 12: one launch for all weight-gradient GEMMs of a backward pass
 static int g_tn_target = 256;      // tuning knob 3: workgroups a weight-gradient GEMM aims for (tiles x row splits)
 static int g_tn_max_splits = 128;  // tuning knob 4: cap on its row splits (each split costs one fp32 slab of the output)
@@ -535,6 +540,8 @@ static void flush_slabs(MlpBufs<P>& B, hipStream_t s) {
     launch_gemm_tn_group<P>(gr, s);
     gr.n = 0;
   }
+  for (int i = 0; i < B.n_join; ++i) join_side(s, B.join_s[i], B.join_idx[i]);
+  B.n_join = 0;
   launch_slab_reduce_batch(B.slab_jobs, s);
   B.slab_jobs.n = 0, B.slab_used = 0;
 }
@@ -702,13 +709,14 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
                        Kft);
       else
         weight_grad<P>(B.dh_all[0], H, H, B.in, L.Kp0, d.in_dim, M, B, grad + pl.W0, d.in_dim, s, true);
+      if (aux != s && g_early_join) B.join_s[B.n_join] = aux, B.join_idx[B.n_join++] = aux_idx;
       flush_slabs(B, s);  // every slab of this backward in one reduction launch
+      if (aux != s && !g_early_join) join_side(s, aux, aux_idx);
       if (oh >= 0)
         launch_time_backward_from_sums(prm + pl.te1_w, prm + pl.te1_b, prm + pl.te2_w, B.part, prm + pl.W0, d.in_dim,
                                        d.act_flat, H, B.part + (size_t)H * Kft, ksteps, Kft, d.time_dim, grad + pl.te1_w,
                                        grad + pl.te1_b, grad + pl.te2_w, grad + pl.te2_b, s);
       if (fin && aux == s) launch_loss_finalize(*fin, s);
-      if (aux_idx >= 0) join_side(s, aux, aux_idx);
       B.dh0_final = B.dh_all[0];
       return;
     }
@@ -1194,9 +1202,11 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   la.part = two_streams ? 1 : 3, la.partial = W.loss_partial;
   launch_ppo_loss<P>(la, s);
   if (!two_streams) mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s, fuse_bout, -1);
+  if (two_streams && g_early_join) W.A.join_s[W.A.n_join] = s2, W.A.join_idx[W.A.n_join++] = 0;
   mlp_backward<P>(a, ap, ak, LA, N, W.A, agrad, W.krow, ksteps, Kft, s, fuse_bout, 1, &la);
   if (a.cond_hidden > 0) cond_backward<P>(a, ap, ak, LA, N, W.A, W.A.dh0_final, W.C.in, agrad, s);
-  join_side(s, s2);
+  if (!(two_streams && g_early_join) || W.A.n_join > 0) join_side(s, s2);  // (n_join > 0: the backward never flushed)
+  W.A.n_join = 0;
   return check_launch();
 }
 
@@ -1348,6 +1358,10 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 13) {
     g_pack_one = value;
+    return 0;
+  }
+  if (knob == 14) {
+    g_early_join = value;
     return 0;
   }
   return fail(-1, "unknown tuning knob %d", knob);
