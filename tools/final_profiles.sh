@@ -1,5 +1,5 @@
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01e; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01f; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 echo "[1] bench full"; timeout -k 10 400 python3 $R/bench.py > $O/bench.json 2> $O/bench.err && tail -c 600 $O/bench.json && echo
 echo "[2] rocprof stats"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/stats.log 2>&1 && echo ok
@@ -10,6 +10,7 @@ cd $R
 echo "[4b] mfma util"; cd /tmp; timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -- python3 $R/bench.py --steps 4 --warmup 1 --n-steps 60 --no-cpu-baseline > $O/pmc_mfma.log 2>&1 && echo ok
 echo "[4c] timeline"; timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/trace.log 2>&1 && echo ok
 cd $R
+python3 tools/pmc_traffic.py $(ls $O/pmc_fetch/*/*counter_collection.csv) $(ls $O/pmc_write/*/*counter_collection.csv) gemm_tn_group_kernel $O/pmc_traffic_probe2g_bf16.json > $O/pmc_traffic.txt
 python3 tools/mfma_util.py $(ls $O/pmc_mfma/*/*counter_collection.csv) $O/mfma_util.json > $O/mfma_util.txt
 python3 tools/trace_step.py $(ls $O/trace/*/*kernel_trace.csv) v 5 > $O/step_overlapped.txt
 python3 tools/trace_step.py $(ls $O/trace/*/*kernel_trace.csv) v > $O/step_serial.txt
