@@ -27,7 +27,7 @@ from dppo_amd.env.synthetic import make_venv
 from dppo_amd.parallel import DataParallel
 from dppo_amd.util.optim import FlatAdamW, step_and_repack
 from dppo_amd.util.reward_scaling import RunningRewardScaler
-from dppo_amd.util.rollout import gae_device
+from dppo_amd.util.rollout import collect_rollout, gae_device
 from dppo_amd.util.scheduler import CosineAnnealingWarmupRestarts
 from dppo_amd import hip
 
@@ -170,20 +170,13 @@ class TrainPPODiffusionAgent:
             else:
                 firsts[0] = done_venv
             last_itr_eval = eval_mode
-            reward_trajs = np.zeros((S, E))
-            terminated_trajs = np.zeros((S, E))
-            # ---------------- rollout: sample on the GPU, step envs on the host (:101-151)
-            for step in range(S):
-                state = torch.from_numpy(prev_obs["state"]).float().to(dev, non_blocking=True)
-                smp = model(cond={"state": state}, deterministic=eval_mode, return_chain=True)
-                action = smp.trajectories[:, :self.act_steps].cpu().numpy()  # the only D2H per env step
-                obs_buf[step * E:(step + 1) * E] = state.reshape(E, -1)
-                chains_buf[step * E:(step + 1) * E] = smp.chains.reshape(E, Kft + 1, AF)
-                obs_venv, reward, terminated, truncated, _ = self.venv.step(action)
-                done_venv = terminated | truncated
-                reward_trajs[step], terminated_trajs[step], firsts[step + 1] = reward, terminated, done_venv
-                prev_obs = obs_venv
-                cnt_train_step += E * self.act_steps * self.world if not eval_mode else 0
+            # ---------------- rollout: sample on the GPU, step envs on the host (:101-151); pinned hand-off, env groups
+            # (env.pipeline_groups) software-pipelined against the sampler (dppo_amd/util/rollout.py)
+            reward_trajs, terminated_trajs, done_trajs, prev_obs = collect_rollout(
+                model, self.venv, prev_obs, S, self.act_steps, obs_buf, chains_buf, deterministic=eval_mode)
+            firsts[1:] = done_trajs
+            done_venv = done_trajs[-1].astype(bool)
+            cnt_train_step += S * E * self.act_steps * self.world if not eval_mode else 0
             # ---------------- episode statistics (:153-193)
             ep_rewards, ep_best = [], []
             for e in range(E):

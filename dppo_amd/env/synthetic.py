@@ -55,9 +55,15 @@ class SyntheticVecEnv:
 def make_venv(cfg):
     """cfg.env.name == 'synthetic' -> SyntheticVecEnv; anything else needs the reference's env stack."""
     env = cfg.env
+    groups = int(env.get("pipeline_groups", 1))  # > 1: env groups stepped on the host while the device samples the others
+    assert env.n_envs % groups == 0, "env.n_envs must be divisible by env.pipeline_groups"
     if str(env.name).startswith("synthetic"):
-        return SyntheticVecEnv(env.n_envs, cfg.obs_dim, cfg.action_dim, cfg.cond_steps, cfg.act_steps,
-                               env.get("max_episode_steps", 1000), cfg.get("seed", 42))
+        mk = lambda g: SyntheticVecEnv(env.n_envs // groups, cfg.obs_dim, cfg.action_dim, cfg.cond_steps, cfg.act_steps,
+                                       env.get("max_episode_steps", 1000), cfg.get("seed", 42) + g * (env.n_envs // groups))
+        if groups == 1:
+            return mk(0)
+        from dppo_amd.util.rollout import GroupedVecEnv
+        return GroupedVecEnv([mk(g) for g in range(groups)])
     try:  # the reference's un-namespaced import (agent/finetune/train_agent.py:16), if the user has that stack
         from env.gym_utils import make_async
     except ImportError as e:
@@ -65,6 +71,13 @@ def make_venv(cfg):
             f"environment {env.name!r} needs the reference's host-side env stack (gym, mujoco-py, d4rl / robomimic), "
             "which is out of scope for dppo_amd and not installed here; pass a vectorised env to the agent "
             "(venv=...) or use env.name=synthetic") from e
-    return make_async(env.name, env_type=env.get("env_type", None), num_envs=env.n_envs, asynchronous=True,
-                      max_episode_steps=env.max_episode_steps, wrappers=env.get("wrappers", None),
-                      obs_dim=cfg.obs_dim, action_dim=cfg.action_dim)
+    mk = lambda: make_async(env.name, env_type=env.get("env_type", None), num_envs=env.n_envs // groups, asynchronous=True,
+                            max_episode_steps=env.max_episode_steps, wrappers=env.get("wrappers", None),
+                            obs_dim=cfg.obs_dim, action_dim=cfg.action_dim)
+    if groups == 1:
+        return mk()
+    from dppo_amd.util.rollout import GroupedVecEnv
+    venvs = [mk() for _ in range(groups)]
+    for v in venvs:
+        v.n_envs = env.n_envs // groups
+    return GroupedVecEnv(venvs)

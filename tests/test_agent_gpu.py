@@ -84,12 +84,16 @@ YAML = textwrap.dedent("""
 """)
 
 
-def test_agent_runs_and_learns_something(tmp_path, monkeypatch):
+@pytest.mark.parametrize("groups", [1, 2])
+def test_agent_runs_and_learns_something(tmp_path, monkeypatch, groups):
+    """groups = 2: the env set is split into two groups whose simulator steps are pipelined against the other group's
+    sampler call (env.pipeline_groups; dppo_amd/util/rollout.py)."""
     from dppo_amd.cfg.loader import get_class, load_config
     monkeypatch.setenv("DPPO_LOG_DIR", str(tmp_path))
     p = tmp_path / "ft.yaml"
-    p.write_text(YAML)
+    p.write_text(YAML.replace("  n_envs: 4\n", f"  n_envs: 4\n  pipeline_groups: {groups}\n"))
     cfg = load_config(str(p))
+    assert cfg.env.get("pipeline_groups", 1) == groups
     agent = get_class(cfg._target_)(cfg)
     w0 = agent.model.actor_ft.flat_params().clone()
     c0 = agent.model.critic.flat_params().clone()
@@ -142,3 +146,38 @@ def test_graph_replayed_update_equals_eager_update():
     for name, a, b in zip(("actor_ft", "critic", "stats"), *out):
         assert torch.equal(a, b), f"{name}: {(a - b).abs().max().item():.3e} at {(a != b).nonzero().flatten().tolist()[:8]}"
 
+
+
+def test_collected_rollout_is_consistent_on_the_device():
+    """collect_rollout with the real sampler and two pipelined env groups: every buffer row holds the observation the
+    env returned and the chain whose last entry is the action chunk that was applied to that env at that step."""
+    import bench
+    from dppo_amd.env.synthetic import SyntheticVecEnv
+    from dppo_amd.util.rollout import GroupedVecEnv, collect_rollout
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    m = bench.build_model(str(dev), "bf16")
+    E, S, n = 64, 5, 32
+    applied = []
+
+    class Recording(SyntheticVecEnv):
+        def step(self, action):
+            applied.append((id(self), np.array(action, copy=True), self._obs()["state"].copy()))
+            return super().step(action)
+
+    groups = [Recording(n, bench.OBS_DIM, bench.ACT_DIM, 1, bench.ACT_STEPS, seed=7 + g * n) for g in range(2)]
+    venv = GroupedVecEnv(groups)
+    obs0 = venv.reset_arg()
+    AF = bench.TA * bench.ACT_DIM
+    obs_buf = torch.zeros(S * E, bench.OBS_DIM, device=dev)
+    chains_buf = torch.zeros(S * E, bench.KFT + 1, AF, device=dev)
+    reward, term, done, last = collect_rollout(m, venv, obs0, S, bench.ACT_STEPS, obs_buf, chains_buf)
+    assert len(applied) == 2 * S and reward.shape == (S, E) and np.isfinite(reward).all()
+    per_group = {id(g): [a for a in applied if a[0] == id(g)] for g in groups}
+    for gi, g in enumerate(groups):
+        for s, (_, action, obs_before) in enumerate(per_group[id(g)]):
+            rows = slice(s * E + gi * n, s * E + (gi + 1) * n)
+            np.testing.assert_array_equal(obs_buf[rows].cpu().numpy(), obs_before.reshape(n, -1))
+            traj = chains_buf[rows, -1].reshape(n, bench.TA, bench.ACT_DIM)[:, :bench.ACT_STEPS]
+            np.testing.assert_array_equal(traj.cpu().numpy(), action)
+    np.testing.assert_array_equal(last["state"][:n], groups[0]._obs()["state"])
