@@ -1008,10 +1008,13 @@ int dppo_chain_logprob(const dppo_net_desc* actor, int prec, const float* params
 
 // ---- behaviour-cloning term ----------------------------------------------------------------------------
 template <class P>
-static size_t carve_bc(Carver& c, const dppo_net_desc& d, int64_t M, MlpBufs<P>& B, int32_t*& brow, int32_t*& krow) {
+static size_t carve_bc(Carver& c, const dppo_net_desc& d, int64_t M, MlpBufs<P>& B, int32_t*& brow, int32_t*& krow,
+                       double** partial = nullptr) {
   carve_mlp<P>(c, d, M, true, true, B);
   brow = (int32_t*)c.take((size_t)M * 4);
   krow = (int32_t*)c.take((size_t)M * 4);
+  double* pp = (double*)c.take((size_t)(bc_loss_blocks(M, pack_layout<P>(d, 0).Kpo) + 1) * sizeof(double));
+  if (partial) *partial = pp;
   return al256(c.off);
 }
 int64_t dppo_bc_loss_workspace_bytes(const dppo_net_desc* actor, int prec, int64_t B, int Kft) {
@@ -1034,7 +1037,8 @@ static int bc_impl(const dppo_net_desc& d, const float* prm, const char* pk, con
   Carver c{(char*)ws, 0, (size_t)wsb};
   MlpBufs<P> B;
   int32_t *brow, *krow;
-  const size_t need = carve_bc<P>(c, d, M, B, brow, krow);
+  double* partial;
+  const size_t need = carve_bc<P>(c, d, M, B, brow, krow, &partial);
   if ((int64_t)need > wsb) return fail(-1, "workspace too small: need %zu bytes, got %lld", need, (long long)wsb);
   const PackLayout L = pack_layout<P>(d, 0);
   BuildRows br;
@@ -1048,7 +1052,7 @@ static int bc_impl(const dppo_net_desc& d, const float* prm, const char* pk, con
   mlp_forward<P>(d, prm, pk, L, M, B, true, s);
   BcArgs ba;
   ba.eps = B.out, ba.lde = B.ldout, ba.chains = chains, ba.ksteps = ksteps, ba.cfg = cfg, ba.Kft = Kft;
-  ba.AF = d.act_flat, ba.M = M, ba.d_eps = B.d_out, ba.ldde = L.Kpo, ba.loss = loss;
+  ba.AF = d.act_flat, ba.M = M, ba.d_eps = B.d_out, ba.ldde = L.Kpo, ba.loss = loss, ba.partial = partial;
   launch_bc_loss<P>(ba, s);
   mlp_backward<P>(d, prm, pk, L, M, B, grad, krow, ksteps, Kft, s, false);
   if (d.cond_hidden > 0) cond_backward<P>(d, prm, pk, L, M, B, B.dh0_final, B.cin, grad, s);
@@ -1073,6 +1077,55 @@ int dppo_axpy(float* y, const float* x, double alpha, int64_t n, dppo_stream_t s
   if (!y || !x || n < 0) return fail(-1, "bad argument");
   launch_axpy(y, x, (float)alpha, n, (hipStream_t)stream);
   return check_launch();
+}
+
+// ---- supervised denoising loss (pre-training) ------------------------------------------------------------
+int64_t dppo_denoise_mse_workspace_bytes(const dppo_net_desc* actor, int prec, int64_t N) {
+  return dppo_bc_loss_workspace_bytes(actor, prec, N, 1);
+}
+template <class P>
+static int mse_impl(const dppo_net_desc& d, const float* prm, const char* pk, const dppo_step* tsteps, int n_time,
+                    const float* obs, const float* pairs, const int64_t* kinds, int64_t M, float* grad, double* loss,
+                    void* ws, int64_t wsb, hipStream_t s) {
+  Carver c{(char*)ws, 0, (size_t)wsb};
+  MlpBufs<P> B;
+  int32_t *brow, *krow;
+  double* partial;
+  const size_t need = carve_bc<P>(c, d, M, B, brow, krow, &partial);
+  if ((int64_t)need > wsb) return fail(-1, "workspace too small: need %zu bytes, got %lld", need, (long long)wsb);
+  const PackLayout L = pack_layout<P>(d, 0);
+  BuildRows br;  // gathered mode: row n = (pairs[n][0], temb(tsteps[kinds[n]].t), obs[n])
+  memset(&br, 0, sizeof(br));
+  br.kinds = kinds, br.chains = pairs, br.obs = obs, br.temb = (const float*)(pk + L.temb), br.ksteps = tsteps;
+  br.Kft = n_time, br.AF = d.act_flat, br.td = d.time_dim, br.cond = d.cond_dim, br.M = M, br.obs_in_a = 1;
+  br.inA = B.in, br.KpA = L.Kp0, br.brow = brow, br.krow = krow, br.onehot0 = temb_onehot_col<P>(d, L, n_time, B);
+  if (d.cond_hidden > 0) br.obs_in_a = 0, br.inC = B.cin, br.KpC = L.Kpc;
+  launch_build_rows<P>(br, s);
+  if (d.cond_hidden > 0) cond_encode<P>(d, prm, pk, L, M, B.cin, B, B.in, nullptr, 0, true, s);
+  mlp_forward<P>(d, prm, pk, L, M, B, true, s);
+  MseArgs ma;
+  ma.eps = B.out, ma.lde = B.ldout, ma.pairs = pairs, ma.AF = d.act_flat, ma.M = M, ma.d_eps = B.d_out, ma.ldde = L.Kpo;
+  ma.loss = loss, ma.partial = partial;
+  launch_mse_loss<P>(ma, s);
+  mlp_backward<P>(d, prm, pk, L, M, B, grad, krow, tsteps, n_time, s, false);
+  if (d.cond_hidden > 0) cond_backward<P>(d, prm, pk, L, M, B, B.dh0_final, B.cin, grad, s);
+  return check_launch();
+}
+int dppo_denoise_mse_fwd_bwd(const dppo_net_desc* actor, int prec, const float* params, const void* packed,
+                             const dppo_step* tsteps, int n_time, const float* obs, const float* pairs,
+                             const int64_t* kinds, int64_t N, float* grad, double* loss, void* workspace,
+                             int64_t workspace_bytes, dppo_stream_t stream) {
+  if (int e = check_net(actor)) return e;
+  if (int e = check_prec(prec)) return e;
+  if (actor->kind != 0) return fail(-1, "dppo_denoise_mse_fwd_bwd needs an actor descriptor");
+  if (!params || !packed || !tsteps || !obs || !pairs || !kinds || !grad || !loss || !workspace)
+    return fail(-1, "null pointer");
+  if (N < 1 || N > 0x7fffffff || n_time < 1 || n_time > 1024) return fail(-1, "N / n_time out of range");
+#define CALL(P)                                                                                                        \
+  mse_impl<P>(*actor, params, (const char*)packed, tsteps, n_time, obs, pairs, kinds, N, grad, loss, workspace, \
+              workspace_bytes, (hipStream_t)stream)
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
 }
 
 // ---- GAE ---------------------------------------------------------------------------------------------

@@ -89,9 +89,28 @@ struct BcArgs {
   void* d_eps;
   int ldde;
   double* loss;
+  double* partial;  // [bc_loss_blocks(M, ldde)] per-block sums + one 8-byte arrival counter behind them: the block that
+                    // finishes last adds them in block order (no floating-point atomics: the same bits every run)
 };
+int64_t bc_loss_blocks(int64_t M, int ldde);
 template <class P>
 void launch_bc_loss(const BcArgs& a, hipStream_t s);
+
+// supervised denoising loss (DiffusionModel.p_losses, model/diffusion/diffusion.py:325-349):
+// loss = mean((eps - target)^2) over [M][AF], d_eps = 2 (eps - target) / (M AF); pairs [M][2][AF] = (x_noisy, target)
+struct MseArgs {
+  const float* eps;
+  int lde;
+  const float* pairs;
+  int AF;
+  int64_t M;
+  void* d_eps;
+  int ldde;
+  double* loss;
+  double* partial;  // as BcArgs::partial
+};
+template <class P>
+void launch_mse_loss(const MseArgs& a, hipStream_t s);
 void launch_axpy(float* y, const float* x, float alpha, int64_t n, hipStream_t s);  // y += alpha * x
 
 // ---- fused PPO loss (diffusion_ppo.py:85-199) -----------------------------------------------------

@@ -326,6 +326,23 @@ void launch_logprob(const LogprobArgs& a, hipStream_t s) {
 // behaviour-cloning term
 // =================================================================================================
 __device__ __forceinline__ double block_sum(double v, double* sh);
+// Deterministic grid sum: every block stores its part, the block that arrives last adds all of them in block order.
+// partial: [gridDim.x] doubles followed by an 8-byte arrival counter (zero on entry).  Call from all 256 threads.
+__device__ __forceinline__ void finish_loss_sum(double part, double* partial, double* out, double* sh) {
+  __shared__ bool last;
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = part;
+    __threadfence();
+    last = atomicAdd((unsigned long long*)(partial + gridDim.x), 1ull) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  double t = 0.0;
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) t += __builtin_nontemporal_load(&partial[b]);
+  t = block_sum(t, sh);
+  if (threadIdx.x == 0) *out = t;
+}
 
 // one thread per (row, padded column); the row's d_eps is written whole (zero padding included)
 template <class P>
@@ -354,17 +371,50 @@ __global__ __launch_bounds__(256) void bc_loss_kernel(const BcArgs a) {
     ((typename P::elem_t*)a.d_eps)[i] = P::from_f32(g);
   }
   part = block_sum(part, sh);
-  if (threadIdx.x == 0) atomicAdd(a.loss, part);
+  finish_loss_sum(part, a.partial, a.loss, sh);
 }
+int64_t bc_loss_blocks(int64_t M, int ldde) { return (M * ldde + 255) / 256; }
 template <class P>
 void launch_bc_loss(const BcArgs& a, hipStream_t s) {
   const int64_t n = a.M * a.ldde;
   if (n <= 0) return;
-  (void)hipMemsetAsync(a.loss, 0, sizeof(double), s);
-  hipLaunchKernelGGL((bc_loss_kernel<P>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+  const int64_t blocks = bc_loss_blocks(a.M, a.ldde);
+  (void)hipMemsetAsync(a.partial + blocks, 0, 8, s);  // the arrival counter
+  hipLaunchKernelGGL((bc_loss_kernel<P>), dim3((unsigned)blocks), dim3(256), 0, s, a);
 }
 template void launch_bc_loss<F32>(const BcArgs&, hipStream_t);
 template void launch_bc_loss<BF16>(const BcArgs&, hipStream_t);
+
+template <class P>
+__global__ __launch_bounds__(256) void mse_loss_kernel(const MseArgs a) {
+  __shared__ double sh[4];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double part = 0.0;
+  if (i < a.M * a.ldde) {
+    const int64_t n = i / a.ldde;
+    const int j = (int)(i - n * a.ldde);
+    float g = 0.f;
+    if (j < a.AF) {
+      const float d = a.eps[(size_t)n * a.lde + j] - a.pairs[((size_t)n * 2 + 1) * a.AF + j];
+      const float scale = 1.f / ((float)a.M * (float)a.AF);
+      part = (double)(d * d) * (double)scale;
+      g = 2.f * d * scale;
+    }
+    ((typename P::elem_t*)a.d_eps)[i] = P::from_f32(g);
+  }
+  part = block_sum(part, sh);
+  finish_loss_sum(part, a.partial, a.loss, sh);
+}
+template <class P>
+void launch_mse_loss(const MseArgs& a, hipStream_t s) {
+  const int64_t n = a.M * a.ldde;
+  if (n <= 0) return;
+  const int64_t blocks = bc_loss_blocks(a.M, a.ldde);
+  (void)hipMemsetAsync(a.partial + blocks, 0, 8, s);
+  hipLaunchKernelGGL((mse_loss_kernel<P>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+}
+template void launch_mse_loss<F32>(const MseArgs&, hipStream_t);
+template void launch_mse_loss<BF16>(const MseArgs&, hipStream_t);
 
 __global__ void axpy_kernel(float* y, const float* x, float alpha, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

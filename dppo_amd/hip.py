@@ -78,6 +78,8 @@ SYMBOLS = {
     "dppo_bc_loss_workspace_bytes": (_L, [_ND, _I, _L, _I]),
     "dppo_bc_loss_fwd_bwd": (_I, [_ND, _I, _P, _P, C.POINTER(DiffusionCfg), _P, _I, _P, _P, _L, _P, _P, _P, _L, _P]),
     "dppo_axpy": (_I, [_P, _P, _D, _L, _P]),
+    "dppo_denoise_mse_workspace_bytes": (_L, [_ND, _I, _L]),
+    "dppo_denoise_mse_fwd_bwd": (_I, [_ND, _I, _P, _P, _P, _I, _P, _P, _P, _L, _P, _P, _P, _L, _P]),
     "dppo_gae": (_I, [_P, _P, _P, _P, _I, _I, _D, _D, _D, _P, _P, _P, _P, _P]),
     "dppo_ppo_workspace_bytes": (_L, [_ND, _ND, _I, _L]),
     "dppo_ppo_loss_fwd_bwd": (_I, [_ND, _ND, _I, _P, _P, _P, _P, C.POINTER(DiffusionCfg), C.POINTER(PpoCfg), _P,

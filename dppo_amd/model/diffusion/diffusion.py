@@ -19,6 +19,20 @@ log = logging.getLogger(__name__)
 Sample = namedtuple("Sample", "trajectories chains")
 
 
+class _FusedDenoiseLoss(torch.autograd.Function):
+    """The supervised loss value with d loss / d parameters precomputed by the HIP kernels (``loss.backward()`` then
+    hands each parameter its slice, like the reference's autograd would)."""
+
+    @staticmethod
+    def forward(ctx, value, grads, *params):
+        ctx.grads = grads
+        return value.float().clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None, *[x * g for x in ctx.grads])
+
+
 class DiffusionModel(nn.Module):
     def __init__(self, network, horizon_steps, obs_dim, action_dim, network_path=None, device="cuda:0",
                  denoised_clip_value=1.0, randn_clip_value=10, final_action_clip_value=None, eps_clip_value=None,
@@ -74,6 +88,73 @@ class DiffusionModel(nn.Module):
             self.ddim_alphas_sqrt = torch.flip(torch.sqrt(al), [0])
             self.ddim_alphas_prev = torch.flip(alp, [0])
             self.ddim_sqrt_one_minus_alphas = torch.flip(som, [0])
+
+    # ------------------------------------------------------------------ supervised training (reference :318-363)
+    def loss(self, x, cond, noise=None, t=None):
+        """E_{t, x0, eps} || eps - eps_theta(sqrt(abar_t) x0 + sqrt(1 - abar_t) eps, t) ||^2 (reference ``loss`` :318-323:
+        t ~ U{0..K-1} per sample).  ``noise`` / ``t`` optionally replace the internal draws (parity tests)."""
+        if t is None:
+            t = torch.randint(0, self.denoising_steps, (len(x),), device=x.device).long()
+        return self.p_losses(x, cond, t, noise=noise)
+
+    def q_sample(self, x_start, t, noise=None):
+        """x_t = sqrt(abar_t) x_0 + sqrt(1 - abar_t) eps (reference :351-363)."""
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        shape = (len(x_start),) + (1,) * (x_start.dim() - 1)
+        a = self.sqrt_alphas_cumprod.to(x_start.device)[t].reshape(shape)
+        b = self.sqrt_one_minus_alphas_cumprod.to(x_start.device)[t].reshape(shape)
+        return a * x_start + b * noise
+
+    def _time_steps(self, device):
+        """dppo_step table whose entry k has diffusion time t = k (the supervised loss indexes it with t itself)."""
+        key = ("time_identity", self.denoising_steps, str(device))
+        cache = self.__dict__.setdefault("_tstep_cache", {})
+        if key not in cache:
+            import numpy as np
+            tab = np.zeros(self.denoising_steps, dtype=hip.STEP_DTYPE)
+            for k in range(self.denoising_steps):
+                tab[k] = (0, k, -1, 0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0)
+            cache[key] = torch.from_numpy(tab.view(np.uint8)).to(device)
+        return cache[key]
+
+    def p_losses(self, x_start, cond, t, noise=None):
+        """mse(eps_theta(x_t, t, cond), eps) with the gradient of every network parameter computed by the same kernels
+        as the PPO update (row builder -> fused forward -> loss -> fused backward -> grouped weight-gradient GEMM); the
+        returned scalar carries them into ``.backward()`` (reference ``p_losses`` :325-349)."""
+        import ctypes as C
+        state = cond["state"]
+        hip.require_gpu(state, "DiffusionModel.p_losses")
+        if t.numel() and int(t.max()) >= 1024:
+            raise NotImplementedError("dppo_amd: supervised loss supports denoising_steps <= 1024")
+        N, dev = len(x_start), x_start.device
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        x_noisy = self.q_sample(x_start, t, noise)
+        pairs = torch.stack([x_noisy.reshape(N, -1), noise.reshape(N, -1)], dim=1).float().contiguous()
+        obs = state.reshape(N, -1).float().contiguous()
+        kinds = t.to(torch.int64).contiguous()
+        net = self.network
+        lib, d = hip.load(), net.net_desc()
+        flat = net.flat_params()
+        grad = torch.empty_like(flat)
+        value = torch.zeros(1, dtype=torch.float64, device=dev)
+        wsb = lib.dppo_denoise_mse_workspace_bytes(C.byref(d), self.prec, N)
+        if wsb < 0:
+            hip.check(int(wsb), "dppo_denoise_mse_workspace_bytes")
+        ws = self.__dict__.setdefault("_ws_mse", hip.Workspace()).get(wsb, dev)
+        ts = self._time_steps(dev)
+        hip.check(lib.dppo_denoise_mse_fwd_bwd(
+            C.byref(d), self.prec, flat.data_ptr(), net.packed(self.prec, self.denoising_steps).data_ptr(), ts.data_ptr(),
+            self.denoising_steps, obs.data_ptr(), pairs.data_ptr(), kinds.data_ptr(), N, grad.data_ptr(),
+            value.data_ptr(), ws.data_ptr(), ws.numel(), hip.stream()), "dppo_denoise_mse_fwd_bwd")
+        object.__setattr__(self, "last_loss_grad", grad)  # flat d loss / d parameters, for callers that step a flat optimiser
+        params = list(net.parameters())  # the flat image is their concatenation in this order
+        views, off = [], 0
+        for p in params:
+            views.append(grad[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        return _FusedDenoiseLoss.apply(value[0], views, *params)
 
     def diffusion_cfg(self) -> hip.DiffusionCfg:
         return hip.DiffusionCfg(

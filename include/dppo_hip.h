@@ -177,7 +177,22 @@ int dppo_bc_loss_fwd_bwd(const dppo_net_desc* actor, int prec, const float* para
                          const dppo_diffusion_cfg* cfg, const dppo_step* ksteps, int Kft, const float* obs,
                          const float* chains, int64_t B, float* grad, double* loss, void* workspace,
                          int64_t workspace_bytes, dppo_stream_t stream);
-int dppo_axpy(float* y, const float* x, double alpha, int64_t n, dppo_stream_t stream); /* y += alpha * x */
+int dppo_axpy(float* y, const float* x, double alpha, int64_t n, dppo_stream_t stream);
+
+/* ---- next row: supervised denoising loss of pre-training ---------------------------------
+ * DiffusionModel.p_losses + loss.backward() (model/diffusion/diffusion.py:325-349, agent/pretrain/train_diffusion_agent.py):
+ * row n = (x_noisy[n], time embedding of tsteps[kinds[n]].t, obs[n]) through the network;
+ *   loss[0] = mean over (n, Ta*Da) of (eps_theta - target)^2   (double, device; summed in a fixed order)
+ *   grad (dppo_net_param_count floats, overwritten) = d loss / d params.
+ * pairs (N, 2, Ta*Da): [n][0] = x_noisy = sqrt(abar_t) x0 + sqrt(1 - abar_t) noise (q_sample, :351-363), [n][1] = the
+ * regression target (the noise when predicting epsilon).  tsteps: n_time entries whose .t is the diffusion time (the
+ * other fields are ignored); kinds (N,) int64 indexes it.  Same kernels as the PPO update: row builder, fused forward /
+ * backward, grouped weight-gradient GEMM. */
+int64_t dppo_denoise_mse_workspace_bytes(const dppo_net_desc* actor, int prec, int64_t N);
+int dppo_denoise_mse_fwd_bwd(const dppo_net_desc* actor, int prec, const float* params, const void* packed,
+                             const dppo_step* tsteps, int n_time, const float* obs, const float* pairs,
+                             const int64_t* kinds, int64_t N, float* grad, double* loss, void* workspace,
+                             int64_t workspace_bytes, dppo_stream_t stream); /* y += alpha * x */
 
 /* ---- A10: GAE (agent/finetune/train_ppo_diffusion_agent.py:255-279) ----------------------- */
 /* reward (S,E) float64 (already scaled by the host-side running scaler), values (S,E) fp32,

@@ -554,6 +554,22 @@ def bc_loss(cfg: DiffusionCfg, spec: NetSpec, base: Params, ft: Params, state: t
     return -lp.mean(), chains
 
 
+def q_sample(K: int, x_start: torch.Tensor, t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    """model/diffusion/diffusion.py:351-363: x_t = sqrt(abar_t) x_0 + sqrt(1 - abar_t) eps (tables as :104-111)."""
+    ac = ddpm_tables(K)["alphas_cumprod"]
+    shape = (len(x_start),) + (1,) * (x_start.dim() - 1)
+    return torch.sqrt(ac)[t].reshape(shape) * x_start + torch.sqrt(1.0 - ac)[t].reshape(shape) * noise
+
+
+def denoise_mse_loss(K: int, spec: NetSpec, params: Params, x_start: torch.Tensor, state: torch.Tensor,
+                     t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    """The supervised (pre-training) loss, model/diffusion/diffusion.py:325-349 with predict_epsilon=True:
+    mse_loss(network(q_sample(x_start, t, noise), t, cond), noise), mean over every element."""
+    x_noisy = q_sample(K, x_start, t, noise)
+    pred = actor_forward(params, spec, x_noisy, t, state)
+    return torch.nn.functional.mse_loss(pred, noise, reduction="mean")
+
+
 def ppo_loss(cfg: DiffusionCfg, aspec: NetSpec, cspec: NetSpec, base: Params, ft: Params, critic: Params,
              obs: torch.Tensor, chains_prev: torch.Tensor, chains_next: torch.Tensor,
              denoising_inds: torch.Tensor, returns: torch.Tensor, oldvalues: torch.Tensor,

@@ -295,6 +295,38 @@ def g8_bc():
     save("g8_bc", **out)
 
 
+# ---------------------------------------------------------------- G9 supervised denoising loss (pre-training)
+MSE_CASES = {"mse_hopper": ("hopper", 20), "mse_can_k100": ("can", 100), "mse_square_like": ("square_like", 20),
+             "mse_ln_relu": ("ln_relu", 20)}
+
+
+def g9_denoise_mse():
+    """DiffusionModel.p_losses of the reference (model/diffusion/diffusion.py:325-349) on its ``network`` (= the base
+    actor of a PPODiffusion, whose weights are the seeded recipe) with recorded t and noise, and every gradient."""
+    out = {}
+    rs = np.random.RandomState(900)
+    N = 24
+    for cname, (sname, K) in MSE_CASES.items():
+        a, c = specs(sname)
+        m = ref_model(a, c, 51, gamma_denoising=0.99, clip_ploss_coef=0.01, ft_denoising_steps=min(10, K),
+                      denoising_steps=K)
+        net = m.network
+        for p in net.parameters():
+            p.requires_grad_(True)
+        x0 = torch.from_numpy(rs.uniform(-1, 1, size=(N, a.horizon_steps, a.action_dim)).astype(np.float32))
+        state = torch.from_numpy(rs.uniform(-1, 1, size=(N, 1, a.cond_dim)).astype(np.float32))
+        t = torch.from_numpy(rs.randint(0, K, size=(N,)).astype(np.int64))
+        noise = torch.from_numpy(rs.randn(N, a.horizon_steps, a.action_dim).astype(np.float32))
+        with recorded_noise([noise]):
+            loss = m.p_losses(x0, {"state": state}, t)
+        loss.backward()
+        out.update({f"{cname}_x0": x0, f"{cname}_state": state, f"{cname}_t": t, f"{cname}_noise": noise,
+                    f"{cname}_xnoisy": m.q_sample(x0, t, noise), f"{cname}_loss": np.float64(loss.item())})
+        for k, p in net.named_parameters():
+            put_grad(out, f"{cname}_g_{k}", p.grad)
+    save("g9_denoise_mse", **out)
+
+
 # ---------------------------------------------------------------- G6 reward scaler (GAE loop is not importable)
 def g6_reward_scaler():
     rs = np.random.RandomState(400)
@@ -335,6 +367,6 @@ def g7_adamw():
 
 if __name__ == "__main__":
     only = sys.argv[1:]  # e.g. `make_golden.py g8_bc` regenerates one file (each generator owns its RNG stream)
-    for fn in (g1_tables, g2_forward, g3_g4_chains, g5_loss, g6_reward_scaler, g7_adamw, g8_bc):
+    for fn in (g1_tables, g2_forward, g3_g4_chains, g5_loss, g6_reward_scaler, g7_adamw, g8_bc, g9_denoise_mse):
         if not only or fn.__name__ in only:
             fn()

@@ -435,6 +435,48 @@ def test_loss_with_bc_term_hands_gradients_to_autograd():
 
 
 # ------------------------------------------------------------------ fused row-tile kernels vs layered GEMM chain
+@pytest.mark.parametrize("case", ["mse_hopper", "mse_can_k100", "mse_square_like", "mse_ln_relu"])
+def test_denoise_mse_loss_and_gradients(golden, case):
+    """DiffusionModel.p_losses (pre-training loss, reference diffusion.py:325-363) through dppo_denoise_mse_fwd_bwd:
+    fp32 against the reference's golden loss and gradients; bf16 against the fp32 result (loss 2e-2, cosine 0.99)."""
+    from tests.test_oracle_golden import MSE_CASES
+    g = golden("g9_denoise_mse")
+    sname, K = MSE_CASES[case]
+    d = lambda k: T(g[f"{case}_{k}"]).to(DEV)
+    flat = {}
+    for prec in ("fp32", "bf16"):
+        m, a, _ = build_model(sname, dict(denoising_steps=K, ft_denoising_steps=min(10, K)), 51, prec)
+        net = m.network
+        for p in net.parameters():  # the fine-tuning wrapper freezes its base policy; pre-training trains it
+            p.requires_grad_(True)
+        np.testing.assert_allclose(m.q_sample(d("x0"), d("t"), d("noise")).cpu().numpy(), g[f"{case}_xnoisy"], rtol=1e-6,
+                                   atol=1e-7)
+        loss = m.p_losses(d("x0"), {"state": d("state")}, d("t"), noise=d("noise"))
+        loss.backward()
+        flat[prec] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).double().cpu().numpy()
+        if prec == "fp32":
+            assert loss.item() == pytest.approx(float(g[f"{case}_loss"]), rel=1e-4)
+            for k, p in net.named_parameters():
+                grad, key = p.grad.cpu().numpy(), f"{case}_g_{k}"
+                ref_n = float(g[key + "__norm"]) if key not in g else float(np.linalg.norm(g[key]))
+                atol = 2e-4 * max(ref_n, 1e-8) / np.sqrt(grad.size) + 1e-7
+                if key in g:
+                    np.testing.assert_allclose(grad, g[key], rtol=2e-3, atol=atol)
+                else:
+                    np.testing.assert_allclose(grad.reshape(-1)[::61], g[key + "__sub"], rtol=2e-3, atol=atol)
+                    assert np.linalg.norm(grad.astype(np.float64)) == pytest.approx(ref_n, rel=2e-4)
+        else:
+            assert loss.item() == pytest.approx(float(g[f"{case}_loss"]), rel=2e-2)
+    x, y = flat["fp32"], flat["bf16"]
+    assert float(np.dot(x, y) / (np.linalg.norm(x) * np.linalg.norm(y))) >= 0.99
+    # the loss draws its own t / noise when none is given, reproducibly under torch.manual_seed
+    from dppo_amd.model.diffusion.diffusion import DiffusionModel  # (PPODiffusion.loss is the PPO loss)
+    torch.manual_seed(4)
+    l1 = DiffusionModel.loss(m, d("x0"), {"state": d("state")}).item()
+    torch.manual_seed(4)
+    assert DiffusionModel.loss(m, d("x0"), {"state": d("state")}).item() == l1
+
+
 @pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
 @pytest.mark.parametrize("sname", ["hopper", "can", "kitchen_like", "square_like", "transport"])
 def test_fused_path_matches_layered_path(prec, tol, sname):

@@ -253,3 +253,24 @@ def test_bc_loss_matches_reference(golden, case):
     for k, v in ft.items():
         check_grad(g, f"{case}_gbc_{k}", v.grad if v.grad is not None else torch.zeros_like(v), 2e-4, 1e-7)
 
+
+
+# ------------------------------------------------------------------ G9 supervised denoising loss (pre-training)
+MSE_CASES = {"mse_hopper": ("hopper", 20), "mse_can_k100": ("can", 100), "mse_square_like": ("square_like", 20),
+             "mse_ln_relu": ("ln_relu", 20)}
+
+
+@pytest.mark.parametrize("case", sorted(MSE_CASES))
+def test_denoise_mse_matches_reference(golden, case):
+    """DiffusionModel.p_losses (reference model/diffusion/diffusion.py:325-363): q_sample, the loss and every gradient."""
+    g = golden("g9_denoise_mse")
+    sname, K = MSE_CASES[case]
+    a, _ = O.named_specs(sname)
+    prm = {k: v.clone().requires_grad_(True) for k, v in O.init_params(a, 51).items()}
+    x0, state, t, noise = (T(g[f"{case}_{k}"]) for k in ("x0", "state", "t", "noise"))
+    close(O.q_sample(K, x0, t, noise), g[f"{case}_xnoisy"], rtol=1e-6, atol=1e-7)
+    loss = O.denoise_mse_loss(K, a, prm, x0, state, t, noise)
+    assert float(loss.detach()) == pytest.approx(float(g[f"{case}_loss"]), rel=1e-5)
+    loss.backward()
+    for k, v in prm.items():
+        check_grad(g, f"{case}_g_{k}", v.grad if v.grad is not None else torch.zeros_like(v), 2e-4, 1e-7)
