@@ -1339,6 +1339,17 @@ int dppo_adamw_step_multi(const dppo_adamw_slot* slots, int n_slots, dppo_stream
   return check_launch();
 }
 
+int dppo_stats_split(const double* stats, float* hi_lo, dppo_stream_t stream) {
+  if (!stats || !hi_lo) return fail(-1, "null pointer");
+  launch_stats_split(stats, hi_lo, DPPO_STAT_COUNT, (hipStream_t)stream);
+  return check_launch();
+}
+int dppo_stats_merge(const float* hi_lo, double* stats, int world, dppo_stream_t stream) {
+  if (!stats || !hi_lo || world < 1) return fail(-1, "bad argument");
+  launch_stats_merge(hi_lo, stats, DPPO_STAT_COUNT, DPPO_STAT_ADV_MEAN, 2, 1.0 / world, (hipStream_t)stream);
+  return check_launch();
+}
+
 // ---- measurement hook ----------------------------------------------------------------------------------
 int dppo_probe_arm(int kernel_id, int max_launches) {
   if (probe_arm(kernel_id, max_launches)) return fail(-1, "probe already armed or bad size");

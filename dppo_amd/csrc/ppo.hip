@@ -986,6 +986,29 @@ void launch_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, i
   hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, s, step_dev);
 }
 
+// float64 statistics <-> (hi, lo) float32 pairs, so that they can ride in the fp32 gradient bucket of the data-parallel
+// all-reduce without losing precision: one launch each way instead of a dozen elementwise torch kernels
+__global__ void stats_split_kernel(const double* st, float* hi_lo, int n) {
+  const int i = threadIdx.x;
+  if (i >= n) return;
+  const float hi = (float)st[i];
+  hi_lo[i] = hi;
+  hi_lo[n + i] = (float)(st[i] - (double)hi);
+}
+__global__ void stats_merge_kernel(const float* hi_lo, double* st, int n, int first_avg, int n_avg, double inv_world) {
+  const int i = threadIdx.x;
+  if (i >= n) return;
+  double v = (double)hi_lo[i] + (double)hi_lo[n + i];
+  if (i >= first_avg && i < first_avg + n_avg) v *= inv_world;  // global values every rank wrote, not partial sums
+  st[i] = v;
+}
+void launch_stats_split(const double* st, float* hi_lo, int n, hipStream_t s) {
+  hipLaunchKernelGGL(stats_split_kernel, dim3(1), dim3(64), 0, s, st, hi_lo, n);
+}
+void launch_stats_merge(const float* hi_lo, double* st, int n, int first_avg, int n_avg, double inv_world, hipStream_t s) {
+  hipLaunchKernelGGL(stats_merge_kernel, dim3(1), dim3(64), 0, s, hi_lo, st, n, first_avg, n_avg, inv_world);
+}
+
 constexpr int ADAMW_MULTI_EPT = 8;  // elements per thread
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwSlots a) {
   int si = 0;

@@ -88,6 +88,8 @@ SYMBOLS = {
     "dppo_adamw_step": (_I, [_P, _P, _P, _P, _L, _I, _D, _D, _D, _D, _D, _P, _D, _P]),
     "dppo_adamw_step_dev": (_I, [_P, _P, _P, _P, _L, _P, _P, _D, _D, _D, _D, _P, _D, _P]),
     "dppo_adamw_step_multi": (_I, [_P, _I, _P]),
+    "dppo_stats_split": (_I, [_P, _P, _P]),
+    "dppo_stats_merge": (_I, [_P, _P, _I, _P]),
     "dppo_probe_arm": (_I, [_I, _I]),
     "dppo_probe_collect": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "dppo_probe_collect_bytes": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double),

@@ -259,6 +259,13 @@ typedef struct dppo_adamw_slot {
 } dppo_adamw_slot;
 int dppo_adamw_step_multi(const dppo_adamw_slot* slots, int n_slots, dppo_stream_t stream);
 
+/* Data parallel: the float64 statistics ride in the fp32 gradient bucket of the one all-reduce per optimiser step
+ *  as (hi, lo) float32 pairs.  split: hi_lo[0..8) = (float)stats, hi_lo[8..16) = the remainder; merge: back
+ * to float64 after the SUM-reduce, with the two advantage statistics (global values every rank wrote) divided by
+ * `world`.  One launch each way. */
+int dppo_stats_split(const double* stats, float* hi_lo, dppo_stream_t stream);
+int dppo_stats_merge(const float* hi_lo, double* stats, int world, dppo_stream_t stream);
+
 /* ---- measurement hook (bench.py only; process-wide, not thread-safe, off by default) ----------- */
 /* While armed for a kernel, each of its launches is bracketed by HIP events on the launch stream.
  * kernel_id: 1 = gemm_nt on an H x H layer (layered path), 2 = gemm_tn weight gradient (N1,N2 >= 128),

@@ -322,6 +322,26 @@ def test_adamw_multi_equals_single_steps(golden):
         np.testing.assert_allclose(p.cpu().numpy(), g[f"p{i + 1}"], rtol=1e-6, atol=1e-7)
 
 
+def test_stats_travel_through_an_fp32_bucket_without_losing_precision():
+    """dppo_stats_split / dppo_stats_merge: float64 statistics as (hi, lo) float32 pairs in the gradient bucket of the
+    data-parallel all-reduce; a SUM over `world` identical ranks gives world x the sums and leaves the two advantage
+    statistics (global values every rank wrote) unchanged."""
+    from dppo_amd import hip
+    lib = hip.load()
+    st = torch.tensor([-4.76771234567891e-4, 0.506691234567891, 1.50361234567e-5, 7.3167e-2, 0.999861234567891,
+                       6.61912345678e-2, 1.02081234567891, 0.0], dtype=torch.float64, device=DEV)
+    tail = torch.zeros(16, dtype=torch.float32, device=DEV)
+    hip.check(lib.dppo_stats_split(st.data_ptr(), tail.data_ptr(), hip.stream()), "dppo_stats_split")
+    assert torch.equal(tail[:8], st.float())
+    world = 4
+    tail *= world  # what the SUM-reduce over `world` identical ranks leaves (exact: a power of two)
+    out = torch.zeros_like(st)
+    hip.check(lib.dppo_stats_merge(tail.data_ptr(), out.data_ptr(), world, hip.stream()), "dppo_stats_merge")
+    expect = st * world
+    expect[5:7] = st[5:7]
+    assert torch.allclose(out, expect, rtol=1e-13, atol=1e-300)
+
+
 @pytest.mark.parametrize("case", ["ddim100_5", "ddpm20_ft10"])
 def test_logprob_subsample_matches_chain_logprobs(golden, case):
     """get_logprobs_subsample (reference diffusion_vpg.py:398-461) == the matching entries of get_logprobs and of the
