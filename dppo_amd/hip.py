@@ -139,7 +139,14 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream() -> int:
+    """hipStream_t of torch's current stream on the current device (called once per library call: the raw getter costs
+    0.3 us where ``torch.cuda.current_stream().cuda_stream`` costs 10)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

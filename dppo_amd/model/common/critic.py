@@ -25,10 +25,14 @@ class CriticObs(HipNet):
         object.__setattr__(self, "_ws", hip.Workspace())
 
     def net_desc(self) -> hip.NetDesc:
-        q = self.Q1
-        return hip.NetDesc(kind=1, in_dim=self.cond_dim, hidden=q.hidden, n_blocks=q.n_blocks, out_dim=1, act=q.act,
-                           time_dim=0, act_flat=0, cond_dim=self.cond_dim, cond_hidden=0, cond_out=0,
-                           use_layernorm=q.use_layernorm)
+        d = self.__dict__.get("_desc_cache")  # architecture is fixed after construction
+        if d is None:
+            q = self.Q1
+            d = hip.NetDesc(kind=1, in_dim=self.cond_dim, hidden=q.hidden, n_blocks=q.n_blocks, out_dim=1, act=q.act,
+                            time_dim=0, act_flat=0, cond_dim=self.cond_dim, cond_hidden=0, cond_out=0,
+                            use_layernorm=q.use_layernorm)
+            object.__setattr__(self, "_desc_cache", d)
+        return d
 
     @torch.no_grad()
     def forward(self, cond: Union[dict, torch.Tensor]) -> torch.Tensor:

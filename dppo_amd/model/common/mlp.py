@@ -82,7 +82,7 @@ class HipNet(nn.Module):
         nn.Module.__init__(new)
         import copy
         for k, v in self.__dict__.items():
-            if k in ("_flat", "_flat_grad", "_packed", "_epoch"):
+            if k in ("_flat", "_flat_grad", "_packed", "_epoch", "_plist", "_last_off", "_desc_cache"):
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         object.__setattr__(new, "_flat", None)
@@ -92,7 +92,16 @@ class HipNet(nn.Module):
         return new
 
     def flat_params(self) -> torch.Tensor:
+        # hot path (called several times per sampler / update call): the cached flat image is valid as long as the first
+        # and the last parameter still sit at their offsets in it -- `.to()` / a re-assigned `.data` move all of them
+        flat, ps = self._flat, self.__dict__.get("_plist")
+        if flat is not None and ps is not None:
+            first, last = ps[0], ps[-1]
+            if first.data_ptr() == flat.data_ptr() and last.data_ptr() == flat.data_ptr() + 4 * self._last_off:
+                return flat
         ps = list(self.parameters())
+        object.__setattr__(self, "_plist", ps)
+        object.__setattr__(self, "_last_off", sum(p.numel() for p in ps[:-1]))
         flat = self._flat
         ok = flat is not None and flat.device == ps[0].device
         if ok:

@@ -22,6 +22,8 @@ log = logging.getLogger(__name__)
 
 
 class VPGDiffusion(DiffusionModel):
+    supports_out = True  # forward(..., out=(trajectories, chains)) writes caller-owned buffers (util/rollout.py)
+
     def __init__(self, actor, critic, ft_denoising_steps, ft_denoising_steps_d=0, ft_denoising_steps_t=0,
                  network_path=None, min_sampling_denoising_std=0.1, min_logprob_denoising_std=0.1, eta=None,
                  learn_eta=False, **kwargs):
@@ -162,8 +164,11 @@ class VPGDiffusion(DiffusionModel):
 
     # ------------------------------------------------------------------ sampling (reference :227-315)
     @torch.no_grad()
-    def forward(self, cond, deterministic=False, return_chain=True, use_base_policy=False, noise=None):
+    def forward(self, cond, deterministic=False, return_chain=True, use_base_policy=False, noise=None, out=None):
         """cond {"state": (B,To,Do)} -> Sample(trajectories (B,Ta,Da), chains (B,Kft+1,Ta,Da)).
+
+        ``out = (trajectories, chains)``: contiguous fp32 device tensors of B*Ta*Da and B*(Kft+1)*Ta*Da elements the
+        kernel writes straight into (the rollout loop passes slices of its buffer: no allocation, no copy kernel).
 
         ``noise`` (n_steps+1,B,Ta,Da) replaces the internal draw (parity tests): noise[0] is the initial x, noise[i+1]
         the draw of step i.  Without it the kernel draws N(0,1) itself (Philox keyed by a 64-bit value taken from
@@ -183,8 +188,14 @@ class VPGDiffusion(DiffusionModel):
         else:
             noise = noise.reshape(n_steps + 1, B, AF).contiguous().float()
         obs = state.reshape(B, -1).contiguous().float()
-        traj = torch.empty((B, AF), device=dev, dtype=torch.float32)
-        chains = torch.empty((B, chain_len, AF), device=dev, dtype=torch.float32) if return_chain else None
+        if out is not None:
+            traj, chains = out
+            assert traj.is_contiguous() and traj.dtype == torch.float32 and traj.numel() == B * AF and traj.device == dev
+            assert not return_chain or (chains.is_contiguous() and chains.dtype == torch.float32 and
+                                        chains.numel() == B * chain_len * AF and chains.device == dev)
+        else:
+            traj = torch.empty((B, AF), device=dev, dtype=torch.float32)
+            chains = torch.empty((B, chain_len, AF), device=dev, dtype=torch.float32) if return_chain else None
         lib = hip.load()
         d = self.actor.net_desc()
         K = self.denoising_steps

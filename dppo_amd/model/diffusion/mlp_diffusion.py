@@ -57,11 +57,16 @@ class DiffusionMLP(HipNet):
         object.__setattr__(self, "_ws", hip.Workspace())
 
     def net_desc(self) -> hip.NetDesc:
+        d = self.__dict__.get("_desc_cache")  # architecture is fixed after construction
+        if d is not None:
+            return d
         m = self.mlp_mean
         ch, co = self.cond_mlp_dims if self.cond_mlp_dims is not None else (0, 0)
-        return hip.NetDesc(kind=0, in_dim=m.in_dim, hidden=m.hidden, n_blocks=m.n_blocks, out_dim=m.out_dim, act=m.act,
-                           time_dim=self.time_dim, act_flat=m.out_dim, cond_dim=self.cond_dim, cond_hidden=ch,
-                           cond_out=co, use_layernorm=m.use_layernorm)
+        d = hip.NetDesc(kind=0, in_dim=m.in_dim, hidden=m.hidden, n_blocks=m.n_blocks, out_dim=m.out_dim, act=m.act,
+                        time_dim=self.time_dim, act_flat=m.out_dim, cond_dim=self.cond_dim, cond_hidden=ch,
+                        cond_out=co, use_layernorm=m.use_layernorm)
+        object.__setattr__(self, "_desc_cache", d)
+        return d
 
     @torch.no_grad()
     def forward(self, x, time, cond, **kwargs):

@@ -36,7 +36,6 @@ class PinnedHandoff:
     """obs numpy -> device tensor, action device tensor -> numpy, through two pinned staging buffers each way."""
 
     def __init__(self, n_envs: int, obs_shape, act_shape, device):
-        import numpy as np  # noqa: F401
         self.device = torch.device(device)
         pin = self.device.type == "cuda"
         mk = lambda shape: [torch.empty((n_envs, *shape), dtype=torch.float32, pin_memory=pin) for _ in range(2)]
@@ -44,17 +43,20 @@ class PinnedHandoff:
         self._ev = [torch.cuda.Event() if pin else None for _ in range(2)]
         self._i = 0
 
-    def obs_to_device(self, obs_np) -> torch.Tensor:
-        """Host copy into the pinned slot, then an asynchronous H2D on the current stream."""
+    def obs_to_device(self, obs_np, out: torch.Tensor = None) -> torch.Tensor:
+        """Host copy into the pinned slot, then an asynchronous H2D on the current stream (into ``out`` when given)."""
         self._i ^= 1
         slot = self._obs[self._i]
         slot.copy_(torch.from_numpy(obs_np).reshape(slot.shape))
-        return slot.to(self.device, non_blocking=True)
+        if out is None:
+            return slot.to(self.device, non_blocking=True)
+        out.copy_(slot.reshape(out.shape), non_blocking=True)
+        return out
 
     def action_to_host_async(self, action_dev: torch.Tensor) -> int:
-        """Start the D2H of an action chunk; returns a ticket for ``action_numpy``.  Does not block the host."""
+        """Start the D2H of an action tensor; returns a ticket for ``action_numpy``.  Does not block the host."""
         i = self._i
-        self._act[i].copy_(action_dev, non_blocking=True)
+        self._act[i].copy_(action_dev.reshape(self._act[i].shape), non_blocking=True)
         if self._ev[i] is not None:
             self._ev[i].record()
         return i
@@ -120,32 +122,43 @@ def collect_rollout(model, venv, prev_obs, n_steps: int, act_steps: int, obs_buf
         key = (n, tuple(state0.shape[1:]), act_steps, chains_buf.shape[-1], str(dev))
         cache = getattr(venv, "_dppo_handoffs", None)
         if cache is None or cache[0] != key:
-            cache = (key, [PinnedHandoff(n, state0.shape[1:], (act_steps, chains_buf.shape[-1] // model.horizon_steps), dev)
-                           for _ in range(G)])
+            Ta = model.horizon_steps  # whole trajectories cross PCIe (contiguous rows); the host keeps the first act_steps
+            cache = (key, [PinnedHandoff(n, state0.shape[1:], (Ta, chains_buf.shape[-1] // Ta), dev) for _ in range(G)],
+                     [torch.empty(n, chains_buf.shape[-1], device=dev) for _ in range(2 * G)])
             try:
                 venv._dppo_handoffs = cache
             except AttributeError:
                 pass
-        handoffs = cache[1]
+        handoffs, traj_bufs = cache[1], cache[2]
+    else:
+        traj_bufs = [torch.empty(n, chains_buf.shape[-1], device=dev) for _ in range(2 * G)]
     reward = np.zeros((n_steps, E))
     terminated = np.zeros((n_steps, E))
     done = np.zeros((n_steps, E))
     obs_g = [state0[g * n:(g + 1) * n] for g in range(G)]
     Kp1 = chains_buf.shape[1]
 
+    To_Do = state0.shape[1:]
+    direct = getattr(model, "supports_out", False)  # PPODiffusion: the kernel writes the buffer slices itself
+
     def launch(step, g):
-        """Sampler call of group g for `step` + buffer fill + asynchronous action D2H; returns the D2H ticket."""
-        state = handoffs[g].obs_to_device(obs_g[g])
-        smp = model(cond={"state": state}, deterministic=deterministic, return_chain=True)
+        """H2D of group g's observations into its buffer rows, the sampler call writing the chain rows in place, the
+        asynchronous D2H of the trajectories; returns the D2H ticket.  No allocation, no copy kernel."""
         r0 = step * E + g * n
-        obs_buf[r0:r0 + n] = state.reshape(n, -1)
-        chains_buf[r0:r0 + n] = smp.chains.reshape(n, Kp1, -1)
-        return handoffs[g].action_to_host_async(smp.trajectories[:, :act_steps])
+        state = handoffs[g].obs_to_device(obs_g[g], out=obs_buf[r0:r0 + n]).view(n, *To_Do)
+        if direct:
+            traj = traj_bufs[2 * g + (step & 1)]
+            model(cond={"state": state}, deterministic=deterministic, return_chain=True, out=(traj, chains_buf[r0:r0 + n]))
+        else:
+            smp = model(cond={"state": state}, deterministic=deterministic, return_chain=True)
+            chains_buf[r0:r0 + n] = smp.chains.reshape(n, Kp1, -1)
+            traj = smp.trajectories
+        return handoffs[g].action_to_host_async(traj)
 
     tickets = [launch(0, g) for g in range(G)]
     for step in range(n_steps):
         for g in range(G):
-            action = handoffs[g].action_numpy(tickets[g])
+            action = handoffs[g].action_numpy(tickets[g])[:, :act_steps]
             o, r, term, trunc, _ = groups[g].step(action)
             if isinstance(o, list):
                 o = {k: np.stack([x[k] for x in o]) for k in o[0]}
