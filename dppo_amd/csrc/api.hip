@@ -1428,6 +1428,10 @@ int dppo_tune_set(int knob, int value) {
     g_early_join = value;
     return 0;
   }
+  if (knob == 15) {
+    set_sampler_l0_lds(value);
+    return 0;
+  }
   return fail(-1, "unknown tuning knob %d", knob);
 }
 

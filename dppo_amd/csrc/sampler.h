@@ -44,11 +44,14 @@ struct SampleArgs {
   int B, AF, td, cond, Kp0, nb, n_steps, chain_len, init_slot, act, use_ddim;
   int has_dclip, has_eclip, has_fclip;
   int consts_lds;  // set by the launcher: 1 = both networks' biases staged in LDS
+  int ks0v;        // set by the launcher: k-steps of layer 0 that hold input columns (the rest of its KS0 is zero padding)
+  int l0_lds;      // set by the launcher: 1 = layer-0 fragments of the current network live in LDS, not in the stream
   float dclip, eclip, rclip, fclip;
 };
 
 template <class P>
 int launch_sample_chain(const SamplerGeom& g, const SampleArgs& a, hipStream_t s);  // 0 ok, <0 unsupported
+void set_sampler_l0_lds(int v);  // tuning knob 15
 
 // W: [H][ld] fp32 (nn.Linear layout).  Writes the fragments of one hidden layer (KS k-steps) into
 // every wave's stream at position pos0.

@@ -39,9 +39,11 @@ __device__ __forceinline__ float philox_normal(uint64_t idx, uint32_t k0, uint32
   return sqrtf(-2.f * __logf(u1)) * __cosf(6.283185307179586f * u2);
 }
 
-template <class P, int TPW, int OT, bool LN, int ACT>
+template <class P, int TPW, int OT, bool LN, int ACT, int PDX = sampler_pd(128 * TPW)>
 __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
-  constexpr int PD = sampler_pd(128 * TPW), ES = P::ESIZE, KB = P::KB;
+  // PDX: ring depth.  (A depth of 8 at H = 512 -- legal once layer 0 is LDS-resident and never passes through the ring --
+  // spills 98 VGPRs: the ring alone would be 128 registers.)
+  constexpr int PD = PDX, ES = P::ESIZE, KB = P::KB;
   constexpr int H = 128 * TPW, KSH = H / KB, CNT = (KSH + SAMPLER_WAVES - 1) / SAMPLER_WAVES;
   constexpr int HRB = H * ES;  // hidden row bytes
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -114,13 +116,24 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
                         a.ostream[1] + (size_t)wid * CNT * OT * 64 + lane};
   const int wbase = wid * 16 * TPW;  // this wave's feature slice; the lane's features: wbase + feat_off<P>(g, tp) + e
 
+  // Layer 0 is 4 of the 36 k-step positions a step streams at H = 512 (2 of them zero padding): its fragments of the
+  // network in use stay in LDS (each wave keeps its own slice: no barrier around a reload, which happens only when the
+  // step table switches network) and the ring skips those positions.
+  const bool l0_lds = a.l0_lds != 0;
+  const int ks0v = a.ks0v, skip = l0_lds ? KS0 : 0;
+  char* w0L = (char*)(biasL + (bias_lds ? 2 * bias_stride : 0)) + (size_t)wid * ks0v * TPW * 1024;
+  auto load_w0 = [&](int net) {
+    for (int q = 0; q < ks0v * TPW; ++q) *(u32x4*)(w0L + ((size_t)q * 64 + lane) * 16) = ws[net][(size_t)q * 64];
+  };
+  if (l0_lds) load_w0(a.sched[0].net);
+
   u32x4 ring[PD][TPW];
   {
     const int n0 = a.sched[0].net;
 #pragma unroll
     for (int p = 0; p < PD; ++p)
 #pragma unroll
-      for (int tp = 0; tp < TPW; ++tp) ring[p][tp] = ws[n0][(p * TPW + tp) * 64];
+      for (int tp = 0; tp < TPW; ++tp) ring[p][tp] = ws[n0][((size_t)(skip + p) * TPW + tp) * 64];
   }
   __syncthreads();
 
@@ -180,7 +193,7 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
           for (int tp = 0; tp < TPW; ++tp) acc[tp][0] = P::mma(ring[p][tp], xb, acc[tp][0]);
           // refill the slot just consumed with the fragments PD positions ahead (next layer / next step included)
           const int np = pos + ks + PD;
-          const u32x4* src_w = np < total ? cur + (size_t)np * TPW * 64 : nxt + (size_t)(np - total) * TPW * 64;
+          const u32x4* src_w = np < total ? cur + (size_t)np * TPW * 64 : nxt + (size_t)(np - total + skip) * TPW * 64;
 #pragma unroll
           for (int tp = 0; tp < TPW; ++tp) ring[p][tp] = src_w[tp * 64];
         }
@@ -230,7 +243,27 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
       }
     };
     // ---- layer 0
-    run_layer(xin, in_rb, in_km, KS0, 0);
+    if (l0_lds) {
+      if (bias_lds) {
+#pragma unroll
+        for (int tp = 0; tp < TPW; ++tp) acc[tp][0] = *(const f32x4*)(biasL + net * bias_stride + wbase + feat_off<P>(g, tp));
+      } else {
+        const int boff = a.bias_off[0];
+#pragma unroll
+        for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[tp][0][e] = prm[boff + wbase + feat_off<P>(g, tp) + e];
+      }
+      for (int ks = 0; ks < ks0v; ++ks) {
+        const u32x4 xb = *(const u32x4*)(xin + r * in_rb + (((ks * 4 + g) ^ (r & in_km)) << 4));
+#pragma unroll
+        for (int tp = 0; tp < TPW; ++tp)
+          acc[tp][0] = P::mma(*(const u32x4*)(w0L + ((size_t)(ks * TPW + tp) * 64 + lane) * 16), xb, acc[tp][0]);
+      }
+      pos = KS0;
+    } else {
+      run_layer(xin, in_rb, in_km, KS0, 0);
+    }
 #pragma unroll
     for (int tp = 0; tp < TPW; ++tp) h[tp][0] = acc[tp][0];
     if (nb > 0)
@@ -329,6 +362,7 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
       }
       // a cond_mlp encodes the observation per network: swap the state columns when the next step switches network
       if (sn.net != st.net && a.obs[0] != a.obs[1]) put_state(sn.net);
+      if (l0_lds && sn.net != st.net) load_w0(sn.net);  // wave-private slice: the wave that wrote it is the one that reads it
     }
     __syncthreads();
   }
@@ -356,6 +390,9 @@ SamplerGeom sampler_geom(const dppo_net_desc& d) {
 template SamplerGeom sampler_geom<F32>(const dppo_net_desc&);
 template SamplerGeom sampler_geom<BF16>(const dppo_net_desc&);
 
+static int g_sampler_l0_lds = 1;  // tuning knob 15: layer-0 weight fragments of the sampler resident in LDS
+void set_sampler_l0_lds(int v) { g_sampler_l0_lds = v; }
+
 template <class P, int TPW, int OT, bool LN, int ACT>
 static int launch_cfg(const SamplerGeom& g, const SampleArgs& a, hipStream_t s) {
   const int ES = P::ESIZE;
@@ -367,6 +404,10 @@ static int launch_cfg(const SamplerGeom& g, const SampleArgs& a, hipStream_t s) 
   const size_t bias_bytes = 2 * ((size_t)(1 + 2 * a.nb) * g.H + OT * 16) * 4;
   b.consts_lds = lds + bias_bytes <= 160 * 1024 ? 1 : 0;
   if (b.consts_lds) lds += bias_bytes;
+  b.ks0v = (g.in_dim + P::KB - 1) / P::KB;
+  const size_t w0_bytes = (size_t)SAMPLER_WAVES * b.ks0v * TPW * 1024;
+  b.l0_lds = g_sampler_l0_lds && lds + w0_bytes <= 160 * 1024 ? 1 : 0;
+  if (b.l0_lds) lds += w0_bytes;
   static bool attr_set = false;  // raising the dynamic-LDS cap is idempotent; racing setters are harmless
   auto kern = sample_chain_kernel<P, TPW, OT, LN, ACT>;
   if (!attr_set) {
