@@ -120,3 +120,31 @@ def test_every_shipped_diffusion_mlp_cfg_builds():
             assert n == net.flat_params().numel(), (p, hip.last_error())
             for prec in (hip.PREC_F32, hip.PREC_BF16):
                 assert lib.dppo_packed_bytes(C.byref(net.net_desc()), prec, int(cfg.denoising_steps)) > 0, p
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason="reference checkout not present (GPU box)")
+def test_every_shipped_pretraining_cfg_builds():
+    """Each pre_diffusion_mlp.yaml the reference ships resolves, maps onto dppo_amd's pre-training agent and model, and
+    its network is one the C ABI accepts (the supervised loss runs on the update's kernels)."""
+    import ctypes as C
+    import glob
+
+    from dppo_amd import hip
+    from dppo_amd.agent.pretrain.train_diffusion_agent import TrainDiffusionAgent
+    from dppo_amd.model.diffusion.diffusion import DiffusionModel
+    os.environ.setdefault("DPPO_LOG_DIR", "/tmp/log")
+    os.environ.setdefault("DPPO_DATA_DIR", "/tmp/data")
+    os.environ.setdefault("DPPO_WANDB_ENTITY", "none")
+    paths = sorted(glob.glob(os.path.join(REF_CFG, "*", "pretrain", "*", "pre_diffusion_mlp.yaml")))
+    assert len(paths) >= 19
+    lib = hip.load()
+    built = 0
+    for p in paths:
+        cfg = load_config(p, overrides=["device=cpu"])
+        assert get_class(cfg._target_) is TrainDiffusionAgent, p
+        assert get_class(cfg.model._target_) is DiffusionModel, p
+        net = instantiate(cfg.model.network)
+        assert lib.dppo_net_param_count(C.byref(net.net_desc())) == net.flat_params().numel(), (p, hip.last_error())
+        assert cfg.train.batch_size >= 1 and cfg.ema.decay < 1
+        built += 1
+    assert built == len(paths)
