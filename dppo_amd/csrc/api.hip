@@ -296,6 +296,7 @@ struct MlpBufs {  // activations of one network for M rows
   hipStream_t join_s[2];
   int join_idx[2], n_join;
   float* part;  // column-sum / segment-sum partials
+  float* lowrank;  // [out_dim][H] T = d_out^T . act(z1) of the top block (see lowrank_dw_kernel)
   size_t slab_floats, part_floats;
 };
 
@@ -362,6 +363,7 @@ static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, b
     B.slab_used = 0, B.slab_jobs.n = 0, B.tn_group.n = 0, B.n_join = 0;
     B.part_floats = (size_t)REDUCE_BLOCKS * (H > 1024 ? H : 1024);
     B.part = (float*)c.take(B.part_floats * 4);
+    B.lowrank = (float*)c.take((size_t)round_up(d.out_dim, 16) * H * 4);
   }
 }
 
@@ -510,6 +512,7 @@ static void join_side(hipStream_t main, hipStream_t sidestream, int idx = 0) {
 }
 
 static int g_dbg = 0;  // tuning knob 8: timing experiments on the fused backward (results are wrong while it is set)
+static int g_lowrank_top = 1;      // tuning knob 16: top block's dW2 from the rank-out_dim factorisation (no H x H GEMM, no dh store)
 static int g_early_join = 1;       // tuning knob 14: side streams joined right behind the weight-gradient GEMM launch
 static int g_tn_group = 1;         // tuning knob 12: one launch for all weight-gradient GEMMs of a backward pass
 static int g_tn_target = 256;      // tuning knob 3: workgroups a weight-gradient GEMM aims for (tiles x row splits)
@@ -666,6 +669,8 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       f.dz1[b] = B.dz1_all[b];
     }
     for (int b = 0; b <= nb; ++b) f.dh[b] = B.dh_all[b];
+    const bool lowrank = g_lowrank_top && nb >= 1;
+    if (lowrank) f.dh[nb] = nullptr;  // only dW2 of the top block read it: see lowrank_dw_kernel
     if (g_dbg & 1)  // timing experiment: no gradient stores (the weight-gradient GEMMs then read stale buffers)
       for (int b = 0; b <= nb; ++b) f.dh[b] = nullptr, f.dz1[b < nb ? b : 0] = nullptr;
     if (g_dbg & 2)  // timing experiment: no derivative-source fetch
@@ -701,7 +706,10 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       if (d.kind == 0 && oh < 0) time_embedding_grad<P>(d, prm, pk, L, M, B, B.dh_all[0], grad, krow, ksteps, Kft, aux);
       weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.hE, H, H, M, B, grad + pl.Wout, H, s, true);
       for (int b = nb - 1; b >= 0; --b) {
-        weight_grad<P>(B.dh_all[b + 1], H, H, B.a2[b], H, H, M, B, grad + pl.l2w[b], H, s, true);
+        if (lowrank && b == nb - 1)  // T = d_out^T . act(z1), [out_dim][H]; dW2 = Wout^T . T after the slab reduce
+          weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.a2[b], H, H, M, B, B.lowrank, H, s, true);
+        else
+          weight_grad<P>(B.dh_all[b + 1], H, H, B.a2[b], H, H, M, B, grad + pl.l2w[b], H, s, true);
         weight_grad<P>(B.dz1_all[b], H, H, B.a1[b], H, H, M, B, grad + pl.l1w[b], H, s, true);
       }
       if (oh >= 0)  // + Kft one-hot columns: their block of the result is S[h][k] (B.part), see temb_onehot_col()
@@ -712,6 +720,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       if (aux != s && g_early_join) B.join_s[B.n_join] = aux, B.join_idx[B.n_join++] = aux_idx;
       flush_slabs(B, s);  // every slab of this backward in one reduction launch
       if (aux != s && !g_early_join) join_side(s, aux, aux_idx);
+      if (lowrank) launch_lowrank_dw(prm + pl.Wout, B.lowrank, d.out_dim, H, grad + pl.l2w[nb - 1], s);
       if (oh >= 0)
         launch_time_backward_from_sums(prm + pl.te1_w, prm + pl.te1_b, prm + pl.te2_w, B.part, prm + pl.W0, d.in_dim,
                                        d.act_flat, H, B.part + (size_t)H * Kft, ksteps, Kft, d.time_dim, grad + pl.te1_w,
@@ -1430,6 +1439,10 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 15) {
     set_sampler_l0_lds(value);
+    return 0;
+  }
+  if (knob == 16) {
+    g_lowrank_top = value;
     return 0;
   }
   return fail(-1, "unknown tuning knob %d", knob);

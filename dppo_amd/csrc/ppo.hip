@@ -986,6 +986,21 @@ void launch_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, i
   hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, s, step_dev);
 }
 
+// dW[i][j] = sum_o Wout[o][i] * T[o][j]: the top block's second-layer weight gradient from T = d_out^T . act(z1).
+// d loss / d h_nb = d_out . Wout has rank <= out_dim, so dz2^T . a2 = Wout^T . (d_out^T . a2): a thin contraction over the
+// batch plus this out_dim-deep product replace an H x H contraction over the batch, and dh_nb never goes to HBM.
+__global__ __launch_bounds__(256) void lowrank_dw_kernel(const float* Wout, const float* T, int out_dim, int H, float* dW) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)H * H) return;
+  const int i = (int)(idx / H), j = (int)(idx - (size_t)i * H);
+  float acc = 0.f;
+  for (int o = 0; o < out_dim; ++o) acc += Wout[(size_t)o * H + i] * T[(size_t)o * H + j];
+  dW[idx] = acc;
+}
+void launch_lowrank_dw(const float* Wout, const float* T, int out_dim, int H, float* dW, hipStream_t s) {
+  hipLaunchKernelGGL(lowrank_dw_kernel, dim3((unsigned)(((size_t)H * H + 255) / 256)), dim3(256), 0, s, Wout, T, out_dim, H, dW);
+}
+
 // float64 statistics <-> (hi, lo) float32 pairs, so that they can ride in the fp32 gradient bucket of the data-parallel
 // all-reduce without losing precision: one launch each way instead of a dozen elementwise torch kernels
 __global__ void stats_split_kernel(const double* st, float* hi_lo, int n) {
