@@ -81,7 +81,7 @@ static ParamLayout param_layout(const dppo_net_desc& d) {
 struct PackLayout {  // byte offsets into the packed image
   // every offset depends on (net, prec) only; the time table sits last so that only `total` grows with n_time
   size_t W0, W1[MAX_BLOCKS], W2[MAX_BLOCKS], Wout, W1T[MAX_BLOCKS], W2T[MAX_BLOCKS], WoutT, W0tT, sstream, ostream,
-      bstream, Wc1, Wc2, Wc2T, W0eT, temb, total;
+      bstream, wcomp, Wc1, Wc2, Wc2T, W0eT, temb, total;
   int Kp0, Kpo, tdp;
   int Kpc, C1p, Ep;  // cond_mlp: padded K of the encoder layers (cond, hidden) and padded encoder width
 };
@@ -112,6 +112,7 @@ static PackLayout pack_layout(const dppo_net_desc& d, int n_time) {
     L.sstream = o, o = al256(o + (size_t)SAMPLER_WAVES * g.hidden_frags_per_wave * 64 * 16);
     L.ostream = o, o = al256(o + (size_t)SAMPLER_WAVES * g.out_frags_per_wave * 64 * 16);
     L.bstream = o, o = al256(o + (size_t)SAMPLER_WAVES * fg.frags_per_wave * 64 * 16);
+    L.wcomp = o, o = al256(o + (size_t)d.out_dim * H * 4);  // fp32 Wout . W2 of the top block (source of its composite layer)
   }
   L.Kpc = round_up(d.cond_dim > 0 ? d.cond_dim : 1, 64);
   if (d.cond_hidden > 0) {  // observation encoder: row-major GEMM operands (small), W2^T and the encoder columns of W0
@@ -220,9 +221,18 @@ static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char*
       ps.layer[ps.n_layers++] = PackLayer{prm + pl.l2w[b], H, 1, H, g.KSH, g.KS0 + (2 * b + 1) * g.KSH, fwd, g.total_pos};
     }
     ps.layer[ps.n_layers++] = PackLayer{prm + pl.Wout, 1, H, d.out_dim, fg.KSB0, 0, bwd, fg.total_pos};
-    for (int b = d.n_blocks - 1, pos = fg.KSB0; b >= 0; --b, pos += 2 * g.KSH) {
-      ps.layer[ps.n_layers++] = PackLayer{prm + pl.l2w[b], 1, H, H, g.KSH, pos, bwd, fg.total_pos};
-      ps.layer[ps.n_layers++] = PackLayer{prm + pl.l1w[b], 1, H, H, g.KSH, pos + g.KSH, bwd, fg.total_pos};
+    for (int b = d.n_blocks - 1, pos = fg.KSB0; b >= 0; --b) {
+      if (b == d.n_blocks - 1) {  // top block: the composite (Wout . W2)^T, laid out like the Wout^T layer
+        float* wc = (float*)(pk + L.wcomp);
+        launch_compose_wc(prm + pl.Wout, prm + pl.l2w[b], d.out_dim, H, wc, s);
+        ps.layer[ps.n_layers++] = PackLayer{wc, 1, H, d.out_dim, fg.KSB0, pos, bwd, fg.total_pos};
+        pos += fg.KSB0;
+      } else {
+        ps.layer[ps.n_layers++] = PackLayer{prm + pl.l2w[b], 1, H, H, g.KSH, pos, bwd, fg.total_pos};
+        pos += g.KSH;
+      }
+      ps.layer[ps.n_layers++] = PackLayer{prm + pl.l1w[b], 1, H, H, g.KSH, pos, bwd, fg.total_pos};
+      pos += g.KSH;
     }
     if (one_launch) {  // + out-layer stream, time-embedding table and W0tT, all in the same launch
       int maxks = 0;

@@ -48,7 +48,9 @@ struct FusedFwdArgs {
 };
 
 struct FusedBwdArgs {
-  const u32x4* bstream;  // backward stream: [dh layer (Wout^T)][per block, top down: W2^T, W1^T]
+  const u32x4* bstream;  // backward stream: [dh layer (Wout^T)][top block: (Wout . W2)^T as short as the dh layer, W1^T]
+                         // [lower blocks, top down: W2^T, W1^T].  d loss / d h_nb = d_out . Wout has rank <= out_dim,
+                         // so the top block's dh . W2 is d_out . (Wout . W2): a K = out_dim layer, not a K = H one.
   const void* d_out;     // [M][Kpo] elem, zero padded
   int ld_dout;
   int M, KpB0, nb, act;

@@ -432,10 +432,10 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
   const int r = lane & 15, g = lane >> 4;
   const int nb = a.nb, M = a.M;
   const int in_rb = a.KpB0 * ES, in_km = kmask16(in_rb), KSB0 = a.KpB0 / KB;
-  const int total = KSB0 + 2 * nb * KSH;
+  const int total = nb >= 1 ? 2 * KSB0 + (2 * nb - 1) * KSH : KSB0;
   char* bufA = smem;
   char* bufB = bufA + MT * HRB;
-  char* xin = bufB;  // d_out tile: consumed by the first layer, which emits into bufA
+  char* xin = bufB;  // d_out tile: consumed by the first layer and by the top block's composite layer
   float* lnred = (float*)(bufB + MT * HRB);  // [8 waves][2][MR][16] LayerNorm row-reduction table (LN only)
   constexpr int DRED_COLS = 128;             // d_out is at most 128 columns wide
   float* dred = lnred + (LN ? LN_WAVES * 2 * MR * 16 : 0);  // [8 waves][128] column sums of the d_out tile
@@ -521,7 +521,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
     for (int tp = 0; tp < TPW; ++tp)
 #pragma unroll
       for (int m = 0; m < MR; ++m) dh[tp][m] = acc[tp][m];
-    emit<P, TPW, MR>(dh, ACT_NONE, bufA, a.dh[nb], H, wbase, g, r, row0, M);
+    // (with blocks, nobody reads the LDS image of dh[nb]: the top block's first layer is the composite on d_out)
+    emit<P, TPW, MR>(dh, ACT_NONE, nb >= 1 ? nullptr : bufA, a.dh[nb], H, wbase, g, r, row0, M);
     STAMP(19);
     colsum(dh, 0, tile);
     STAMP(20);
@@ -533,14 +534,21 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
       for (int w = 0; w < SAMPLER_WAVES; ++w) t += dred[w * DRED_COLS + tid];
       a.colsum[((size_t)a.dout_slot * ntiles + tile) * H + tid] = t;
     }
+    // pa: image the block's first layer reads (dh[b+1]) and its second layer's emit target; pb: the other one.  The top
+    // block reads the d_out tile (which lives in bufB) instead, so its dz1 goes to bufA and the roles swap from there on.
+    char* pa = bufA;
+    char* pb = bufB;
     for (int b = nb - 1; b >= 0; --b) {
+      const bool top = b == nb - 1;
       // ---- dz1 = (dh . W2) * act'(z1)       [LayerNorm: back through act(LN2(z1))]
+      // top block: dh[nb] . W2 = d_out . (Wout . W2) -- a K = out_dim layer on the d_out tile instead of a K = H one
       u32x4 d[MR][Chunks<P, TPW>::CH];
       // derivative sources: issued ahead of the layer so the latency hides under it -- except at two workgroups per CU,
       // where 128 VGPRs cannot carry them through the k-loop and the other workgroup hides the latency instead
       if constexpr (!FETCH_LATE) fetch<P, ACT == ACT_RELU && !LN, TPW>(d, a.m1[b], H, wbase, g, r, row0, M);
       zero_acc();
-      eng.run(acc, bufA, HRB, 15, KSH, r, g);
+      // (one call site with selected operands: a second inlined copy of the k-loop costs 150 spilled VGPRs)
+      eng.run(acc, top ? xin : pa, top ? in_rb : HRB, top ? in_km : 15, top ? KSB0 : KSH, r, g);
       if constexpr (FETCH_LATE) fetch<P, ACT == ACT_RELU && !LN, TPW>(d, a.m1[b], H, wbase, g, r, row0, M);
       STAMP(22);
       if constexpr (LN) {
@@ -560,7 +568,11 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[tp][m][e] *= grad_at<P, ACT>(d, tp, m, e);
       }
-      emit<P, TPW, MR>(acc, ACT_NONE, bufB, a.dz1[b], H, wbase, g, r, row0, M);
+      if (top) {  // xin == bufB is still being read by slower waves: dz1 goes to the other image
+        char* t = pa;
+        pa = pb, pb = t;
+      }
+      emit<P, TPW, MR>(acc, ACT_NONE, pb, a.dz1[b], H, wbase, g, r, row0, M);
       STAMP(23);
       colsum(acc, (nb + 1) + (nb - 1 - b), tile);
       STAMP(24);
@@ -569,7 +581,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
       // ---- dh[b] = dh[b+1] + (dz1 . W1) * act'(h_b)       [LayerNorm: back through act(LN1(h_b))]
       if constexpr (!FETCH_LATE) fetch<P, ACT == ACT_RELU && !LN, TPW>(d, a.m0[b], H, wbase, g, r, row0, M);
       zero_acc();
-      eng.run(acc, bufB, HRB, 15, KSH, r, g);
+      eng.run(acc, pb, HRB, 15, KSH, r, g);
       if constexpr (FETCH_LATE) fetch<P, ACT == ACT_RELU && !LN, TPW>(d, a.m0[b], H, wbase, g, r, row0, M);
       STAMP(26);
       if constexpr (LN) {
@@ -593,7 +605,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
 #pragma unroll
             for (int e = 0; e < 4; ++e) dh[tp][m][e] += acc[tp][m][e] * grad_at<P, ACT>(d, tp, m, e);
       }
-      emit<P, TPW, MR>(dh, ACT_NONE, bufA, a.dh[b], H, wbase, g, r, row0, M);
+      emit<P, TPW, MR>(dh, ACT_NONE, pa, a.dh[b], H, wbase, g, r, row0, M);
       STAMP(27);
       colsum(dh, nb - b, tile);
       STAMP(28);
@@ -652,7 +664,8 @@ FusedGeom fused_geom(const dppo_net_desc& d) {
   const int pd = sampler_pd(d.hidden);
   g.KpB0 = round_up(round_up(d.out_dim, 64), pd * P::KB);
   g.KSB0 = g.KpB0 / P::KB;
-  g.total_pos = g.KSB0 + 2 * d.n_blocks * (d.hidden / P::KB);
+  // top block: its W2^T layer is replaced by the composite (Wout . W2)^T, as short as the Wout^T layer (see FusedBwdArgs)
+  g.total_pos = d.n_blocks >= 1 ? 2 * g.KSB0 + (2 * d.n_blocks - 1) * (d.hidden / P::KB) : g.KSB0;
   g.frags_per_wave = (size_t)g.total_pos * (d.hidden / 128);
   return g;
 }

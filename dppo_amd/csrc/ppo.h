@@ -239,6 +239,7 @@ struct AdamwSlots {
   int n;
 };
 void launch_adamw_multi(AdamwSlots& a, hipStream_t s);
+void launch_compose_wc(const float* Wout, const float* W2, int out_dim, int H, float* Wc, hipStream_t s);
 void launch_lowrank_dw(const float* Wout, const float* T, int out_dim, int H, float* dW, hipStream_t s);
 void launch_stats_split(const double* st, float* hi_lo, int n, hipStream_t s);
 void launch_stats_merge(const float* hi_lo, double* st, int n, int first_avg, int n_avg, double inv_world, hipStream_t s);

@@ -986,6 +986,34 @@ void launch_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, i
   hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, s, step_dev);
 }
 
+// Wc[o][k] = sum_j Wout[o][j] * W2[j][k]  ([out_dim][H], fp32): the composite layer of the fused backward's top block.
+// One block per (o, 64 columns k): sixteen waves split j, lanes are consecutive k (coalesced rows of W2); eight loads in
+// flight per lane (a plain loop over j is one L2 latency per iteration: 128 of them cost 50 us on the optimiser tail).
+__global__ __launch_bounds__(1024) void compose_wc_kernel(const float* Wout, const float* W2, int H, float* Wc) {
+  __shared__ float red[16][64];
+  const int o = blockIdx.y, lane = threadIdx.x & 63, k = blockIdx.x * 64 + lane, w = threadIdx.x >> 6;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (k < H) {
+    int j = w;
+    for (; j + 7 * 16 < H; j += 8 * 16) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += Wout[(size_t)o * H + j + 16 * u] * W2[(size_t)(j + 16 * u) * H + k];
+    }
+    for (; j < H; j += 16) acc[0] += Wout[(size_t)o * H + j] * W2[(size_t)j * H + k];
+  }
+  red[w][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (w == 0 && k < H) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][lane];
+    Wc[(size_t)o * H + k] = t;
+  }
+}
+void launch_compose_wc(const float* Wout, const float* W2, int out_dim, int H, float* Wc, hipStream_t s) {
+  hipLaunchKernelGGL(compose_wc_kernel, dim3((H + 63) / 64, out_dim), dim3(1024), 0, s, Wout, W2, H, Wc);
+}
+
 // dW[i][j] = sum_o Wout[o][i] * T[o][j]: the top block's second-layer weight gradient from T = d_out^T . act(z1).
 // d loss / d h_nb = d_out . Wout has rank <= out_dim, so dz2^T . a2 = Wout^T . (d_out^T . a2): a thin contraction over the
 // batch plus this out_dim-deep product replace an H x H contraction over the batch, and dh_nb never goes to HBM.
