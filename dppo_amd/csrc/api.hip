@@ -81,7 +81,7 @@ static ParamLayout param_layout(const dppo_net_desc& d) {
 struct PackLayout {  // byte offsets into the packed image
   // every offset depends on (net, prec) only; the time table sits last so that only `total` grows with n_time
   size_t W0, W1[MAX_BLOCKS], W2[MAX_BLOCKS], Wout, W1T[MAX_BLOCKS], W2T[MAX_BLOCKS], WoutT, W0tT, sstream, ostream,
-      bstream, wcomp, Wc1, Wc2, Wc2T, W0eT, temb, total;
+      bstream, wcomp, ostream2, cbias, Wc1, Wc2, Wc2T, W0eT, temb, total;
   int Kp0, Kpo, tdp;
   int Kpc, C1p, Ep;  // cond_mlp: padded K of the encoder layers (cond, hidden) and padded encoder width
 };
@@ -113,6 +113,9 @@ static PackLayout pack_layout(const dppo_net_desc& d, int n_time) {
     L.ostream = o, o = al256(o + (size_t)SAMPLER_WAVES * g.out_frags_per_wave * 64 * 16);
     L.bstream = o, o = al256(o + (size_t)SAMPLER_WAVES * fg.frags_per_wave * 64 * 16);
     L.wcomp = o, o = al256(o + (size_t)d.out_dim * H * 4);  // fp32 Wout . W2 of the top block (source of its composite layer)
+    // merged out layer (inference): out = Wout . h_in + (Wout . W2) . act(z1) + cbias, cbias = bout + Wout . b2
+    L.ostream2 = o, o = al256(o + (size_t)SAMPLER_WAVES * g.out_frags_per_wave * 64 * 16);
+    L.cbias = o, o = al256(o + (size_t)round_up(d.out_dim, 16) * 4);
   }
   L.Kpc = round_up(d.cond_dim > 0 ? d.cond_dim : 1, 64);
   if (d.cond_hidden > 0) {  // observation encoder: row-major GEMM operands (small), W2^T and the encoder columns of W0
@@ -224,7 +227,8 @@ static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char*
     for (int b = d.n_blocks - 1, pos = fg.KSB0; b >= 0; --b) {
       if (b == d.n_blocks - 1) {  // top block: the composite (Wout . W2)^T, laid out like the Wout^T layer
         float* wc = (float*)(pk + L.wcomp);
-        launch_compose_wc(prm + pl.Wout, prm + pl.l2w[b], d.out_dim, H, wc, s);
+        launch_compose_wc(prm + pl.Wout, prm + pl.l2w[b], d.out_dim, H, wc, prm + pl.l2b[b], prm + pl.bout,
+                          (float*)(pk + L.cbias), s);
         ps.layer[ps.n_layers++] = PackLayer{wc, 1, H, d.out_dim, fg.KSB0, pos, bwd, fg.total_pos};
         pos += fg.KSB0;
       } else {
@@ -240,6 +244,7 @@ static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char*
       pn.ps_x = SAMPLER_WAVES * maxks * ps.TPW;
       pn.Wout = prm + pl.Wout, pn.out_dim = d.out_dim, pn.H = H, pn.OT = g.OT, pn.CNT = g.CNT;
       pn.ostream = (u32x4*)(pk + L.ostream);
+      if (d.n_blocks >= 1) pn.Wc = (const float*)(pk + L.wcomp), pn.ostream2 = (u32x4*)(pk + L.ostream2);
       if (d.kind == 0) {
         pn.te_w1 = prm + pl.te1_w, pn.te_b1 = prm + pl.te1_b, pn.te_w2 = prm + pl.te2_w, pn.te_b2 = prm + pl.te2_b;
         pn.td = d.time_dim, pn.n_time = n_time, pn.temb = (float*)(pk + L.temb);
@@ -250,6 +255,8 @@ static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char*
     } else {
       launch_pack_stream<P>(ps, s);
       launch_pack_out<P>(prm + pl.Wout, d.out_dim, H, g.OT, g.CNT, (u32x4*)(pk + L.ostream), s);
+      if (d.n_blocks >= 1)
+        launch_pack_out<P>((const float*)(pk + L.wcomp), d.out_dim, H, g.OT, g.CNT, (u32x4*)(pk + L.ostream2), s);
     }
   }
   return check_launch();
@@ -522,6 +529,7 @@ static void join_side(hipStream_t main, hipStream_t sidestream, int idx = 0) {
 }
 
 static int g_dbg = 0;  // tuning knob 8: timing experiments on the fused backward (results are wrong while it is set)
+static int g_merge_top = 1;        // tuning knob 17: sampler merges the top block's second layer into the out layer
 static int g_lowrank_top = 1;      // tuning knob 16: top block's dW2 from the rank-out_dim factorisation (no H x H GEMM, no dh store)
 static int g_early_join = 1;       // tuning knob 14: side streams joined right behind the weight-gradient GEMM launch
 static int g_tn_group = 1;         // tuning knob 12: one launch for all weight-gradient GEMMs of a backward pass
@@ -907,6 +915,9 @@ static int sample_impl(const dppo_net_desc& d, const float* pb, const char* kb, 
   memset(&a, 0, sizeof(a));
   a.wstream[0] = (const u32x4*)(kb + L.sstream), a.wstream[1] = (const u32x4*)(kf + L.sstream);
   a.ostream[0] = (const u32x4*)(kb + L.ostream), a.ostream[1] = (const u32x4*)(kf + L.ostream);
+  a.ostream2[0] = (const u32x4*)(kb + L.ostream2), a.ostream2[1] = (const u32x4*)(kf + L.ostream2);
+  a.cbias[0] = (const float*)(kb + L.cbias), a.cbias[1] = (const float*)(kf + L.cbias);
+  a.merge_top = g_merge_top && d.n_blocks >= 1 ? 1 : 0;
   a.params[0] = pb, a.params[1] = pf;
   a.temb[0] = (const float*)(kb + L.temb), a.temb[1] = (const float*)(kf + L.temb);
   fill_bias_off(d, pl, a.bias_off);
@@ -1453,6 +1464,10 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 16) {
     g_lowrank_top = value;
+    return 0;
+  }
+  if (knob == 17) {
+    g_merge_top = value;
     return 0;
   }
   return fail(-1, "unknown tuning knob %d", knob);

@@ -209,6 +209,8 @@ struct PackNet {
   const float* Wout;
   int out_dim, H, OT, CNT;
   u32x4* ostream;
+  const float* Wc;  // non-null: fp32 [out_dim][H] composite Wout . W2 of the top block -> ostream2 (same layout as ostream)
+  u32x4* ostream2;
   const float *te_w1, *te_b1, *te_w2, *te_b2;  // n_time = 0: no table
   int td, n_time;
   float* temb;
@@ -239,7 +241,8 @@ struct AdamwSlots {
   int n;
 };
 void launch_adamw_multi(AdamwSlots& a, hipStream_t s);
-void launch_compose_wc(const float* Wout, const float* W2, int out_dim, int H, float* Wc, hipStream_t s);
+void launch_compose_wc(const float* Wout, const float* W2, int out_dim, int H, float* Wc, const float* b2,
+                       const float* bout, float* cbias, hipStream_t s);
 void launch_lowrank_dw(const float* Wout, const float* T, int out_dim, int H, float* dW, hipStream_t s);
 void launch_stats_split(const double* st, float* hi_lo, int n, hipStream_t s);
 void launch_stats_merge(const float* hi_lo, double* st, int n, int first_avg, int n_avg, double inv_world, hipStream_t s);

@@ -95,6 +95,13 @@ __global__ __launch_bounds__(64) void pack_net_kernel(const PackNet n) {
     return;
   }
   b -= n_out;
+  if (n.Wc != nullptr) {  // the merged out layer's second half: (Wout . W2) on act(z1) of the top block
+    if (b < n_out) {
+      pack_out_block<P>(n.Wc, n.out_dim, n.H, n.OT, n.CNT, n.ostream2, b);
+      return;
+    }
+    b -= n_out;
+  }
   if (b < n.n_time) {
     time_table_block(n.te_w1, n.te_b1, n.te_w2, n.te_b2, n.td, n.temb, b, sh);
     return;
@@ -109,7 +116,8 @@ __global__ __launch_bounds__(64) void pack_net_kernel(const PackNet n) {
 template <class P>
 void launch_pack_net(const PackNet& n, hipStream_t s) {
   const size_t tblocks = ((size_t)n.t_cols * n.t_ldd + 63) / 64;
-  const size_t blocks = (size_t)n.ps_x * n.ps.n_layers + (size_t)SAMPLER_WAVES * n.CNT * n.OT + n.n_time + tblocks;
+  const size_t blocks = (size_t)n.ps_x * n.ps.n_layers + (size_t)SAMPLER_WAVES * n.CNT * n.OT * (n.Wc ? 2 : 1) + n.n_time +
+                        tblocks;
   hipLaunchKernelGGL((pack_net_kernel<P>), dim3((unsigned)blocks), dim3(64), 0, s, n);
 }
 template void launch_pack_net<F32>(const PackNet&, hipStream_t);
@@ -989,9 +997,24 @@ void launch_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, i
 // Wc[o][k] = sum_j Wout[o][j] * W2[j][k]  ([out_dim][H], fp32): the composite layer of the fused backward's top block.
 // One block per (o, 64 columns k): sixteen waves split j, lanes are consecutive k (coalesced rows of W2); eight loads in
 // flight per lane (a plain loop over j is one L2 latency per iteration: 128 of them cost 50 us on the optimiser tail).
-__global__ __launch_bounds__(1024) void compose_wc_kernel(const float* Wout, const float* W2, int H, float* Wc) {
+__global__ __launch_bounds__(1024) void compose_wc_kernel(const float* Wout, const float* W2, int H, float* Wc,
+                                                          const float* b2, const float* bout, float* cbias) {
   __shared__ float red[16][64];
-  const int o = blockIdx.y, lane = threadIdx.x & 63, k = blockIdx.x * 64 + lane, w = threadIdx.x >> 6;
+  const int o = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (blockIdx.x == gridDim.x - 1) {  // extra column: cbias[o] = bout[o] + Wout[o] . b2 (the merged out layer's constant)
+    float t = 0.f;
+    for (int j = threadIdx.x; j < H; j += 1024) t += Wout[(size_t)o * H + j] * b2[j];
+    for (int d = 32; d > 0; d >>= 1) t += __shfl_down(t, d);
+    if (lane == 0) red[w][0] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float u = bout[o];
+      for (int i = 0; i < 16; ++i) u += red[i][0];
+      cbias[o] = u;
+    }
+    return;
+  }
+  const int k = blockIdx.x * 64 + lane;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (k < H) {
     int j = w;
@@ -1010,8 +1033,10 @@ __global__ __launch_bounds__(1024) void compose_wc_kernel(const float* Wout, con
     Wc[(size_t)o * H + k] = t;
   }
 }
-void launch_compose_wc(const float* Wout, const float* W2, int out_dim, int H, float* Wc, hipStream_t s) {
-  hipLaunchKernelGGL(compose_wc_kernel, dim3((H + 63) / 64, out_dim), dim3(1024), 0, s, Wout, W2, H, Wc);
+void launch_compose_wc(const float* Wout, const float* W2, int out_dim, int H, float* Wc, const float* b2,
+                       const float* bout, float* cbias, hipStream_t s) {
+  hipLaunchKernelGGL(compose_wc_kernel, dim3((H + 63) / 64 + 1, out_dim), dim3(1024), 0, s, Wout, W2, H, Wc, b2, bout,
+                     cbias);
 }
 
 // dW[i][j] = sum_o Wout[o][i] * T[o][j]: the top block's second-layer weight gradient from T = d_out^T . act(z1).

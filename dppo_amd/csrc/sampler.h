@@ -29,6 +29,11 @@ SamplerGeom sampler_geom(const dppo_net_desc& d);
 struct SampleArgs {
   const u32x4* wstream[2];
   const u32x4* ostream[2];
+  const u32x4* ostream2[2];  // merged out layer: fragments of Wout . W2 (top block), applied to act(z1)
+  const float* cbias[2];     // merged out layer: bout + Wout . b2
+  int merge_top;  // request: out = Wout . h_in + (Wout . W2) . act(z1) + cbias, the top block's second layer is never run
+                  // (h_nb = h_in + W2 act(z1) + b2 is only ever consumed by the out layer).  The launcher clears it when
+                  // the extra LDS image does not fit.
   const float* params[2];
   const float* temb[2];  // [n_time][td]
   int bias_off[2 + 2 * MAX_BLOCKS];  // L0, (l1,l2) x nb, out  -- float offsets into params

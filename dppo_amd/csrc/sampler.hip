@@ -57,14 +57,19 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
   const int KS0 = Kp0 / KB;
   const int total = KS0 + 2 * nb * KSH;
 
+  // merge: the top block's second layer is folded into the out layer (see SampleArgs::merge_top); bufC then holds the raw
+  // input h_in of that block and the out layer reads bufC and bufB
+  const bool merge = a.merge_top != 0;
   char* xin = smem;
   char* bufA = xin + 16 * in_rb;
   char* bufB = bufA + 16 * HRB;
-  float* xcur = (float*)(bufB + 16 * HRB);            // [16][AF]
+  char* bufC = bufB + 16 * HRB;
+  float* xcur = (float*)(bufC + (merge ? 16 * HRB : 0));  // [16][AF]
   // out-layer partials [8 waves][OT*16 features][16 rows]: bufB is idle while the out layer reads bufA, reuse it when it fits
-  constexpr bool PART_IN_B = SAMPLER_WAVES * OT * 16 * 16 * 4 <= 16 * HRB;
-  float* part = PART_IN_B ? (float*)bufB : xcur + ((16 * AF + 3) & ~3);
-  float* lnred = (PART_IN_B ? xcur + ((16 * AF + 3) & ~3) : part + SAMPLER_WAVES * OT * 16 * 16);  // [8][16]
+  constexpr bool PART_FITS_B = SAMPLER_WAVES * OT * 16 * 16 * 4 <= 16 * HRB;
+  const bool part_in_b = PART_FITS_B && !merge;
+  float* part = part_in_b ? (float*)bufB : xcur + ((16 * AF + 3) & ~3);
+  float* lnred = (part_in_b ? xcur + ((16 * AF + 3) & ~3) : part + SAMPLER_WAVES * OT * 16 * 16);  // [8][16]
   // both networks' biases, staged once: [net][(1 + 2 nb) * H hidden | OT*16 out].  A global load at a layer's start
   // would wait behind every weight fragment the ring has in flight (vmcnt is in issue order), 3 x 20 times per call.
   float* biasL = lnred + LN_WAVES * 16;
@@ -75,7 +80,8 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
       for (int idx = tid; idx < (1 + 2 * nb) * H; idx += 512)
         biasL[net * bias_stride + idx] = a.params[net][a.bias_off[idx / H] + idx % H];
       for (int idx = tid; idx < OT * 16; idx += 512)
-        biasL[net * bias_stride + (1 + 2 * nb) * H + idx] = idx < AF ? a.params[net][a.bias_off[1 + 2 * nb] + idx] : 0.f;
+        biasL[net * bias_stride + (1 + 2 * nb) * H + idx] =
+            idx < AF ? (merge ? a.cbias[net][idx] : a.params[net][a.bias_off[1 + 2 * nb] + idx]) : 0.f;
     }
   }
 
@@ -114,6 +120,9 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
   const u32x4* ws[2] = {a.wstream[0] + wid * wave_stride + lane, a.wstream[1] + wid * wave_stride + lane};
   const u32x4* os[2] = {a.ostream[0] + (size_t)wid * CNT * OT * 64 + lane,
                         a.ostream[1] + (size_t)wid * CNT * OT * 64 + lane};
+  const u32x4* os2[2] = {a.ostream2[0] + (size_t)wid * CNT * OT * 64 + lane,
+                         a.ostream2[1] + (size_t)wid * CNT * OT * 64 + lane};
+  const int total_eff = total - (merge ? KSH : 0);  // the ring never sees the top block's second layer when merged
   const int wbase = wid * 16 * TPW;  // this wave's feature slice; the lane's features: wbase + feat_off<P>(g, tp) + e
 
   // Layer 0 is 4 of the 36 k-step positions a step streams at H = 512 (2 of them zero padding): its fragments of the
@@ -160,12 +169,15 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
     // loaded right before use at H = 1024 (the registers are needed) and for wide outputs (two groups)
     constexpr int OG = OT < 4 ? OT : 4;
     constexpr bool OF_EARLY = TPW < 8 && OT <= 4;
-    u32x4 of[CNT][OG];
+    u32x4 of[CNT][OG], of2[CNT][OG];
     if constexpr (OF_EARLY) {
 #pragma unroll
       for (int c = 0; c < CNT; ++c)
 #pragma unroll
-        for (int to = 0; to < OG; ++to) of[c][to] = os[net][(c * OT + to) * 64];
+        for (int to = 0; to < OG; ++to) {
+          of[c][to] = os[net][(c * OT + to) * 64];
+          if (merge) of2[c][to] = os2[net][(c * OT + to) * 64];
+        }
     }
 
     f32x4 h[TPW][1], acc[TPW][1];
@@ -193,7 +205,8 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
           for (int tp = 0; tp < TPW; ++tp) acc[tp][0] = P::mma(ring[p][tp], xb, acc[tp][0]);
           // refill the slot just consumed with the fragments PD positions ahead (next layer / next step included)
           const int np = pos + ks + PD;
-          const u32x4* src_w = np < total ? cur + (size_t)np * TPW * 64 : nxt + (size_t)(np - total + skip) * TPW * 64;
+          const u32x4* src_w =
+              np < total_eff ? cur + (size_t)np * TPW * 64 : nxt + (size_t)(np - total_eff + skip) * TPW * 64;
 #pragma unroll
           for (int tp = 0; tp < TPW; ++tp) ring[p][tp] = src_w[tp * 64];
         }
@@ -266,10 +279,12 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
     }
 #pragma unroll
     for (int tp = 0; tp < TPW; ++tp) h[tp][0] = acc[tp][0];
-    if (nb > 0)
+    if (nb > 0) {
       put_block_input(0);
-    else
+      if (merge && nb == 1) put_hidden(bufC, h, ACT_NONE);  // raw input of the top block, for the merged out layer
+    } else {
       put_hidden(bufA, h, ACT_NONE);
+    }
     __syncthreads();
     // ---- residual blocks: h += l2(act([LN2] l1(act([LN1] h))))
     for (int b = 0; b < nb; ++b) {
@@ -279,13 +294,16 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
                               ln_m, ln_r);
       put_hidden(bufB, acc, ACT);
       __syncthreads();
+      if (merge && b == nb - 1) break;  // W2 of the top block only ever feeds the out layer: folded into it
       run_layer(bufB, HRB, 15, KSH, 2 + 2 * b);
 #pragma unroll
       for (int tp = 0; tp < TPW; ++tp) h[tp][0] += acc[tp][0];
-      if (b + 1 < nb)
+      if (b + 1 < nb) {
         put_block_input(b + 1);
-      else
+        if (merge && b + 1 == nb - 1) put_hidden(bufC, h, ACT_NONE);
+      } else {
         put_hidden(bufA, h, ACT_NONE);
+      }
       __syncthreads();
     }
     // ---- output layer: K split over the 8 waves, partial tiles reduced through LDS
@@ -296,7 +314,10 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
 #pragma unroll
           for (int c = 0; c < CNT; ++c)
 #pragma unroll
-            for (int to = 0; to < OG; ++to) of[c][to] = os[net][(c * OT + og + to) * 64];
+            for (int to = 0; to < OG; ++to) {
+              of[c][to] = os[net][(c * OT + og + to) * 64];
+              if (merge) of2[c][to] = os2[net][(c * OT + og + to) * 64];
+            }
         }
         f32x4 oacc[OG];
 #pragma unroll
@@ -305,9 +326,14 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
         for (int c = 0; c < CNT; ++c) {
           const int ks = wid * CNT + c;
           if (ks < KSH) {
-            const u32x4 xb = *(const u32x4*)(bufA + r * HRB + (((ks * 4 + g) ^ (r & 15)) << 4));
+            const u32x4 xb = *(const u32x4*)((merge ? bufC : bufA) + r * HRB + (((ks * 4 + g) ^ (r & 15)) << 4));
 #pragma unroll
             for (int to = 0; to < OG; ++to) oacc[to] = P::mma(of[c][to], xb, oacc[to]);
+            if (merge) {
+              const u32x4 xb2 = *(const u32x4*)(bufB + r * HRB + (((ks * 4 + g) ^ (r & 15)) << 4));
+#pragma unroll
+              for (int to = 0; to < OG; ++to) oacc[to] = P::mma(of2[c][to], xb2, oacc[to]);
+            }
           }
         }
 #pragma unroll
@@ -323,7 +349,8 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
       for (int idx = tid; idx < 16 * AF; idx += 512) {
         const int row = idx / AF, j = idx - row * AF;
         const int grow = grow0 + row;
-        float eps = bias_lds ? biasL[net * bias_stride + (1 + 2 * nb) * H + j] : prm[a.bias_off[1 + 2 * nb] + j];
+        float eps = bias_lds ? biasL[net * bias_stride + (1 + 2 * nb) * H + j]
+                             : (merge ? a.cbias[net][j] : prm[a.bias_off[1 + 2 * nb] + j]);
 #pragma unroll
         for (int w = 0; w < SAMPLER_WAVES; ++w) eps += part[(w * OT * 16 + j) * 16 + row];
         const float x = xcur[row * AF + j];
@@ -397,10 +424,14 @@ template <class P, int TPW, int OT, bool LN, int ACT>
 static int launch_cfg(const SamplerGeom& g, const SampleArgs& a, hipStream_t s) {
   const int ES = P::ESIZE;
   const size_t part_bytes = (size_t)SAMPLER_WAVES * OT * 16 * 16 * 4;
-  size_t lds = (size_t)16 * a.Kp0 * ES + 2 * (size_t)16 * g.H * ES + (size_t)((16 * a.AF + 3) & ~3) * 4 +
-               (part_bytes <= (size_t)16 * g.H * ES ? 0 : part_bytes) + (size_t)LN_WAVES * 16 * 4;
-  if (lds > 160 * 1024) return -2;
+  auto lds_of = [&](bool merge) {
+    return (size_t)16 * a.Kp0 * ES + (merge ? 3 : 2) * (size_t)16 * g.H * ES + (size_t)((16 * a.AF + 3) & ~3) * 4 +
+           (part_bytes <= (size_t)16 * g.H * ES && !merge ? 0 : part_bytes) + (size_t)LN_WAVES * 16 * 4;
+  };
   SampleArgs b = a;
+  if (b.merge_top && lds_of(true) > 160 * 1024) b.merge_top = 0;
+  size_t lds = lds_of(b.merge_top != 0);
+  if (lds > 160 * 1024) return -2;
   const size_t bias_bytes = 2 * ((size_t)(1 + 2 * a.nb) * g.H + OT * 16) * 4;
   b.consts_lds = lds + bias_bytes <= 160 * 1024 ? 1 : 0;
   if (b.consts_lds) lds += bias_bytes;

@@ -296,7 +296,9 @@ int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* 
  * knob 14: side streams of the update joined right behind the weight-gradient launch (default 1); 0 = at the call's end
  * knob 15: sampler keeps the layer-0 weight fragments of the network in use in LDS when they fit (default 1)
  * knob 16: the top block's second-layer weight gradient from the rank-out_dim factorisation
- *          dW2 = Wout^T . (d_out^T . act(z1)) instead of an H x H contraction over the batch (default 1) */
+ *          dW2 = Wout^T . (d_out^T . act(z1)) instead of an H x H contraction over the batch (default 1)
+ * knob 17: the sampler never runs the top block's second layer: out = Wout . h_in + (Wout . W2) . act(z1) + const
+ *          (default 1) */
 int dppo_tune_set(int knob, int value);
 /* one bare layer GEMM: out[M][ldo] = act(X[M][Kp] . W[N][Kp]^T + bias) with elem = prec operands;
  * out_f32 and/or out_elem may be NULL; ldo >= round_up(N,16) */
