@@ -687,7 +687,9 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       f.dz1[b] = B.dz1_all[b];
     }
     for (int b = 0; b <= nb; ++b) f.dh[b] = B.dh_all[b];
-    const bool lowrank = g_lowrank_top && nb >= 1;
+    // (the out_dim-deep product costs H^2 out_dim scalar MACs against the M H^2 MFMA MACs it saves: on for M >= 200 out_dim;
+    // measured a loss at out_dim = 112, M = 10,000)
+    const bool lowrank = g_lowrank_top && nb >= 1 && M >= (int64_t)200 * d.out_dim;
     if (lowrank) f.dh[nb] = nullptr;  // only dW2 of the top block read it: see lowrank_dw_kernel
     if (g_dbg & 1)  // timing experiment: no gradient stores (the weight-gradient GEMMs then read stale buffers)
       for (int b = 0; b <= nb; ++b) f.dh[b] = nullptr, f.dz1[b < nb ? b : 0] = nullptr;

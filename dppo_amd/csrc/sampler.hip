@@ -59,7 +59,8 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
 
   // merge: the top block's second layer is folded into the out layer (see SampleArgs::merge_top); bufC then holds the raw
   // input h_in of that block and the out layer reads bufC and bufB
-  const bool merge = a.merge_top != 0;
+  constexpr bool MERGE_OK = OT < 8;  // compiled out for wide outputs (see the launcher): no register cost there
+  const bool merge = MERGE_OK && a.merge_top != 0;
   char* xin = smem;
   char* bufA = xin + 16 * in_rb;
   char* bufB = bufA + 16 * HRB;
@@ -429,7 +430,9 @@ static int launch_cfg(const SamplerGeom& g, const SampleArgs& a, hipStream_t s) 
            (part_bytes <= (size_t)16 * g.H * ES && !merge ? 0 : part_bytes) + (size_t)LN_WAVES * 16 * 4;
   };
   SampleArgs b = a;
-  if (b.merge_top && lds_of(true) > 160 * 1024) b.merge_top = 0;
+  // (wide outputs, OT = 8: the second set of out-layer fragments does not fit the registers next to the ring -- measured
+  // slower at Ta*Da = 112 -- so the merge stays off there)
+  if (b.merge_top && (OT >= 8 || lds_of(true) > 160 * 1024)) b.merge_top = 0;
   size_t lds = lds_of(b.merge_top != 0);
   if (lds > 160 * 1024) return -2;
   const size_t bias_bytes = 2 * ((size_t)(1 + 2 * a.nb) * g.H + OT * 16) * 4;
