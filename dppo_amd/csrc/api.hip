@@ -177,11 +177,15 @@ static bool fused_ok(const dppo_net_desc& d) {
 // ------------------------------------------------------------------------------------------------
 static int g_pack_one = 1;  // tuning knob 13: one launch per network for all of its kernel-ready images
 template <class P>
-static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char* pk, hipStream_t s) {
+static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char* pk, hipStream_t s,
+                     PackNet* defer_pn = nullptr, ComposeJob* defer_cj = nullptr, bool* deferred = nullptr) {
+  // defer_pn / defer_cj: the caller launches the one-launch pack (and the composite) itself, batched with another
+  // network's (dppo_pack_nets); *deferred tells whether this network's could be deferred
   const ParamLayout pl = param_layout(d);
   const PackLayout L = pack_layout<P>(d, n_time);
   const int H = d.hidden;
   const bool one_launch = fused_ok<P>(d) && g_pack_one && pack_net_supports(d.time_dim);
+  if (deferred) *deferred = false;
   if (d.kind == 0 && !one_launch)
     launch_time_table(prm + pl.te1_w, prm + pl.te1_b, prm + pl.te2_w, prm + pl.te2_b, d.time_dim, n_time,
                       (float*)(pk + L.temb), s);
@@ -218,24 +222,30 @@ static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char*
     ps.TPW = g.TPW;
     u32x4* fwd = (u32x4*)(pk + L.sstream);
     u32x4* bwd = (u32x4*)(pk + L.bstream);
-    ps.layer[ps.n_layers++] = PackLayer{prm + pl.W0, d.in_dim, 1, d.in_dim, g.KS0, 0, fwd, g.total_pos};
+    ps.layer[ps.n_layers++] = pack_layer(prm + pl.W0, d.in_dim, 1, d.in_dim, g.KS0, 0, fwd, g.total_pos);
     for (int b = 0; b < d.n_blocks; ++b) {
-      ps.layer[ps.n_layers++] = PackLayer{prm + pl.l1w[b], H, 1, H, g.KSH, g.KS0 + 2 * b * g.KSH, fwd, g.total_pos};
-      ps.layer[ps.n_layers++] = PackLayer{prm + pl.l2w[b], H, 1, H, g.KSH, g.KS0 + (2 * b + 1) * g.KSH, fwd, g.total_pos};
+      ps.layer[ps.n_layers++] = pack_layer(prm + pl.l1w[b], H, 1, H, g.KSH, g.KS0 + 2 * b * g.KSH, fwd, g.total_pos);
+      ps.layer[ps.n_layers++] = pack_layer(prm + pl.l2w[b], H, 1, H, g.KSH, g.KS0 + (2 * b + 1) * g.KSH, fwd, g.total_pos);
     }
-    ps.layer[ps.n_layers++] = PackLayer{prm + pl.Wout, 1, H, d.out_dim, fg.KSB0, 0, bwd, fg.total_pos};
+    ps.layer[ps.n_layers++] = pack_layer(prm + pl.Wout, 1, H, d.out_dim, fg.KSB0, 0, bwd, fg.total_pos);
     for (int b = d.n_blocks - 1, pos = fg.KSB0; b >= 0; --b) {
       if (b == d.n_blocks - 1) {  // top block: the composite (Wout . W2)^T, laid out like the Wout^T layer
         float* wc = (float*)(pk + L.wcomp);
-        launch_compose_wc(prm + pl.Wout, prm + pl.l2w[b], d.out_dim, H, wc, prm + pl.l2b[b], prm + pl.bout,
-                          (float*)(pk + L.cbias), s);
-        ps.layer[ps.n_layers++] = PackLayer{wc, 1, H, d.out_dim, fg.KSB0, pos, bwd, fg.total_pos};
+        ComposeJobs cq;
+        cq.n = 1;
+        cq.j[0] = ComposeJob{prm + pl.Wout, prm + pl.l2w[b], prm + pl.l2b[b], prm + pl.bout, wc, (float*)(pk + L.cbias), H,
+                             d.out_dim};
+        if (one_launch && defer_cj != nullptr)
+          *defer_cj = cq.j[0];
+        else
+          launch_compose(cq, s);
+        ps.layer[ps.n_layers++] = pack_layer(wc, 1, H, d.out_dim, fg.KSB0, pos, bwd, fg.total_pos);
         pos += fg.KSB0;
       } else {
-        ps.layer[ps.n_layers++] = PackLayer{prm + pl.l2w[b], 1, H, H, g.KSH, pos, bwd, fg.total_pos};
+        ps.layer[ps.n_layers++] = pack_layer(prm + pl.l2w[b], 1, H, H, g.KSH, pos, bwd, fg.total_pos);
         pos += g.KSH;
       }
-      ps.layer[ps.n_layers++] = PackLayer{prm + pl.l1w[b], 1, H, H, g.KSH, pos, bwd, fg.total_pos};
+      ps.layer[ps.n_layers++] = pack_layer(prm + pl.l1w[b], 1, H, H, g.KSH, pos, bwd, fg.total_pos);
       pos += g.KSH;
     }
     if (one_launch) {  // + out-layer stream, time-embedding table and W0tT, all in the same launch
@@ -251,7 +261,12 @@ static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char*
         pn.tsrc = prm + pl.W0, pn.t_rows = H, pn.t_cols = d.time_dim, pn.t_lds = d.in_dim, pn.t_coff = d.act_flat;
         pn.t_ldd = H, pn.tdst = pk + L.W0tT;
       }
-      launch_pack_net<P>(pn, s);
+      if (defer_pn != nullptr && (d.n_blocks == 0 || defer_cj != nullptr)) {
+        *defer_pn = pn;
+        if (deferred) *deferred = true;
+      } else {
+        launch_pack_net<P>(pn, s);
+      }
     } else {
       launch_pack_stream<P>(ps, s);
       launch_pack_out<P>(prm + pl.Wout, d.out_dim, H, g.OT, g.CNT, (u32x4*)(pk + L.ostream), s);
@@ -803,6 +818,45 @@ int64_t dppo_packed_bytes(const dppo_net_desc* net, int prec, int n_time) {
   if (check_net(net) || check_prec(prec)) return -1;
   if (n_time < 0) return fail(-1, "n_time < 0");
 #define CALL(P) (int64_t) pack_layout<P>(*net, n_time).total
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
+}
+
+template <class P>
+static int pack_two_impl(const dppo_net_desc& d0, int t0, const float* p0, char* k0, const dppo_net_desc& d1, int t1,
+                         const float* p1, char* k1, hipStream_t s) {
+  PackNets q;
+  ComposeJobs cq;
+  memset(&q, 0, sizeof(q));
+  memset(&cq, 0, sizeof(cq));
+  bool def0 = false, def1 = false;
+  ComposeJob c0, c1;
+  memset(&c0, 0, sizeof(c0));
+  memset(&c1, 0, sizeof(c1));
+  if (int e = pack_impl<P>(d0, t0, p0, k0, s, &q.n[0], &c0, &def0)) return e;
+  if (int e = pack_impl<P>(d1, t1, p1, k1, s, &q.n[1], &c1, &def1)) return e;
+  if (def0 && c0.Wout) cq.j[cq.n++] = c0;
+  if (def1 && c1.Wout) cq.j[cq.n++] = c1;
+  launch_compose(cq, s);  // both composites in one launch, then both networks' images in one launch
+  if (def0 && def1)
+    launch_pack_nets<P>(q, s);
+  else if (def0)
+    launch_pack_net<P>(q.n[0], s);
+  else if (def1)
+    launch_pack_net<P>(q.n[1], s);
+  return check_launch();
+}
+
+int dppo_pack_nets(const dppo_net_desc* net0, int n_time0, const float* params0, void* packed0,
+                   const dppo_net_desc* net1, int n_time1, const float* params1, void* packed1, int prec,
+                   dppo_stream_t stream) {
+  if (int e = check_net(net0)) return e;
+  if (int e = check_net(net1)) return e;
+  if (int e = check_prec(prec)) return e;
+  if (!params0 || !packed0 || !params1 || !packed1) return fail(-1, "null pointer");
+  if ((net0->kind == 0 && n_time0 < 1) || (net1->kind == 0 && n_time1 < 1)) return fail(-1, "actor needs n_time >= 1");
+#define CALL(P)                                                                                                  \
+  pack_two_impl<P>(*net0, n_time0, params0, (char*)packed0, *net1, n_time1, params1, (char*)packed1, (hipStream_t)stream)
   return DPPO_DISPATCH(prec, CALL);
 #undef CALL
 }

@@ -84,13 +84,18 @@ int fused_rows_per_tile(const dppo_net_desc& d);  // rows per tile of the BACKWA
 
 // Fragment packing of a whole stream in ONE launch: layer l occupies positions [pos0, pos0 + KS); element
 // (feature f, contraction index k) of its weight matrix is W[f*rs + k*cs] (rs = ld, cs = 1 for W; rs = 1, cs = ld for W^T)
-struct PackLayer {
+struct PackLayer {  // 40 bytes: two networks' worth of layers must fit one kernel-argument block (pack_nets_kernel)
   const float* W;
-  long rs, cs;
-  int in_valid, KS, pos0;
   u32x4* stream;  // destination stream and its length in k-step positions (forward and backward streams differ)
+  int rs, cs;
+  int in_valid, KS, pos0;
   int total_pos;
 };
+inline PackLayer pack_layer(const float* W, int rs, int cs, int in_valid, int KS, int pos0, u32x4* stream, int total_pos) {
+  PackLayer L;
+  L.W = W, L.stream = stream, L.rs = rs, L.cs = cs, L.in_valid = in_valid, L.KS = KS, L.pos0 = pos0, L.total_pos = total_pos;
+  return L;
+}
 struct PackStream {  // every layer of both streams of a network: one launch
   PackLayer layer[2 * (1 + 2 * MAX_BLOCKS)];
   int n_layers, TPW;

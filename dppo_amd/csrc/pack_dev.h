@@ -20,13 +20,13 @@ __device__ __forceinline__ void pack_stream_block(const PackLayer& L, const int 
   uint32_t out[4];
   if constexpr (P::ESIZE == 4) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) out[j] = __float_as_uint(k0 + j < L.in_valid ? L.W[feat * L.rs + (k0 + j) * L.cs] : 0.f);
+    for (int j = 0; j < 4; ++j) out[j] = __float_as_uint(k0 + j < L.in_valid ? L.W[feat * L.rs + (long)(k0 + j) * L.cs] : 0.f);
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = k0 + 2 * j;
-      const float lo = k < L.in_valid ? L.W[feat * L.rs + k * L.cs] : 0.f;
-      const float hi = k + 1 < L.in_valid ? L.W[feat * L.rs + (k + 1) * L.cs] : 0.f;
+      const float lo = k < L.in_valid ? L.W[feat * L.rs + (long)k * L.cs] : 0.f;
+      const float hi = k + 1 < L.in_valid ? L.W[feat * L.rs + (long)(k + 1) * L.cs] : 0.f;
       out[j] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
     }
   }

@@ -220,6 +220,13 @@ struct PackNet {
 };
 template <class P>
 void launch_pack_net(const PackNet& n, hipStream_t s);
+struct PackNets {  // two networks in one launch (dppo_pack_nets)
+  PackNet n[2];
+  int base1;  // first block of the second network
+};
+static_assert(sizeof(PackNets) <= 4096, "kernel arguments are limited to 4 KB");
+template <class P>
+void launch_pack_nets(PackNets& q, hipStream_t s);
 bool pack_net_supports(int time_dim);
 
 // AdamW on up to four flat parameter vectors in one launch; step counts / learning rates in device memory.
@@ -241,8 +248,17 @@ struct AdamwSlots {
   int n;
 };
 void launch_adamw_multi(AdamwSlots& a, hipStream_t s);
-void launch_compose_wc(const float* Wout, const float* W2, int out_dim, int H, float* Wc, const float* b2,
-                       const float* bout, float* cbias, hipStream_t s);
+// Wc = Wout . W2 ([out_dim][H] fp32) and cbias = bout + Wout . b2 of the top block, for up to two networks in one launch
+struct ComposeJob {
+  const float *Wout, *W2, *b2, *bout;
+  float *Wc, *cbias;
+  int H, out_dim;
+};
+struct ComposeJobs {
+  ComposeJob j[2];
+  int n;
+};
+void launch_compose(const ComposeJobs& q, hipStream_t s);
 void launch_lowrank_dw(const float* Wout, const float* T, int out_dim, int H, float* dW, hipStream_t s);
 void launch_stats_split(const double* st, float* hi_lo, int n, hipStream_t s);
 void launch_stats_merge(const float* hi_lo, double* st, int n, int first_avg, int n_avg, double inv_world, hipStream_t s);

@@ -80,9 +80,7 @@ void launch_time_table(const float* w1, const float* b1, const float* w2, const 
 
 constexpr int PACK_TD_MAX = 128;  // time_dim bound of the one-launch packer (3 * td floats of LDS)
 template <class P>
-__global__ __launch_bounds__(64) void pack_net_kernel(const PackNet n) {
-  __shared__ float sh[3 * PACK_TD_MAX];
-  int b = blockIdx.x;
+__device__ __forceinline__ void pack_net_block(const PackNet& n, int b, float* sh) {
   const int n_stream = n.ps_x * n.ps.n_layers;
   if (b < n_stream) {
     pack_stream_block<P>(n.ps.layer[b / n.ps_x], n.ps.TPW, b % n.ps_x);
@@ -113,12 +111,33 @@ __global__ __launch_bounds__(64) void pack_net_kernel(const PackNet n) {
   const int c = (int)(i / n.t_ldd), r = (int)(i % n.t_ldd);
   dst[i] = P::from_f32(r < n.t_rows ? n.tsrc[(size_t)r * n.t_lds + n.t_coff + c] : 0.f);
 }
+static size_t pack_net_blocks(const PackNet& n) {
+  const size_t tblocks = ((size_t)n.t_cols * n.t_ldd + 63) / 64;
+  return (size_t)n.ps_x * n.ps.n_layers + (size_t)SAMPLER_WAVES * n.CNT * n.OT * (n.Wc ? 2 : 1) + n.n_time + tblocks;
+}
+template <class P>
+__global__ __launch_bounds__(64) void pack_net_kernel(const PackNet n) {
+  __shared__ float sh[3 * PACK_TD_MAX];
+  pack_net_block<P>(n, blockIdx.x, sh);
+}
+// two networks (actor_ft and critic after an optimiser step) in one launch
+template <class P>
+__global__ __launch_bounds__(64) void pack_nets_kernel(const PackNets q) {
+  __shared__ float sh[3 * PACK_TD_MAX];
+  const int k = (int)blockIdx.x >= q.base1 ? 1 : 0;
+  pack_net_block<P>(q.n[k], blockIdx.x - (k ? q.base1 : 0), sh);
+}
+template <class P>
+void launch_pack_nets(PackNets& q, hipStream_t s) {
+  q.base1 = (int)pack_net_blocks(q.n[0]);
+  const size_t blocks = (size_t)q.base1 + pack_net_blocks(q.n[1]);
+  hipLaunchKernelGGL((pack_nets_kernel<P>), dim3((unsigned)blocks), dim3(64), 0, s, q);
+}
+template void launch_pack_nets<F32>(PackNets&, hipStream_t);
+template void launch_pack_nets<BF16>(PackNets&, hipStream_t);
 template <class P>
 void launch_pack_net(const PackNet& n, hipStream_t s) {
-  const size_t tblocks = ((size_t)n.t_cols * n.t_ldd + 63) / 64;
-  const size_t blocks = (size_t)n.ps_x * n.ps.n_layers + (size_t)SAMPLER_WAVES * n.CNT * n.OT * (n.Wc ? 2 : 1) + n.n_time +
-                        tblocks;
-  hipLaunchKernelGGL((pack_net_kernel<P>), dim3((unsigned)blocks), dim3(64), 0, s, n);
+  hipLaunchKernelGGL((pack_net_kernel<P>), dim3((unsigned)pack_net_blocks(n)), dim3(64), 0, s, n);
 }
 template void launch_pack_net<F32>(const PackNet&, hipStream_t);
 template void launch_pack_net<BF16>(const PackNet&, hipStream_t);
@@ -997,11 +1016,15 @@ void launch_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, i
 // Wc[o][k] = sum_j Wout[o][j] * W2[j][k]  ([out_dim][H], fp32): the composite layer of the fused backward's top block.
 // One block per (o, 64 columns k): sixteen waves split j, lanes are consecutive k (coalesced rows of W2); eight loads in
 // flight per lane (a plain loop over j is one L2 latency per iteration: 128 of them cost 50 us on the optimiser tail).
-__global__ __launch_bounds__(1024) void compose_wc_kernel(const float* Wout, const float* W2, int H, float* Wc,
-                                                          const float* b2, const float* bout, float* cbias) {
+__global__ __launch_bounds__(1024) void compose_wc_kernel(const ComposeJobs q) {
   __shared__ float red[16][64];
+  const ComposeJob& jb = q.j[blockIdx.z];
+  const float *Wout = jb.Wout, *W2 = jb.W2, *b2 = jb.b2, *bout = jb.bout;
+  float *Wc = jb.Wc, *cbias = jb.cbias;
+  const int H = jb.H, cols = (H + 63) / 64;
+  if ((int)blockIdx.y >= jb.out_dim || (int)blockIdx.x > cols) return;  // the grid is sized for the larger network
   const int o = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (blockIdx.x == gridDim.x - 1) {  // extra column: cbias[o] = bout[o] + Wout[o] . b2 (the merged out layer's constant)
+  if ((int)blockIdx.x == cols) {  // extra column: cbias[o] = bout[o] + Wout[o] . b2 (the merged out layer's constant)
     float t = 0.f;
     for (int j = threadIdx.x; j < H; j += 1024) t += Wout[(size_t)o * H + j] * b2[j];
     for (int d = 32; d > 0; d >>= 1) t += __shfl_down(t, d);
@@ -1033,10 +1056,13 @@ __global__ __launch_bounds__(1024) void compose_wc_kernel(const float* Wout, con
     Wc[(size_t)o * H + k] = t;
   }
 }
-void launch_compose_wc(const float* Wout, const float* W2, int out_dim, int H, float* Wc, const float* b2,
-                       const float* bout, float* cbias, hipStream_t s) {
-  hipLaunchKernelGGL(compose_wc_kernel, dim3((H + 63) / 64 + 1, out_dim), dim3(1024), 0, s, Wout, W2, H, Wc, b2, bout,
-                     cbias);
+void launch_compose(const ComposeJobs& q, hipStream_t s) {
+  int cols = 0, rows = 0;
+  for (int i = 0; i < q.n; ++i) {
+    cols = q.j[i].H > cols ? q.j[i].H : cols;
+    rows = q.j[i].out_dim > rows ? q.j[i].out_dim : rows;
+  }
+  if (q.n > 0) hipLaunchKernelGGL(compose_wc_kernel, dim3((cols + 63) / 64 + 1, rows, q.n), dim3(1024), 0, s, q);
 }
 
 // dW[i][j] = sum_o Wout[o][i] * T[o][j]: the top block's second-layer weight gradient from T = d_out^T . act(z1).

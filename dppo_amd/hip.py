@@ -88,6 +88,7 @@ SYMBOLS = {
     "dppo_adamw_step": (_I, [_P, _P, _P, _P, _L, _I, _D, _D, _D, _D, _D, _P, _D, _P]),
     "dppo_adamw_step_dev": (_I, [_P, _P, _P, _P, _L, _P, _P, _D, _D, _D, _D, _P, _D, _P]),
     "dppo_adamw_step_multi": (_I, [_P, _I, _P]),
+    "dppo_pack_nets": (_I, [_ND, _I, _P, _P, _ND, _I, _P, _P, _I, _P]),
     "dppo_stats_split": (_I, [_P, _P, _P]),
     "dppo_stats_merge": (_I, [_P, _P, _I, _P]),
     "dppo_probe_arm": (_I, [_I, _I]),

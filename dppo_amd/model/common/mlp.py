@@ -82,7 +82,7 @@ class HipNet(nn.Module):
         nn.Module.__init__(new)
         import copy
         for k, v in self.__dict__.items():
-            if k in ("_flat", "_flat_grad", "_packed", "_epoch", "_plist", "_last_off", "_desc_cache"):
+            if k in ("_flat", "_flat_grad", "_packed", "_epoch", "_plist", "_last_off", "_desc_cache", "_packed_bytes"):
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         object.__setattr__(new, "_flat", None)
@@ -149,22 +149,49 @@ class HipNet(nn.Module):
         """Call after a kernel wrote the flat parameter buffer behind torch's back (fused AdamW)."""
         object.__setattr__(self, "_epoch", self._epoch + 1)
 
-    def packed(self, prec: int, n_time: int) -> torch.Tensor:
+    def _packed_slot(self, prec: int, n_time: int):
+        """(buffer, stamp, stale): the packed image's buffer for (prec, n_time), allocated if needed, and whether the
+        parameters changed since it was last written."""
         flat = self.flat_params()
         hip.require_gpu(flat, type(self).__name__)
         key = (prec, n_time)
         stamp = (flat.data_ptr(), flat._version, self._epoch)
         hit = self._packed.get(key)
         if hit is not None and hit[0] == stamp:
-            return hit[1]
-        lib = hip.load()
-        d = self.net_desc()
-        nbytes = lib.dppo_packed_bytes(C.byref(d), prec, n_time)
-        if nbytes < 0:
-            hip.check(int(nbytes), "dppo_packed_bytes")
+            return hit[1], stamp, False
+        nbytes = self.__dict__.setdefault("_packed_bytes", {}).get(key)
+        if nbytes is None:
+            d = self.net_desc()
+            nbytes = hip.load().dppo_packed_bytes(C.byref(d), prec, n_time)
+            if nbytes < 0:
+                hip.check(int(nbytes), "dppo_packed_bytes")
+            self._packed_bytes[key] = nbytes
         buf = hit[1] if hit is not None and hit[1].numel() == nbytes else torch.empty(
             nbytes, dtype=torch.uint8, device=flat.device)
-        hip.check(lib.dppo_pack_net(C.byref(d), prec, n_time, flat.data_ptr(), buf.data_ptr(), hip.stream()),
-                  "dppo_pack_net")
-        self._packed[key] = (stamp, buf)
+        return buf, stamp, True
+
+    def packed(self, prec: int, n_time: int) -> torch.Tensor:
+        buf, stamp, stale = self._packed_slot(prec, n_time)
+        if stale:
+            d = self.net_desc()
+            hip.check(hip.load().dppo_pack_net(C.byref(d), prec, n_time, self.flat_params().data_ptr(), buf.data_ptr(),
+                                               hip.stream()), "dppo_pack_net")
+            self._packed[(prec, n_time)] = (stamp, buf)
         return buf
+
+
+def pack_pair(net0: "HipNet", n_time0: int, net1: "HipNet", n_time1: int, prec: int) -> None:
+    """Re-pack two networks after an optimiser step: when both images are stale, both composites and both images go out
+    in two launches (dppo_pack_nets) instead of four."""
+    b0, s0, stale0 = net0._packed_slot(prec, n_time0)
+    b1, s1, stale1 = net1._packed_slot(prec, n_time1)
+    if stale0 and stale1:
+        hip.check(hip.load().dppo_pack_nets(
+            C.byref(net0.net_desc()), n_time0, net0.flat_params().data_ptr(), b0.data_ptr(),
+            C.byref(net1.net_desc()), n_time1, net1.flat_params().data_ptr(), b1.data_ptr(), prec, hip.stream()),
+            "dppo_pack_nets")
+        net0._packed[(prec, n_time0)] = (s0, b0)
+        net1._packed[(prec, n_time1)] = (s1, b1)
+        return
+    net0.packed(prec, n_time0)
+    net1.packed(prec, n_time1)

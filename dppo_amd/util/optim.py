@@ -86,7 +86,7 @@ def step_and_repack(model, actor_opt: "FlatAdamW", critic_opt: "FlatAdamW", upda
     """Optimiser step + kernel-image repack of both networks (reference train_ppo_diffusion_agent.py:360-373).
 
     The tail of an update is a chain of launch-latency-bound kernels, so it is kept short: one AdamW launch for both
-    networks, then one pack launch per network, all on the caller's stream (a side stream for the critic's chain costs
+    networks, then both networks' weight images in two launches, all on the caller's stream (a side stream for the critic's chain costs
     a cross-stream hop of 10-20 us, more than the two launches it hides).
     """
     n_time = model.denoising_steps if n_time is None else n_time
@@ -95,7 +95,9 @@ def step_and_repack(model, actor_opt: "FlatAdamW", critic_opt: "FlatAdamW", upda
         slots.append(actor_opt.slot(model.actor_ft.flat_grads(), max_norm=max_norm))
     step_many(slots)
     model.critic.mark_updated()
-    model.critic.packed(model.prec, 0)
     if update_actor:
+        from dppo_amd.model.common.mlp import pack_pair
         model.actor_ft.mark_updated()
-        model.actor_ft.packed(model.prec, n_time)
+        pack_pair(model.critic, 0, model.actor_ft, n_time, model.prec)  # both composites, then both images: 2 launches
+    else:
+        model.critic.packed(model.prec, 0)

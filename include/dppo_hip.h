@@ -130,6 +130,11 @@ int64_t dppo_packed_bytes(const dppo_net_desc* net, int prec, int n_time);
 /* build the packed image from the fp32 master parameters; call again after every optimiser step */
 int dppo_pack_net(const dppo_net_desc* net, int prec, int n_time, const float* params, void* packed,
                   dppo_stream_t stream);
+/* The same for two networks (actor_ft and critic after an optimiser step) in two launches instead of four: both
+ * composites, then both networks' images. */
+int dppo_pack_nets(const dppo_net_desc* net0, int n_time0, const float* params0, void* packed0,
+                   const dppo_net_desc* net1, int n_time1, const float* params1, void* packed1, int prec,
+                   dppo_stream_t stream);
 
 /* ---- A2-A5: network forwards ------------------------------------------------------------- */
 /* DiffusionMLP.forward (model/diffusion/mlp_diffusion.py:218-250): x (B,Ta*Da), t (B,) int64,
