@@ -329,6 +329,8 @@ struct MlpBufs {  // activations of one network for M rows
   int join_idx[2], n_join;
   float* part;  // column-sum / segment-sum partials
   float* lowrank;  // [out_dim][H] T = d_out^T . act(z1) of the top block (see lowrank_dw_kernel)
+  bool post_zeroed;      // the caller's row builder zeroed post_counter in this call
+  double* post_counter;  // 8 zeroed bytes: arrival counter of post_reduce_kernel (zeroed by the row builder, left zero)
   size_t slab_floats, part_floats;
 };
 
@@ -396,6 +398,8 @@ static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, b
     B.part_floats = (size_t)REDUCE_BLOCKS * (H > 1024 ? H : 1024);
     B.part = (float*)c.take(B.part_floats * 4);
     B.lowrank = (float*)c.take((size_t)round_up(d.out_dim, 16) * H * 4);
+    B.post_counter = (double*)c.take(8);
+    B.post_zeroed = false;
   }
 }
 
@@ -544,6 +548,7 @@ static void join_side(hipStream_t main, hipStream_t sidestream, int idx = 0) {
 }
 
 static int g_dbg = 0;  // tuning knob 8: timing experiments on the fused backward (results are wrong while it is set)
+static int g_post_one = 1;         // tuning knob 18: low-rank dW2 + time-embedding gradient in one launch after the slab reduce
 static int g_merge_top = 1;        // tuning knob 17: sampler merges the top block's second layer into the out layer
 static int g_lowrank_top = 1;      // tuning knob 16: top block's dW2 from the rank-out_dim factorisation (no H x H GEMM, no dh store)
 static int g_early_join = 1;       // tuning knob 14: side streams joined right behind the weight-gradient GEMM launch
@@ -755,11 +760,26 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       if (aux != s && g_early_join) B.join_s[B.n_join] = aux, B.join_idx[B.n_join++] = aux_idx;
       flush_slabs(B, s);  // every slab of this backward in one reduction launch
       if (aux != s && !g_early_join) join_side(s, aux, aux_idx);
-      if (lowrank) launch_lowrank_dw(prm + pl.Wout, B.lowrank, d.out_dim, H, grad + pl.l2w[nb - 1], s);
-      if (oh >= 0)
-        launch_time_backward_from_sums(prm + pl.te1_w, prm + pl.te1_b, prm + pl.te2_w, B.part, prm + pl.W0, d.in_dim,
-                                       d.act_flat, H, B.part + (size_t)H * Kft, ksteps, Kft, d.time_dim, grad + pl.te1_w,
-                                       grad + pl.te1_b, grad + pl.te2_w, grad + pl.te2_b, s);
+      if (g_post_one && B.post_zeroed && (lowrank || oh >= 0)) {  // both in one launch (knob 18)
+        PostReduce q;
+        memset(&q, 0, sizeof(q));
+        q.H = H;
+        if (lowrank) q.Wout = prm + pl.Wout, q.T = B.lowrank, q.dW = grad + pl.l2w[nb - 1], q.out_dim = d.out_dim;
+        if (oh >= 0) {
+          q.S = B.part, q.W0 = prm + pl.W0, q.ldw0 = d.in_dim, q.AF = d.act_flat, q.Kft = Kft, q.td = d.time_dim;
+          q.G = B.part + (size_t)H * Kft, q.w1 = prm + pl.te1_w, q.b1 = prm + pl.te1_b, q.w2 = prm + pl.te2_w;
+          q.ksteps = ksteps, q.gw1 = grad + pl.te1_w, q.gb1 = grad + pl.te1_b, q.gw2 = grad + pl.te2_w;
+          q.gb2 = grad + pl.te2_b;
+        }
+        q.counter = (unsigned*)B.post_counter;
+        launch_post_reduce(q, s);
+      } else {
+        if (lowrank) launch_lowrank_dw(prm + pl.Wout, B.lowrank, d.out_dim, H, grad + pl.l2w[nb - 1], s);
+        if (oh >= 0)
+          launch_time_backward_from_sums(prm + pl.te1_w, prm + pl.te1_b, prm + pl.te2_w, B.part, prm + pl.W0, d.in_dim,
+                                         d.act_flat, H, B.part + (size_t)H * Kft, ksteps, Kft, d.time_dim, grad + pl.te1_w,
+                                         grad + pl.te1_b, grad + pl.te2_w, grad + pl.te2_b, s);
+      }
       if (fin && aux == s) launch_loss_finalize(*fin, s);
       B.dh0_final = B.dh_all[0];
       return;
@@ -1285,6 +1305,7 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   BuildRows br;
   memset(&br, 0, sizeof(br));
   br.zero_b = W.moments, br.n_zero_b = 32;  // zeroed by the row builder (every statistic has one owner launch that writes it)
+  br.zero_a = W.A.post_counter, br.n_zero_a = 1, W.A.post_zeroed = true;  // post_reduce_kernel's arrival counter
   if (Kft <= 1024) br.loss_tab = W.loss_tab, br.pcfg = pcfg;
   br.inds = inds, br.kinds = kinds, br.chains = chains_k, br.obs = obs_k, br.temb = (const float*)(ak + LA.temb);
   br.ksteps = ksteps;
@@ -1524,6 +1545,10 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 17) {
     g_merge_top = value;
+    return 0;
+  }
+  if (knob == 18) {
+    g_post_one = value;
     return 0;
   }
   return fail(-1, "unknown tuning knob %d", knob);

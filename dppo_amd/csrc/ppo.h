@@ -259,6 +259,20 @@ struct ComposeJobs {
   int n;
 };
 void launch_compose(const ComposeJobs& q, hipStream_t s);
+struct PostReduce {  // see post_reduce_kernel; dW == null: no low-rank part; G == null: no time-embedding part
+  const float *Wout, *T;
+  float* dW;
+  int out_dim, H;
+  const float *S, *W0;
+  int ldw0, AF, Kft, td;
+  float* G;
+  const float *w1, *b1, *w2;
+  const dppo_step* ksteps;
+  float *gw1, *gb1, *gw2, *gb2;
+  unsigned* counter;  // zero on entry; left zero
+  int n_lowrank, n_temb;  // set by the launcher
+};
+void launch_post_reduce(PostReduce& q, hipStream_t s);
 void launch_lowrank_dw(const float* Wout, const float* T, int out_dim, int H, float* dW, hipStream_t s);
 void launch_stats_split(const double* st, float* hi_lo, int n, hipStream_t s);
 void launch_stats_merge(const float* hi_lo, double* st, int n, int first_avg, int n_avg, double inv_world, hipStream_t s);

@@ -766,10 +766,10 @@ void launch_temb_segsum(const float* dtemb, int ld, const int32_t* krow, int64_t
 }
 
 // single block: recompute the tiny time MLP per fine-tuned step and back-propagate G[k][td] through it
-__global__ __launch_bounds__(256) void time_backward_kernel(const float* w1, const float* b1, const float* w2,
-                                                            const float* G_in, const dppo_step* ksteps, int Kft, int td,
-                                                            float* gw1, float* gb1, float* gw2, float* gb2) {
-  extern __shared__ float sh[];  // per k: e0[td], z1[2td], a1[2td], dz1[2td]
+__device__ __forceinline__ void time_backward_block(const float* w1, const float* b1, const float* w2, const float* G_in,
+                                                    const dppo_step* ksteps, int Kft, int td, float* gw1, float* gb1,
+                                                    float* gw2, float* gb2, float* sh) {
+  // sh: per k: e0[td], z1[2td], a1[2td], dz1[2td]
   const int per = 7 * td;
   const int tid = threadIdx.x;
   const float* G = G_in;
@@ -815,6 +815,55 @@ __global__ __launch_bounds__(256) void time_backward_kernel(const float* w1, con
     for (int k = 0; k < Kft; ++k) s += sh[k * per + 5 * td + o];
     gb1[o] = s;
   }
+}
+__global__ __launch_bounds__(256) void time_backward_kernel(const float* w1, const float* b1, const float* w2,
+                                                            const float* G_in, const dppo_step* ksteps, int Kft, int td,
+                                                            float* gw1, float* gb1, float* gw2, float* gb2) {
+  extern __shared__ float sh[];
+  time_backward_block(w1, b1, w2, G_in, ksteps, Kft, td, gw1, gb1, gw2, gb2, sh);
+}
+
+// Everything that follows the slab reduction of a backward pass, in ONE launch: the low-rank dW2 (lowrank_dw_kernel's
+// body), G = W0_temb^T . S (temb_from_sums_kernel's, one wave per output) and, in the block that finishes G last, the
+// time MLP's backward -- three dependent-looking launches of 5-17 us that only shared the slab reduction as an input.
+__global__ __launch_bounds__(256) void post_reduce_kernel(const PostReduce q) {
+  extern __shared__ float sh[];
+  __shared__ bool last;
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < q.n_lowrank) {
+    const size_t idx = (size_t)blockIdx.x * 256 + tid;
+    if (idx >= (size_t)q.H * q.H) return;
+    const int i = (int)(idx / q.H), j = (int)(idx - (size_t)i * q.H);
+    float acc = 0.f;
+    for (int o = 0; o < q.out_dim; ++o) acc += q.Wout[(size_t)o * q.H + i] * q.T[(size_t)o * q.H + j];
+    q.dW[idx] = acc;
+    return;
+  }
+  const int tb = blockIdx.x - q.n_lowrank, lane = tid & 63, out = tb * 4 + (tid >> 6);
+  if (out < q.Kft * q.td) {
+    const int k = out / q.td, j = out % q.td;
+    float acc = 0.f;
+    for (int h = lane; h < q.H; h += 64) acc += q.W0[(size_t)h * q.ldw0 + q.AF + j] * q.S[(size_t)h * q.Kft + k];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if (lane == 0) q.G[out] = acc;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    last = atomicAdd(q.counter, 1u) == (unsigned)q.n_temb - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (tid == 0) *q.counter = 0;  // ready for the next call
+  time_backward_block(q.w1, q.b1, q.w2, q.G, q.ksteps, q.Kft, q.td, q.gw1, q.gb1, q.gw2, q.gb2, sh);
+}
+void launch_post_reduce(PostReduce& q, hipStream_t s) {
+  q.n_lowrank = q.dW != nullptr ? (int)(((size_t)q.H * q.H + 255) / 256) : 0;
+  q.n_temb = q.G != nullptr ? (q.Kft * q.td + 3) / 4 : 0;
+  const int blocks = q.n_lowrank + q.n_temb;
+  if (blocks > 0)
+    hipLaunchKernelGGL(post_reduce_kernel, dim3(blocks), dim3(256), (size_t)(q.G ? q.Kft * 7 * q.td : 1) * sizeof(float), s, q);
 }
 void launch_time_backward(const float* w1, const float* b1, const float* w2, const float* G, const dppo_step* ksteps,
                           int Kft, int td, float* gw1, float* gb1, float* gw2, float* gb2, hipStream_t s) {

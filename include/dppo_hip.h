@@ -303,6 +303,8 @@ int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* 
  * knob 16: the top block's second-layer weight gradient from the rank-out_dim factorisation
  *          dW2 = Wout^T . (d_out^T . act(z1)) instead of an H x H contraction over the batch (default 1)
  * knob 17: the sampler never runs the top block's second layer: out = Wout . h_in + (Wout . W2) . act(z1) + const
+ *          (default 1)
+ * knob 18: what follows the slab reduction of the actor's backward (low-rank dW2, time-embedding gradient) in one launch
  *          (default 1) */
 int dppo_tune_set(int knob, int value);
 /* one bare layer GEMM: out[M][ldo] = act(X[M][Kp] . W[N][Kp]^T + bias) with elem = prec operands;
