@@ -12,7 +12,10 @@
  *    *_workspace_bytes queries) and the HIP stream (hipStream_t passed as void*);
  *  - return 0 = ok, <0 = bad argument / unsupported shape (dppo_last_error() has the text),
  *    >0 = hipError_t from a launch;
- *  - re-entrant across streams: no global mutable state besides the thread-local error string.
+ *  - state: the error string is thread-local; the tuning knobs (dppo_tune_set) and the measurement probe are
+ *    process-wide.  dppo_ppo_loss_fwd_bwd / dppo_bc_loss_fwd_bwd / dppo_denoise_mse_fwd_bwd fork onto library-owned side
+ *    streams (one set per device, joined back into the caller's stream before they return control of it, capture-safe):
+ *    issue at most one such call per device at a time.  Every other entry point is re-entrant across streams.
  *
  * Networks are the reference's residual MLP family: Linear(in,H) -> n_blocks x
  * [h + l2(act(l1(act(h))))] -> Linear(H,out)  (model/common/mlp.py:84-154), for the actor preceded
