@@ -242,6 +242,7 @@ struct AdamwSlot {
   float eps, max_norm;
   const double* sq_norm;  // null: no clipping
   int block0, blocks;
+  int vec4;  // set by the launcher: all four vectors are 16-byte aligned
 };
 struct AdamwSlots {
   AdamwSlot s[4];

@@ -1169,19 +1169,42 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwSlots a) {
   float clip = 1.f;
   if (sl.sq_norm != nullptr) clip = fminf(sl.max_norm / ((float)sqrt(sl.sq_norm[0]) + 1e-6f), 1.0f);
   const float one_m_b1 = (float)(1.0 - sl.beta1), b2 = (float)sl.beta2, one_m_b2 = (float)(1.0 - sl.beta2);
-  const int64_t i0 = (int64_t)(blockIdx.x - sl.block0) * (256 * ADAMW_MULTI_EPT) + threadIdx.x;
-#pragma unroll
-  for (int u = 0; u < ADAMW_MULTI_EPT; ++u) {  // few, fat blocks: the arrival counter below is one contended address
-    const int64_t i = i0 + u * 256;
-    if (i >= sl.n) break;
-    float gi = sl.g[i];
-    if (sl.sq_norm != nullptr) gi *= clip;
-    float pi = sl.p[i] * c[0];
-    float mi = sl.m[i];
+  const bool clipping = sl.sq_norm != nullptr;
+  auto upd = [&](float& pi, float gi, float& mi, float& vi) {
+    if (clipping) gi *= clip;
+    pi = pi * c[0];
     mi = mi + one_m_b1 * (gi - mi);
-    const float vi = sl.v[i] * b2 + one_m_b2 * (gi * gi);
+    vi = vi * b2 + one_m_b2 * (gi * gi);
     pi = pi - c[1] * (mi / (sqrtf(vi) / c[2] + sl.eps));
-    sl.p[i] = pi, sl.m[i] = mi, sl.v[i] = vi;
+  };
+  const int lb = blockIdx.x - sl.block0;
+  if (sl.vec4) {  // 16-byte accesses: few, fat blocks (the arrival counter below is one contended address)
+    const int64_t n4 = sl.n >> 2;
+#pragma unroll
+    for (int u = 0; u < ADAMW_MULTI_EPT / 4; ++u) {
+      const int64_t q = (int64_t)lb * (256 * ADAMW_MULTI_EPT / 4) + u * 256 + threadIdx.x;
+      if (q >= n4) break;
+      float4 p4 = ((float4*)sl.p)[q], m4 = ((float4*)sl.m)[q], v4 = ((float4*)sl.v)[q];
+      const float4 g4 = ((const float4*)sl.g)[q];
+      upd(p4.x, g4.x, m4.x, v4.x), upd(p4.y, g4.y, m4.y, v4.y), upd(p4.z, g4.z, m4.z, v4.z), upd(p4.w, g4.w, m4.w, v4.w);
+      ((float4*)sl.p)[q] = p4, ((float4*)sl.m)[q] = m4, ((float4*)sl.v)[q] = v4;
+    }
+    if (lb == 0 && threadIdx.x < (sl.n & 3)) {  // the last n % 4 elements
+      const int64_t i = (n4 << 2) + threadIdx.x;
+      float pi = sl.p[i], mi = sl.m[i], vi = sl.v[i];
+      upd(pi, sl.g[i], mi, vi);
+      sl.p[i] = pi, sl.m[i] = mi, sl.v[i] = vi;
+    }
+  } else {
+    const int64_t i0 = (int64_t)lb * (256 * ADAMW_MULTI_EPT) + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < ADAMW_MULTI_EPT; ++u) {
+      const int64_t i = i0 + u * 256;
+      if (i >= sl.n) break;
+      float pi = sl.p[i], mi = sl.m[i], vi = sl.v[i];
+      upd(pi, sl.g[i], mi, vi);
+      sl.p[i] = pi, sl.m[i] = mi, sl.v[i] = vi;
+    }
   }
   // every block of the slot has read step_dev[0] before it arrives here: the last one to arrive advances the count
   if (threadIdx.x == 0 && atomicAdd(&sl.step_dev[1], 1) == sl.blocks - 1) {
@@ -1194,6 +1217,7 @@ void launch_adamw_multi(AdamwSlots& a, hipStream_t s) {
   for (int i = 0; i < a.n; ++i) {
     a.s[i].block0 = blocks;
     a.s[i].blocks = (int)((a.s[i].n + 256 * ADAMW_MULTI_EPT - 1) / (256 * ADAMW_MULTI_EPT));
+    a.s[i].vec4 = (((uintptr_t)a.s[i].p | (uintptr_t)a.s[i].g | (uintptr_t)a.s[i].m | (uintptr_t)a.s[i].v) & 15) == 0;
     blocks += a.s[i].blocks;
   }
   if (blocks > 0) hipLaunchKernelGGL(adamw_multi_kernel, dim3(blocks), dim3(256), 0, s, a);

@@ -1,3 +1,4 @@
+# A/B of bench.py under different --tune settings, two rounds each (run on the GPU box).
 # usage: tools/_ab.sh "<tune args A>" "<tune args B>" ...   (each a string of --tune flags; "" = defaults)
 for rep in 1 2; do
 for t in "$@"; do
