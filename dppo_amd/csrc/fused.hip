@@ -645,6 +645,7 @@ static int pick_mr(int hidden) {
 template <class P>
 static int pick_mr_bwd(int hidden, int ln) {
   if (short_tiles<P>(hidden, ln, 0)) return 2;
+  if (P::ESIZE == 2 && hidden == 256 && !ln && ((g_short_tiles >> 3) & 1)) return 2;
   int mr = pick_mr<P>(hidden);
   if (hidden >= 1024 && mr > 1) mr /= 2;
   if (P::ESIZE == 2 && hidden == 256) mr /= 2;  // 8 row sub-tiles of dh, acc, derivative chunks and B fragments do not fit 256 VGPRs
@@ -715,6 +716,10 @@ int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStrea
   if constexpr (P::ESIZE == 2) {
     if (short_tiles<P>(d.hidden, a.use_ln, 1) && ot == 1)
       return relu ? launch_fwd_cfg<P, 4, 2, 1, false, ACT_RELU, 2>(a, s) : launch_fwd_cfg<P, 4, 2, 1, false, ACT_MISH, 2>(a, s);
+    // knob 7 bit 2: H = 256 (the critic) in 64-row tiles at two workgroups per CU: its Mish emits are VALU-bound, one
+    // workgroup's emit can run under the other's MFMAs
+    if (d.hidden == 256 && !a.use_ln && ot == 1 && ((g_short_tiles >> 2) & 1))
+      return relu ? launch_fwd_cfg<P, 2, 4, 1, false, ACT_RELU, 2>(a, s) : launch_fwd_cfg<P, 2, 4, 1, false, ACT_MISH, 2>(a, s);
   }
 #define DPPO_FWD(T, R, O) \
   if (tpw == T && mr == R && ot == O)                                                                                  \
@@ -756,6 +761,8 @@ int launch_fused_backward(const dppo_net_desc& d, const FusedBwdArgs& a, hipStre
   if constexpr (P::ESIZE == 2) {
     if (short_tiles<P>(d.hidden, a.use_ln, 0))
       return relu ? launch_bwd_cfg<P, 4, 2, false, ACT_RELU, 2>(a, s) : launch_bwd_cfg<P, 4, 2, false, ACT_MISH, 2>(a, s);
+    if (d.hidden == 256 && !a.use_ln && ((g_short_tiles >> 3) & 1))  // knob 7 bit 3: the same for the backward (32-row tiles)
+      return relu ? launch_bwd_cfg<P, 2, 2, false, ACT_RELU, 2>(a, s) : launch_bwd_cfg<P, 2, 2, false, ACT_MISH, 2>(a, s);
   }
 #define DPPO_BWD(T, R, L) \
   if (tpw == T && mr == R && (a.use_ln != 0) == L) \

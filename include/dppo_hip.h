@@ -291,7 +291,9 @@ int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* 
  * knob 1: big-batch MLP path, 1 = fused row-tile kernels (default), 0 = layer-by-layer gemm_nt chain
  * knob 2: PPO update, 1 = critic half on a side stream, overlapping the actor half (default), 0 = one stream
  * knob 3 / 4: weight-gradient GEMMs, workgroups aimed for (default 256) / cap on the row splits (default 128)
- * knob 7: fused kernels, bit 0 / 1 = 32-row tiles at two workgroups per CU in the backward / forward (default 0)
+ * knob 7: fused kernels, bit 0 / 1 = 32-row tiles at two workgroups per CU in the backward / forward at H = 512,
+ *         bit 2 / 3 = 64- / 32-row tiles at two workgroups per CU in the forward / backward at H = 256 (default 0: none
+ *         of them pays)
  * knob 8: timing experiments on the fused backward (results are wrong while set); knob 9: side streams at low priority
  * knob 5: weight-gradient GEMM kernel, 0 = register-staged (default), 1..8 = an LDS-DMA ring configuration, -1 = by shape
  * knob 6: thin (512 x 64) weight-gradient tiles on / off; knob 10: critic side stream gated on the actor's forward (0 off)
