@@ -322,6 +322,31 @@ def test_adamw_multi_equals_single_steps(golden):
         np.testing.assert_allclose(p.cpu().numpy(), g[f"p{i + 1}"], rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("sname", ["hopper", "square_like", "ln_relu"])
+def test_packing_two_networks_at_once_equals_packing_each(sname):
+    """dppo_pack_nets (both composites in one launch, both images in one launch) writes byte for byte what two
+    dppo_pack_net calls write."""
+    from dppo_amd.model.common.mlp import pack_pair
+    for prec_name in ("fp32", "bf16"):
+        m, a, c = build_model(sname, dict(denoising_steps=20, ft_denoising_steps=10), 71, prec_name)
+        K = m.denoising_steps
+
+        def poison():  # invalidate both images; regions a pack does not write (layered-path copies) stay 0xAB either way
+            for net in (m.actor_ft, m.critic):
+                net.mark_updated()
+                for _, buf in net._packed.values():
+                    buf.fill_(0xAB)
+
+        m.actor_ft.packed(m.prec, K), m.critic.packed(m.prec, 0)  # allocate
+        poison()
+        one_a = m.actor_ft.packed(m.prec, K).clone()
+        one_c = m.critic.packed(m.prec, 0).clone()
+        poison()
+        pack_pair(m.critic, 0, m.actor_ft, K, m.prec)
+        assert torch.equal(m.actor_ft.packed(m.prec, K), one_a)
+        assert torch.equal(m.critic.packed(m.prec, 0), one_c)
+
+
 def test_stats_travel_through_an_fp32_bucket_without_losing_precision():
     """dppo_stats_split / dppo_stats_merge: float64 statistics as (hi, lo) float32 pairs in the gradient bucket of the
     data-parallel all-reduce; a SUM over `world` identical ranks gives world x the sums and leaves the two advantage
