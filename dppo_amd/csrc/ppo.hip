@@ -1160,10 +1160,15 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwSlots a) {
     if (i < a.n && (int)blockIdx.x >= a.s[i].block0) si = i;
   const AdamwSlot& sl = a.s[si];
   __shared__ float c[4];
+  // the two double-precision pow() calls are the longest dependency of a block: one wave each
   if (threadIdx.x == 0) {
     const double t = (double)(sl.step_dev[0] + 1), lr = (double)sl.lr_dev[0];
-    const double bc1 = 1.0 - pow(sl.beta1, t), bc2 = 1.0 - pow(sl.beta2, t);
-    c[0] = (float)(1.0 - lr * sl.weight_decay), c[1] = (float)(lr / bc1), c[2] = (float)sqrt(bc2);
+    const double bc1 = 1.0 - pow(sl.beta1, t);
+    c[0] = (float)(1.0 - lr * sl.weight_decay), c[1] = (float)(lr / bc1);
+  }
+  if (threadIdx.x == 64) {
+    const double t = (double)(sl.step_dev[0] + 1);
+    c[2] = (float)sqrt(1.0 - pow(sl.beta2, t));
   }
   __syncthreads();
   float clip = 1.f;
