@@ -506,7 +506,6 @@ constexpr int LOSS_PASSES = 2;  // samples per block = 16 * LOSS_PASSES: short b
 template <class P>
 __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
   typedef typename P::elem_t E;
-  __shared__ double sh[4];
   // per-k constants (only Kft distinct values exist): denoising discount and clip range, built once per block in
   // the reference's precision recipe (double pow / exp, then fp32) instead of per lane
   extern __shared__ float tab[];  // [Kft] discount, [Kft] eps_k, [2] adv mean / std
@@ -633,11 +632,24 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
   }
   // per-block partial sums; loss_finalize_kernel adds them in block order (no atomics: reproducible, and thousands of
   // double atomics on five addresses serialise in L2)
-  s_pg = block_sum(s_pg, sh);
-  s_v = block_sum(s_v, sh);
-  s_kl = block_sum(s_kl, sh);
-  s_cf = block_sum(s_cf, sh);
-  s_ratio = block_sum(s_ratio, sh);
+  {  // the five sums in one pass (same per-value order as block_sum(): wave shuffle, then the four waves' partials)
+    __shared__ double sh5[4][5];
+    double v5[5] = {s_pg, s_v, s_kl, s_cf, s_ratio};
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      for (int o = 32; o > 0; o >>= 1) v5[q] += __shfl_down(v5[q], o);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) sh5[w][q] = v5[q];
+    }
+    __syncthreads();
+    s_pg = sh5[0][0] + sh5[1][0] + sh5[2][0] + sh5[3][0];
+    s_v = sh5[0][1] + sh5[1][1] + sh5[2][1] + sh5[3][1];
+    s_kl = sh5[0][2] + sh5[1][2] + sh5[2][2] + sh5[3][2];
+    s_cf = sh5[0][3] + sh5[1][3] + sh5[2][3] + sh5[3][3];
+    s_ratio = sh5[0][4] + sh5[1][4] + sh5[2][4] + sh5[3][4];
+  }
   if (threadIdx.x == 0) {
     double* o = a.partial + (size_t)blockIdx.x * 8;
     o[DPPO_STAT_PG_LOSS] = s_pg, o[DPPO_STAT_V_LOSS] = s_v, o[DPPO_STAT_APPROX_KL] = s_kl;
