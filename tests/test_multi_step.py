@@ -83,3 +83,31 @@ def test_agent_protocol_shapes():
     o, r, te, tr, info = env.step(np.zeros((2, 3, 1)))
     assert o["state"].shape == (2, 2, 2) and r.shape == (2,) and te.dtype == bool and len(info) == 2
     assert list(o["state"][0, :, 0]) == [2.0, 3.0]
+
+
+def test_rollout_collector_over_multistep_groups():
+    """The pieces compose: two MultiStepVec groups behind GroupedVecEnv, driven by collect_rollout with a stand-in policy."""
+    from collections import namedtuple
+
+    import torch
+
+    from dppo_amd.util.rollout import GroupedVecEnv, collect_rollout
+    Sample = namedtuple("Sample", "trajectories chains")
+
+    class Policy:
+        horizon_steps = 4
+
+        def __call__(self, cond, deterministic=False, return_chain=True):
+            st = cond["state"]
+            traj = torch.tanh(st[:, -1, :1]).reshape(-1, 1, 1).repeat(1, 4, 1)
+            return Sample(traj, torch.stack([traj * 0.5, traj], dim=1))
+
+    groups = [MultiStepVec(CounterSim([5, 9]), 2, n_obs_steps=2, n_action_steps=3, max_episode_steps=8) for _ in range(2)]
+    venv = GroupedVecEnv(groups)
+    obs = venv.reset_arg()
+    S, E = 4, 4
+    obs_buf, chains_buf = torch.zeros(S * E, 2 * 2), torch.zeros(S * E, 2, 4)
+    reward, term, done, last = collect_rollout(Policy(), venv, obs, S, 3, obs_buf, chains_buf)
+    assert reward.shape == (S, E) and done.sum() > 0 and last["state"].shape == (E, 2, 2)
+    assert (reward[:, 0] == reward[:, 2]).all() and (reward[:, 1] == reward[:, 3]).all()  # the two groups are twins
+    assert torch.equal(obs_buf[:E].reshape(E, 2, 2), torch.from_numpy(obs["state"]).float())
