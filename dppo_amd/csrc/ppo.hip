@@ -777,14 +777,25 @@ void launch_temb_segsum(const float* dtemb, int ld, const int32_t* krow, int64_t
   hipLaunchKernelGGL(temb_segsum_kernel, dim3(blocks, Kft), dim3(256), 0, s, dtemb, ld, krow, M, Kft, td, partial);
 }
 
+static size_t time_backward_lds(int Kft, int td) {  // see time_backward_block
+  return (size_t)(Kft * 7 * td + 4 * td * td + 2 * td + Kft * td) * sizeof(float);
+}
 // single block: recompute the tiny time MLP per fine-tuned step and back-propagate G[k][td] through it
 __device__ __forceinline__ void time_backward_block(const float* w1, const float* b1, const float* w2, const float* G_in,
                                                     const dppo_step* ksteps, int Kft, int td, float* gw1, float* gb1,
                                                     float* gw2, float* gb2, float* sh) {
-  // sh: per k: e0[td], z1[2td], a1[2td], dz1[2td]
+  // sh: per k: e0[td], z1[2td], a1[2td], dz1[2td]; then w1[2td][td], w2[td][2td], b1[2td], G[Kft][td] staged once (each
+  // phase below otherwise pays an L2 latency per inner-loop iteration: this block is the tail of the update's critical path)
   const int per = 7 * td;
   const int tid = threadIdx.x;
-  const float* G = G_in;
+  float* w1s = sh + Kft * per;
+  float* w2s = w1s + 2 * td * td;
+  float* b1s = w2s + 2 * td * td;
+  float* Gs = b1s + 2 * td;
+  for (int i = tid; i < 2 * td * td; i += 256) w1s[i] = w1[i], w2s[i] = w2[i];
+  for (int i = tid; i < 2 * td; i += 256) b1s[i] = b1[i];
+  for (int i = tid; i < Kft * td; i += 256) Gs[i] = G_in[i];
+  const float* G = Gs;
   for (int i = tid; i < Kft * td; i += 256) {
     const int k = i / td, j = i % td;
     sh[k * per + j] = sinus_feat(ksteps[k].t, j, td);
@@ -792,8 +803,8 @@ __device__ __forceinline__ void time_backward_block(const float* w1, const float
   __syncthreads();
   for (int i = tid; i < Kft * 2 * td; i += 256) {
     const int k = i / (2 * td), o = i % (2 * td);
-    float s = b1[o];
-    for (int j = 0; j < td; ++j) s += w1[o * td + j] * sh[k * per + j];
+    float s = b1s[o];
+    for (int j = 0; j < td; ++j) s += w1s[o * td + j] * sh[k * per + j];
     sh[k * per + td + o] = s;
     sh[k * per + 3 * td + o] = mish_f(s);
   }
@@ -801,7 +812,7 @@ __device__ __forceinline__ void time_backward_block(const float* w1, const float
   for (int i = tid; i < Kft * 2 * td; i += 256) {
     const int k = i / (2 * td), o = i % (2 * td);
     float s = 0.f;
-    for (int j = 0; j < td; ++j) s += w2[j * 2 * td + o] * G[k * td + j];
+    for (int j = 0; j < td; ++j) s += w2s[j * 2 * td + o] * G[k * td + j];
     sh[k * per + 5 * td + o] = s * mish_grad_f(sh[k * per + td + o]);
   }
   __syncthreads();
@@ -875,11 +886,11 @@ void launch_post_reduce(PostReduce& q, hipStream_t s) {
   q.n_temb = q.G != nullptr ? (q.Kft * q.td + 3) / 4 : 0;
   const int blocks = q.n_lowrank + q.n_temb;
   if (blocks > 0)
-    hipLaunchKernelGGL(post_reduce_kernel, dim3(blocks), dim3(256), (size_t)(q.G ? q.Kft * 7 * q.td : 1) * sizeof(float), s, q);
+    hipLaunchKernelGGL(post_reduce_kernel, dim3(blocks), dim3(256), (q.G ? time_backward_lds(q.Kft, q.td) : sizeof(float)), s, q);
 }
 void launch_time_backward(const float* w1, const float* b1, const float* w2, const float* G, const dppo_step* ksteps,
                           int Kft, int td, float* gw1, float* gb1, float* gw2, float* gb2, hipStream_t s) {
-  hipLaunchKernelGGL(time_backward_kernel, dim3(1), dim3(256), (size_t)Kft * 7 * td * sizeof(float), s, w1, b1, w2, G,
+  hipLaunchKernelGGL(time_backward_kernel, dim3(1), dim3(256), time_backward_lds(Kft, td), s, w1, b1, w2, G,
                      ksteps, Kft, td, gw1, gb1, gw2, gb2);
 }
 // G[k][j] = sum_h W0[h*ldw0 + AF + j] * S[h*Kft + k]: one wave per output, lanes over h (a single block looping over h
