@@ -1227,6 +1227,8 @@ int dppo_denoise_mse_fwd_bwd(const dppo_net_desc* actor, int prec, const float* 
   if (!params || !packed || !tsteps || !obs || !pairs || !kinds || !grad || !loss || !workspace)
     return fail(-1, "null pointer");
   if (N < 1 || N > 0x7fffffff || n_time < 1 || n_time > 1024) return fail(-1, "N / n_time out of range");
+  if (time_backward_lds_bytes(n_time, actor->time_dim) > 156 * 1024)
+    return fail(-1, "n_time * time_dim = %d too large for the time-embedding backward (LDS)", n_time * actor->time_dim);
 #define CALL(P)                                                                                                        \
   mse_impl<P>(*actor, params, (const char*)packed, tsteps, n_time, obs, pairs, kinds, N, grad, loss, workspace, \
               workspace_bytes, (hipStream_t)stream)
@@ -1389,7 +1391,9 @@ int dppo_ppo_loss_fwd_bwd(const dppo_net_desc* actor, const dppo_net_desc* criti
   if ((inds == nullptr) == (kinds == nullptr)) return fail(-1, "pass exactly one of inds (rollout mode) / kinds (gathered mode)");
   if (N < 2 || N > 0x7fffffff) return fail(-1, "N out of range");
   if (pcfg->ft_denoising_steps < 1 || pcfg->ft_denoising_steps > 1024) return fail(-1, "Kft out of range");
-  if ((int64_t)pcfg->ft_denoising_steps * actor->time_dim > 65536) return fail(-1, "Kft * time_dim too large");
+  if ((int64_t)pcfg->ft_denoising_steps * actor->time_dim > 65536 ||
+      time_backward_lds_bytes(pcfg->ft_denoising_steps, actor->time_dim) > 156 * 1024)
+    return fail(-1, "Kft * time_dim too large");
   if (pcfg->horizon_steps * pcfg->action_dim != actor->act_flat) return fail(-1, "Ta*Da != act_flat");
   if (pcfg->reward_horizon < 1) return fail(-1, "reward_horizon must be >= 1");
 #define CALL(P)                                                                                                        \

@@ -274,6 +274,7 @@ struct PostReduce {  // see post_reduce_kernel; dW == null: no low-rank part; G 
   int n_lowrank, n_temb;  // set by the launcher
 };
 void launch_post_reduce(PostReduce& q, hipStream_t s);
+size_t time_backward_lds_bytes(int Kft, int td);  // LDS of the time MLP's backward block: must stay <= 156 KB
 void launch_lowrank_dw(const float* Wout, const float* T, int out_dim, int H, float* dW, hipStream_t s);
 void launch_stats_split(const double* st, float* hi_lo, int n, hipStream_t s);
 void launch_stats_merge(const float* hi_lo, double* st, int n, int first_avg, int n_avg, double inv_world, hipStream_t s);

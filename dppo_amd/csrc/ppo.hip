@@ -780,6 +780,13 @@ void launch_temb_segsum(const float* dtemb, int ld, const int32_t* krow, int64_t
 static size_t time_backward_lds(int Kft, int td) {  // see time_backward_block
   return (size_t)(Kft * 7 * td + 4 * td * td + 2 * td + Kft * td) * sizeof(float);
 }
+size_t time_backward_lds_bytes(int Kft, int td) { return time_backward_lds(Kft, td); }
+template <class K>
+static void raise_dyn_lds(K kern) {  // above 64 KB of dynamic LDS a kernel needs its cap raised (once); the cap counts
+  // static __shared__ too (post_reduce_kernel has a few bytes): ask for a little less than the 160 KB a CU has
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+    (void)hipGetLastError();  // not fatal: launches below 64 KB do not need it
+}
 // single block: recompute the tiny time MLP per fine-tuned step and back-propagate G[k][td] through it
 __device__ __forceinline__ void time_backward_block(const float* w1, const float* b1, const float* w2, const float* G_in,
                                                     const dppo_step* ksteps, int Kft, int td, float* gw1, float* gb1,
@@ -885,11 +892,15 @@ void launch_post_reduce(PostReduce& q, hipStream_t s) {
   q.n_lowrank = q.dW != nullptr ? (int)(((size_t)q.H * q.H + 255) / 256) : 0;
   q.n_temb = q.G != nullptr ? (q.Kft * q.td + 3) / 4 : 0;
   const int blocks = q.n_lowrank + q.n_temb;
+  static bool raised = false;
+  if (!raised) raise_dyn_lds(post_reduce_kernel), raised = true;
   if (blocks > 0)
     hipLaunchKernelGGL(post_reduce_kernel, dim3(blocks), dim3(256), (q.G ? time_backward_lds(q.Kft, q.td) : sizeof(float)), s, q);
 }
 void launch_time_backward(const float* w1, const float* b1, const float* w2, const float* G, const dppo_step* ksteps,
                           int Kft, int td, float* gw1, float* gb1, float* gw2, float* gb2, hipStream_t s) {
+  static bool raised = false;
+  if (!raised) raise_dyn_lds(time_backward_kernel), raised = true;
   hipLaunchKernelGGL(time_backward_kernel, dim3(1), dim3(256), time_backward_lds(Kft, td), s, w1, b1, w2, G,
                      ksteps, Kft, td, gw1, gb1, gw2, gb2);
 }

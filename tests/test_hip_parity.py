@@ -322,6 +322,31 @@ def test_adamw_multi_equals_single_steps(golden):
         np.testing.assert_allclose(p.cpu().numpy(), g[f"p{i + 1}"], rtol=1e-6, atol=1e-7)
 
 
+def test_denoise_mse_with_100_steps_and_a_32_wide_time_embedding_matches_oracle():
+    """K = 100, time_dim = 32 (the furniture cfgs' pre-training): the time MLP's backward block needs 119 KB of LDS, above
+    the 64 KB a kernel gets without asking.  fp32 loss and every gradient against the oracle on the same draws."""
+    K, N = 100, 48
+    m, a, _ = build_model("furniture_256", dict(denoising_steps=K, ft_denoising_steps=10), 81, "fp32")
+    for p in m.network.parameters():
+        p.requires_grad_(True)
+    gen = torch.Generator().manual_seed(9)
+    x0 = torch.rand(N, a.horizon_steps, a.action_dim, generator=gen) * 2 - 1
+    state = torch.rand(N, 1, a.cond_dim, generator=gen) * 2 - 1
+    t = torch.randint(0, K, (N,), generator=gen)
+    noise = torch.randn(N, a.horizon_steps, a.action_dim, generator=gen)
+    loss = m.p_losses(x0.to(DEV), {"state": state.to(DEV)}, t.to(DEV), noise=noise.to(DEV))
+    loss.backward()
+    prm = {k: v.clone().requires_grad_(True) for k, v in O.init_params(a, 81).items()}
+    ref = O.denoise_mse_loss(K, a, prm, x0, state, t, noise)
+    ref.backward()
+    assert loss.item() == pytest.approx(ref.item(), rel=1e-4)
+    got = torch.cat([p.grad.reshape(-1) for p in m.network.parameters()]).cpu().double().numpy()
+    want = flat_of({n: (p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in prm.items()}, a).astype(np.float64)
+    assert np.linalg.norm(got - want) <= 2e-4 * np.linalg.norm(want)
+    te = slice(0, 32 * 64 + 64 + 64 * 32 + 32)  # the time MLP's parameters come first in the flat layout
+    assert np.linalg.norm(want[te]) > 0 and np.linalg.norm(got[te] - want[te]) <= 2e-4 * np.linalg.norm(want[te])
+
+
 @pytest.mark.parametrize("sname", ["hopper", "square_like", "ln_relu"])
 def test_packing_two_networks_at_once_equals_packing_each(sname):
     """dppo_pack_nets (both composites in one launch, both images in one launch) writes byte for byte what two
