@@ -85,6 +85,11 @@ class TrainPPODiffusionAgent:
         self.gamma = cfg.train.gamma
         self.n_critic_warmup_itr = cfg.train.n_critic_warmup_itr
         self.dp = DataParallel(self.model, self.world)
+        if self.world > 1:
+            # the broadcast above made the weights identical; from here on every rank needs its OWN random stream
+            # (sampler Philox key, minibatch permutation, BC noise): same seed everywhere would give env row i of
+            # every shard the same exploration noise
+            self.reseed(self.seed + self.rank)
         self.actor_optimizer = FlatAdamW(self.model.actor_ft.flat_params(), lr=cfg.train.actor_lr,
                                          weight_decay=cfg.train.actor_weight_decay)
         self.critic_optimizer = FlatAdamW(self.model.critic.flat_params(), lr=cfg.train.critic_lr,
@@ -110,6 +115,12 @@ class TrainPPODiffusionAgent:
         # ---- TrainPPODiffusionAgent (:22-45)
         self.reward_horizon = cfg.get("reward_horizon", self.act_steps)
         self.learn_eta = self.model.learn_eta
+
+    @staticmethod
+    def reseed(seed: int):
+        random.seed(seed)
+        np.random.seed(seed)
+        torch.manual_seed(seed)  # CPU generator (the sampler's Philox key is drawn from it) and the device generators
 
     # -------------------------------------------------------------------------------------------------
     def _pool_return_moments(self, mean, var, cnt):
@@ -140,6 +151,8 @@ class TrainPPODiffusionAgent:
         data = torch.load(os.path.join(self.checkpoint_dir, f"state_{itr}.pt"), weights_only=True)
         self.itr = data["itr"]
         self.model.load_state_dict(data["model"])
+        for net in (self.model.actor, self.model.actor_ft, self.model.critic):
+            net.mark_updated()  # kernel images are rebuilt from the loaded weights on next use
 
     # -------------------------------------------------------------------------------------------------
     def run(self):

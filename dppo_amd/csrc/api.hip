@@ -1126,6 +1126,9 @@ static size_t carve_bc(Carver& c, const dppo_net_desc& d, int64_t M, MlpBufs<P>&
 int64_t dppo_bc_loss_workspace_bytes(const dppo_net_desc* actor, int prec, int64_t B, int Kft) {
   if (check_net(actor) || check_prec(prec)) return -1;
   if (B < 1 || Kft < 1 || B * Kft > 0x7fffffff) return fail(-1, "B*Kft out of range");
+  if (Kft > 1024 || (int64_t)Kft * actor->time_dim > 65536 ||
+      time_backward_lds_bytes(Kft, actor->time_dim) > 156 * 1024)
+    return fail(-1, "Kft * time_dim = %d too large for the time-embedding backward (LDS)", Kft * actor->time_dim);
   Carver c{nullptr, 0, 0};
   int32_t *br, *kr;
   if (prec == DPPO_PREC_F32) {
@@ -1173,6 +1176,9 @@ int dppo_bc_loss_fwd_bwd(const dppo_net_desc* actor, int prec, const float* para
   if (actor->kind != 0) return fail(-1, "dppo_bc_loss_fwd_bwd needs an actor descriptor");
   if (!params || !packed || !cfg || !ksteps || !obs || !chains || !grad || !loss || !workspace) return fail(-1, "null pointer");
   if (B < 1 || Kft < 1 || B * Kft > 0x7fffffff) return fail(-1, "B*Kft out of range");
+  if (Kft > 1024) return fail(-1, "Kft out of range");
+  if ((int64_t)Kft * actor->time_dim > 65536 || time_backward_lds_bytes(Kft, actor->time_dim) > 156 * 1024)
+    return fail(-1, "Kft * time_dim = %d too large for the time-embedding backward (LDS)", Kft * actor->time_dim);
 #define CALL(P)                                                                                                       \
   bc_impl<P>(*actor, params, (const char*)packed, *cfg, ksteps, Kft, obs, chains, B, grad, loss, workspace, workspace_bytes, \
              (hipStream_t)stream)

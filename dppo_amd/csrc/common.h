@@ -14,7 +14,23 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace dppo {
+
+// hipFuncSetAttribute (the > 64 KB dynamic-LDS cap) is PER DEVICE: one latch bit per device ordinal instead of a
+// process-wide bool, so a second device of the same process gets its cap raised too.  Atomic; two threads racing on the
+// same device both set the attribute, which is idempotent.
+struct DevLatch {
+  std::atomic<uint64_t> bits{0};
+  static int dev() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d & 63;
+  }
+  bool need() const { return !((bits.load(std::memory_order_acquire) >> dev()) & 1); }
+  void done() { bits.fetch_or(1ull << dev(), std::memory_order_release); }
+};
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

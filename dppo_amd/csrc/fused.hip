@@ -676,10 +676,10 @@ template FusedGeom fused_geom<BF16>(const dppo_net_desc&);
 constexpr int NUM_CUS = 256;
 
 template <class K>
-static void raise_lds(K kern, bool& done) {
-  if (!done) {
+static void raise_lds(K kern, DevLatch& done) {
+  if (done.need()) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    done = true;
+    done.done();
   }
 }
 
@@ -697,7 +697,7 @@ static int launch_fwd_cfg(const FusedFwdArgs& a, hipStream_t s) {
     b.consts_lds |= 1, lds += bias_bytes;
     if (lds + wout_bytes <= cap) b.consts_lds |= 2, lds += wout_bytes;
   }
-  static bool attr = false;
+  static DevLatch attr;
   raise_lds(fused_forward_kernel<P, TPW, MR, OT, LN, ACT, OCC>, attr);
   const int ntiles = (a.M + MT - 1) / MT;
   const bool probe = probe_begin(PROBE_FUSED_FWD, s);
@@ -743,7 +743,7 @@ static int launch_bwd_cfg(const FusedBwdArgs& a, hipStream_t s) {
   constexpr int ES = P::ESIZE, MT = 16 * MR, H = 128 * TPW;
   const size_t lds = 2 * (size_t)MT * H * ES + (LN ? (size_t)LN_WAVES * 2 * MR * 16 * 4 : 0) + SAMPLER_WAVES * 128 * 4;
   if (lds > 160 * 1024 / OCC || a.KpB0 > H || a.KpB0 > 128) return -2;
-  static bool attr = false;
+  static DevLatch attr;
   raise_lds(fused_backward_kernel<P, TPW, MR, LN, ACT, OCC>, attr);
   const int ntiles = (a.M + MT - 1) / MT;
   const bool probe = probe_begin(PROBE_FUSED_BWD, s);

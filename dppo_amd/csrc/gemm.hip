@@ -267,11 +267,11 @@ static void launch_nt_cfg(const GemmNT& a, hipStream_t s) {
   dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
   const size_t lds = 2 * (BN + BM) * 128;
   if constexpr (2 * (BN + BM) * 128 > 65536) {  // the 16 x 256 tile needs 68 KiB: raise the dynamic-LDS cap once
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DevLatch attr_set;
+    if (attr_set.need()) {
       (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<P, WN, WM, TN, TM, TAG, DMA>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set = true;
+      attr_set.done();
     }
   }
   const bool probe = TAG == 1 && probe_begin(PROBE_GEMM_NT_HIDDEN, s);
@@ -631,11 +631,11 @@ static void launch_tn_dma_cfg(const GemmTN& a, hipStream_t s) {
   constexpr int LDS = NST * ROWS * (BA + BB) * ES;
   static_assert(LDS <= 160 * 1024, "ring does not fit LDS");
   dim3 grid(a.splits, (a.N1 + BA - 1) / BA, (a.N2 + BB - 1) / BB);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevLatch attr_set;
+  if (attr_set.need()) {
     (void)hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<P, WA, WB, TA, TB, NST, KS>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
+    attr_set.done();
   }
   const bool probe = a.N1 >= 128 && a.N2 >= 128 && probe_begin(PROBE_GEMM_TN, s);  // H x H gradients
   hipLaunchKernelGGL((gemm_tn_dma_kernel<P, WA, WB, TA, TB, NST, KS>), grid, dim3(WA * WB * 64), LDS, s, a);
@@ -647,11 +647,11 @@ static void launch_tn_cfg(const GemmTN& a, hipStream_t s) {
   constexpr int ES = P::ESIZE, BA = WA * TA * 16, BB = WB * TB * 16, ROWS = (ES == 2) ? 64 : 32;
   constexpr int LDS = 2 * ROWS * ((BA * ES + 32) + (BB * ES + 32));
   dim3 grid(a.splits, (a.N1 + BA - 1) / BA, (a.N2 + BB - 1) / BB);
-  static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the cap raised once per kernel
-  if (!attr_set) {
+  static DevLatch attr_set;  // > 64 KiB of dynamic LDS needs the cap raised once per kernel
+  if (attr_set.need()) {
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<P, WA, WB, TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               LDS);
-    attr_set = true;
+    attr_set.done();
   }
   const bool probe = BA == 128 && a.N1 >= 128 && a.N2 >= 128 && probe_begin(PROBE_GEMM_TN, s);  // H x H gradients
   hipLaunchKernelGGL((gemm_tn_kernel<P, WA, WB, TA, TB>), grid, dim3(256), LDS, s, a);
@@ -663,10 +663,10 @@ void launch_gemm_tn_group(const GemmTNGroup& gr, hipStream_t s) {
   if (gr.n <= 0) return;
   constexpr int ES = P::ESIZE, ROWS = (ES == 2) ? 64 : 32;
   constexpr int LDS = 2 * ROWS * 2 * (128 * ES + 32);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevLatch attr_set;
+  if (attr_set.need()) {
     (void)hipFuncSetAttribute((const void*)gemm_tn_group_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
+    attr_set.done();
   }
   double flops = 0, bytes = 0;
   for (int i = 0; i < gr.n; ++i) {

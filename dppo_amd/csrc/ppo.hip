@@ -892,15 +892,15 @@ void launch_post_reduce(PostReduce& q, hipStream_t s) {
   q.n_lowrank = q.dW != nullptr ? (int)(((size_t)q.H * q.H + 255) / 256) : 0;
   q.n_temb = q.G != nullptr ? (q.Kft * q.td + 3) / 4 : 0;
   const int blocks = q.n_lowrank + q.n_temb;
-  static bool raised = false;
-  if (!raised) raise_dyn_lds(post_reduce_kernel), raised = true;
+  static DevLatch raised;
+  if (raised.need()) raise_dyn_lds(post_reduce_kernel), raised.done();
   if (blocks > 0)
     hipLaunchKernelGGL(post_reduce_kernel, dim3(blocks), dim3(256), (q.G ? time_backward_lds(q.Kft, q.td) : sizeof(float)), s, q);
 }
 void launch_time_backward(const float* w1, const float* b1, const float* w2, const float* G, const dppo_step* ksteps,
                           int Kft, int td, float* gw1, float* gb1, float* gw2, float* gb2, hipStream_t s) {
-  static bool raised = false;
-  if (!raised) raise_dyn_lds(time_backward_kernel), raised = true;
+  static DevLatch raised;
+  if (raised.need()) raise_dyn_lds(time_backward_kernel), raised.done();
   hipLaunchKernelGGL(time_backward_kernel, dim3(1), dim3(256), time_backward_lds(Kft, td), s, w1, b1, w2, G,
                      ksteps, Kft, td, gw1, gb1, gw2, gb2);
 }

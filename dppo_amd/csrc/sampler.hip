@@ -442,11 +442,11 @@ static int launch_cfg(const SamplerGeom& g, const SampleArgs& a, hipStream_t s) 
   const size_t w0_bytes = (size_t)SAMPLER_WAVES * b.ks0v * TPW * 1024;
   b.l0_lds = g_sampler_l0_lds && lds + w0_bytes <= 160 * 1024 ? 1 : 0;
   if (b.l0_lds) lds += w0_bytes;
-  static bool attr_set = false;  // raising the dynamic-LDS cap is idempotent; racing setters are harmless
+  static DevLatch attr_set;  // per device; raising the dynamic-LDS cap is idempotent, racing setters are harmless
   auto kern = sample_chain_kernel<P, TPW, OT, LN, ACT>;
-  if (!attr_set) {
+  if (attr_set.need()) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_set.done();
   }
   const bool probe = probe_begin(PROBE_SAMPLER, s);
   hipLaunchKernelGGL(kern, dim3((a.B + 15) / 16), dim3(512), lds, s, b);

@@ -155,7 +155,12 @@ class HipNet(nn.Module):
         flat = self.flat_params()
         hip.require_gpu(flat, type(self).__name__)
         key = (prec, n_time)
-        stamp = (flat.data_ptr(), flat._version, self._epoch)
+        # the Parameters are `.data` views of `flat`: in-place writes through them (torch.optim steps, load_state_dict)
+        # advance THEIR version counters, never `flat._version` -- so the stamp folds every parameter's counter in
+        ver = 0
+        for p in self._plist:
+            ver += p._version
+        stamp = (flat.data_ptr(), flat._version, ver, self._epoch)
         hit = self._packed.get(key)
         if hit is not None and hit[0] == stamp:
             return hit[1], stamp, False

@@ -40,16 +40,40 @@ class GraphedUpdate:
         step_and_repack(self.model, self.oa, self.oc, update_actor=self.update_actor, max_norm=self.max_norm,
                         n_time=self.n_time)
 
+    def _snapshot(self):
+        nets = (self.model.actor_ft, self.model.critic)
+        return ([n.flat_params().clone() for n in nets],
+                [(o.exp_avg.clone(), o.exp_avg_sq.clone(), o._step_dev.clone(), o.step_count) for o in (self.oa, self.oc)])
+
+    def _restore(self, snap):
+        from dppo_amd.model.common.mlp import pack_pair
+        params, opts = snap
+        for n, p in zip((self.model.actor_ft, self.model.critic), params):
+            n.flat_params().copy_(p)
+            n.mark_updated()
+        for o, (m, v, st, cnt) in zip((self.oa, self.oc), opts):
+            o.exp_avg.copy_(m), o.exp_avg_sq.copy_(v), o._step_dev.copy_(st)
+            o.step_count = cnt
+        pack_pair(self.model.critic, 0, self.model.actor_ft,
+                  self.model.denoising_steps if self.n_time is None else self.n_time, self.model.prec)
+
     def _capture(self):
+        # warm-up runs (first-use allocations, kernel attributes, library side streams) are real updates: they run on a
+        # snapshot -- parameters, AdamW moments and step counters are put back afterwards, so the first step() is ONE
+        # optimiser step on its minibatch, like every later one
+        snap = self._snapshot() if self._warmup > 0 else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(self._warmup):  # first-use allocations, kernel attributes, library side streams
+            for _ in range(self._warmup):
                 self._grads()
                 self.dp.allreduce_grads()
                 self._apply()
+            if snap is not None:
+                self._restore(snap)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self._captured_for = (self.update_actor, self.max_norm)
         if self.world == 1:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -73,9 +97,10 @@ class GraphedUpdate:
             self.moments.copy_(global_moments)
         self.oa.sync_lr()
         self.oc.sync_lr()
+        if self._graphs is not None and self._captured_for != (self.update_actor, self.max_norm):
+            self._graphs = None  # e.g. the critic warm-up iterations ended: update_actor is frozen into a capture
         if self._graphs is None:
-            self._capture()  # note: the capture's warm-up runs are real updates on whatever self.inds holds
-            self.inds.copy_(inds)
+            self._capture()
         if len(self._graphs) == 1:
             self._graphs[0].replay()
         else:

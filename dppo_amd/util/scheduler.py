@@ -20,7 +20,9 @@ class CosineAnnealingWarmupRestarts:
         self.step_in_cycle = last_epoch
         self.last_epoch = last_epoch
         self.base_lrs = [min_lr for _ in optimizer.param_groups]
-        self.step()  # the torch base class takes one initial step: step_in_cycle 0, lr = min_lr
+        self.step()  # the torch base class takes one initial step (step_in_cycle 0) ...
+        for group in optimizer.param_groups:  # ... and the reference's init_lr() (:76-80) then sets min_lr, whatever that
+            group["lr"] = min_lr  # step computed (with warmup_steps = 0 it computed max_lr)
 
     def get_lr(self):
         if self.step_in_cycle == -1:

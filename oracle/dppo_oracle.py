@@ -154,7 +154,12 @@ def named_specs(name: str) -> Tuple[NetSpec, NetSpec]:
     """(actor, critic) shapes used by the golden fixtures and parity tests (BASELINE.json configs C2-C4 + variants)."""
     if name == "hopper":
         return hopper_actor_spec(), hopper_critic_spec()
-    if name == "can":  # BASELINE C3: Do=23 Da=7 Ta=8 (cfg/robomimic/finetune/can/ft_ppo_diffusion_mlp.yaml)
+    if name == "can":  # BASELINE C3: Do=23 Da=7 Ta=8; the shipped actor leaves activation_type unset => Mish
+        # (cfg/robomimic/finetune/can/ft_ppo_diffusion_mlp.yaml:93-99, mlp_diffusion.py:184)
+        return (NetSpec("actor", cond_dim=23, mlp_dims=[512, 512, 512], activation="Mish", residual=True,
+                          action_dim=7, horizon_steps=8, time_dim=16),
+                NetSpec("critic", cond_dim=23, mlp_dims=[256, 256, 256], activation="Mish", residual=True))
+    if name == "can_relu":  # the same shapes with a ReLU actor (round 1's "can" fixtures; no shipped cfg)
         return (NetSpec("actor", cond_dim=23, mlp_dims=[512, 512, 512], activation="ReLU", residual=True,
                           action_dim=7, horizon_steps=8, time_dim=16),
                 NetSpec("critic", cond_dim=23, mlp_dims=[256, 256, 256], activation="Mish", residual=True))

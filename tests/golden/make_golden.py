@@ -122,7 +122,7 @@ def g2_forward():
     rs = np.random.RandomState(100)
     out = {}
     for name in ("hopper", "can", "halfcheetah", "furniture_like", "plain_mlp", "kitchen_like", "square_like", "furniture_256", "ln_relu",
-                 "transport", "furniture_one_leg"):
+                 "transport", "furniture_one_leg", "can_relu"):
         a, c = specs(name)
         B = 8
         pa, pc = O.init_params(a, 11), O.init_params(c, 12)
@@ -167,6 +167,11 @@ def g3_g4_chains():
         "furniture_one_leg": ("furniture_one_leg", 3, dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True,
                                                            ddim_steps=5, randn_clip_value=3,
                                                            min_sampling_denoising_std=0.04), False),
+        # appended in round 2 (the RNG stream of the cases above is unchanged)
+        "ddpm100_can_relu": ("can_relu", 4, dict(denoising_steps=100, ft_denoising_steps=10, randn_clip_value=3,
+                                                 min_sampling_denoising_std=0.08), False),
+        "ddpm20_halfcheetah": ("halfcheetah", 6, dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3),
+                               False),  # BASELINE C4 as shipped: cfg/gym/finetune/halfcheetah-v2/ft_ppo_diffusion_mlp.yaml:16-22
     }
     out = {}
     rs = np.random.RandomState(200)
@@ -211,6 +216,10 @@ def g5_loss():
         "furniture_one_leg": ("furniture_one_leg", dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True,
                                                         ddim_steps=5, clip_ploss_coef=0.001, clip_ploss_coef_base=0.001,
                                                         min_sampling_denoising_std=0.04), 8),
+        # appended in round 2
+        "can_relu_k100": ("can_relu", dict(denoising_steps=100, ft_denoising_steps=10, clip_ploss_coef=0.01), 4),
+        "halfcheetah": ("halfcheetah", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01,
+                                            clip_ploss_coef_base=0.01), 4),  # C4 as shipped (:77-80)
     }
     out = {}
     rs = np.random.RandomState(300)
@@ -297,7 +306,7 @@ def g8_bc():
 
 # ---------------------------------------------------------------- G9 supervised denoising loss (pre-training)
 MSE_CASES = {"mse_hopper": ("hopper", 20), "mse_can_k100": ("can", 100), "mse_square_like": ("square_like", 20),
-             "mse_ln_relu": ("ln_relu", 20)}
+             "mse_ln_relu": ("ln_relu", 20), "mse_can_relu_k100": ("can_relu", 100)}
 
 
 def g9_denoise_mse():
@@ -365,8 +374,30 @@ def g7_adamw():
     save("g7_adamw", **out)
 
 
+# ---------------------------------------------------------------- G10 LR schedule trace
+from make_golden_cases import SCHED_CASES  # noqa: E402
+
+
+def g10_scheduler():
+    """Learning rate after construction and after every step() of the reference's CosineAnnealingWarmupRestarts
+    (util/scheduler.py:32-147) driving a torch.optim.AdamW, as the agents use it (step() without an epoch)."""
+    from dppo.util.scheduler import CosineAnnealingWarmupRestarts
+    out = {}
+    for name, (kw, n, lr0) in SCHED_CASES.items():
+        p = torch.nn.Parameter(torch.zeros(3))
+        opt = torch.optim.AdamW([p], lr=lr0)
+        sch = CosineAnnealingWarmupRestarts(opt, **kw)
+        trace = [opt.param_groups[0]["lr"]]
+        for _ in range(n):
+            opt.step()
+            sch.step()
+            trace.append(opt.param_groups[0]["lr"])
+        out[name] = np.array(trace, dtype=np.float64)
+    save("g10_scheduler", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]  # e.g. `make_golden.py g8_bc` regenerates one file (each generator owns its RNG stream)
-    for fn in (g1_tables, g2_forward, g3_g4_chains, g5_loss, g6_reward_scaler, g7_adamw, g8_bc, g9_denoise_mse):
+    for fn in (g1_tables, g2_forward, g3_g4_chains, g5_loss, g6_reward_scaler, g7_adamw, g8_bc, g9_denoise_mse, g10_scheduler):
         if not only or fn.__name__ in only:
             fn()

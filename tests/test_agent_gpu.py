@@ -110,9 +110,13 @@ def test_agent_runs_and_learns_something(tmp_path, monkeypatch, groups):
                        agent.model.actor_ft.mlp_mean.layers[0].weight.detach().cpu())
 
 
-def test_graph_replayed_update_equals_eager_update():
-    """dppo_amd.util.graphed.GraphedUpdate: three minibatch updates replayed from captured hipGraphs leave the same
-    parameters and statistics as the same three updates issued launch by launch (device-resident AdamW step / lr)."""
+@pytest.mark.parametrize("warmup", [0, 2])
+def test_graph_replayed_update_equals_eager_update(warmup):
+    """dppo_amd.util.graphed.GraphedUpdate: minibatch updates replayed from captured hipGraphs leave the same
+    parameters and statistics as the same updates issued launch by launch (device-resident AdamW step / lr).
+    warmup = 0: the first two steps are issued eagerly by the test and the capture follows them; warmup = 2 (the
+    default): the helper's own warm-up updates run on a snapshot that is put back, so the first step() already is exactly
+    one optimiser step."""
     import copy
 
     import bench
@@ -131,11 +135,11 @@ def test_graph_replayed_update_equals_eager_update():
         m = copy.deepcopy(m0)
         oa = FlatAdamW(m.actor_ft.flat_params(), lr=1e-4, weight_decay=0.0)
         oc = FlatAdamW(m.critic.flat_params(), lr=1e-3, weight_decay=0.0)
-        g = GraphedUpdate(m, oa, oc, DataParallel(m, 1), ro, N, bench.ACT_STEPS, n_time=bench.K, warmup=0) if graphed else None
+        g = GraphedUpdate(m, oa, oc, DataParallel(m, 1), ro, N, bench.ACT_STEPS, n_time=bench.K, warmup=warmup) if graphed else None
         for i, inds in enumerate(mbs):
             if i == 3:  # an LR scheduler steps between iterations
                 oa.param_groups[0]["lr"] = 5e-5
-            if graphed and i >= 2:  # the first two steps are the helper's eager warm-up on these very minibatches
+            if graphed and (i >= 2 or warmup > 0):  # warmup = 0: the first two steps are eager warm-up on these minibatches
                 g.step(inds)
             else:
                 if graphed:
@@ -181,3 +185,57 @@ def test_collected_rollout_is_consistent_on_the_device():
             traj = chains_buf[rows, -1].reshape(n, bench.TA, bench.ACT_DIM)[:, :bench.ACT_STEPS]
             np.testing.assert_array_equal(traj.cpu().numpy(), action)
     np.testing.assert_array_equal(last["state"][:n], groups[0]._obs()["state"])
+
+
+def test_torch_optimizer_steps_and_load_state_dict_refresh_the_kernel_images():
+    """The drop-in path of INTEGRATION.md: ``model.loss(...)``, ``loss.backward()``, ``torch.optim.AdamW(model.actor_ft
+    .parameters())``.  The Parameters are views of the flat buffer, so torch writes through them without the flat
+    tensor's version moving: the packed kernel images must still be rebuilt.  Two such steps must (1) change the
+    log-probs, (2) land where two FlatAdamW steps on a twin land; and a ``load_state_dict`` after a forward must change
+    what the sampler and the critic compute."""
+    from dppo_amd.util.optim import FlatAdamW
+    from tests.test_hip_parity import DEV, build_model
+    kw = dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01, randn_clip_value=3)
+    m, a, c = build_model("hopper", kw, 5, "fp32")
+    twin, _, _ = build_model("hopper", kw, 5, "fp32")
+    N, Kft = 64, 10
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    state = (torch.rand(N, 1, a.cond_dim, generator=gen) * 2 - 1).to(DEV)
+    noise = torch.randn(21, N, a.horizon_steps, a.action_dim, generator=gen).to(DEV)
+    chains = m(cond={"state": state}, noise=noise).chains
+    kinds = torch.randint(0, Kft, (N,), generator=gen).to(DEV)
+    rows = torch.arange(N, device=DEV)
+    prev, nxt = chains[rows, kinds], chains[rows, kinds + 1]
+    lp0 = m.get_logprobs_subsample({"state": state}, prev, nxt, kinds).clone()
+    v0 = m.critic({"state": state}).clone()
+    ret, adv = torch.randn(N, generator=gen).to(DEV), torch.randn(N, generator=gen).to(DEV)
+    oldlp = lp0 + 0.01
+    opt_a = torch.optim.AdamW(m.actor_ft.parameters(), lr=1e-3, weight_decay=0.0)
+    opt_c = torch.optim.AdamW(m.critic.parameters(), lr=1e-3, weight_decay=0.0)
+    fa = FlatAdamW(twin.actor_ft.flat_params(), lr=1e-3, weight_decay=0.0)
+    fc = FlatAdamW(twin.critic.flat_params(), lr=1e-3, weight_decay=0.0)
+    lps = [lp0]
+    for _ in range(2):
+        res = m.loss({"state": state}, prev, nxt, kinds, ret, v0.reshape(-1), adv, oldlp)
+        opt_a.zero_grad(), opt_c.zero_grad()
+        (res[0] + res[2]).backward()
+        opt_a.step(), opt_c.step()
+        lps.append(m.get_logprobs_subsample({"state": state}, prev, nxt, kinds).clone())
+        twin.loss({"state": state}, prev, nxt, kinds, ret, v0.reshape(-1), adv, oldlp)
+        fa.step(twin.actor_ft.flat_grads()), fc.step(twin.critic.flat_grads())
+        twin.actor_ft.mark_updated(), twin.critic.mark_updated()
+    assert (lps[1] - lps[0]).abs().max().item() > 1e-4 and (lps[2] - lps[1]).abs().max().item() > 1e-4
+    assert (m.critic({"state": state}) - v0).abs().max().item() > 1e-4
+    assert torch.allclose(m.actor_ft.flat_params(), twin.actor_ft.flat_params(), rtol=1e-5, atol=1e-7)
+    lp_twin = twin.get_logprobs_subsample({"state": state}, prev, nxt, kinds)
+    assert torch.allclose(lps[2], lp_twin, rtol=1e-4, atol=1e-4)
+    # load_state_dict after forwards: the next forward runs on the loaded weights
+    before = m(cond={"state": state}, noise=noise).chains.clone()
+    sd = {k: v.clone() for k, v in twin.state_dict().items()}
+    for k in sd:
+        if k.startswith("actor_ft.mlp_mean.layers.0") or k.startswith("critic.Q1.layers.0"):
+            sd[k] = sd[k] * 1.5
+    m.load_state_dict(sd)
+    after = m(cond={"state": state}, noise=noise).chains
+    assert (after - before).abs().max().item() > 1e-3
+    assert (m.critic({"state": state}) - twin.critic({"state": state})).abs().max().item() > 1e-4

@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 
 T = torch.from_numpy
 DEV = "cuda:0"
-HIP_SUPPORTED = {"hopper", "can", "halfcheetah", "kitchen_like", "square_like", "furniture_256", "ln_relu",
+HIP_SUPPORTED = {"hopper", "can", "can_relu", "halfcheetah", "kitchen_like", "square_like", "furniture_256", "ln_relu",
                  "transport", "furniture_one_leg"}  # plain (non-residual) MLPs: "next" row
 
 
@@ -59,8 +59,8 @@ def test_library_loads_and_versions():
 
 # ------------------------------------------------------------------ G2 network forwards
 @pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16", 3e-2)])
-@pytest.mark.parametrize("name", ["hopper", "can", "halfcheetah", "kitchen_like", "square_like", "furniture_256", "ln_relu",
-                                  "transport", "furniture_one_leg"])
+@pytest.mark.parametrize("name", ["hopper", "can", "can_relu", "halfcheetah", "kitchen_like", "square_like", "furniture_256",
+                                  "ln_relu", "transport", "furniture_one_leg"])
 def test_network_forward(golden, name, prec, tol):
     from dppo_amd.model.common.critic import CriticObs
     from dppo_amd.model.diffusion.mlp_diffusion import DiffusionMLP
@@ -505,7 +505,7 @@ def test_loss_with_bc_term_hands_gradients_to_autograd():
 
 
 # ------------------------------------------------------------------ fused row-tile kernels vs layered GEMM chain
-@pytest.mark.parametrize("case", ["mse_hopper", "mse_can_k100", "mse_square_like", "mse_ln_relu"])
+@pytest.mark.parametrize("case", ["mse_hopper", "mse_can_k100", "mse_can_relu_k100", "mse_square_like", "mse_ln_relu"])
 def test_denoise_mse_loss_and_gradients(golden, case):
     """DiffusionModel.p_losses (pre-training loss, reference diffusion.py:325-363) through dppo_denoise_mse_fwd_bwd:
     fp32 against the reference's golden loss and gradients; bf16 against the fp32 result (loss 2e-2, cosine 0.99)."""

@@ -44,7 +44,7 @@ def test_survey_check_values():
 
 # ------------------------------------------------------------------ G2
 @pytest.mark.parametrize("name", ["hopper", "can", "halfcheetah", "furniture_like", "plain_mlp", "kitchen_like", "square_like", "furniture_256", "ln_relu",
-                                  "transport", "furniture_one_leg"])
+                                  "transport", "furniture_one_leg", "can_relu"])
 def test_network_forward(golden, name):
     g = golden("g2_forward")
     a, c = O.named_specs(name)
@@ -85,6 +85,9 @@ CHAIN_CASES = {
                                     min_sampling_denoising_std=0.1, min_logprob_denoising_std=0.1), False),
     "furniture_one_leg": ("furniture_one_leg", dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
                                                     randn_clip_value=3, min_sampling_denoising_std=0.04), False),
+    "ddpm100_can_relu": ("can_relu", dict(denoising_steps=100, ft_denoising_steps=10, randn_clip_value=3,
+                                          min_sampling_denoising_std=0.08), False),
+    "ddpm20_halfcheetah": ("halfcheetah", dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3), False),
 }
 
 
@@ -136,6 +139,9 @@ LOSS_CASES = {
     "furniture_one_leg": ("furniture_one_leg", dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
                                                     clip_ploss_coef=0.001, clip_ploss_coef_base=0.001,
                                                     min_sampling_denoising_std=0.04)),
+    "can_relu_k100": ("can_relu", dict(denoising_steps=100, ft_denoising_steps=10, clip_ploss_coef=0.01)),
+    "halfcheetah": ("halfcheetah", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01,
+                                        clip_ploss_coef_base=0.01)),
 }
 
 
@@ -257,7 +263,7 @@ def test_bc_loss_matches_reference(golden, case):
 
 # ------------------------------------------------------------------ G9 supervised denoising loss (pre-training)
 MSE_CASES = {"mse_hopper": ("hopper", 20), "mse_can_k100": ("can", 100), "mse_square_like": ("square_like", 20),
-             "mse_ln_relu": ("ln_relu", 20)}
+             "mse_ln_relu": ("ln_relu", 20), "mse_can_relu_k100": ("can_relu", 100)}
 
 
 @pytest.mark.parametrize("case", sorted(MSE_CASES))
