@@ -18,9 +18,16 @@ Synthetic data (seed 42): random-init networks of the ref
 N(0,1) noise clipped at +-3, the rollout buffer is the sampler's own chains over 500 obs batches, rewards ~ N(0,1),
 terminated ~ Bernoulli(0.002), values from the random critic.
 
-The line also carries `roofline` (dominant kernel: the 128x128-tile bf16 MFMA GEMM on the 512x512 hidden layers,
-timed live with HIP events on its launch stream) and `cpu_baseline` (the CPU oracle = op-for-op restatement of the
-reference's PyTorch path, timed on this box's host cores on a bounded sample).
+The line also carries
+  `roofline`     SURVEY.md 8(d)'s figure: the update path's algorithmic FLOP rate (samples/s x 4.11 MFLOP) against the
+                 dense MFMA peak of the operand dtype, the sampler's (chunks/s x 22.06 MFLOP) beside it, and as
+                 `dominant_kernel` the largest kernel of the step (`gemm_tn_group_kernel`: every weight gradient of one
+                 network's backward pass in one launch) timed live with HIP events on its launch stream: its operand
+                 bytes per second against the HBM peak and its own MFMA fraction;
+  `fp32`         the same two legs with fp32 operands (the reference's arithmetic), secondary;
+  `allreduce_ms` the gradient bucket's all-reduce alone (N > 1), so an N-GPU run reads as compute + collective;
+  `cpu_baseline` the CPU oracle = op-for-op restatement of the reference's PyTorch path, timed on this box's host
+                 cores on a bounded sample.
 """
 import argparse
 import ctypes as C
@@ -163,14 +170,16 @@ def main():
     ap.add_argument("--n-steps", type=int, default=500, help="rollout length behind the update buffer")
     ap.add_argument("--batch", type=int, default=50000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the secondary fp32 (the reference's own precision) pass")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu rehearses the data-parallel path with several ranks on ONE GPU")
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     ap.add_argument("--probe", type=int, default=2,
-                    help="kernel timed live for `roofline`: 2 gemm_tn (weight grads), 3 fused fwd, 4 fused bwd, 5 sampler")
+                    help="kernel timed live for `roofline.dominant_kernel`: 2 gemm_tn (weight grads), 3 fused fwd, "
+                         "4 fused bwd, 5 sampler")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the update step as captured hipGraphs (dppo_amd.util.graphed) instead of issuing its ~38 "
-                         "launches one by one; pays at small minibatches, not at this workload (0.69 vs 0.65 ms)")
+                    help="replay the update step as captured hipGraphs (dppo_amd.util.graphed) instead of issuing its "
+                         "launches one by one; pays at small minibatches, not at this workload")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
                     help="dppo_tune_set knob (include/dppo_hip.h), e.g. 2=0: critic half on the main stream (serial kernels)")
     args = ap.parse_args()
@@ -192,85 +201,101 @@ def main():
     torch.cuda.set_device(device)
     from dppo_amd import hip
     from dppo_amd.parallel import DataParallel
+    from dppo_amd.util.graphed import GraphedUpdate
     from dppo_amd.util.optim import FlatAdamW, step_and_repack
     lib = hip.load()
     for kv in args.tune:
         k, v = kv.split("=")
         hip.check(lib.dppo_tune_set(int(k), int(v)), "dppo_tune_set")
-
-    model = build_model(str(device), args.prec)  # same seed on every rank => identical initial weights
-    gen = torch.Generator(device=device).manual_seed(42 + rank)  # env shards differ per rank
-    torch.manual_seed(42 + rank)
-    dp = DataParallel(model, world)
-    obs_k, chains_k, ret_k, val_k, adv_k, logp_k = make_rollout(model, args.n_envs, args.n_steps, device, gen)
-    R = args.n_envs * args.n_steps
-    opt_a = FlatAdamW(model.actor_ft.flat_params(), lr=1e-4, weight_decay=0.0)
-    opt_c = FlatAdamW(model.critic.flat_params(), lr=1e-3, weight_decay=0.0)
     n_total = args.steps + args.warmup
-    perm = torch.randperm(R * KFT, device=device, generator=gen)
-    n_mb = (R * KFT) // args.batch
-    minibatches = [perm[(i % n_mb) * args.batch:(i % n_mb + 1) * args.batch].contiguous() for i in range(n_total)]
-    moments = dp.minibatch_moments(adv_k, minibatches, KFT)  # ONE small collective for all steps (None if world == 1)
-    obs_batches = [torch.rand(args.n_envs, 1, OBS_DIM, device=device, generator=gen) * 2 - 1 for _ in range(4)]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    from dppo_amd.util.graphed import GraphedUpdate
-    graphed = None
-    if args.graph:
-        graphed = GraphedUpdate(model, opt_a, opt_c, dp, (obs_k, chains_k, ret_k, val_k, adv_k, logp_k), args.batch,
-                                ACT_STEPS, n_time=K)
-
-    eager = [False]  # the roofline pass issues the launches one by one (per-launch HIP events cannot be captured)
-
-    def update_step(i):
-        if graphed is not None and not eager[0]:  # same work as below, launched as hipGraph replays (captured in warm-up)
-            graphed.step(minibatches[i], None if moments is None else moments[i])
-            return
-        model.ppo_update(obs_k, chains_k, ret_k, val_k, adv_k, logp_k, minibatches[i], reward_horizon=ACT_STEPS,
-                         global_moments=None if moments is None else moments[i])
-        dp.allreduce_grads()  # one RCCL all-reduce of [actor grads | critic grads | stats]; no-op when world == 1
-        # 2 x AdamW, then re-pack so the next sampling / update call sees the new weights (part of the step's cost)
-        step_and_repack(model, opt_a, opt_c, n_time=K)
-
-    def sample_step(i):
-        return model(cond={"state": obs_batches[i % 4]}, deterministic=False, return_chain=True)
-
-    def timed(fn, probe=False):
-        for i in range(args.warmup):
-            fn(i)
-        barrier()
-        if probe:
-            hip.check(lib.dppo_probe_arm(args.probe, 16 * args.steps), "dppo_probe_arm")
-        t0 = time.perf_counter()
-        for i in range(args.warmup, n_total):
-            fn(i)
-        barrier()
-        dt = time.perf_counter() - t0
+    def max_over_ranks(dt):
         if world > 1:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
 
-    dt_sample = timed(sample_step, probe=(rank == 0 and args.probe == 5))
-    dt_update = timed(update_step)
-    # Roofline pass: the same K update steps once more with the library's side streams off (knob 2 = 0).  In the timed
-    # region above the critic half and the gradient tails run beside the probed kernel, so an event-bracketed launch
-    # duration there includes its co-runners' share of the chip; serial, it is the kernel's own (rocprofv3 on
-    # `bench.py --tune 2=0` reports the same average).  `value` always comes from the default (overlapped) pass.
-    dt_serial = None
-    if args.probe != 5:
-        overlap = next((int(kv.split("=")[1]) for kv in args.tune if kv.split("=")[0] == "2"), 1)
-        hip.check(lib.dppo_tune_set(2, 0), "dppo_tune_set")
-        eager[0] = True
-        dt_serial = timed(update_step, probe=(rank == 0))
-        eager[0] = False
-        hip.check(lib.dppo_tune_set(2, overlap), "dppo_tune_set")
-    probe = None
+    def run_path(prec, nranks, probe_id):
+        """Both legs of a step at one operand precision: `steps` sampling calls and `steps` update steps, each timed
+        between barriers (+ the serial roofline pass of the update when `probe_id` is set).  nranks = 1 runs the path
+        rank-locally (no collective): the secondary fp32 pass."""
+        model = build_model(str(device), prec)  # same seed on every rank => identical initial weights
+        gen = torch.Generator(device=device).manual_seed(42 + rank)  # env shards differ per rank
+        torch.manual_seed(42 + rank)
+        dp = DataParallel(model, nranks)
+        ro = make_rollout(model, args.n_envs, args.n_steps, device, gen)
+        adv_k = ro[4]
+        R = args.n_envs * args.n_steps
+        opt_a = FlatAdamW(model.actor_ft.flat_params(), lr=1e-4, weight_decay=0.0)
+        opt_c = FlatAdamW(model.critic.flat_params(), lr=1e-3, weight_decay=0.0)
+        perm = torch.randperm(R * KFT, device=device, generator=gen)
+        n_mb = (R * KFT) // args.batch
+        minibatches = [perm[(i % n_mb) * args.batch:(i % n_mb + 1) * args.batch].contiguous() for i in range(n_total)]
+        moments = dp.minibatch_moments(adv_k, minibatches, KFT)  # ONE small collective for all steps (None if 1 rank)
+        obs_batches = [torch.rand(args.n_envs, 1, OBS_DIM, device=device, generator=gen) * 2 - 1 for _ in range(4)]
+        graphed = GraphedUpdate(model, opt_a, opt_c, dp, ro, args.batch, ACT_STEPS, n_time=K) if args.graph else None
+        eager = [False]  # the roofline pass issues the launches one by one (per-launch HIP events cannot be captured)
+
+        def update_step(i):
+            if graphed is not None and not eager[0]:  # same work as below, launched as hipGraph replays
+                graphed.step(minibatches[i], None if moments is None else moments[i])
+                return
+            model.ppo_update(*ro, minibatches[i], reward_horizon=ACT_STEPS,
+                             global_moments=None if moments is None else moments[i])
+            dp.allreduce_grads()  # one RCCL all-reduce of [actor grads | critic grads | stats]; no-op with one rank
+            # 2 x AdamW, then re-pack so the next sampling / update call sees the new weights (part of the step's cost)
+            step_and_repack(model, opt_a, opt_c, n_time=K)
+
+        def sample_step(i):
+            return model(cond={"state": obs_batches[i % 4]}, deterministic=False, return_chain=True)
+
+        def allreduce_only(i):
+            dp.allreduce_grads()
+
+        def timed(fn, probe=False):
+            for i in range(args.warmup):
+                fn(i)
+            barrier()
+            if probe:
+                hip.check(lib.dppo_probe_arm(probe_id, 16 * args.steps), "dppo_probe_arm")
+            t0 = time.perf_counter()
+            for i in range(args.warmup, n_total):
+                fn(i)
+            barrier()
+            return max_over_ranks(time.perf_counter() - t0)
+
+        r = {"model": model, "prec": prec}
+        r["dt_sample"] = timed(sample_step, probe=(rank == 0 and probe_id == 5))
+        r["dt_update"] = timed(update_step)
+        # the collective alone, same bucket, same `steps`: lets an N-GPU run be read as compute + all-reduce
+        r["dt_allreduce"] = timed(allreduce_only) if nranks > 1 else None
+        # Roofline pass: the same update steps once more with the library's side streams off (knob 2 = 0).  In the timed
+        # region above the critic half and the gradient tails run beside the probed kernel, so an event-bracketed launch
+        # duration there includes its co-runners' share of the chip; serial, it is the kernel's own (rocprofv3 on
+        # `bench.py --tune 2=0` reports the same average).  `value` always comes from the default (overlapped) pass.
+        r["dt_serial"] = None
+        if probe_id not in (None, 5):
+            overlap = next((int(kv.split("=")[1]) for kv in args.tune if kv.split("=")[0] == "2"), 1)
+            hip.check(lib.dppo_tune_set(2, 0), "dppo_tune_set")
+            eager[0] = True
+            r["dt_serial"] = timed(update_step, probe=(rank == 0))
+            eager[0] = False
+            hip.check(lib.dppo_tune_set(2, overlap), "dppo_tune_set")
+        r["stats"] = model._stats.tolist()
+        r["graphed"] = graphed is not None
+        return r
+
+    main_run = run_path(args.prec, world, args.probe)
+    model = main_run["model"]
+    dt_sample, dt_update, dt_serial = main_run["dt_sample"], main_run["dt_update"], main_run["dt_serial"]
+
+    kernel_probe = None  # the dominant kernel of the update, timed live with HIP events on its launch stream
     if rank == 0:
         ms, cnt, fl, nb_lib = C.c_double(), C.c_int(), C.c_double(), C.c_double()
         hip.check(lib.dppo_probe_collect_bytes(C.byref(ms), C.byref(cnt), C.byref(fl), C.byref(nb_lib)),
@@ -289,54 +314,75 @@ def main():
             tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_probe{args.probe}{'g' if grouped else ''}_{args.prec}.json")
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            probe = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
-                     "traffic": traffic, "kernel": f"{names[args.probe]}, {args.prec}", "avg_launch_ms": avg_ms,
-                     "launches": cnt.value, "algorithmic_gflop_per_launch": fl.value / cnt.value / 1e9,
-                     "measured": "HIP events around every launch of the kernel" + (
-                         "" if dt_serial is None else
-                         f", in a second pass of the same {args.steps} steps with side streams off "
-                         f"({dt_serial / args.steps * 1e3:.3f} ms per step)")}
+            kernel_probe = {"kernel": f"{names[args.probe]}, {args.prec}", "avg_launch_ms": avg_ms, "launches": cnt.value,
+                            "algorithmic_gflop_per_launch": fl.value / cnt.value / 1e9, "mfma_tflops": tf,
+                            "mfma_frac": tf / peak, "traffic": traffic,
+                            "measured": "HIP events around every launch of the kernel" + (
+                                "" if dt_serial is None else
+                                f", in a second pass of the same {args.steps} steps with side streams off "
+                                f"({dt_serial / args.steps * 1e3:.3f} ms per step)")}
             if args.probe == 2:
-                # dW[N1 x N2] = A[M x N1]^T . B[M x N2]: algorithmic bytes = both operands once + the fp32 result.
-                # 253 (512^2) / 128 (256^2) FLOP per byte at bf16 against a machine balance of 2500 / 8 = 312: the
-                # contraction over 50,000 batch rows is HBM-bound, so that is the roof it is priced against.
+                # dW[N1 x N2] = A[M x N1]^T . B[M x N2]: bytes = both operands once + the fp32 result (per GEMM of the
+                # group, counted by the library at launch).  Intermediate ACTIVATION bytes, not SURVEY 8(d)'s algorithmic
+                # bytes of the update (13 MB): this sub-entry says how well the launch streams what it has to read, the
+                # top-level `frac` says what the path achieves.
                 es = 2 if args.prec == "bf16" else 4
                 shapes = [(model.actor_ft.mlp_mean.hidden, model.actor_ft.mlp_mean.n_blocks),
                           (model.critic.Q1.hidden, model.critic.Q1.n_blocks)]
                 nbytes = sum(2 * nb * (args.batch * 2 * h * es + h * h * 4) for h, nb in shapes)
-                nlaunch = sum(2 * nb for _, nb in shapes)
-                b_per = nbytes / nlaunch
-                if grouped:  # the library's own count: per GEMM of the group, M (N1 + N2) elements + N1 N2 floats
-                    b_per = nb_lib.value / cnt.value
-                intensity = (fl.value / cnt.value) / b_per
-                if intensity < peak * 1e12 / (HBM_PEAK_GBS * 1e9):
-                    gbs = b_per / (avg_ms * 1e-3) / 1e9
-                    probe.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": gbs / HBM_PEAK_GBS, "algorithmic_mb_per_launch": b_per / 1e6,
-                                  "flop_per_byte": intensity, "mfma_tflops": tf, "mfma_frac": tf / peak})
-    stats = model._stats.tolist()
+                b_per = nb_lib.value / cnt.value if grouped else nbytes / sum(2 * nb for _, nb in shapes)
+                gbs = b_per / (avg_ms * 1e-3) / 1e9
+                kernel_probe.update({"operand_mb_per_launch": b_per / 1e6, "operand_gb_per_s": gbs,
+                                     "hbm_frac": gbs / HBM_PEAK_GBS, "flop_per_operand_byte": (fl.value / cnt.value) / b_per})
+
+    fp32_run = None
+    if world == 1 and args.prec != "fp32" and not args.no_fp32:  # the reference's own arithmetic, same steps, same shapes
+        fp32_run = run_path("fp32", 1, None)
+        del fp32_run["model"]
+        torch.cuda.empty_cache()
+
+    stats = main_run["stats"]
     if rank == 0:
         ms_update = dt_update / args.steps * 1e3
         ms_sample = dt_sample / args.steps * 1e3
         samples_per_s = args.batch * world / (dt_update / args.steps)
-        env_steps_per_s = args.n_envs * ACT_STEPS * world / (dt_sample / args.steps)
-        peak = MFMA_PEAK_TFLOPS[args.prec] * 1e12 * world
+        chunks_per_s = args.n_envs * world / (dt_sample / args.steps)
+        env_steps_per_s = chunks_per_s * ACT_STEPS
+        peak_tf = MFMA_PEAK_TFLOPS[args.prec] * world
+        upd_tf, smp_tf = samples_per_s * FLOP_PER_SAMPLE / 1e12, chunks_per_s * FLOP_PER_CHUNK / 1e12
+        # the path is MFMA-bound (20 kFLOP per algorithmic byte); achieved = units/s x algorithmic FLOP per
+        # unit (necessary network evaluations only), priced against the dense MFMA peak of the operand dtype.
+        roofline = {"bound": "mfma", "achieved": upd_tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": upd_tf / peak_tf,
+                    "traffic": None if kernel_probe is None else kernel_probe["traffic"],
+                    "what": "PPO update path: samples/s x 4.11 MFLOP per sample (SURVEY 8d) / dense MFMA peak of the dtype",
+                    "sampler": {"achieved": smp_tf, "frac": smp_tf / peak_tf,
+                                "what": "chunks/s x 22.06 MFLOP per action chunk / the same peak"},
+                    "dominant_kernel": kernel_probe,
+                    "traffic_is": "HBM bytes per launch of dominant_kernel (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"}
         out = {
             "metric": "PPO-update samples/sec (+ env-steps/sec of the K=20 sampler), hopper K=20 n_envs=512",
             "value": samples_per_s, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_update, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.prec, "data": "synthetic",
-            "launch": "eager" if graphed is None else "hipGraph replay of the update step (captured once in warm-up)",
+            "launch": "hipGraph replay of the update step (captured once in warm-up)" if main_run["graphed"] else "eager",
             "config": {"workload": "hopper-medium-v2 ft_ppo_diffusion_mlp K=20 Kft=10 Ta=4 (BASELINE configs[1])",
                        "n_envs_per_gpu": args.n_envs, "minibatch_per_gpu": args.batch,
-                       "rollout_rows_per_gpu": R, "parallelism": f"dp{world} (env-sharded, RCCL grad all-reduce)"},
-            "env_steps_per_sec": env_steps_per_s, "sampler_ms_per_call": ms_sample,
-            "chunks_per_sec": args.n_envs * world / (dt_sample / args.steps),
-            "path_mfma_frac": {"update": samples_per_s * FLOP_PER_SAMPLE / peak,
-                               "sampler": args.n_envs * world / (dt_sample / args.steps) * FLOP_PER_CHUNK / peak},
+                       "rollout_rows_per_gpu": args.n_envs * args.n_steps,
+                       "parallelism": f"dp{world} (env-sharded, RCCL grad all-reduce)"},
+            "env_steps_per_sec": env_steps_per_s, "sampler_ms_per_call": ms_sample, "chunks_per_sec": chunks_per_s,
+            "allreduce_ms": None if main_run["dt_allreduce"] is None else main_run["dt_allreduce"] / args.steps * 1e3,
             "last_stats": {"pg_loss": stats[0], "v_loss": stats[1], "approx_kl": stats[2], "ratio": stats[4]},
-            "roofline": probe,
+            "roofline": roofline,
         }
+        if fp32_run is not None:
+            f_sps = args.batch / (fp32_run["dt_update"] / args.steps)
+            f_cps = args.n_envs / (fp32_run["dt_sample"] / args.steps)
+            out["fp32"] = {"what": "the same two legs with fp32 MFMA operands (the reference's own arithmetic); secondary",
+                           "samples_per_sec": f_sps, "ms_per_step": fp32_run["dt_update"] / args.steps * 1e3,
+                           "env_steps_per_sec": f_cps * ACT_STEPS, "sampler_ms_per_call": fp32_run["dt_sample"] / args.steps * 1e3,
+                           "peak_tflops": MFMA_PEAK_TFLOPS["fp32"],
+                           "update_frac": f_sps * FLOP_PER_SAMPLE / 1e12 / MFMA_PEAK_TFLOPS["fp32"],
+                           "sampler_frac": f_cps * FLOP_PER_CHUNK / 1e12 / MFMA_PEAK_TFLOPS["fp32"]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.n_envs, args.batch)
         print(json.dumps(out), flush=True)

@@ -1,23 +1,25 @@
 """The BENCHMARKED precision (bf16 MFMA operands, fp32 accumulation, fp32 loss epilogue) against the reference's golden
 vectors and the CPU oracle with ratio != 1 -- the stated tolerances of the bf16 path.
 
-What bf16 can and cannot hold.  The network output eps carries a relative error of ~2^-8 per operand rounding; the
-log-prob of one action element amplifies d mu by z / sigma (up to 30 at sigma = 0.1), so a sample's new log-prob (mean
-over Ta x Da elements) is off by ~1e-2 from the fp32 reference, i.e. AS MUCH AS the clip range eps_k in [1e-3, 1e-2] of the
-shipped cfgs.  Consequences, measured over all G5 cases (profiles/r02_bf16_parity.txt, regenerated by
-``python tools/bf16_parity_report.py``):
-  * v_loss, entropy/eta, bc_loss: the critic / BC terms have no such amplification -> relative 2e-2;
-  * ratio (mean), pg_loss: absolute 2e-2 / 4e-2-class (an error of 1e-2 in log-ratio times |A| ~ 1);
-  * approx_kl = mean((r - 1) - log r) ~ 0.5 var(log r): the fp32 value is ~2e-5 (old log-probs = new + N(0, 0.02) / 12
-    elements), the bf16 error variance adds ~1e-4: kl is held to an ABSOLUTE 2e-3, not relatively;
-  * clipfrac: |r - 1| > eps_k flips for any sample whose log-ratio error exceeds eps_k: NOT held (difference up to 0.6);
-    it is a diagnostic in the reference too (logged, never used in the update);
-  * gradients: direction and size -- per-network cosine >= 0.98 and norm within 15 % for the actor (the clipped surrogate's
-    branch pattern differs), cosine >= 0.995 and 5 % for the critic.
+Measured over all 14 G5 loss cases and both G8 cases (profiles/r02_bf16_parity.txt, regenerated on an MI355X by
+``python tools/bf16_parity_report.py``; N = 64 samples per case, fp32 path beside it), worst case -> tolerance held here:
+  pg_loss      |d| 2.8e-5   -> 1e-4 abs          v_loss   rel 4.1e-4 -> 2e-3
+  approx_kl    |d| 2.7e-7   -> 2e-6 abs          ratio    |d| 5.6e-5 -> 2e-4 abs        entropy / eta: exact (a constant)
+  bc_loss      rel 9.2e-4   -> 5e-3              BC gradient: per-tensor cosine >= 0.999, norm 3e-4 -> 2e-3
+  gradients, cases where no sample changes its surrogate branch (10 of 14): every tensor's cosine >= 0.997 -> 0.995,
+               network gradient norm within 2.1e-3 -> 1e-2
+  clipfrac and the gradient when samples DO change branch: a sample whose |ratio - 1| lies within the bf16 error of its
+               log-ratio (<= 1e-3) of the clip bound eps_k takes the other branch of max(-A r, -A clip(r)), and its whole
+               gradient contribution appears or vanishes.  With eps_k = 1e-3 (the furniture cfgs: clip_ploss_coef 0.001)
+               that is 2-4 of 64 samples: clipfrac differs by <= 0.0625, the actor gradient by up to 27 % in norm and
+               0.59 in the worst tensor's cosine (furniture_256); ln_relu 2 flips (0.954 / 4.7 %), furniture_one_leg 3 (0.983),
+               transport 1 (0.9998).  This is the ONE statistic bf16 cannot hold to a useful tolerance on those cfgs; the
+               reference logs clipfrac and never uses it, and `precision: fp32` is there for a run that must reproduce
+               the branch pattern.  Held here: tensor cosine >= 0.5, norm within 35 %, clipfrac within 0.1.
 What IS exact in bf16: the loss epilogue itself.  With old log-probs = the bf16 path's OWN log-probs + a recorded
 perturbation d, the log-ratio is -mean(d) bit for bit, so pg_loss / approx_kl / clipfrac / ratio have a closed form in
-float64 numpy: ``test_loss_epilogue_closed_form_with_ratio_ne_1`` holds the kernel to it at N = 50,000 (1e-6-class), and
-``test_minibatch_of_50000_matches_oracle_bf16`` is the bf16 twin of the fp32 oracle test with the tolerances above.
+float64 numpy: ``test_loss_epilogue_closed_form_with_ratio_ne_1`` holds the kernel to it at N = 50,000, and
+``test_minibatch_of_50000_matches_oracle_bf16`` is the bf16 twin of the fp32 oracle test at the benchmark's size.
 """
 import numpy as np
 import pytest
@@ -32,8 +34,29 @@ T = torch.from_numpy
 cos = lambda x, y: float(np.dot(x, y) / (np.linalg.norm(x) * np.linalg.norm(y) + 1e-30))
 
 # stated bf16 tolerances vs the reference's fp32 goldens (see the header; measured maxima in profiles/r02_bf16_parity.txt)
-TOL = dict(pg_abs=4e-2, v_rel=2e-2, kl_abs=2e-3, ratio_abs=2e-2, actor_cos=0.98, actor_norm=0.15, critic_cos=0.995,
-           critic_norm=0.05, bc_rel=2e-2, bc_cos=0.99, bc_norm=0.05)
+TOL = dict(pg_abs=1e-4, v_rel=2e-3, kl_abs=2e-6, ratio_abs=2e-4, tensor_cos=0.995, norm=1e-2, flip_tensor_cos=0.5,
+           flip_norm=0.35, flip_clipfrac=0.1, bc_rel=5e-3, bc_tensor_cos=0.999, bc_norm=2e-3)
+
+
+def grad_metrics(g, prefix, named_grads):
+    """Per-tensor cosine (on the stored elements: small tensors whole, big ones every 61st element) of the tensors that
+    carry >= 1 % of the gradient's norm, and the whole gradient's norm against the stored one."""
+    n_got = n_ref = 0.0
+    per = []
+    for k, grad in named_grads:
+        grad = grad.double().cpu().numpy().reshape(-1)
+        key = f"{prefix}_{k}"
+        if key in g:
+            r, x = g[key].astype(np.float64).reshape(-1), grad
+            nr = float(np.dot(r, r))
+        else:
+            r, x = g[key + "__sub"].astype(np.float64), grad[::61]
+            nr = float(g[key + "__norm"]) ** 2
+        per.append((nr, cos(x, r)))
+        n_got += float(np.dot(grad, grad))
+        n_ref += nr
+    worst = min(c for nr, c in per if nr >= 1e-4 * n_ref)
+    return worst, abs(np.sqrt(n_got / n_ref) - 1.0)
 
 
 def loss_metrics(golden, case, prec="bf16"):
@@ -50,27 +73,10 @@ def loss_metrics(golden, case, prec="bf16"):
     out = dict(pg_abs=abs(got[0] - ref[0]), v_rel=abs(got[2] - ref[2]) / abs(ref[2]), clipfrac_abs=abs(got[3] - ref[3]),
                kl_abs=abs(got[4] - ref[4]), ratio_abs=abs(got[5] - ref[5]), ent_abs=abs(got[1] - ref[1]),
                eta_abs=abs(got[7] - ref[7]), ref_pg=ref[0], ref_kl=ref[4], ref_clipfrac=ref[3])
-    for mod, tag, scale in ((m.actor_ft, "gactor", 1.0), (m.critic, "gcritic", 0.5)):
-        dots = n_got = n_ref = 0.0
-        worst = 1.0
-        for k, p in mod.named_parameters():
-            grad = p.grad.double().cpu().numpy().reshape(-1)
-            key = f"{case}_{tag}_{k}"
-            if key in g:
-                r = g[key].astype(np.float64).reshape(-1)
-                x = grad
-            else:  # big tensors are stored subsampled (every 61st element) + their norm
-                r = g[key + "__sub"].astype(np.float64)
-                x = grad[::61]
-            if np.linalg.norm(r) > 1e-12:
-                worst = min(worst, cos(x, r))
-            dots += float(np.dot(x, r)) * (1.0 if key in g else 61.0)
-            n_got += float(np.dot(grad, grad))
-            n_ref += float(np.linalg.norm(g[key])) ** 2 if key in g else float(g[key + "__norm"]) ** 2
-        name = "actor" if tag == "gactor" else "critic"
-        out[f"{name}_cos"] = dots / (np.sqrt(n_got * n_ref) + 1e-30)  # subsampled tensors: unbiased estimate of the dot
-        out[f"{name}_norm"] = abs(np.sqrt(n_got / n_ref) - 1.0)
-        out[f"{name}_worst_tensor_cos"] = worst
+    out["actor_tensor_cos"], out["actor_norm"] = grad_metrics(
+        g, f"{case}_gactor", [(k, p.grad) for k, p in m.actor_ft.named_parameters()])
+    out["critic_tensor_cos"], out["critic_norm"] = grad_metrics(
+        g, f"{case}_gcritic", [(k, p.grad) for k, p in m.critic.named_parameters()])
     return out
 
 
@@ -82,8 +88,12 @@ def test_ppo_loss_and_grads_bf16_vs_reference_goldens(golden, case):
     assert r["kl_abs"] <= TOL["kl_abs"], r
     assert r["ratio_abs"] <= TOL["ratio_abs"], r
     assert r["ent_abs"] == 0 and r["eta_abs"] == 0, r  # -eta: a constant of the schedule
-    assert r["actor_cos"] >= TOL["actor_cos"] and r["actor_norm"] <= TOL["actor_norm"], r
-    assert r["critic_cos"] >= TOL["critic_cos"] and r["critic_norm"] <= TOL["critic_norm"], r
+    assert r["critic_tensor_cos"] >= TOL["tensor_cos"] and r["critic_norm"] <= TOL["norm"], r
+    if r["clipfrac_abs"] == 0:  # every sample on the reference's branch of the clipped surrogate
+        assert r["actor_tensor_cos"] >= TOL["tensor_cos"] and r["actor_norm"] <= TOL["norm"], r
+    else:  # samples within the bf16 log-ratio error of the clip bound changed branch (header)
+        assert r["clipfrac_abs"] <= TOL["flip_clipfrac"], r
+        assert r["actor_tensor_cos"] >= TOL["flip_tensor_cos"] and r["actor_norm"] <= TOL["flip_norm"], r
 
 
 def bc_metrics(golden, case, prec="bf16"):
@@ -93,28 +103,18 @@ def bc_metrics(golden, case, prec="bf16"):
     state, noise = T(g[f"{case}_state"]).to(DEV), T(g[f"{case}_noise"]).to(DEV)
     value, grad = m.bc_loss_and_grad({"state": state}, noise=noise)
     ref = float(g[f"{case}_bc_loss"])
-    dots = n_got = n_ref = 0.0
-    off = 0
+    named, off = [], 0
     for k, p in m.actor_ft.named_parameters():
-        x = grad[off:off + p.numel()].double().cpu().numpy()
+        named.append((k, grad[off:off + p.numel()]))
         off += p.numel()
-        key = f"{case}_gbc_{k}"
-        if key in g:
-            r = g[key].astype(np.float64).reshape(-1)
-            dots += float(np.dot(x, r))
-            n_ref += float(np.dot(r, r))
-        else:
-            dots += 61.0 * float(np.dot(x[::61], g[key + "__sub"].astype(np.float64)))
-            n_ref += float(g[key + "__norm"]) ** 2
-        n_got += float(np.dot(x, x))
-    return dict(bc_rel=abs(float(value.item()) - ref) / abs(ref), bc_cos=dots / (np.sqrt(n_got * n_ref) + 1e-30),
-                bc_norm=abs(np.sqrt(n_got / n_ref) - 1.0), ref_bc=ref)
+    worst, norm = grad_metrics(g, f"{case}_gbc", named)
+    return dict(bc_rel=abs(float(value.item()) - ref) / abs(ref), bc_tensor_cos=worst, bc_norm=norm, ref_bc=ref)
 
 
 @pytest.mark.parametrize("case", sorted(BC_CASES))
 def test_bc_loss_and_gradient_bf16_vs_reference_goldens(golden, case):
     r = bc_metrics(golden, case, "bf16")
-    assert r["bc_rel"] <= TOL["bc_rel"] and r["bc_cos"] >= TOL["bc_cos"] and r["bc_norm"] <= TOL["bc_norm"], r
+    assert r["bc_rel"] <= TOL["bc_rel"] and r["bc_tensor_cos"] >= TOL["bc_tensor_cos"] and r["bc_norm"] <= TOL["bc_norm"], r
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -181,6 +181,13 @@ def test_loss_epilogue_closed_form_with_ratio_ne_1(prec):
     assert st[hip.STAT_V_LOSS] == pytest.approx(0.5 * ((v - ret) ** 2).mean(), rel=1e-4 if prec == "fp32" else 5e-3)
 
 
+# N = 50,000, full gradient vectors (exact cosines).  Measured (profiles/r02_bf16_parity.txt, last block): pg |d| 6e-7,
+# v rel 5.5e-5, kl |d| 1.7e-8, clipfrac |d| 1.6e-4 (8 of 50,000 samples on the other branch at eps_k in [1e-3, 1e-2]),
+# ratio |d| 3.6e-7, actor gradient cosine 0.9952 / norm -1.5 %, critic 0.9996 / -0.7 %
+FULL_TOL = dict(pg_abs=2e-5, v_rel=5e-4, kl_abs=2e-7, ratio_abs=5e-6, clipfrac_abs=2e-3, actor_cos=0.99, actor_norm=0.03,
+                critic_cos=0.999, critic_norm=0.015)
+
+
 def test_minibatch_of_50000_matches_oracle_bf16():
     """bf16 twin of tests/test_full_size.py::test_minibatch_of_50000_matches_oracle_fp32: the oracle (fp32 CPU) on the
     same 50,000 gathered samples, old log-probs from the HIP path + N(0, 0.02) so that ratio != 1."""
@@ -206,9 +213,15 @@ def test_minibatch_of_50000_matches_oracle_bf16():
                   ratio=(stats[hip.STAT_RATIO], float(res[5])), cos_a=cos(ga, ref_a), cos_c=cos(gc, ref_c),
                   norm_a=np.linalg.norm(ga) / np.linalg.norm(ref_a), norm_c=np.linalg.norm(gc) / np.linalg.norm(ref_c))
     print("bf16 N=50000 vs oracle:", report)
-    assert stats[hip.STAT_PG_LOSS] == pytest.approx(res[0].item(), abs=TOL["pg_abs"]), report
-    assert stats[hip.STAT_V_LOSS] == pytest.approx(res[2].item(), rel=TOL["v_rel"]), report
-    assert stats[hip.STAT_APPROX_KL] == pytest.approx(float(res[4]), abs=TOL["kl_abs"]), report
-    assert stats[hip.STAT_RATIO] == pytest.approx(float(res[5]), abs=TOL["ratio_abs"]), report
-    assert report["cos_a"] >= TOL["actor_cos"] and abs(report["norm_a"] - 1) <= TOL["actor_norm"], report
-    assert report["cos_c"] >= TOL["critic_cos"] and abs(report["norm_c"] - 1) <= TOL["critic_norm"], report
+    import json
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump({k: (list(map(float, v)) if isinstance(v, tuple) else float(v)) for k, v in report.items()},
+              open("gpurun_out/bf16_n50000_vs_oracle.json", "w"), indent=1)
+    assert stats[hip.STAT_PG_LOSS] == pytest.approx(res[0].item(), abs=FULL_TOL["pg_abs"]), report
+    assert stats[hip.STAT_V_LOSS] == pytest.approx(res[2].item(), rel=FULL_TOL["v_rel"]), report
+    assert stats[hip.STAT_APPROX_KL] == pytest.approx(float(res[4]), abs=FULL_TOL["kl_abs"]), report
+    assert stats[hip.STAT_RATIO] == pytest.approx(float(res[5]), abs=FULL_TOL["ratio_abs"]), report
+    assert stats[hip.STAT_CLIPFRAC] == pytest.approx(float(res[3]), abs=FULL_TOL["clipfrac_abs"]), report
+    assert report["cos_a"] >= FULL_TOL["actor_cos"] and abs(report["norm_a"] - 1) <= FULL_TOL["actor_norm"], report
+    assert report["cos_c"] >= FULL_TOL["critic_cos"] and abs(report["norm_c"] - 1) <= FULL_TOL["critic_norm"], report

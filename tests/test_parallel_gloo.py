@@ -101,3 +101,91 @@ def test_moments_single_process_passthrough():
     adv = torch.arange(12, dtype=torch.float32)
     m = pool_minibatch_moments(adv, [torch.tensor([0, 5, 23, 47])], 4)  # rows 0, 1, 5, 11
     np.testing.assert_allclose(m.numpy(), [[17.0, 0 + 1 + 25 + 121, 4.0]])
+
+
+# ------------------------------------------------------------------ the DataParallel class itself, world_size 2
+def dp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from dppo_amd.agent.finetune.train_ppo_diffusion_agent import TrainPPODiffusionAgent
+    from dppo_amd.model.common.critic import CriticObs
+    from dppo_amd.model.diffusion.diffusion_ppo import PPODiffusion
+    from dppo_amd.model.diffusion.mlp_diffusion import DiffusionMLP
+    from dppo_amd.parallel import STATS_SLOTS, DataParallel
+    a, c, cfg, params, data, inds = make_problem()
+    # every rank starts from DIFFERENT weights: the constructor's broadcast must make them rank 0's
+    actor = DiffusionMLP(3, 4, 11, mlp_dims=[512, 512, 512], activation_type="ReLU", residual_style=True)
+    critic = CriticObs(11, [256, 256, 256], residual_style=True)
+    actor.load_state_dict(O.init_params(a, 100 + rank))
+    critic.load_state_dict(O.init_params(c, 200 + rank))
+    model = PPODiffusion(actor=actor, critic=critic, horizon_steps=4, obs_dim=11, action_dim=3, device="cpu", **KW)
+    model.actor_ft.load_state_dict(O.init_params(a, 300 + rank))
+    epochs = [model.actor_ft._epoch, model.critic._epoch, model.actor._epoch]
+    dp = DataParallel(model, world)
+    res = {}
+    # (1) bucket aliasing: the networks' flat gradient buffers ARE slices of the one bucket
+    na, nc = model.actor_ft.flat_params().numel(), model.critic.flat_params().numel()
+    res["alias"] = (model.actor_ft.flat_grads().data_ptr() == dp.bucket.data_ptr()
+                    and model.critic.flat_grads().data_ptr() == dp.bucket.data_ptr() + 4 * na
+                    and dp.bucket.numel() == na + nc + 2 * STATS_SLOTS)
+    # (2) broadcast: every rank now holds rank 0's weights, and the kernel images were invalidated
+    res["weights"] = [model.actor_ft.flat_params().clone(), model.critic.flat_params().clone(),
+                      model.actor.flat_params().clone()]
+    res["epochs_bumped"] = [model.actor_ft._epoch > epochs[0], model.critic._epoch > epochs[1], model.actor._epoch > epochs[2]]
+    # (3) one update: per-rank gradients (oracle as the per-rank compute, on rank 0's weights) written into the aliased
+    # buffers, per-rank float64 statistics, then the class's all-reduce (non-CUDA branch: hi/lo split of the statistics)
+    w = (O.init_params(a, 61), O.init_params(a, 300), O.init_params(c, 200))
+    mine = inds[rank::world].contiguous()
+    mom = dp.minibatch_moments(data[3], [mine], cfg.ft_denoising_steps)[0]
+    flat, stats = loss_and_grads(a, c, cfg, w, data, mine, global_moments=mom.tolist())
+    model.actor_ft.flat_grads().copy_(flat[:na])
+    model.critic.flat_grads().copy_(flat[na:])
+    st = torch.zeros(STATS_SLOTS, dtype=torch.float64)
+    st[:5] = torch.tensor([stats[0], stats[1], stats[2], stats[3], stats[4]])  # pg, v, kl, clipfrac, ratio partial sums
+    st[5], st[6] = 0.123456789012345, 1.987654321098765  # adv mean / std: global values every rank writes
+    object.__setattr__(model, "_stats", st)
+    dp.allreduce_grads()
+    res["grads"] = torch.cat([model.actor_ft.flat_grads(), model.critic.flat_grads()]).clone()
+    res["stats"] = model._stats.clone()
+    res["moments"] = mom.clone()
+    # (4) after the broadcast every rank draws its own random stream (sampler key, permutations)
+    TrainPPODiffusionAgent.reseed(42 + rank)
+    res["sampler_key"] = int(torch.randint(0, 2 ** 62, (1,)).item())  # what VPGDiffusion.forward draws
+    out.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_class_on_two_ranks():
+    world, port = 2, free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, c, cfg, params, data, inds = make_problem()
+    r0, r1 = got[0], got[1]
+    assert r0["alias"] and r1["alias"]
+    assert all(r0["epochs_bumped"]) and all(r1["epochs_bumped"])
+    for x, y, spec, seed in zip(r0["weights"], r1["weights"], (a, c, a), (300, 200, 100)):
+        assert torch.equal(x, y)
+        want = torch.cat([O.init_params(spec, seed)[n].reshape(-1) for n, _, _ in O.param_shapes(spec)])
+        assert torch.equal(x, want)  # rank 0's
+    # the reduced gradient / statistics equal the single-process ones on the whole minibatch, on both ranks
+    w = (O.init_params(a, 61), O.init_params(a, 300), O.init_params(c, 200))
+    flat, stats = loss_and_grads(a, c, cfg, w, data, inds)
+    for r in (r0, r1):
+        assert torch.equal(r["grads"], r0["grads"])
+        assert (r["grads"] - flat).norm().item() <= 1e-4 * flat.norm().item()
+        np.testing.assert_allclose(r["stats"][:5].numpy(), stats.numpy(), rtol=2e-5, atol=1e-6)
+        # float64 statistics survive the fp32 bucket (hi + lo), and the two global values are not doubled
+        assert r["stats"][5].item() == pytest.approx(0.123456789012345, rel=1e-13)
+        assert r["stats"][6].item() == pytest.approx(1.987654321098765, rel=1e-13)
+    adv_g = data[3][inds // 10].double()
+    np.testing.assert_allclose(r0["moments"].numpy(), [adv_g.sum().item(), (adv_g * adv_g).sum().item(), 128.0], rtol=1e-12)
+    assert r0["sampler_key"] != r1["sampler_key"]

@@ -23,17 +23,17 @@ def golden(name):
     return cache[name]
 
 
-cols = ("pg_abs", "v_rel", "kl_abs", "ratio_abs", "clipfrac_abs", "actor_cos", "actor_norm", "actor_worst_tensor_cos",
-        "critic_cos", "critic_norm", "ref_pg", "ref_kl", "ref_clipfrac")
+cols = ("pg_abs", "v_rel", "kl_abs", "ratio_abs", "clipfrac_abs", "actor_tensor_cos", "actor_norm", "critic_tensor_cos",
+        "critic_norm", "ref_pg", "ref_kl", "ref_clipfrac")
 print("G5 PPODiffusion.loss vs reference goldens (N = 64 per case)")
-print(f"{'case':20s} {'prec':5s} " + " ".join(f"{c:>12s}" for c in cols))
+print(f"{'case':20s} {'prec':5s} " + " ".join(f"{c:>17s}" for c in cols))
 worst = {}
 for case in sorted(k for k, v in LOSS_CASES.items() if v[0] in HIP_SUPPORTED):
     for prec in ("fp32", "bf16"):
         r = loss_metrics(golden, case, prec)
-        print(f"{case:20s} {prec:5s} " + " ".join(f"{r[c]:12.4e}" for c in cols))
+        print(f"{case:20s} {prec:5s} " + " ".join(f"{r[c]:17.4e}" for c in cols))
         if prec == "bf16":
-            for c in cols[:10]:
+            for c in cols[:9]:
                 f = min if "cos" in c else max
                 worst[c] = f(worst.get(c, r[c]), r[c])
 print("worst bf16:", {k: float(f"{v:.4g}") for k, v in worst.items()})
