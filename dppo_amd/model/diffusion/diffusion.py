@@ -6,9 +6,11 @@ bit-identical; the K-step loop itself is the HIP sampler (see diffusion_vpg.py).
 """
 from __future__ import annotations
 
+import ctypes as C
 import logging
 from collections import namedtuple
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -88,6 +90,137 @@ class DiffusionModel(nn.Module):
             self.ddim_alphas_sqrt = torch.flip(torch.sqrt(al), [0])
             self.ddim_alphas_prev = torch.flip(alp, [0])
             self.ddim_sqrt_one_minus_alphas = torch.flip(som, [0])
+
+    # ------------------------------------------------------------------ per-step coefficient tables (reference :200-311)
+    # defaults of the attributes the fine-tuning subclasses set: a plain DiffusionModel samples with `network` on every step
+    ft_denoising_steps = 0
+    min_sampling_denoising_std = 0.1
+
+    def get_min_sampling_denoising_std(self):
+        return self.min_sampling_denoising_std
+
+    def _eta_value(self, deterministic: bool) -> float:
+        if deterministic:
+            return 0.0
+        return self.eta.value() if hasattr(self, "eta") else 1.0
+
+    def _ddim_coefs(self, i: int, eta: float):
+        """(c0..c3, std_raw) of DDIM index i; expressions of reference :171-213, fp32 torch scalars."""
+        al, alp = self.ddim_alphas[i], self.ddim_alphas_prev[i]
+        som = self.ddim_sqrt_one_minus_alphas[i]
+        etas = torch.tensor(eta, dtype=torch.float32)
+        sigma = (etas * ((1 - alp) / (1 - al) * (1 - al / alp)) ** 0.5).clamp(min=1e-10)
+        dirc = (1.0 - alp - sigma ** 2).clamp(min=0).sqrt()
+        logvar = torch.log(sigma ** 2)
+        return float(al ** 0.5), float(som), float(alp ** 0.5), float(dirc), torch.exp(0.5 * logvar)
+
+    def _ddpm_coefs(self, t: int):
+        return (float(self.sqrt_recip_alphas_cumprod[t]), float(self.sqrt_recipm1_alphas_cumprod[t]),
+                float(self.ddpm_mu_coef1[t]), float(self.ddpm_mu_coef2[t]),
+                torch.exp(0.5 * self.ddpm_logvar_clipped[t]))
+
+    def _sampling_schedule(self, deterministic: bool, use_base_policy: bool, device):
+        """dppo_step table of the sampling loop (reference :258-311) + chain geometry."""
+        min_std = float(self.get_min_sampling_denoising_std())
+        key = ("sample", deterministic, use_base_policy, min_std, self.ft_denoising_steps, str(device),
+               self._eta_value(deterministic))
+        cache = self.__dict__.setdefault("_sched_cache", {})
+        hit = cache.get(key)
+        if hit is not None:
+            return hit
+        Kft = self.ft_denoising_steps
+        if self.use_ddim:
+            t_all = [int(v) for v in self.ddim_t]
+            n_steps = self.ddim_steps
+        else:
+            t_all = list(reversed(range(self.denoising_steps)))
+            n_steps = self.denoising_steps
+        tab = np.zeros(n_steps, dtype=hip.STEP_DTYPE)
+        init_slot = 0 if Kft == n_steps else -1
+        slot = 1 if Kft == n_steps else 0
+        for i, t in enumerate(t_all):
+            if self.use_ddim:
+                ft = i >= (self.ddim_steps - Kft)
+                c0, c1, c2, c3, std = self._ddim_coefs(i, self._eta_value(deterministic))
+                std = torch.zeros_like(std) if deterministic else torch.clip(std, min=min_std)
+                keep = i >= (self.ddim_steps - Kft - 1)
+            else:
+                ft = t < Kft
+                c0, c1, c2, c3, std = self._ddpm_coefs(t)
+                if deterministic and t == 0:
+                    std = torch.zeros_like(std)
+                elif deterministic:
+                    std = torch.clip(std, min=1e-3)
+                else:
+                    std = torch.clip(std, min=min_std)
+                keep = t <= Kft
+            tab[i] = (int(ft and not use_base_policy), t, slot if keep else -1,
+                      int(self.final_action_clip_value is not None and i == n_steps - 1), c0, c1, c2, c3,
+                      float(std), 0.0)
+            slot += int(keep)
+        out = (torch.from_numpy(tab.view(np.uint8)).to(device), n_steps, slot, init_slot)
+        cache[key] = out
+        return out
+
+    # ------------------------------------------------------------------ the sampler launch
+    def _run_sampler(self, cond, deterministic, return_chain, use_base_policy, noise, out, who):
+        """One ``dppo_sample_chain`` launch for all denoising steps: ``actor`` on the frozen steps, ``actor_ft`` on the
+        fine-tuned ones (for a plain DiffusionModel both are ``network`` and ``ft_denoising_steps`` is 0)."""
+        state = cond["state"]
+        hip.require_gpu(state, who)
+        B = state.shape[0]
+        dev = state.device
+        AF = self.horizon_steps * self.action_dim
+        sched, n_steps, chain_len, init_slot = self._sampling_schedule(deterministic, use_base_policy, dev)
+        cfg = self.diffusion_cfg()
+        if noise is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: no device sync
+            cfg.seed_lo, cfg.seed_hi = seed & 0xFFFFFFFF, seed >> 32
+        else:
+            noise = noise.reshape(n_steps + 1, B, AF).contiguous().float()
+        obs = state.reshape(B, -1).contiguous().float()
+        if out is not None:
+            traj, chains = out
+            assert traj.is_contiguous() and traj.dtype == torch.float32 and traj.numel() == B * AF and traj.device == dev
+            assert not return_chain or (chains.is_contiguous() and chains.dtype == torch.float32 and
+                                        chains.numel() == B * chain_len * AF and chains.device == dev)
+        else:
+            traj = torch.empty((B, AF), device=dev, dtype=torch.float32)
+            chains = torch.empty((B, chain_len, AF), device=dev, dtype=torch.float32) if return_chain else None
+        lib = hip.load()
+        mods = self._modules  # fine-tuning subclasses register `actor` (frozen) and `actor_ft`; the base class only `network`
+        base = mods.get("actor")
+        if base is None:
+            base = self.network
+        ft = mods.get("actor_ft")
+        if ft is None:
+            ft = base
+        d = base.net_desc()
+        K = self.denoising_steps
+        wsb = lib.dppo_sample_chain_workspace_bytes(C.byref(d), self.prec, B)
+        ws = self.__dict__.setdefault("_ws_sample", hip.Workspace()).get(wsb, dev) if wsb > 0 else None
+        hip.check(lib.dppo_sample_chain(
+            C.byref(d), self.prec, base.flat_params().data_ptr(), base.packed(self.prec, K).data_ptr(),
+            ft.flat_params().data_ptr(), ft.packed(self.prec, K).data_ptr(), C.byref(cfg),
+            sched.data_ptr(), n_steps, obs.data_ptr(), noise.data_ptr() if noise is not None else None, B, traj.data_ptr(),
+            chains.data_ptr() if return_chain else None, chain_len if return_chain else 0,
+            init_slot if return_chain else -1, ws.data_ptr() if ws is not None else None, wsb, hip.stream()),
+            "dppo_sample_chain")
+        traj = traj.view(B, self.horizon_steps, self.action_dim)
+        if return_chain:
+            chains = chains.view(B, chain_len, self.horizon_steps, self.action_dim)
+        return Sample(traj, chains)
+
+    @torch.no_grad()
+    def forward(self, cond, deterministic=True, noise=None):
+        """Evaluation sampling (reference ``DiffusionModel.forward`` :261-316): no chain, x_{t-1} = mu + std * z with std = 0
+        under DDIM and at t = 0, clip(std, 1e-3) otherwise -- whatever ``deterministic`` says, like the reference (its flag
+        only reaches ``p_mean_var``, where it selects eta = 0 under DDIM).  Same kernel as the fine-tuning sampler, with
+        the deterministic step table."""
+        if self.use_ddim and not deterministic and not hasattr(self, "eta"):
+            raise AttributeError("DDIM sampling with deterministic=False needs an eta module (the reference fails the same way)")
+        smp = self._run_sampler(cond, True, False, False, noise, None, type(self).__name__ + ".forward")
+        return Sample(smp.trajectories, None)
 
     # ------------------------------------------------------------------ supervised training (reference :318-363)
     def loss(self, x, cond, noise=None, t=None):

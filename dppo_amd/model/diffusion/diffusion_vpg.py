@@ -77,68 +77,7 @@ class VPGDiffusion(DiffusionModel):
         return self.min_sampling_denoising_std()
 
     # ------------------------------------------------------------------ per-step coefficient tables
-    def _eta_value(self, deterministic: bool) -> float:
-        if deterministic:
-            return 0.0
-        return self.eta.value() if hasattr(self, "eta") else 1.0
-
-    def _ddim_coefs(self, i: int, eta: float):
-        """(c0..c3, std_raw) of DDIM index i; expressions of reference :171-213, fp32 torch scalars."""
-        al, alp = self.ddim_alphas[i], self.ddim_alphas_prev[i]
-        som = self.ddim_sqrt_one_minus_alphas[i]
-        etas = torch.tensor(eta, dtype=torch.float32)
-        sigma = (etas * ((1 - alp) / (1 - al) * (1 - al / alp)) ** 0.5).clamp(min=1e-10)
-        dirc = (1.0 - alp - sigma ** 2).clamp(min=0).sqrt()
-        logvar = torch.log(sigma ** 2)
-        return float(al ** 0.5), float(som), float(alp ** 0.5), float(dirc), torch.exp(0.5 * logvar)
-
-    def _ddpm_coefs(self, t: int):
-        return (float(self.sqrt_recip_alphas_cumprod[t]), float(self.sqrt_recipm1_alphas_cumprod[t]),
-                float(self.ddpm_mu_coef1[t]), float(self.ddpm_mu_coef2[t]),
-                torch.exp(0.5 * self.ddpm_logvar_clipped[t]))
-
-    def _sampling_schedule(self, deterministic: bool, use_base_policy: bool, device):
-        """dppo_step table of the sampling loop (reference :258-311) + chain geometry."""
-        min_std = float(self.get_min_sampling_denoising_std())
-        key = ("sample", deterministic, use_base_policy, min_std, self.ft_denoising_steps, str(device),
-               self._eta_value(deterministic))
-        hit = self._sched_cache.get(key)
-        if hit is not None:
-            return hit
-        Kft = self.ft_denoising_steps
-        if self.use_ddim:
-            t_all = [int(v) for v in self.ddim_t]
-            n_steps = self.ddim_steps
-        else:
-            t_all = list(reversed(range(self.denoising_steps)))
-            n_steps = self.denoising_steps
-        tab = np.zeros(n_steps, dtype=hip.STEP_DTYPE)
-        init_slot = 0 if Kft == n_steps else -1
-        slot = 1 if Kft == n_steps else 0
-        for i, t in enumerate(t_all):
-            if self.use_ddim:
-                ft = i >= (self.ddim_steps - Kft)
-                c0, c1, c2, c3, std = self._ddim_coefs(i, self._eta_value(deterministic))
-                std = torch.zeros_like(std) if deterministic else torch.clip(std, min=min_std)
-                keep = i >= (self.ddim_steps - Kft - 1)
-            else:
-                ft = t < Kft
-                c0, c1, c2, c3, std = self._ddpm_coefs(t)
-                if deterministic and t == 0:
-                    std = torch.zeros_like(std)
-                elif deterministic:
-                    std = torch.clip(std, min=1e-3)
-                else:
-                    std = torch.clip(std, min=min_std)
-                keep = t <= Kft
-            tab[i] = (int(ft and not use_base_policy), t, slot if keep else -1,
-                      int(self.final_action_clip_value is not None and i == n_steps - 1), c0, c1, c2, c3,
-                      float(std), 0.0)
-            slot += int(keep)
-        out = (torch.from_numpy(tab.view(np.uint8)).to(device), n_steps, slot, init_slot)
-        self._sched_cache[key] = out
-        return out
-
+    # (_eta_value, _ddim_coefs, _ddpm_coefs, _sampling_schedule and the sampler launch live in DiffusionModel)
     def _logprob_schedule(self, device):
         """dppo_step table of chain position k = 0..Kft-1 (reference :351-370, :388-389)."""
         key = ("logprob", self.ft_denoising_steps, float(self.min_logprob_denoising_std), str(device),
@@ -165,7 +104,8 @@ class VPGDiffusion(DiffusionModel):
     # ------------------------------------------------------------------ sampling (reference :227-315)
     @torch.no_grad()
     def forward(self, cond, deterministic=False, return_chain=True, use_base_policy=False, noise=None, out=None):
-        """cond {"state": (B,To,Do)} -> Sample(trajectories (B,Ta,Da), chains (B,Kft+1,Ta,Da)).
+        """cond {"state": (B,To,Do)} -> Sample(trajectories (B,Ta,Da), chains (B,Kft+1,Ta,Da)): the K-step loop of the
+        reference's ``VPGDiffusion.forward`` as ONE launch (``DiffusionModel._run_sampler``).
 
         ``out = (trajectories, chains)``: contiguous fp32 device tensors of B*Ta*Da and B*(Kft+1)*Ta*Da elements the
         kernel writes straight into (the rollout loop passes slices of its buffer: no allocation, no copy kernel).
@@ -175,43 +115,7 @@ class VPGDiffusion(DiffusionModel):
         torch's CPU generator, so ``torch.manual_seed`` reproduces a run) -- the reference's ``torch.randn`` /
         ``randn_like`` (:271, :303) in distribution, without a separate noise launch and tensor.
         """
-        state = cond["state"]
-        hip.require_gpu(state, "VPGDiffusion.forward")
-        B = state.shape[0]
-        dev = state.device
-        AF = self.horizon_steps * self.action_dim
-        sched, n_steps, chain_len, init_slot = self._sampling_schedule(deterministic, use_base_policy, dev)
-        cfg = self.diffusion_cfg()
-        if noise is None:
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: no device sync
-            cfg.seed_lo, cfg.seed_hi = seed & 0xFFFFFFFF, seed >> 32
-        else:
-            noise = noise.reshape(n_steps + 1, B, AF).contiguous().float()
-        obs = state.reshape(B, -1).contiguous().float()
-        if out is not None:
-            traj, chains = out
-            assert traj.is_contiguous() and traj.dtype == torch.float32 and traj.numel() == B * AF and traj.device == dev
-            assert not return_chain or (chains.is_contiguous() and chains.dtype == torch.float32 and
-                                        chains.numel() == B * chain_len * AF and chains.device == dev)
-        else:
-            traj = torch.empty((B, AF), device=dev, dtype=torch.float32)
-            chains = torch.empty((B, chain_len, AF), device=dev, dtype=torch.float32) if return_chain else None
-        lib = hip.load()
-        d = self.actor.net_desc()
-        K = self.denoising_steps
-        wsb = lib.dppo_sample_chain_workspace_bytes(C.byref(d), self.prec, B)
-        ws = self._ws_sample.get(wsb, dev) if wsb > 0 else None
-        hip.check(lib.dppo_sample_chain(
-            C.byref(d), self.prec, self.actor.flat_params().data_ptr(), self.actor.packed(self.prec, K).data_ptr(),
-            self.actor_ft.flat_params().data_ptr(), self.actor_ft.packed(self.prec, K).data_ptr(), C.byref(cfg),
-            sched.data_ptr(), n_steps, obs.data_ptr(), noise.data_ptr() if noise is not None else None, B, traj.data_ptr(),
-            chains.data_ptr() if return_chain else None, chain_len if return_chain else 0,
-            init_slot if return_chain else -1, ws.data_ptr() if ws is not None else None, wsb, hip.stream()),
-            "dppo_sample_chain")
-        traj = traj.view(B, self.horizon_steps, self.action_dim)
-        if return_chain:
-            chains = chains.view(B, chain_len, self.horizon_steps, self.action_dim)
-        return Sample(traj, chains)
+        return self._run_sampler(cond, deterministic, return_chain, use_base_policy, noise, out, "VPGDiffusion.forward")
 
     # ------------------------------------------------------------------ log-probs (reference :319-396)
     @torch.no_grad()

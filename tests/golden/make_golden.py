@@ -374,6 +374,40 @@ def g7_adamw():
     save("g7_adamw", **out)
 
 
+# ---------------------------------------------------------------- G11 DiffusionEval (checkpoint -> evaluation sampling)
+from make_golden_cases import EVAL_CASES  # noqa: E402
+
+
+def g11_eval():
+    """The reference's DiffusionEval (model/diffusion/diffusion_eval.py:19-150) built from a checkpoint file written here
+    from seeded weights (RL checkpoint: actor.* / actor_ft.* keys of a PPODiffusion; pre-training checkpoint: network.*
+    keys), sampled with recorded noise.  Only inputs / outputs are stored; the test rebuilds the checkpoint itself."""
+    import tempfile
+    from dppo.model.diffusion.diffusion_eval import DiffusionEval
+    out = {}
+    rs = np.random.RandomState(1100)
+    for cname, (sname, B, kw, ft, kind) in EVAL_CASES.items():
+        a, c = specs(sname)
+        src = ref_model(a, c, 61, gamma_denoising=0.99, clip_ploss_coef=0.01, ft_denoising_steps=max(ft, 1),
+                        **({"eta": EtaFixed(base_eta=1.0)} if kw.get("use_ddim") else {}), **kw)
+        sd = src.state_dict()
+        if kind == "pretrain":  # what agent/pretrain/train_agent.py:146-168 saves: a DiffusionModel's `network.*`
+            sd = {k: v for k, v in sd.items() if k.startswith("network.")}
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "state.pt")
+            torch.save({"itr": 0, "model": sd}, path)
+            ev = DiffusionEval(network_path=path, ft_denoising_steps=ft, network=ref_actor(a, O.init_params(a, 999)),
+                               horizon_steps=a.horizon_steps, obs_dim=a.cond_dim, action_dim=a.action_dim, device="cpu",
+                               **kw)
+        n_steps = kw["ddim_steps"] if kw.get("use_ddim") else kw["denoising_steps"]
+        state = torch.from_numpy(rs.uniform(-1, 1, size=(B, 1, a.cond_dim)).astype(np.float32))
+        noise = torch.from_numpy(rs.randn(n_steps + 1, B, a.horizon_steps, a.action_dim).astype(np.float32))
+        with recorded_noise(list(noise)):
+            smp = ev(cond={"state": state}, deterministic=True)
+        out.update({f"{cname}_state": state, f"{cname}_noise": noise, f"{cname}_traj": smp.trajectories})
+    save("g11_eval", **out)
+
+
 # ---------------------------------------------------------------- G10 LR schedule trace
 from make_golden_cases import SCHED_CASES  # noqa: E402
 
@@ -398,6 +432,6 @@ def g10_scheduler():
 
 if __name__ == "__main__":
     only = sys.argv[1:]  # e.g. `make_golden.py g8_bc` regenerates one file (each generator owns its RNG stream)
-    for fn in (g1_tables, g2_forward, g3_g4_chains, g5_loss, g6_reward_scaler, g7_adamw, g8_bc, g9_denoise_mse, g10_scheduler):
+    for fn in (g1_tables, g2_forward, g3_g4_chains, g5_loss, g6_reward_scaler, g7_adamw, g8_bc, g9_denoise_mse, g10_scheduler, g11_eval):
         if not only or fn.__name__ in only:
             fn()

@@ -6,3 +6,10 @@ SCHED_CASES = {
     "nowarm_mult2": (dict(first_cycle_steps=10, cycle_mult=2.0, max_lr=3e-4, min_lr=1e-6, warmup_steps=0, gamma=0.9), 45, 3e-4),
     "pretrain_like": (dict(first_cycle_steps=200, cycle_mult=1.0, max_lr=1e-3, min_lr=1e-4, warmup_steps=1, gamma=1.0), 30, 1e-3),
 }
+
+EVAL_CASES = {
+    # name: (spec, B, model kwargs, ft_denoising_steps, checkpoint kind)
+    "eval_ddpm_ft10": ("hopper", 6, dict(denoising_steps=20, randn_clip_value=3), 10, "rl"),
+    "eval_ddim_ft5": ("hopper", 5, dict(denoising_steps=100, use_ddim=True, ddim_steps=5, randn_clip_value=3), 5, "rl"),
+    "eval_pretrained_can": ("can", 4, dict(denoising_steps=20, randn_clip_value=3, final_action_clip_value=1.0), 0, "pretrain"),
+}

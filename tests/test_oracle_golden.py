@@ -280,3 +280,21 @@ def test_denoise_mse_matches_reference(golden, case):
     loss.backward()
     for k, v in prm.items():
         check_grad(g, f"{case}_g_{k}", v.grad if v.grad is not None else torch.zeros_like(v), 2e-4, 1e-7)
+
+
+# ------------------------------------------------------------------ G11 DiffusionEval
+from tests.golden.make_golden_cases import EVAL_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("case", sorted(EVAL_CASES))
+def test_eval_sampling_matches_reference(golden, case):
+    """DiffusionEval.forward (reference diffusion_eval.py + diffusion.py:261-316) == the oracle's deterministic chain with
+    the checkpoint's base / fine-tuned weights (seed 61 / 62 of the recipe)."""
+    g = golden("g11_eval")
+    sname, B, kw, ft, kind = EVAL_CASES[case]
+    a, _ = O.named_specs(sname)
+    cfg = make_cfg(a, dict(kw, ft_denoising_steps=ft))
+    base, ftw = O.init_params(a, 61), O.init_params(a, 62)
+    traj, _ = O.sample_chain(cfg, a, base, ftw if kind == "rl" else base, T(g[f"{case}_state"]), T(g[f"{case}_noise"]),
+                             deterministic=True)
+    close(traj, g[f"{case}_traj"], rtol=1e-4, atol=1e-4)
