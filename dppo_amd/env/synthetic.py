@@ -1,7 +1,7 @@
 """A dependency-free vectorised environment with the interface the agent drives.
 
-The reference's env layer (env/gym_utils: AsyncVectorEnv + MultiStep + MuJoCo / Robomimic wrappers) stays on
-host CPU and is out of scope for this build; gym / mujoco / d4rl are not installed here.
+The env layer proper is dppo_amd/env/gym_utils (worker-pool AsyncVectorEnv, MultiStep, MujocoLocomotionLowdimWrapper:
+SURVEY.md 8f row 1); gym / mujoco / d4rl are not installed here, so the agent's end-to-end tests need a simulator that is.
 This stand-in exposes the same calls the agent makes -- ``reset_arg``, ``step`` on (n_envs, act_steps, act_dim)
 action chunks returning multi-step-summed rewards, ``seed`` -- over a stable linear system, so the training loop
 can be exercised end to end on synthetic data.
@@ -64,13 +64,9 @@ def make_venv(cfg):
             return mk(0)
         from dppo_amd.util.rollout import GroupedVecEnv
         return GroupedVecEnv([mk(g) for g in range(groups)])
-    try:  # the reference's un-namespaced import (agent/finetune/train_agent.py:16), if the user has that stack
-        from env.gym_utils import make_async
-    except ImportError as e:
-        raise ImportError(
-            f"environment {env.name!r} needs the reference's host-side env stack (gym, mujoco-py, d4rl / robomimic), "
-            "which is out of scope for dppo_amd and not installed here; pass a vectorised env to the agent "
-            "(venv=...) or use env.name=synthetic") from e
+    # named simulators: this build's own worker-pool env layer (dppo_amd/env/gym_utils: AsyncVectorEnv + the cfg's wrappers),
+    # which needs gym + the simulator stack of that env on the host (not installed in this image: ImportError says so)
+    from dppo_amd.env.gym_utils import make_async
     mk = lambda: make_async(env.name, env_type=env.get("env_type", None), num_envs=env.n_envs // groups, asynchronous=True,
                             max_episode_steps=env.max_episode_steps, wrappers=env.get("wrappers", None),
                             obs_dim=cfg.obs_dim, action_dim=cfg.action_dim)
