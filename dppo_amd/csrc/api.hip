@@ -8,6 +8,7 @@
 #include "fused.h"
 #include "gemm.h"
 #include "ppo.h"
+#include "gaussian.h"
 #include "sampler.h"
 
 using namespace dppo;
@@ -148,7 +149,6 @@ static int check_net(const dppo_net_desc* d) {
   } else {
     if (d->in_dim != d->cond_dim) return fail(-1, "critic in_dim must equal cond_dim");
     if (d->cond_hidden || d->cond_out) return fail(-1, "critic has no cond_mlp");
-    if (d->out_dim != 1) return fail(-1, "critic out_dim must be 1");
   }
   if (d->in_dim < 1 || d->in_dim > 1024) return fail(-1, "in_dim=%d out of [1,1024]", d->in_dim);
   if (d->use_layernorm != 0 && d->use_layernorm != 1) return fail(-1, "use_layernorm must be 0 or 1");
@@ -1388,7 +1388,8 @@ int dppo_ppo_loss_fwd_bwd(const dppo_net_desc* actor, const dppo_net_desc* criti
   if (int e = check_net(actor)) return e;
   if (int e = check_net(critic)) return e;
   if (int e = check_prec(prec)) return e;
-  if (actor->kind != 0 || critic->kind != 1) return fail(-1, "descriptor kinds must be (actor, critic)");
+  if (actor->kind != 0 || critic->kind != 1 || critic->out_dim != 1)
+    return fail(-1, "descriptor kinds must be (actor, critic with out_dim 1)");
   if (actor->cond_dim != critic->cond_dim) return fail(-1, "actor and critic observe different cond_dim");
   if (!actor_params || !actor_packed || !critic_params || !critic_packed || !dcfg || !pcfg || !ksteps || !obs_k ||
       !chains_k || !returns_k || !values_k || !adv_k || !logprobs_k || !actor_grad || !critic_grad || !stats ||
@@ -1406,6 +1407,149 @@ int dppo_ppo_loss_fwd_bwd(const dppo_net_desc* actor, const dppo_net_desc* criti
   ppo_impl<P>(*actor, *critic, actor_params, (const char*)actor_packed, critic_params, (const char*)critic_packed, *dcfg,     \
               *pcfg, ksteps, obs_k, chains_k, returns_k, values_k, adv_k, logprobs_k, inds, kinds, N, global_moments, actor_grad, critic_grad, stats, \
               workspace, workspace_bytes, (hipStream_t)stream)
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
+}
+
+// ---- Gaussian-policy PPO (gaussian.hip) ----------------------------------------------------------------------
+static int check_gauss(const dppo_net_desc* actor, const dppo_gaussian_cfg* cfg, const float* logvar) {
+  if (int e = check_net(actor)) return e;
+  if (actor->kind != 1) return fail(-1, "the Gaussian actor is a kind-1 (observation trunk) descriptor");
+  if (!cfg) return fail(-1, "null cfg");
+  if (cfg->horizon_steps * cfg->action_dim != actor->out_dim) return fail(-1, "Ta*Da != actor out_dim");
+  if (cfg->std_mode != 0 && cfg->std_mode != 1) return fail(-1, "std_mode must be 0 (fixed) or 1 (learned per dimension)");
+  if (cfg->std_mode == 1 && !logvar) return fail(-1, "std_mode 1 needs logvar");
+  if (cfg->std_mode == 0 && !(cfg->fixed_std > 0)) return fail(-1, "fixed_std must be positive");
+  return 0;
+}
+template <class P>
+static size_t carve_gauss(Carver& c, const dppo_net_desc& a, const dppo_net_desc* cr, int64_t N, bool train, MlpBufs<P>& A,
+                          MlpBufs<P>& Cb, double*& moments, double*& scratch, double*& partial) {
+  moments = (double*)c.take(4 * sizeof(double));
+  scratch = (double*)c.take(2 * 64 * sizeof(double));
+  partial = (double*)c.take((size_t)gauss_blocks(N) * (8 + a.out_dim) * sizeof(double));
+  carve_mlp<P>(c, a, N, train, train, A);
+  if (cr) carve_mlp<P>(c, *cr, N, train, train, Cb);
+  return al256(c.off);
+}
+int64_t dppo_gaussian_workspace_bytes(const dppo_net_desc* actor, const dppo_net_desc* critic, int prec, int64_t N) {
+  if (check_net(actor) || (critic && check_net(critic)) || check_prec(prec)) return -1;
+  if (N < 1 || N > 0x7fffffff) return fail(-1, "N out of range");
+  Carver c{nullptr, 0, 0};
+  double *m, *sc, *pa;
+  if (prec == DPPO_PREC_F32) {
+    MlpBufs<F32> A, Cb;
+    return (int64_t)carve_gauss<F32>(c, *actor, critic, N, critic != nullptr, A, Cb, m, sc, pa);
+  }
+  MlpBufs<BF16> A, Cb;
+  return (int64_t)carve_gauss<BF16>(c, *actor, critic, N, critic != nullptr, A, Cb, m, sc, pa);
+}
+template <class P>
+static int gauss_infer_impl(const dppo_net_desc& d, const float* prm, const char* pk, const dppo_gaussian_cfg& cfg,
+                            const float* logvar, const float* obs, const float* noise, const float* actions, int64_t N,
+                            float* out_actions, float* out_mean, float* out_logp, void* ws, int64_t wsb, hipStream_t s) {
+  Carver c{(char*)ws, 0, (size_t)wsb};
+  MlpBufs<P> A, Cb;
+  double *m, *sc, *pa;
+  const size_t need = carve_gauss<P>(c, d, nullptr, N, false, A, Cb, m, sc, pa);
+  if (!ws || (int64_t)need > wsb) return fail(-1, "workspace too small: need %zu bytes, got %lld", need, (long long)wsb);
+  const PackLayout L = pack_layout<P>(d, 0);
+  launch_build_direct<P>(nullptr, nullptr, obs, nullptr, 0, 0, d.cond_dim, N, A.in, L.Kp0, s);
+  mlp_forward<P>(d, prm, pk, L, N, A, false, s);
+  GaussArgs g;
+  memset(&g, 0, sizeof(g));
+  g.cfg = cfg, g.mean_pre = A.out, g.ldm = A.ldout, g.logvar = logvar, g.N = N, g.AF = d.out_dim;
+  if (out_actions) {
+    g.noise = noise, g.out_actions = out_actions, g.out_mean = out_mean;
+    launch_gauss_sample(g, s);
+  } else {
+    g.actions = actions, g.out_logp = out_logp;
+    launch_gauss_logprob(g, s);
+  }
+  return check_launch();
+}
+int dppo_gaussian_sample(const dppo_net_desc* actor, int prec, const float* params, const void* packed,
+                         const dppo_gaussian_cfg* cfg, const float* logvar, const float* obs, const float* noise,
+                         int64_t B, float* actions, float* mean_out, void* workspace, int64_t workspace_bytes,
+                         dppo_stream_t stream) {
+  if (int e = check_gauss(actor, cfg, logvar)) return e;
+  if (int e = check_prec(prec)) return e;
+  if (!params || !packed || !obs || !actions) return fail(-1, "null pointer");
+  if (B < 1 || B > 0x7fffffff) return fail(-1, "B out of range");
+#define CALL(P)                                                                                                        \
+  gauss_infer_impl<P>(*actor, params, (const char*)packed, *cfg, logvar, obs, noise, nullptr, B, actions, mean_out, nullptr, \
+                      workspace, workspace_bytes, (hipStream_t)stream)
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
+}
+int dppo_gaussian_logprob(const dppo_net_desc* actor, int prec, const float* params, const void* packed,
+                          const dppo_gaussian_cfg* cfg, const float* logvar, const float* obs, const float* actions,
+                          int64_t N, float* logp, void* workspace, int64_t workspace_bytes, dppo_stream_t stream) {
+  if (int e = check_gauss(actor, cfg, logvar)) return e;
+  if (int e = check_prec(prec)) return e;
+  if (!params || !packed || !obs || !actions || !logp) return fail(-1, "null pointer");
+  if (N < 1 || N > 0x7fffffff) return fail(-1, "N out of range");
+#define CALL(P)                                                                                                        \
+  gauss_infer_impl<P>(*actor, params, (const char*)packed, *cfg, logvar, obs, nullptr, actions, N, nullptr, nullptr, logp, \
+                      workspace, workspace_bytes, (hipStream_t)stream)
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
+}
+template <class P>
+static int gauss_ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float* ap, const char* ak, const float* cp,
+                          const char* ck, const dppo_gaussian_cfg& cfg, const float* logvar, const float* obs,
+                          const float* actions, const float* returns, const float* oldvalues, const float* adv,
+                          const float* oldlogp, int64_t N, const double* gmom, float* agrad, float* cgrad, float* lvgrad,
+                          double* stats, void* ws, int64_t wsb, hipStream_t s) {
+  Carver c{(char*)ws, 0, (size_t)wsb};
+  MlpBufs<P> A, Cb;
+  double *moments, *scratch, *partial;
+  const size_t need = carve_gauss<P>(c, a, &cr, N, true, A, Cb, moments, scratch, partial);
+  if ((int64_t)need > wsb) return fail(-1, "workspace too small: need %zu bytes, got %lld", need, (long long)wsb);
+  const PackLayout LA = pack_layout<P>(a, 0), LC = pack_layout<P>(cr, 0);
+  // the critic pipeline on the side stream beside the actor's forward (one fork here, one join at the end)
+  hipStream_t s2 = fork_side(s);
+  launch_build_direct<P>(nullptr, nullptr, obs, nullptr, 0, 0, cr.cond_dim, N, Cb.in, LC.Kp0, s2);
+  mlp_forward<P>(cr, cp, ck, LC, N, Cb, true, s2);
+  launch_build_direct<P>(nullptr, nullptr, obs, nullptr, 0, 0, a.cond_dim, N, A.in, LA.Kp0, s);
+  if (gmom == nullptr) launch_gauss_moments(adv, N, moments, scratch, s);
+  mlp_forward<P>(a, ap, ak, LA, N, A, true, s);
+  if (s2 != s) join_side(s, s2);  // the loss reads both outputs
+  GaussArgs g;
+  memset(&g, 0, sizeof(g));
+  g.cfg = cfg, g.mean_pre = A.out, g.ldm = A.ldout, g.logvar = logvar, g.actions = actions, g.N = N, g.AF = a.out_dim;
+  g.vnew = Cb.out, g.ldv = Cb.ldout, g.returns = returns, g.oldvalues = oldvalues, g.adv = adv, g.oldlogp = oldlogp;
+  g.moments = gmom ? gmom : moments, g.d_mean = A.d_out, g.lddm = LA.Kpo, g.d_v = Cb.d_out, g.lddv = LC.Kpo;
+  g.partial = partial, g.stats = stats, g.logvar_grad = lvgrad;
+  launch_gauss_loss<P>(g, s);
+  s2 = fork_side(s);
+  mlp_backward<P>(cr, cp, ck, LC, N, Cb, cgrad, nullptr, nullptr, 0, s2, false, -1);
+  mlp_backward<P>(a, ap, ak, LA, N, A, agrad, nullptr, nullptr, 0, s, false, 1);
+  if (s2 != s) join_side(s, s2);
+  return check_launch();
+}
+int dppo_gaussian_ppo_loss_fwd_bwd(const dppo_net_desc* actor, const dppo_net_desc* critic, int prec,
+                                   const float* actor_params, const void* actor_packed, const float* critic_params,
+                                   const void* critic_packed, const dppo_gaussian_cfg* cfg, const float* logvar,
+                                   const float* obs, const float* actions, const float* returns,
+                                   const float* oldvalues, const float* adv, const float* oldlogp, int64_t N,
+                                   const double* global_moments, float* actor_grad, float* critic_grad,
+                                   float* logvar_grad, double* stats, void* workspace, int64_t workspace_bytes,
+                                   dppo_stream_t stream) {
+  if (int e = check_gauss(actor, cfg, logvar)) return e;
+  if (int e = check_net(critic)) return e;
+  if (int e = check_prec(prec)) return e;
+  if (critic->kind != 1 || critic->out_dim != 1) return fail(-1, "critic descriptor must be kind 1 with out_dim 1");
+  if (actor->cond_dim != critic->cond_dim) return fail(-1, "actor and critic observe different cond_dim");
+  if (!actor_params || !actor_packed || !critic_params || !critic_packed || !obs || !actions || !returns || !oldvalues ||
+      !adv || !oldlogp || !actor_grad || !critic_grad || !stats || !workspace)
+    return fail(-1, "null pointer");
+  if (cfg->std_mode == 1 && !logvar_grad) return fail(-1, "std_mode 1 needs logvar_grad");
+  if (N < 2 || N > 0x7fffffff) return fail(-1, "N out of range");
+#define CALL(P)                                                                                                          \
+  gauss_ppo_impl<P>(*actor, *critic, actor_params, (const char*)actor_packed, critic_params, (const char*)critic_packed, *cfg, \
+                    logvar, obs, actions, returns, oldvalues, adv, oldlogp, N, global_moments, actor_grad, critic_grad,       \
+                    logvar_grad, stats, workspace, workspace_bytes, (hipStream_t)stream)
   return DPPO_DISPATCH(prec, CALL);
 #undef CALL
 }

@@ -135,6 +135,22 @@ __device__ __forceinline__ void with_act(int actk, F&& body) {
     body(ActTag<ACT_NONE>{});
 }
 
+// N(0,1) draw number `idx` of the stream keyed by (k0, k1): Philox4x32-10 on counter (idx, 0), Box-Muller on two of its
+// four words.  The counter is the element's index in the (n_steps+1, B, AF) noise tensor the host would have drawn.
+__device__ __forceinline__ float philox_normal(uint64_t idx, uint32_t k0, uint32_t k1) {
+  uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = 0, c3 = 0;
+#pragma unroll
+  for (int rnd = 0; rnd < 10; ++rnd) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0, c1 = lo1, c2 = hi0 ^ c3 ^ k1, c3 = lo0;
+    k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+  }
+  const float u1 = ((float)c0 + 1.f) * 2.3283064365386963e-10f;  // (0, 1]
+  const float u2 = (float)c1 * 2.3283064365386963e-10f;          // [0, 1)
+  return sqrtf(-2.f * __logf(u1)) * __cosf(6.283185307179586f * u2);
+}
+
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // Which features of its wave's 16*TPW-feature slice a lane owns in the streamed-weight kernels (sampler, fused):

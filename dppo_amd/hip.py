@@ -53,6 +53,16 @@ class PpoCfg(C.Structure):
                 ("clip_vloss_coef", C.c_double), ("adv_clip_lo", C.c_float), ("adv_clip_hi", C.c_float)]
 
 
+class GaussianCfg(C.Structure):  # struct dppo_gaussian_cfg
+    _fields_ = [("horizon_steps", C.c_int32), ("action_dim", C.c_int32), ("tanh_mean", C.c_int32), ("std_mode", C.c_int32),
+                ("norm_adv", C.c_int32), ("has_vclip", C.c_int32), ("deterministic", C.c_int32), ("pad", C.c_int32),
+                ("fixed_std", C.c_float), ("logvar_min", C.c_float), ("logvar_max", C.c_float), ("randn_clip", C.c_float),
+                ("clip_ploss_coef", C.c_double), ("clip_vloss_coef", C.c_double), ("seed_lo", C.c_uint32),
+                ("seed_hi", C.c_uint32)]
+
+
+GAUSS_STAT_ENTROPY, GAUSS_STAT_STD, GAUSS_STAT_COUNT = 7, 8, 9
+
 # numpy mirror of `dppo_step` (40 bytes) so schedules are built vectorised on the host
 STEP_DTYPE = np.dtype([("net", "<i4"), ("t", "<i4"), ("chain_slot", "<i4"), ("final_clip", "<i4"),
                        ("c0", "<f4"), ("c1", "<f4"), ("c2", "<f4"), ("c3", "<f4"), ("std", "<f4"), ("pad", "<f4")])
@@ -84,6 +94,11 @@ SYMBOLS = {
     "dppo_ppo_workspace_bytes": (_L, [_ND, _ND, _I, _L]),
     "dppo_ppo_loss_fwd_bwd": (_I, [_ND, _ND, _I, _P, _P, _P, _P, C.POINTER(DiffusionCfg), C.POINTER(PpoCfg), _P,
                                    _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P]),
+    "dppo_gaussian_workspace_bytes": (_L, [_ND, _ND, _I, _L]),
+    "dppo_gaussian_sample": (_I, [_ND, _I, _P, _P, C.POINTER(GaussianCfg), _P, _P, _P, _L, _P, _P, _P, _L, _P]),
+    "dppo_gaussian_logprob": (_I, [_ND, _I, _P, _P, C.POINTER(GaussianCfg), _P, _P, _P, _L, _P, _P, _L, _P]),
+    "dppo_gaussian_ppo_loss_fwd_bwd": (_I, [_ND, _ND, _I, _P, _P, _P, _P, C.POINTER(GaussianCfg), _P, _P, _P, _P, _P, _P,
+                                            _P, _L, _P, _P, _P, _P, _P, _P, _L, _P]),
     "dppo_grad_sq_norm": (_I, [_P, _L, _P, _P, _P]),
     "dppo_adamw_step": (_I, [_P, _P, _P, _P, _L, _I, _D, _D, _D, _D, _D, _P, _D, _P]),
     "dppo_adamw_step_dev": (_I, [_P, _P, _P, _P, _L, _P, _P, _D, _D, _D, _D, _P, _D, _P]),

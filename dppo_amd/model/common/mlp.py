@@ -75,6 +75,11 @@ class HipNet(nn.Module):
     def net_desc(self) -> hip.NetDesc:
         raise NotImplementedError
 
+    def trunk_parameters(self):
+        """The parameters the C ABI's flat layout covers, in state-dict order (default: all of them; a module with extra
+        parameters outside the trunk -- Gaussian_MLP's logvar -- narrows this)."""
+        return list(self.parameters())
+
     def __deepcopy__(self, memo):
         # default Module deepcopy would alias the private caches; copy parameters only
         cls = self.__class__
@@ -99,7 +104,7 @@ class HipNet(nn.Module):
             first, last = ps[0], ps[-1]
             if first.data_ptr() == flat.data_ptr() and last.data_ptr() == flat.data_ptr() + 4 * self._last_off:
                 return flat
-        ps = list(self.parameters())
+        ps = self.trunk_parameters()
         object.__setattr__(self, "_plist", ps)
         object.__setattr__(self, "_last_off", sum(p.numel() for p in ps[:-1]))
         flat = self._flat
@@ -140,7 +145,7 @@ class HipNet(nn.Module):
     def grad_views(self) -> List[torch.Tensor]:
         g = self.flat_grads()
         out, off = [], 0
-        for p in self.parameters():
+        for p in self.trunk_parameters():
             out.append(g[off:off + p.numel()].view(p.shape))
             off += p.numel()
         return out

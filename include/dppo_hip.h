@@ -48,11 +48,11 @@ extern "C" {
 typedef void* dppo_stream_t; /* hipStream_t */
 
 typedef struct dppo_net_desc {
-  int32_t kind;     /* 0 = actor (DiffusionMLP), 1 = critic (CriticObs)                     */
+  int32_t kind;     /* 0 = actor (DiffusionMLP), 1 = trunk on the observation (CriticObs; Gaussian_MLP mean) */
   int32_t in_dim;   /* actor: Ta*Da + time_dim + cond_dim ; critic: cond_dim                 */
   int32_t hidden;   /* H, multiple of 128                                                    */
   int32_t n_blocks; /* residual blocks = (len(mlp_dims)-1)/2                                  */
-  int32_t out_dim;  /* actor: Ta*Da ; critic: 1                                              */
+  int32_t out_dim;  /* actor: Ta*Da ; critic: 1 ; Gaussian actor (kind 1): Ta*Da                */
   int32_t act;      /* DPPO_ACT_*                                                            */
   int32_t time_dim; /* actor: td (even, >= 4) ; critic: 0                                    */
   int32_t act_flat; /* actor: Ta*Da ; critic: 0                                              */
@@ -234,6 +234,48 @@ int dppo_ppo_loss_fwd_bwd(const dppo_net_desc* actor, const dppo_net_desc* criti
                           const float* logprobs_k, const int64_t* inds, const int64_t* kinds, int64_t N,
                           const double* global_moments, float* actor_grad, float* critic_grad, double* stats,
                           void* workspace, int64_t workspace_bytes, dppo_stream_t stream);
+
+/* ---- Gaussian-policy PPO on the same trunk kernels --------------------------------------------
+ * Replaces model/common/mlp_gaussian.py:283-362 (Gaussian_MLP.forward, fixed / learned-per-dimension std),
+ * model/common/gaussian.py:63-121 (GaussianModel.forward_train / forward), model/rl/gaussian_vpg.py:46-62
+ * (get_logprobs) and model/rl/gaussian_ppo.py:39-128 (PPO_Gaussian.loss).  The actor is a trunk on the flattened
+ * observation: a kind-1 descriptor with out_dim = Ta*Da (a critic is the out_dim = 1 case). */
+typedef struct dppo_gaussian_cfg {
+  int32_t horizon_steps, action_dim;
+  int32_t tanh_mean;     /* Gaussian_MLP.tanh_output: mean = tanh(trunk output)                                 */
+  int32_t std_mode;      /* 0: fixed_std ; 1: sigma_j = exp(0.5 clamp(logvar[j], logvar_min, logvar_max)), j < Da */
+  int32_t norm_adv, has_vclip;
+  int32_t deterministic; /* forward_train(deterministic=True): sigma = 1e-4                                      */
+  int32_t pad;
+  float fixed_std, logvar_min, logvar_max, randn_clip;
+  double clip_ploss_coef, clip_vloss_coef;
+  uint32_t seed_lo, seed_hi; /* dppo_gaussian_sample with noise == NULL: key of the in-kernel Philox generator   */
+} dppo_gaussian_cfg;
+#define DPPO_GAUSS_STAT_ENTROPY 7 /* dist.entropy().mean()                                       */
+#define DPPO_GAUSS_STAT_STD 8     /* dist.scale.mean()                                           */
+#define DPPO_GAUSS_STAT_COUNT 9   /* stats[0..6] as DPPO_STAT_*                                  */
+int64_t dppo_gaussian_workspace_bytes(const dppo_net_desc* actor, const dppo_net_desc* critic, int prec, int64_t N);
+/* actions (B,Ta*Da) = mean + sigma * clamp(z, +-randn_clip); z = noise (B,Ta*Da) or, if NULL, drawn in the kernel.
+ * mean_out (B,Ta*Da) optional. */
+int dppo_gaussian_sample(const dppo_net_desc* actor, int prec, const float* params, const void* packed,
+                         const dppo_gaussian_cfg* cfg, const float* logvar, const float* obs, const float* noise,
+                         int64_t B, float* actions, float* mean_out, void* workspace, int64_t workspace_bytes,
+                         dppo_stream_t stream);
+/* logp (N,) = mean over Ta*Da of log N(actions; mean, sigma) */
+int dppo_gaussian_logprob(const dppo_net_desc* actor, int prec, const float* params, const void* packed,
+                          const dppo_gaussian_cfg* cfg, const float* logvar, const float* obs, const float* actions,
+                          int64_t N, float* logp, void* workspace, int64_t workspace_bytes, dppo_stream_t stream);
+/* obs (N,cond), actions (N,Ta*Da), returns / oldvalues / adv / oldlogp (N,).  global_moments as in
+ * dppo_ppo_loss_fwd_bwd.  Writes d pg_loss / d actor params, d v_loss / d critic params, d pg_loss / d logvar (Da; only
+ * std_mode 1, may be NULL otherwise) and stats[DPPO_GAUSS_STAT_COUNT]. */
+int dppo_gaussian_ppo_loss_fwd_bwd(const dppo_net_desc* actor, const dppo_net_desc* critic, int prec,
+                                   const float* actor_params, const void* actor_packed, const float* critic_params,
+                                   const void* critic_packed, const dppo_gaussian_cfg* cfg, const float* logvar,
+                                   const float* obs, const float* actions, const float* returns,
+                                   const float* oldvalues, const float* adv, const float* oldlogp, int64_t N,
+                                   const double* global_moments, float* actor_grad, float* critic_grad,
+                                   float* logvar_grad, double* stats, void* workspace, int64_t workspace_bytes,
+                                   dppo_stream_t stream);
 
 /* ---- A12: optimiser (torch.optim.AdamW + clip_grad_norm_ semantics) ----------------------- */
 /* out[0] = sum g^2 (float64), deterministic two-stage reduction; scratch >= 1024 doubles */

@@ -44,7 +44,7 @@ class NetSpec:
     actor: model/diffusion/mlp_diffusion.py:176-215; critic: model/common/critic.py:18-38.
     """
 
-    kind: str  # "actor" | "critic"
+    kind: str  # "actor" | "critic" | "gaussian" (Gaussian_MLP mean trunk on the observation)
     cond_dim: int  # To*Do
     mlp_dims: List[int]
     activation: str = "Mish"
@@ -62,7 +62,7 @@ class NetSpec:
 
     @property
     def in_dim(self) -> int:
-        if self.kind == "critic":
+        if self.kind in ("critic", "gaussian"):
             return self.cond_dim
         c = self.cond_mlp_dims[-1] if self.cond_mlp_dims else self.cond_dim
         return self.time_dim + self.act_flat + c
@@ -199,6 +199,15 @@ def named_specs(name: str) -> Tuple[NetSpec, NetSpec]:
         # (cfg/furniture/finetune/one_leg_low/ft_ppo_diffusion_mlp.yaml:16-23,98-113)
         return (NetSpec("actor", cond_dim=58, mlp_dims=[1024] * 7, activation="Mish", residual=True,
                         use_layernorm=True, action_dim=10, horizon_steps=8, time_dim=32, cond_mlp_dims=[512, 64]),
+                NetSpec("critic", cond_dim=58, mlp_dims=[512, 512, 512], activation="Mish", residual=True))
+    if name == "gauss_d3il":  # cfg/d3il/finetune/avoid_m1/ft_ppo_gaussian_mlp.yaml:84-102 (fixed std 0.1)
+        return (NetSpec("gaussian", cond_dim=4, mlp_dims=[256, 256, 256], activation="ReLU", residual=True, action_dim=2,
+                        horizon_steps=4),
+                NetSpec("critic", cond_dim=4, mlp_dims=[256, 256, 256], activation="Mish", residual=True))
+    if name == "gauss_furniture":  # cfg/furniture/finetune/one_leg_low/ft_ppo_gaussian_mlp.yaml:78-110, 2 blocks of 512
+        # instead of 5 of 1024 (learned per-dimension std, std in [0.01, 0.2])
+        return (NetSpec("gaussian", cond_dim=58, mlp_dims=[512] * 5, activation="ReLU", residual=True, action_dim=10,
+                        horizon_steps=8),
                 NetSpec("critic", cond_dim=58, mlp_dims=[512, 512, 512], activation="Mish", residual=True))
     if name == "plain_mlp":
         return (NetSpec("actor", cond_dim=11, mlp_dims=[64, 64], activation="Mish", residual=False,
@@ -630,6 +639,89 @@ def ppo_loss(cfg: DiffusionCfg, aspec: NetSpec, cspec: NetSpec, base: Params, ft
     else:
         v_loss = 0.5 * mean_((newv - returns) ** 2)
     return (pg, entropy_loss, v_loss, clipfrac, approx_kl.item(), mean_(ratio).item(), 0, eta.mean().item())
+
+
+# --------------------------------------------------------------------------
+# 8f row 4  Gaussian policy PPO
+# --------------------------------------------------------------------------
+@dataclass
+class GaussianCfg:
+    """Gaussian_MLP / PPO_Gaussian constructor values (model/common/mlp_gaussian.py:283-344, model/rl/gaussian_ppo.py:21-37)."""
+
+    fixed_std: float = 0.1
+    learn_fixed_std: bool = False
+    std_min: float = 0.01
+    std_max: float = 1.0
+    tanh_output: bool = True
+    clip_ploss_coef: float = 0.01
+    clip_vloss_coef: Optional[float] = None
+    norm_adv: bool = True
+    randn_clip_value: float = 10.0
+
+
+def gaussian_dist(gc: GaussianCfg, spec: NetSpec, p: Params, logvar: Optional[torch.Tensor], state: torch.Tensor,
+                  deterministic: bool = False):
+    """(mean, scale), both (B, Ta*Da): Gaussian_MLP.forward (mlp_gaussian.py:346-362) + forward_train (gaussian.py:63-79)."""
+    B = state.shape[0]
+    mean = trunk_forward(p, spec, state.reshape(B, -1))
+    if gc.tanh_output:
+        mean = torch.tanh(mean)
+    if deterministic:
+        return mean, torch.ones_like(mean) * 1e-4
+    if gc.learn_fixed_std:
+        lv = torch.clamp(logvar, math.log(gc.std_min ** 2), math.log(gc.std_max ** 2))
+        scale = torch.exp(0.5 * lv).view(1, spec.action_dim).repeat(B, spec.horizon_steps)
+    else:
+        scale = torch.ones_like(mean) * gc.fixed_std
+    return mean, scale
+
+
+def gaussian_sample(gc: GaussianCfg, spec: NetSpec, p: Params, logvar, state, noise, deterministic=False):
+    """GaussianModel.forward (gaussian.py:81-121): loc + scale z, clamped to loc +- randn_clip_value scale."""
+    mean, scale = gaussian_dist(gc, spec, p, logvar, state, deterministic)
+    a = mean + scale * noise.reshape(mean.shape)
+    a = torch.max(torch.min(a, mean + gc.randn_clip_value * scale), mean - gc.randn_clip_value * scale)
+    return a.view(state.shape[0], spec.horizon_steps, -1)
+
+
+def gaussian_logprob(gc: GaussianCfg, spec: NetSpec, p: Params, logvar, state, actions):
+    """VPG_Gaussian.get_logprobs (gaussian_vpg.py:46-62): (log_prob (B,), entropy, std)."""
+    mean, scale = gaussian_dist(gc, spec, p, logvar, state)
+    dist = torch.distributions.Normal(mean, scale)
+    return dist.log_prob(actions.reshape(mean.shape)).mean(-1), dist.entropy().mean(), dist.scale.mean()
+
+
+def gaussian_ppo_loss(gc: GaussianCfg, aspec: NetSpec, cspec: NetSpec, ft: Params, logvar, critic: Params, obs, actions,
+                      returns, oldvalues, advantages, oldlogprobs, global_moments=None):
+    """PPO_Gaussian.loss without the BC term (gaussian_ppo.py:39-128): (pg, entropy_loss, v, clipfrac, kl, ratio, 0, std)."""
+    newlp, entropy, std = gaussian_logprob(gc, aspec, ft, logvar, obs, actions)
+    newlp = newlp.clamp(min=-5, max=2)
+    oldlp = oldlogprobs.clamp(min=-5, max=2)
+    logratio = newlp - oldlp
+    ratio = logratio.exp()
+    n_glob = float(advantages.numel())
+    mean_ = lambda x: x.mean()
+    adv = advantages
+    if global_moments is not None:
+        g_sum, g_sq, n_glob = (float(v) for v in global_moments)
+        g_mean = g_sum / n_glob
+        g_std = math.sqrt(max((g_sq - n_glob * g_mean * g_mean) / (n_glob - 1.0), 0.0))
+        mean_ = lambda x: x.sum() / n_glob
+        if gc.norm_adv:
+            adv = (adv - float(np.float32(g_mean))) / (float(np.float32(g_std)) + 1e-8)
+    elif gc.norm_adv:
+        adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+    with torch.no_grad():
+        approx_kl = mean_((ratio - 1) - logratio)
+        clipfrac = mean_(((ratio - 1.0).abs() > gc.clip_ploss_coef).float()).item()
+    pg = mean_(torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1 - gc.clip_ploss_coef, 1 + gc.clip_ploss_coef)))
+    newv = critic_forward(critic, cspec, obs).view(-1)
+    if gc.clip_vloss_coef is not None:
+        vcl = oldvalues + torch.clamp(newv - oldvalues, -gc.clip_vloss_coef, gc.clip_vloss_coef)
+        v_loss = 0.5 * mean_(torch.max((newv - returns) ** 2, (vcl - returns) ** 2))
+    else:
+        v_loss = 0.5 * mean_((newv - returns) ** 2)
+    return pg, -entropy, v_loss, clipfrac, approx_kl.item(), mean_(ratio).item(), 0.0, std.item()
 
 
 # --------------------------------------------------------------------------

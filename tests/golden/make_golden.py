@@ -408,6 +408,70 @@ def g11_eval():
     save("g11_eval", **out)
 
 
+# ---------------------------------------------------------------- G12 Gaussian-policy PPO
+from make_golden_cases import GAUSS_CASES  # noqa: E402
+
+
+def gauss_logvar(spec, kw, seed):
+    """Seeded per-dimension log-variance: the constructor's log(fixed_std^2) plus U(-0.4, 0.4) (some entries leave the
+    clamp range of the `gauss_nonorm` case on purpose)."""
+    rs = np.random.RandomState(seed)
+    return torch.from_numpy((np.log(kw["fixed_std"] ** 2) + rs.uniform(-0.4, 0.4, size=spec.action_dim)).astype(np.float32))
+
+
+def g12_gaussian():
+    """PPO_Gaussian (model/rl/gaussian_ppo.py) over Gaussian_MLP (model/common/mlp_gaussian.py:283-362) + CriticObs:
+    sampling with recorded noise, get_logprobs, loss 8-tuple and every gradient (incl. the learned logvar's)."""
+    from dppo.model.common.mlp_gaussian import Gaussian_MLP
+    from dppo.model.rl.gaussian_ppo import PPO_Gaussian
+    out = {}
+    rs = np.random.RandomState(1200)
+    N = 64
+    for cname, (sname, kw) in GAUSS_CASES.items():
+        a, c = specs(sname)
+        actor = Gaussian_MLP(action_dim=a.action_dim, horizon_steps=a.horizon_steps, cond_dim=a.cond_dim,
+                             mlp_dims=list(a.mlp_dims), activation_type=a.activation, residual_style=True,
+                             fixed_std=kw["fixed_std"], learn_fixed_std=kw["learn_fixed_std"], std_min=kw["std_min"],
+                             std_max=kw["std_max"])
+        sd = dict(O.init_params(a, 71))
+        sd["logvar_min"], sd["logvar_max"] = actor.logvar_min.data.clone(), actor.logvar_max.data.clone()
+        if kw["learn_fixed_std"]:
+            sd["logvar"] = gauss_logvar(a, kw, 73)
+        actor.load_state_dict(sd, strict=True)
+        m = PPO_Gaussian(actor=actor, critic=ref_critic(c, O.init_params(c, 72)), horizon_steps=a.horizon_steps, device="cpu",
+                         clip_ploss_coef=kw["clip_ploss_coef"], clip_vloss_coef=kw.get("clip_vloss_coef"),
+                         norm_adv=kw.get("norm_adv", True), randn_clip_value=kw["randn_clip_value"])
+        state = torch.from_numpy(rs.uniform(-1, 1, size=(N, 1, a.cond_dim)).astype(np.float32))
+        noise = torch.from_numpy(rs.randn(N, a.horizon_steps * a.action_dim).astype(np.float32))
+        normal0 = torch.normal
+        torch.normal = lambda loc, scale, *a_, **k_: loc + scale * noise  # dist.sample() -> torch.normal(loc, scale)
+        try:
+            actions = m(cond={"state": state}, deterministic=False)
+            det = m(cond={"state": state}, deterministic=True)
+        finally:
+            torch.normal = normal0
+        with torch.no_grad():
+            lp, ent, std = m.get_logprobs({"state": state}, actions)
+        oldlp = lp + torch.from_numpy(rs.normal(0, 0.02, N).astype(np.float32))
+        with torch.no_grad():
+            oldv = m.critic({"state": state}).view(-1) + torch.from_numpy(rs.normal(0, 0.3, N).astype(np.float32))
+        ret = torch.from_numpy(rs.normal(0, 1, N).astype(np.float32))
+        adv = torch.from_numpy(rs.normal(0.3, 2.0, N).astype(np.float32))
+        res = m.loss({"state": state}, actions, ret, oldv, adv.clone(), oldlp, use_bc_loss=False)
+        (res[0] + 0.01 * res[1] + 0.5 * res[2]).backward()
+        out.update({f"{cname}_state": state, f"{cname}_noise": noise, f"{cname}_actions": actions, f"{cname}_actions_det": det,
+                    f"{cname}_logprobs": lp, f"{cname}_entropy": np.float64(ent.item()), f"{cname}_std": np.float64(std.item()),
+                    f"{cname}_oldlogprobs": oldlp, f"{cname}_oldvalues": oldv, f"{cname}_returns": ret, f"{cname}_adv": adv,
+                    f"{cname}_stats": np.array([res[0].item(), res[1].item(), res[2].item(), res[3], res[4], res[5],
+                                                float(res[6]), res[7]], dtype=np.float64)})
+        for k, p in m.actor_ft.named_parameters():
+            if p.grad is not None:
+                put_grad(out, f"{cname}_gactor_{k}", p.grad)
+        for k, p in m.critic.named_parameters():
+            put_grad(out, f"{cname}_gcritic_{k}", p.grad)
+    save("g12_gaussian", **out)
+
+
 # ---------------------------------------------------------------- G10 LR schedule trace
 from make_golden_cases import SCHED_CASES  # noqa: E402
 
@@ -432,6 +496,6 @@ def g10_scheduler():
 
 if __name__ == "__main__":
     only = sys.argv[1:]  # e.g. `make_golden.py g8_bc` regenerates one file (each generator owns its RNG stream)
-    for fn in (g1_tables, g2_forward, g3_g4_chains, g5_loss, g6_reward_scaler, g7_adamw, g8_bc, g9_denoise_mse, g10_scheduler, g11_eval):
+    for fn in (g1_tables, g2_forward, g3_g4_chains, g5_loss, g6_reward_scaler, g7_adamw, g8_bc, g9_denoise_mse, g10_scheduler, g11_eval, g12_gaussian):
         if not only or fn.__name__ in only:
             fn()

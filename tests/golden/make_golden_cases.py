@@ -13,3 +13,13 @@ EVAL_CASES = {
     "eval_ddim_ft5": ("hopper", 5, dict(denoising_steps=100, use_ddim=True, ddim_steps=5, randn_clip_value=3), 5, "rl"),
     "eval_pretrained_can": ("can", 4, dict(denoising_steps=20, randn_clip_value=3, final_action_clip_value=1.0), 0, "pretrain"),
 }
+
+GAUSS_CASES = {
+    # name: (spec, GaussianCfg kwargs)
+    "gauss_d3il_fixed": ("gauss_d3il", dict(fixed_std=0.1, learn_fixed_std=False, std_min=0.01, std_max=1.0,
+                                            clip_ploss_coef=0.1, randn_clip_value=3)),
+    "gauss_furniture_learned": ("gauss_furniture", dict(fixed_std=0.04, learn_fixed_std=True, std_min=0.01, std_max=0.2,
+                                                        clip_ploss_coef=0.01, clip_vloss_coef=0.2, randn_clip_value=3)),
+    "gauss_nonorm": ("gauss_d3il", dict(fixed_std=0.1, learn_fixed_std=True, std_min=0.05, std_max=0.12,
+                                        clip_ploss_coef=0.02, norm_adv=False, randn_clip_value=3)),
+}
