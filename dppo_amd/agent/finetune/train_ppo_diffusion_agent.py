@@ -114,7 +114,7 @@ class TrainPPODiffusionAgent:
         self.bc_loss_coeff = cfg.train.get("bc_loss_coeff", 0)
         # ---- TrainPPODiffusionAgent (:22-45)
         self.reward_horizon = cfg.get("reward_horizon", self.act_steps)
-        self.learn_eta = self.model.learn_eta
+        self.learn_eta = getattr(self.model, "learn_eta", False)
 
     @staticmethod
     def reseed(seed: int):
@@ -157,7 +157,7 @@ class TrainPPODiffusionAgent:
     # -------------------------------------------------------------------------------------------------
     def run(self):
         model, dev = self.model, self.device
-        Kft = model.ft_denoising_steps
+        Kft = getattr(model, "ft_denoising_steps", 0)  # 0: a one-shot (Gaussian) policy, the "chain" is the action itself
         AF = self.horizon_steps * self.action_dim
         S, E = self.n_steps, self.n_envs
         R = S * E
@@ -186,7 +186,7 @@ class TrainPPODiffusionAgent:
             # ---------------- rollout: sample on the GPU, step envs on the host (:101-151); pinned hand-off, env groups
             # (env.pipeline_groups) software-pipelined against the sampler (dppo_amd/util/rollout.py)
             reward_trajs, terminated_trajs, done_trajs, prev_obs = collect_rollout(
-                model, self.venv, prev_obs, S, self.act_steps, obs_buf, chains_buf, deterministic=eval_mode)
+                self._policy(), self.venv, prev_obs, S, self.act_steps, obs_buf, chains_buf, deterministic=eval_mode)
             firsts[1:] = done_trajs
             done_venv = done_trajs[-1].astype(bool)
             cnt_train_step += S * E * self.act_steps * self.world if not eval_mode else 0
@@ -212,7 +212,8 @@ class TrainPPODiffusionAgent:
             if self.itr >= self.n_critic_warmup_itr:
                 self.actor_lr_scheduler.step()
             self.critic_lr_scheduler.step()
-            model.step()
+            if hasattr(model, "step"):
+                model.step()
             if self.itr % self.save_model_freq == 0 or self.itr == self.n_train_itr - 1:
                 self.save_model()
             rec = {"itr": self.itr, "step": cnt_train_step}
@@ -235,6 +236,10 @@ class TrainPPODiffusionAgent:
                     pickle.dump(run_results, f)
             self.itr += 1
         return run_results
+
+    def _policy(self):
+        """What collect_rollout calls per env step: (cond, deterministic, return_chain[, out]) -> Sample."""
+        return self.model
 
     # -------------------------------------------------------------------------------------------------
     def _update(self, obs_buf, chains_buf, values_buf, logp_buf, reward_trajs, terminated_trajs, firsts, last_obs, R,

@@ -239,3 +239,56 @@ def test_torch_optimizer_steps_and_load_state_dict_refresh_the_kernel_images():
     after = m(cond={"state": state}, noise=noise).chains
     assert (after - before).abs().max().item() > 1e-3
     assert (m.critic({"state": state}) - twin.critic({"state": state})).abs().max().item() > 1e-4
+
+
+GAUSS_YAML = YAML.replace(
+    "dppo.agent.finetune.train_ppo_diffusion_agent.TrainPPODiffusionAgent",
+    "dppo.agent.finetune.train_ppo_gaussian_agent.TrainPPOGaussianAgent")
+GAUSS_YAML = GAUSS_YAML[:GAUSS_YAML.index("    model:\n")] if "    model:\n" in GAUSS_YAML else GAUSS_YAML[:GAUSS_YAML.index("model:\n")]
+GAUSS_YAML += textwrap.dedent("""
+    model:
+      _target_: dppo.model.rl.gaussian_ppo.PPO_Gaussian
+      clip_ploss_coef: 0.01
+      randn_clip_value: 3
+      network_path: null
+      actor:
+        _target_: dppo.model.common.mlp_gaussian.Gaussian_MLP
+        mlp_dims: [256, 256, 256]
+        activation_type: ReLU
+        residual_style: True
+        fixed_std: 0.1
+        learn_fixed_std: True
+        std_min: 0.01
+        std_max: 0.2
+        cond_dim: ${eval:'${obs_dim} * ${cond_steps}'}
+        horizon_steps: ${horizon_steps}
+        action_dim: ${action_dim}
+      critic:
+        _target_: dppo.model.common.critic.CriticObs
+        cond_dim: ${eval:'${obs_dim} * ${cond_steps}'}
+        mlp_dims: [256, 256, 256]
+        activation_type: Mish
+        residual_style: True
+      horizon_steps: ${horizon_steps}
+      device: ${device}
+""")
+
+
+def test_gaussian_agent_runs_and_updates_policy_value_and_std(tmp_path, monkeypatch):
+    from dppo_amd.cfg.loader import get_class, load_config
+    monkeypatch.setenv("DPPO_LOG_DIR", str(tmp_path))
+    p = tmp_path / "ft_gauss.yaml"
+    p.write_text(GAUSS_YAML.replace("      ent_coef: 0\n", "").replace("      vf_coef: 0.5\n", "      vf_coef: 0.5\n      ent_coef: 0.01\n"))
+    cfg = load_config(str(p))
+    agent = get_class(cfg._target_)(cfg)
+    w0 = agent.model.actor_ft.flat_params().clone()
+    c0 = agent.model.critic.flat_params().clone()
+    lv0 = agent.model.actor_ft.logvar.detach().clone()
+    base0 = agent.model.actor.flat_params().clone()
+    res = agent.run()
+    assert len(res) == 3 and "pg_loss" in res[1] and np.isfinite(res[1]["loss"]) and 0.01 <= res[1]["std"] <= 0.2
+    assert not torch.equal(agent.model.actor_ft.flat_params(), w0) and not torch.equal(agent.model.critic.flat_params(), c0)
+    assert not torch.equal(agent.model.actor_ft.logvar.detach(), lv0), "the learned std was not stepped"
+    assert torch.equal(agent.model.actor.flat_params(), base0)
+    ck = torch.load(os.path.join(str(tmp_path), "synthetic", "checkpoint", "state_2.pt"), weights_only=True)
+    assert "actor_ft.logvar" in ck["model"] and "actor_ft.mlp_mean.layers.1.l1.weight" in ck["model"]
