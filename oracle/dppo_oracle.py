@@ -336,7 +336,13 @@ def trunk_forward(p: Params, spec: NetSpec, x: torch.Tensor) -> torch.Tensor:
     return F.linear(h, p[f"{t}.layers.{n_blocks + 1}.weight"], p[f"{t}.layers.{n_blocks + 1}.bias"])
 
 
-def actor_forward(p: Params, spec: NetSpec, x: torch.Tensor, t: torch.Tensor, state: torch.Tensor) -> torch.Tensor:
+def actor_forward(p: Params, spec, x: torch.Tensor, t: torch.Tensor, state: torch.Tensor) -> torch.Tensor:
+    if getattr(spec, "kind", "") == "unet":  # conv denoiser (8f row 2): same (x, t, state) -> eps contract
+        return unet_forward(p, spec, x, t, state)
+    return _mlp_actor_forward(p, spec, x, t, state)
+
+
+def _mlp_actor_forward(p: Params, spec: NetSpec, x: torch.Tensor, t: torch.Tensor, state: torch.Tensor) -> torch.Tensor:
     """DiffusionMLP.forward, model/diffusion/mlp_diffusion.py:218-250.
 
     x (B,Ta,Da), t (B,) int, state (B,To,Do) -> (B,Ta,Da).
@@ -639,6 +645,178 @@ def ppo_loss(cfg: DiffusionCfg, aspec: NetSpec, cspec: NetSpec, base: Params, ft
     else:
         v_loss = 0.5 * mean_((newv - returns) ** 2)
     return (pg, entropy_loss, v_loss, clipfrac, approx_kl.item(), mean_(ratio).item(), 0, eta.mean().item())
+
+
+# --------------------------------------------------------------------------
+# 8f row 2  conv denoiser (Unet1D)
+# --------------------------------------------------------------------------
+@dataclass
+class UnetSpec:
+    """Unet1D constructor values (model/diffusion/unet.py:123-137).  ``kind`` lets it travel where a NetSpec does."""
+
+    action_dim: int
+    cond_dim: int
+    horizon_steps: int
+    diffusion_step_embed_dim: int = 16
+    dim: int = 64
+    dim_mults: Sequence[int] = (1, 2)
+    kernel_size: int = 5
+    n_groups: int = 8
+    smaller_encoder: bool = False
+    cond_predict_scale: bool = True
+    activation: str = "Mish"
+    groupnorm_eps: float = 1e-5
+    kind: str = "unet"
+
+    @property
+    def act_flat(self) -> int:
+        return self.action_dim * self.horizon_steps
+
+    @property
+    def cond_block_dim(self) -> int:
+        return self.diffusion_step_embed_dim + self.cond_dim
+
+    def blocks(self) -> List[Tuple[str, int, int]]:
+        """(state-dict prefix, in_channels, out_channels) of every ResidualBlock1D, in state-dict order (:152-243)."""
+        dims = [self.action_dim] + [self.dim * m for m in self.dim_mults]
+        in_out = list(zip(dims[:-1], dims[1:]))
+        out = [(f"mid_modules.{i}", dims[-1], dims[-1]) for i in range(2)]
+        for i, (ci, co) in enumerate(in_out):
+            out += [(f"down_modules.{i}.0", ci, co), (f"down_modules.{i}.1", co, co)]
+        for i, (ci, co) in enumerate(reversed(in_out[1:])):
+            out += [(f"up_modules.{i}.0", co * 2, ci), (f"up_modules.{i}.1", ci, ci)]
+        return out
+
+
+def unet_param_shapes(spec: UnetSpec) -> List[Tuple[str, Tuple[int, ...], int]]:
+    """Ordered (name, shape, fan_in) in the reference's state-dict order; fan_in 0 marks GroupNorm affine parameters."""
+    out: List[Tuple[str, Tuple[int, ...], int]] = []
+    d, k = spec.diffusion_step_embed_dim, spec.kernel_size
+
+    def lin(name, i, o):
+        out.append((f"{name}.weight", (o, i), i))
+        out.append((f"{name}.bias", (o,), i))
+
+    def conv(name, ci, co, ks):
+        out.append((f"{name}.weight", (co, ci, ks), ci * ks))
+        out.append((f"{name}.bias", (co,), ci * ks))
+
+    def convblock(name, ci, co):
+        conv(f"{name}.block.0", ci, co, k)
+        out.append((f"{name}.block.2.weight", (co,), 0))
+        out.append((f"{name}.block.2.bias", (co,), 0))
+
+    def resblock(name, ci, co):
+        convblock(f"{name}.blocks.0", ci, co)
+        convblock(f"{name}.blocks.1", co, co)
+        cc = co * 2 if spec.cond_predict_scale else co
+        if not spec.smaller_encoder:  # larger encoder: Linear, act, Linear, act, Linear (:76-84)
+            lin(f"{name}.cond_encoder.0", spec.cond_block_dim, cc)
+            lin(f"{name}.cond_encoder.2", cc, cc)
+            lin(f"{name}.cond_encoder.4", cc, cc)
+        else:  # act, Linear (:86-90)
+            lin(f"{name}.cond_encoder.1", spec.cond_block_dim, cc)
+        if ci != co:
+            conv(f"{name}.residual_conv", ci, co, 1)
+
+    lin("time_mlp.1", d, 4 * d)
+    lin("time_mlp.3", 4 * d, d)
+    dims = [spec.action_dim] + [spec.dim * m for m in spec.dim_mults]
+    n_lvl = len(dims) - 1
+    blocks = spec.blocks()
+    for name, ci, co in blocks[:2]:
+        resblock(name, ci, co)
+    for i in range(n_lvl):
+        for name, ci, co in blocks[2 + 2 * i:4 + 2 * i]:
+            resblock(name, ci, co)
+        if i < n_lvl - 1:
+            conv(f"down_modules.{i}.2.conv", dims[i + 1], dims[i + 1], 3)
+    ups = blocks[2 + 2 * n_lvl:]
+    for i in range(n_lvl - 1):
+        for name, ci, co in ups[2 * i:2 * i + 2]:
+            resblock(name, ci, co)
+        c = ups[2 * i + 1][2]
+        # ConvTranspose1d weight is (in, out, k); `is_last` is never true inside the loop (:219-222), so every level upsamples
+        out.append((f"up_modules.{i}.2.conv.weight", (c, c, 4), c * 4))
+        out.append((f"up_modules.{i}.2.conv.bias", (c,), c * 4))
+    convblock("final_conv.0", spec.dim, spec.dim)
+    conv("final_conv.1", spec.dim, spec.action_dim, 1)
+    return out
+
+
+def unet_init_params(spec: UnetSpec, seed: int) -> Params:
+    rs = np.random.RandomState(seed)
+    p: Params = {}
+    for name, shape, fan_in in unet_param_shapes(spec):
+        if fan_in > 0:
+            b = 1.0 / math.sqrt(fan_in)
+            a = rs.uniform(-b, b, size=shape)
+        elif name.endswith("weight"):
+            a = rs.uniform(0.5, 1.5, size=shape)
+        else:
+            a = rs.uniform(-0.1, 0.1, size=shape)
+        p[name] = torch.from_numpy(a.astype(np.float32))
+    return p
+
+
+def conv1d_block(p: Params, name: str, x: torch.Tensor, spec: UnetSpec) -> torch.Tensor:
+    """Conv1d -> GroupNorm -> act (model/diffusion/modules.py:50-95).  x (B, C, T)."""
+    k = p[f"{name}.block.0.weight"].shape[-1]
+    y = F.conv1d(x, p[f"{name}.block.0.weight"], p[f"{name}.block.0.bias"], padding=k // 2)
+    y = F.group_norm(y, spec.n_groups, p[f"{name}.block.2.weight"], p[f"{name}.block.2.bias"], spec.groupnorm_eps)
+    return _ACT[spec.activation](y)
+
+
+def residual_block1d(p: Params, name: str, x: torch.Tensor, cond: torch.Tensor, spec: UnetSpec) -> torch.Tensor:
+    """ResidualBlock1D.forward (unet.py:100-118): conv block, FiLM from the conditioning vector, conv block, skip."""
+    act = _ACT[spec.activation]
+    out = conv1d_block(p, f"{name}.blocks.0", x, spec)
+    if not spec.smaller_encoder:
+        e = F.linear(cond, p[f"{name}.cond_encoder.0.weight"], p[f"{name}.cond_encoder.0.bias"])
+        e = F.linear(act(e), p[f"{name}.cond_encoder.2.weight"], p[f"{name}.cond_encoder.2.bias"])
+        e = F.linear(act(e), p[f"{name}.cond_encoder.4.weight"], p[f"{name}.cond_encoder.4.bias"])
+    else:
+        e = F.linear(act(cond), p[f"{name}.cond_encoder.1.weight"], p[f"{name}.cond_encoder.1.bias"])
+    e = e.unsqueeze(-1)
+    co = out.shape[1]
+    if spec.cond_predict_scale:
+        e = e.reshape(e.shape[0], 2, co, 1)
+        out = e[:, 0] * out + e[:, 1]
+    else:
+        out = out + e
+    out = conv1d_block(p, f"{name}.blocks.1", out, spec)
+    if f"{name}.residual_conv.weight" in p:
+        x = F.conv1d(x, p[f"{name}.residual_conv.weight"], p[f"{name}.residual_conv.bias"])
+    return out + x
+
+
+def unet_forward(p: Params, spec: UnetSpec, x: torch.Tensor, t: torch.Tensor, state: torch.Tensor) -> torch.Tensor:
+    """Unet1D.forward (unet.py:264-327).  x (B, Ta, Da), t (B,) int64, state (B, To, Do) -> (B, Ta, Da)."""
+    B = x.shape[0]
+    h = x.transpose(1, 2)  # channels = action dims, length = chunk steps
+    d = spec.diffusion_step_embed_dim
+    emb = sinusoidal(t, d)
+    g = F.linear(mish(F.linear(emb, p["time_mlp.1.weight"], p["time_mlp.1.bias"])), p["time_mlp.3.weight"],
+                 p["time_mlp.3.bias"])
+    g = torch.cat([g, state.reshape(B, -1)], dim=-1)
+    n_lvl = len(spec.dim_mults)
+    skips = []
+    for i in range(n_lvl):
+        h = residual_block1d(p, f"down_modules.{i}.0", h, g, spec)
+        h = residual_block1d(p, f"down_modules.{i}.1", h, g, spec)
+        skips.append(h)
+        if i < n_lvl - 1:
+            h = F.conv1d(h, p[f"down_modules.{i}.2.conv.weight"], p[f"down_modules.{i}.2.conv.bias"], stride=2, padding=1)
+    for i in range(2):
+        h = residual_block1d(p, f"mid_modules.{i}", h, g, spec)
+    for i in range(n_lvl - 1):
+        h = torch.cat((h, skips.pop()), dim=1)
+        h = residual_block1d(p, f"up_modules.{i}.0", h, g, spec)
+        h = residual_block1d(p, f"up_modules.{i}.1", h, g, spec)
+        h = F.conv_transpose1d(h, p[f"up_modules.{i}.2.conv.weight"], p[f"up_modules.{i}.2.conv.bias"], stride=2, padding=1)
+    h = conv1d_block(p, "final_conv.0", h, spec)
+    h = F.conv1d(h, p["final_conv.1.weight"], p["final_conv.1.bias"])
+    return h.transpose(1, 2)
 
 
 # --------------------------------------------------------------------------

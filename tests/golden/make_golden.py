@@ -472,6 +472,65 @@ def g12_gaussian():
     save("g12_gaussian", **out)
 
 
+# ---------------------------------------------------------------- G13 conv denoiser (Unet1D)
+from make_golden_cases import UNET_CHAIN_CASES, UNET_SPECS  # noqa: E402
+
+
+def ref_unet(spec, params):
+    from dppo.model.diffusion.unet import Unet1D
+    m = Unet1D(action_dim=spec.action_dim, cond_dim=spec.cond_dim, diffusion_step_embed_dim=spec.diffusion_step_embed_dim,
+               dim=spec.dim, dim_mults=list(spec.dim_mults), smaller_encoder=spec.smaller_encoder,
+               kernel_size=spec.kernel_size, n_groups=spec.n_groups, activation_type=spec.activation,
+               cond_predict_scale=spec.cond_predict_scale, groupnorm_eps=spec.groupnorm_eps)
+    m.load_state_dict(params, strict=True)  # strict: the oracle's parameter list IS the reference's state dict
+    return m
+
+
+def g13_unet():
+    """Unet1D.forward (model/diffusion/unet.py:264-327), one ResidualBlock1D (:100-118), one Conv1dBlock
+    (modules.py:50-95), and K-step chains + log-probs of a PPODiffusion whose actor is the UNet."""
+    out = {}
+    rs = np.random.RandomState(1300)
+    for name, kw in UNET_SPECS.items():
+        u = O.UnetSpec(**kw)
+        p = O.unet_init_params(u, 81)
+        net = ref_unet(u, p)
+        B = 6
+        x = torch.from_numpy(rs.randn(B, u.horizon_steps, u.action_dim).astype(np.float32))
+        t = torch.from_numpy(rs.randint(0, 20, size=(B,)).astype(np.int64))
+        s = torch.from_numpy(rs.uniform(-1, 1, size=(B, 1, u.cond_dim)).astype(np.float32))
+        with torch.no_grad():
+            y = net(x, t, cond={"state": s})
+            # pieces, fed with recorded inputs
+            blk = net.down_modules[1][0]
+            ci = blk.blocks[0].block[0].in_channels
+            bx = torch.from_numpy(rs.randn(B, ci, u.horizon_steps // 2).astype(np.float32))
+            bc = torch.from_numpy(rs.randn(B, u.cond_block_dim).astype(np.float32))
+            by = blk(bx, bc)
+            cy = net.final_conv[0](bx[:, :u.dim].repeat(1, 2, 1)[:, :u.dim])
+        out.update({f"{name}_x": x, f"{name}_t": t, f"{name}_state": s, f"{name}_eps": y, f"{name}_blk_x": bx,
+                    f"{name}_blk_cond": bc, f"{name}_blk_y": by, f"{name}_cb_y": cy})
+    for cname, (sname, B, kw, det) in UNET_CHAIN_CASES.items():
+        u = O.UnetSpec(**UNET_SPECS[sname])
+        _, c = specs("hopper")
+        c = O.NetSpec("critic", cond_dim=u.cond_dim, mlp_dims=[256, 256, 256], activation="Mish", residual=True)
+        kw2 = dict(kw, eta=EtaFixed(base_eta=1.0)) if kw.get("use_ddim") else kw
+        m = PPODiffusion(actor=ref_unet(u, O.unet_init_params(u, 21)), critic=ref_critic(c, O.init_params(c, 23)),
+                         horizon_steps=u.horizon_steps, obs_dim=u.cond_dim, action_dim=u.action_dim, device="cpu",
+                         gamma_denoising=0.99, clip_ploss_coef=0.01, **kw2)
+        m.actor_ft.load_state_dict(O.unet_init_params(u, 22), strict=True)
+        n_steps = kw["ddim_steps"] if kw.get("use_ddim") else kw["denoising_steps"]
+        state = torch.from_numpy(rs.uniform(-1, 1, size=(B, 1, u.cond_dim)).astype(np.float32))
+        noise = torch.from_numpy(rs.randn(n_steps + 1, B, u.horizon_steps, u.action_dim).astype(np.float32))
+        with recorded_noise(list(noise)):
+            smp = m(cond={"state": state}, deterministic=det, return_chain=True)
+        with torch.no_grad():
+            lp = m.get_logprobs({"state": state}, smp.chains)
+        out.update({f"{cname}_state": state, f"{cname}_noise": noise, f"{cname}_traj": smp.trajectories,
+                    f"{cname}_chains": smp.chains, f"{cname}_logprobs": lp})
+    save("g13_unet", **out)
+
+
 # ---------------------------------------------------------------- G10 LR schedule trace
 from make_golden_cases import SCHED_CASES  # noqa: E402
 
@@ -496,6 +555,6 @@ def g10_scheduler():
 
 if __name__ == "__main__":
     only = sys.argv[1:]  # e.g. `make_golden.py g8_bc` regenerates one file (each generator owns its RNG stream)
-    for fn in (g1_tables, g2_forward, g3_g4_chains, g5_loss, g6_reward_scaler, g7_adamw, g8_bc, g9_denoise_mse, g10_scheduler, g11_eval, g12_gaussian):
+    for fn in (g1_tables, g2_forward, g3_g4_chains, g5_loss, g6_reward_scaler, g7_adamw, g8_bc, g9_denoise_mse, g10_scheduler, g11_eval, g12_gaussian, g13_unet):
         if not only or fn.__name__ in only:
             fn()

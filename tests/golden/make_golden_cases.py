@@ -23,3 +23,24 @@ GAUSS_CASES = {
     "gauss_nonorm": ("gauss_d3il", dict(fixed_std=0.1, learn_fixed_std=True, std_min=0.05, std_max=0.12,
                                         clip_ploss_coef=0.02, norm_adv=False, randn_clip_value=3)),
 }
+
+UNET_SPECS = {
+    # name: UnetSpec kwargs (+ horizon_steps)
+    # shipped robomimic state cfgs (cfg/robomimic/finetune/square/ft_ppo_diffusion_unet.yaml:93-103): Ta 4, two levels
+    "unet_square": dict(action_dim=7, cond_dim=23, horizon_steps=4, diffusion_step_embed_dim=16, dim=64, dim_mults=(1, 2),
+                        kernel_size=5, n_groups=8, smaller_encoder=False, cond_predict_scale=True),
+    # shipped furniture cfgs (cfg/furniture/finetune/one_leg_low/ft_ppo_diffusion_unet.yaml:99-109): three levels, Ta 8
+    "unet_furniture": dict(action_dim=10, cond_dim=58, horizon_steps=8, diffusion_step_embed_dim=16, dim=64,
+                           dim_mults=(1, 2, 4), kernel_size=5, n_groups=8, smaller_encoder=False, cond_predict_scale=True),
+    # the other constructor branches: one-layer encoder, additive conditioning, ReLU, kernel 3, eps 1e-4
+    "unet_small": dict(action_dim=3, cond_dim=11, horizon_steps=4, diffusion_step_embed_dim=16, dim=64, dim_mults=(1, 2),
+                       kernel_size=3, n_groups=4, smaller_encoder=True, cond_predict_scale=False, activation="ReLU",
+                       groupnorm_eps=1e-4),
+}
+UNET_CHAIN_CASES = {
+    # name: (spec name, B, model kwargs, deterministic)
+    "unet_ddpm20_ft10": ("unet_square", 5, dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3), False),
+    "unet_ddim100_5": ("unet_furniture", 3, dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
+                                                 randn_clip_value=3, min_sampling_denoising_std=0.04), False),
+    "unet_small_det": ("unet_small", 4, dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3), True),
+}
