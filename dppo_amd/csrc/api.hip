@@ -21,6 +21,14 @@ static int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+namespace dppo {  // the same two helpers for the other translation units that export entry points (unet.hip)
+int api_fail(int code, const char* msg) { return fail(code, "%s", msg); }
+int api_check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail((int)e, "HIP launch failed: %s", hipGetErrorString(e));
+  return 0;
+}
+}  // namespace dppo
 // A fused kernel refused a shape that fused_ok() admitted: the packed image then holds no layered operands to fall back
 // on, so the call must fail (reported by the check_launch() that ends every entry point).
 static int g_fused_fault = 0;

@@ -63,6 +63,13 @@ class GaussianCfg(C.Structure):  # struct dppo_gaussian_cfg
 
 GAUSS_STAT_ENTROPY, GAUSS_STAT_STD, GAUSS_STAT_COUNT = 7, 8, 9
 
+
+class UnetDesc(C.Structure):  # struct dppo_unet_desc
+    _fields_ = [("action_dim", C.c_int32), ("cond_dim", C.c_int32), ("horizon_steps", C.c_int32), ("time_dim", C.c_int32),
+                ("dim", C.c_int32), ("n_levels", C.c_int32), ("mults", C.c_int32 * 4), ("kernel_size", C.c_int32),
+                ("n_groups", C.c_int32), ("larger_encoder", C.c_int32), ("cond_predict_scale", C.c_int32),
+                ("act", C.c_int32), ("groupnorm_eps", C.c_float)]
+
 # numpy mirror of `dppo_step` (40 bytes) so schedules are built vectorised on the host
 STEP_DTYPE = np.dtype([("net", "<i4"), ("t", "<i4"), ("chain_slot", "<i4"), ("final_clip", "<i4"),
                        ("c0", "<f4"), ("c1", "<f4"), ("c2", "<f4"), ("c3", "<f4"), ("std", "<f4"), ("pad", "<f4")])
@@ -99,6 +106,15 @@ SYMBOLS = {
     "dppo_gaussian_logprob": (_I, [_ND, _I, _P, _P, C.POINTER(GaussianCfg), _P, _P, _P, _L, _P, _P, _L, _P]),
     "dppo_gaussian_ppo_loss_fwd_bwd": (_I, [_ND, _ND, _I, _P, _P, _P, _P, C.POINTER(GaussianCfg), _P, _P, _P, _P, _P, _P,
                                             _P, _L, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "dppo_unet_param_count": (_L, [C.POINTER(UnetDesc)]),
+    "dppo_unet_packed_bytes": (_L, [C.POINTER(UnetDesc), _I, _I]),
+    "dppo_unet_pack": (_I, [C.POINTER(UnetDesc), _I, _I, _P, _P, _P]),
+    "dppo_unet_workspace_bytes": (_L, [C.POINTER(UnetDesc), _I, _L]),
+    "dppo_unet_forward": (_I, [C.POINTER(UnetDesc), _I, _P, _P, _P, _P, _P, _L, _P, _P, _L, _P]),
+    "dppo_unet_sample_chain": (_I, [C.POINTER(UnetDesc), _I, _P, _P, _P, _P, C.POINTER(DiffusionCfg), _P, _I, _P, _P, _L, _P,
+                                    _P, _I, _I, _P, _L, _P]),
+    "dppo_unet_chain_logprob": (_I, [C.POINTER(UnetDesc), _I, _P, _P, C.POINTER(DiffusionCfg), _P, _P, _I, _P, _P, _L, _P, _P,
+                                     _L, _P]),
     "dppo_grad_sq_norm": (_I, [_P, _L, _P, _P, _P]),
     "dppo_adamw_step": (_I, [_P, _P, _P, _P, _L, _I, _D, _D, _D, _D, _D, _P, _D, _P]),
     "dppo_adamw_step_dev": (_I, [_P, _P, _P, _P, _L, _P, _P, _D, _D, _D, _D, _P, _D, _P]),

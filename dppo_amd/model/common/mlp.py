@@ -128,11 +128,24 @@ class HipNet(nn.Module):
                 off += n
             object.__setattr__(self, "_flat", flat)
             self._packed.clear()
-            d = self.net_desc()
             if flat.is_cuda:
-                want = hip.load().dppo_net_param_count(C.byref(d))
+                want = self._abi_param_count()
                 assert want == total, f"flat layout mismatch: python {total} vs C ABI {want}"
         return flat
+
+    # the three ABI calls that depend on the network family (MLP trunks here; the conv denoiser overrides them)
+    def _abi_param_count(self) -> int:
+        d = self.net_desc()
+        return hip.load().dppo_net_param_count(C.byref(d))
+
+    def _abi_packed_bytes(self, prec: int, n_time: int) -> int:
+        d = self.net_desc()
+        return hip.load().dppo_packed_bytes(C.byref(d), prec, n_time)
+
+    def _abi_pack(self, prec: int, n_time: int, buf: torch.Tensor) -> None:
+        d = self.net_desc()
+        hip.check(hip.load().dppo_pack_net(C.byref(d), prec, n_time, self.flat_params().data_ptr(), buf.data_ptr(),
+                                           hip.stream()), "dppo_pack_net")
 
     def flat_grads(self) -> torch.Tensor:
         flat = self.flat_params()
@@ -171,8 +184,7 @@ class HipNet(nn.Module):
             return hit[1], stamp, False
         nbytes = self.__dict__.setdefault("_packed_bytes", {}).get(key)
         if nbytes is None:
-            d = self.net_desc()
-            nbytes = hip.load().dppo_packed_bytes(C.byref(d), prec, n_time)
+            nbytes = self._abi_packed_bytes(prec, n_time)
             if nbytes < 0:
                 hip.check(int(nbytes), "dppo_packed_bytes")
             self._packed_bytes[key] = nbytes
@@ -183,9 +195,7 @@ class HipNet(nn.Module):
     def packed(self, prec: int, n_time: int) -> torch.Tensor:
         buf, stamp, stale = self._packed_slot(prec, n_time)
         if stale:
-            d = self.net_desc()
-            hip.check(hip.load().dppo_pack_net(C.byref(d), prec, n_time, self.flat_params().data_ptr(), buf.data_ptr(),
-                                               hip.stream()), "dppo_pack_net")
+            self._abi_pack(prec, n_time, buf)
             self._packed[(prec, n_time)] = (stamp, buf)
         return buf
 

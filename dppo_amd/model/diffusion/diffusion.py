@@ -53,6 +53,8 @@ class DiffusionModel(nn.Module):
         self.eps_clip_value = eps_clip_value
         self.prec = hip.PREC_BY_NAME[precision] if precision is not None else network.prec
 
+        if getattr(network, "is_unet", False) and network.horizon_steps is None:
+            network.horizon_steps = horizon_steps  # the conv denoiser's descriptor / workspace need the chunk length
         self.network = network.to(device)
         if network_path is not None:  # reference :77-86 -- "ema" preferred, safe loader only
             checkpoint = torch.load(network_path, map_location=device, weights_only=True)
@@ -160,6 +162,7 @@ class DiffusionModel(nn.Module):
             slot += int(keep)
         out = (torch.from_numpy(tab.view(np.uint8)).to(device), n_steps, slot, init_slot)
         cache[key] = out
+        cache[("host",) + key] = tab  # the conv denoiser's K-step loop runs on the host: it reads the table there
         return out
 
     # ------------------------------------------------------------------ the sampler launch
@@ -197,6 +200,21 @@ class DiffusionModel(nn.Module):
             ft = base
         d = base.net_desc()
         K = self.denoising_steps
+        if getattr(base, "is_unet", False):  # conv denoiser: host loop over the steps, dppo_unet_sample_chain
+            key = ("host", "sample", deterministic, use_base_policy, float(self.get_min_sampling_denoising_std()),
+                   self.ft_denoising_steps, str(dev), self._eta_value(deterministic))
+            tab = self._sched_cache[key]
+            ws = base.workspace(B, dev)
+            hip.check(lib.dppo_unet_sample_chain(
+                C.byref(d), self.prec, base.flat_params().data_ptr(), base.packed(self.prec, K).data_ptr(),
+                ft.flat_params().data_ptr(), ft.packed(self.prec, K).data_ptr(), C.byref(cfg), tab.ctypes.data, n_steps,
+                obs.data_ptr(), noise.data_ptr() if noise is not None else None, B, traj.data_ptr(),
+                chains.data_ptr() if return_chain else None, chain_len if return_chain else 0,
+                init_slot if return_chain else -1, ws.data_ptr(), ws.numel(), hip.stream()), "dppo_unet_sample_chain")
+            traj = traj.view(B, self.horizon_steps, self.action_dim)
+            if return_chain:
+                chains = chains.view(B, chain_len, self.horizon_steps, self.action_dim)
+            return Sample(traj, chains)
         wsb = lib.dppo_sample_chain_workspace_bytes(C.byref(d), self.prec, B)
         ws = self.__dict__.setdefault("_ws_sample", hip.Workspace()).get(wsb, dev) if wsb > 0 else None
         hip.check(lib.dppo_sample_chain(

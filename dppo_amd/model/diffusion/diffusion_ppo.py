@@ -98,6 +98,9 @@ class PPODiffusion(VPGDiffusion):
 
     def _run_ppo(self, obs, chains, returns, values, adv, logprobs, inds, kinds, N, reward_horizon, adv_gathered,
                  global_moments=None):
+        if getattr(self.actor_ft, "is_unet", False):
+            raise NotImplementedError("dppo_amd: the PPO update (backward pass) of a conv denoiser actor is not built yet; "
+                                      "sampling, log-probs and evaluation are")
         lib = hip.load()
         dev = obs.device
         da, dc = self.actor_ft.net_desc(), self.critic.net_desc()

@@ -137,12 +137,19 @@ class VPGDiffusion(DiffusionModel):
         out = torch.empty((B * Kft, AF), device=dev, dtype=torch.float32)
         ks = self._logprob_schedule(dev)
         cfg = self.diffusion_cfg()
-        wsb = lib.dppo_chain_logprob_workspace_bytes(C.byref(d), self.prec, B, Kft)
-        ws = self._ws_logprob.get(wsb, dev)
-        hip.check(lib.dppo_chain_logprob(
-            C.byref(d), self.prec, net.flat_params().data_ptr(), net.packed(self.prec, self.denoising_steps).data_ptr(),
-            C.byref(cfg), ks.data_ptr(), Kft, obs.data_ptr(), ch.data_ptr(), B, out.data_ptr(), ws.data_ptr(),
-            ws.numel(), hip.stream()), "dppo_chain_logprob")
+        if getattr(net, "is_unet", False):  # conv denoiser
+            ws = net.workspace(B * Kft, dev)
+            hip.check(lib.dppo_unet_chain_logprob(
+                C.byref(d), self.prec, net.flat_params().data_ptr(), net.packed(self.prec, self.denoising_steps).data_ptr(),
+                C.byref(cfg), ks.data_ptr(), None, Kft, obs.data_ptr(), ch.data_ptr(), B, out.data_ptr(), ws.data_ptr(),
+                ws.numel(), hip.stream()), "dppo_unet_chain_logprob")
+        else:
+            wsb = lib.dppo_chain_logprob_workspace_bytes(C.byref(d), self.prec, B, Kft)
+            ws = self._ws_logprob.get(wsb, dev)
+            hip.check(lib.dppo_chain_logprob(
+                C.byref(d), self.prec, net.flat_params().data_ptr(), net.packed(self.prec, self.denoising_steps).data_ptr(),
+                C.byref(cfg), ks.data_ptr(), Kft, obs.data_ptr(), ch.data_ptr(), B, out.data_ptr(), ws.data_ptr(),
+                ws.numel(), hip.stream()), "dppo_chain_logprob")
         out = out.view(B * Kft, self.horizon_steps, self.action_dim)
         if get_ent:
             eta = torch.full_like(out, 1.0) if not self.use_ddim else torch.full(
@@ -159,6 +166,8 @@ class VPGDiffusion(DiffusionModel):
         Inference only: inside ``PPODiffusion.loss`` the same evaluation runs fused and differentiable.  Here the
         samples are grouped by k and each group goes through the chain kernel as a one-step chain.
         """
+        if getattr(self.actor_ft, "is_unet", False):
+            raise NotImplementedError("dppo_amd: get_logprobs_subsample with a conv denoiser is not built yet (use get_logprobs)")
         state = cond["state"]
         hip.require_gpu(state, "VPGDiffusion.get_logprobs_subsample")
         B, dev = chains_prev.shape[0], chains_prev.device

@@ -277,6 +277,46 @@ int dppo_gaussian_ppo_loss_fwd_bwd(const dppo_net_desc* actor, const dppo_net_de
                                    float* logvar_grad, double* stats, void* workspace, int64_t workspace_bytes,
                                    dppo_stream_t stream);
 
+/* ---- conv denoiser (Unet1D), inference side ------------------------------------------------------
+ * Replaces model/diffusion/unet.py:27-327 (ResidualBlock1D, Unet1D.forward), model/diffusion/modules.py:28-95
+ * (Downsample1d, Upsample1d, Conv1dBlock) as the actor of the same K-step sampler and log-prob evaluation
+ * (diffusion_vpg.py:227-396).  Every convolution is an MFMA GEMM over a channel-last, time-padded activation image
+ * (the im2col row of (b, t) is a contiguous window of it); GroupNorm + activation + FiLM / residual are one epilogue
+ * kernel per block half.  Parameters: one flat fp32 buffer in the reference's state-dict order.
+ * Not built: cond_mlp_dims (no shipped cfg sets it), the backward pass (PPODiffusion.loss with a conv actor). */
+typedef struct dppo_unet_desc {
+  int32_t action_dim, cond_dim, horizon_steps;
+  int32_t time_dim;           /* diffusion_step_embed_dim                                        */
+  int32_t dim, n_levels;      /* channels of level i = dim * mults[i]                              */
+  int32_t mults[4];
+  int32_t kernel_size, n_groups;
+  int32_t larger_encoder;     /* cond_mlp_dims is None and not smaller_encoder (unet.py:151)       */
+  int32_t cond_predict_scale;
+  int32_t act;                /* DPPO_ACT_*                                                        */
+  float groupnorm_eps;
+} dppo_unet_desc;
+int64_t dppo_unet_param_count(const dppo_unet_desc* net);
+int64_t dppo_unet_packed_bytes(const dppo_unet_desc* net, int prec, int n_time);
+int dppo_unet_pack(const dppo_unet_desc* net, int prec, int n_time, const float* params, void* packed,
+                   dppo_stream_t stream);
+int64_t dppo_unet_workspace_bytes(const dppo_unet_desc* net, int prec, int64_t rows);
+/* eps (rows,Ta,Da) = Unet1D(x (rows,Ta,Da), t (rows,) int64, state (rows,cond)) */
+int dppo_unet_forward(const dppo_unet_desc* net, int prec, const float* params, const void* packed, const float* x,
+                      const int64_t* t, const float* state, int64_t rows, float* eps, void* workspace,
+                      int64_t workspace_bytes, dppo_stream_t stream);
+/* dppo_sample_chain with the conv denoiser.  sched_host: the n_steps dppo_step entries in HOST memory (the loop over
+ * steps is on the host: one forward of a few dozen launches + one posterior / noise launch per step; capturable). */
+int dppo_unet_sample_chain(const dppo_unet_desc* net, int prec, const float* params_base, const void* packed_base,
+                           const float* params_ft, const void* packed_ft, const dppo_diffusion_cfg* cfg,
+                           const dppo_step* sched_host, int n_steps, const float* obs, const float* noise, int64_t B,
+                           float* traj, float* chains, int chain_len, int init_slot, void* workspace,
+                           int64_t workspace_bytes, dppo_stream_t stream);
+/* dppo_chain_logprob with the conv denoiser: ksteps (device) / ksteps_host (host) hold the same Kft entries. */
+int dppo_unet_chain_logprob(const dppo_unet_desc* net, int prec, const float* params, const void* packed,
+                            const dppo_diffusion_cfg* cfg, const dppo_step* ksteps, const dppo_step* ksteps_host,
+                            int Kft, const float* obs, const float* chains, int64_t B, float* logp, void* workspace,
+                            int64_t workspace_bytes, dppo_stream_t stream);
+
 /* ---- A12: optimiser (torch.optim.AdamW + clip_grad_norm_ semantics) ----------------------- */
 /* out[0] = sum g^2 (float64), deterministic two-stage reduction; scratch >= 1024 doubles */
 int dppo_grad_sq_norm(const float* grad, int64_t n, double* scratch, double* out, dppo_stream_t stream);
