@@ -118,4 +118,5 @@ def test_hip_unet_chains_and_logprobs(golden, case, prec):
     torch.manual_seed(5)
     assert torch.equal(s1.chains, m(cond={"state": state}).chains) and torch.isfinite(s1.chains).all()
     with pytest.raises(NotImplementedError):
-        m.ppo_update(None, None, None, None, None, None, torch.zeros(4, dtype=torch.long, device=dev))
+        z = torch.zeros(4, device=dev)
+        m.ppo_update(z, z, z, z, z, z, torch.zeros(4, dtype=torch.long, device=dev))
