@@ -531,6 +531,74 @@ def g13_unet():
     save("g13_unet", **out)
 
 
+# ---------------------------------------------------------------- G14 conv denoiser: PPO loss and supervised loss with gradients
+from make_golden_cases import UNET_LOSS_CASES, UNET_MSE_CASES  # noqa: E402
+
+
+def unet_model(u, seed, **kw):
+    c = O.NetSpec("critic", cond_dim=u.cond_dim, mlp_dims=[256, 256, 256], activation="Mish", residual=True)
+    if kw.get("use_ddim"):
+        kw = dict(kw, eta=EtaFixed(base_eta=1.0))
+    m = PPODiffusion(actor=ref_unet(u, O.unet_init_params(u, seed)), critic=ref_critic(c, O.init_params(c, seed + 2)),
+                     horizon_steps=u.horizon_steps, obs_dim=u.cond_dim, action_dim=u.action_dim, device="cpu",
+                     gamma_denoising=0.99, randn_clip_value=3, **kw)
+    m.actor_ft.load_state_dict(O.unet_init_params(u, seed + 1), strict=True)
+    return m, c
+
+
+def g14_unet_loss():
+    out = {}
+    rs = np.random.RandomState(1400)
+    for cname, (sname, N, kw, rh) in UNET_LOSS_CASES.items():
+        u = O.UnetSpec(**UNET_SPECS[sname])
+        m, c = unet_model(u, 31, **kw)
+        Kft = kw["ft_denoising_steps"]
+        n_steps = kw["ddim_steps"] if kw.get("use_ddim") else kw["denoising_steps"]
+        state = torch.from_numpy(rs.uniform(-1, 1, size=(N, 1, u.cond_dim)).astype(np.float32))
+        noise = torch.from_numpy(rs.randn(n_steps + 1, N, u.horizon_steps, u.action_dim).astype(np.float32))
+        with recorded_noise(list(noise)):
+            chains = m(cond={"state": state}, deterministic=False, return_chain=True).chains
+        kinds = torch.from_numpy(rs.randint(0, Kft, size=(N,)).astype(np.int64))
+        rows = torch.arange(N)
+        prev, nxt = chains[rows, kinds], chains[rows, kinds + 1]
+        with torch.no_grad():
+            oldlp_all = m.get_logprobs({"state": state}, chains).reshape(N, Kft, u.horizon_steps, u.action_dim)
+            oldlp = oldlp_all[rows, kinds] + torch.from_numpy(
+                rs.normal(0, 0.02, size=(N, u.horizon_steps, u.action_dim)).astype(np.float32))
+            oldv = m.critic({"state": state}).view(-1) + torch.from_numpy(rs.normal(0, 0.3, N).astype(np.float32))
+        ret = torch.from_numpy(rs.normal(0, 1, N).astype(np.float32))
+        adv = torch.from_numpy(rs.normal(0.3, 2.0, N).astype(np.float32))
+        res = m.loss({"state": state}, prev, nxt, kinds, ret, oldv, adv.clone(), oldlp, use_bc_loss=False, reward_horizon=rh)
+        (res[0] + 0.5 * res[2]).backward()
+        out.update({f"{cname}_state": state, f"{cname}_prev": prev, f"{cname}_next": nxt, f"{cname}_kinds": kinds,
+                    f"{cname}_returns": ret, f"{cname}_oldvalues": oldv, f"{cname}_adv": adv, f"{cname}_oldlogprobs": oldlp,
+                    f"{cname}_reward_horizon": rh,
+                    f"{cname}_stats": np.array([res[0].item(), float(res[1]), res[2].item(), res[3], res[4], res[5],
+                                                float(res[6]), res[7]], dtype=np.float64)})
+        for k, p in m.actor_ft.named_parameters():
+            put_grad(out, f"{cname}_gactor_{k}", p.grad)
+        for k, p in m.critic.named_parameters():
+            put_grad(out, f"{cname}_gcritic_{k}", p.grad)
+    for cname, (sname, K, N) in UNET_MSE_CASES.items():
+        u = O.UnetSpec(**UNET_SPECS[sname])
+        m, _ = unet_model(u, 51, denoising_steps=K, ft_denoising_steps=min(10, K), clip_ploss_coef=0.01)
+        net = m.network
+        for p in net.parameters():
+            p.requires_grad_(True)
+        x0 = torch.from_numpy(rs.uniform(-1, 1, size=(N, u.horizon_steps, u.action_dim)).astype(np.float32))
+        state = torch.from_numpy(rs.uniform(-1, 1, size=(N, 1, u.cond_dim)).astype(np.float32))
+        t = torch.from_numpy(rs.randint(0, K, size=(N,)).astype(np.int64))
+        noise = torch.from_numpy(rs.randn(N, u.horizon_steps, u.action_dim).astype(np.float32))
+        with recorded_noise([noise]):
+            loss = m.p_losses(x0, {"state": state}, t)
+        loss.backward()
+        out.update({f"{cname}_x0": x0, f"{cname}_state": state, f"{cname}_t": t, f"{cname}_noise": noise,
+                    f"{cname}_loss": np.float64(loss.item())})
+        for k, p in net.named_parameters():
+            put_grad(out, f"{cname}_g_{k}", p.grad)
+    save("g14_unet_loss", **out)
+
+
 # ---------------------------------------------------------------- G10 LR schedule trace
 from make_golden_cases import SCHED_CASES  # noqa: E402
 
@@ -555,6 +623,6 @@ def g10_scheduler():
 
 if __name__ == "__main__":
     only = sys.argv[1:]  # e.g. `make_golden.py g8_bc` regenerates one file (each generator owns its RNG stream)
-    for fn in (g1_tables, g2_forward, g3_g4_chains, g5_loss, g6_reward_scaler, g7_adamw, g8_bc, g9_denoise_mse, g10_scheduler, g11_eval, g12_gaussian, g13_unet):
+    for fn in (g1_tables, g2_forward, g3_g4_chains, g5_loss, g6_reward_scaler, g7_adamw, g8_bc, g9_denoise_mse, g10_scheduler, g11_eval, g12_gaussian, g13_unet, g14_unet_loss):
         if not only or fn.__name__ in only:
             fn()

@@ -44,3 +44,15 @@ UNET_CHAIN_CASES = {
                                                  randn_clip_value=3, min_sampling_denoising_std=0.04), False),
     "unet_small_det": ("unet_small", 4, dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3), True),
 }
+
+UNET_LOSS_CASES = {
+    # name: (spec name, N, model kwargs, reward_horizon)
+    "unet_loss_square": ("unet_square", 32, dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01,
+                                                 clip_ploss_coef_base=0.001), 4),
+    "unet_loss_small": ("unet_small", 32, dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.1,
+                                               clip_ploss_coef_base=0.01, clip_vloss_coef=0.2), 4),
+    "unet_loss_furniture_ddim": ("unet_furniture", 16, dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True,
+                                                            ddim_steps=5, clip_ploss_coef=0.01,
+                                                            min_sampling_denoising_std=0.04), 8),
+}
+UNET_MSE_CASES = {"unet_mse_square": ("unet_square", 20, 24), "unet_mse_furniture": ("unet_furniture", 100, 12)}

@@ -120,3 +120,46 @@ def test_hip_unet_chains_and_logprobs(golden, case, prec):
     with pytest.raises(NotImplementedError):
         z = torch.zeros(4, device=dev)
         m.ppo_update(z, z, z, z, z, z, torch.zeros(4, dtype=torch.long, device=dev))
+
+
+# ------------------------------------------------------------------ G14: PPO loss / supervised loss with a conv actor
+from tests.golden.make_golden_cases import UNET_LOSS_CASES, UNET_MSE_CASES  # noqa: E402
+from tests.test_oracle_golden import check_grad  # noqa: E402
+
+CRITIC = lambda u: O.NetSpec("critic", cond_dim=u.cond_dim, mlp_dims=[256, 256, 256], activation="Mish", residual=True)
+
+
+@pytest.mark.parametrize("case", sorted(UNET_LOSS_CASES))
+def test_oracle_unet_ppo_loss_and_grads(golden, case):
+    g = golden("g14_unet_loss")
+    sname, N, kw, rh = UNET_LOSS_CASES[case]
+    u = O.UnetSpec(**UNET_SPECS[sname])
+    c = CRITIC(u)
+    cfg = make_cfg(u, dict(kw, gamma_denoising=0.99, randn_clip_value=3))
+    base = O.unet_init_params(u, 31)
+    ft = {k: v.clone().requires_grad_(True) for k, v in O.unet_init_params(u, 32).items()}
+    cr = {k: v.clone().requires_grad_(True) for k, v in O.init_params(c, 33).items()}
+    d = lambda k: T(g[f"{case}_{k}"])
+    res = O.ppo_loss(cfg, u, c, base, ft, cr, d("state"), d("prev"), d("next"), d("kinds"), d("returns"), d("oldvalues"),
+                     d("adv"), d("oldlogprobs"), reward_horizon=rh)
+    got = np.array([res[0].item(), float(res[1]), res[2].item(), res[3], res[4], res[5], float(res[6]), res[7]])
+    np.testing.assert_allclose(got, g[f"{case}_stats"], rtol=5e-5, atol=5e-6)
+    (res[0] + 0.5 * res[2]).backward()
+    for k, p in ft.items():
+        check_grad(g, f"{case}_gactor_{k}", p.grad if p.grad is not None else torch.zeros_like(p), rtol=2e-3, atol=2e-6)
+    for k, p in cr.items():
+        check_grad(g, f"{case}_gcritic_{k}", p.grad, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", sorted(UNET_MSE_CASES))
+def test_oracle_unet_denoise_mse(golden, case):
+    g = golden("g14_unet_loss")
+    sname, K, N = UNET_MSE_CASES[case]
+    u = O.UnetSpec(**UNET_SPECS[sname])
+    prm = {k: v.clone().requires_grad_(True) for k, v in O.unet_init_params(u, 51).items()}
+    d = lambda k: T(g[f"{case}_{k}"])
+    loss = O.denoise_mse_loss(K, u, prm, d("x0"), d("state"), d("t"), d("noise"))
+    assert float(loss.detach()) == pytest.approx(float(g[f"{case}_loss"]), rel=1e-5)
+    loss.backward()
+    for k, v in prm.items():
+        check_grad(g, f"{case}_g_{k}", v.grad if v.grad is not None else torch.zeros_like(v), 2e-3, 1e-6)
