@@ -9,6 +9,7 @@
 #include "gemm.h"
 #include "ppo.h"
 #include "gaussian.h"
+#include "unet.h"
 #include "sampler.h"
 
 using namespace dppo;
@@ -625,6 +626,7 @@ static void weight_grad(const void* A, int lda, int N1, const void* Bm, int ldb,
   const int64_t need = (M + rps - 1) / rps;
   if (need < splits) splits = need >= 8 ? (need + 7) / 8 * 8 : need;  // surplus splits see no rows and store zeros
   GemmTN t;
+  memset(&t, 0, sizeof(t));
   t.A = A, t.B = Bm, t.M = (int)M, t.N1 = N1, t.N2 = N2, t.lda = lda, t.ldb = ldb;
   float* sub = B.slab + B.slab_used;
   B.slab_used += (size_t)splits * N1 * N2;
@@ -1562,6 +1564,171 @@ int dppo_gaussian_ppo_loss_fwd_bwd(const dppo_net_desc* actor, const dppo_net_de
 #undef CALL
 }
 
+// ---- conv denoiser: PPO update and supervised loss (unet.hip does the network, this file the loss and the critic) -------
+template <class P>
+struct UnetPpoWs {
+  double *moments, *loss_partial;
+  float* loss_tab;
+  int32_t *brow, *krow;
+  MlpBufs<P> C;
+  void* d_eps;
+  void* uws;
+  size_t ubytes;
+  int ldde;
+};
+template <class P>
+static size_t carve_unet_ppo(Carver& c, const dppo_unet_desc& u, const dppo_net_desc* cr, int64_t N, UnetPpoWs<P>& W) {
+  W.moments = (double*)c.take((8 + 2 * ADV_MOMENT_BLOCKS) * sizeof(double));
+  W.loss_tab = (float*)c.take(2 * 1024 * sizeof(float));
+  W.ldde = round_up(u.horizon_steps * u.action_dim, 64);
+  const int64_t lb = loss_blocks(N), mb = bc_loss_blocks(N, W.ldde) + 1;
+  W.loss_partial = (double*)c.take((size_t)(lb * 8 > mb ? lb * 8 : mb) * sizeof(double));
+  W.brow = (int32_t*)c.take((size_t)N * 4);
+  W.krow = (int32_t*)c.take((size_t)N * 4);
+  if (cr) carve_mlp<P>(c, *cr, N, true, true, W.C);
+  W.d_eps = c.take((size_t)N * W.ldde * P::ESIZE);
+  W.ubytes = unet_trainer_bytes<P>(u, N);
+  W.uws = c.take(W.ubytes);
+  return al256(c.off);
+}
+int64_t dppo_unet_ppo_workspace_bytes(const dppo_unet_desc* actor, const dppo_net_desc* critic, int prec, int64_t N) {
+  if (unet_check_desc(actor) || check_net(critic) || check_prec(prec)) return -1;
+  if (N < 2 || N > (1 << 24)) return fail(-1, "N out of range");
+  Carver c{nullptr, 0, 0};
+  if (prec == DPPO_PREC_F32) {
+    UnetPpoWs<F32> W;
+    return (int64_t)carve_unet_ppo<F32>(c, *actor, critic, N, W);
+  }
+  UnetPpoWs<BF16> W;
+  return (int64_t)carve_unet_ppo<BF16>(c, *actor, critic, N, W);
+}
+template <class P>
+static int unet_ppo_impl(const dppo_unet_desc& u, const dppo_net_desc& cr, const float* ap, const char* ak, const float* cp,
+                         const char* ck, const dppo_diffusion_cfg& dcfg, const dppo_ppo_cfg& pcfg, const dppo_step* ksteps,
+                         const float* obs_k, const float* chains_k, const float* returns_k, const float* values_k,
+                         const float* adv_k, const float* logprobs_k, const int64_t* inds, const int64_t* kinds, int64_t N,
+                         const double* gmom, float* agrad, float* cgrad, double* stats, void* ws, int64_t wsb, hipStream_t s) {
+  Carver c{(char*)ws, 0, (size_t)wsb};
+  UnetPpoWs<P> W;
+  const size_t need = carve_unet_ppo<P>(c, u, &cr, N, W);
+  if ((int64_t)need > wsb) return fail(-1, "workspace too small: need %zu bytes, got %lld", need, (long long)wsb);
+  const PackLayout LC = pack_layout<P>(cr, 0);
+  const int Kft = pcfg.ft_denoising_steps, AF = u.horizon_steps * u.action_dim;
+  BuildRows br;  // critic rows + the zeroing / loss table side jobs; the conv actor builds its own input images
+  memset(&br, 0, sizeof(br));
+  br.zero_b = W.moments, br.n_zero_b = 32;
+  if (Kft <= 1024) br.loss_tab = W.loss_tab, br.pcfg = pcfg;
+  br.inds = inds, br.kinds = kinds, br.chains = chains_k, br.obs = obs_k, br.ksteps = ksteps, br.Kft = Kft, br.AF = AF;
+  br.cond = cr.cond_dim, br.M = N, br.inC = W.C.in, br.KpC = LC.Kp0, br.brow = W.brow, br.onehot0 = -1;
+  launch_build_rows<P>(br, s);
+  launch_unet_index(inds, kinds, Kft, N, W.brow, W.krow, s);
+  if (gmom == nullptr) launch_adv_moments(adv_k, W.brow, N, W.moments, s);
+  // critic pipeline beside the actor's forward
+  hipStream_t s2 = fork_side(s);
+  mlp_forward<P>(cr, cp, ck, LC, N, W.C, true, s2);
+  UnetTrainer<P>* T = unet_trainer_new<P>(u, ap, ak, N, W.uws, W.ubytes, s);
+  UnetTrainIO io;
+  memset(&io, 0, sizeof(io));
+  io.chains = chains_k, io.obs = obs_k, io.brow = W.brow, io.krow = W.krow, io.ksteps = ksteps, io.Kft = Kft;
+  io.gathered = kinds != nullptr;
+  const float* eps = unet_trainer_forward<P>(T, io);
+  if (s2 != s) join_side(s, s2);
+  LossArgs la;
+  memset(&la, 0, sizeof(la));
+  la.eps = eps, la.lde = AF, la.vnew = W.C.out, la.ldv = W.C.ldout, la.brow = W.brow, la.krow = W.krow;
+  la.gathered = kinds != nullptr;
+  la.chains = chains_k, la.logprobs_k = logprobs_k, la.returns_k = returns_k, la.values_k = values_k, la.adv_k = adv_k;
+  la.ksteps = ksteps, la.dcfg = dcfg, la.pcfg = pcfg, la.AF = AF, la.N = N;
+  la.moments = gmom ? gmom : W.moments;
+  la.tab = Kft <= 1024 ? W.loss_tab : nullptr;
+  la.d_eps = W.d_eps, la.ldde = W.ldde, la.d_v = W.C.d_out, la.lddv = LC.Kpo, la.stats = stats;
+  la.part = 3, la.partial = W.loss_partial;
+  launch_ppo_loss<P>(la, s);
+  s2 = fork_side(s);
+  mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s2, false, -1, &la);
+  unet_trainer_backward<P>(T, W.d_eps, W.ldde, agrad);
+  unet_trainer_free<P>(T);
+  if (s2 != s) join_side(s, s2);
+  return check_launch();
+}
+int dppo_unet_ppo_loss_fwd_bwd(const dppo_unet_desc* actor, const dppo_net_desc* critic, int prec, const float* actor_params,
+                               const void* actor_packed, const float* critic_params, const void* critic_packed,
+                               const dppo_diffusion_cfg* dcfg, const dppo_ppo_cfg* pcfg, const dppo_step* ksteps,
+                               const float* obs_k, const float* chains_k, const float* returns_k, const float* values_k,
+                               const float* adv_k, const float* logprobs_k, const int64_t* inds, const int64_t* kinds,
+                               int64_t N, const double* global_moments, float* actor_grad, float* critic_grad,
+                               double* stats, void* workspace, int64_t workspace_bytes, dppo_stream_t stream) {
+  if (int e = unet_check_desc(actor)) return e;
+  if (int e = check_net(critic)) return e;
+  if (int e = check_prec(prec)) return e;
+  if (critic->kind != 1 || critic->out_dim != 1) return fail(-1, "critic descriptor must be kind 1 with out_dim 1");
+  if (actor->cond_dim != critic->cond_dim) return fail(-1, "actor and critic observe different cond_dim");
+  if (!actor_params || !actor_packed || !critic_params || !critic_packed || !dcfg || !pcfg || !ksteps || !obs_k ||
+      !chains_k || !returns_k || !values_k || !adv_k || !logprobs_k || !actor_grad || !critic_grad || !stats || !workspace)
+    return fail(-1, "null pointer");
+  if ((inds == nullptr) == (kinds == nullptr)) return fail(-1, "pass exactly one of inds (rollout mode) / kinds (gathered mode)");
+  if (N < 2 || N > (1 << 24)) return fail(-1, "N out of range");
+  if (pcfg->ft_denoising_steps < 1 || pcfg->ft_denoising_steps > 1024) return fail(-1, "Kft out of range");
+  if ((size_t)pcfg->ft_denoising_steps * 9 * actor->time_dim * 4 > 64 * 1024) return fail(-1, "Kft * time_dim too large (LDS of the time MLP's backward)");
+  if (pcfg->horizon_steps != actor->horizon_steps || pcfg->action_dim != actor->action_dim) return fail(-1, "Ta / Da mismatch");
+  if (pcfg->reward_horizon < 1) return fail(-1, "reward_horizon must be >= 1");
+#define CALL(P)                                                                                                          \
+  unet_ppo_impl<P>(*actor, *critic, actor_params, (const char*)actor_packed, critic_params, (const char*)critic_packed, *dcfg, \
+                   *pcfg, ksteps, obs_k, chains_k, returns_k, values_k, adv_k, logprobs_k, inds, kinds, N, global_moments,     \
+                   actor_grad, critic_grad, stats, workspace, workspace_bytes, (hipStream_t)stream)
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
+}
+int64_t dppo_unet_denoise_mse_workspace_bytes(const dppo_unet_desc* net, int prec, int64_t N) {
+  if (unet_check_desc(net) || check_prec(prec)) return -1;
+  if (N < 1 || N > (1 << 24)) return fail(-1, "N out of range");
+  Carver c{nullptr, 0, 0};
+  if (prec == DPPO_PREC_F32) {
+    UnetPpoWs<F32> W;
+    return (int64_t)carve_unet_ppo<F32>(c, *net, nullptr, N, W);
+  }
+  UnetPpoWs<BF16> W;
+  return (int64_t)carve_unet_ppo<BF16>(c, *net, nullptr, N, W);
+}
+template <class P>
+static int unet_mse_impl(const dppo_unet_desc& u, const float* prm, const char* pk, const dppo_step* tsteps, int n_time,
+                         const float* obs, const float* pairs, const int64_t* kinds, int64_t N, float* grad, double* loss,
+                         void* ws, int64_t wsb, hipStream_t s) {
+  Carver c{(char*)ws, 0, (size_t)wsb};
+  UnetPpoWs<P> W;
+  const size_t need = carve_unet_ppo<P>(c, u, nullptr, N, W);
+  if ((int64_t)need > wsb) return fail(-1, "workspace too small: need %zu bytes, got %lld", need, (long long)wsb);
+  const int AF = u.horizon_steps * u.action_dim;
+  launch_unet_index(nullptr, kinds, n_time, N, W.brow, W.krow, s);
+  UnetTrainer<P>* T = unet_trainer_new<P>(u, prm, pk, N, W.uws, W.ubytes, s);
+  UnetTrainIO io;
+  memset(&io, 0, sizeof(io));
+  io.chains = pairs, io.obs = obs, io.brow = W.brow, io.krow = W.krow, io.ksteps = tsteps, io.Kft = n_time, io.gathered = 1;
+  const float* eps = unet_trainer_forward<P>(T, io);
+  MseArgs ma;
+  ma.eps = eps, ma.lde = AF, ma.pairs = pairs, ma.AF = AF, ma.M = N, ma.d_eps = W.d_eps, ma.ldde = W.ldde, ma.loss = loss;
+  ma.partial = W.loss_partial;
+  launch_mse_loss<P>(ma, s);
+  unet_trainer_backward<P>(T, W.d_eps, W.ldde, grad);
+  unet_trainer_free<P>(T);
+  return check_launch();
+}
+int dppo_unet_denoise_mse_fwd_bwd(const dppo_unet_desc* net, int prec, const float* params, const void* packed,
+                                  const dppo_step* tsteps, int n_time, const float* obs, const float* pairs,
+                                  const int64_t* kinds, int64_t N, float* grad, double* loss, void* workspace,
+                                  int64_t workspace_bytes, dppo_stream_t stream) {
+  if (int e = unet_check_desc(net)) return e;
+  if (int e = check_prec(prec)) return e;
+  if (!params || !packed || !tsteps || !obs || !pairs || !kinds || !grad || !loss || !workspace) return fail(-1, "null pointer");
+  if (N < 1 || N > (1 << 24) || n_time < 1 || n_time > 1024) return fail(-1, "N / n_time out of range");
+  if ((size_t)n_time * 9 * net->time_dim * 4 > 64 * 1024) return fail(-1, "n_time * time_dim too large (LDS of the time MLP's backward)");
+#define CALL(P)                                                                                                          \
+  unet_mse_impl<P>(*net, params, (const char*)packed, tsteps, n_time, obs, pairs, kinds, N, grad, loss, workspace, workspace_bytes, \
+                   (hipStream_t)stream)
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
+}
+
 // ---- optimiser ----------------------------------------------------------------------------------------
 int dppo_grad_sq_norm(const float* grad, int64_t n, double* scratch, double* out, dppo_stream_t stream) {
   if (!grad || !scratch || !out || n < 1) return fail(-1, "bad argument");
@@ -1740,6 +1907,7 @@ int dppo_gemm_tn_raw(int prec, const void* A, int lda, int N1, const void* B, in
   if (!A || !B || !slab || !C || M < 1 || M > 0x7fffffff || N1 < 1 || N2 < 1) return fail(-1, "bad argument");
   if (rows_per_split < 64 || rows_per_split % 64) return fail(-1, "rows_per_split must be a multiple of 64");
   GemmTN t;
+  memset(&t, 0, sizeof(t));
   t.A = A, t.B = B, t.M = (int)M, t.N1 = N1, t.N2 = N2, t.lda = lda, t.ldb = ldb, t.slab = slab, t.ldc = N2;
   t.rows_per_split = rows_per_split, t.splits = (int)((M + rows_per_split - 1) / rows_per_split);
   if (prec == DPPO_PREC_F32)

@@ -38,6 +38,9 @@ struct GemmTN {
   int M, N1, N2, lda, ldb;
   float* slab;  // [splits][N1][ldc] partial sums
   int ldc, splits, rows_per_split;  // rows_per_split multiple of 64
+  // readable columns of a row when they differ from its stride (0 = lda / ldb): rows may OVERLAP -- an im2col operand
+  // that is a window of stride C and width k*C over a channel-last image (unet.hip).  Register-staged kernel only.
+  int ncol_a, ncol_b;
 };
 
 constexpr int MAX_TN_JOBS = 8;

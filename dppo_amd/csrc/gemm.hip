@@ -334,6 +334,7 @@ __device__ __forceinline__ void tn_tile(const GemmTN& a, const int split, const 
   const char* Bb = (const char*)a.B;
 
   u32x4 areg[NCA], breg[NCB];
+  const int lim_a = a.ncol_a > 0 ? a.ncol_a : a.lda, lim_b = a.ncol_b > 0 ? a.ncol_b : a.ldb;
   auto gload = [&](int m0) {
 #pragma unroll
     for (int i = 0; i < NCA; ++i) {
@@ -341,7 +342,7 @@ __device__ __forceinline__ void tn_tile(const GemmTN& a, const int split, const 
       const int rr = q / CPA, c = q % CPA;
       const int row = m0 + rr, ca = fa0 + c * (16 / ES);
       areg[i] = (u32x4){0, 0, 0, 0};
-      if (row < m_end && ca < a.lda) areg[i] = *(const u32x4*)(Ab + ((size_t)row * a.lda + ca) * ES);
+      if (row < m_end && ca < lim_a) areg[i] = *(const u32x4*)(Ab + ((size_t)row * a.lda + ca) * ES);
     }
 #pragma unroll
     for (int i = 0; i < NCB; ++i) {
@@ -349,7 +350,7 @@ __device__ __forceinline__ void tn_tile(const GemmTN& a, const int split, const 
       const int rr = q / CPB, c = q % CPB;
       const int row = m0 + rr, cb = fb0 + c * (16 / ES);
       breg[i] = (u32x4){0, 0, 0, 0};
-      if (row < m_end && cb < a.ldb) breg[i] = *(const u32x4*)(Bb + ((size_t)row * a.ldb + cb) * ES);
+      if (row < m_end && cb < lim_b) breg[i] = *(const u32x4*)(Bb + ((size_t)row * a.ldb + cb) * ES);
     }
   };
   auto sstore = [&](int st) {
@@ -695,6 +696,10 @@ void set_gemm_tn_variant(int v) { g_tn_variant = v; }
 
 template <class P>
 void launch_gemm_tn(const GemmTN& a, hipStream_t s) {
+  if (a.ncol_a > 0 || a.ncol_b > 0) {  // overlapping rows: the register-staged 128 x 128 kernel knows about them
+    launch_tn_cfg<P, 2, 2, 4, 4>(a, s);
+    return;
+  }
   if (gemm_tn_thin(a.N1, a.N2)) {
     launch_tn_cfg<P, 4, 1, 8, 4>(a, s);
     return;

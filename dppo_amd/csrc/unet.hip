@@ -17,6 +17,7 @@
 #include "gemm.h"
 #include "posterior.h"
 #include "ppo.h"
+#include "unet.h"
 
 namespace dppo {
 int api_fail(int code, const char* msg);
@@ -34,13 +35,16 @@ inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Lin {
   int64_t w, b;   // float offsets in the flat parameter buffer
   size_t pk;      // byte offset of the packed [out][Kp] operand
-  int in, out, Kp;
+  size_t pkT;     // backward: W^T as [in_p][out] (data gradient); in_p = inT rows kept (all, or the time-embedding columns)
+  int in, out, Kp, inT;
 };
 struct Conv {
   int64_t w, b;
   size_t pk;
+  size_t pkT;  // backward (data gradient) operand, see pack_convT_bwd / pack_conv_bwd / pack_down_bwd
   int ci, co, ks, cip, Kp;  // cip: padded input channels (ld of the image it reads)
   bool transposed;
+  int stride;  // 1, or 2 for Downsample1d
 };
 struct Norm {
   int64_t g, b;
@@ -78,6 +82,7 @@ Layout make_layout(const dppo_unet_desc& d, int es, int n_time) {
     l.w = o, o += (int64_t)in * out;
     l.b = o, o += out;
     l.pk = pk, pk = al(pk + (size_t)out * l.Kp * es);
+    l.inT = in, l.pkT = pk, pk = al(pk + (size_t)rup(in, 16) * rup(out, 64) * es);
     return l;
   };
   auto conv = [&](int ci, int co, int ks, bool tr = false) {
@@ -85,12 +90,17 @@ Layout make_layout(const dppo_unet_desc& d, int es, int n_time) {
     c.ci = ci, c.co = co, c.ks = ks, c.cip = rup(ci, 64), c.transposed = tr;
     c.w = o, o += (int64_t)ci * co * ks;
     c.b = o, o += co;
+    c.stride = 1;
     if (!tr) {
       c.Kp = ks * c.cip;
       c.pk = pk, pk = al(pk + (size_t)co * c.Kp * es);
+      // data gradient: a convolution of the padded dU image with the flipped kernel, [ci][ks * co]; the stride-2 conv's
+      // is a two-phase GEMM [2 ci][2 co] (set by the caller below)
+      c.pkT = pk, pk = al(pk + (size_t)2 * rup(ci, 16) * ks * rup(co, 64) * es);
     } else {  // ConvTranspose1d(C, C, 4, 2, 1) as one GEMM: N = 2 co (even | odd phase), K = 3 ci (window m-1, m, m+1)
       c.Kp = 3 * c.cip;
       c.pk = pk, pk = al(pk + (size_t)2 * co * c.Kp * es);
+      c.pkT = pk, pk = al(pk + (size_t)ci * 4 * co * es);  // strided conv over dy: [ci][4 co]
     }
     return c;
   };
@@ -127,7 +137,10 @@ Layout make_layout(const dppo_unet_desc& d, int es, int n_time) {
   for (int i = 0; i < nl; ++i) {
     L.down.push_back(resblock(L.dims[i], L.dims[i + 1]));
     L.down.push_back(resblock(L.dims[i + 1], L.dims[i + 1]));
-    if (i < nl - 1) L.downs.push_back(conv(L.dims[i + 1], L.dims[i + 1], 3));
+    if (i < nl - 1) {
+      L.downs.push_back(conv(L.dims[i + 1], L.dims[i + 1], 3));
+      L.downs.back().stride = 2;
+    }
   }
   for (int j = 0; j < nl - 1; ++j) {  // (dim_in, dim_out) = reversed(in_out[1:])[j] = (dims[nl-1-j], dims[nl-j])
     const int din = L.dims[nl - 1 - j], dout = L.dims[nl - j];
@@ -189,6 +202,38 @@ __global__ void pack_convT_kernel(const float* w, int ch, typename P::elem_t* ds
   else k = slot == 2 ? 0 : (slot == 1 ? 2 : -1);
   dst[i] = P::from_f32(k >= 0 ? w[((size_t)ci * ch + co) * 4 + k] : 0.f);
 }
+// backward (data-gradient) operands ---------------------------------------------------------------------------------
+template <class P>
+__global__ void pack_conv_bwd_kernel(const float* w, int co, int ci, int ks, typename P::elem_t* dst) {
+  // dX[b][t][ci] = sum_j sum_co dUimg[b][t - ks/2 + j][co] * w[co][ci][ks-1-j]  ->  dst[ci][j * co + o]
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t K = (size_t)ks * co;
+  if (i >= (size_t)ci * K) return;
+  const int c = (int)(i / K), r = (int)(i % K), j = r / co, o = r % co;
+  dst[i] = P::from_f32(w[((size_t)o * ci + c) * ks + (ks - 1 - j)]);
+}
+template <class P>
+__global__ void pack_down_bwd_kernel(const float* w, int ch, typename P::elem_t* dst) {
+  // Downsample1d (k 3, stride 2, pad 1): dx[2m] = W1^T dy[m]; dx[2m+1] = W2^T dy[m] + W0^T dy[m+1]
+  // window slots (dy[m], dy[m+1]) -> dst[phase * ch + ci][slot * ch + co]
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t K = (size_t)2 * ch;
+  if (i >= (size_t)2 * ch * K) return;
+  const int row = (int)(i / K), r = (int)(i % K), slot = r / ch, co = r % ch, phase = row / ch, ci = row % ch;
+  int k = -1;
+  if (phase == 0) k = slot == 0 ? 1 : -1;
+  else k = slot == 0 ? 2 : 0;
+  dst[i] = P::from_f32(k >= 0 ? w[((size_t)co * ch + ci) * 3 + k] : 0.f);
+}
+template <class P>
+__global__ void pack_convT_bwd_kernel(const float* w, int ch, typename P::elem_t* dst) {
+  // Upsample1d: dx[s][ci] = sum_k sum_co dy[2s - 1 + k][co] w[ci][co][k]  ->  dst[ci][k * ch + co]
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t K = (size_t)4 * ch;
+  if (i >= (size_t)ch * K) return;
+  const int ci = (int)(i / K), r = (int)(i % K), k = r / ch, co = r % ch;
+  dst[i] = P::from_f32(w[((size_t)ci * ch + co) * 4 + k]);
+}
 __device__ __forceinline__ float sinus(int t, int j, int td) {
   const int half = td / 2;
   const float step = -logf(10000.f) / (float)(half - 1);
@@ -222,16 +267,31 @@ template <class P>
 int pack_impl(const dppo_unet_desc& d, int n_time, const float* prm, char* pk, hipStream_t s) {
   typedef typename P::elem_t E;
   const Layout L = make_layout(d, P::ESIZE, n_time);
-  auto pl = [&](const Lin& l) { launch_cast_pad<P>(prm + l.w, l.out, l.in, l.in, pk + l.pk, l.Kp, s); };
+  auto pl = [&](const Lin& l) {
+    launch_cast_pad<P>(prm + l.w, l.out, l.in, l.in, pk + l.pk, l.Kp, s);
+    launch_transpose_cast<P>(prm + l.w, l.out, l.inT, l.in, 0, pk + l.pkT, rup(l.out, 64), s);  // [inT][out_p] = W^T
+  };
   auto pc = [&](const Conv& c) {
     if (!c.transposed) {
       const size_t n = (size_t)c.co * c.Kp;
       hipLaunchKernelGGL((pack_conv_kernel<P>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, prm + c.w, c.co, c.ci,
                          c.ks, c.cip, (E*)(pk + c.pk));
+      if (c.stride == 2) {
+        const size_t nb = (size_t)4 * c.co * c.co;
+        hipLaunchKernelGGL((pack_down_bwd_kernel<P>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, prm + c.w, c.co,
+                           (E*)(pk + c.pkT));
+      } else if (c.co % 64 == 0) {  // (the 1x1 output conv, co = action_dim, gets its data gradient from its forward pack)
+        const size_t nb = (size_t)c.ci * c.ks * c.co;
+        hipLaunchKernelGGL((pack_conv_bwd_kernel<P>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, prm + c.w, c.co,
+                           c.ci, c.ks, (E*)(pk + c.pkT));
+      }
     } else {
       const size_t n = (size_t)2 * c.co * c.Kp;
       hipLaunchKernelGGL((pack_convT_kernel<P>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, prm + c.w, c.co,
                          (E*)(pk + c.pk));
+      const size_t nb = (size_t)4 * c.co * c.co;
+      hipLaunchKernelGGL((pack_convT_bwd_kernel<P>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, prm + c.w, c.co,
+                         (E*)(pk + c.pkT));
     }
   };
   auto pr = [&](const ResBlock& r) {
@@ -245,6 +305,8 @@ int pack_impl(const dppo_unet_desc& d, int n_time, const float* prm, char* pk, h
   for (auto& c : L.downs) pc(c);
   for (auto& c : L.ups) pc(c);
   pc(L.fin), pc(L.fin_out);
+  // the 1x1 output conv's data-gradient operand: [dim][64] = Wout^T, zero beyond action_dim
+  launch_transpose_cast<P>(prm + L.fin_out.w, d.action_dim, d.dim, d.dim, 0, pk + L.fin_out.pkT, 64, s);
   if (n_time > 0)
     hipLaunchKernelGGL(unet_time_table_kernel, dim3(n_time), dim3(64), 5 * d.time_dim * sizeof(float), s, prm + L.t1.w,
                        prm + L.t1.b, prm + L.t2.w, prm + L.t2.b, d.time_dim, (float*)(pk + L.temb));
@@ -674,6 +736,904 @@ struct Runner {
                        src_img.Tp(), src_img.T, C, prm + c.b, dst, ldd, zero_pads);
   }
 };
+
+
+// =====================================================================================================================
+// training: forward with a tape, backward to every parameter gradient
+// =====================================================================================================================
+// Gradients of activation images travel in the GEMMs' f32 output-row format: G[(b * Tp + t) * ld + coff + c], valid for
+// t < T (the other rows hold garbage nobody reads).  A gradient handed to a GEMM as an OPERAND is first turned into a
+// padded elem image with ZERO pads (gn_bwd / rows_to_img), which then serves both the data-gradient GEMM (the same
+// contiguous-window trick as the forward, flipped kernel) and, shifted by PAD rows, the A operand of the weight gradient.
+struct GradSrc {
+  const float* p;
+  int ld, coff, Tp;
+};
+
+template <class P>
+__global__ __launch_bounds__(256) void unet_train_input_kernel(const UnetTrainIO io, int T, int Da, int cond, int td,
+                                                               const float* temb, typename P::elem_t* img, int C,
+                                                               typename P::elem_t* g, typename P::elem_t* graw, int Kg,
+                                                               int act) {
+  const int64_t n = blockIdx.x;
+  const int b = io.brow[n], k = io.krow[n], AF = T * Da, Tp = T + 2 * PAD;
+  const float* x = io.gathered ? io.chains + (size_t)b * 2 * AF : io.chains + ((size_t)b * (io.Kft + 1) + k) * AF;
+  for (int i = threadIdx.x; i < Tp * C; i += 256) {
+    const int tp = i / C, c = i % C, t = tp - PAD;
+    img[(size_t)n * Tp * C + i] = P::from_f32((t >= 0 && t < T && c < Da) ? x[t * Da + c] : 0.f);
+  }
+  const int tt = io.ksteps[k].t;
+  for (int c = threadIdx.x; c < Kg; c += 256) {
+    float v = 0.f;
+    if (c < td)
+      v = temb[(size_t)tt * td + c];
+    else if (c < td + cond)
+      v = io.obs[(size_t)b * cond + (c - td)];
+    graw[(size_t)n * Kg + c] = P::from_f32(v);
+    if (act >= 0 && c < td + cond) v = act_f(act, v);
+    g[(size_t)n * Kg + c] = P::from_f32(v);
+  }
+}
+
+// d_eps elem [N][ldde] (column t * Da + c) -> padded image [N][Tp][64]
+template <class P>
+__global__ __launch_bounds__(256) void unet_deps_img_kernel(const typename P::elem_t* de, int ldde, int T, int Da,
+                                                            typename P::elem_t* img) {
+  const int64_t n = blockIdx.x;
+  const int Tp = T + 2 * PAD;
+  for (int i = threadIdx.x; i < Tp * 64; i += 256) {
+    const int tp = i / 64, c = i % 64, t = tp - PAD;
+    img[(size_t)n * Tp * 64 + i] = (t >= 0 && t < T && c < Da) ? de[(size_t)n * ldde + t * Da + c] : P::from_f32(0.f);
+  }
+}
+
+struct GnBwdArgs {
+  const float* u;  // conv output (pre-GroupNorm) rows [rows * Tps][lds]
+  int lds, Tps, T, C, G;
+  const float *gamma, *beta;
+  float eps;
+  int act;
+  GradSrc up[2];   // upstream gradient(s) w.r.t. this half's OUTPUT (after FiLM for the first half)
+  int n_up;
+  int film;        // 0 none, 1 additive, 2 scale / bias
+  const float* emb;
+  int lde;
+  float* demb;     // [rows][lde]: d loss / d FiLM parameters (film != 0)
+  void* dU;        // out: padded elem image [rows][Tp][C], zero pads
+  float* dgb;      // out: per-sample [rows][2 C]: d gamma | d beta contributions
+};
+template <class P>
+__global__ __launch_bounds__(256) void unet_gn_bwd_kernel(const GnBwdArgs a) {
+  typedef typename P::elem_t E;
+  __shared__ float mean[32], rstd[32], s1[32], s2[32];
+  const int64_t b = blockIdx.x;
+  const int cg = a.C / a.G, cnt = cg * a.T, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float* u = a.u + (size_t)b * a.Tps * a.lds;
+  auto upstream = [&](int t, int c) {
+    float v = a.up[0].p[((size_t)b * a.up[0].Tp + t) * a.up[0].ld + a.up[0].coff + c];
+    if (a.n_up > 1) v += a.up[1].p[((size_t)b * a.up[1].Tp + t) * a.up[1].ld + a.up[1].coff + c];
+    return v;
+  };
+  // d loss / d z (z = GroupNorm output, the activation's input) of element (t, c), given the group statistics
+  auto dz_of = [&](int t, int c, float m, float r, float& xhat) {
+    xhat = (u[(size_t)t * a.lds + c] - m) * r;
+    const float z = xhat * a.gamma[c] + a.beta[c];
+    float dh = upstream(t, c);
+    if (a.film == 2) dh *= a.emb[(size_t)b * a.lde + c];
+    return dh * act_grad_f(a.act, z);
+  };
+  for (int g = w; g < a.G; g += 4) {
+    float s = 0.f;
+    for (int i = lane; i < cnt; i += 64) s += u[(size_t)(i / cg) * a.lds + g * cg + (i % cg)];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float m = s / (float)cnt;
+    float q = 0.f;
+    for (int i = lane; i < cnt; i += 64) {
+      const float dlt = u[(size_t)(i / cg) * a.lds + g * cg + (i % cg)] - m;
+      q += dlt * dlt;
+    }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float r = 1.f / sqrtf(q / (float)cnt + a.eps);
+    float t1 = 0.f, t2 = 0.f;  // sum dxhat, sum dxhat * xhat over the group
+    for (int i = lane; i < cnt; i += 64) {
+      const int t = i / cg, c = g * cg + (i % cg);
+      float xh;
+      const float dxh = dz_of(t, c, m, r, xh) * a.gamma[c];
+      t1 += dxh, t2 += dxh * xh;
+    }
+    for (int o = 32; o > 0; o >>= 1) t1 += __shfl_xor(t1, o), t2 += __shfl_xor(t2, o);
+    if (lane == 0) mean[g] = m, rstd[g] = r, s1[g] = t1 / (float)cnt, s2[g] = t2 / (float)cnt;
+  }
+  __syncthreads();
+  const int Tp = a.T + 2 * PAD;
+  E* dU = (E*)a.dU + (size_t)b * Tp * a.C;
+  for (int i = threadIdx.x; i < a.T * a.C; i += 256) {
+    const int t = i / a.C, c = i % a.C, g = c / cg;
+    float xh;
+    const float dxh = dz_of(t, c, mean[g], rstd[g], xh) * a.gamma[c];
+    dU[(size_t)(t + PAD) * a.C + c] = P::from_f32(rstd[g] * (dxh - s1[g] - xh * s2[g]));
+  }
+  for (int i = threadIdx.x; i < 2 * PAD * a.C; i += 256) {
+    const int r = i / a.C, c = i % a.C;
+    dU[(size_t)(r < PAD ? r : a.T + r) * a.C + c] = P::from_f32(0.f);
+  }
+  // per-channel sums over t: d gamma, d beta, and the FiLM parameter gradients
+  for (int c = threadIdx.x; c < a.C; c += 256) {
+    const int g = c / cg;
+    float dg = 0.f, db = 0.f, dsc = 0.f, dbi = 0.f;
+    for (int t = 0; t < a.T; ++t) {
+      float xh;
+      const float dz = dz_of(t, c, mean[g], rstd[g], xh);
+      dg += dz * xh, db += dz;
+      if (a.film != 0) {
+        const float dout = upstream(t, c);
+        dbi += dout;
+        if (a.film == 2) dsc += dout * act_f(a.act, xh * a.gamma[c] + a.beta[c]);
+      }
+    }
+    a.dgb[(size_t)b * 2 * a.C + c] = dg;
+    a.dgb[(size_t)b * 2 * a.C + a.C + c] = db;
+    if (a.film == 1) a.demb[(size_t)b * a.lde + c] = dbi;
+    if (a.film == 2) a.demb[(size_t)b * a.lde + c] = dsc, a.demb[(size_t)b * a.lde + a.C + c] = dbi;
+  }
+}
+
+// sum of up to two gradient sources -> padded elem image with zero pads (an operand for the residual conv's GEMMs)
+template <class P>
+__global__ __launch_bounds__(256) void unet_rows_to_img_kernel(GradSrc a0, GradSrc a1, int n_src, int T, int C,
+                                                               typename P::elem_t* img) {
+  const int64_t b = blockIdx.x;
+  const int Tp = T + 2 * PAD;
+  typename P::elem_t* d = img + (size_t)b * Tp * C;
+  for (int i = threadIdx.x; i < Tp * C; i += 256) {
+    const int tp = i / C, c = i % C, t = tp - PAD;
+    float v = 0.f;
+    if (t >= 0 && t < T) {
+      v = a0.p[((size_t)b * a0.Tp + t) * a0.ld + a0.coff + c];
+      if (n_src > 1) v += a1.p[((size_t)b * a1.Tp + t) * a1.ld + a1.coff + c];
+    }
+    d[i] = P::from_f32(v);
+  }
+}
+// the same into the FORWARD GEMM's output-row format of a strided / phase layer (the A operand of its weight gradient):
+//   mode 1 (Downsample1d): rows b * Tps + t', t' < T: dst[.][c] = G(b, t', c); zero rows beyond
+//   mode 2 (Upsample1d)  : rows b * Tps + m, m < T / 2: dst[.][ph * C + c] = G(b, 2 m + ph, c)
+template <class P>
+__global__ __launch_bounds__(256) void unet_rows_fmt_kernel(GradSrc a0, GradSrc a1, int n_src, int T, int C, int mode, int Tps,
+                                                            typename P::elem_t* dst) {
+  const int64_t b = blockIdx.x;
+  const int W = mode == 2 ? 2 * C : C;
+  typename P::elem_t* d = dst + (size_t)b * Tps * W;
+  for (int i = threadIdx.x; i < Tps * W; i += 256) {
+    const int r = i / W, cc = i % W;
+    int t = r, c = cc;
+    if (mode == 2) t = 2 * r + cc / C, c = cc % C;
+    float v = 0.f;
+    if (t < T) {
+      v = a0.p[((size_t)b * a0.Tp + t) * a0.ld + a0.coff + c];
+      if (n_src > 1) v += a1.p[((size_t)b * a1.Tp + t) * a1.ld + a1.coff + c];
+    }
+    d[i] = P::from_f32(v);
+  }
+}
+// two-phase data gradient of Downsample1d: src rows b * Tps + m hold [dx(2m) | dx(2m+1)] -> f32 rows of the big image
+__global__ __launch_bounds__(256) void unet_phase_rows_kernel(const float* src, int lds, int Tps, int Tsmall, int C, float* dst,
+                                                              int Tpd) {
+  const int64_t b = blockIdx.x;
+  for (int i = threadIdx.x; i < 2 * Tsmall * C; i += 256) {
+    const int t = i / C, c = i % C, m = t / 2, ph = t % 2;
+    dst[((size_t)b * Tpd + t) * C + c] = src[((size_t)b * Tps + m) * lds + ph * C + c];
+  }
+}
+// deterministic column sums of an f32 matrix: out[c] (+)= sum_r A[r][c]
+__global__ __launch_bounds__(256) void unet_colsum1_kernel(const float* A, int64_t M, int N, int lda, float* part, int blocks) {
+  const int64_t per = (M + blocks - 1) / blocks, r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < M ? r0 + per : M;
+  for (int c = threadIdx.x; c < N; c += 256) {
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += A[r * lda + c];
+    part[(size_t)blockIdx.x * N + c] = s;
+  }
+}
+__global__ __launch_bounds__(256) void unet_colsum2_kernel(const float* part, int blocks, int N, float* out, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  float s = 0.f;
+  for (int b = 0; b < blocks; ++b) s += part[(size_t)b * N + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+// bias gradient = column sums over the rows of a padded elem image (pads are zero)
+template <class P>
+__global__ __launch_bounds__(256) void unet_colsumE_kernel(const typename P::elem_t* A, int64_t M, int N, int lda, float* part,
+                                                           int blocks) {
+  const int64_t per = (M + blocks - 1) / blocks, r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < M ? r0 + per : M;
+  for (int c = threadIdx.x; c < N; c += 256) {
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += P::to_f32(A[r * lda + c]);
+    part[(size_t)blockIdx.x * N + c] = s;
+  }
+}
+// packed weight gradient [N1][ld] -> the flat layout: conv w[co][ci][k] <- dWp[co][k * cip + ci]; linear: ks = 1
+__global__ void unet_unpack_conv_kernel(const float* dWp, int ld, int co, int ci, int ks, int cip, float* out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)co * ci * ks) return;
+  const int k = (int)(i % ks), c = (int)((i / ks) % ci), o = (int)(i / ((size_t)ks * ci));
+  out[i] = dWp[(size_t)o * ld + k * cip + c];
+}
+// ConvTranspose1d w[ci][co][4] <- dW2[phase * C + co][slot * C + ci] (see pack_convT_kernel)
+__global__ void unet_unpack_convT_kernel(const float* dW2, int ld, int ch, float* out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)ch * ch * 4) return;
+  const int k = (int)(i % 4), co = (int)((i / 4) % ch), ci = (int)(i / ((size_t)4 * ch));
+  const int phase = (k == 1 || k == 3) ? 0 : 1;
+  const int slot = k == 1 ? 1 : (k == 3 ? 0 : (k == 0 ? 2 : 1));
+  out[i] = dW2[(size_t)(phase * ch + co) * ld + slot * ch + ci];
+}
+// G[k][j] = sum over rows with krow == k of dg[row][j] (j < td): one block per k, fixed order
+__global__ __launch_bounds__(256) void unet_temb_segsum_kernel(const float* dg, int ld, const int32_t* krow, int64_t N, int td,
+                                                               float* G) {
+  __shared__ float red[256];
+  const int k = blockIdx.x;
+  for (int j = 0; j < td; ++j) {
+    float s = 0.f;
+    for (int64_t n = threadIdx.x; n < N; n += 256)
+      if (krow[n] == k) s += dg[n * ld + j];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) G[(size_t)k * td + j] = red[0];
+    __syncthreads();
+  }
+}
+// backward of time_mlp (Linear(d, 4d) -> Mish -> Linear(4d, d)) from G[k][d] = d loss / d temb[t_k]; one block
+__global__ __launch_bounds__(256) void unet_time_bwd_kernel(const float* w1, const float* b1, const float* w2, const float* G,
+                                                            const dppo_step* ksteps, int Kft, int td, float* gw1, float* gb1,
+                                                            float* gw2, float* gb2) {
+  extern __shared__ float sh[];  // per k: e0[td], z1[4td], dz1[4td]
+  const int H = 4 * td, per = td + 2 * H, tid = threadIdx.x;
+  for (int k = 0; k < Kft; ++k) {
+    float* e0 = sh + k * per;
+    for (int j = tid; j < td; j += 256) e0[j] = sinus(ksteps[k].t, j, td);
+  }
+  __syncthreads();
+  for (int i = tid; i < Kft * H; i += 256) {
+    const int k = i / H, o = i % H;
+    const float* e0 = sh + k * per;
+    float s = b1[o];
+    for (int j = 0; j < td; ++j) s += w1[o * td + j] * e0[j];
+    sh[k * per + td + o] = s;
+  }
+  __syncthreads();
+  for (int i = tid; i < Kft * H; i += 256) {  // dz1 = (W2^T G[k]) * mish'(z1)
+    const int k = i / H, o = i % H;
+    float s = 0.f;
+    for (int j = 0; j < td; ++j) s += w2[j * H + o] * G[k * td + j];
+    sh[k * per + td + H + o] = s * mish_grad_f(sh[k * per + td + o]);
+  }
+  __syncthreads();
+  for (int i = tid; i < td * H; i += 256) {  // gw2[j][o] = sum_k G[k][j] mish(z1[k][o])
+    const int j = i / H, o = i % H;
+    float s = 0.f;
+    for (int k = 0; k < Kft; ++k) s += G[k * td + j] * mish_f(sh[k * per + td + o]);
+    gw2[i] = s;
+  }
+  for (int j = tid; j < td; j += 256) {
+    float s = 0.f;
+    for (int k = 0; k < Kft; ++k) s += G[k * td + j];
+    gb2[j] = s;
+  }
+  for (int i = tid; i < H * td; i += 256) {  // gw1[o][j] = sum_k dz1[k][o] e0[k][j]
+    const int o = i / td, j = i % td;
+    float s = 0.f;
+    for (int k = 0; k < Kft; ++k) s += sh[k * per + td + H + o] * sh[k * per + j];
+    gw1[i] = s;
+  }
+  for (int o = tid; o < H; o += 256) {
+    float s = 0.f;
+    for (int k = 0; k < Kft; ++k) s += sh[k * per + td + H + o];
+    gb1[o] = s;
+  }
+}
+
+}  // namespace
+
+template <class P>
+struct UnetTrainer {
+  typedef typename P::elem_t E;
+  dppo_unet_desc d;
+  Layout L;
+  const float* prm;
+  const char* pk;
+  int64_t rows;
+  hipStream_t s;
+  char* base;
+  size_t off, cap;
+  bool dry;
+  UnetTrainIO io;
+  // tape
+  struct RBTape {
+    const ResBlock* r;
+    Img in;
+    float *u1, *u2, *emb;
+    Img mid;
+    void *ez[2], *ea[2];  // encoder pre-activations / activations
+    int T;
+  };
+  std::vector<RBTape> tape;  // forward order
+  struct LvlTape {
+    Img skip_in;  // input of Downsample1d / Upsample1d
+  };
+  Img in_img, down_in[4], up_in[4], fin_in, fin_mid;
+  float* fin_u;
+  void* g;      // conditioning rows [rows][Kg] (activated for the one-layer encoder)
+  void* graw;   // the same before the activation
+  float* eps;   // [rows][AF]
+  float* dgacc; // [rows][Kg-ish] accumulated d loss / d g (time-embedding columns)
+  // scratch shared by the backward
+  float *tmpA, *tmpB, *tmpC, *slab, *dwp, *part, *dgb;
+  void *imgA, *imgB;
+  size_t tmp_floats, slab_floats;
+
+  void* take(size_t bytes) {
+    off = al(off);
+    void* p = dry ? nullptr : base + off;
+    off += bytes + 65536;
+    return p;
+  }
+  Img new_img(int T, int C) { return Img{take((size_t)rows * (T + 2 * PAD) * C * P::ESIZE), T, C}; }
+  float* new_f32(size_t n) { return (float*)take(n * 4); }
+
+  // ------------------------------------------------------------------------------------------------ GEMM wrappers
+  void gemm(const void* X, int ldx, int M, const void* Wp, int N, int Kp, const float* bias, float* out, int ldo,
+            const float* res = nullptr, int ldres = 0) {
+    if (dry) return;
+    GemmNT g2;
+    memset(&g2, 0, sizeof(g2));
+    g2.X = X, g2.ldx = ldx, g2.M = M, g2.N = N, g2.Kp = Kp, g2.W = Wp, g2.ldw = Kp, g2.bias = bias, g2.out_f32 = out;
+    g2.ldo32 = ldo, g2.res = res, g2.ldres = ldres;
+    launch_gemm_nt<P>(g2, s);
+  }
+  const char* imgrow(const Img& im, int r0) const { return (const char*)im.p + (size_t)r0 * im.C * P::ESIZE; }
+  // conv forward / data gradient over an image: rows = rows * Tp / stride
+  void conv_gemm(const Img& in, int r0, int stride, const void* Wp, int N, int Kp, const float* bias, float* out, int ldo,
+                 const float* res = nullptr, int ldres = 0) {
+    gemm(dry ? nullptr : imgrow(in, r0), stride * in.C, (int)(rows * in.Tp() / stride), Wp, N, Kp, bias, out, ldo, res, ldres);
+  }
+  // dWp[N1][N2] = A^T . B over M rows (A [M][lda] elem, B rows may overlap: width N2 over stride ldb); -> dwp (f32 [N1][N2])
+  void wgrad(const void* A, int lda, int N1, const void* Bm, int ldb, int N2, int64_t M) {
+    if (dry) return;
+    int64_t splits = (M + 2047) / 2048;
+    if (splits > 32) splits = 32;
+    while (splits > 1 && (size_t)splits * N1 * N2 > slab_floats) --splits;
+    int64_t rps = ((M + splits - 1) / splits + 63) / 64 * 64;
+    splits = (M + rps - 1) / rps;
+    GemmTN t;
+    memset(&t, 0, sizeof(t));
+    t.A = A, t.B = Bm, t.M = (int)M, t.N1 = N1, t.N2 = N2, t.lda = lda, t.ldb = ldb, t.ncol_a = N1, t.ncol_b = N2;
+    t.slab = slab, t.ldc = N2, t.splits = (int)splits, t.rows_per_split = (int)rps;
+    launch_gemm_tn<P>(t, s);
+    launch_slab_reduce_2d(slab, (int)splits, N1, N2, N2, dwp, N2, 1.f, s);
+  }
+  void colsum_f32(const float* A, int64_t M, int N, int lda, float* out, int accumulate = 0) {
+    if (dry) return;
+    const int blocks = 64;
+    hipLaunchKernelGGL(unet_colsum1_kernel, dim3(blocks), dim3(256), 0, s, A, M, N, lda, part, blocks);
+    hipLaunchKernelGGL(unet_colsum2_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, blocks, N, out, accumulate);
+  }
+  void colsum_img(const void* A, int64_t M, int N, int lda, float* out) {
+    if (dry) return;
+    const int blocks = 64;
+    hipLaunchKernelGGL((unet_colsumE_kernel<P>), dim3(blocks), dim3(256), 0, s, (const E*)A, M, N, lda, part, blocks);
+    hipLaunchKernelGGL(unet_colsum2_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, blocks, N, out, 0);
+  }
+
+  // ------------------------------------------------------------------------------------------------ forward
+  void encoder_fwd(RBTape& tp) {
+    const ResBlock& r = *tp.r;
+    const void* x = g;
+    int K = L.Kg;
+    tp.emb = new_f32((size_t)rows * rup(r.cc, 16));
+    for (int i = 0; i < r.n_enc; ++i) {
+      const Lin& l = r.enc[i];
+      if (i + 1 < r.n_enc) {
+        tp.ez[i] = take((size_t)rows * rup(l.out, 64) * P::ESIZE);
+        tp.ea[i] = take((size_t)rows * rup(l.out, 64) * P::ESIZE);
+      }
+      if (!dry) {
+        GemmNT g2;
+        memset(&g2, 0, sizeof(g2));
+        g2.X = x, g2.ldx = K, g2.M = (int)rows, g2.N = l.out, g2.Kp = l.Kp, g2.W = pk + l.pk, g2.ldw = l.Kp, g2.bias = prm + l.b;
+        if (i + 1 < r.n_enc)
+          g2.out_pre = tp.ez[i], g2.out_act = tp.ea[i], g2.ldo = rup(l.out, 64), g2.act = d.act;
+        else
+          g2.out_f32 = tp.emb, g2.ldo32 = rup(r.cc, 16);
+        launch_gemm_nt<P>(g2, s);
+      }
+      if (i + 1 < r.n_enc) x = tp.ea[i], K = rup(l.out, 64);
+    }
+  }
+  // one block; `out` is an image of width ldd the block writes at channel offset coff (and optionally a second place)
+  void resblock_fwd(const ResBlock& r, const Img& in, void* out, int ldd, int coff, int zero_pads, void* dst2 = nullptr,
+                    int ldd2 = 0, int coff2 = 0, int zero2 = 0) {
+    RBTape tp;
+    memset(&tp, 0, sizeof(tp));
+    tp.r = &r, tp.in = in, tp.T = in.T;
+    const int T = in.T, Tp = in.Tp(), ldc = rup(r.co, 16);
+    encoder_fwd(tp);
+    tp.u1 = new_f32((size_t)rows * Tp * ldc);
+    tp.u2 = new_f32((size_t)rows * Tp * ldc);
+    tp.mid = new_img(T, r.co);
+    conv_gemm(in, PAD - r.c1.ks / 2, 1, pk + r.c1.pk, r.co, r.c1.Kp, prm + r.c1.b, tp.u1, ldc);
+    GnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src = tp.u1, a.lds = ldc, a.Tps = Tp, a.T = T, a.C = r.co, a.G = d.n_groups, a.gamma = prm + r.n1.g;
+    a.beta = prm + r.n1.b, a.eps = d.groupnorm_eps, a.act = d.act, a.film = d.cond_predict_scale ? 2 : 1, a.emb = tp.emb;
+    a.lde = rup(r.cc, 16), a.dst = tp.mid.p, a.ldd = r.co, a.zero_pads = 1;
+    if (!dry) hipLaunchKernelGGL((unet_gn_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, a);
+    conv_gemm(tp.mid, PAD - r.c2.ks / 2, 1, pk + r.c2.pk, r.co, r.c2.Kp, prm + r.c2.b, tp.u2, ldc);
+    memset(&a, 0, sizeof(a));
+    a.src = tp.u2, a.lds = ldc, a.Tps = Tp, a.T = T, a.C = r.co, a.G = d.n_groups, a.gamma = prm + r.n2.g;
+    a.beta = prm + r.n2.b, a.eps = d.groupnorm_eps, a.act = d.act;
+    if (r.has_res) {
+      conv_gemm(in, PAD, 1, pk + r.res.pk, r.co, r.res.Kp, prm + r.res.b, tmpA, ldc);
+      a.res = 1, a.resf = tmpA, a.ldr = ldc;
+    } else {
+      a.res = 2, a.resi = in.p, a.ldri = in.C;
+    }
+    a.dst = out, a.ldd = ldd, a.coff = coff, a.zero_pads = zero_pads, a.dst2 = dst2, a.ldd2 = ldd2, a.coff2 = coff2;
+    a.zero_pads2 = zero2;
+    if (!dry) hipLaunchKernelGGL((unet_gn_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, a);
+    tape.push_back(tp);
+  }
+  Img cat[4];
+  void forward() {
+    const int nl = d.n_levels, T0 = d.horizon_steps;
+    tape.clear();
+    in_img = new_img(T0, 64);
+    g = take((size_t)rows * L.Kg * P::ESIZE);
+    graw = take((size_t)rows * L.Kg * P::ESIZE);
+    eps = new_f32((size_t)rows * T0 * d.action_dim);
+    if (!dry)
+      hipLaunchKernelGGL((unet_train_input_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, io, T0, d.action_dim, d.cond_dim,
+                         d.time_dim, (const float*)(pk + L.temb), (E*)in_img.p, 64, (E*)g, (E*)graw, L.Kg,
+                         d.larger_encoder ? -1 : d.act);
+    for (int l = 1; l < nl; ++l) cat[l] = new_img(T0 >> l, 2 * L.dims[l + 1]);
+    Img cur = in_img;
+    for (int i = 0; i < nl; ++i) {
+      const int C = L.dims[i + 1], T = T0 >> i;
+      Img a = new_img(T, C);
+      resblock_fwd(L.down[2 * i], cur, a.p, C, 0, 1);
+      Img o = new_img(T, C);
+      resblock_fwd(L.down[2 * i + 1], a, o.p, C, 0, 1, i >= 1 ? cat[i].p : nullptr, 2 * C, C, 1);
+      cur = o;
+      if (i < nl - 1) {
+        const Conv& c = L.downs[i];
+        down_in[i] = cur;
+        conv_gemm(cur, PAD - 1, 2, pk + c.pk, c.co, c.Kp, prm + c.b, tmpA, rup(C, 16));
+        Img dn = new_img(T / 2, C);
+        if (!dry)
+          hipLaunchKernelGGL((unet_scatter_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, tmpA, rup(C, 16), cur.Tp() / 2,
+                             T / 2, 1, C, (E*)dn.p, C, 0, 1);
+        cur = dn;
+      }
+    }
+    for (int i = 0; i < 2; ++i) {
+      const int C = L.dims[nl];
+      const bool to_cat = i == 1 && nl >= 2;
+      Img o = to_cat ? cat[nl - 1] : new_img(cur.T, C);
+      resblock_fwd(L.mid[i], cur, o.p, to_cat ? 2 * C : C, 0, to_cat ? 0 : 1);
+      cur = Img{o.p, cur.T, to_cat ? 2 * C : C};
+    }
+    for (int j = 0; j < nl - 1; ++j) {
+      const int din = L.dims[nl - 1 - j];
+      Img a = new_img(cur.T, din);
+      resblock_fwd(L.up[2 * j], cur, a.p, din, 0, 1);
+      Img b2 = new_img(cur.T, din);
+      resblock_fwd(L.up[2 * j + 1], a, b2.p, din, 0, 1);
+      const Conv& c = L.ups[j];
+      up_in[j] = b2;
+      conv_gemm(b2, PAD - 1, 1, pk + c.pk, 2 * din, c.Kp, nullptr, tmpA, rup(2 * din, 16));
+      const int lvl = nl - 2 - j;
+      const bool to_cat = lvl >= 1;
+      Img up = to_cat ? cat[lvl] : new_img(b2.T * 2, din);
+      const int ldd = to_cat ? 2 * din : din;
+      if (!dry)
+        hipLaunchKernelGGL((unet_up_scatter_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, tmpA, rup(2 * din, 16), b2.Tp(),
+                           b2.T, din, prm + c.b, up.p, ldd, to_cat ? 0 : 1);
+      cur = Img{up.p, b2.T * 2, ldd};
+    }
+    {
+      const int C = d.dim, T = cur.T, ldc = rup(C, 16);
+      fin_in = cur;
+      fin_u = new_f32((size_t)rows * cur.Tp() * ldc);
+      fin_mid = new_img(T, C);
+      conv_gemm(cur, PAD - L.fin.ks / 2, 1, pk + L.fin.pk, C, L.fin.Kp, prm + L.fin.b, fin_u, ldc);
+      GnArgs a;
+      memset(&a, 0, sizeof(a));
+      a.src = fin_u, a.lds = ldc, a.Tps = cur.Tp(), a.T = T, a.C = C, a.G = d.n_groups, a.gamma = prm + L.fin_n.g;
+      a.beta = prm + L.fin_n.b, a.eps = d.groupnorm_eps, a.act = d.act, a.dst = fin_mid.p, a.ldd = C, a.zero_pads = 1;
+      if (!dry) hipLaunchKernelGGL((unet_gn_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, a);
+      const int ldo = 16 * ((d.action_dim + 15) / 16);
+      conv_gemm(fin_mid, PAD, 1, pk + L.fin_out.pk, d.action_dim, L.fin_out.Kp, prm + L.fin_out.b, tmpA, ldo);
+      const int64_t n = rows * T * d.action_dim;
+      if (!dry)
+        hipLaunchKernelGGL(unet_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tmpA, ldo, fin_mid.Tp(), T,
+                           d.action_dim, eps, rows);
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------------ backward
+  float* grad;
+  // rows a weight-gradient GEMM may include: the window of its last row must end inside the image
+  int64_t wrows(const Img& im, int r0, int stride, int win) const { return ((int64_t)rows * im.Tp() - r0 - win) / stride + 1; }
+  void conv_wgrad(const Conv& c, const void* dUimg_or_rows, int lda, int N1, const Img& in, int r0, int stride, int win) {
+    // A: gradient rows [.][N1] aligned with the forward GEMM's output rows; B: the forward's X operand
+    wgrad(dUimg_or_rows, lda, N1, dry ? nullptr : imgrow(in, r0), stride * in.C, win * in.C, wrows(in, r0, stride, win));
+  }
+  void unpack_conv(const Conv& c, int ld) {
+    if (dry) return;
+    const size_t n = (size_t)c.co * c.ci * c.ks;
+    hipLaunchKernelGGL(unet_unpack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dwp, ld, c.co, c.ci, c.ks,
+                       c.cip, grad + c.w);
+  }
+  // Conv1dBlock backward: upstream gradient(s) of the block-half output -> dU image (returned in `dU`), parameter
+  // gradients of the conv and the norm; FiLM gradients -> demb
+  void convblock_bwd(const Conv& c, const Norm& nm, const Img& in, const float* u, int T, GradSrc* up, int n_up, int film,
+                     const float* emb, int lde, float* demb, void* dU) {
+    const int C = c.co, Tp = T + 2 * PAD, ldc = rup(C, 16);
+    GnBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.u = u, a.lds = ldc, a.Tps = Tp, a.T = T, a.C = C, a.G = d.n_groups, a.gamma = prm + nm.g, a.beta = prm + nm.b;
+    a.eps = d.groupnorm_eps, a.act = d.act, a.n_up = n_up, a.up[0] = up[0];
+    if (n_up > 1) a.up[1] = up[1];
+    a.film = film, a.emb = emb, a.lde = lde, a.demb = demb, a.dU = dU, a.dgb = dgb;
+    if (!dry) hipLaunchKernelGGL((unet_gn_bwd_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, a);
+    colsum_f32(dgb, rows, 2 * C, 2 * C, grad + nm.g);  // d gamma | d beta are adjacent in the flat layout
+    // conv parameters: dW = dU^T . Xwin (A = dU image shifted by PAD rows = the GEMM's output-row alignment), db = colsum
+    Img dUi{dU, T, C};
+    conv_wgrad(c, dry ? nullptr : imgrow(dUi, PAD), C, C, in, PAD - c.ks / 2, 1, c.ks);
+    unpack_conv(c, c.ks * c.cip);
+    colsum_img(dU, rows * Tp, C, C, grad + c.b);
+  }
+  void encoder_bwd(const RBTape& tp, float* demb) {
+    // emb = L_last(...): gradients of the encoder's linears; d loss / d g accumulates into dgacc (time-embedding columns)
+    const ResBlock& r = *tp.r;
+    const int lde = rup(r.cc, 16);
+    // demb f32 -> elem operand
+    void* dcur = imgA;  // [rows][rup(cc,64)] elem
+    const int ldq = rup(r.cc, 64);
+    if (!dry) launch_cast_pad<P>(demb, (int)rows, r.cc, lde, dcur, ldq, s);
+    for (int i = r.n_enc - 1; i >= 0; --i) {
+      const Lin& l = r.enc[i];
+      const void* xin = i == 0 ? g : tp.ea[i - 1];
+      const int ldx = i == 0 ? L.Kg : rup(r.enc[i - 1].out, 64);
+      wgrad(dcur, ldq, l.out, xin, ldx, l.in, rows);
+      if (!dry) {
+        const size_t n = (size_t)l.out * l.in;
+        hipLaunchKernelGGL(unet_unpack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dwp, l.in, l.out, l.in,
+                           1, l.in, grad + l.w);
+      }
+      colsum_img(dcur, rows, l.out, ldq, grad + l.b);
+      if (i > 0) {  // d (previous activation) = dcur . W, times act'(z_{i-1})
+        if (!dry) {
+          GemmNT g2;
+          memset(&g2, 0, sizeof(g2));
+          g2.X = dcur, g2.ldx = ldq, g2.M = (int)rows, g2.N = l.in, g2.Kp = rup(l.out, 64), g2.W = pk + l.pkT;
+          g2.ldw = rup(l.out, 64), g2.dsrc = tp.ez[i - 1], g2.dsrc_kind = 2, g2.dsrc_ld = rup(r.enc[i - 1].out, 64);
+          g2.dact = d.act, g2.out_pre = dcur == imgA ? imgB : imgA, g2.ldo = ldq;
+          launch_gemm_nt<P>(g2, s);
+        }
+        dcur = dcur == imgA ? imgB : imgA;
+      } else {  // d g (time-embedding columns only; the state is data): accumulate over the blocks
+        if (!dry) {
+          GemmNT g2;
+          memset(&g2, 0, sizeof(g2));
+          g2.X = dcur, g2.ldx = ldq, g2.M = (int)rows, g2.N = d.time_dim, g2.Kp = rup(l.out, 64), g2.W = pk + l.pkT;
+          g2.ldw = rup(l.out, 64), g2.out_f32 = dgacc, g2.ldo32 = rup(d.time_dim, 16);
+          if (dg_started) g2.res = dgacc, g2.ldres = rup(d.time_dim, 16);
+          if (!d.larger_encoder)  // one-layer encoder = Linear(act(g)): the chain rule's act'(g) on the raw vector
+            g2.dsrc = graw, g2.dsrc_kind = 2, g2.dsrc_ld = L.Kg, g2.dact = d.act;
+          launch_gemm_nt<P>(g2, s);
+        }
+        dg_started = true;
+      }
+    }
+  }
+  bool dg_started;
+  // ResidualBlock1D backward.  up / n_up: gradient of the block's output; returns the gradient of its input in `gin`
+  // (f32 rows [rows * Tp][ci_ld]) unless `need_in` is false (the network input)
+  void resblock_bwd(const RBTape& tp, GradSrc* up, int n_up, float* gin, bool need_in) {
+    const ResBlock& r = *tp.r;
+    const int T = tp.T, Tp = T + 2 * PAD, C = r.co;
+    // second half: y = act(GN(u2)) + res
+    void* dU2 = imgA;
+    convblock_bwd(r.c2, r.n2, tp.mid, tp.u2, T, up, n_up, 0, nullptr, 0, nullptr, dU2);
+    // d mid = conv2 data gradient (f32 rows, width C)
+    Img dU2i{dU2, T, C};
+    conv_gemm(dU2i, PAD - r.c2.ks / 2, 1, pk + r.c2.pkT, C, r.c2.ks * C, nullptr, tmpB, rup(C, 16));
+    // first half: mid = FiLM(act(GN(u1)))
+    GradSrc gm{tmpB, rup(C, 16), 0, Tp};
+    float* demb = tmpC;
+    void* dU1 = imgB;
+    convblock_bwd(r.c1, r.n1, tp.in, tp.u1, T, &gm, 1, d.cond_predict_scale ? 2 : 1, tp.emb, rup(r.cc, 16), demb, dU1);
+    // input gradient: conv1 data gradient + the skip path
+    if (need_in) {
+      Img dU1i{dU1, T, C};
+      const int ldi = rup(r.ci, 16);
+      if (r.has_res) {
+        // dY image (sum of the upstream sources) feeds the 1x1 conv's data gradient, then conv1's adds to it
+        if (!dry)
+          hipLaunchKernelGGL((unet_rows_to_img_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, up[0], n_up > 1 ? up[1] : up[0],
+                             n_up, T, C, (E*)imgA);
+        Img dYi{imgA, T, C};
+        conv_gemm(dYi, PAD, 1, pk + r.res.pkT, r.ci, C, nullptr, gin, ldi);
+        conv_gemm(dU1i, PAD - r.c1.ks / 2, 1, pk + r.c1.pkT, r.ci, r.c1.ks * C, nullptr, gin, ldi, gin, ldi);
+      } else {
+        // identity skip: gin = conv1 data gradient + sum(up).  The GEMM's f32 addend takes one source; a second is added first
+        if (n_up == 1 && up[0].coff == 0 && up[0].Tp == Tp) {
+          conv_gemm(dU1i, PAD - r.c1.ks / 2, 1, pk + r.c1.pkT, r.ci, r.c1.ks * C, nullptr, gin, ldi, up[0].p, up[0].ld);
+        } else {
+          if (!dry)
+            hipLaunchKernelGGL((unet_rows_to_img_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, up[0],
+                               n_up > 1 ? up[1] : up[0], n_up, T, C, (E*)imgA);
+          conv_gemm(dU1i, PAD - r.c1.ks / 2, 1, pk + r.c1.pkT, r.ci, r.c1.ks * C, nullptr, gin, ldi);
+          if (!dry) add_img_rows(gin, ldi, imgA, T, C);
+        }
+      }
+    }
+    if (r.has_res) {  // parameters of the 1x1 residual conv: dW = dY^T . x, db = colsum(dY)
+      if (!need_in && !dry)
+        hipLaunchKernelGGL((unet_rows_to_img_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, up[0], n_up > 1 ? up[1] : up[0],
+                           n_up, T, C, (E*)imgA);
+      Img dYi{imgA, T, C};
+      conv_wgrad(r.res, dry ? nullptr : imgrow(dYi, PAD), C, C, tp.in, PAD, 1, 1);
+      unpack_conv(r.res, r.res.cip);
+      colsum_img(imgA, rows * Tp, C, C, grad + r.res.b);
+    }
+    encoder_bwd(tp, demb);
+  }
+  // gin[(b, t)][c] += img[b][t + PAD][c]
+  void add_img_rows(float* gin, int ld, const void* img, int T, int C);
+
+  void backward(const void* d_eps, int ldde, float* grad_) {
+    grad = grad_;
+    dg_started = false;
+    const int nl = d.n_levels, T0 = d.horizon_steps, Tp0 = T0 + 2 * PAD;
+    if (!dry) hipMemsetAsync(grad, 0, (size_t)L.n_params * 4, s);
+    // ---- final 1x1 conv
+    Img dE = new_img(T0, 64);
+    if (!dry)
+      hipLaunchKernelGGL((unet_deps_img_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, (const E*)d_eps, ldde, T0,
+                         d.action_dim, (E*)dE.p);
+    {
+      const Conv& c = L.fin_out;
+      wgrad(dry ? nullptr : imgrow(dE, PAD), 64, d.action_dim, dry ? nullptr : imgrow(fin_mid, PAD), fin_mid.C, fin_mid.C,
+            wrows(fin_mid, PAD, 1, 1));
+      unpack_conv(c, c.cip);
+      colsum_img(dE.p, rows * Tp0, d.action_dim, 64, grad + c.b);
+    }
+    // gradient buffers (f32 rows), two per level ping-pong + one for concat splits
+    size_t gmax = 0;
+    for (int l = 0; l < nl; ++l) {
+      const size_t b = (size_t)((T0 >> l) + 2 * PAD) * rup(2 * L.dims[l + 1], 16);
+      gmax = b > gmax ? b : gmax;
+    }
+    float* G[4];
+    for (int i = 0; i < 4; ++i) G[i] = new_f32((size_t)rows * gmax);
+    int gi = 0;
+    auto nextG = [&]() { return G[(gi++) & 3]; };
+    // d fin_mid = dE . Wout  (f32 rows, width dim)
+    float* g_finmid = nextG();
+    conv_gemm(dE, PAD, 1, pk + L.fin_out.pkT, d.dim, 64, nullptr, g_finmid, rup(d.dim, 16));
+    // final Conv1dBlock
+    GradSrc up0{g_finmid, rup(d.dim, 16), 0, Tp0};
+    convblock_bwd(L.fin, L.fin_n, fin_in, fin_u, T0, &up0, 1, 0, nullptr, 0, nullptr, imgA);
+    Img dUf{imgA, T0, d.dim};
+    float* gcur = nextG();
+    int gcur_ld = rup(fin_in.C, 16);
+    conv_gemm(dUf, PAD - L.fin.ks / 2, 1, pk + L.fin.pkT, fin_in.C, L.fin.ks * d.dim, nullptr, gcur, gcur_ld);
+    GradSrc cur{gcur, gcur_ld, 0, Tp0};  // gradient of the image feeding final_conv (width = its C)
+    int ti = (int)tape.size() - 1;
+    GradSrc skipg[4];
+    memset(skipg, 0, sizeof(skipg));
+    // ---- up path (reverse)
+    for (int j = nl - 2; j >= 0; --j) {
+      const int din = L.dims[nl - 1 - j];
+      const int lvl = nl - 2 - j;  // the level the upsampled map landed on
+      const Img& xin = up_in[j];   // Upsample1d's input (T small)
+      const int Ts = xin.T, Tb = 2 * Ts;
+      // `cur` is the gradient of the upsampled image: when it was written into a concat image its width is 2 din and the
+      // upper half belongs to the skip (handled at the consumer below), the lower half is ours
+      const Conv& c = L.ups[j];
+      // parameters: forward form Y2[(b, m)][ph * C + co] = Xwin . W2^T
+      void* dY2 = imgA;
+      if (!dry)
+        hipLaunchKernelGGL((unet_rows_fmt_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, cur, cur, 1, Tb, din, 2, xin.Tp(),
+                           (E*)dY2);
+      wgrad(dY2, 2 * din, 2 * din, dry ? nullptr : imgrow(xin, PAD - 1), din, 3 * din, wrows(xin, PAD - 1, 1, 3));
+      if (!dry) {
+        const size_t n = (size_t)din * din * 4;
+        hipLaunchKernelGGL(unet_unpack_convT_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dwp, 3 * din, din,
+                           grad + c.w);
+      }
+      // bias: both phases share it: column sums of the big-T gradient
+      void* dYimg = imgB;
+      if (!dry)
+        hipLaunchKernelGGL((unet_rows_to_img_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, cur, cur, 1, Tb, din, (E*)dYimg);
+      colsum_img(dYimg, rows * (Tb + 2 * PAD), din, din, grad + c.b);
+      // data: strided conv over the dy image: rows r' = b * (Tpb / 2) + s
+      Img dYi{dYimg, Tb, din};
+      float* gx = nextG();
+      conv_gemm(dYi, PAD - 1, 2, pk + c.pkT, din, 4 * din, nullptr, gx, rup(din, 16));
+      GradSrc up1{gx, rup(din, 16), 0, dYi.Tp() / 2};
+      // second block of the level
+      float* g1 = nextG();
+      resblock_bwd(tape[ti--], &up1, 1, g1, true);
+      GradSrc up2{g1, rup(din, 16), 0, Ts + 2 * PAD};
+      const int dout = L.dims[nl - j];
+      // (dedicated, not from the rotating set: its upper half is the skip's gradient, consumed much later by the down path)
+      float* g0 = new_f32((size_t)rows * (Ts + 2 * PAD) * rup(2 * dout, 16));
+      resblock_bwd(tape[ti--], &up2, 1, g0, true);  // input: concat image, width 2 * dims[nl - j]
+      cur = GradSrc{g0, rup(2 * dout, 16), 0, Ts + 2 * PAD};
+      skipg[nl - 1 - j] = GradSrc{g0, rup(2 * dout, 16), dout, Ts + 2 * PAD};  // the skip's half (level nl-1-j)
+      (void)lvl;
+    }
+    // ---- mid
+    for (int i = 1; i >= 0; --i) {
+      float* gq = nextG();
+      resblock_bwd(tape[ti--], &cur, 1, gq, true);
+      cur = GradSrc{gq, rup(L.dims[nl], 16), 0, (T0 >> (nl - 1)) + 2 * PAD};
+    }
+    // ---- down path (reverse)
+    for (int i = nl - 1; i >= 0; --i) {
+      const int C = L.dims[i + 1], T = T0 >> i;
+      GradSrc ups[2];
+      int n_up = 0;
+      ups[n_up++] = cur;                       // from the next layer (mid, or this level's Downsample1d below)
+      if (i >= 1 && nl >= 2) ups[n_up++] = skipg[i];  // from the concat consumer
+      float* g1 = nextG();
+      resblock_bwd(tape[ti--], ups, n_up, g1, true);
+      GradSrc u2{g1, rup(C, 16), 0, T + 2 * PAD};
+      float* g0 = nextG();
+      const bool need_in = i > 0;
+      resblock_bwd(tape[ti--], &u2, 1, g0, need_in);
+      if (i > 0) {
+        // Downsample1d of level i-1 produced this level's input: g0 is the gradient of its output (T small)
+        const Conv& c = L.downs[i - 1];
+        const Img& xin = down_in[i - 1];  // big-T image, C = dims[i]
+        const int Cb = L.dims[i], Tb = xin.T;
+        GradSrc gy{g0, rup(Cb, 16), 0, T + 2 * PAD};
+        // A operand in the forward GEMM's row format (b * Tpb / 2 + t'), and as an image for the data gradient
+        void* dYr = imgA;
+        if (!dry)
+          hipLaunchKernelGGL((unet_rows_fmt_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, gy, gy, 1, T, Cb, 1, xin.Tp() / 2,
+                             (E*)dYr);
+        wgrad(dYr, Cb, Cb, dry ? nullptr : imgrow(xin, PAD - 1), 2 * Cb, 3 * Cb, wrows(xin, PAD - 1, 2, 3));
+        unpack_conv(c, c.ks * c.cip);
+        colsum_img(dYr, rows * (xin.Tp() / 2), Cb, Cb, grad + c.b);
+        void* dYimg = imgB;
+        if (!dry)
+          hipLaunchKernelGGL((unet_rows_to_img_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, gy, gy, 1, T, Cb, (E*)dYimg);
+        Img dYi{dYimg, T, Cb};
+        conv_gemm(dYi, PAD, 1, pk + c.pkT, 2 * Cb, 2 * Cb, nullptr, tmpB, rup(2 * Cb, 16));
+        float* gb = nextG();
+        if (!dry)
+          hipLaunchKernelGGL(unet_phase_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, tmpB, rup(2 * Cb, 16), dYi.Tp(), T, Cb,
+                             gb, Tb + 2 * PAD);
+        cur = GradSrc{gb, Cb, 0, Tb + 2 * PAD};
+      }
+    }
+    // ---- time embedding: G[k][td] = segmented sum of d g over the rows of step k, then the time MLP's backward
+    if (!dry) {
+      float* Gk = part;  // [Kft][td]
+      hipLaunchKernelGGL(unet_temb_segsum_kernel, dim3(io.Kft), dim3(256), 0, s, dgacc, rup(d.time_dim, 16), io.krow, rows,
+                         d.time_dim, Gk);
+      const size_t lds = (size_t)io.Kft * (d.time_dim + 8 * d.time_dim) * 4;
+      hipLaunchKernelGGL(unet_time_bwd_kernel, dim3(1), dim3(256), lds, s, prm + L.t1.w, prm + L.t1.b, prm + L.t2.w, Gk, io.ksteps,
+                         io.Kft, d.time_dim, grad + L.t1.w, grad + L.t1.b, grad + L.t2.w, grad + L.t2.b);
+    }
+  }
+
+  void plan_scratch() {
+    const int nl = d.n_levels, T0 = d.horizon_steps;
+    int cmax = 64;
+    for (int i = 1; i <= nl; ++i) cmax = L.dims[i] > cmax ? L.dims[i] : cmax;
+    tmp_floats = (size_t)rows * (T0 + 2 * PAD) * 2 * cmax;
+    tmpA = new_f32(tmp_floats), tmpB = new_f32(tmp_floats), tmpC = new_f32((size_t)rows * 2 * cmax);
+    imgA = take(tmp_floats * P::ESIZE), imgB = take(tmp_floats * P::ESIZE);
+    size_t wmax = (size_t)2 * cmax * 5 * 2 * cmax;  // largest packed weight: first up block's conv1 (2C -> C, 5 taps) etc.
+    dwp = new_f32(wmax);
+    slab_floats = wmax * 8;
+    slab = new_f32(slab_floats);
+    part = new_f32((size_t)64 * 4 * cmax + 4096);
+    dgb = new_f32((size_t)rows * 2 * cmax);
+    dgacc = new_f32((size_t)rows * rup(d.time_dim, 16));
+  }
+};
+
+template <class P>
+__global__ __launch_bounds__(256) void unet_add_img_rows_kernel(float* gin, int ld, const typename P::elem_t* img, int T, int C) {
+  const int64_t b = blockIdx.x;
+  const int Tp = T + 2 * PAD;
+  for (int i = threadIdx.x; i < T * C; i += 256) {
+    const int t = i / C, c = i % C;
+    gin[((size_t)b * Tp + t) * ld + c] += P::to_f32(img[((size_t)b * Tp + t + PAD) * C + c]);
+  }
+}
+template <class P>
+void UnetTrainer<P>::add_img_rows(float* gin, int ld, const void* img, int T, int C) {
+  hipLaunchKernelGGL((unet_add_img_rows_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, gin, ld, (const E*)img, T, C);
+}
+
+template <class P>
+static void trainer_init(UnetTrainer<P>& t, const dppo_unet_desc& d, int64_t N) {
+  t.d = d;
+  t.L = make_layout(d, P::ESIZE, 0);
+  t.rows = N, t.off = 0, t.grad = nullptr;
+  memset(&t.io, 0, sizeof(t.io));
+  t.io.Kft = 1;
+}
+template <class P>
+size_t unet_trainer_bytes(const dppo_unet_desc& d, int64_t N) {
+  UnetTrainer<P> t;
+  trainer_init(t, d, N);
+  t.dry = true, t.base = nullptr, t.s = nullptr, t.prm = nullptr, t.pk = nullptr;
+  t.plan_scratch();
+  t.forward();
+  t.backward(nullptr, 0, nullptr);
+  return al(t.off);
+}
+template <class P>
+UnetTrainer<P>* unet_trainer_new(const dppo_unet_desc& d, const float* prm, const char* pk, int64_t N, void* ws, size_t wsb,
+                                 hipStream_t s) {
+  UnetTrainer<P>* t = new UnetTrainer<P>();
+  trainer_init(*t, d, N);
+  t->dry = false, t->base = (char*)ws, t->cap = wsb, t->s = s, t->prm = prm, t->pk = pk;
+  t->plan_scratch();
+  return t;
+}
+template <class P>
+float* unet_trainer_forward(UnetTrainer<P>* t, const UnetTrainIO& io) {
+  t->io = io;
+  t->forward();
+  return t->eps;
+}
+template <class P>
+void unet_trainer_backward(UnetTrainer<P>* t, const void* d_eps, int ldde, float* grad) {
+  t->backward(d_eps, ldde, grad);
+}
+template <class P>
+void unet_trainer_free(UnetTrainer<P>* t) {
+  delete t;
+}
+int unet_check_desc(const dppo_unet_desc* d) { return check_desc(d); }
+__global__ void unet_index_kernel(const int64_t* inds, const int64_t* kinds, int Kft, int64_t N, int32_t* brow, int32_t* krow) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  if (kinds != nullptr) {
+    brow[n] = (int32_t)n, krow[n] = (int32_t)kinds[n];
+  } else {
+    const int64_t ind = inds ? inds[n] : n;
+    brow[n] = (int32_t)(ind / Kft), krow[n] = (int32_t)(ind % Kft);
+  }
+}
+void launch_unet_index(const int64_t* inds, const int64_t* kinds, int Kft, int64_t N, int32_t* brow, int32_t* krow,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(unet_index_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, inds, kinds, Kft, N, brow, krow);
+}
+#define UNET_INST(P)                                                                                                    \
+  template size_t unet_trainer_bytes<P>(const dppo_unet_desc&, int64_t);                                                \
+  template UnetTrainer<P>* unet_trainer_new<P>(const dppo_unet_desc&, const float*, const char*, int64_t, void*, size_t, \
+                                               hipStream_t);                                                            \
+  template float* unet_trainer_forward<P>(UnetTrainer<P>*, const UnetTrainIO&);                                         \
+  template void unet_trainer_backward<P>(UnetTrainer<P>*, const void*, int, float*);                                    \
+  template void unet_trainer_free<P>(UnetTrainer<P>*);
+UNET_INST(F32)
+UNET_INST(BF16)
+
+namespace {
 
 template <class P>
 int forward_impl(const dppo_unet_desc& d, const float* prm, const char* pk, const float* x, const int64_t* t,

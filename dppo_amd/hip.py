@@ -115,6 +115,11 @@ SYMBOLS = {
                                     _P, _I, _I, _P, _L, _P]),
     "dppo_unet_chain_logprob": (_I, [C.POINTER(UnetDesc), _I, _P, _P, C.POINTER(DiffusionCfg), _P, _P, _I, _P, _P, _L, _P, _P,
                                      _L, _P]),
+    "dppo_unet_ppo_workspace_bytes": (_L, [C.POINTER(UnetDesc), _ND, _I, _L]),
+    "dppo_unet_ppo_loss_fwd_bwd": (_I, [C.POINTER(UnetDesc), _ND, _I, _P, _P, _P, _P, C.POINTER(DiffusionCfg),
+                                        C.POINTER(PpoCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P]),
+    "dppo_unet_denoise_mse_workspace_bytes": (_L, [C.POINTER(UnetDesc), _I, _L]),
+    "dppo_unet_denoise_mse_fwd_bwd": (_I, [C.POINTER(UnetDesc), _I, _P, _P, _P, _I, _P, _P, _P, _L, _P, _P, _P, _L, _P]),
     "dppo_grad_sq_norm": (_I, [_P, _L, _P, _P, _P]),
     "dppo_adamw_step": (_I, [_P, _P, _P, _P, _L, _I, _D, _D, _D, _D, _D, _P, _D, _P]),
     "dppo_adamw_step_dev": (_I, [_P, _P, _P, _P, _L, _P, _P, _D, _D, _D, _D, _P, _D, _P]),

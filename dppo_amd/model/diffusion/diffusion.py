@@ -290,17 +290,20 @@ class DiffusionModel(nn.Module):
         flat = net.flat_params()
         grad = torch.empty_like(flat)
         value = torch.zeros(1, dtype=torch.float64, device=dev)
-        wsb = lib.dppo_denoise_mse_workspace_bytes(C.byref(d), self.prec, N)
+        unet = getattr(net, "is_unet", False)
+        ws_bytes, entry = (lib.dppo_unet_denoise_mse_workspace_bytes, lib.dppo_unet_denoise_mse_fwd_bwd) if unet else (
+            lib.dppo_denoise_mse_workspace_bytes, lib.dppo_denoise_mse_fwd_bwd)
+        wsb = ws_bytes(C.byref(d), self.prec, N)
         if wsb < 0:
             hip.check(int(wsb), "dppo_denoise_mse_workspace_bytes")
         ws = self.__dict__.setdefault("_ws_mse", hip.Workspace()).get(wsb, dev)
         ts = self._time_steps(dev)
-        hip.check(lib.dppo_denoise_mse_fwd_bwd(
+        hip.check(entry(
             C.byref(d), self.prec, flat.data_ptr(), net.packed(self.prec, self.denoising_steps).data_ptr(), ts.data_ptr(),
             self.denoising_steps, obs.data_ptr(), pairs.data_ptr(), kinds.data_ptr(), N, grad.data_ptr(),
             value.data_ptr(), ws.data_ptr(), ws.numel(), hip.stream()), "dppo_denoise_mse_fwd_bwd")
         object.__setattr__(self, "last_loss_grad", grad)  # flat d loss / d parameters, for callers that step a flat optimiser
-        params = list(net.parameters())  # the flat image is their concatenation in this order
+        params = net.trunk_parameters()  # the flat image is their concatenation in this order
         views, off = [], 0
         for p in params:
             views.append(grad[off:off + p.numel()].view(p.shape))

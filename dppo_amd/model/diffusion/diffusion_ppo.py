@@ -98,9 +98,6 @@ class PPODiffusion(VPGDiffusion):
 
     def _run_ppo(self, obs, chains, returns, values, adv, logprobs, inds, kinds, N, reward_horizon, adv_gathered,
                  global_moments=None):
-        if getattr(self.actor_ft, "is_unet", False):
-            raise NotImplementedError("dppo_amd: the PPO update (backward pass) of a conv denoiser actor is not built yet; "
-                                      "sampling, log-probs and evaluation are")
         lib = hip.load()
         dev = obs.device
         da, dc = self.actor_ft.net_desc(), self.critic.net_desc()
@@ -110,12 +107,15 @@ class PPODiffusion(VPGDiffusion):
         pcfg = self._ppo_cfg(reward_horizon, adv_gathered)
         dcfg = self.diffusion_cfg()
         ks = self._logprob_schedule(dev)
-        wsb = lib.dppo_ppo_workspace_bytes(C.byref(da), C.byref(dc), self.prec, N)
+        unet = getattr(self.actor_ft, "is_unet", False)  # conv denoiser: same call, dppo_unet_* entry points
+        ws_bytes, entry = (lib.dppo_unet_ppo_workspace_bytes, lib.dppo_unet_ppo_loss_fwd_bwd) if unet else (
+            lib.dppo_ppo_workspace_bytes, lib.dppo_ppo_loss_fwd_bwd)
+        wsb = ws_bytes(C.byref(da), C.byref(dc), self.prec, N)
         if wsb < 0:
             hip.check(int(wsb), "dppo_ppo_workspace_bytes")
         ws = self._ws_ppo.get(wsb, dev)
         ga, gc = self.actor_ft.flat_grads(), self.critic.flat_grads()
-        hip.check(lib.dppo_ppo_loss_fwd_bwd(
+        hip.check(entry(
             C.byref(da), C.byref(dc), self.prec, self.actor_ft.flat_params().data_ptr(),
             self.actor_ft.packed(self.prec, K).data_ptr(), self.critic.flat_params().data_ptr(),
             self.critic.packed(self.prec, 0).data_ptr(), C.byref(dcfg), C.byref(pcfg), ks.data_ptr(), hip.ptr(obs),

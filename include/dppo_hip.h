@@ -283,7 +283,10 @@ int dppo_gaussian_ppo_loss_fwd_bwd(const dppo_net_desc* actor, const dppo_net_de
  * (diffusion_vpg.py:227-396).  Every convolution is an MFMA GEMM over a channel-last, time-padded activation image
  * (the im2col row of (b, t) is a contiguous window of it); GroupNorm + activation + FiLM / residual are one epilogue
  * kernel per block half.  Parameters: one flat fp32 buffer in the reference's state-dict order.
- * Not built: cond_mlp_dims (no shipped cfg sets it), the backward pass (PPODiffusion.loss with a conv actor). */
+ * The training side (dppo_unet_ppo_loss_fwd_bwd, dppo_unet_denoise_mse_fwd_bwd) re-runs the forward keeping every block's
+ * conv outputs and images, and back-propagates with the same two tricks: data gradients are convolutions of the padded
+ * gradient image with the flipped kernel, weight gradients are gemm_tn over the forward's (overlapping-row) operands.
+ * Not built: cond_mlp_dims (no shipped cfg sets it). */
 typedef struct dppo_unet_desc {
   int32_t action_dim, cond_dim, horizon_steps;
   int32_t time_dim;           /* diffusion_step_embed_dim                                        */
@@ -311,6 +314,21 @@ int dppo_unet_sample_chain(const dppo_unet_desc* net, int prec, const float* par
                            const dppo_step* sched_host, int n_steps, const float* obs, const float* noise, int64_t B,
                            float* traj, float* chains, int chain_len, int init_slot, void* workspace,
                            int64_t workspace_bytes, dppo_stream_t stream);
+/* dppo_ppo_loss_fwd_bwd with a conv actor (same arguments, semantics and statistics; the critic is the MLP critic) */
+int64_t dppo_unet_ppo_workspace_bytes(const dppo_unet_desc* actor, const dppo_net_desc* critic, int prec, int64_t N);
+int dppo_unet_ppo_loss_fwd_bwd(const dppo_unet_desc* actor, const dppo_net_desc* critic, int prec, const float* actor_params,
+                               const void* actor_packed, const float* critic_params, const void* critic_packed,
+                               const dppo_diffusion_cfg* dcfg, const dppo_ppo_cfg* pcfg, const dppo_step* ksteps,
+                               const float* obs_k, const float* chains_k, const float* returns_k, const float* values_k,
+                               const float* adv_k, const float* logprobs_k, const int64_t* inds, const int64_t* kinds,
+                               int64_t N, const double* global_moments, float* actor_grad, float* critic_grad,
+                               double* stats, void* workspace, int64_t workspace_bytes, dppo_stream_t stream);
+/* dppo_denoise_mse_fwd_bwd with a conv denoiser */
+int64_t dppo_unet_denoise_mse_workspace_bytes(const dppo_unet_desc* net, int prec, int64_t N);
+int dppo_unet_denoise_mse_fwd_bwd(const dppo_unet_desc* net, int prec, const float* params, const void* packed,
+                                  const dppo_step* tsteps, int n_time, const float* obs, const float* pairs,
+                                  const int64_t* kinds, int64_t N, float* grad, double* loss, void* workspace,
+                                  int64_t workspace_bytes, dppo_stream_t stream);
 /* dppo_chain_logprob with the conv denoiser: ksteps (device) / ksteps_host (host) hold the same Kft entries. */
 int dppo_unet_chain_logprob(const dppo_unet_desc* net, int prec, const float* params, const void* packed,
                             const dppo_diffusion_cfg* cfg, const dppo_step* ksteps, const dppo_step* ksteps_host,

@@ -112,14 +112,11 @@ def test_hip_unet_chains_and_logprobs(golden, case, prec):
     lt = 2e-3 if prec == "fp32" else 1.0
     np.testing.assert_allclose(lp[sel], ref[sel], rtol=lt, atol=lt)
     assert np.abs(lp[sel] - ref[sel]).mean() <= (2e-4 if prec == "fp32" else 0.15)
-    # in-kernel noise: reproducible, and the update path says clearly that it is not built
+    # in-kernel noise: reproducible
     torch.manual_seed(5)
     s1 = m(cond={"state": state})
     torch.manual_seed(5)
     assert torch.equal(s1.chains, m(cond={"state": state}).chains) and torch.isfinite(s1.chains).all()
-    with pytest.raises(NotImplementedError):
-        z = torch.zeros(4, device=dev)
-        m.ppo_update(z, z, z, z, z, z, torch.zeros(4, dtype=torch.long, device=dev))
 
 
 # ------------------------------------------------------------------ G14: PPO loss / supervised loss with a conv actor
@@ -163,3 +160,122 @@ def test_oracle_unet_denoise_mse(golden, case):
     loss.backward()
     for k, v in prm.items():
         check_grad(g, f"{case}_g_{k}", v.grad if v.grad is not None else torch.zeros_like(v), 2e-3, 1e-6)
+
+
+def grad_report(g, prefix, named_grads):
+    """(worst per-tensor relative L2 error over the tensors carrying >= 0.1 % of the gradient norm, whole-gradient norm ratio)"""
+    worst, n_got, n_ref = ("", 0.0), 0.0, 0.0
+    per = []
+    for k, grad in named_grads:
+        x = grad.double().cpu().numpy().reshape(-1)
+        key = f"{prefix}_{k}"
+        if key in g:
+            r = g[key].astype(np.float64).reshape(-1)
+            nr, xs = float(np.dot(r, r)), x
+        else:
+            r, xs = g[key + "__sub"].astype(np.float64), x[::61]
+            nr = float(g[key + "__norm"]) ** 2
+        per.append((k, nr, float(np.linalg.norm(xs - r) / (np.linalg.norm(r) + 1e-30))))
+        n_got += float(np.dot(x, x))
+        n_ref += nr
+    for k, nr, e in per:
+        if nr >= 1e-6 * n_ref and e > worst[1]:
+            worst = (k, e)
+    return worst, abs(np.sqrt(n_got / n_ref) - 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(UNET_LOSS_CASES))
+def test_hip_unet_ppo_loss_and_grads(golden, case):
+    """PPODiffusion.loss with a conv actor through dppo_unet_ppo_loss_fwd_bwd: fp32 statistics and EVERY gradient (time
+    MLP, conv / GroupNorm / FiLM-encoder / residual-conv / down- and up-sampling parameters, critic) against the reference."""
+    from dppo_amd.model.common.critic import CriticObs
+    from dppo_amd.model.diffusion.diffusion_ppo import PPODiffusion
+    from dppo_amd.model.diffusion.eta import EtaFixed
+    g = golden("g14_unet_loss")
+    sname, N, kw, rh = UNET_LOSS_CASES[case]
+    u = O.UnetSpec(**UNET_SPECS[sname])
+    c = CRITIC(u)
+    dev = "cuda:0"
+    actor = hip_unet(u, 31, "fp32", dev="cpu")
+    critic = CriticObs(cond_dim=u.cond_dim, mlp_dims=[256, 256, 256], residual_style=True, precision="fp32")
+    critic.load_state_dict(O.init_params(c, 33))
+    kw2 = dict(kw, eta=EtaFixed(base_eta=1.0)) if kw.get("use_ddim") else dict(kw)
+    m = PPODiffusion(actor=actor, critic=critic, horizon_steps=u.horizon_steps, obs_dim=u.cond_dim, action_dim=u.action_dim,
+                     device=dev, gamma_denoising=0.99, randn_clip_value=3, **kw2)
+    m.actor_ft.load_state_dict(O.unet_init_params(u, 32), strict=True)
+    d = lambda k: T(g[f"{case}_{k}"]).to(dev)
+    res = m.loss({"state": d("state")}, d("prev"), d("next"), d("kinds"), d("returns"), d("oldvalues"), d("adv"),
+                 d("oldlogprobs"), use_bc_loss=False, reward_horizon=rh)
+    got = np.array([res[0].item(), float(res[1]), res[2].item(), res[3], res[4], res[5], float(res[6]), res[7]])
+    np.testing.assert_allclose(got, g[f"{case}_stats"], rtol=5e-4, atol=5e-5)
+    (res[0] + 0.5 * res[2]).backward()
+    worst, norm = grad_report(g, f"{case}_gactor", [(k, p.grad) for k, p in m.actor_ft.named_parameters()])
+    assert worst[1] <= 5e-3 and norm <= 2e-3, (worst, norm)
+    worst, norm = grad_report(g, f"{case}_gcritic", [(k, p.grad) for k, p in m.critic.named_parameters()])
+    assert worst[1] <= 2e-3 and norm <= 1e-3, (worst, norm)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(UNET_MSE_CASES))
+def test_hip_unet_denoise_mse_and_grads(golden, case):
+    from dppo_amd.model.diffusion.diffusion import DiffusionModel
+    g = golden("g14_unet_loss")
+    sname, K, N = UNET_MSE_CASES[case]
+    u = O.UnetSpec(**UNET_SPECS[sname])
+    dev = "cuda:0"
+    flat = {}
+    for prec in ("fp32", "bf16"):
+        net = hip_unet(u, 51, prec, dev="cpu")
+        m = DiffusionModel(network=net, horizon_steps=u.horizon_steps, obs_dim=u.cond_dim, action_dim=u.action_dim, device=dev,
+                           denoising_steps=K)
+        d = lambda k: T(g[f"{case}_{k}"]).to(dev)
+        loss = m.p_losses(d("x0"), {"state": d("state")}, d("t"), noise=d("noise"))
+        loss.backward()
+        flat[prec] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).double().cpu().numpy()
+        if prec == "fp32":
+            assert loss.item() == pytest.approx(float(g[f"{case}_loss"]), rel=2e-4)
+            worst, norm = grad_report(g, f"{case}_g", [(k, p.grad) for k, p in net.named_parameters()])
+            assert worst[1] <= 5e-3 and norm <= 2e-3, (worst, norm)
+        else:
+            assert loss.item() == pytest.approx(float(g[f"{case}_loss"]), rel=3e-2)
+    x, y = flat["fp32"], flat["bf16"]
+    assert float(np.dot(x, y) / (np.linalg.norm(x) * np.linalg.norm(y))) >= 0.98
+
+
+@pytest.mark.gpu
+def test_hip_unet_update_in_bf16_and_rollout_mode():
+    """The benchmark-style path with a conv actor: ppo_update straight from a rollout buffer (rollout mode, bf16), ratio == 1
+    against its own log-probs, finite gradients with the direction of the fp32 path."""
+    from dppo_amd import hip
+    from dppo_amd.model.common.critic import CriticObs
+    from dppo_amd.model.diffusion.diffusion_ppo import PPODiffusion
+    u = O.UnetSpec(**UNET_SPECS["unet_square"])
+    dev = "cuda:0"
+    out = {}
+    for prec in ("fp32", "bf16"):
+        actor = hip_unet(u, 41, prec, dev="cpu")
+        critic = CriticObs(cond_dim=u.cond_dim, mlp_dims=[256, 256, 256], residual_style=True, precision=prec)
+        critic.load_state_dict(O.init_params(CRITIC(u), 43))
+        m = PPODiffusion(actor=actor, critic=critic, horizon_steps=u.horizon_steps, obs_dim=u.cond_dim, action_dim=u.action_dim,
+                         device=dev, gamma_denoising=0.99, clip_ploss_coef=0.01, randn_clip_value=3, denoising_steps=20,
+                         ft_denoising_steps=10)
+        m.actor_ft.load_state_dict(O.unet_init_params(u, 42), strict=True)
+        R, Kft, AF, N = 200, 10, u.horizon_steps * u.action_dim, 1000
+        gen = torch.Generator().manual_seed(2)
+        obs = (torch.rand(R, 1, u.cond_dim, generator=gen) * 2 - 1).to(dev)
+        noise = torch.randn(21, R, AF, generator=gen).to(dev)
+        chains = m(cond={"state": obs}, noise=noise).chains
+        logp = m.get_logprobs({"state": obs}, chains).reshape(R, Kft, AF)
+        val = m.critic({"state": obs}).reshape(R)
+        ret, adv = val + torch.randn(R, generator=gen).to(dev), torch.randn(R, generator=gen).to(dev)
+        inds = torch.randperm(R * Kft, generator=gen)[:N].to(dev).contiguous()
+        st = m.ppo_update(obs.reshape(R, -1).contiguous(), chains.reshape(R, Kft + 1, AF).contiguous(), ret, val, adv, logp,
+                          inds).cpu().numpy().copy()
+        assert st[hip.STAT_RATIO] == pytest.approx(1.0, abs=1e-5 if prec == "fp32" else 1e-3)  # two forward kernels (inference / training)
+        ga = m.actor_ft.flat_grads().double().cpu().numpy().copy()
+        gc = m.critic.flat_grads().double().cpu().numpy().copy()
+        assert np.isfinite(ga).all() and np.isfinite(gc).all() and np.linalg.norm(ga) > 0
+        out[prec] = (ga, gc)
+    cos = lambda x, y: float(np.dot(x, y) / (np.linalg.norm(x) * np.linalg.norm(y) + 1e-30))
+    assert cos(out["fp32"][1], out["bf16"][1]) >= 0.99
