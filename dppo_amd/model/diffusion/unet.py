@@ -5,8 +5,9 @@ state-dict names and order (``time_mlp.{1,3}``, ``mid_modules.i.blocks.j.block.{
 
 The classes own parameters only (views of one flat fp32 buffer); the arithmetic is the HIP library's ``dppo_unet_*``
 (csrc/unet.hip): every convolution an MFMA GEMM over a channel-last, time-padded activation image, GroupNorm + activation +
-FiLM / residual in one epilogue kernel per block half.  Inference side only for now: ``forward``, the K-step sampler and
-the log-prob evaluation of ``VPGDiffusion`` run on it; ``PPODiffusion.loss`` with a conv actor (the backward pass) is not built.
+FiLM / residual in one epilogue kernel per block half.  ``forward``, the K-step sampler and the log-prob evaluation of
+``VPGDiffusion``, ``PPODiffusion.loss`` / ``ppo_update`` and ``DiffusionModel.p_losses`` (forward with a tape + backward to every
+parameter gradient) run on it.
 """
 from __future__ import annotations
 
