@@ -292,3 +292,49 @@ def test_gaussian_agent_runs_and_updates_policy_value_and_std(tmp_path, monkeypa
     assert torch.equal(agent.model.actor.flat_params(), base0)
     ck = torch.load(os.path.join(str(tmp_path), "synthetic", "checkpoint", "state_2.pt"), weights_only=True)
     assert "actor_ft.logvar" in ck["model"] and "actor_ft.mlp_mean.layers.1.l1.weight" in ck["model"]
+
+
+UNET_YAML = YAML[:YAML.index("  actor:\n")] + """  actor:
+    _target_: dppo.model.diffusion.unet.Unet1D
+    diffusion_step_embed_dim: 16
+    dim: 64
+    dim_mults: [1, 2]
+    kernel_size: 5
+    n_groups: 8
+    smaller_encoder: False
+    cond_predict_scale: True
+    cond_dim: ${eval:'${obs_dim} * ${cond_steps}'}
+    action_dim: ${action_dim}
+  critic:
+    _target_: dppo.model.common.critic.CriticObs
+    cond_dim: ${eval:'${obs_dim} * ${cond_steps}'}
+    mlp_dims: [256, 256, 256]
+    activation_type: Mish
+    residual_style: True
+  ft_denoising_steps: ${ft_denoising_steps}
+  horizon_steps: ${horizon_steps}
+  obs_dim: ${obs_dim}
+  action_dim: ${action_dim}
+  denoising_steps: ${denoising_steps}
+  device: ${device}
+"""
+
+
+def test_agent_fine_tunes_a_conv_denoiser(tmp_path, monkeypatch):
+    """The same agent loop with the reference's ft_ppo_diffusion_unet model block (Unet1D actor): rollout through the
+    host-looped conv sampler, log-prob precompute, PPO updates through dppo_unet_ppo_loss_fwd_bwd, checkpoint."""
+    from dppo_amd.cfg.loader import get_class, load_config
+    from dppo_amd.model.diffusion.unet import Unet1D
+    monkeypatch.setenv("DPPO_LOG_DIR", str(tmp_path))
+    p = tmp_path / "ft_unet.yaml"
+    p.write_text(UNET_YAML.replace("n_steps: 12", "n_steps: 6"))
+    cfg = load_config(str(p))
+    agent = get_class(cfg._target_)(cfg)
+    assert isinstance(agent.model.actor_ft, Unet1D)
+    w0 = agent.model.actor_ft.flat_params().clone()
+    base0 = agent.model.actor.flat_params().clone()
+    res = agent.run()
+    assert len(res) == 3 and np.isfinite(res[1]["loss"]) and np.isfinite(res[1]["pg_loss"]) and res[1]["approx_kl"] < 1.0
+    assert not torch.equal(agent.model.actor_ft.flat_params(), w0) and torch.equal(agent.model.actor.flat_params(), base0)
+    ck = torch.load(os.path.join(str(tmp_path), "synthetic", "checkpoint", "state_2.pt"), weights_only=True)
+    assert "actor_ft.down_modules.0.0.blocks.0.block.0.weight" in ck["model"] and "actor_ft.final_conv.1.bias" in ck["model"]
