@@ -42,10 +42,14 @@ struct Conv {
   int64_t w, b;
   size_t pk;
   size_t pkT;  // backward (data gradient) operand, see pack_convT_bwd / pack_conv_bwd / pack_down_bwd
-  int ci, co, ks, cip, Kp;  // cip: padded input channels (ld of the image it reads)
+  int ci, co, ks, cip, Kp;  // cip: channel stride of the image it reads (each map padded to a multiple of 64 channels)
   bool transposed;
   int stride;  // 1, or 2 for Downsample1d
+  int split;   // > 0: the input is a concat image [x (split, padded) | skip (split, padded)]: channel c >= split sits at
+               // rup(split, 64) + c - split
 };
+// position of real input channel c in the image a conv reads
+__host__ __device__ inline int chan_pos(int c, int split) { return (split > 0 && c >= split) ? ((split + 63) / 64 * 64) + c - split : c; }
 struct Norm {
   int64_t g, b;
 };
@@ -85,9 +89,9 @@ Layout make_layout(const dppo_unet_desc& d, int es, int n_time) {
     l.inT = in, l.pkT = pk, pk = al(pk + (size_t)rup(in, 16) * rup(out, 64) * es);
     return l;
   };
-  auto conv = [&](int ci, int co, int ks, bool tr = false) {
+  auto conv = [&](int ci, int co, int ks, bool tr = false, int split = 0) {
     Conv c;
-    c.ci = ci, c.co = co, c.ks = ks, c.cip = rup(ci, 64), c.transposed = tr;
+    c.ci = ci, c.co = co, c.ks = ks, c.cip = split > 0 ? 2 * rup(split, 64) : rup(ci, 64), c.transposed = tr, c.split = split;
     c.w = o, o += (int64_t)ci * co * ks;
     c.b = o, o += co;
     c.stride = 1;
@@ -96,11 +100,11 @@ Layout make_layout(const dppo_unet_desc& d, int es, int n_time) {
       c.pk = pk, pk = al(pk + (size_t)co * c.Kp * es);
       // data gradient: a convolution of the padded dU image with the flipped kernel, [ci][ks * co]; the stride-2 conv's
       // is a two-phase GEMM [2 ci][2 co] (set by the caller below)
-      c.pkT = pk, pk = al(pk + (size_t)2 * rup(ci, 16) * ks * rup(co, 64) * es);
+      c.pkT = pk, pk = al(pk + (size_t)2 * rup(ci, 16) * 3 * rup(co, 64) * es + (size_t)rup(ci, 16) * ks * rup(co, 64) * es);
     } else {  // ConvTranspose1d(C, C, 4, 2, 1) as one GEMM: N = 2 co (even | odd phase), K = 3 ci (window m-1, m, m+1)
       c.Kp = 3 * c.cip;
       c.pk = pk, pk = al(pk + (size_t)2 * co * c.Kp * es);
-      c.pkT = pk, pk = al(pk + (size_t)ci * 4 * co * es);  // strided conv over dy: [ci][4 co]
+      c.pkT = pk, pk = al(pk + (size_t)rup(ci, 16) * 4 * rup(co, 64) * es);  // strided conv over dy: [ci][4 co_p]
     }
     return c;
   };
@@ -110,11 +114,11 @@ Layout make_layout(const dppo_unet_desc& d, int es, int n_time) {
     n.b = o, o += c;
     return n;
   };
-  auto resblock = [&](int ci, int co) {
+  auto resblock = [&](int ci, int co, int split = 0) {
     ResBlock r;
     memset(&r, 0, sizeof(r));
     r.ci = ci, r.co = co, r.cc = d.cond_predict_scale ? 2 * co : co;
-    r.c1 = conv(ci, co, d.kernel_size), r.n1 = norm(co);
+    r.c1 = conv(ci, co, d.kernel_size, false, split), r.n1 = norm(co);
     r.c2 = conv(co, co, d.kernel_size), r.n2 = norm(co);
     if (d.larger_encoder) {
       r.n_enc = 3;
@@ -124,7 +128,7 @@ Layout make_layout(const dppo_unet_desc& d, int es, int n_time) {
       r.enc[0] = lin(cbd, r.cc);
     }
     r.has_res = ci != co;
-    if (r.has_res) r.res = conv(ci, co, 1);
+    if (r.has_res) r.res = conv(ci, co, 1, false, split);
     return r;
   };
   L.t1 = lin(d.time_dim, 4 * d.time_dim);
@@ -144,7 +148,7 @@ Layout make_layout(const dppo_unet_desc& d, int es, int n_time) {
   }
   for (int j = 0; j < nl - 1; ++j) {  // (dim_in, dim_out) = reversed(in_out[1:])[j] = (dims[nl-1-j], dims[nl-j])
     const int din = L.dims[nl - 1 - j], dout = L.dims[nl - j];
-    L.up.push_back(resblock(2 * dout, din));
+    L.up.push_back(resblock(2 * dout, din, dout));
     L.up.push_back(resblock(din, din));
     L.ups.push_back(conv(din, din, 4, true));
   }
@@ -159,7 +163,7 @@ Layout make_layout(const dppo_unet_desc& d, int es, int n_time) {
 int check_desc(const dppo_unet_desc* d) {
   if (!d) return api_fail(-1, "null unet descriptor");
   if (d->n_levels < 1 || d->n_levels > 4) return api_fail(-1, "unet: n_levels out of [1,4]");
-  if (d->dim < 64 || d->dim % 64) return api_fail(-1, "unet: dim must be a positive multiple of 64");
+  if (d->dim < 8 || d->dim % 8) return api_fail(-1, "unet: dim must be a positive multiple of 8");
   for (int i = 0; i < d->n_levels; ++i)
     if (d->mults[i] < 1 || d->dim * d->mults[i] > 1024) return api_fail(-1, "unet: channel count out of range");
   if (d->kernel_size != 3 && d->kernel_size != 5) return api_fail(-1, "unet: kernel_size must be 3 or 5");
@@ -180,59 +184,58 @@ int check_desc(const dppo_unet_desc* d) {
 // pack kernels
 // ---------------------------------------------------------------------------------------------------------------------
 template <class P>
-__global__ void pack_conv_kernel(const float* w, int co, int ci, int ks, int cip, typename P::elem_t* dst) {
-  // dst[o][k * cip + c] = w[o][c][k]
+__global__ void pack_conv_kernel(const float* w, int co, int ci, int ks, int cip, int split, typename P::elem_t* dst) {
+  // dst[o][k * cip + chan_pos(c)] = w[o][c][k]; zero elsewhere (dst is cleared by the caller's memset)
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t Kp = (size_t)ks * cip;
-  if (i >= (size_t)co * Kp) return;
-  const int o = (int)(i / Kp), r = (int)(i % Kp), k = r / cip, c = r % cip;
-  dst[i] = P::from_f32(c < ci ? w[((size_t)o * ci + c) * ks + k] : 0.f);
+  if (i >= (size_t)co * ci * ks) return;
+  const int k = (int)(i % ks), c = (int)((i / ks) % ci), o = (int)(i / ((size_t)ks * ci));
+  dst[(size_t)o * ks * cip + (size_t)k * cip + chan_pos(c, split)] = P::from_f32(w[i]);
 }
 template <class P>
-__global__ void pack_convT_kernel(const float* w, int ch, typename P::elem_t* dst) {
+__global__ void pack_convT_kernel(const float* w, int ch, int chp, typename P::elem_t* dst) {
   // w[ci][co][4] (ConvTranspose1d, stride 2, padding 1): out[2m] = x[m] w[.,.,1] + x[m-1] w[.,.,3];
-  // out[2m+1] = x[m+1] w[.,.,0] + x[m] w[.,.,2].  Window slots (m-1, m, m+1) -> dst[phase * ch + co][slot * ch + ci]
+  // out[2m+1] = x[m+1] w[.,.,0] + x[m] w[.,.,2].  Window slots (m-1, m, m+1) -> dst[phase * ch + co][slot * chp + ci]
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t Kp = (size_t)3 * ch;
+  const size_t Kp = (size_t)3 * chp;
   if (i >= (size_t)2 * ch * Kp) return;
-  const int row = (int)(i / Kp), r = (int)(i % Kp), slot = r / ch, ci = r % ch;
+  const int row = (int)(i / Kp), r = (int)(i % Kp), slot = r / chp, ci = r % chp;
   const int phase = row / ch, co = row % ch;
   int k = -1;
   if (phase == 0) k = slot == 1 ? 1 : (slot == 0 ? 3 : -1);
   else k = slot == 2 ? 0 : (slot == 1 ? 2 : -1);
-  dst[i] = P::from_f32(k >= 0 ? w[((size_t)ci * ch + co) * 4 + k] : 0.f);
+  dst[i] = P::from_f32(k >= 0 && ci < ch ? w[((size_t)ci * ch + co) * 4 + k] : 0.f);
 }
 // backward (data-gradient) operands ---------------------------------------------------------------------------------
 template <class P>
-__global__ void pack_conv_bwd_kernel(const float* w, int co, int ci, int ks, typename P::elem_t* dst) {
-  // dX[b][t][ci] = sum_j sum_co dUimg[b][t - ks/2 + j][co] * w[co][ci][ks-1-j]  ->  dst[ci][j * co + o]
+__global__ void pack_conv_bwd_kernel(const float* w, int co, int ci, int ks, int cop, typename P::elem_t* dst) {
+  // dX[b][t][ci] = sum_j sum_co dUimg[b][t - ks/2 + j][co] * w[co][ci][ks-1-j]  ->  dst[ci][j * cop + o] (real ci order)
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t K = (size_t)ks * co;
+  const size_t K = (size_t)ks * cop;
   if (i >= (size_t)ci * K) return;
-  const int c = (int)(i / K), r = (int)(i % K), j = r / co, o = r % co;
-  dst[i] = P::from_f32(w[((size_t)o * ci + c) * ks + (ks - 1 - j)]);
+  const int c = (int)(i / K), r = (int)(i % K), j = r / cop, o = r % cop;
+  dst[i] = P::from_f32(o < co ? w[((size_t)o * ci + c) * ks + (ks - 1 - j)] : 0.f);
 }
 template <class P>
-__global__ void pack_down_bwd_kernel(const float* w, int ch, typename P::elem_t* dst) {
+__global__ void pack_down_bwd_kernel(const float* w, int ch, int chp, typename P::elem_t* dst) {
   // Downsample1d (k 3, stride 2, pad 1): dx[2m] = W1^T dy[m]; dx[2m+1] = W2^T dy[m] + W0^T dy[m+1]
-  // window slots (dy[m], dy[m+1]) -> dst[phase * ch + ci][slot * ch + co]
+  // window slots (dy[m], dy[m+1]) -> dst[phase * ch + ci][slot * chp + co]
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t K = (size_t)2 * ch;
+  const size_t K = (size_t)2 * chp;
   if (i >= (size_t)2 * ch * K) return;
-  const int row = (int)(i / K), r = (int)(i % K), slot = r / ch, co = r % ch, phase = row / ch, ci = row % ch;
+  const int row = (int)(i / K), r = (int)(i % K), slot = r / chp, co = r % chp, phase = row / ch, ci = row % ch;
   int k = -1;
   if (phase == 0) k = slot == 0 ? 1 : -1;
   else k = slot == 0 ? 2 : 0;
-  dst[i] = P::from_f32(k >= 0 ? w[((size_t)co * ch + ci) * 3 + k] : 0.f);
+  dst[i] = P::from_f32(k >= 0 && co < ch ? w[((size_t)co * ch + ci) * 3 + k] : 0.f);
 }
 template <class P>
-__global__ void pack_convT_bwd_kernel(const float* w, int ch, typename P::elem_t* dst) {
-  // Upsample1d: dx[s][ci] = sum_k sum_co dy[2s - 1 + k][co] w[ci][co][k]  ->  dst[ci][k * ch + co]
+__global__ void pack_convT_bwd_kernel(const float* w, int ch, int chp, typename P::elem_t* dst) {
+  // Upsample1d: dx[s][ci] = sum_k sum_co dy[2s - 1 + k][co] w[ci][co][k]  ->  dst[ci][k * chp + co]
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t K = (size_t)4 * ch;
+  const size_t K = (size_t)4 * chp;
   if (i >= (size_t)ch * K) return;
-  const int ci = (int)(i / K), r = (int)(i % K), k = r / ch, co = r % ch;
-  dst[i] = P::from_f32(w[((size_t)ci * ch + co) * 4 + k]);
+  const int ci = (int)(i / K), r = (int)(i % K), k = r / chp, co = r % chp;
+  dst[i] = P::from_f32(co < ch ? w[((size_t)ci * ch + co) * 4 + k] : 0.f);
 }
 __device__ __forceinline__ float sinus(int t, int j, int td) {
   const int half = td / 2;
@@ -272,26 +275,28 @@ int pack_impl(const dppo_unet_desc& d, int n_time, const float* prm, char* pk, h
     launch_transpose_cast<P>(prm + l.w, l.out, l.inT, l.in, 0, pk + l.pkT, rup(l.out, 64), s);  // [inT][out_p] = W^T
   };
   auto pc = [&](const Conv& c) {
+    const int cop = rup(c.co, 64);
     if (!c.transposed) {
-      const size_t n = (size_t)c.co * c.Kp;
+      (void)hipMemsetAsync(pk + c.pk, 0, (size_t)c.co * c.Kp * P::ESIZE, s);
+      const size_t n = (size_t)c.co * c.ci * c.ks;
       hipLaunchKernelGGL((pack_conv_kernel<P>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, prm + c.w, c.co, c.ci,
-                         c.ks, c.cip, (E*)(pk + c.pk));
+                         c.ks, c.cip, c.split, (E*)(pk + c.pk));
       if (c.stride == 2) {
-        const size_t nb = (size_t)4 * c.co * c.co;
+        const size_t nb = (size_t)2 * c.co * 2 * cop;
         hipLaunchKernelGGL((pack_down_bwd_kernel<P>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, prm + c.w, c.co,
-                           (E*)(pk + c.pkT));
-      } else if (c.co % 64 == 0) {  // (the 1x1 output conv, co = action_dim, gets its data gradient from its forward pack)
-        const size_t nb = (size_t)c.ci * c.ks * c.co;
+                           cop, (E*)(pk + c.pkT));
+      } else if (&c != &L.fin_out) {  // (the 1x1 output conv's data-gradient operand is packed below)
+        const size_t nb = (size_t)c.ci * c.ks * cop;
         hipLaunchKernelGGL((pack_conv_bwd_kernel<P>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, prm + c.w, c.co,
-                           c.ci, c.ks, (E*)(pk + c.pkT));
+                           c.ci, c.ks, cop, (E*)(pk + c.pkT));
       }
     } else {
       const size_t n = (size_t)2 * c.co * c.Kp;
-      hipLaunchKernelGGL((pack_convT_kernel<P>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, prm + c.w, c.co,
+      hipLaunchKernelGGL((pack_convT_kernel<P>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, prm + c.w, c.co, cop,
                          (E*)(pk + c.pk));
-      const size_t nb = (size_t)4 * c.co * c.co;
+      const size_t nb = (size_t)c.co * 4 * cop;
       hipLaunchKernelGGL((pack_convT_bwd_kernel<P>), dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, prm + c.w, c.co,
-                         (E*)(pk + c.pkT));
+                         cop, (E*)(pk + c.pkT));
     }
   };
   auto pr = [&](const ResBlock& r) {
@@ -381,6 +386,7 @@ struct GnArgs {
   int ldd, coff, zero_pads;
   void* dst2;        // optional second destination (the skip connection's half of a concat image)
   int ldd2, coff2, zero_pads2;
+  int Cw;            // width of the map in the image (C padded to a multiple of 64): channels [C, Cw) are written as zeros
 };
 // Conv1dBlock's GroupNorm + activation (modules.py:50-95), then FiLM (unet.py:105-113) or the block's skip sum (:116)
 template <class P>
@@ -408,18 +414,22 @@ __global__ __launch_bounds__(256) void unet_gn_kernel(const GnArgs a) {
   const int Tp = a.T + 2 * PAD;
   E* dst = (E*)a.dst + (size_t)b * Tp * a.ldd;
   E* dst2 = a.dst2 ? (E*)a.dst2 + (size_t)b * Tp * a.ldd2 : nullptr;
-  for (int i = threadIdx.x; i < a.T * a.C; i += 256) {
-    const int t = i / a.C, c = i % a.C, g = c / cg;
-    float v = (src[(size_t)t * a.lds + c] - mean[g]) * rstd[g] * a.gamma[c] + a.beta[c];
-    v = act_f(a.act, v);
-    if (a.film == 1)
-      v = v + a.emb[(size_t)b * a.lde + c];
-    else if (a.film == 2)
-      v = a.emb[(size_t)b * a.lde + c] * v + a.emb[(size_t)b * a.lde + a.C + c];
-    if (a.res == 1)
-      v = v + a.resf[((size_t)b * a.Tps + t) * a.ldr + c];
-    else if (a.res == 2)
-      v = v + P::to_f32(((const E*)a.resi)[((size_t)b * Tp + t + PAD) * a.ldri + c]);
+  for (int i = threadIdx.x; i < a.T * a.Cw; i += 256) {
+    const int t = i / a.Cw, c = i % a.Cw;
+    float v = 0.f;
+    if (c < a.C) {
+      const int g = c / cg;
+      v = (src[(size_t)t * a.lds + c] - mean[g]) * rstd[g] * a.gamma[c] + a.beta[c];
+      v = act_f(a.act, v);
+      if (a.film == 1)
+        v = v + a.emb[(size_t)b * a.lde + c];
+      else if (a.film == 2)
+        v = a.emb[(size_t)b * a.lde + c] * v + a.emb[(size_t)b * a.lde + a.C + c];
+      if (a.res == 1)
+        v = v + a.resf[((size_t)b * a.Tps + t) * a.ldr + c];
+      else if (a.res == 2)
+        v = v + P::to_f32(((const E*)a.resi)[((size_t)b * Tp + t + PAD) * a.ldri + c]);
+    }
     dst[(size_t)(t + PAD) * a.ldd + a.coff + c] = P::from_f32(v);
     if (dst2) dst2[(size_t)(t + PAD) * a.ldd2 + a.coff2 + c] = P::from_f32(v);
   }
@@ -441,11 +451,11 @@ template <class P>
 __global__ __launch_bounds__(256) void unet_scatter_kernel(const float* src, int lds, int Tps, int Tsrc, int nsub, int C,
                                                            typename P::elem_t* dst, int ldd, int coff, int zero_pads) {
   const int64_t b = blockIdx.x;
-  const int Tout = Tsrc * nsub, Tp = Tout + 2 * PAD;
+  const int Tout = Tsrc * nsub, Tp = Tout + 2 * PAD, Cw = (C + 63) / 64 * 64;
   typename P::elem_t* d = dst + (size_t)b * Tp * ldd;
-  for (int i = threadIdx.x; i < Tout * C; i += 256) {
-    const int t = i / C, c = i % C, m = t / nsub, sub = t % nsub;
-    d[(size_t)(t + PAD) * ldd + coff + c] = P::from_f32(src[((size_t)b * Tps + m) * lds + sub * C + c]);
+  for (int i = threadIdx.x; i < Tout * Cw; i += 256) {
+    const int t = i / Cw, c = i % Cw, m = t / nsub, sub = t % nsub;
+    d[(size_t)(t + PAD) * ldd + coff + c] = P::from_f32(c < C ? src[((size_t)b * Tps + m) * lds + sub * C + c] : 0.f);
   }
   if (zero_pads)
     for (int i = threadIdx.x; i < 2 * PAD * ldd; i += 256) {
@@ -459,11 +469,11 @@ __global__ __launch_bounds__(256) void unet_up_scatter_kernel(const float* src, 
                                               void* dstv, int ldd, int zero_pads) {
   typedef typename P::elem_t E;
   const int64_t b = blockIdx.x;
-  const int Tout = 2 * Tsrc, Tp = Tout + 2 * PAD;
+  const int Tout = 2 * Tsrc, Tp = Tout + 2 * PAD, Cw = (C + 63) / 64 * 64;
   E* dd = (E*)dstv + (size_t)b * Tp * ldd;
-  for (int i = threadIdx.x; i < Tout * C; i += 256) {
-    const int t = i / C, c = i % C, m = t / 2, sub = t % 2;
-    dd[(size_t)(t + PAD) * ldd + c] = P::from_f32(src[((size_t)b * Tps + m) * lds + sub * C + c] + bias[c]);
+  for (int i = threadIdx.x; i < Tout * Cw; i += 256) {
+    const int t = i / Cw, c = i % Cw, m = t / 2, sub = t % 2;
+    dd[(size_t)(t + PAD) * ldd + c] = P::from_f32(c < C ? src[((size_t)b * Tps + m) * lds + sub * C + c] + bias[c] : 0.f);
   }
   if (zero_pads)
     for (int i = threadIdx.x; i < 2 * PAD * ldd; i += 256) {
@@ -561,11 +571,11 @@ void carve(const dppo_unet_desc& d, const Layout& L, int64_t rows, char* base, W
   };
   const int T0 = d.horizon_steps, T0p = T0 + 2 * PAD, nl = d.n_levels;
   int cmax = 64, ccmax = 64;
-  for (int i = 1; i <= nl; ++i) cmax = L.dims[i] > cmax ? L.dims[i] : cmax;
+  for (int i = 1; i <= nl; ++i) cmax = rup(L.dims[i], 64) > cmax ? rup(L.dims[i], 64) : cmax;
   ccmax = 2 * cmax;
   size_t img_max = 0;
   for (int l = 0; l < nl; ++l) {
-    const size_t b = (size_t)((T0 >> l) + 2 * PAD) * (size_t)(2 * L.dims[l + 1]);
+    const size_t b = (size_t)((T0 >> l) + 2 * PAD) * (size_t)(2 * rup(L.dims[l + 1], 64));
     img_max = b > img_max ? b : img_max;
   }
   W.in_img = take((size_t)rows * T0p * 64 * ES);
@@ -579,7 +589,7 @@ void carve(const dppo_unet_desc& d, const Layout& L, int64_t rows, char* base, W
   W.bufB = take((size_t)rows * img_max * ES);
   W.bufC = take((size_t)rows * img_max * ES);
   for (int l = 0; l < 4; ++l)
-    W.cat[l] = l < nl ? take((size_t)rows * ((T0 >> l) + 2 * PAD) * 2 * L.dims[l + 1] * ES) : nullptr;
+    W.cat[l] = l < nl ? take((size_t)rows * ((T0 >> l) + 2 * PAD) * 2 * rup(L.dims[l + 1], 64) * ES) : nullptr;
   W.x = (float*)take((size_t)rows * T0 * d.action_dim * 4);
   W.eps = (float*)take((size_t)rows * T0 * d.action_dim * 4);
   W.tdev = (int64_t*)take((size_t)rows * 8);
@@ -623,25 +633,27 @@ struct Runner {
         g.out_f32 = W.emb, g.ldo32 = rup(r.cc, 16);
       }
       launch_gemm_nt<P>(g, s);
+      if (i + 1 < r.n_enc && rup(l.out, 16) < g.ldo)  // the next GEMM's K runs over the padded width
+        launch_zero_cols<P>(g.out_act, (int)rows, rup(l.out, 16), g.ldo, g.ldo, s);
     }
   }
   // ResidualBlock1D.forward (unet.py:100-118): in -> out image (channel offset coff of an image of width ldd), optionally
   // also into dst2 (the skip's half of a concat image)
   void resblock(const ResBlock& r, const Img& in, void* mid_img, void* out_img, int ldd, int coff, int zero_pads,
                 void* dst2 = nullptr, int ldd2 = 0, int coff2 = 0, int zero2 = 0) {
-    const int T = in.T, Tp = in.Tp(), ldc = rup(r.co, 16);
+    const int T = in.T, Tp = in.Tp(), ldc = rup(r.co, 16), Cw = rup(r.co, 64);
     encoder(r);
     conv(r.c1, in, W.conv, ldc);
     GnArgs a;
     memset(&a, 0, sizeof(a));
-    a.src = W.conv, a.lds = ldc, a.Tps = Tp, a.T = T, a.C = r.co, a.G = d.n_groups, a.gamma = prm + r.n1.g;
+    a.src = W.conv, a.lds = ldc, a.Tps = Tp, a.T = T, a.C = r.co, a.Cw = Cw, a.G = d.n_groups, a.gamma = prm + r.n1.g;
     a.beta = prm + r.n1.b, a.eps = d.groupnorm_eps, a.act = d.act, a.film = d.cond_predict_scale ? 2 : 1, a.emb = W.emb;
-    a.lde = rup(r.cc, 16), a.dst = mid_img, a.ldd = r.co, a.coff = 0, a.zero_pads = 1;
+    a.lde = rup(r.cc, 16), a.dst = mid_img, a.ldd = Cw, a.coff = 0, a.zero_pads = 1;
     hipLaunchKernelGGL((unet_gn_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, a);
-    Img mid{mid_img, T, r.co};
+    Img mid{mid_img, T, Cw};
     conv(r.c2, mid, W.conv, ldc);
     memset(&a, 0, sizeof(a));
-    a.src = W.conv, a.lds = ldc, a.Tps = Tp, a.T = T, a.C = r.co, a.G = d.n_groups, a.gamma = prm + r.n2.g;
+    a.src = W.conv, a.lds = ldc, a.Tps = Tp, a.T = T, a.C = r.co, a.Cw = Cw, a.G = d.n_groups, a.gamma = prm + r.n2.g;
     a.beta = prm + r.n2.b, a.eps = d.groupnorm_eps, a.act = d.act;
     if (r.has_res) {
       gemm(in, PAD, 1, pk + r.res.pk, r.co, r.res.Kp, prm + r.res.b, W.res, ldc);
@@ -655,6 +667,7 @@ struct Runner {
   }
 
   // Unet1D.forward (unet.py:264-327) from the prepared input image + conditioning rows; eps -> out [rows][T][Da]
+  // (every map sits in its image padded to a multiple of 64 channels, the padding written as zeros: Img.C is that stride)
   void forward(float* out) {
     const int nl = d.n_levels, T0 = d.horizon_steps;
     Img cur{W.in_img, T0, 64};
@@ -665,65 +678,65 @@ struct Runner {
       return (void*)nullptr;
     };
     for (int i = 0; i < nl; ++i) {
-      const int C = L.dims[i + 1], T = T0 >> i;
+      const int C = L.dims[i + 1], Cw = rup(C, 64), T = T0 >> i;
       void* m = pick(cur.p, nullptr);
       void* o = pick(cur.p, m);
-      resblock(L.down[2 * i], cur, m, o, C, 0, 1);
-      Img a{o, T, C};
+      resblock(L.down[2 * i], cur, m, o, Cw, 0, 1);
+      Img a{o, T, Cw};
       m = pick(a.p, nullptr);
       o = pick(a.p, m);
       // second block of the level: its output is the skip connection -> also the upper half of the level's concat image
       const bool skip_used = i >= 1;  // up_modules has n_levels - 1 entries: the level-0 skip is never popped (:300-308)
-      resblock(L.down[2 * i + 1], a, m, o, C, 0, 1, skip_used ? W.cat[i] : nullptr, 2 * C, C, 1);
-      cur = Img{o, T, C};
+      resblock(L.down[2 * i + 1], a, m, o, Cw, 0, 1, skip_used ? W.cat[i] : nullptr, 2 * Cw, Cw, 1);
+      cur = Img{o, T, Cw};
       if (i < nl - 1) {  // Downsample1d: Conv1d(C, C, 3, stride 2, padding 1)
         const Conv& c = L.downs[i];
         gemm(cur, PAD - 1, 2, pk + c.pk, c.co, c.Kp, prm + c.b, W.conv, rup(C, 16));
         void* dn = pick(cur.p, nullptr);
         hipLaunchKernelGGL((unet_scatter_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, W.conv, rup(C, 16),
-                           cur.Tp() / 2, T / 2, 1, C, (typename P::elem_t*)dn, C, 0, 1);
-        cur = Img{dn, T / 2, C};
+                           cur.Tp() / 2, T / 2, 1, C, (typename P::elem_t*)dn, Cw, 0, 1);
+        cur = Img{dn, T / 2, Cw};
       }
     }
     for (int i = 0; i < 2; ++i) {
       void* m = pick(cur.p, nullptr);
       const bool to_cat = i == 1 && nl >= 2;  // the last mid block feeds cat(x, skip) of the first up level
       void* o = to_cat ? W.cat[nl - 1] : pick(cur.p, m);
-      const int C = L.dims[nl];
-      resblock(L.mid[i], cur, m, o, to_cat ? 2 * C : C, 0, to_cat ? 0 : 1);
-      cur = Img{o, cur.T, to_cat ? 2 * C : C};
+      const int Cw = rup(L.dims[nl], 64);
+      resblock(L.mid[i], cur, m, o, to_cat ? 2 * Cw : Cw, 0, to_cat ? 0 : 1);
+      cur = Img{o, cur.T, to_cat ? 2 * Cw : Cw};
     }
     for (int j = 0; j < nl - 1; ++j) {
-      const int din = L.dims[nl - 1 - j];
+      const int din = L.dims[nl - 1 - j], dinw = rup(din, 64);
       void* m = pick(cur.p, nullptr);
       void* o = pick(cur.p, m);
-      resblock(L.up[2 * j], cur, m, o, din, 0, 1);
-      Img a{o, cur.T, din};
+      resblock(L.up[2 * j], cur, m, o, dinw, 0, 1);
+      Img a{o, cur.T, dinw};
       m = pick(a.p, nullptr);
       o = pick(a.p, m);
-      resblock(L.up[2 * j + 1], a, m, o, din, 0, 1);
-      Img b2{o, cur.T, din};
+      resblock(L.up[2 * j + 1], a, m, o, dinw, 0, 1);
+      Img b2{o, cur.T, dinw};
       // Upsample1d: ConvTranspose1d(din, din, 4, 2, 1) as one GEMM (even | odd phase)
       const Conv& c = L.ups[j];
       gemm(b2, PAD - 1, 1, pk + c.pk, 2 * din, c.Kp, nullptr, W.conv, rup(2 * din, 16));
       const int lvl = nl - 2 - j;  // the level the upsampled map lands on
       const bool to_cat = lvl >= 1;  // another up level follows: write the lower half of that level's concat image
       void* up = to_cat ? W.cat[lvl] : pick(b2.p, nullptr);
-      const int ldd = to_cat ? 2 * din : din;
+      const int ldd = to_cat ? 2 * dinw : dinw;
       up_bias_scatter(c, b2, up, ldd, din, to_cat ? 0 : 1);
       cur = Img{up, b2.T * 2, ldd};
     }
     // final_conv: Conv1dBlock(dim, dim) + Conv1d(dim, action_dim, 1)
     {
-      const int C = d.dim, T = cur.T, ldc = rup(C, 16);
+      const int C = d.dim, Cw = rup(C, 64), T = cur.T, ldc = rup(C, 16);
       conv(L.fin, cur, W.conv, ldc);
       GnArgs a;
       memset(&a, 0, sizeof(a));
       void* o = pick(cur.p, nullptr);
-      a.src = W.conv, a.lds = ldc, a.Tps = cur.Tp(), a.T = T, a.C = C, a.G = d.n_groups, a.gamma = prm + L.fin_n.g;
-      a.beta = prm + L.fin_n.b, a.eps = d.groupnorm_eps, a.act = d.act, a.dst = o, a.ldd = C, a.zero_pads = 1;
+      a.src = W.conv, a.lds = ldc, a.Tps = cur.Tp(), a.T = T, a.C = C, a.Cw = Cw, a.G = d.n_groups, a.gamma = prm + L.fin_n.g;
+      a.beta = prm + L.fin_n.b, a.eps = d.groupnorm_eps, a.act = d.act, a.dst = o, a.ldd = Cw, a.zero_pads = 1;
       hipLaunchKernelGGL((unet_gn_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, a);
-      Img f{o, T, C};
+      Img f{o, T, Cw};
       gemm(f, PAD, 1, pk + L.fin_out.pk, d.action_dim, L.fin_out.Kp, prm + L.fin_out.b, W.res, 16 * ((d.action_dim + 15) / 16));
       const int64_t n = rows * T * d.action_dim;
       hipLaunchKernelGGL(unet_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W.res,
@@ -799,8 +812,9 @@ struct GnBwdArgs {
   const float* emb;
   int lde;
   float* demb;     // [rows][lde]: d loss / d FiLM parameters (film != 0)
-  void* dU;        // out: padded elem image [rows][Tp][C], zero pads
+  void* dU;        // out: padded elem image [rows][Tp][Cw], zero pads and zero channels [C, Cw)
   float* dgb;      // out: per-sample [rows][2 C]: d gamma | d beta contributions
+  int Cw;
 };
 template <class P>
 __global__ __launch_bounds__(256) void unet_gn_bwd_kernel(const GnBwdArgs a) {
@@ -846,16 +860,21 @@ __global__ __launch_bounds__(256) void unet_gn_bwd_kernel(const GnBwdArgs a) {
   }
   __syncthreads();
   const int Tp = a.T + 2 * PAD;
-  E* dU = (E*)a.dU + (size_t)b * Tp * a.C;
-  for (int i = threadIdx.x; i < a.T * a.C; i += 256) {
-    const int t = i / a.C, c = i % a.C, g = c / cg;
-    float xh;
-    const float dxh = dz_of(t, c, mean[g], rstd[g], xh) * a.gamma[c];
-    dU[(size_t)(t + PAD) * a.C + c] = P::from_f32(rstd[g] * (dxh - s1[g] - xh * s2[g]));
+  E* dU = (E*)a.dU + (size_t)b * Tp * a.Cw;
+  for (int i = threadIdx.x; i < a.T * a.Cw; i += 256) {
+    const int t = i / a.Cw, c = i % a.Cw;
+    float v = 0.f;
+    if (c < a.C) {
+      const int g = c / cg;
+      float xh;
+      const float dxh = dz_of(t, c, mean[g], rstd[g], xh) * a.gamma[c];
+      v = rstd[g] * (dxh - s1[g] - xh * s2[g]);
+    }
+    dU[(size_t)(t + PAD) * a.Cw + c] = P::from_f32(v);
   }
-  for (int i = threadIdx.x; i < 2 * PAD * a.C; i += 256) {
-    const int r = i / a.C, c = i % a.C;
-    dU[(size_t)(r < PAD ? r : a.T + r) * a.C + c] = P::from_f32(0.f);
+  for (int i = threadIdx.x; i < 2 * PAD * a.Cw; i += 256) {
+    const int r = i / a.Cw, c = i % a.Cw;
+    dU[(size_t)(r < PAD ? r : a.T + r) * a.Cw + c] = P::from_f32(0.f);
   }
   // per-channel sums over t: d gamma, d beta, and the FiLM parameter gradients
   for (int c = threadIdx.x; c < a.C; c += 256) {
@@ -883,12 +902,12 @@ template <class P>
 __global__ __launch_bounds__(256) void unet_rows_to_img_kernel(GradSrc a0, GradSrc a1, int n_src, int T, int C,
                                                                typename P::elem_t* img) {
   const int64_t b = blockIdx.x;
-  const int Tp = T + 2 * PAD;
-  typename P::elem_t* d = img + (size_t)b * Tp * C;
-  for (int i = threadIdx.x; i < Tp * C; i += 256) {
-    const int tp = i / C, c = i % C, t = tp - PAD;
+  const int Tp = T + 2 * PAD, Cw = (C + 63) / 64 * 64;
+  typename P::elem_t* d = img + (size_t)b * Tp * Cw;
+  for (int i = threadIdx.x; i < Tp * Cw; i += 256) {
+    const int tp = i / Cw, c = i % Cw, t = tp - PAD;
     float v = 0.f;
-    if (t >= 0 && t < T) {
+    if (t >= 0 && t < T && c < C) {
       v = a0.p[((size_t)b * a0.Tp + t) * a0.ld + a0.coff + c];
       if (n_src > 1) v += a1.p[((size_t)b * a1.Tp + t) * a1.ld + a1.coff + c];
     }
@@ -953,20 +972,20 @@ __global__ __launch_bounds__(256) void unet_colsumE_kernel(const typename P::ele
   }
 }
 // packed weight gradient [N1][ld] -> the flat layout: conv w[co][ci][k] <- dWp[co][k * cip + ci]; linear: ks = 1
-__global__ void unet_unpack_conv_kernel(const float* dWp, int ld, int co, int ci, int ks, int cip, float* out) {
+__global__ void unet_unpack_conv_kernel(const float* dWp, int ld, int co, int ci, int ks, int cip, int split, float* out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)co * ci * ks) return;
   const int k = (int)(i % ks), c = (int)((i / ks) % ci), o = (int)(i / ((size_t)ks * ci));
-  out[i] = dWp[(size_t)o * ld + k * cip + c];
+  out[i] = dWp[(size_t)o * ld + k * cip + chan_pos(c, split)];
 }
 // ConvTranspose1d w[ci][co][4] <- dW2[phase * C + co][slot * C + ci] (see pack_convT_kernel)
-__global__ void unet_unpack_convT_kernel(const float* dW2, int ld, int ch, float* out) {
+__global__ void unet_unpack_convT_kernel(const float* dW2, int ld, int ch, int chp, float* out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)ch * ch * 4) return;
   const int k = (int)(i % 4), co = (int)((i / 4) % ch), ci = (int)(i / ((size_t)4 * ch));
   const int phase = (k == 1 || k == 3) ? 0 : 1;
   const int slot = k == 1 ? 1 : (k == 3 ? 0 : (k == 0 ? 2 : 1));
-  out[i] = dW2[(size_t)(phase * ch + co) * ld + slot * ch + ci];
+  out[i] = dW2[(size_t)(phase * ch + co) * ld + slot * chp + ci];
 }
 // G[k][j] = sum over rows with krow == k of dg[row][j] (j < td): one block per k, fixed order
 __global__ __launch_bounds__(256) void unet_temb_segsum_kernel(const float* dg, int ld, const int32_t* krow, int64_t N, int td,
@@ -1150,6 +1169,10 @@ struct UnetTrainer {
         else
           g2.out_f32 = tp.emb, g2.ldo32 = rup(r.cc, 16);
         launch_gemm_nt<P>(g2, s);
+        if (i + 1 < r.n_enc && rup(l.out, 16) < rup(l.out, 64)) {
+          launch_zero_cols<P>(tp.ez[i], (int)rows, rup(l.out, 16), rup(l.out, 64), rup(l.out, 64), s);
+          launch_zero_cols<P>(tp.ea[i], (int)rows, rup(l.out, 16), rup(l.out, 64), rup(l.out, 64), s);
+        }
       }
       if (i + 1 < r.n_enc) x = tp.ea[i], K = rup(l.out, 64);
     }
@@ -1160,21 +1183,21 @@ struct UnetTrainer {
     RBTape tp;
     memset(&tp, 0, sizeof(tp));
     tp.r = &r, tp.in = in, tp.T = in.T;
-    const int T = in.T, Tp = in.Tp(), ldc = rup(r.co, 16);
+    const int T = in.T, Tp = in.Tp(), ldc = rup(r.co, 16), Cw = rup(r.co, 64);
     encoder_fwd(tp);
     tp.u1 = new_f32((size_t)rows * Tp * ldc);
     tp.u2 = new_f32((size_t)rows * Tp * ldc);
-    tp.mid = new_img(T, r.co);
+    tp.mid = new_img(T, Cw);
     conv_gemm(in, PAD - r.c1.ks / 2, 1, pk + r.c1.pk, r.co, r.c1.Kp, prm + r.c1.b, tp.u1, ldc);
     GnArgs a;
     memset(&a, 0, sizeof(a));
-    a.src = tp.u1, a.lds = ldc, a.Tps = Tp, a.T = T, a.C = r.co, a.G = d.n_groups, a.gamma = prm + r.n1.g;
+    a.src = tp.u1, a.lds = ldc, a.Tps = Tp, a.T = T, a.C = r.co, a.Cw = Cw, a.G = d.n_groups, a.gamma = prm + r.n1.g;
     a.beta = prm + r.n1.b, a.eps = d.groupnorm_eps, a.act = d.act, a.film = d.cond_predict_scale ? 2 : 1, a.emb = tp.emb;
-    a.lde = rup(r.cc, 16), a.dst = tp.mid.p, a.ldd = r.co, a.zero_pads = 1;
+    a.lde = rup(r.cc, 16), a.dst = tp.mid.p, a.ldd = Cw, a.zero_pads = 1;
     if (!dry) hipLaunchKernelGGL((unet_gn_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, a);
     conv_gemm(tp.mid, PAD - r.c2.ks / 2, 1, pk + r.c2.pk, r.co, r.c2.Kp, prm + r.c2.b, tp.u2, ldc);
     memset(&a, 0, sizeof(a));
-    a.src = tp.u2, a.lds = ldc, a.Tps = Tp, a.T = T, a.C = r.co, a.G = d.n_groups, a.gamma = prm + r.n2.g;
+    a.src = tp.u2, a.lds = ldc, a.Tps = Tp, a.T = T, a.C = r.co, a.Cw = Cw, a.G = d.n_groups, a.gamma = prm + r.n2.g;
     a.beta = prm + r.n2.b, a.eps = d.groupnorm_eps, a.act = d.act;
     if (r.has_res) {
       conv_gemm(in, PAD, 1, pk + r.res.pk, r.co, r.res.Kp, prm + r.res.b, tmpA, ldc);
@@ -1199,61 +1222,61 @@ struct UnetTrainer {
       hipLaunchKernelGGL((unet_train_input_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, io, T0, d.action_dim, d.cond_dim,
                          d.time_dim, (const float*)(pk + L.temb), (E*)in_img.p, 64, (E*)g, (E*)graw, L.Kg,
                          d.larger_encoder ? -1 : d.act);
-    for (int l = 1; l < nl; ++l) cat[l] = new_img(T0 >> l, 2 * L.dims[l + 1]);
+    for (int l = 1; l < nl; ++l) cat[l] = new_img(T0 >> l, 2 * rup(L.dims[l + 1], 64));
     Img cur = in_img;
     for (int i = 0; i < nl; ++i) {
-      const int C = L.dims[i + 1], T = T0 >> i;
-      Img a = new_img(T, C);
-      resblock_fwd(L.down[2 * i], cur, a.p, C, 0, 1);
-      Img o = new_img(T, C);
-      resblock_fwd(L.down[2 * i + 1], a, o.p, C, 0, 1, i >= 1 ? cat[i].p : nullptr, 2 * C, C, 1);
+      const int C = L.dims[i + 1], Cw = rup(C, 64), T = T0 >> i;
+      Img a = new_img(T, Cw);
+      resblock_fwd(L.down[2 * i], cur, a.p, Cw, 0, 1);
+      Img o = new_img(T, Cw);
+      resblock_fwd(L.down[2 * i + 1], a, o.p, Cw, 0, 1, i >= 1 ? cat[i].p : nullptr, 2 * Cw, Cw, 1);
       cur = o;
       if (i < nl - 1) {
         const Conv& c = L.downs[i];
         down_in[i] = cur;
         conv_gemm(cur, PAD - 1, 2, pk + c.pk, c.co, c.Kp, prm + c.b, tmpA, rup(C, 16));
-        Img dn = new_img(T / 2, C);
+        Img dn = new_img(T / 2, Cw);
         if (!dry)
           hipLaunchKernelGGL((unet_scatter_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, tmpA, rup(C, 16), cur.Tp() / 2,
-                             T / 2, 1, C, (E*)dn.p, C, 0, 1);
+                             T / 2, 1, C, (E*)dn.p, Cw, 0, 1);
         cur = dn;
       }
     }
     for (int i = 0; i < 2; ++i) {
-      const int C = L.dims[nl];
+      const int Cw = rup(L.dims[nl], 64);
       const bool to_cat = i == 1 && nl >= 2;
-      Img o = to_cat ? cat[nl - 1] : new_img(cur.T, C);
-      resblock_fwd(L.mid[i], cur, o.p, to_cat ? 2 * C : C, 0, to_cat ? 0 : 1);
-      cur = Img{o.p, cur.T, to_cat ? 2 * C : C};
+      Img o = to_cat ? cat[nl - 1] : new_img(cur.T, Cw);
+      resblock_fwd(L.mid[i], cur, o.p, to_cat ? 2 * Cw : Cw, 0, to_cat ? 0 : 1);
+      cur = Img{o.p, cur.T, to_cat ? 2 * Cw : Cw};
     }
     for (int j = 0; j < nl - 1; ++j) {
-      const int din = L.dims[nl - 1 - j];
-      Img a = new_img(cur.T, din);
-      resblock_fwd(L.up[2 * j], cur, a.p, din, 0, 1);
-      Img b2 = new_img(cur.T, din);
-      resblock_fwd(L.up[2 * j + 1], a, b2.p, din, 0, 1);
+      const int din = L.dims[nl - 1 - j], dinw = rup(din, 64);
+      Img a = new_img(cur.T, dinw);
+      resblock_fwd(L.up[2 * j], cur, a.p, dinw, 0, 1);
+      Img b2 = new_img(cur.T, dinw);
+      resblock_fwd(L.up[2 * j + 1], a, b2.p, dinw, 0, 1);
       const Conv& c = L.ups[j];
       up_in[j] = b2;
       conv_gemm(b2, PAD - 1, 1, pk + c.pk, 2 * din, c.Kp, nullptr, tmpA, rup(2 * din, 16));
       const int lvl = nl - 2 - j;
       const bool to_cat = lvl >= 1;
-      Img up = to_cat ? cat[lvl] : new_img(b2.T * 2, din);
-      const int ldd = to_cat ? 2 * din : din;
+      Img up = to_cat ? cat[lvl] : new_img(b2.T * 2, dinw);
+      const int ldd = to_cat ? 2 * dinw : dinw;
       if (!dry)
         hipLaunchKernelGGL((unet_up_scatter_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, tmpA, rup(2 * din, 16), b2.Tp(),
                            b2.T, din, prm + c.b, up.p, ldd, to_cat ? 0 : 1);
       cur = Img{up.p, b2.T * 2, ldd};
     }
     {
-      const int C = d.dim, T = cur.T, ldc = rup(C, 16);
+      const int C = d.dim, Cw = rup(C, 64), T = cur.T, ldc = rup(C, 16);
       fin_in = cur;
       fin_u = new_f32((size_t)rows * cur.Tp() * ldc);
-      fin_mid = new_img(T, C);
+      fin_mid = new_img(T, Cw);
       conv_gemm(cur, PAD - L.fin.ks / 2, 1, pk + L.fin.pk, C, L.fin.Kp, prm + L.fin.b, fin_u, ldc);
       GnArgs a;
       memset(&a, 0, sizeof(a));
-      a.src = fin_u, a.lds = ldc, a.Tps = cur.Tp(), a.T = T, a.C = C, a.G = d.n_groups, a.gamma = prm + L.fin_n.g;
-      a.beta = prm + L.fin_n.b, a.eps = d.groupnorm_eps, a.act = d.act, a.dst = fin_mid.p, a.ldd = C, a.zero_pads = 1;
+      a.src = fin_u, a.lds = ldc, a.Tps = cur.Tp(), a.T = T, a.C = C, a.Cw = Cw, a.G = d.n_groups, a.gamma = prm + L.fin_n.g;
+      a.beta = prm + L.fin_n.b, a.eps = d.groupnorm_eps, a.act = d.act, a.dst = fin_mid.p, a.ldd = Cw, a.zero_pads = 1;
       if (!dry) hipLaunchKernelGGL((unet_gn_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, a);
       const int ldo = 16 * ((d.action_dim + 15) / 16);
       conv_gemm(fin_mid, PAD, 1, pk + L.fin_out.pk, d.action_dim, L.fin_out.Kp, prm + L.fin_out.b, tmpA, ldo);
@@ -1276,26 +1299,26 @@ struct UnetTrainer {
     if (dry) return;
     const size_t n = (size_t)c.co * c.ci * c.ks;
     hipLaunchKernelGGL(unet_unpack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dwp, ld, c.co, c.ci, c.ks,
-                       c.cip, grad + c.w);
+                       c.cip, c.split, grad + c.w);
   }
   // Conv1dBlock backward: upstream gradient(s) of the block-half output -> dU image (returned in `dU`), parameter
   // gradients of the conv and the norm; FiLM gradients -> demb
   void convblock_bwd(const Conv& c, const Norm& nm, const Img& in, const float* u, int T, GradSrc* up, int n_up, int film,
                      const float* emb, int lde, float* demb, void* dU) {
-    const int C = c.co, Tp = T + 2 * PAD, ldc = rup(C, 16);
+    const int C = c.co, Cw = rup(C, 64), Tp = T + 2 * PAD, ldc = rup(C, 16);
     GnBwdArgs a;
     memset(&a, 0, sizeof(a));
-    a.u = u, a.lds = ldc, a.Tps = Tp, a.T = T, a.C = C, a.G = d.n_groups, a.gamma = prm + nm.g, a.beta = prm + nm.b;
+    a.u = u, a.lds = ldc, a.Tps = Tp, a.T = T, a.C = C, a.Cw = Cw, a.G = d.n_groups, a.gamma = prm + nm.g, a.beta = prm + nm.b;
     a.eps = d.groupnorm_eps, a.act = d.act, a.n_up = n_up, a.up[0] = up[0];
     if (n_up > 1) a.up[1] = up[1];
     a.film = film, a.emb = emb, a.lde = lde, a.demb = demb, a.dU = dU, a.dgb = dgb;
     if (!dry) hipLaunchKernelGGL((unet_gn_bwd_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, a);
     colsum_f32(dgb, rows, 2 * C, 2 * C, grad + nm.g);  // d gamma | d beta are adjacent in the flat layout
     // conv parameters: dW = dU^T . Xwin (A = dU image shifted by PAD rows = the GEMM's output-row alignment), db = colsum
-    Img dUi{dU, T, C};
-    conv_wgrad(c, dry ? nullptr : imgrow(dUi, PAD), C, C, in, PAD - c.ks / 2, 1, c.ks);
+    Img dUi{dU, T, Cw};
+    conv_wgrad(c, dry ? nullptr : imgrow(dUi, PAD), Cw, C, in, PAD - c.ks / 2, 1, c.ks);
     unpack_conv(c, c.ks * c.cip);
-    colsum_img(dU, rows * Tp, C, C, grad + c.b);
+    colsum_img(dU, rows * Tp, C, Cw, grad + c.b);
   }
   void encoder_bwd(const RBTape& tp, float* demb) {
     // emb = L_last(...): gradients of the encoder's linears; d loss / d g accumulates into dgacc (time-embedding columns)
@@ -1313,7 +1336,7 @@ struct UnetTrainer {
       if (!dry) {
         const size_t n = (size_t)l.out * l.in;
         hipLaunchKernelGGL(unet_unpack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dwp, l.in, l.out, l.in,
-                           1, l.in, grad + l.w);
+                           1, l.in, 0, grad + l.w);
       }
       colsum_img(dcur, rows, l.out, ldq, grad + l.b);
       if (i > 0) {  // d (previous activation) = dcur . W, times act'(z_{i-1})
@@ -1324,6 +1347,7 @@ struct UnetTrainer {
           g2.ldw = rup(l.out, 64), g2.dsrc = tp.ez[i - 1], g2.dsrc_kind = 2, g2.dsrc_ld = rup(r.enc[i - 1].out, 64);
           g2.dact = d.act, g2.out_pre = dcur == imgA ? imgB : imgA, g2.ldo = ldq;
           launch_gemm_nt<P>(g2, s);
+          if (rup(l.in, 16) < ldq) launch_zero_cols<P>(g2.out_pre, (int)rows, rup(l.in, 16), ldq, ldq, s);
         }
         dcur = dcur == imgA ? imgB : imgA;
       } else {  // d g (time-embedding columns only; the state is data): accumulate over the blocks
@@ -1346,13 +1370,13 @@ struct UnetTrainer {
   // (f32 rows [rows * Tp][ci_ld]) unless `need_in` is false (the network input)
   void resblock_bwd(const RBTape& tp, GradSrc* up, int n_up, float* gin, bool need_in) {
     const ResBlock& r = *tp.r;
-    const int T = tp.T, Tp = T + 2 * PAD, C = r.co;
+    const int T = tp.T, Tp = T + 2 * PAD, C = r.co, Cw = rup(C, 64);
     // second half: y = act(GN(u2)) + res
     void* dU2 = imgA;
     convblock_bwd(r.c2, r.n2, tp.mid, tp.u2, T, up, n_up, 0, nullptr, 0, nullptr, dU2);
     // d mid = conv2 data gradient (f32 rows, width C)
-    Img dU2i{dU2, T, C};
-    conv_gemm(dU2i, PAD - r.c2.ks / 2, 1, pk + r.c2.pkT, C, r.c2.ks * C, nullptr, tmpB, rup(C, 16));
+    Img dU2i{dU2, T, Cw};
+    conv_gemm(dU2i, PAD - r.c2.ks / 2, 1, pk + r.c2.pkT, C, r.c2.ks * Cw, nullptr, tmpB, rup(C, 16));
     // first half: mid = FiLM(act(GN(u1)))
     GradSrc gm{tmpB, rup(C, 16), 0, Tp};
     float* demb = tmpC;
@@ -1360,25 +1384,25 @@ struct UnetTrainer {
     convblock_bwd(r.c1, r.n1, tp.in, tp.u1, T, &gm, 1, d.cond_predict_scale ? 2 : 1, tp.emb, rup(r.cc, 16), demb, dU1);
     // input gradient: conv1 data gradient + the skip path
     if (need_in) {
-      Img dU1i{dU1, T, C};
+      Img dU1i{dU1, T, Cw};
       const int ldi = rup(r.ci, 16);
       if (r.has_res) {
         // dY image (sum of the upstream sources) feeds the 1x1 conv's data gradient, then conv1's adds to it
         if (!dry)
           hipLaunchKernelGGL((unet_rows_to_img_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, up[0], n_up > 1 ? up[1] : up[0],
                              n_up, T, C, (E*)imgA);
-        Img dYi{imgA, T, C};
-        conv_gemm(dYi, PAD, 1, pk + r.res.pkT, r.ci, C, nullptr, gin, ldi);
-        conv_gemm(dU1i, PAD - r.c1.ks / 2, 1, pk + r.c1.pkT, r.ci, r.c1.ks * C, nullptr, gin, ldi, gin, ldi);
+        Img dYi{imgA, T, Cw};
+        conv_gemm(dYi, PAD, 1, pk + r.res.pkT, r.ci, Cw, nullptr, gin, ldi);
+        conv_gemm(dU1i, PAD - r.c1.ks / 2, 1, pk + r.c1.pkT, r.ci, r.c1.ks * Cw, nullptr, gin, ldi, gin, ldi);
       } else {
         // identity skip: gin = conv1 data gradient + sum(up).  The GEMM's f32 addend takes one source; a second is added first
         if (n_up == 1 && up[0].coff == 0 && up[0].Tp == Tp) {
-          conv_gemm(dU1i, PAD - r.c1.ks / 2, 1, pk + r.c1.pkT, r.ci, r.c1.ks * C, nullptr, gin, ldi, up[0].p, up[0].ld);
+          conv_gemm(dU1i, PAD - r.c1.ks / 2, 1, pk + r.c1.pkT, r.ci, r.c1.ks * Cw, nullptr, gin, ldi, up[0].p, up[0].ld);
         } else {
           if (!dry)
             hipLaunchKernelGGL((unet_rows_to_img_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, up[0],
                                n_up > 1 ? up[1] : up[0], n_up, T, C, (E*)imgA);
-          conv_gemm(dU1i, PAD - r.c1.ks / 2, 1, pk + r.c1.pkT, r.ci, r.c1.ks * C, nullptr, gin, ldi);
+          conv_gemm(dU1i, PAD - r.c1.ks / 2, 1, pk + r.c1.pkT, r.ci, r.c1.ks * Cw, nullptr, gin, ldi);
           if (!dry) add_img_rows(gin, ldi, imgA, T, C);
         }
       }
@@ -1387,10 +1411,10 @@ struct UnetTrainer {
       if (!need_in && !dry)
         hipLaunchKernelGGL((unet_rows_to_img_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, up[0], n_up > 1 ? up[1] : up[0],
                            n_up, T, C, (E*)imgA);
-      Img dYi{imgA, T, C};
-      conv_wgrad(r.res, dry ? nullptr : imgrow(dYi, PAD), C, C, tp.in, PAD, 1, 1);
+      Img dYi{imgA, T, Cw};
+      conv_wgrad(r.res, dry ? nullptr : imgrow(dYi, PAD), Cw, C, tp.in, PAD, 1, 1);
       unpack_conv(r.res, r.res.cip);
-      colsum_img(imgA, rows * Tp, C, C, grad + r.res.b);
+      colsum_img(imgA, rows * Tp, C, Cw, grad + r.res.b);
     }
     encoder_bwd(tp, demb);
   }
@@ -1417,7 +1441,7 @@ struct UnetTrainer {
     // gradient buffers (f32 rows), two per level ping-pong + one for concat splits
     size_t gmax = 0;
     for (int l = 0; l < nl; ++l) {
-      const size_t b = (size_t)((T0 >> l) + 2 * PAD) * rup(2 * L.dims[l + 1], 16);
+      const size_t b = (size_t)((T0 >> l) + 2 * PAD) * rup(2 * rup(L.dims[l + 1], 64), 16);
       gmax = b > gmax ? b : gmax;
     }
     float* G[4];
@@ -1430,17 +1454,17 @@ struct UnetTrainer {
     // final Conv1dBlock
     GradSrc up0{g_finmid, rup(d.dim, 16), 0, Tp0};
     convblock_bwd(L.fin, L.fin_n, fin_in, fin_u, T0, &up0, 1, 0, nullptr, 0, nullptr, imgA);
-    Img dUf{imgA, T0, d.dim};
+    Img dUf{imgA, T0, rup(d.dim, 64)};
     float* gcur = nextG();
-    int gcur_ld = rup(fin_in.C, 16);
-    conv_gemm(dUf, PAD - L.fin.ks / 2, 1, pk + L.fin.pkT, fin_in.C, L.fin.ks * d.dim, nullptr, gcur, gcur_ld);
+    int gcur_ld = rup(d.dim, 16);  // final_conv's input map has `dim` channels (real)
+    conv_gemm(dUf, PAD - L.fin.ks / 2, 1, pk + L.fin.pkT, d.dim, L.fin.ks * rup(d.dim, 64), nullptr, gcur, gcur_ld);
     GradSrc cur{gcur, gcur_ld, 0, Tp0};  // gradient of the image feeding final_conv (width = its C)
     int ti = (int)tape.size() - 1;
     GradSrc skipg[4];
     memset(skipg, 0, sizeof(skipg));
     // ---- up path (reverse)
     for (int j = nl - 2; j >= 0; --j) {
-      const int din = L.dims[nl - 1 - j];
+      const int din = L.dims[nl - 1 - j], dinw = rup(din, 64);
       const int lvl = nl - 2 - j;  // the level the upsampled map landed on
       const Img& xin = up_in[j];   // Upsample1d's input (T small)
       const int Ts = xin.T, Tb = 2 * Ts;
@@ -1452,21 +1476,21 @@ struct UnetTrainer {
       if (!dry)
         hipLaunchKernelGGL((unet_rows_fmt_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, cur, cur, 1, Tb, din, 2, xin.Tp(),
                            (E*)dY2);
-      wgrad(dY2, 2 * din, 2 * din, dry ? nullptr : imgrow(xin, PAD - 1), din, 3 * din, wrows(xin, PAD - 1, 1, 3));
+      wgrad(dY2, 2 * din, 2 * din, dry ? nullptr : imgrow(xin, PAD - 1), dinw, 3 * dinw, wrows(xin, PAD - 1, 1, 3));
       if (!dry) {
         const size_t n = (size_t)din * din * 4;
-        hipLaunchKernelGGL(unet_unpack_convT_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dwp, 3 * din, din,
+        hipLaunchKernelGGL(unet_unpack_convT_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dwp, 3 * dinw, din, dinw,
                            grad + c.w);
       }
       // bias: both phases share it: column sums of the big-T gradient
       void* dYimg = imgB;
       if (!dry)
         hipLaunchKernelGGL((unet_rows_to_img_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, cur, cur, 1, Tb, din, (E*)dYimg);
-      colsum_img(dYimg, rows * (Tb + 2 * PAD), din, din, grad + c.b);
+      colsum_img(dYimg, rows * (Tb + 2 * PAD), din, dinw, grad + c.b);
       // data: strided conv over the dy image: rows r' = b * (Tpb / 2) + s
-      Img dYi{dYimg, Tb, din};
+      Img dYi{dYimg, Tb, dinw};
       float* gx = nextG();
-      conv_gemm(dYi, PAD - 1, 2, pk + c.pkT, din, 4 * din, nullptr, gx, rup(din, 16));
+      conv_gemm(dYi, PAD - 1, 2, pk + c.pkT, din, 4 * dinw, nullptr, gx, rup(din, 16));
       GradSrc up1{gx, rup(din, 16), 0, dYi.Tp() / 2};
       // second block of the level
       float* g1 = nextG();
@@ -1503,21 +1527,21 @@ struct UnetTrainer {
         // Downsample1d of level i-1 produced this level's input: g0 is the gradient of its output (T small)
         const Conv& c = L.downs[i - 1];
         const Img& xin = down_in[i - 1];  // big-T image, C = dims[i]
-        const int Cb = L.dims[i], Tb = xin.T;
+        const int Cb = L.dims[i], Cbw = rup(Cb, 64), Tb = xin.T;
         GradSrc gy{g0, rup(Cb, 16), 0, T + 2 * PAD};
         // A operand in the forward GEMM's row format (b * Tpb / 2 + t'), and as an image for the data gradient
         void* dYr = imgA;
         if (!dry)
           hipLaunchKernelGGL((unet_rows_fmt_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, gy, gy, 1, T, Cb, 1, xin.Tp() / 2,
                              (E*)dYr);
-        wgrad(dYr, Cb, Cb, dry ? nullptr : imgrow(xin, PAD - 1), 2 * Cb, 3 * Cb, wrows(xin, PAD - 1, 2, 3));
+        wgrad(dYr, Cb, Cb, dry ? nullptr : imgrow(xin, PAD - 1), 2 * Cbw, 3 * Cbw, wrows(xin, PAD - 1, 2, 3));
         unpack_conv(c, c.ks * c.cip);
         colsum_img(dYr, rows * (xin.Tp() / 2), Cb, Cb, grad + c.b);
         void* dYimg = imgB;
         if (!dry)
           hipLaunchKernelGGL((unet_rows_to_img_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, gy, gy, 1, T, Cb, (E*)dYimg);
-        Img dYi{dYimg, T, Cb};
-        conv_gemm(dYi, PAD, 1, pk + c.pkT, 2 * Cb, 2 * Cb, nullptr, tmpB, rup(2 * Cb, 16));
+        Img dYi{dYimg, T, Cbw};
+        conv_gemm(dYi, PAD, 1, pk + c.pkT, 2 * Cb, 2 * Cbw, nullptr, tmpB, rup(2 * Cb, 16));
         float* gb = nextG();
         if (!dry)
           hipLaunchKernelGGL(unet_phase_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, tmpB, rup(2 * Cb, 16), dYi.Tp(), T, Cb,
@@ -1539,7 +1563,7 @@ struct UnetTrainer {
   void plan_scratch() {
     const int nl = d.n_levels, T0 = d.horizon_steps;
     int cmax = 64;
-    for (int i = 1; i <= nl; ++i) cmax = L.dims[i] > cmax ? L.dims[i] : cmax;
+    for (int i = 1; i <= nl; ++i) cmax = rup(L.dims[i], 64) > cmax ? rup(L.dims[i], 64) : cmax;
     tmp_floats = (size_t)rows * (T0 + 2 * PAD) * 2 * cmax;
     tmpA = new_f32(tmp_floats), tmpB = new_f32(tmp_floats), tmpC = new_f32((size_t)rows * 2 * cmax);
     imgA = take(tmp_floats * P::ESIZE), imgB = take(tmp_floats * P::ESIZE);
@@ -1556,10 +1580,10 @@ struct UnetTrainer {
 template <class P>
 __global__ __launch_bounds__(256) void unet_add_img_rows_kernel(float* gin, int ld, const typename P::elem_t* img, int T, int C) {
   const int64_t b = blockIdx.x;
-  const int Tp = T + 2 * PAD;
+  const int Tp = T + 2 * PAD, Cw = (C + 63) / 64 * 64;
   for (int i = threadIdx.x; i < T * C; i += 256) {
     const int t = i / C, c = i % C;
-    gin[((size_t)b * Tp + t) * ld + c] += P::to_f32(img[((size_t)b * Tp + t + PAD) * C + c]);
+    gin[((size_t)b * Tp + t) * ld + c] += P::to_f32(img[((size_t)b * Tp + t + PAD) * Cw + c]);
   }
 }
 template <class P>

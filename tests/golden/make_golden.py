@@ -486,11 +486,12 @@ def ref_unet(spec, params):
     return m
 
 
-def g13_unet():
+def g13_unet(UNET_SPECS=UNET_SPECS, UNET_CHAIN_CASES=UNET_CHAIN_CASES, seed=1300, fname="g13_unet", out=None):
     """Unet1D.forward (model/diffusion/unet.py:264-327), one ResidualBlock1D (:100-118), one Conv1dBlock
     (modules.py:50-95), and K-step chains + log-probs of a PPODiffusion whose actor is the UNet."""
-    out = {}
-    rs = np.random.RandomState(1300)
+    own = out is None
+    out = {} if own else out
+    rs = np.random.RandomState(seed)
     for name, kw in UNET_SPECS.items():
         u = O.UnetSpec(**kw)
         p = O.unet_init_params(u, 81)
@@ -528,7 +529,8 @@ def g13_unet():
             lp = m.get_logprobs({"state": state}, smp.chains)
         out.update({f"{cname}_state": state, f"{cname}_noise": noise, f"{cname}_traj": smp.trajectories,
                     f"{cname}_chains": smp.chains, f"{cname}_logprobs": lp})
-    save("g13_unet", **out)
+    if own:
+        save(fname, **out)
 
 
 # ---------------------------------------------------------------- G14 conv denoiser: PPO loss and supervised loss with gradients
@@ -546,9 +548,11 @@ def unet_model(u, seed, **kw):
     return m, c
 
 
-def g14_unet_loss():
-    out = {}
-    rs = np.random.RandomState(1400)
+def g14_unet_loss(UNET_SPECS=UNET_SPECS, UNET_LOSS_CASES=UNET_LOSS_CASES, UNET_MSE_CASES=UNET_MSE_CASES, seed=1400,
+                  fname="g14_unet_loss", out=None):
+    own = out is None
+    out = {} if own else out
+    rs = np.random.RandomState(seed)
     for cname, (sname, N, kw, rh) in UNET_LOSS_CASES.items():
         u = O.UnetSpec(**UNET_SPECS[sname])
         m, c = unet_model(u, 31, **kw)
@@ -596,7 +600,18 @@ def g14_unet_loss():
                     f"{cname}_loss": np.float64(loss.item())})
         for k, p in net.named_parameters():
             put_grad(out, f"{cname}_g_{k}", p.grad)
-    save("g14_unet_loss", **out)
+    if own:
+        save(fname, **out)
+
+
+def g15_unet_dim40():
+    """The dim: 40 conv denoiser of the robomimic can / lift cfgs (cfg/robomimic/finetune/can/ft_ppo_diffusion_unet.yaml:93-103)
+    and a three-level variant: forward, blocks, chain + log-probs, PPO loss and supervised loss with every gradient."""
+    from make_golden_cases import UNET40_CHAIN_CASES, UNET40_LOSS_CASES, UNET40_MSE_CASES, UNET40_SPECS
+    out = {}
+    g13_unet(UNET40_SPECS, UNET40_CHAIN_CASES, 1500, None, out)
+    g14_unet_loss(UNET40_SPECS, UNET40_LOSS_CASES, UNET40_MSE_CASES, 1501, None, out)
+    save("g15_unet_dim40", **out)
 
 
 # ---------------------------------------------------------------- G10 LR schedule trace
@@ -623,6 +638,6 @@ def g10_scheduler():
 
 if __name__ == "__main__":
     only = sys.argv[1:]  # e.g. `make_golden.py g8_bc` regenerates one file (each generator owns its RNG stream)
-    for fn in (g1_tables, g2_forward, g3_g4_chains, g5_loss, g6_reward_scaler, g7_adamw, g8_bc, g9_denoise_mse, g10_scheduler, g11_eval, g12_gaussian, g13_unet, g14_unet_loss):
+    for fn in (g1_tables, g2_forward, g3_g4_chains, g5_loss, g6_reward_scaler, g7_adamw, g8_bc, g9_denoise_mse, g10_scheduler, g11_eval, g12_gaussian, g13_unet, g14_unet_loss, g15_unet_dim40):
         if not only or fn.__name__ in only:
             fn()

@@ -56,3 +56,16 @@ UNET_LOSS_CASES = {
                                                             min_sampling_denoising_std=0.04), 8),
 }
 UNET_MSE_CASES = {"unet_mse_square": ("unet_square", 20, 24), "unet_mse_furniture": ("unet_furniture", 100, 12)}
+
+# the robomimic can / lift cfgs ship dim: 40 (channel counts 40 / 80, not multiples of the 64-element GEMM k-step: every map
+# is padded to 64 / 128 channels in its image) -- its own fixture file, g15_unet_dim40.npz
+UNET40_SPECS = {"unet_dim40": dict(action_dim=7, cond_dim=23, horizon_steps=4, diffusion_step_embed_dim=16, dim=40,
+                                   dim_mults=(1, 2), kernel_size=5, n_groups=8, smaller_encoder=False, cond_predict_scale=True),
+                "unet_dim40_l3": dict(action_dim=7, cond_dim=19, horizon_steps=8, diffusion_step_embed_dim=16, dim=40,
+                                      dim_mults=(1, 2, 4), kernel_size=5, n_groups=8, smaller_encoder=False,
+                                      cond_predict_scale=True)}
+UNET40_CHAIN_CASES = {"unet40_ddpm20_ft10": ("unet_dim40", 5, dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3), False)}
+UNET40_LOSS_CASES = {"unet40_loss": ("unet_dim40", 32, dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01,
+                                                           clip_ploss_coef_base=0.001), 4),
+                     "unet40_l3_loss": ("unet_dim40_l3", 16, dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01), 8)}
+UNET40_MSE_CASES = {"unet40_mse": ("unet_dim40", 20, 24)}

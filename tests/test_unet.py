@@ -279,3 +279,91 @@ def test_hip_unet_update_in_bf16_and_rollout_mode():
         out[prec] = (ga, gc)
     cos = lambda x, y: float(np.dot(x, y) / (np.linalg.norm(x) * np.linalg.norm(y) + 1e-30))
     assert cos(out["fp32"][1], out["bf16"][1]) >= 0.99
+
+
+# ------------------------------------------------------------------ G15: dim 40 (maps padded to 64 / 128 channels in their images)
+from tests.golden.make_golden_cases import UNET40_CHAIN_CASES, UNET40_LOSS_CASES, UNET40_MSE_CASES, UNET40_SPECS  # noqa: E402
+
+
+def test_oracle_dim40_fixtures(golden):
+    g = golden("g15_unet_dim40")
+    for name, kw in UNET40_SPECS.items():
+        u = O.UnetSpec(**kw)
+        with torch.no_grad():
+            eps = O.unet_forward(O.unet_init_params(u, 81), u, T(g[f"{name}_x"]), T(g[f"{name}_t"]), T(g[f"{name}_state"]))
+        np.testing.assert_allclose(eps.numpy(), g[f"{name}_eps"], rtol=2e-5, atol=2e-5)
+    for case, (sname, N, kw, rh) in UNET40_LOSS_CASES.items():
+        u = O.UnetSpec(**UNET40_SPECS[sname])
+        c = CRITIC(u)
+        cfg = make_cfg(u, dict(kw, gamma_denoising=0.99, randn_clip_value=3))
+        ft = {k: v.clone().requires_grad_(True) for k, v in O.unet_init_params(u, 32).items()}
+        cr = {k: v.clone().requires_grad_(True) for k, v in O.init_params(c, 33).items()}
+        d = lambda k: T(g[f"{case}_{k}"])
+        res = O.ppo_loss(cfg, u, c, O.unet_init_params(u, 31), ft, cr, d("state"), d("prev"), d("next"), d("kinds"), d("returns"),
+                         d("oldvalues"), d("adv"), d("oldlogprobs"), reward_horizon=rh)
+        got = np.array([res[0].item(), float(res[1]), res[2].item(), res[3], res[4], res[5], float(res[6]), res[7]])
+        np.testing.assert_allclose(got, g[f"{case}_stats"], rtol=5e-5, atol=5e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16", 6e-2)])
+def test_hip_dim40_forward_and_chain(golden, prec, tol):
+    from dppo_amd.model.common.critic import CriticObs
+    from dppo_amd.model.diffusion.diffusion_ppo import PPODiffusion
+    g = golden("g15_unet_dim40")
+    dev = "cuda:0"
+    for name, kw in UNET40_SPECS.items():
+        u = O.UnetSpec(**kw)
+        m = hip_unet(u, 81, prec)
+        eps = m(T(g[f"{name}_x"]).to(dev), T(g[f"{name}_t"]).to(dev), {"state": T(g[f"{name}_state"]).to(dev)})
+        np.testing.assert_allclose(eps.cpu().numpy(), g[f"{name}_eps"], rtol=tol, atol=tol)
+    for case, (sname, B, kw, det) in UNET40_CHAIN_CASES.items():
+        u = O.UnetSpec(**UNET40_SPECS[sname])
+        actor = hip_unet(u, 21, prec, dev="cpu")
+        critic = CriticObs(cond_dim=u.cond_dim, mlp_dims=[256, 256, 256], residual_style=True, precision=prec)
+        m = PPODiffusion(actor=actor, critic=critic, horizon_steps=u.horizon_steps, obs_dim=u.cond_dim, action_dim=u.action_dim,
+                         device=dev, gamma_denoising=0.99, clip_ploss_coef=0.01, **kw)
+        m.actor_ft.load_state_dict(O.unet_init_params(u, 22), strict=True)
+        smp = m(cond={"state": T(g[f"{case}_state"]).to(dev)}, deterministic=det, noise=T(g[f"{case}_noise"]).to(dev))
+        ct = 5e-4 if prec == "fp32" else 8e-2
+        np.testing.assert_allclose(smp.chains.cpu().numpy(), g[f"{case}_chains"], rtol=ct, atol=ct)
+        lp = m.get_logprobs({"state": T(g[f"{case}_state"]).to(dev)}, T(g[f"{case}_chains"]).to(dev)).cpu().numpy()
+        ref = g[f"{case}_logprobs"]
+        sel = ref > -50
+        assert np.abs(lp[sel] - ref[sel]).mean() <= (2e-4 if prec == "fp32" else 0.15)
+
+
+@pytest.mark.gpu
+def test_hip_dim40_losses_and_grads(golden):
+    from dppo_amd.model.common.critic import CriticObs
+    from dppo_amd.model.diffusion.diffusion import DiffusionModel
+    from dppo_amd.model.diffusion.diffusion_ppo import PPODiffusion
+    g = golden("g15_unet_dim40")
+    dev = "cuda:0"
+    for case, (sname, N, kw, rh) in UNET40_LOSS_CASES.items():
+        u = O.UnetSpec(**UNET40_SPECS[sname])
+        actor = hip_unet(u, 31, "fp32", dev="cpu")
+        critic = CriticObs(cond_dim=u.cond_dim, mlp_dims=[256, 256, 256], residual_style=True, precision="fp32")
+        critic.load_state_dict(O.init_params(CRITIC(u), 33))
+        m = PPODiffusion(actor=actor, critic=critic, horizon_steps=u.horizon_steps, obs_dim=u.cond_dim, action_dim=u.action_dim,
+                         device=dev, gamma_denoising=0.99, randn_clip_value=3, **kw)
+        m.actor_ft.load_state_dict(O.unet_init_params(u, 32), strict=True)
+        d = lambda k: T(g[f"{case}_{k}"]).to(dev)
+        res = m.loss({"state": d("state")}, d("prev"), d("next"), d("kinds"), d("returns"), d("oldvalues"), d("adv"),
+                     d("oldlogprobs"), use_bc_loss=False, reward_horizon=rh)
+        got = np.array([res[0].item(), float(res[1]), res[2].item(), res[3], res[4], res[5], float(res[6]), res[7]])
+        np.testing.assert_allclose(got, g[f"{case}_stats"], rtol=5e-4, atol=5e-5)
+        (res[0] + 0.5 * res[2]).backward()
+        worst, norm = grad_report(g, f"{case}_gactor", [(k, p.grad) for k, p in m.actor_ft.named_parameters()])
+        assert worst[1] <= 5e-3 and norm <= 2e-3, (case, worst, norm)
+    for case, (sname, K, N) in UNET40_MSE_CASES.items():
+        u = O.UnetSpec(**UNET40_SPECS[sname])
+        net = hip_unet(u, 51, "fp32", dev="cpu")
+        m = DiffusionModel(network=net, horizon_steps=u.horizon_steps, obs_dim=u.cond_dim, action_dim=u.action_dim, device=dev,
+                           denoising_steps=K)
+        d = lambda k: T(g[f"{case}_{k}"]).to(dev)
+        loss = m.p_losses(d("x0"), {"state": d("state")}, d("t"), noise=d("noise"))
+        loss.backward()
+        assert loss.item() == pytest.approx(float(g[f"{case}_loss"]), rel=2e-4)
+        worst, norm = grad_report(g, f"{case}_g", [(k, p.grad) for k, p in net.named_parameters()])
+        assert worst[1] <= 5e-3 and norm <= 2e-3, (case, worst, norm)
