@@ -9,6 +9,9 @@ EXTRA=""
 if [ -n "${DPPO_STAMPS:-}" ]; then  # debug variant with in-kernel phase stamps (tools/fused_bench.py --stamps)
   OBJ="$HERE/obj_stamps"; LIB="libdppo_hip_stamps.so"; EXTRA="-DDPPO_STAMPS"
 fi
+if [ -n "${DPPO_VARIANT:-}" ]; then  # experiment build: DPPO_VARIANT=name DPPO_CXXFLAGS="-D..." -> lib/libdppo_hip_name.so
+  OBJ="$HERE/obj_${DPPO_VARIANT}"; LIB="libdppo_hip_${DPPO_VARIANT}.so"; EXTRA="${DPPO_CXXFLAGS:-}"
+fi
 mkdir -p "$OUT" "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I$HERE/../../include $EXTRA"

@@ -241,6 +241,13 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_forward_kernel(const Fused
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifndef DPPO_NO_SETPRIO
+  // static priority for the younger half of the workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4): waves 4-7
+  // lose every VALU arbitration against their SIMD partners and reach each layer's barrier 3.5-6.5k cycles late
+  // (profiles/r01_h_fused_phase_stamps.txt); measured +0.8 % on the update step (profiles/r02_i_setprio_ab.txt).  The
+  // same line in the sampler costs 7 % there (one 16-row tile per workgroup: the older half is the critical path).
+  if (wid >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   const int r = lane & 15, g = lane >> 4;
   const int Kp0 = a.Kp0, nb = a.nb, M = a.M;
   const int in_rb = Kp0 * ES, in_km = kmask16(in_rb), KS0 = Kp0 / KB;
@@ -429,6 +436,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifndef DPPO_NO_SETPRIO
+  if (wid >= 4) __builtin_amdgcn_s_setprio(1);  // see fused_forward_kernel
+#endif
   const int r = lane & 15, g = lane >> 4;
   const int nb = a.nb, M = a.M;
   const int in_rb = a.KpB0 * ES, in_km = kmask16(in_rb), KSB0 = a.KpB0 / KB;
