@@ -336,7 +336,24 @@ def trunk_forward(p: Params, spec: NetSpec, x: torch.Tensor) -> torch.Tensor:
     return F.linear(h, p[f"{t}.layers.{n_blocks + 1}.weight"], p[f"{t}.layers.{n_blocks + 1}.bias"])
 
 
-def actor_forward(p: Params, spec, x: torch.Tensor, t: torch.Tensor, state: torch.Tensor) -> torch.Tensor:
+def _n_rows(state) -> int:
+    """Observations are a (B,To,Do) tensor, or the reference's cond dict {"state", "rgb"} for the pixel networks."""
+    return (state["state"] if isinstance(state, dict) else state).shape[0]
+
+
+def _take_rows(state, idx):
+    return {k: v[idx] for k, v in state.items()} if isinstance(state, dict) else state[idx]
+
+
+def _repeat_rows(state, K: int):
+    if isinstance(state, dict):
+        return {k: _repeat_rows(v, K) for k, v in state.items()}
+    return state.unsqueeze(1).repeat(1, K, *([1] * (state.dim() - 1))).flatten(0, 1)
+
+
+def actor_forward(p: Params, spec, x: torch.Tensor, t: torch.Tensor, state) -> torch.Tensor:
+    if getattr(spec, "kind", "") == "vision":  # ViT encoder + SpatialEmb in front of either denoiser
+        return vision_actor_forward(p, spec.vis, spec.trunk, x, t, state)
     if getattr(spec, "kind", "") == "unet":  # conv denoiser (8f row 2): same (x, t, state) -> eps contract
         return unet_forward(p, spec, x, t, state)
     return _mlp_actor_forward(p, spec, x, t, state)
@@ -357,6 +374,8 @@ def _mlp_actor_forward(p: Params, spec: NetSpec, x: torch.Tensor, t: torch.Tenso
 
 def critic_forward(p: Params, spec: NetSpec, state: torch.Tensor) -> torch.Tensor:
     """CriticObs.forward, model/common/critic.py:40-54: (B,To,Do) -> (B,1)."""
+    if getattr(spec, "kind", "") == "vision":  # ViTCritic, critic.py:159-206
+        return vit_critic_forward(p, spec.vis, spec.trunk, state)
     return trunk_forward(p, spec, state.reshape(state.shape[0], -1))
 
 
@@ -428,7 +447,7 @@ def p_mean_var(cfg: DiffusionCfg, spec: NetSpec, base: Params, ft: Params,
         ft_rows = torch.where(t < cfg.ft_denoising_steps)[0]
     net = base if use_base_policy else ft
     if len(ft_rows) > 0:
-        eps_ft = actor_forward(net, spec, x[ft_rows], t[ft_rows], state[ft_rows])
+        eps_ft = actor_forward(net, spec, x[ft_rows], t[ft_rows], _take_rows(state, ft_rows))
         eps = eps.index_put((ft_rows,), eps_ft)
     if cfg.use_ddim:
         al = _col(T["ddim_alphas"], index)
@@ -468,7 +487,7 @@ def sample_chain(cfg: DiffusionCfg, spec: NetSpec, base: Params, ft: Params, sta
     (the reference draws with torch.randn / randn_like; parity runs pass the recorded draws).
     Returns (trajectories (B,Ta,Da), chains (B,Kft+1,Ta,Da)).
     """
-    B = state.shape[0]
+    B = _n_rows(state)
     x = noise[0].clone()
     if cfg.use_ddim:
         t_all = [int(v) for v in cfg.tables["ddim_t"]]
@@ -540,7 +559,7 @@ def chain_logprob(cfg: DiffusionCfg, spec: NetSpec, base: Params, ft: Params, st
     """VPGDiffusion.get_logprobs, diffusion_vpg.py:319-396: (B,Kft+1,Ta,Da) -> (B*Kft,Ta,Da)."""
     B = chains.shape[0]
     Kft = cfg.ft_denoising_steps
-    st = state.unsqueeze(1).repeat(1, Kft, 1, 1).flatten(0, 1)
+    st = _repeat_rows(state, Kft)
     k = torch.arange(Kft).repeat(B)
     prev = chains[:, :-1].reshape(-1, cfg.horizon_steps, cfg.action_dim)
     nxt = chains[:, 1:].reshape(-1, cfg.horizon_steps, cfg.action_dim)
@@ -817,6 +836,194 @@ def unet_forward(p: Params, spec: UnetSpec, x: torch.Tensor, t: torch.Tensor, st
     h = conv1d_block(p, "final_conv.0", h, spec)
     h = F.conv1d(h, p["final_conv.1.weight"], p["final_conv.1.bias"])
     return h.transpose(1, 2)
+
+
+# --------------------------------------------------------------------------
+# 8f row 2 (pixel observations): ViT encoder + SpatialEmb in front of the denoiser / the critic
+# --------------------------------------------------------------------------
+@dataclass
+class VisSpec:
+    """VitEncoder (model/common/vit.py:28-62, embed_style "embed2", embed_norm 0) + SpatialEmb (model/common/modules.py:10-41)
+    as VisionDiffusionMLP / VisionUnet1D / ViTCritic assemble them (mlp_diffusion.py:42-75, unet.py:355-383, critic.py:131-157).
+    ``in_ch`` = 3 * img_cond_steps per camera; ``prop_dim`` = To*Do of the low-dimensional state."""
+
+    in_ch: int = 3
+    img_h: int = 96
+    img_w: int = 96
+    embed_dim: int = 128
+    num_heads: int = 4
+    depth: int = 1
+    prop_dim: int = 9
+    spatial_emb: int = 128
+    num_img: int = 1
+
+    @property
+    def grid(self) -> Tuple[int, int, int, int]:
+        """(H1, W1, H2, W2): maps after Conv2d(k8, s4) and Conv2d(k3, s2) (vit.py:92-96)."""
+        h1, w1 = (self.img_h - 8) // 4 + 1, (self.img_w - 8) // 4 + 1
+        return h1, w1, (h1 - 3) // 2 + 1, (w1 - 3) // 2 + 1
+
+    @property
+    def num_patch(self) -> int:
+        g = self.grid
+        return g[2] * g[3]
+
+    @property
+    def feat_dim(self) -> int:
+        return self.spatial_emb * self.num_img
+
+    def compress_names(self) -> List[str]:
+        return ["compress"] if self.num_img == 1 else ["compress1", "compress2"]
+
+
+def vis_param_shapes(v: VisSpec) -> List[Tuple[str, Tuple[int, ...], int]]:
+    """(name, shape, code) in the reference's state-dict order: a module's own Parameters precede its children, so
+    ``pos_embed`` leads MinVit and ``weight`` leads SpatialEmb.  code > 0: fan-in of a Linear / Conv; 0: norm affine;
+    -1: pos_embed; -2: SpatialEmb.weight."""
+    D, out = v.embed_dim, []
+
+    def lin(name, i, o):
+        out.append((f"{name}.weight", (o, i), i))
+        out.append((f"{name}.bias", (o,), i))
+
+    def norm(name, d):
+        out.append((f"{name}.weight", (d,), 0))
+        out.append((f"{name}.bias", (d,), 0))
+
+    b = "backbone.vit"
+    out.append((f"{b}.pos_embed", (1, v.num_patch, D), -1))
+    out.append((f"{b}.patch_embed.embed.0.weight", (D, v.in_ch, 8, 8), v.in_ch * 64))
+    out.append((f"{b}.patch_embed.embed.0.bias", (D,), v.in_ch * 64))
+    out.append((f"{b}.patch_embed.embed.3.weight", (D, D, 3, 3), D * 9))
+    out.append((f"{b}.patch_embed.embed.3.bias", (D,), D * 9))
+    for l in range(v.depth):
+        n = f"{b}.net.{l}"
+        norm(f"{n}.layer_norm1", D)
+        lin(f"{n}.mha.qkv_proj", D, 3 * D)
+        lin(f"{n}.mha.out_proj", D, D)
+        norm(f"{n}.layer_norm2", D)
+        lin(f"{n}.linear1", D, 4 * D)
+        lin(f"{n}.linear2", 4 * D, D)
+    norm(f"{b}.norm", D)
+    for c in v.compress_names():
+        out.append((f"{c}.weight", (1, D, v.spatial_emb), -2))
+        lin(f"{c}.input_proj.0", v.num_patch + v.prop_dim, v.spatial_emb)
+        norm(f"{c}.input_proj.1", v.spatial_emb)
+    return out
+
+
+def vis_init_params(v: VisSpec, seed: int) -> Params:
+    rs = np.random.RandomState(seed)
+    p: Params = {}
+    for name, shape, code in vis_param_shapes(v):
+        if code > 0:
+            b = 1.0 / math.sqrt(code)
+            a = rs.uniform(-b, b, size=shape)
+        elif code == -1:
+            a = rs.uniform(-0.2, 0.2, size=shape)
+        elif code == -2:
+            a = rs.uniform(-1.5, 1.5, size=shape)
+        elif name.endswith("weight"):
+            a = rs.uniform(0.5, 1.5, size=shape)
+        else:
+            a = rs.uniform(-0.1, 0.1, size=shape)
+        p[name] = torch.from_numpy(a.astype(np.float32))
+    return p
+
+
+def vit_forward(p: Params, v: VisSpec, img: torch.Tensor) -> torch.Tensor:
+    """VitEncoder.forward (vit.py:55-61) -> MinVit.forward (:191-195).  img (B, in_ch, H, W) in 0..255 -> (B, P, D)."""
+    b, D, nh = "backbone.vit", v.embed_dim, v.num_heads
+    x = img / 255.0 - 0.5
+    y = F.conv2d(x, p[f"{b}.patch_embed.embed.0.weight"], p[f"{b}.patch_embed.embed.0.bias"], stride=4)
+    y = F.conv2d(F.relu(y), p[f"{b}.patch_embed.embed.3.weight"], p[f"{b}.patch_embed.embed.3.bias"], stride=2)
+    y = y.flatten(2).transpose(1, 2) + p[f"{b}.pos_embed"]  # "b c h w -> b (h w) c"
+    B, T, _ = y.shape
+    for l in range(v.depth):
+        n = f"{b}.net.{l}"
+        h = F.layer_norm(y, (D,), p[f"{n}.layer_norm1.weight"], p[f"{n}.layer_norm1.bias"])
+        qkv = F.linear(h, p[f"{n}.mha.qkv_proj.weight"], p[f"{n}.mha.qkv_proj.bias"])
+        q, k, val = qkv.reshape(B, T, 3, nh, D // nh).permute(2, 0, 3, 1, 4)  # "b t (k h d) -> b k h t d" (:117-119)
+        att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(D // nh), dim=-1) @ val
+        att = att.permute(0, 2, 1, 3).reshape(B, T, D)  # "b h t d -> b t (h d)"
+        y = y + F.linear(att, p[f"{n}.mha.out_proj.weight"], p[f"{n}.mha.out_proj.bias"])
+        h = F.layer_norm(y, (D,), p[f"{n}.layer_norm2.weight"], p[f"{n}.layer_norm2.bias"])
+        h = F.gelu(F.linear(h, p[f"{n}.linear1.weight"], p[f"{n}.linear1.bias"]))
+        y = y + F.linear(h, p[f"{n}.linear2.weight"], p[f"{n}.linear2.bias"])
+    return F.layer_norm(y, (D,), p[f"{b}.norm.weight"], p[f"{b}.norm.bias"])
+
+
+def spatial_emb_forward(p: Params, name: str, feat: torch.Tensor, prop: torch.Tensor) -> torch.Tensor:
+    """SpatialEmb.forward (modules.py:31-41): feat (B, P, D), prop (B, prop_dim) -> (B, proj_dim)."""
+    f = feat.transpose(1, 2)
+    f = torch.cat((f, prop.unsqueeze(1).repeat(1, f.shape[1], 1)), dim=-1)
+    y = F.linear(f, p[f"{name}.input_proj.0.weight"], p[f"{name}.input_proj.0.bias"])
+    S = y.shape[-1]
+    y = F.relu(F.layer_norm(y, (S,), p[f"{name}.input_proj.1.weight"], p[f"{name}.input_proj.1.bias"]))
+    return (p[f"{name}.weight"] * y).sum(1)
+
+
+def vis_features(p: Params, v: VisSpec, rgb: torch.Tensor, state: torch.Tensor) -> torch.Tensor:
+    """The visual half of VisionDiffusionMLP / VisionUnet1D / ViTCritic.forward (mlp_diffusion.py:120-160): rgb
+    (B, T_rgb, 3 * num_img, H, W) with T_rgb = img_cond_steps, state (B, To, Do) -> cat[feat, state] (B, feat_dim + To*Do)."""
+    B, T, C, H, W = rgb.shape
+    s = state.reshape(B, -1)
+    rgb = rgb.float()
+    if v.num_img > 1:
+        imgs = rgb.reshape(B, T, v.num_img, 3, H, W).permute(0, 2, 1, 3, 4, 5).reshape(B, v.num_img, T * 3, H, W)
+        feats = [spatial_emb_forward(p, c, vit_forward(p, v, imgs[:, i]), s) for i, c in enumerate(v.compress_names())]
+        feat = torch.cat(feats, dim=-1)
+    else:
+        feat = spatial_emb_forward(p, "compress", vit_forward(p, v, rgb.reshape(B, T * C, H, W)), s)
+    return torch.cat([feat, s], dim=-1)
+
+
+@dataclass
+class VisionSpec:
+    """A pixel network = encoder + trunk; travels where a NetSpec / UnetSpec does (``state`` is then the cond dict)."""
+
+    vis: VisSpec
+    trunk: object  # NetSpec ("actor" / "critic") or UnetSpec, on the observation vector cat[feat, state]
+    kind: str = "vision"
+
+    @property
+    def horizon_steps(self):
+        return self.trunk.horizon_steps
+
+    @property
+    def action_dim(self):
+        return self.trunk.action_dim
+
+    @property
+    def act_flat(self):
+        return self.trunk.act_flat
+
+
+def vision_spec(v: VisSpec, spec) -> VisionSpec:
+    return VisionSpec(v, vision_trunk_spec(v, spec))
+
+
+def vision_trunk_spec(v: VisSpec, spec):
+    """The denoiser / critic trunk behind the encoder: the same network on the observation vector cat[feat, state]
+    (mlp_diffusion.py:78-80,162-171; unet.py:398-400,581; critic.py:129-130,205-206)."""
+    import dataclasses
+    return dataclasses.replace(spec, cond_dim=v.feat_dim + v.prop_dim)
+
+
+def vision_init_params(v: VisSpec, spec, seed: int) -> Params:
+    """State dict of a VisionDiffusionMLP / VisionUnet1D / ViTCritic: encoder + trunk (``spec`` = vision_trunk_spec(...))."""
+    p = vis_init_params(v, seed)
+    p.update(unet_init_params(spec, seed + 7) if getattr(spec, "kind", "") == "unet" else init_params(spec, seed + 7))
+    return p
+
+
+def vision_actor_forward(p: Params, v: VisSpec, spec, x: torch.Tensor, t: torch.Tensor, cond: Dict[str, torch.Tensor]):
+    obs = vis_features(p, v, cond["rgb"], cond["state"])
+    return actor_forward(p, spec, x, t, obs.unsqueeze(1))
+
+
+def vit_critic_forward(p: Params, v: VisSpec, spec: NetSpec, cond: Dict[str, torch.Tensor]) -> torch.Tensor:
+    return critic_forward(p, spec, vis_features(p, v, cond["rgb"], cond["state"]).unsqueeze(1))
 
 
 # --------------------------------------------------------------------------

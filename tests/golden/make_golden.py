@@ -614,6 +614,186 @@ def g15_unet_dim40():
     save("g15_unet_dim40", **out)
 
 
+# ---------------------------------------------------------------- G16 / G17 pixel observations: ViT + SpatialEmb networks
+from make_golden_cases import (VIS_CHAIN_CASES, VIS_FWD_BATCH, VIS_LOSS_CASES, VIS_MSE_CASES, VIS_NETS,  # noqa: E402
+                               VIS_SPECS)
+
+
+def vis_net_specs(name):
+    """(VisSpec, trunk spec on cat[feat, state], critic trunk spec) of a VIS_NETS entry."""
+    vname, kind, kw = VIS_NETS[name]
+    v = O.VisSpec(**VIS_SPECS[vname])
+    cd = v.feat_dim + v.prop_dim
+    trunk = O.UnetSpec(cond_dim=cd, **kw) if kind == "unet" else O.NetSpec("actor", cond_dim=cd, residual=True, **kw)
+    critic = O.NetSpec("critic", cond_dim=cd, mlp_dims=[256, 256, 256], activation="Mish", residual=True)
+    return v, trunk, critic
+
+
+def ref_vit(v):
+    from dppo.model.common.vit import VitEncoder, VitEncoderConfig
+    cfg = VitEncoderConfig(patch_size=8, depth=v.depth, embed_dim=v.embed_dim, num_heads=v.num_heads, embed_style="embed2",
+                           embed_norm=0)
+    return VitEncoder([v.in_ch, v.img_h, v.img_w], cfg, num_channel=v.in_ch, img_h=v.img_h, img_w=v.img_w)
+
+
+def ref_vision_actor(v, trunk, params):
+    common = dict(backbone=ref_vit(v), action_dim=trunk.action_dim, cond_dim=v.prop_dim, img_cond_steps=v.in_ch // 3,
+                  spatial_emb=v.spatial_emb, num_img=v.num_img, augment=False)
+    if trunk.kind == "unet":
+        from dppo.model.diffusion.unet import VisionUnet1D
+        m = VisionUnet1D(diffusion_step_embed_dim=trunk.diffusion_step_embed_dim, dim=trunk.dim,
+                         dim_mults=list(trunk.dim_mults), smaller_encoder=trunk.smaller_encoder,
+                         kernel_size=trunk.kernel_size, n_groups=trunk.n_groups, activation_type=trunk.activation,
+                         cond_predict_scale=trunk.cond_predict_scale, groupnorm_eps=trunk.groupnorm_eps, **common)
+    else:
+        from dppo.model.diffusion.mlp_diffusion import VisionDiffusionMLP
+        m = VisionDiffusionMLP(horizon_steps=trunk.horizon_steps, time_dim=trunk.time_dim, mlp_dims=list(trunk.mlp_dims),
+                               activation_type=trunk.activation, residual_style=True, **common)
+    m.load_state_dict(params, strict=True)  # strict: the oracle's parameter list IS the reference's state dict
+    return m
+
+
+def ref_vit_critic(v, cspec, params):
+    from dppo.model.common.critic import ViTCritic
+    m = ViTCritic(backbone=ref_vit(v), cond_dim=v.prop_dim, img_cond_steps=v.in_ch // 3, spatial_emb=v.spatial_emb,
+                  num_img=v.num_img, augment=False, mlp_dims=list(cspec.mlp_dims), activation_type=cspec.activation,
+                  residual_style=True)
+    m.load_state_dict(params, strict=True)
+    return m
+
+
+def vis_inputs(rs, v, B):
+    """Images with three bits per byte (they compress), (B, img_cond_steps, 3 * num_img, H, W) uint8; state in [-1, 1]."""
+    T = v.in_ch // 3
+    rgb = (rs.randint(0, 8, size=(B, T, 3 * v.num_img, v.img_h, v.img_w)) * 36).astype(np.uint8)
+    state = rs.uniform(-1, 1, size=(B, 1, v.prop_dim)).astype(np.float32)
+    return rgb, state
+
+
+def vis_cond(rgb, state):
+    return {"rgb": torch.from_numpy(rgb), "state": torch.from_numpy(state)}
+
+
+def vision_model(name, seed, **kw):
+    v, trunk, cspec = vis_net_specs(name)
+    if kw.get("use_ddim"):
+        kw = dict(kw, eta=EtaFixed(base_eta=1.0))
+    actor = ref_vision_actor(v, trunk, O.vision_init_params(v, trunk, seed))
+    critic = ref_vit_critic(v, cspec, O.vision_init_params(v, cspec, seed + 2))
+    m = PPODiffusion(actor=actor, critic=critic, horizon_steps=trunk.horizon_steps, obs_dim=v.prop_dim,
+                     action_dim=trunk.action_dim, device="cpu", gamma_denoising=0.99, **dict(dict(randn_clip_value=3), **kw))
+    m.actor_ft.load_state_dict(O.vision_init_params(v, trunk, seed + 1), strict=True)
+    return m, v, trunk, cspec
+
+
+def g16_vision():
+    """VitEncoder.forward (model/common/vit.py:55-61), SpatialEmb.forward (modules.py:31-41), VisionDiffusionMLP /
+    VisionUnet1D / ViTCritic.forward (mlp_diffusion.py:101-171, unet.py:530-620, critic.py:159-206), and K-step chains +
+    log-probs of a PPODiffusion whose actor observes pixels."""
+    out = {}
+    rs = np.random.RandomState(1600)
+    for vname, kw in VIS_SPECS.items():
+        v = O.VisSpec(**kw)
+        p = O.vis_init_params(v, 61)
+        B = VIS_FWD_BATCH[vname]
+        rgb, state = vis_inputs(rs, v, B)
+        enc = ref_vit(v)
+        enc.load_state_dict({k[len("backbone."):]: t for k, t in p.items() if k.startswith("backbone.")}, strict=True)
+        from dppo.model.common.modules import SpatialEmb
+        img = torch.from_numpy(rgb).float()
+        if v.num_img > 1:
+            img = img.reshape(B, -1, v.num_img, 3, v.img_h, v.img_w).permute(0, 2, 1, 3, 4, 5).flatten(2, 3)[:, 0]
+        else:
+            img = img.flatten(1, 2)
+        with torch.no_grad():
+            feats = enc(img)
+            c = v.compress_names()[0]
+            se = SpatialEmb(num_patch=v.num_patch, patch_dim=v.embed_dim, prop_dim=v.prop_dim, proj_dim=v.spatial_emb, dropout=0)
+            se.load_state_dict({k[len(c) + 1:]: t for k, t in p.items() if k.startswith(c + ".")}, strict=True)
+            z = se(feats, torch.from_numpy(state).reshape(B, -1))
+        out.update({f"{vname}_rgb": rgb, f"{vname}_state": state, f"{vname}_feats0": feats[0], f"{vname}_z": z})
+    for name in VIS_NETS:
+        v, trunk, cspec = vis_net_specs(name)
+        B = 2 if v.img_h > 64 else 5
+        rgb, state = vis_inputs(rs, v, B)
+        net = ref_vision_actor(v, trunk, O.vision_init_params(v, trunk, 71))
+        cr = ref_vit_critic(v, cspec, O.vision_init_params(v, cspec, 73))
+        x = torch.from_numpy(rs.randn(B, trunk.horizon_steps, trunk.action_dim).astype(np.float32))
+        t = torch.from_numpy(rs.randint(0, 20, size=(B,)).astype(np.int64))
+        with torch.no_grad():
+            y = net(x, t, cond=vis_cond(rgb, state))
+            val = cr(vis_cond(rgb, state))
+        out.update({f"{name}_rgb": rgb, f"{name}_state": state, f"{name}_x": x, f"{name}_t": t, f"{name}_eps": y,
+                    f"{name}_value": val})
+    for cname, (name, B, kw, det) in VIS_CHAIN_CASES.items():
+        m, v, trunk, _ = vision_model(name, 21, clip_ploss_coef=0.01, **kw)
+        n_steps = kw["ddim_steps"] if kw.get("use_ddim") else kw["denoising_steps"]
+        rgb, state = vis_inputs(rs, v, B)
+        noise = torch.from_numpy(rs.randn(n_steps + 1, B, trunk.horizon_steps, trunk.action_dim).astype(np.float32))
+        with recorded_noise(list(noise)):
+            smp = m(cond=vis_cond(rgb, state), deterministic=det, return_chain=True)
+        with torch.no_grad():
+            lp = m.get_logprobs(vis_cond(rgb, state), smp.chains)
+        out.update({f"{cname}_rgb": rgb, f"{cname}_state": state, f"{cname}_noise": noise, f"{cname}_traj": smp.trajectories,
+                    f"{cname}_chains": smp.chains, f"{cname}_logprobs": lp})
+    save("g16_vision", **out)
+
+
+def g17_vision_loss():
+    """PPODiffusion.loss (diffusion_ppo.py:57-199) and the supervised loss (diffusion.py:325-349) with pixel networks: the
+    gradients reach the ViT and SpatialEmb parameters of the fine-tuned actor and of the critic."""
+    out = {}
+    rs = np.random.RandomState(1700)
+    for cname, (name, N, kw, rh) in VIS_LOSS_CASES.items():
+        m, v, trunk, cspec = vision_model(name, 31, **kw)
+        Kft = kw["ft_denoising_steps"]
+        n_steps = kw["ddim_steps"] if kw.get("use_ddim") else kw["denoising_steps"]
+        rgb, state = vis_inputs(rs, v, N)
+        cond = vis_cond(rgb, state)
+        Ta, Da = trunk.horizon_steps, trunk.action_dim
+        noise = torch.from_numpy(rs.randn(n_steps + 1, N, Ta, Da).astype(np.float32))
+        with recorded_noise(list(noise)):
+            chains = m(cond=cond, deterministic=False, return_chain=True).chains
+        kinds = torch.from_numpy(rs.randint(0, Kft, size=(N,)).astype(np.int64))
+        rows = torch.arange(N)
+        prev, nxt = chains[rows, kinds], chains[rows, kinds + 1]
+        with torch.no_grad():
+            oldlp_all = m.get_logprobs(cond, chains).reshape(N, Kft, Ta, Da)
+            oldlp = oldlp_all[rows, kinds] + torch.from_numpy(rs.normal(0, 0.02, size=(N, Ta, Da)).astype(np.float32))
+            oldv = m.critic(cond).view(-1) + torch.from_numpy(rs.normal(0, 0.3, N).astype(np.float32))
+        ret = torch.from_numpy(rs.normal(0, 1, N).astype(np.float32))
+        adv = torch.from_numpy(rs.normal(0.3, 2.0, N).astype(np.float32))
+        res = m.loss(cond, prev, nxt, kinds, ret, oldv, adv.clone(), oldlp, use_bc_loss=False, reward_horizon=rh)
+        (res[0] + 0.5 * res[2]).backward()
+        out.update({f"{cname}_rgb": rgb, f"{cname}_state": state, f"{cname}_prev": prev, f"{cname}_next": nxt,
+                    f"{cname}_kinds": kinds, f"{cname}_returns": ret, f"{cname}_oldvalues": oldv, f"{cname}_adv": adv,
+                    f"{cname}_oldlogprobs": oldlp, f"{cname}_reward_horizon": rh,
+                    f"{cname}_stats": np.array([res[0].item(), float(res[1]), res[2].item(), res[3], res[4], res[5],
+                                                float(res[6]), res[7]], dtype=np.float64)})
+        for k, p in m.actor_ft.named_parameters():
+            put_grad(out, f"{cname}_gactor_{k}", p.grad)
+        for k, p in m.critic.named_parameters():
+            put_grad(out, f"{cname}_gcritic_{k}", p.grad)
+    for cname, (name, K, N) in VIS_MSE_CASES.items():
+        m, v, trunk, _ = vision_model(name, 51, denoising_steps=K, ft_denoising_steps=min(10, K), clip_ploss_coef=0.01)
+        net = m.network
+        for p in net.parameters():
+            p.requires_grad_(True)
+        Ta, Da = trunk.horizon_steps, trunk.action_dim
+        x0 = torch.from_numpy(rs.uniform(-1, 1, size=(N, Ta, Da)).astype(np.float32))
+        rgb, state = vis_inputs(rs, v, N)
+        t = torch.from_numpy(rs.randint(0, K, size=(N,)).astype(np.int64))
+        noise = torch.from_numpy(rs.randn(N, Ta, Da).astype(np.float32))
+        with recorded_noise([noise]):
+            loss = m.p_losses(x0, vis_cond(rgb, state), t)
+        loss.backward()
+        out.update({f"{cname}_x0": x0, f"{cname}_rgb": rgb, f"{cname}_state": state, f"{cname}_t": t, f"{cname}_noise": noise,
+                    f"{cname}_loss": np.float64(loss.item())})
+        for k, p in net.named_parameters():
+            put_grad(out, f"{cname}_g_{k}", p.grad)
+    save("g17_vision_loss", **out)
+
+
 # ---------------------------------------------------------------- G10 LR schedule trace
 from make_golden_cases import SCHED_CASES  # noqa: E402
 
@@ -638,6 +818,7 @@ def g10_scheduler():
 
 if __name__ == "__main__":
     only = sys.argv[1:]  # e.g. `make_golden.py g8_bc` regenerates one file (each generator owns its RNG stream)
-    for fn in (g1_tables, g2_forward, g3_g4_chains, g5_loss, g6_reward_scaler, g7_adamw, g8_bc, g9_denoise_mse, g10_scheduler, g11_eval, g12_gaussian, g13_unet, g14_unet_loss, g15_unet_dim40):
+    for fn in (g1_tables, g2_forward, g3_g4_chains, g5_loss, g6_reward_scaler, g7_adamw, g8_bc, g9_denoise_mse, g10_scheduler, g11_eval, g12_gaussian, g13_unet, g14_unet_loss, g15_unet_dim40, g16_vision,
+               g17_vision_loss):
         if not only or fn.__name__ in only:
             fn()

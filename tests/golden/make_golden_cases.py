@@ -69,3 +69,42 @@ UNET40_LOSS_CASES = {"unet40_loss": ("unet_dim40", 32, dict(denoising_steps=20, 
                                                            clip_ploss_coef_base=0.001), 4),
                      "unet40_l3_loss": ("unet_dim40_l3", 16, dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01), 8)}
 UNET40_MSE_CASES = {"unet40_mse": ("unet_dim40", 20, 24)}
+
+# ---- pixel observations: ViT encoder + SpatialEmb (model/common/vit.py, modules.py) in front of either denoiser / the critic
+VIS_SPECS = {
+    # shipped robomimic image cfgs (cfg/robomimic/finetune/square/ft_ppo_diffusion_mlp_img.yaml:49-56,118-140): one 96x96 camera
+    "vis_square": dict(in_ch=3, img_h=96, img_w=96, prop_dim=9),
+    # small maps (16 patches) with a two-frame image history (img_cond_steps = 2 -> six input channels)
+    "vis_small": dict(in_ch=6, img_h=40, img_w=40, prop_dim=5),
+    # two cameras sharing the backbone, one SpatialEmb each (transport: .../transport/ft_ppo_diffusion_unet_img.yaml:52-59,140)
+    "vis_two": dict(in_ch=3, img_h=40, img_w=40, prop_dim=6, num_img=2),
+}
+# trunk behind the encoder: name -> (vis spec, kind, kwargs); cond_dim is filled in as feat_dim + prop_dim
+VIS_NETS = {
+    "vmlp_square": ("vis_square", "mlp", dict(mlp_dims=[768, 768, 768], activation="Mish", action_dim=7, horizon_steps=4, time_dim=32)),
+    "vmlp_small": ("vis_small", "mlp", dict(mlp_dims=[256, 256, 256], activation="Mish", action_dim=3, horizon_steps=4, time_dim=16)),
+    "vunet_small": ("vis_small", "unet", dict(action_dim=3, horizon_steps=4, diffusion_step_embed_dim=32, dim=64, dim_mults=(1, 2),
+                                               kernel_size=5, n_groups=8, smaller_encoder=False, cond_predict_scale=True)),
+    "vunet_two": ("vis_two", "unet", dict(action_dim=4, horizon_steps=8, diffusion_step_embed_dim=32, dim=64, dim_mults=(1, 2),
+                                           kernel_size=5, n_groups=8, smaller_encoder=False, cond_predict_scale=True)),
+}
+VIS_FWD_BATCH = {"vis_square": 2, "vis_small": 6, "vis_two": 5}
+VIS_CHAIN_CASES = {
+    # name: (net, B, model kwargs, deterministic)
+    "vmlp_ddim100_5": ("vmlp_small", 5, dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
+                                            randn_clip_value=3, min_sampling_denoising_std=0.1), False),
+    "vunet_ddim100_5": ("vunet_small", 4, dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
+                                              randn_clip_value=3, min_sampling_denoising_std=0.1), False),
+    "vunet_two_ddpm20_ft10": ("vunet_two", 3, dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3), False),
+}
+VIS_LOSS_CASES = {
+    # name: (net, N, model kwargs, reward_horizon)
+    "vmlp_loss": ("vmlp_small", 24, dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
+                                        clip_ploss_coef=0.01, clip_ploss_coef_base=0.001, min_sampling_denoising_std=0.1), 4),
+    "vunet_loss": ("vunet_small", 16, dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
+                                          clip_ploss_coef=0.01, clip_ploss_coef_base=0.001, min_sampling_denoising_std=0.1), 4),
+    "vunet_two_loss": ("vunet_two", 12, dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01, clip_vloss_coef=0.2), 8),
+    "vmlp_square_loss": ("vmlp_square", 6, dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
+                                               clip_ploss_coef=0.01, clip_ploss_coef_base=0.001, min_sampling_denoising_std=0.1), 4),
+}
+VIS_MSE_CASES = {"vmlp_mse": ("vmlp_small", 20, 16), "vunet_mse": ("vunet_small", 20, 12)}

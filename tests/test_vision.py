@@ -1,0 +1,109 @@
+"""Pixel observations (BASELINE configs[4]): ViT encoder + SpatialEmb in front of either denoiser and of
+the critic.  The oracle's restatement against the reference's golden vectors (CPU); the HIP path (dppo_vis_* and the *_obs
+loss entries through the C ABI) against the same vectors (GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dppo_oracle as O
+from tests.golden.make_golden_cases import (VIS_CHAIN_CASES, VIS_FWD_BATCH, VIS_LOSS_CASES, VIS_MSE_CASES, VIS_NETS,
+                                            VIS_SPECS)
+from tests.test_oracle_golden import check_grad, make_cfg
+
+T = torch.from_numpy
+
+
+def net_specs(name):
+    """(VisSpec, trunk spec on cat[feat, state], critic trunk spec) of a VIS_NETS entry (as tests/golden/make_golden.py)."""
+    vname, kind, kw = VIS_NETS[name]
+    v = O.VisSpec(**VIS_SPECS[vname])
+    cd = v.feat_dim + v.prop_dim
+    trunk = O.UnetSpec(cond_dim=cd, **kw) if kind == "unet" else O.NetSpec("actor", cond_dim=cd, residual=True, **kw)
+    critic = O.NetSpec("critic", cond_dim=cd, mlp_dims=[256, 256, 256], activation="Mish", residual=True)
+    return v, trunk, critic
+
+
+def cond_of(g, key):
+    return {"rgb": T(g[f"{key}_rgb"]), "state": T(g[f"{key}_state"])}
+
+
+@pytest.mark.parametrize("vname", sorted(VIS_SPECS))
+def test_oracle_vit_and_spatial_emb(golden, vname):
+    g = golden("g16_vision")
+    v = O.VisSpec(**VIS_SPECS[vname])
+    p = O.vis_init_params(v, 61)
+    B = VIS_FWD_BATCH[vname]
+    img = T(g[f"{vname}_rgb"]).float()
+    if v.num_img > 1:
+        img = img.reshape(B, -1, v.num_img, 3, v.img_h, v.img_w).permute(0, 2, 1, 3, 4, 5).flatten(2, 3)[:, 0]
+    else:
+        img = img.flatten(1, 2)
+    with torch.no_grad():
+        feats = O.vit_forward(p, v, img)
+        z = O.spatial_emb_forward(p, v.compress_names()[0], feats, T(g[f"{vname}_state"]).reshape(B, -1))
+    assert feats.shape == (B, v.num_patch, v.embed_dim)
+    np.testing.assert_allclose(feats[0].numpy(), g[f"{vname}_feats0"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(z.numpy(), g[f"{vname}_z"], rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("name", sorted(VIS_NETS))
+def test_oracle_vision_networks_forward(golden, name):
+    g = golden("g16_vision")
+    v, trunk, cspec = net_specs(name)
+    pa, pc = O.vision_init_params(v, trunk, 71), O.vision_init_params(v, cspec, 73)
+    with torch.no_grad():
+        eps = O.vision_actor_forward(pa, v, trunk, T(g[f"{name}_x"]), T(g[f"{name}_t"]), cond_of(g, name))
+        val = O.vit_critic_forward(pc, v, cspec, cond_of(g, name))
+    np.testing.assert_allclose(eps.numpy(), g[f"{name}_eps"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(val.numpy(), g[f"{name}_value"], rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("case", sorted(VIS_CHAIN_CASES))
+def test_oracle_vision_chains_and_logprobs(golden, case):
+    g = golden("g16_vision")
+    name, B, kw, det = VIS_CHAIN_CASES[case]
+    v, trunk, _ = net_specs(name)
+    spec = O.VisionSpec(v, trunk)
+    cfg = make_cfg(trunk, dict(kw))
+    base, ft = O.vision_init_params(v, trunk, 21), O.vision_init_params(v, trunk, 22)
+    traj, chains = O.sample_chain(cfg, spec, base, ft, cond_of(g, case), T(g[f"{case}_noise"]), deterministic=det)
+    np.testing.assert_allclose(chains.numpy(), g[f"{case}_chains"], rtol=3e-4, atol=3e-4)
+    np.testing.assert_allclose(traj.numpy(), g[f"{case}_traj"], rtol=3e-4, atol=3e-4)
+    with torch.no_grad():
+        lp = O.chain_logprob(cfg, spec, base, ft, cond_of(g, case), T(g[f"{case}_chains"]))
+    np.testing.assert_allclose(lp.numpy(), g[f"{case}_logprobs"], rtol=3e-4, atol=3e-4)
+
+
+@pytest.mark.parametrize("case", sorted(VIS_LOSS_CASES))
+def test_oracle_vision_ppo_loss_and_grads(golden, case):
+    g = golden("g17_vision_loss")
+    name, N, kw, rh = VIS_LOSS_CASES[case]
+    v, trunk, cspec = net_specs(name)
+    cfg = make_cfg(trunk, dict(kw, gamma_denoising=0.99, randn_clip_value=3))
+    base = O.vision_init_params(v, trunk, 31)
+    ft = {k: t.clone().requires_grad_(True) for k, t in O.vision_init_params(v, trunk, 32).items()}
+    cr = {k: t.clone().requires_grad_(True) for k, t in O.vision_init_params(v, cspec, 33).items()}
+    d = lambda k: T(g[f"{case}_{k}"])
+    res = O.ppo_loss(cfg, O.VisionSpec(v, trunk), O.VisionSpec(v, cspec), base, ft, cr, cond_of(g, case), d("prev"), d("next"),
+                     d("kinds"), d("returns"), d("oldvalues"), d("adv"), d("oldlogprobs"), reward_horizon=rh)
+    got = np.array([res[0].item(), float(res[1]), res[2].item(), res[3], res[4], res[5], float(res[6]), res[7]])
+    np.testing.assert_allclose(got, g[f"{case}_stats"], rtol=1e-4, atol=1e-5)
+    (res[0] + 0.5 * res[2]).backward()
+    for k, p in ft.items():
+        check_grad(g, f"{case}_gactor_{k}", p.grad if p.grad is not None else torch.zeros_like(p), rtol=5e-3, atol=5e-6)
+    for k, p in cr.items():
+        check_grad(g, f"{case}_gcritic_{k}", p.grad, rtol=2e-3, atol=2e-6)
+
+
+@pytest.mark.parametrize("case", sorted(VIS_MSE_CASES))
+def test_oracle_vision_denoise_mse(golden, case):
+    g = golden("g17_vision_loss")
+    name, K, N = VIS_MSE_CASES[case]
+    v, trunk, _ = net_specs(name)
+    prm = {k: t.clone().requires_grad_(True) for k, t in O.vision_init_params(v, trunk, 51).items()}
+    d = lambda k: T(g[f"{case}_{k}"])
+    loss = O.denoise_mse_loss(K, O.VisionSpec(v, trunk), prm, d("x0"), cond_of(g, case), d("t"), d("noise"))
+    assert float(loss.detach()) == pytest.approx(float(g[f"{case}_loss"]), rel=2e-5)
+    loss.backward()
+    for k, t in prm.items():
+        check_grad(g, f"{case}_g_{k}", t.grad if t.grad is not None else torch.zeros_like(t), 5e-3, 2e-6)
