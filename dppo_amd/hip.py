@@ -70,6 +70,12 @@ class UnetDesc(C.Structure):  # struct dppo_unet_desc
                 ("n_groups", C.c_int32), ("larger_encoder", C.c_int32), ("cond_predict_scale", C.c_int32),
                 ("act", C.c_int32), ("groupnorm_eps", C.c_float)]
 
+class VisDesc(C.Structure):  # struct dppo_vis_desc
+    _fields_ = [("in_ch", C.c_int32), ("img_h", C.c_int32), ("img_w", C.c_int32), ("embed_dim", C.c_int32),
+                ("num_heads", C.c_int32), ("depth", C.c_int32), ("embed_norm", C.c_int32), ("prop_dim", C.c_int32),
+                ("spatial_emb", C.c_int32), ("num_img", C.c_int32)]
+
+
 # numpy mirror of `dppo_step` (40 bytes) so schedules are built vectorised on the host
 STEP_DTYPE = np.dtype([("net", "<i4"), ("t", "<i4"), ("chain_slot", "<i4"), ("final_clip", "<i4"),
                        ("c0", "<f4"), ("c1", "<f4"), ("c2", "<f4"), ("c3", "<f4"), ("std", "<f4"), ("pad", "<f4")])
@@ -108,6 +114,12 @@ SYMBOLS = {
                                             _P, _L, _P, _P, _P, _P, _P, _P, _L, _P]),
     "dppo_unet_param_count": (_L, [C.POINTER(UnetDesc)]),
     "dppo_unet_packed_bytes": (_L, [C.POINTER(UnetDesc), _I, _I]),
+    "dppo_vis_param_count": (_L, [C.POINTER(VisDesc)]),
+    "dppo_vis_packed_bytes": (_L, [C.POINTER(VisDesc), _I]),
+    "dppo_vis_pack": (_I, [C.POINTER(VisDesc), _I, _P, _P, _P]),
+    "dppo_vis_workspace_bytes": (_L, [C.POINTER(VisDesc), _I, _L, _I]),
+    "dppo_vis_encode": (_I, [C.POINTER(VisDesc), _I, _P, _P, _P, _I, _P, _L, _P, _I, _I, _P, _L, _P]),
+    "dppo_vis_backward": (_I, [C.POINTER(VisDesc), _I, _P, _P, _P, _I, _L, _P, _P, _L, _P]),
     "dppo_unet_pack": (_I, [C.POINTER(UnetDesc), _I, _I, _P, _P, _P]),
     "dppo_unet_workspace_bytes": (_L, [C.POINTER(UnetDesc), _I, _L]),
     "dppo_unet_forward": (_I, [C.POINTER(UnetDesc), _I, _P, _P, _P, _P, _P, _L, _P, _P, _L, _P]),

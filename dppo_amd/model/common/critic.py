@@ -8,6 +8,7 @@ import torch
 
 from dppo_amd import hip
 from dppo_amd.model.common.mlp import HipNet, ResidualMLP
+from dppo_amd.model.common.vit import VisionMixin
 
 
 class CriticObs(HipNet):
@@ -51,3 +52,20 @@ class CriticObs(HipNet):
                                           out.data_ptr(), ws.data_ptr(), ws.numel(), hip.stream()),
                   "dppo_critic_forward")
         return out.view(B, 1)
+
+
+class ViTCritic(VisionMixin, CriticObs):
+    """ViT backbone + SpatialEmb, then the state-value MLP on cat[feat, state].  Mirrors
+    ``dppo/model/common/critic.py:116-206`` (Q1 is registered before the backbone there too)."""
+
+    def __init__(self, backbone, cond_dim, img_cond_steps=1, spatial_emb=128, dropout=0, augment=False, num_img=1,
+                 precision="bf16", **kwargs):
+        CriticObs.__init__(self, cond_dim=spatial_emb * num_img + cond_dim, precision=precision, **kwargs)
+        self._init_vision(backbone, cond_dim, img_cond_steps, spatial_emb, num_img, augment, dropout, precision)
+
+    def trunk_parameters(self):
+        return list(self.Q1.parameters())
+
+    @torch.no_grad()
+    def forward(self, cond, no_augment=False):
+        return CriticObs.forward(self, self.encode_obs(cond, augment=self.augment and not no_augment))

@@ -87,7 +87,7 @@ class HipNet(nn.Module):
         nn.Module.__init__(new)
         import copy
         for k, v in self.__dict__.items():
-            if k in ("_flat", "_flat_grad", "_packed", "_epoch", "_plist", "_last_off", "_desc_cache", "_packed_bytes"):
+            if k in ("_flat", "_flat_grad", "_packed", "_epoch", "_plist", "_last_off", "_desc_cache", "_packed_bytes", "_vis"):
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         object.__setattr__(new, "_flat", None)

@@ -8,6 +8,7 @@ from torch import nn
 
 from dppo_amd import hip
 from dppo_amd.model.common.mlp import HipNet, ResidualMLP
+from dppo_amd.model.common.vit import VisionMixin
 
 
 class _NoParams(nn.Module):
@@ -87,3 +88,27 @@ class DiffusionMLP(HipNet):
                                          t.data_ptr(), state.data_ptr(), B, out.data_ptr(), ws.data_ptr(), ws.numel(),
                                          hip.stream()), "dppo_actor_forward")
         return out.view(B, Ta, Da)
+
+
+class VisionDiffusionMLP(VisionMixin, DiffusionMLP):
+    """ViT backbone + SpatialEmb, then DiffusionMLP on cat[x, time_emb, feat, state].  Mirrors
+    ``dppo/model/diffusion/mlp_diffusion.py:19-171``: the trunk is a DiffusionMLP whose observation vector is
+    cat[feat, state] (same column order: :162-167), so every kernel of the state-observation path serves it."""
+
+    def __init__(self, backbone, action_dim, horizon_steps, cond_dim, img_cond_steps=1, time_dim=16, mlp_dims=[256, 256],
+                 activation_type="Mish", out_activation_type="Identity", use_layernorm=False, residual_style=False,
+                 spatial_emb=0, visual_feature_dim=128, dropout=0, num_img=1, augment=False, precision="bf16"):
+        vis_dim = spatial_emb * num_img
+        DiffusionMLP.__init__(self, action_dim, horizon_steps, cond_dim + vis_dim, time_dim=time_dim, mlp_dims=mlp_dims,
+                              activation_type=activation_type, out_activation_type=out_activation_type,
+                              use_layernorm=use_layernorm, residual_style=residual_style, precision=precision)
+        self._init_vision(backbone, cond_dim, img_cond_steps, spatial_emb, num_img, augment, dropout, precision)
+        self._vision_modules_first("backbone", "compress", "compress1", "compress2")
+
+    def trunk_parameters(self):
+        skip = self._vision_parameter_ids()
+        return [p for p in self.parameters() if id(p) not in skip]
+
+    @torch.no_grad()
+    def forward(self, x, time, cond, **kwargs):
+        return DiffusionMLP.forward(self, x, time, {"state": self.encode_obs(cond)})

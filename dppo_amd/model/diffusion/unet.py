@@ -17,6 +17,7 @@ import torch
 from torch import nn
 
 from dppo_amd import hip
+from dppo_amd.model.common.vit import VisionMixin
 from dppo_amd.model.common.mlp import SUPPORTED_ACT, HipNet
 
 
@@ -160,3 +161,28 @@ class Unet1D(HipNet):
             xf.data_ptr(), t.data_ptr(), state.data_ptr(), B, out.data_ptr(), ws.data_ptr(), ws.numel(), hip.stream()),
             "dppo_unet_forward")
         return out
+
+
+class VisionUnet1D(VisionMixin, Unet1D):
+    """ViT backbone + SpatialEmb, then Unet1D conditioned on cat[time_emb, feat, state].  Mirrors
+    ``dppo/model/diffusion/unet.py:330-620`` (same column order: :581-593)."""
+
+    def __init__(self, backbone, action_dim, img_cond_steps=1, cond_dim=None, diffusion_step_embed_dim=32, dim=32,
+                 dim_mults=(1, 2, 4, 8), smaller_encoder=False, cond_mlp_dims=None, kernel_size=5, n_groups=None,
+                 activation_type="Mish", cond_predict_scale=False, groupnorm_eps=1e-5, spatial_emb=0, dropout=0, num_img=1,
+                 augment=False, horizon_steps=None, precision="bf16"):
+        Unet1D.__init__(self, action_dim, cond_dim=cond_dim + spatial_emb * num_img,
+                        diffusion_step_embed_dim=diffusion_step_embed_dim, dim=dim, dim_mults=dim_mults,
+                        smaller_encoder=smaller_encoder, cond_mlp_dims=cond_mlp_dims, kernel_size=kernel_size,
+                        n_groups=n_groups, activation_type=activation_type, cond_predict_scale=cond_predict_scale,
+                        groupnorm_eps=groupnorm_eps, horizon_steps=horizon_steps, precision=precision)
+        self._init_vision(backbone, cond_dim, img_cond_steps, spatial_emb, num_img, augment, dropout, precision)
+        self._vision_modules_first("backbone", "compress", "compress1", "compress2")
+
+    def trunk_parameters(self):
+        skip = self._vision_parameter_ids()
+        return [p for p in self.parameters() if id(p) not in skip]
+
+    @torch.no_grad()
+    def forward(self, x, time, cond, **kwargs):
+        return Unet1D.forward(self, x, time, {"state": self.encode_obs(cond)})

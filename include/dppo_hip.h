@@ -421,6 +421,42 @@ int dppo_gemm_nt_raw(int prec, const void* X, const void* W, const float* bias, 
 int dppo_gemm_tn_raw(int prec, const void* A, int lda, int N1, const void* B, int ldb, int N2, int64_t M,
                      int rows_per_split, float* slab, float* C, dppo_stream_t stream);
 
+/* ---- 8f row 2 (pixel observations): ViT patch encoder + SpatialEmb ------------------------------------------------
+ * Replaces model/common/vit.py:28-62 (VitEncoder: PatchEmbed2 = Conv2d(k8,s4) -> ReLU -> Conv2d(k3,s2), + pos_embed,
+ * `depth` pre-norm TransformerLayers, final LayerNorm) and model/common/modules.py:10-41 (SpatialEmb), assembled as
+ * VisionDiffusionMLP / VisionUnet1D / ViTCritic do (mlp_diffusion.py:120-160, unet.py:548-581, critic.py:177-205): the
+ * encoder turns cond = {rgb, state} into the observation vector cat[feat, state] of width spatial_emb * num_img + prop_dim,
+ * and the trunk behind it is the state-observation network on that vector (dppo_sample_chain, dppo_chain_logprob,
+ * dppo_unet_*, dppo_critic_forward take it as `obs`).  The feature does not depend on the denoising step: one encode per
+ * observation serves the whole K-step chain.  Training: dppo_vis_encode(train = 1) keeps its tape in the workspace, the
+ * *_obs loss entries below return d loss / d obs, dppo_vis_backward (same workspace) turns it into the encoder's gradients.
+ * Flat parameter order = the reference's state dict: backbone.vit.{pos_embed, patch_embed.embed.0, .3, net.l.{layer_norm1,
+ * mha.qkv_proj, mha.out_proj, layer_norm2, linear1, linear2}, norm}, then compress (or compress1, compress2).{weight,
+ * input_proj.0, input_proj.1}.  Not built: embed_style "embed1", embed_norm, the Linear `compress` of spatial_emb = 0,
+ * RandomShiftsAug inside the network (the host-side augmentation of dppo_amd shifts the images before the call). */
+typedef struct dppo_vis_desc {
+  int32_t in_ch;           /* 3 * img_cond_steps, per camera                                  */
+  int32_t img_h, img_w;
+  int32_t embed_dim, num_heads, depth;
+  int32_t embed_norm;      /* must be 0                                                        */
+  int32_t prop_dim;        /* To*Do of the low-dimensional state                               */
+  int32_t spatial_emb;     /* SpatialEmb proj_dim                                              */
+  int32_t num_img;         /* cameras: 1, or 2 sharing the backbone with one SpatialEmb each   */
+} dppo_vis_desc;
+int64_t dppo_vis_param_count(const dppo_vis_desc* net);
+int64_t dppo_vis_packed_bytes(const dppo_vis_desc* net, int prec);
+int dppo_vis_pack(const dppo_vis_desc* net, int prec, const float* params, void* packed, dppo_stream_t stream);
+int64_t dppo_vis_workspace_bytes(const dppo_vis_desc* net, int prec, int64_t B, int train);
+/* rgb: the reference's cond["rgb"], (B, img_cond_steps, 3 * num_img, H, W), fp32 or (rgb_u8 != 0) uint8, values 0..255;
+ * state (B, prop_dim); obs (B, ld_obs) <- cat[feat, state]. */
+int dppo_vis_encode(const dppo_vis_desc* net, int prec, const float* params, const void* packed, const void* rgb, int rgb_u8,
+                    const float* state, int64_t B, float* obs, int ld_obs, int train, void* workspace,
+                    int64_t workspace_bytes, dppo_stream_t stream);
+/* d_obs (B, ld_dobs): d loss / d obs (its first spatial_emb * num_img columns are read).  grad: flat, OVERWRITTEN.
+ * `workspace` must be the one the matching dppo_vis_encode(train = 1) call on the same B wrote. */
+int dppo_vis_backward(const dppo_vis_desc* net, int prec, const float* params, const void* packed, const float* d_obs,
+                      int ld_dobs, int64_t B, float* grad, void* workspace, int64_t workspace_bytes, dppo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,3 +107,93 @@ def test_oracle_vision_denoise_mse(golden, case):
     loss.backward()
     for k, t in prm.items():
         check_grad(g, f"{case}_g_{k}", t.grad if t.grad is not None else torch.zeros_like(t), 5e-3, 2e-6)
+
+
+# ------------------------------------------------------------------ HIP path
+def hip_backbone(v, prec):
+    from dppo_amd.model.common.vit import VitEncoder, VitEncoderConfig
+    cfg = VitEncoderConfig(patch_size=8, depth=v.depth, embed_dim=v.embed_dim, num_heads=v.num_heads, embed_style="embed2",
+                           embed_norm=0)
+    return VitEncoder([v.in_ch, v.img_h, v.img_w], cfg, num_channel=v.in_ch, img_h=v.img_h, img_w=v.img_w)
+
+
+def hip_vision_actor(v, trunk, params, prec, dev="cuda:0"):
+    common = dict(backbone=hip_backbone(v, prec), action_dim=trunk.action_dim, cond_dim=v.prop_dim, img_cond_steps=v.in_ch // 3,
+                  spatial_emb=v.spatial_emb, num_img=v.num_img, augment=False, precision=prec)
+    if trunk.kind == "unet":
+        from dppo_amd.model.diffusion.unet import VisionUnet1D
+        m = VisionUnet1D(diffusion_step_embed_dim=trunk.diffusion_step_embed_dim, dim=trunk.dim, dim_mults=list(trunk.dim_mults),
+                         smaller_encoder=trunk.smaller_encoder, kernel_size=trunk.kernel_size, n_groups=trunk.n_groups,
+                         activation_type=trunk.activation, cond_predict_scale=trunk.cond_predict_scale,
+                         groupnorm_eps=trunk.groupnorm_eps, horizon_steps=trunk.horizon_steps, **common)
+    else:
+        from dppo_amd.model.diffusion.mlp_diffusion import VisionDiffusionMLP
+        m = VisionDiffusionMLP(horizon_steps=trunk.horizon_steps, time_dim=trunk.time_dim, mlp_dims=list(trunk.mlp_dims),
+                               activation_type=trunk.activation, residual_style=True, **common)
+    m.load_state_dict(params, strict=True)
+    return m.to(dev)
+
+
+def hip_vit_critic(v, cspec, params, prec, dev="cuda:0"):
+    from dppo_amd.model.common.critic import ViTCritic
+    m = ViTCritic(backbone=hip_backbone(v, prec), cond_dim=v.prop_dim, img_cond_steps=v.in_ch // 3, spatial_emb=v.spatial_emb,
+                  num_img=v.num_img, augment=False, mlp_dims=list(cspec.mlp_dims), activation_type=cspec.activation,
+                  residual_style=True, precision=prec)
+    m.load_state_dict(params, strict=True)
+    return m.to(dev)
+
+
+def test_state_dict_names_and_order_match_the_reference():
+    for name in VIS_NETS:
+        v, trunk, cspec = net_specs(name)
+        pa, pc = O.vision_init_params(v, trunk, 1), O.vision_init_params(v, cspec, 2)
+        a = hip_vision_actor(v, trunk, pa, "fp32", dev="cpu")
+        c = hip_vit_critic(v, cspec, pc, "fp32", dev="cpu")
+        vis_names = [n for n, _, _ in O.vis_param_shapes(v)]
+        trunk_names = [n for n, _, _ in (O.unet_param_shapes(trunk) if trunk.kind == "unet" else O.param_shapes(trunk))]
+        assert list(a.state_dict()) == vis_names + trunk_names, name
+        assert list(c.state_dict()) == [n for n, _, _ in O.param_shapes(cspec)] + vis_names, name
+        # the encoder's flat buffer covers exactly the encoder's parameters, in that order
+        assert [id(p) for p in a.vis.trunk_parameters()] == [id(dict(a.named_parameters())[n]) for n in vis_names]
+        assert [id(p) for p in a.trunk_parameters()] == [id(dict(a.named_parameters())[n]) for n in trunk_names]
+
+
+def cuda_cond(g, key, u8=False):
+    rgb = T(g[f"{key}_rgb"]).cuda()
+    return {"rgb": rgb if u8 else rgb.float(), "state": T(g[f"{key}_state"]).cuda()}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,tol", [("fp32", 3e-4), ("bf16", 6e-2)])
+@pytest.mark.parametrize("vname", sorted(VIS_SPECS))
+def test_hip_visual_encoder(golden, vname, prec, tol):
+    """dppo_vis_encode against the reference's SpatialEmb output (the z of camera 1), from uint8 and from float images."""
+    g = golden("g16_vision")
+    v = O.VisSpec(**VIS_SPECS[vname])
+    trunk = O.NetSpec("critic", cond_dim=v.feat_dim + v.prop_dim, mlp_dims=[256, 256, 256], activation="Mish", residual=True)
+    p = O.vision_init_params(v, trunk, 61)  # seed 61: the encoder part is vis_init_params(v, 61), as the fixture's
+    if v.num_img == 2:  # the fixture's single SpatialEmb is compress1 here; compress2 gets the same weights
+        p.update({k.replace("compress1", "compress2"): t for k, t in p.items() if k.startswith("compress1")})
+    m = hip_vit_critic(v, trunk, p, prec)
+    ref = g[f"{vname}_z"]
+    scale = float(np.abs(ref).max())
+    for u8 in (True, False):
+        obs = m.encode_obs(cuda_cond(g, vname, u8)).cpu().numpy()
+        assert obs.shape == (ref.shape[0], v.feat_dim + v.prop_dim)
+        np.testing.assert_allclose(obs[:, :v.spatial_emb], ref, rtol=tol, atol=tol * scale)
+        np.testing.assert_array_equal(obs[:, v.feat_dim:], g[f"{vname}_state"].reshape(ref.shape[0], -1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,tol", [("fp32", 3e-4), ("bf16", 6e-2)])
+@pytest.mark.parametrize("name", sorted(VIS_NETS))
+def test_hip_vision_networks_forward(golden, name, prec, tol):
+    g = golden("g16_vision")
+    v, trunk, cspec = net_specs(name)
+    a = hip_vision_actor(v, trunk, O.vision_init_params(v, trunk, 71), prec)
+    c = hip_vit_critic(v, cspec, O.vision_init_params(v, cspec, 73), prec)
+    cond = cuda_cond(g, name, u8=True)
+    eps = a(T(g[f"{name}_x"]).cuda(), T(g[f"{name}_t"]).cuda(), cond).cpu().numpy()
+    val = c(cond).cpu().numpy()
+    np.testing.assert_allclose(eps, g[f"{name}_eps"], rtol=tol, atol=tol * float(np.abs(g[f"{name}_eps"]).max()))
+    np.testing.assert_allclose(val, g[f"{name}_value"], rtol=tol, atol=tol * max(1.0, float(np.abs(g[f"{name}_value"]).max())))
