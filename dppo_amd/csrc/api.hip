@@ -326,6 +326,8 @@ struct MlpBufs {  // activations of one network for M rows
   void* dz1_all[MAX_BLOCKS];
   float* ln_stats;               // [nb][2][M][2] LayerNorm row statistics (training)
   const void* dh0_final;         // where the last backward left d loss / d h_0
+  void* w0T;                     // [cond_dim][H] elem: layer 0's observation columns, transposed (obs_grad)
+  float* dobs;                   // [M][round_up(cond_dim, 16)]: obs_grad's GEMM output (the epilogue stores 16-column groups)
   float* tile_colsum;            // [(2nb+1)][tiles][H]
   int tiles;
   float* slab;  // split-M partial weight gradients: a pool, one sub-slab per pending weight-gradient GEMM
@@ -409,6 +411,8 @@ static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, b
     B.lowrank = (float*)c.take((size_t)round_up(d.out_dim, 16) * H * 4);
     B.post_counter = (double*)c.take(8);
     B.post_zeroed = false;
+    B.w0T = c.take((size_t)round_up(d.cond_dim > 0 ? d.cond_dim : 1, 16) * H * ES);
+    B.dobs = (float*)c.take((size_t)M * round_up(d.cond_dim > 0 ? d.cond_dim : 1, 16) * 4);
   }
 }
 
@@ -831,6 +835,23 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
   B.dh0_final = B.dh;
 }
 
+// d loss / d observation of a trunk WITHOUT an observation encoder: d_obs[m][c] = sum_h dh0[m][h] W0[h][col0 + c], where the
+// observation sits in layer 0's input at columns col0 = act_flat + time_dim (actor: cat[x, temb, obs]) or 0 (critic).  What a
+// visual encoder in front of the trunk (vision.hip) back-propagates from.  One transposing pack of cond_dim x H weights
+// + one gemm_nt.
+template <class P>
+static void obs_grad(const dppo_net_desc& d, const float* prm, int64_t M, MlpBufs<P>& B, float* d_obs, hipStream_t s) {
+  const ParamLayout pl = param_layout(d);
+  const int H = d.hidden, col0 = d.kind == 0 ? d.act_flat + d.time_dim : 0;
+  launch_transpose_cast<P>(prm + pl.W0, H, d.cond_dim, d.in_dim, col0, B.w0T, H, s);
+  GemmNT g;
+  memset(&g, 0, sizeof(g));
+  g.M = (int)M, g.N = d.cond_dim, g.Kp = H, g.ldx = H, g.ldw = H, g.X = B.dh0_final, g.W = B.w0T;
+  g.out_f32 = B.dobs, g.ldo32 = round_up(d.cond_dim, 16);
+  launch_gemm_nt<P>(g, s);
+  launch_copy_cols(B.dobs, g.ldo32, 0, d.cond_dim, M, d_obs, s);
+}
+
 // ------------------------------------------------------------------------------------------------
 // exported functions
 // ------------------------------------------------------------------------------------------------
@@ -1208,7 +1229,7 @@ int64_t dppo_denoise_mse_workspace_bytes(const dppo_net_desc* actor, int prec, i
 template <class P>
 static int mse_impl(const dppo_net_desc& d, const float* prm, const char* pk, const dppo_step* tsteps, int n_time,
                     const float* obs, const float* pairs, const int64_t* kinds, int64_t M, float* grad, double* loss,
-                    void* ws, int64_t wsb, hipStream_t s) {
+                    void* ws, int64_t wsb, hipStream_t s, float* d_obs = nullptr) {
   Carver c{(char*)ws, 0, (size_t)wsb};
   MlpBufs<P> B;
   int32_t *brow, *krow;
@@ -1231,15 +1252,17 @@ static int mse_impl(const dppo_net_desc& d, const float* prm, const char* pk, co
   launch_mse_loss<P>(ma, s);
   mlp_backward<P>(d, prm, pk, L, M, B, grad, krow, tsteps, n_time, s, false);
   if (d.cond_hidden > 0) cond_backward<P>(d, prm, pk, L, M, B, B.dh0_final, B.cin, grad, s);
+  if (d_obs) obs_grad<P>(d, prm, M, B, d_obs, s);
   return check_launch();
 }
-int dppo_denoise_mse_fwd_bwd(const dppo_net_desc* actor, int prec, const float* params, const void* packed,
+static int mse_entry(const dppo_net_desc* actor, int prec, const float* params, const void* packed,
                              const dppo_step* tsteps, int n_time, const float* obs, const float* pairs,
                              const int64_t* kinds, int64_t N, float* grad, double* loss, void* workspace,
-                             int64_t workspace_bytes, dppo_stream_t stream) {
+                             int64_t workspace_bytes, dppo_stream_t stream, float* d_obs) {
   if (int e = check_net(actor)) return e;
   if (int e = check_prec(prec)) return e;
   if (actor->kind != 0) return fail(-1, "dppo_denoise_mse_fwd_bwd needs an actor descriptor");
+  if (d_obs && actor->cond_hidden > 0) return fail(-1, "d_obs with a cond_mlp actor is not built");
   if (!params || !packed || !tsteps || !obs || !pairs || !kinds || !grad || !loss || !workspace)
     return fail(-1, "null pointer");
   if (N < 1 || N > 0x7fffffff || n_time < 1 || n_time > 1024) return fail(-1, "N / n_time out of range");
@@ -1247,9 +1270,24 @@ int dppo_denoise_mse_fwd_bwd(const dppo_net_desc* actor, int prec, const float* 
     return fail(-1, "n_time * time_dim = %d too large for the time-embedding backward (LDS)", n_time * actor->time_dim);
 #define CALL(P)                                                                                                        \
   mse_impl<P>(*actor, params, (const char*)packed, tsteps, n_time, obs, pairs, kinds, N, grad, loss, workspace, \
-              workspace_bytes, (hipStream_t)stream)
+              workspace_bytes, (hipStream_t)stream, d_obs)
   return DPPO_DISPATCH(prec, CALL);
 #undef CALL
+}
+int dppo_denoise_mse_fwd_bwd(const dppo_net_desc* actor, int prec, const float* params, const void* packed,
+                             const dppo_step* tsteps, int n_time, const float* obs, const float* pairs,
+                             const int64_t* kinds, int64_t N, float* grad, double* loss, void* workspace,
+                             int64_t workspace_bytes, dppo_stream_t stream) {
+  return mse_entry(actor, prec, params, packed, tsteps, n_time, obs, pairs, kinds, N, grad, loss, workspace, workspace_bytes,
+                   stream, nullptr);
+}
+int dppo_denoise_mse_fwd_bwd_obs(const dppo_net_desc* actor, int prec, const float* params, const void* packed,
+                                 const dppo_step* tsteps, int n_time, const float* obs, const float* pairs,
+                                 const int64_t* kinds, int64_t N, float* grad, double* loss, void* workspace,
+                                 int64_t workspace_bytes, dppo_stream_t stream, float* d_obs) {
+  if (!d_obs) return fail(-1, "null pointer");
+  return mse_entry(actor, prec, params, packed, tsteps, n_time, obs, pairs, kinds, N, grad, loss, workspace, workspace_bytes,
+                   stream, d_obs);
 }
 
 // ---- GAE ---------------------------------------------------------------------------------------------
@@ -1306,7 +1344,8 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
                     const char* ck, const dppo_diffusion_cfg& dcfg, const dppo_ppo_cfg& pcfg, const dppo_step* ksteps,
                     const float* obs_k, const float* chains_k, const float* returns_k, const float* values_k,
                     const float* adv_k, const float* logprobs_k, const int64_t* inds, const int64_t* kinds, int64_t N,
-                    const double* gmom, float* agrad, float* cgrad, double* stats, void* ws, int64_t wsb, hipStream_t s) {
+                    const double* gmom, float* agrad, float* cgrad, double* stats, void* ws, int64_t wsb, hipStream_t s,
+                    const dppo_obs_io* oio = nullptr) {
   Carver c{(char*)ws, 0, (size_t)wsb};
   PpoWs<P> W;
   const size_t need = carve_ppo<P>(c, a, cr, N, W);
@@ -1331,11 +1370,14 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   br.inA = W.A.in, br.KpA = LA.Kp0, br.inC = W.C.in, br.KpC = LC.Kp0, br.brow = W.brow, br.krow = W.krow;
   br.obs_in_a = a.cond_hidden > 0 ? 0 : 1;  // with cond_mlp the encoder fills the state columns (from the critic's obs rows)
   br.onehot0 = temb_onehot_col<P>(a, LA, Kft, W.A);
-  const bool split = s2 != s;
+  const float* obs_c = oio && oio->obs_critic ? oio->obs_critic : nullptr;  // the critic's own observation rows (pixel nets)
+  const bool split = s2 != s || obs_c != nullptr;
   if (split) {
     BuildRows bc = br;  // critic rows only, on the critic's stream
     bc.zero_a = bc.zero_b = nullptr, bc.n_zero_a = bc.n_zero_b = 0, bc.loss_tab = nullptr;
     bc.inA = nullptr, bc.brow = W.brow_c, bc.krow = nullptr;
+    if (obs_c) bc.obs = obs_c;
+    bc.cond = cr.cond_dim;
     launch_build_rows<P>(bc, s2);
     br.inC = nullptr;
   }
@@ -1374,37 +1416,50 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
     // (no tail stream of its own: a fork from a forked stream crashes hipGraph capture on ROCm 7.0 at capture end, and
     // the critic's tail is one 10-us reduction)
     mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s2, fuse_bout, -1, &lv);
+    if (oio && oio->d_obs_critic) obs_grad<P>(cr, cp, N, W.C, oio->d_obs_critic, s2);
   }
   // actor half
   if (!actor_first) mlp_forward<P>(a, ap, ak, LA, N, W.A, true, s);
   la.part = two_streams ? 1 : 3, la.partial = W.loss_partial;
   launch_ppo_loss<P>(la, s);
-  if (!two_streams) mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s, fuse_bout, -1);
+  if (!two_streams) {
+    mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s, fuse_bout, -1);
+    if (oio && oio->d_obs_critic) obs_grad<P>(cr, cp, N, W.C, oio->d_obs_critic, s);
+  }
   if (two_streams && g_early_join) W.A.join_s[W.A.n_join] = s2, W.A.join_idx[W.A.n_join++] = 0;
   mlp_backward<P>(a, ap, ak, LA, N, W.A, agrad, W.krow, ksteps, Kft, s, fuse_bout, 1, &la);
   if (a.cond_hidden > 0) cond_backward<P>(a, ap, ak, LA, N, W.A, W.A.dh0_final, W.C.in, agrad, s);
+  if (oio && oio->d_obs_actor) obs_grad<P>(a, ap, N, W.A, oio->d_obs_actor, s);
   if (!(two_streams && g_early_join) || W.A.n_join > 0) join_side(s, s2);  // (n_join > 0: the backward never flushed)
   W.A.n_join = 0;
   return check_launch();
 }
 
-int dppo_ppo_loss_fwd_bwd(const dppo_net_desc* actor, const dppo_net_desc* critic, int prec, const float* actor_params,
+static int check_obs_io(const dppo_obs_io* io, const int64_t* kinds, bool actor_has_encoder) {
+  if (!io) return 0;
+  if (kinds == nullptr) return fail(-1, "the _obs entries take pre-gathered samples (kinds), one observation row per sample");
+  if (actor_has_encoder && (io->obs_critic || io->d_obs_actor)) return fail(-1, "d_obs / obs_critic with a cond_mlp actor is not built");
+  return 0;
+}
+static int ppo_entry(const dppo_net_desc* actor, const dppo_net_desc* critic, int prec, const float* actor_params,
                           const void* actor_packed, const float* critic_params, const void* critic_packed,
                           const dppo_diffusion_cfg* dcfg, const dppo_ppo_cfg* pcfg, const dppo_step* ksteps,
                           const float* obs_k, const float* chains_k, const float* returns_k, const float* values_k,
                           const float* adv_k, const float* logprobs_k, const int64_t* inds, const int64_t* kinds,
                           int64_t N, const double* global_moments, float* actor_grad, float* critic_grad,
-                          double* stats, void* workspace, int64_t workspace_bytes, dppo_stream_t stream) {
+                          double* stats, void* workspace, int64_t workspace_bytes, dppo_stream_t stream, const dppo_obs_io* io) {
   if (int e = check_net(actor)) return e;
   if (int e = check_net(critic)) return e;
   if (int e = check_prec(prec)) return e;
   if (actor->kind != 0 || critic->kind != 1 || critic->out_dim != 1)
     return fail(-1, "descriptor kinds must be (actor, critic with out_dim 1)");
-  if (actor->cond_dim != critic->cond_dim) return fail(-1, "actor and critic observe different cond_dim");
+  if (actor->cond_dim != critic->cond_dim && !(io && io->obs_critic))
+    return fail(-1, "actor and critic observe different cond_dim");
   if (!actor_params || !actor_packed || !critic_params || !critic_packed || !dcfg || !pcfg || !ksteps || !obs_k ||
       !chains_k || !returns_k || !values_k || !adv_k || !logprobs_k || !actor_grad || !critic_grad || !stats ||
       !workspace)
     return fail(-1, "null pointer");
+  if (int e = check_obs_io(io, kinds, actor->cond_hidden > 0)) return e;
   if ((inds == nullptr) == (kinds == nullptr)) return fail(-1, "pass exactly one of inds (rollout mode) / kinds (gathered mode)");
   if (N < 2 || N > 0x7fffffff) return fail(-1, "N out of range");
   if (pcfg->ft_denoising_steps < 1 || pcfg->ft_denoising_steps > 1024) return fail(-1, "Kft out of range");
@@ -1416,9 +1471,32 @@ int dppo_ppo_loss_fwd_bwd(const dppo_net_desc* actor, const dppo_net_desc* criti
 #define CALL(P)                                                                                                        \
   ppo_impl<P>(*actor, *critic, actor_params, (const char*)actor_packed, critic_params, (const char*)critic_packed, *dcfg,     \
               *pcfg, ksteps, obs_k, chains_k, returns_k, values_k, adv_k, logprobs_k, inds, kinds, N, global_moments, actor_grad, critic_grad, stats, \
-              workspace, workspace_bytes, (hipStream_t)stream)
+              workspace, workspace_bytes, (hipStream_t)stream, io)
   return DPPO_DISPATCH(prec, CALL);
 #undef CALL
+}
+int dppo_ppo_loss_fwd_bwd(const dppo_net_desc* actor, const dppo_net_desc* critic, int prec, const float* actor_params,
+                          const void* actor_packed, const float* critic_params, const void* critic_packed,
+                          const dppo_diffusion_cfg* dcfg, const dppo_ppo_cfg* pcfg, const dppo_step* ksteps,
+                          const float* obs_k, const float* chains_k, const float* returns_k, const float* values_k,
+                          const float* adv_k, const float* logprobs_k, const int64_t* inds, const int64_t* kinds,
+                          int64_t N, const double* global_moments, float* actor_grad, float* critic_grad,
+                          double* stats, void* workspace, int64_t workspace_bytes, dppo_stream_t stream) {
+  return ppo_entry(actor, critic, prec, actor_params, actor_packed, critic_params, critic_packed, dcfg, pcfg, ksteps, obs_k,
+                   chains_k, returns_k, values_k, adv_k, logprobs_k, inds, kinds, N, global_moments, actor_grad, critic_grad,
+                   stats, workspace, workspace_bytes, stream, nullptr);
+}
+int dppo_ppo_loss_fwd_bwd_obs(const dppo_net_desc* actor, const dppo_net_desc* critic, int prec, const float* actor_params,
+                              const void* actor_packed, const float* critic_params, const void* critic_packed,
+                              const dppo_diffusion_cfg* dcfg, const dppo_ppo_cfg* pcfg, const dppo_step* ksteps,
+                              const float* obs_k, const float* chains_k, const float* returns_k, const float* values_k,
+                              const float* adv_k, const float* logprobs_k, const int64_t* kinds, int64_t N,
+                              const double* global_moments, float* actor_grad, float* critic_grad, double* stats,
+                              void* workspace, int64_t workspace_bytes, dppo_stream_t stream, const dppo_obs_io* io) {
+  if (!io) return fail(-1, "null pointer");
+  return ppo_entry(actor, critic, prec, actor_params, actor_packed, critic_params, critic_packed, dcfg, pcfg, ksteps, obs_k,
+                   chains_k, returns_k, values_k, adv_k, logprobs_k, nullptr, kinds, N, global_moments, actor_grad, critic_grad,
+                   stats, workspace, workspace_bytes, stream, io);
 }
 
 // ---- Gaussian-policy PPO (gaussian.hip) ----------------------------------------------------------------------
@@ -1607,7 +1685,8 @@ static int unet_ppo_impl(const dppo_unet_desc& u, const dppo_net_desc& cr, const
                          const char* ck, const dppo_diffusion_cfg& dcfg, const dppo_ppo_cfg& pcfg, const dppo_step* ksteps,
                          const float* obs_k, const float* chains_k, const float* returns_k, const float* values_k,
                          const float* adv_k, const float* logprobs_k, const int64_t* inds, const int64_t* kinds, int64_t N,
-                         const double* gmom, float* agrad, float* cgrad, double* stats, void* ws, int64_t wsb, hipStream_t s) {
+                         const double* gmom, float* agrad, float* cgrad, double* stats, void* ws, int64_t wsb, hipStream_t s,
+                         const dppo_obs_io* oio = nullptr) {
   Carver c{(char*)ws, 0, (size_t)wsb};
   UnetPpoWs<P> W;
   const size_t need = carve_unet_ppo<P>(c, u, &cr, N, W);
@@ -1618,7 +1697,8 @@ static int unet_ppo_impl(const dppo_unet_desc& u, const dppo_net_desc& cr, const
   memset(&br, 0, sizeof(br));
   br.zero_b = W.moments, br.n_zero_b = 32;
   if (Kft <= 1024) br.loss_tab = W.loss_tab, br.pcfg = pcfg;
-  br.inds = inds, br.kinds = kinds, br.chains = chains_k, br.obs = obs_k, br.ksteps = ksteps, br.Kft = Kft, br.AF = AF;
+  br.inds = inds, br.kinds = kinds, br.chains = chains_k, br.ksteps = ksteps, br.Kft = Kft, br.AF = AF;
+  br.obs = oio && oio->obs_critic ? oio->obs_critic : obs_k;  // (pixel nets: the critic encodes the images itself)
   br.cond = cr.cond_dim, br.M = N, br.inC = W.C.in, br.KpC = LC.Kp0, br.brow = W.brow, br.onehot0 = -1;
   launch_build_rows<P>(br, s);
   launch_unet_index(inds, kinds, Kft, N, W.brow, W.krow, s);
@@ -1646,26 +1726,30 @@ static int unet_ppo_impl(const dppo_unet_desc& u, const dppo_net_desc& cr, const
   launch_ppo_loss<P>(la, s);
   s2 = fork_side(s);
   mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s2, false, -1, &la);
-  unet_trainer_backward<P>(T, W.d_eps, W.ldde, agrad);
+  if (oio && oio->d_obs_critic) obs_grad<P>(cr, cp, N, W.C, oio->d_obs_critic, s2);
+  unet_trainer_backward<P>(T, W.d_eps, W.ldde, agrad, oio ? oio->d_obs_actor : nullptr);
   unet_trainer_free<P>(T);
   if (s2 != s) join_side(s, s2);
   return check_launch();
 }
-int dppo_unet_ppo_loss_fwd_bwd(const dppo_unet_desc* actor, const dppo_net_desc* critic, int prec, const float* actor_params,
+static int unet_ppo_entry(const dppo_unet_desc* actor, const dppo_net_desc* critic, int prec, const float* actor_params,
                                const void* actor_packed, const float* critic_params, const void* critic_packed,
                                const dppo_diffusion_cfg* dcfg, const dppo_ppo_cfg* pcfg, const dppo_step* ksteps,
                                const float* obs_k, const float* chains_k, const float* returns_k, const float* values_k,
                                const float* adv_k, const float* logprobs_k, const int64_t* inds, const int64_t* kinds,
                                int64_t N, const double* global_moments, float* actor_grad, float* critic_grad,
-                               double* stats, void* workspace, int64_t workspace_bytes, dppo_stream_t stream) {
+                               double* stats, void* workspace, int64_t workspace_bytes, dppo_stream_t stream,
+                               const dppo_obs_io* io) {
   if (int e = unet_check_desc(actor)) return e;
   if (int e = check_net(critic)) return e;
   if (int e = check_prec(prec)) return e;
   if (critic->kind != 1 || critic->out_dim != 1) return fail(-1, "critic descriptor must be kind 1 with out_dim 1");
-  if (actor->cond_dim != critic->cond_dim) return fail(-1, "actor and critic observe different cond_dim");
+  if (actor->cond_dim != critic->cond_dim && !(io && io->obs_critic))
+    return fail(-1, "actor and critic observe different cond_dim");
   if (!actor_params || !actor_packed || !critic_params || !critic_packed || !dcfg || !pcfg || !ksteps || !obs_k ||
       !chains_k || !returns_k || !values_k || !adv_k || !logprobs_k || !actor_grad || !critic_grad || !stats || !workspace)
     return fail(-1, "null pointer");
+  if (int e = check_obs_io(io, kinds, false)) return e;
   if ((inds == nullptr) == (kinds == nullptr)) return fail(-1, "pass exactly one of inds (rollout mode) / kinds (gathered mode)");
   if (N < 2 || N > (1 << 24)) return fail(-1, "N out of range");
   if (pcfg->ft_denoising_steps < 1 || pcfg->ft_denoising_steps > 1024) return fail(-1, "Kft out of range");
@@ -1675,9 +1759,32 @@ int dppo_unet_ppo_loss_fwd_bwd(const dppo_unet_desc* actor, const dppo_net_desc*
 #define CALL(P)                                                                                                          \
   unet_ppo_impl<P>(*actor, *critic, actor_params, (const char*)actor_packed, critic_params, (const char*)critic_packed, *dcfg, \
                    *pcfg, ksteps, obs_k, chains_k, returns_k, values_k, adv_k, logprobs_k, inds, kinds, N, global_moments,     \
-                   actor_grad, critic_grad, stats, workspace, workspace_bytes, (hipStream_t)stream)
+                   actor_grad, critic_grad, stats, workspace, workspace_bytes, (hipStream_t)stream, io)
   return DPPO_DISPATCH(prec, CALL);
 #undef CALL
+}
+int dppo_unet_ppo_loss_fwd_bwd(const dppo_unet_desc* actor, const dppo_net_desc* critic, int prec, const float* actor_params,
+                               const void* actor_packed, const float* critic_params, const void* critic_packed,
+                               const dppo_diffusion_cfg* dcfg, const dppo_ppo_cfg* pcfg, const dppo_step* ksteps,
+                               const float* obs_k, const float* chains_k, const float* returns_k, const float* values_k,
+                               const float* adv_k, const float* logprobs_k, const int64_t* inds, const int64_t* kinds,
+                               int64_t N, const double* global_moments, float* actor_grad, float* critic_grad,
+                               double* stats, void* workspace, int64_t workspace_bytes, dppo_stream_t stream) {
+  return unet_ppo_entry(actor, critic, prec, actor_params, actor_packed, critic_params, critic_packed, dcfg, pcfg, ksteps, obs_k,
+                        chains_k, returns_k, values_k, adv_k, logprobs_k, inds, kinds, N, global_moments, actor_grad,
+                        critic_grad, stats, workspace, workspace_bytes, stream, nullptr);
+}
+int dppo_unet_ppo_loss_fwd_bwd_obs(const dppo_unet_desc* actor, const dppo_net_desc* critic, int prec, const float* actor_params,
+                                   const void* actor_packed, const float* critic_params, const void* critic_packed,
+                                   const dppo_diffusion_cfg* dcfg, const dppo_ppo_cfg* pcfg, const dppo_step* ksteps,
+                                   const float* obs_k, const float* chains_k, const float* returns_k, const float* values_k,
+                                   const float* adv_k, const float* logprobs_k, const int64_t* kinds, int64_t N,
+                                   const double* global_moments, float* actor_grad, float* critic_grad, double* stats,
+                                   void* workspace, int64_t workspace_bytes, dppo_stream_t stream, const dppo_obs_io* io) {
+  if (!io) return fail(-1, "null pointer");
+  return unet_ppo_entry(actor, critic, prec, actor_params, actor_packed, critic_params, critic_packed, dcfg, pcfg, ksteps, obs_k,
+                        chains_k, returns_k, values_k, adv_k, logprobs_k, nullptr, kinds, N, global_moments, actor_grad,
+                        critic_grad, stats, workspace, workspace_bytes, stream, io);
 }
 int64_t dppo_unet_denoise_mse_workspace_bytes(const dppo_unet_desc* net, int prec, int64_t N) {
   if (unet_check_desc(net) || check_prec(prec)) return -1;
@@ -1693,7 +1800,7 @@ int64_t dppo_unet_denoise_mse_workspace_bytes(const dppo_unet_desc* net, int pre
 template <class P>
 static int unet_mse_impl(const dppo_unet_desc& u, const float* prm, const char* pk, const dppo_step* tsteps, int n_time,
                          const float* obs, const float* pairs, const int64_t* kinds, int64_t N, float* grad, double* loss,
-                         void* ws, int64_t wsb, hipStream_t s) {
+                         void* ws, int64_t wsb, hipStream_t s, float* d_obs = nullptr) {
   Carver c{(char*)ws, 0, (size_t)wsb};
   UnetPpoWs<P> W;
   const size_t need = carve_unet_ppo<P>(c, u, nullptr, N, W);
@@ -1709,14 +1816,14 @@ static int unet_mse_impl(const dppo_unet_desc& u, const float* prm, const char* 
   ma.eps = eps, ma.lde = AF, ma.pairs = pairs, ma.AF = AF, ma.M = N, ma.d_eps = W.d_eps, ma.ldde = W.ldde, ma.loss = loss;
   ma.partial = W.loss_partial;
   launch_mse_loss<P>(ma, s);
-  unet_trainer_backward<P>(T, W.d_eps, W.ldde, grad);
+  unet_trainer_backward<P>(T, W.d_eps, W.ldde, grad, d_obs);
   unet_trainer_free<P>(T);
   return check_launch();
 }
-int dppo_unet_denoise_mse_fwd_bwd(const dppo_unet_desc* net, int prec, const float* params, const void* packed,
+static int unet_mse_entry(const dppo_unet_desc* net, int prec, const float* params, const void* packed,
                                   const dppo_step* tsteps, int n_time, const float* obs, const float* pairs,
                                   const int64_t* kinds, int64_t N, float* grad, double* loss, void* workspace,
-                                  int64_t workspace_bytes, dppo_stream_t stream) {
+                                  int64_t workspace_bytes, dppo_stream_t stream, float* d_obs) {
   if (int e = unet_check_desc(net)) return e;
   if (int e = check_prec(prec)) return e;
   if (!params || !packed || !tsteps || !obs || !pairs || !kinds || !grad || !loss || !workspace) return fail(-1, "null pointer");
@@ -1724,9 +1831,24 @@ int dppo_unet_denoise_mse_fwd_bwd(const dppo_unet_desc* net, int prec, const flo
   if ((size_t)n_time * 9 * net->time_dim * 4 > 64 * 1024) return fail(-1, "n_time * time_dim too large (LDS of the time MLP's backward)");
 #define CALL(P)                                                                                                          \
   unet_mse_impl<P>(*net, params, (const char*)packed, tsteps, n_time, obs, pairs, kinds, N, grad, loss, workspace, workspace_bytes, \
-                   (hipStream_t)stream)
+                   (hipStream_t)stream, d_obs)
   return DPPO_DISPATCH(prec, CALL);
 #undef CALL
+}
+int dppo_unet_denoise_mse_fwd_bwd(const dppo_unet_desc* net, int prec, const float* params, const void* packed,
+                                  const dppo_step* tsteps, int n_time, const float* obs, const float* pairs,
+                                  const int64_t* kinds, int64_t N, float* grad, double* loss, void* workspace,
+                                  int64_t workspace_bytes, dppo_stream_t stream) {
+  return unet_mse_entry(net, prec, params, packed, tsteps, n_time, obs, pairs, kinds, N, grad, loss, workspace, workspace_bytes,
+                        stream, nullptr);
+}
+int dppo_unet_denoise_mse_fwd_bwd_obs(const dppo_unet_desc* net, int prec, const float* params, const void* packed,
+                                      const dppo_step* tsteps, int n_time, const float* obs, const float* pairs,
+                                      const int64_t* kinds, int64_t N, float* grad, double* loss, void* workspace,
+                                      int64_t workspace_bytes, dppo_stream_t stream, float* d_obs) {
+  if (!d_obs) return fail(-1, "null pointer");
+  return unet_mse_entry(net, prec, params, packed, tsteps, n_time, obs, pairs, kinds, N, grad, loss, workspace, workspace_bytes,
+                        stream, d_obs);
 }
 
 // ---- optimiser ----------------------------------------------------------------------------------------

@@ -16,6 +16,8 @@ void launch_cast_pad(const float* src, int rows, int cols, int lds, void* dst, i
 template <class P>
 void launch_transpose_cast(const float* src, int rows, int cols, int lds, int coff, void* dst, int ldd,
                            hipStream_t s);
+// out[r][c] (dense, ncols wide) = src[r][col0 + c]
+void launch_copy_cols(const float* src, int ld, int col0, int ncols, int64_t rows, float* out, hipStream_t s);
 // time-embedding table: temb[t][td] for t < n_time (model/diffusion/mlp_diffusion.py:191-196,
 // modules.py:20-27); hid[t][2td] keeps the pre-Mish activations for the backward
 void launch_time_table(const float* w1, const float* b1, const float* w2, const float* b2, int td, int n_time,

@@ -274,6 +274,16 @@ template void launch_build_direct<F32>(const float*, const int64_t*, const float
 template void launch_build_direct<BF16>(const float*, const int64_t*, const float*, const float*, int, int, int,
                                         int64_t, void*, int, hipStream_t);
 
+__global__ void copy_cols_kernel(const float* src, int ld, int col0, int ncols, int64_t rows, float* out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < (size_t)rows * ncols) out[i] = src[(i / ncols) * ld + col0 + i % ncols];
+}
+void launch_copy_cols(const float* src, int ld, int col0, int ncols, int64_t rows, float* out, hipStream_t s) {
+  const size_t n = (size_t)rows * ncols;
+  if (n == 0) return;
+  hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, ld, col0, ncols, rows, out);
+}
+
 template <class P>
 __global__ void zero_cols_kernel(typename P::elem_t* X, int M, int c0, int c1, int ld) {
   const int w = c1 - c0;

@@ -24,8 +24,9 @@ UnetTrainer<P>* unet_trainer_new(const dppo_unet_desc& d, const float* prm, cons
 template <class P>
 float* unet_trainer_forward(UnetTrainer<P>* t, const UnetTrainIO& io);  // eps [N][Ta*Da] f32 (lives in the workspace)
 // d_eps: elem [N][ldde] = d loss / d eps (column t*Da + c), zero beyond Ta*Da; grad: flat fp32, state-dict order, OVERWRITTEN
+// d_obs (optional): f32 [N][cond_dim] <- d loss / d observation (what a visual encoder in front of the network continues from)
 template <class P>
-void unet_trainer_backward(UnetTrainer<P>* t, const void* d_eps, int ldde, float* grad);
+void unet_trainer_backward(UnetTrainer<P>* t, const void* d_eps, int ldde, float* grad, float* d_obs = nullptr);
 template <class P>
 void unet_trainer_free(UnetTrainer<P>* t);
 int unet_check_desc(const dppo_unet_desc* d);

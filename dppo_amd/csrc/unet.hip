@@ -1056,6 +1056,12 @@ __global__ __launch_bounds__(256) void unet_time_bwd_kernel(const float* w1, con
   }
 }
 
+// out[r][c] = src[r][col0 + c]
+__global__ void unet_copy_cols_kernel(const float* src, int ld, int col0, int ncols, int64_t rows, float* out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < (size_t)rows * ncols) out[i] = src[(i / ncols) * ld + col0 + i % ncols];
+}
+
 }  // namespace
 
 template <class P>
@@ -1354,9 +1360,11 @@ struct UnetTrainer {
         if (!dry) {
           GemmNT g2;
           memset(&g2, 0, sizeof(g2));
-          g2.X = dcur, g2.ldx = ldq, g2.M = (int)rows, g2.N = d.time_dim, g2.Kp = rup(l.out, 64), g2.W = pk + l.pkT;
-          g2.ldw = rup(l.out, 64), g2.out_f32 = dgacc, g2.ldo32 = rup(d.time_dim, 16);
-          if (dg_started) g2.res = dgacc, g2.ldres = rup(d.time_dim, 16);
+          // (with d_obs requested -- a visual encoder feeds the observation columns -- all of g's columns are kept)
+          g2.X = dcur, g2.ldx = ldq, g2.M = (int)rows, g2.N = dobs_out ? d.time_dim + d.cond_dim : d.time_dim;
+          g2.Kp = rup(l.out, 64), g2.W = pk + l.pkT;
+          g2.ldw = rup(l.out, 64), g2.out_f32 = dgacc, g2.ldo32 = dg_ld();
+          if (dg_started) g2.res = dgacc, g2.ldres = dg_ld();
           if (!d.larger_encoder)  // one-layer encoder = Linear(act(g)): the chain rule's act'(g) on the raw vector
             g2.dsrc = graw, g2.dsrc_kind = 2, g2.dsrc_ld = L.Kg, g2.dact = d.act;
           launch_gemm_nt<P>(g2, s);
@@ -1366,6 +1374,8 @@ struct UnetTrainer {
     }
   }
   bool dg_started;
+  float* dobs_out = nullptr;  // [rows][cond] f32: d loss / d observation columns of g (optional output of backward())
+  int dg_ld() const { return rup(d.time_dim + d.cond_dim, 16); }
   // ResidualBlock1D backward.  up / n_up: gradient of the block's output; returns the gradient of its input in `gin`
   // (f32 rows [rows * Tp][ci_ld]) unless `need_in` is false (the network input)
   void resblock_bwd(const RBTape& tp, GradSrc* up, int n_up, float* gin, bool need_in) {
@@ -1421,11 +1431,12 @@ struct UnetTrainer {
   // gin[(b, t)][c] += img[b][t + PAD][c]
   void add_img_rows(float* gin, int ld, const void* img, int T, int C);
 
-  void backward(const void* d_eps, int ldde, float* grad_) {
+  void backward(const void* d_eps, int ldde, float* grad_, float* dobs = nullptr) {
     grad = grad_;
+    dobs_out = dobs;
     dg_started = false;
     const int nl = d.n_levels, T0 = d.horizon_steps, Tp0 = T0 + 2 * PAD;
-    if (!dry) hipMemsetAsync(grad, 0, (size_t)L.n_params * 4, s);
+    if (!dry) (void)hipMemsetAsync(grad, 0, (size_t)L.n_params * 4, s);
     // ---- final 1x1 conv
     Img dE = new_img(T0, 64);
     if (!dry)
@@ -1552,8 +1563,13 @@ struct UnetTrainer {
     // ---- time embedding: G[k][td] = segmented sum of d g over the rows of step k, then the time MLP's backward
     if (!dry) {
       float* Gk = part;  // [Kft][td]
-      hipLaunchKernelGGL(unet_temb_segsum_kernel, dim3(io.Kft), dim3(256), 0, s, dgacc, rup(d.time_dim, 16), io.krow, rows,
+      hipLaunchKernelGGL(unet_temb_segsum_kernel, dim3(io.Kft), dim3(256), 0, s, dgacc, dg_ld(), io.krow, rows,
                          d.time_dim, Gk);
+      if (dobs_out) {
+        const size_t n = (size_t)rows * d.cond_dim;
+        hipLaunchKernelGGL(unet_copy_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dgacc, dg_ld(), d.time_dim,
+                           d.cond_dim, rows, dobs_out);
+      }
       const size_t lds = (size_t)io.Kft * (d.time_dim + 8 * d.time_dim) * 4;
       hipLaunchKernelGGL(unet_time_bwd_kernel, dim3(1), dim3(256), lds, s, prm + L.t1.w, prm + L.t1.b, prm + L.t2.w, Gk, io.ksteps,
                          io.Kft, d.time_dim, grad + L.t1.w, grad + L.t1.b, grad + L.t2.w, grad + L.t2.b);
@@ -1573,7 +1589,7 @@ struct UnetTrainer {
     slab = new_f32(slab_floats);
     part = new_f32((size_t)64 * 4 * cmax + 4096);
     dgb = new_f32((size_t)rows * 2 * cmax);
-    dgacc = new_f32((size_t)rows * rup(d.time_dim, 16));
+    dgacc = new_f32((size_t)rows * dg_ld());
   }
 };
 
@@ -1625,8 +1641,8 @@ float* unet_trainer_forward(UnetTrainer<P>* t, const UnetTrainIO& io) {
   return t->eps;
 }
 template <class P>
-void unet_trainer_backward(UnetTrainer<P>* t, const void* d_eps, int ldde, float* grad) {
-  t->backward(d_eps, ldde, grad);
+void unet_trainer_backward(UnetTrainer<P>* t, const void* d_eps, int ldde, float* grad, float* d_obs) {
+  t->backward(d_eps, ldde, grad, d_obs);
 }
 template <class P>
 void unet_trainer_free(UnetTrainer<P>* t) {
@@ -1652,7 +1668,7 @@ void launch_unet_index(const int64_t* inds, const int64_t* kinds, int Kft, int64
   template UnetTrainer<P>* unet_trainer_new<P>(const dppo_unet_desc&, const float*, const char*, int64_t, void*, size_t, \
                                                hipStream_t);                                                            \
   template float* unet_trainer_forward<P>(UnetTrainer<P>*, const UnetTrainIO&);                                         \
-  template void unet_trainer_backward<P>(UnetTrainer<P>*, const void*, int, float*);                                    \
+  template void unet_trainer_backward<P>(UnetTrainer<P>*, const void*, int, float*, float*);                            \
   template void unet_trainer_free<P>(UnetTrainer<P>*);
 UNET_INST(F32)
 UNET_INST(BF16)

@@ -76,6 +76,10 @@ class VisDesc(C.Structure):  # struct dppo_vis_desc
                 ("spatial_emb", C.c_int32), ("num_img", C.c_int32)]
 
 
+class ObsIO(C.Structure):  # struct dppo_obs_io
+    _fields_ = [("obs_critic", C.c_void_p), ("d_obs_actor", C.c_void_p), ("d_obs_critic", C.c_void_p)]
+
+
 # numpy mirror of `dppo_step` (40 bytes) so schedules are built vectorised on the host
 STEP_DTYPE = np.dtype([("net", "<i4"), ("t", "<i4"), ("chain_slot", "<i4"), ("final_clip", "<i4"),
                        ("c0", "<f4"), ("c1", "<f4"), ("c2", "<f4"), ("c3", "<f4"), ("std", "<f4"), ("pad", "<f4")])
@@ -114,6 +118,14 @@ SYMBOLS = {
                                             _P, _L, _P, _P, _P, _P, _P, _P, _L, _P]),
     "dppo_unet_param_count": (_L, [C.POINTER(UnetDesc)]),
     "dppo_unet_packed_bytes": (_L, [C.POINTER(UnetDesc), _I, _I]),
+    # the *_obs entries: pre-gathered mode only (no `inds`), + dppo_obs_io* / d_obs
+    "dppo_ppo_loss_fwd_bwd_obs": (_I, [_ND, _ND, _I, _P, _P, _P, _P, C.POINTER(DiffusionCfg), C.POINTER(PpoCfg), _P,
+                                       _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P, C.POINTER(ObsIO)]),
+    "dppo_unet_ppo_loss_fwd_bwd_obs": (_I, [C.POINTER(UnetDesc), _ND, _I, _P, _P, _P, _P, C.POINTER(DiffusionCfg),
+                                            C.POINTER(PpoCfg), _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P,
+                                            C.POINTER(ObsIO)]),
+    "dppo_denoise_mse_fwd_bwd_obs": (_I, [_ND, _I, _P, _P, _P, _I, _P, _P, _P, _L, _P, _P, _P, _L, _P, _P]),
+    "dppo_unet_denoise_mse_fwd_bwd_obs": (_I, [C.POINTER(UnetDesc), _I, _P, _P, _P, _I, _P, _P, _P, _L, _P, _P, _P, _L, _P, _P]),
     "dppo_vis_param_count": (_L, [C.POINTER(VisDesc)]),
     "dppo_vis_packed_bytes": (_L, [C.POINTER(VisDesc), _I]),
     "dppo_vis_pack": (_I, [C.POINTER(VisDesc), _I, _P, _P, _P]),

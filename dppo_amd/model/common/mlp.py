@@ -163,6 +163,10 @@ class HipNet(nn.Module):
             off += p.numel()
         return out
 
+    def grad_views_all(self) -> List[torch.Tensor]:
+        """One gradient view per entry of ``self.parameters()`` (a pixel network adds its encoder's, see VisionMixin)."""
+        return self.grad_views()
+
     def mark_updated(self):
         """Call after a kernel wrote the flat parameter buffer behind torch's back (fused AdamW)."""
         object.__setattr__(self, "_epoch", self._epoch + 1)

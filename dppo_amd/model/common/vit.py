@@ -241,6 +241,15 @@ class VisionMixin:
     def _vision_parameter_ids(self):
         return {id(p) for m in self.vis._mods for p in m.parameters()}
 
+    def grad_views_all(self):
+        by_id = {id(p): g for p, g in zip(self.vis.trunk_parameters(), self.vis.grad_views())}
+        by_id.update({id(p): g for p, g in zip(self.trunk_parameters(), self.grad_views())})
+        return [by_id[id(p)] for p in self.parameters()]
+
+    def mark_updated(self):
+        HipNet.mark_updated(self)
+        self.vis.mark_updated()
+
     def encode_obs(self, cond, train: bool = False, augment: bool = None):
         """cond {"rgb", "state"} -> (B, spatial_emb * num_img + To*Do): what the trunk observes."""
         use_aug = self.augment if augment is None else augment

@@ -200,30 +200,46 @@ class DiffusionModel(nn.Module):
             ft = base
         d = base.net_desc()
         K = self.denoising_steps
-        if getattr(base, "is_unet", False):  # conv denoiser: host loop over the steps, dppo_unet_sample_chain
-            key = ("host", "sample", deterministic, use_base_policy, float(self.get_min_sampling_denoising_std()),
-                   self.ft_denoising_steps, str(dev), self._eta_value(deterministic))
-            tab = self._sched_cache[key]
-            ws = base.workspace(B, dev)
-            hip.check(lib.dppo_unet_sample_chain(
-                C.byref(d), self.prec, base.flat_params().data_ptr(), base.packed(self.prec, K).data_ptr(),
-                ft.flat_params().data_ptr(), ft.packed(self.prec, K).data_ptr(), C.byref(cfg), tab.ctypes.data, n_steps,
-                obs.data_ptr(), noise.data_ptr() if noise is not None else None, B, traj.data_ptr(),
-                chains.data_ptr() if return_chain else None, chain_len if return_chain else 0,
-                init_slot if return_chain else -1, ws.data_ptr(), ws.numel(), hip.stream()), "dppo_unet_sample_chain")
-            traj = traj.view(B, self.horizon_steps, self.action_dim)
-            if return_chain:
-                chains = chains.view(B, chain_len, self.horizon_steps, self.action_dim)
-            return Sample(traj, chains)
-        wsb = lib.dppo_sample_chain_workspace_bytes(C.byref(d), self.prec, B)
-        ws = self.__dict__.setdefault("_ws_sample", hip.Workspace()).get(wsb, dev) if wsb > 0 else None
-        hip.check(lib.dppo_sample_chain(
-            C.byref(d), self.prec, base.flat_params().data_ptr(), base.packed(self.prec, K).data_ptr(),
-            ft.flat_params().data_ptr(), ft.packed(self.prec, K).data_ptr(), C.byref(cfg),
-            sched.data_ptr(), n_steps, obs.data_ptr(), noise.data_ptr() if noise is not None else None, B, traj.data_ptr(),
-            chains.data_ptr() if return_chain else None, chain_len if return_chain else 0,
-            init_slot if return_chain else -1, ws.data_ptr() if ws is not None else None, wsb, hip.stream()),
-            "dppo_sample_chain")
+        key = ("host", "sample", deterministic, use_base_policy, float(self.get_min_sampling_denoising_std()),
+               self.ft_denoising_steps, str(dev), self._eta_value(deterministic))
+        tab = self._sched_cache[key]
+        is_unet = getattr(base, "is_unet", False)
+        # Pixel networks: the observation vector is cat[encoder(rgb, state), state], and the frozen and the fine-tuned network
+        # each own an encoder -- one launch per run of consecutive steps on the same network (the shipped image cfgs
+        # fine-tune every DDIM step: one run).  A second run starts from the first one's output, which the kernel takes as
+        # noise[0]: with in-kernel noise that needs an explicit draw.
+        if getattr(base, "is_vision", False):
+            cuts = [0] + [i for i in range(1, n_steps) if tab["net"][i] != tab["net"][i - 1]] + [n_steps]
+            segs = [(cuts[i], cuts[i + 1], (ft if tab["net"][cuts[i]] else base).encode_obs(cond)) for i in range(len(cuts) - 1)]
+            if len(segs) > 1 and noise is None:
+                noise = torch.randn(n_steps + 1, B, AF, device=dev)
+        else:
+            segs = [(0, n_steps, obs)]
+        step_bytes = hip.STEP_DTYPE.itemsize
+        for a, b, ob in segs:
+            nz = noise
+            if noise is not None and a > 0:
+                nz = torch.cat([traj.reshape(1, B, AF), noise[a + 1:b + 1]], 0).contiguous()
+            elif noise is not None:
+                nz = noise[:b + 1]
+            chp = chains.data_ptr() if return_chain else None
+            cl, isl = (chain_len if return_chain else 0), (init_slot if return_chain and a == 0 else -1)
+            if is_unet:  # conv denoiser: host loop over the steps, dppo_unet_sample_chain
+                ws = base.workspace(B, dev)
+                hip.check(lib.dppo_unet_sample_chain(
+                    C.byref(d), self.prec, base.flat_params().data_ptr(), base.packed(self.prec, K).data_ptr(),
+                    ft.flat_params().data_ptr(), ft.packed(self.prec, K).data_ptr(), C.byref(cfg), tab[a:b].ctypes.data, b - a,
+                    ob.data_ptr(), nz.data_ptr() if nz is not None else None, B, traj.data_ptr(), chp, cl, isl,
+                    ws.data_ptr(), ws.numel(), hip.stream()), "dppo_unet_sample_chain")
+            else:
+                wsb = lib.dppo_sample_chain_workspace_bytes(C.byref(d), self.prec, B)
+                ws = self.__dict__.setdefault("_ws_sample", hip.Workspace()).get(wsb, dev) if wsb > 0 else None
+                hip.check(lib.dppo_sample_chain(
+                    C.byref(d), self.prec, base.flat_params().data_ptr(), base.packed(self.prec, K).data_ptr(),
+                    ft.flat_params().data_ptr(), ft.packed(self.prec, K).data_ptr(), C.byref(cfg),
+                    sched.data_ptr() + a * step_bytes, b - a, ob.data_ptr(), nz.data_ptr() if nz is not None else None, B,
+                    traj.data_ptr(), chp, cl, isl, ws.data_ptr() if ws is not None else None, wsb, hip.stream()),
+                    "dppo_sample_chain")
         traj = traj.view(B, self.horizon_steps, self.action_dim)
         if return_chain:
             chains = chains.view(B, chain_len, self.horizon_steps, self.action_dim)
@@ -283,9 +299,10 @@ class DiffusionModel(nn.Module):
             noise = torch.randn_like(x_start)
         x_noisy = self.q_sample(x_start, t, noise)
         pairs = torch.stack([x_noisy.reshape(N, -1), noise.reshape(N, -1)], dim=1).float().contiguous()
-        obs = state.reshape(N, -1).float().contiguous()
         kinds = t.to(torch.int64).contiguous()
         net = self.network
+        vision = getattr(net, "is_vision", False)  # pixel network: encoder forward with a tape, its backward after the loss
+        obs = net.encode_obs(cond, train=True) if vision else state.reshape(N, -1).float().contiguous()
         lib, d = hip.load(), net.net_desc()
         flat = net.flat_params()
         grad = torch.empty_like(flat)
@@ -298,16 +315,26 @@ class DiffusionModel(nn.Module):
             hip.check(int(wsb), "dppo_denoise_mse_workspace_bytes")
         ws = self.__dict__.setdefault("_ws_mse", hip.Workspace()).get(wsb, dev)
         ts = self._time_steps(dev)
-        hip.check(entry(
-            C.byref(d), self.prec, flat.data_ptr(), net.packed(self.prec, self.denoising_steps).data_ptr(), ts.data_ptr(),
-            self.denoising_steps, obs.data_ptr(), pairs.data_ptr(), kinds.data_ptr(), N, grad.data_ptr(),
-            value.data_ptr(), ws.data_ptr(), ws.numel(), hip.stream()), "dppo_denoise_mse_fwd_bwd")
+        args = (C.byref(d), self.prec, flat.data_ptr(), net.packed(self.prec, self.denoising_steps).data_ptr(), ts.data_ptr(),
+                self.denoising_steps, obs.data_ptr(), pairs.data_ptr(), kinds.data_ptr(), N, grad.data_ptr(),
+                value.data_ptr(), ws.data_ptr(), ws.numel(), hip.stream())
+        if vision:
+            d_obs = torch.empty_like(obs)
+            entry = lib.dppo_unet_denoise_mse_fwd_bwd_obs if unet else lib.dppo_denoise_mse_fwd_bwd_obs
+            hip.check(entry(*args, d_obs.data_ptr()), "dppo_denoise_mse_fwd_bwd_obs")
+            vgrad = net.vis.backward(d_obs)
+        else:
+            hip.check(entry(*args), "dppo_denoise_mse_fwd_bwd")
         object.__setattr__(self, "last_loss_grad", grad)  # flat d loss / d parameters, for callers that step a flat optimiser
         params = net.trunk_parameters()  # the flat image is their concatenation in this order
         views, off = [], 0
         for p in params:
             views.append(grad[off:off + p.numel()].view(p.shape))
             off += p.numel()
+        if vision:  # + the encoder's parameters and gradients (its own flat buffer)
+            object.__setattr__(self, "last_loss_grad_vis", vgrad)
+            params = params + net.vis.trunk_parameters()
+            views = views + net.vis.grad_views()
         return _FusedDenoiseLoss.apply(value[0], views, *params)
 
     def diffusion_cfg(self) -> hip.DiffusionCfg:

@@ -124,6 +124,43 @@ class PPODiffusion(VPGDiffusion):
             ws.data_ptr(), ws.numel(), hip.stream()), "dppo_ppo_loss_fwd_bwd")
         return self._stats
 
+    def _run_ppo_vision(self, cond, pairs, returns, values, adv, logprobs, kinds, N, reward_horizon, adv_gathered,
+                        global_moments=None):
+        """The PPO loss with pixel networks: both encoders run with a tape, the fused loss entry returns d loss / d obs for
+        each of them next to the trunk gradients, and the encoders' backward turns those into their own flat gradients
+        (``actor_ft.vis.flat_grads()`` / ``critic.vis.flat_grads()``)."""
+        lib = hip.load()
+        a, c = self.actor_ft, self.critic
+        obs_a = a.encode_obs(cond, train=True)
+        obs_c = c.encode_obs(cond, train=True, augment=False)
+        dev = obs_a.device
+        da, dc = a.net_desc(), c.net_desc()
+        K = self.denoising_steps
+        if self._stats is None or self._stats.device != dev:
+            object.__setattr__(self, "_stats", torch.zeros(hip.STAT_COUNT, dtype=torch.float64, device=dev))
+        pcfg = self._ppo_cfg(reward_horizon, adv_gathered)
+        dcfg = self.diffusion_cfg()
+        ks = self._logprob_schedule(dev)
+        unet = getattr(a, "is_unet", False)
+        ws_bytes, entry = (lib.dppo_unet_ppo_workspace_bytes, lib.dppo_unet_ppo_loss_fwd_bwd_obs) if unet else (
+            lib.dppo_ppo_workspace_bytes, lib.dppo_ppo_loss_fwd_bwd_obs)
+        wsb = ws_bytes(C.byref(da), C.byref(dc), self.prec, N)
+        if wsb < 0:
+            hip.check(int(wsb), "dppo_ppo_workspace_bytes")
+        ws = self._ws_ppo.get(wsb, dev)
+        d_a, d_c = torch.empty_like(obs_a), torch.empty_like(obs_c)
+        io = hip.ObsIO(obs_c.data_ptr(), d_a.data_ptr(), d_c.data_ptr())
+        ga, gc = a.flat_grads(), c.flat_grads()
+        hip.check(entry(
+            C.byref(da), C.byref(dc), self.prec, a.flat_params().data_ptr(), a.packed(self.prec, K).data_ptr(),
+            c.flat_params().data_ptr(), c.packed(self.prec, 0).data_ptr(), C.byref(dcfg), C.byref(pcfg), ks.data_ptr(),
+            hip.ptr(obs_a), hip.ptr(pairs), hip.ptr(returns), hip.ptr(values), hip.ptr(adv), hip.ptr(logprobs), hip.ptr(kinds), N,
+            hip.ptr(global_moments), ga.data_ptr(), gc.data_ptr(), self._stats.data_ptr(), ws.data_ptr(), ws.numel(),
+            hip.stream(), C.byref(io)), "dppo_ppo_loss_fwd_bwd_obs")
+        a.vis.backward(d_a)
+        c.vis.backward(d_c)
+        return self._stats
+
     def _eta_mean(self) -> float:
         return self._eta_value(False) if self.use_ddim else 1.0
 
@@ -178,16 +215,23 @@ class PPODiffusion(VPGDiffusion):
         N = state.shape[0]
         AF = self.horizon_steps * self.action_dim
         f32 = dict(dtype=torch.float32)
-        obs_f = state.reshape(N, -1).contiguous().to(**f32)
         pairs = torch.stack([chains_prev.reshape(N, AF), chains_next.reshape(N, AF)], dim=1).contiguous().to(**f32)
         kinds = denoising_inds.reshape(N).to(torch.long).contiguous()
         adv = advantages.reshape(N).contiguous().to(**f32)
-        stats = self._run_ppo(obs_f, pairs, returns.reshape(N).contiguous().to(**f32),
-                              oldvalues.reshape(N).contiguous().to(**f32), adv,
-                              oldlogprobs.reshape(N, AF).contiguous().to(**f32), None, kinds, N, reward_horizon, adv)
+        if getattr(self.actor_ft, "is_vision", False):
+            if use_bc_loss:
+                raise NotImplementedError("dppo_amd: the BC term with pixel networks is not built")
+            stats = self._run_ppo_vision(obs, pairs, returns.reshape(N).contiguous().to(**f32),
+                                         oldvalues.reshape(N).contiguous().to(**f32), adv,
+                                         oldlogprobs.reshape(N, AF).contiguous().to(**f32), kinds, N, reward_horizon, adv)
+        else:
+            obs_f = state.reshape(N, -1).contiguous().to(**f32)
+            stats = self._run_ppo(obs_f, pairs, returns.reshape(N).contiguous().to(**f32),
+                                  oldvalues.reshape(N).contiguous().to(**f32), adv,
+                                  oldlogprobs.reshape(N, AF).contiguous().to(**f32), None, kinds, N, reward_horizon, adv)
         a_params = list(self.actor_ft.parameters())
         c_params = list(self.critic.parameters())
-        pg_loss, v_loss = _FusedPPOLoss.apply(stats, self.actor_ft.grad_views(), self.critic.grad_views(),
+        pg_loss, v_loss = _FusedPPOLoss.apply(stats, self.actor_ft.grad_views_all(), self.critic.grad_views_all(),
                                               len(a_params), *a_params, *c_params)
         host = stats.tolist()  # one D2H sync, like the reference's .item() calls
         eta = self._eta_mean()

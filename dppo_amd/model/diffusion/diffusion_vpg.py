@@ -133,7 +133,9 @@ class VPGDiffusion(DiffusionModel):
         net = self.actor if use_base_policy else self.actor_ft
         lib, d = hip.load(), net.net_desc()
         ch = chains.reshape(B, Kft + 1, AF).contiguous().float()
-        obs = state.reshape(B, -1).contiguous().float()
+        # pixel networks: ONE encoder pass per observation serves its Kft chain steps (the reference repeats the images Kft
+        # times and encodes every copy, diffusion_vpg.py:340-345)
+        obs = net.encode_obs(cond) if getattr(net, "is_vision", False) else state.reshape(B, -1).contiguous().float()
         out = torch.empty((B * Kft, AF), device=dev, dtype=torch.float32)
         ks = self._logprob_schedule(dev)
         cfg = self.diffusion_cfg()
@@ -174,7 +176,7 @@ class VPGDiffusion(DiffusionModel):
         AF = self.horizon_steps * self.action_dim
         net = self.actor if use_base_policy else self.actor_ft
         lib, d = hip.load(), net.net_desc()
-        obs = state.reshape(B, -1).contiguous().float()
+        obs = net.encode_obs(cond) if getattr(net, "is_vision", False) else state.reshape(B, -1).contiguous().float()
         pairs = torch.stack([chains_prev.reshape(B, AF), chains_next.reshape(B, AF)], dim=1).contiguous().float()
         kinds = denoising_inds.reshape(B).to(torch.long)
         ks = self._logprob_schedule(dev)

@@ -421,6 +421,41 @@ int dppo_gemm_nt_raw(int prec, const void* X, const void* W, const float* bias, 
 int dppo_gemm_tn_raw(int prec, const void* A, int lda, int N1, const void* B, int ldb, int N2, int64_t M,
                      int rows_per_split, float* slab, float* C, dppo_stream_t stream);
 
+/* ---- loss entries that also return d loss / d observation (a visual encoder sits in front of the trunk) ------------
+ * Same arguments as the entry without the suffix, in pre-gathered mode (one observation row per sample, `kinds` given), plus:
+ *   obs_critic   (N, critic cond_dim) or NULL: the critic's own observation rows -- ViTCritic encodes the images with its own
+ *                backbone (model/common/critic.py:177-205), so actor and critic see different vectors;
+ *   d_obs_actor  (N, actor cond_dim)  or NULL: <- d pg_loss / d obs_k ;
+ *   d_obs_critic (N, critic cond_dim) or NULL: <- d v_loss / d obs_critic (or obs_k).
+ * d_obs of the supervised loss: (N, cond_dim) <- d loss / d obs.  Not built for actors with a cond_mlp. */
+typedef struct dppo_obs_io {
+  const float* obs_critic;
+  float* d_obs_actor;
+  float* d_obs_critic;
+} dppo_obs_io;
+int dppo_ppo_loss_fwd_bwd_obs(const dppo_net_desc* actor, const dppo_net_desc* critic, int prec, const float* actor_params,
+                              const void* actor_packed, const float* critic_params, const void* critic_packed,
+                              const dppo_diffusion_cfg* dcfg, const dppo_ppo_cfg* pcfg, const dppo_step* ksteps,
+                              const float* obs_k, const float* chains_k, const float* returns_k, const float* values_k,
+                              const float* adv_k, const float* logprobs_k, const int64_t* kinds, int64_t N,
+                              const double* global_moments, float* actor_grad, float* critic_grad, double* stats,
+                              void* workspace, int64_t workspace_bytes, dppo_stream_t stream, const dppo_obs_io* io);
+int dppo_unet_ppo_loss_fwd_bwd_obs(const dppo_unet_desc* actor, const dppo_net_desc* critic, int prec, const float* actor_params,
+                                   const void* actor_packed, const float* critic_params, const void* critic_packed,
+                                   const dppo_diffusion_cfg* dcfg, const dppo_ppo_cfg* pcfg, const dppo_step* ksteps,
+                                   const float* obs_k, const float* chains_k, const float* returns_k, const float* values_k,
+                                   const float* adv_k, const float* logprobs_k, const int64_t* kinds, int64_t N,
+                                   const double* global_moments, float* actor_grad, float* critic_grad, double* stats,
+                                   void* workspace, int64_t workspace_bytes, dppo_stream_t stream, const dppo_obs_io* io);
+int dppo_denoise_mse_fwd_bwd_obs(const dppo_net_desc* actor, int prec, const float* params, const void* packed,
+                                 const dppo_step* tsteps, int n_time, const float* obs, const float* pairs,
+                                 const int64_t* kinds, int64_t N, float* grad, double* loss, void* workspace,
+                                 int64_t workspace_bytes, dppo_stream_t stream, float* d_obs);
+int dppo_unet_denoise_mse_fwd_bwd_obs(const dppo_unet_desc* net, int prec, const float* params, const void* packed,
+                                      const dppo_step* tsteps, int n_time, const float* obs, const float* pairs,
+                                      const int64_t* kinds, int64_t N, float* grad, double* loss, void* workspace,
+                                      int64_t workspace_bytes, dppo_stream_t stream, float* d_obs);
+
 /* ---- 8f row 2 (pixel observations): ViT patch encoder + SpatialEmb ------------------------------------------------
  * Replaces model/common/vit.py:28-62 (VitEncoder: PatchEmbed2 = Conv2d(k8,s4) -> ReLU -> Conv2d(k3,s2), + pos_embed,
  * `depth` pre-norm TransformerLayers, final LayerNorm) and model/common/modules.py:10-41 (SpatialEmb), assembled as

@@ -197,3 +197,107 @@ def test_hip_vision_networks_forward(golden, name, prec, tol):
     val = c(cond).cpu().numpy()
     np.testing.assert_allclose(eps, g[f"{name}_eps"], rtol=tol, atol=tol * float(np.abs(g[f"{name}_eps"]).max()))
     np.testing.assert_allclose(val, g[f"{name}_value"], rtol=tol, atol=tol * max(1.0, float(np.abs(g[f"{name}_value"]).max())))
+
+
+def hip_vision_model(name, seed, prec, kw):
+    from dppo_amd.model.diffusion.diffusion_ppo import PPODiffusion
+    from dppo_amd.model.diffusion.eta import EtaFixed
+    v, trunk, cspec = net_specs(name)
+    kw = dict(dict(randn_clip_value=3), **kw)
+    if kw.get("use_ddim"):
+        kw["eta"] = EtaFixed(base_eta=1.0)
+    actor = hip_vision_actor(v, trunk, O.vision_init_params(v, trunk, seed), prec)
+    critic = hip_vit_critic(v, cspec, O.vision_init_params(v, cspec, seed + 2), prec)
+    m = PPODiffusion(actor=actor, critic=critic, horizon_steps=trunk.horizon_steps, obs_dim=v.prop_dim,
+                     action_dim=trunk.action_dim, device="cuda:0", gamma_denoising=0.99, precision=prec, **kw)
+    m.actor_ft.load_state_dict({k: t.cuda() for k, t in O.vision_init_params(v, trunk, seed + 1).items()}, strict=True)
+    m.actor_ft.mark_updated()
+    return m, v, trunk, cspec
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", sorted(VIS_CHAIN_CASES))
+def test_hip_vision_chains_and_logprobs(golden, case, prec):
+    """K-step sampling with recorded noise and the log-probs of the reference's chains, pixels in; the frozen and the fine-tuned
+    network each encode with their own ViT (vunet_two_ddpm20_ft10 switches networks mid-chain)."""
+    g = golden("g16_vision")
+    name, B, kw, det = VIS_CHAIN_CASES[case]
+    m, v, trunk, _ = hip_vision_model(name, 21, prec, dict(kw, clip_ploss_coef=0.01))
+    cond = cuda_cond(g, case, u8=True)
+    smp = m(cond=cond, deterministic=det, return_chain=True, noise=T(g[f"{case}_noise"]).cuda())
+    lp = m.get_logprobs(cond, T(g[f"{case}_chains"]).cuda())
+    if prec == "fp32":
+        np.testing.assert_allclose(smp.chains.cpu().numpy(), g[f"{case}_chains"], rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(smp.trajectories.cpu().numpy(), g[f"{case}_traj"], rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(lp.cpu().numpy(), g[f"{case}_logprobs"], rtol=2e-3, atol=2e-3)
+    else:  # bf16 operands: the chain stays on the reference's within the step noise scale
+        err = np.abs(smp.chains.cpu().numpy() - g[f"{case}_chains"])
+        assert float(err.mean()) < 0.05 and np.isfinite(lp.cpu().numpy()).all()
+
+
+def vis_grad_report(g, prefix, named_grads):
+    from tests.test_unet import grad_report
+    return grad_report(g, prefix, named_grads)
+
+
+@pytest.mark.gpu
+def test_hip_encoder_backward_against_autograd():
+    """dppo_vis_backward alone: d(sum(obs * R)) / d(encoder parameters) against torch autograd on the oracle (fp32)."""
+    v = O.VisSpec(**VIS_SPECS["vis_small"])
+    cspec = O.NetSpec("critic", cond_dim=v.feat_dim + v.prop_dim, mlp_dims=[256, 256, 256], activation="Mish", residual=True)
+    p = O.vision_init_params(v, cspec, 5)
+    rs = np.random.RandomState(0)
+    B = 7
+    rgb = (rs.randint(0, 256, size=(B, v.in_ch // 3, 3, v.img_h, v.img_w))).astype(np.uint8)
+    state = rs.uniform(-1, 1, size=(B, 1, v.prop_dim)).astype(np.float32)
+    R = rs.normal(0, 1, size=(B, v.feat_dim + v.prop_dim)).astype(np.float32)
+    pr = {k: t.clone().requires_grad_(True) for k, t in p.items() if not k.startswith("Q1")}
+    obs_ref = O.vis_features(pr, v, T(rgb), T(state))
+    (obs_ref * T(R)).sum().backward()
+    m = hip_vit_critic(v, cspec, p, "fp32")
+    obs = m.encode_obs({"rgb": T(rgb).cuda(), "state": T(state).cuda()}, train=True)
+    np.testing.assert_allclose(obs.cpu().numpy(), obs_ref.detach().numpy(), rtol=3e-4, atol=3e-4)
+    m.vis.backward(T(R).cuda())
+    names = [n for n, _, _ in O.vis_param_shapes(v)]
+    for n, gv in zip(names, m.vis.grad_views()):
+        ref = pr[n].grad.numpy()
+        err = np.linalg.norm(gv.cpu().numpy() - ref) / (np.linalg.norm(ref) + 1e-12)
+        assert err < 2e-3, (n, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(VIS_LOSS_CASES))
+def test_hip_vision_ppo_loss_and_grads(golden, case):
+    """PPODiffusion.loss with pixel networks (fp32): statistics and EVERY gradient -- ViT, SpatialEmb and trunk of the
+    fine-tuned actor and of the critic -- against the reference's autograd."""
+    g = golden("g17_vision_loss")
+    name, N, kw, rh = VIS_LOSS_CASES[case]
+    m, v, trunk, cspec = hip_vision_model(name, 31, "fp32", kw)
+    d = lambda k: T(g[f"{case}_{k}"]).cuda()
+    res = m.loss(cuda_cond(g, case, u8=True), d("prev"), d("next"), d("kinds"), d("returns"), d("oldvalues"), d("adv"),
+                 d("oldlogprobs"), use_bc_loss=False, reward_horizon=rh)
+    got = np.array([res[0].item(), float(res[1]), res[2].item(), res[3], res[4], res[5], float(res[6]), res[7]])
+    np.testing.assert_allclose(got, g[f"{case}_stats"], rtol=2e-3, atol=2e-5)
+    (res[0] + 0.5 * res[2]).backward()
+    (worst, e), nerr = vis_grad_report(g, f"{case}_gactor", [(k, p.grad) for k, p in m.actor_ft.named_parameters()])
+    assert e < 2e-2 and nerr < 2e-3, ("actor", worst, e, nerr)
+    (worst, e), nerr = vis_grad_report(g, f"{case}_gcritic", [(k, p.grad) for k, p in m.critic.named_parameters()])
+    assert e < 5e-3 and nerr < 1e-3, ("critic", worst, e, nerr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(VIS_MSE_CASES))
+def test_hip_vision_denoise_mse_and_grads(golden, case):
+    g = golden("g17_vision_loss")
+    name, K, N = VIS_MSE_CASES[case]
+    m, v, trunk, _ = hip_vision_model(name, 51, "fp32", dict(denoising_steps=K, ft_denoising_steps=min(10, K), clip_ploss_coef=0.01))
+    net = m.network
+    for p in net.parameters():
+        p.requires_grad_(True)
+    d = lambda k: T(g[f"{case}_{k}"]).cuda()
+    loss = m.p_losses(d("x0"), cuda_cond(g, case, u8=True), d("t"), noise=d("noise"))
+    assert float(loss.detach()) == pytest.approx(float(g[f"{case}_loss"]), rel=2e-4)
+    loss.backward()
+    (worst, e), nerr = vis_grad_report(g, f"{case}_g", [(k, p.grad) for k, p in net.named_parameters()])
+    assert e < 5e-3 and nerr < 1e-3, (worst, e, nerr)
