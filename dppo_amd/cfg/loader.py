@@ -56,7 +56,11 @@ _TOKEN = re.compile(r"\$\{([^${}]*)\}")
 def _lookup(root, path):
     cur = root
     for part in path.split("."):
-        cur = cur[int(part)] if isinstance(cur, list) else cur[part]
+        m = re.fullmatch(r"([^\[\]]+)((?:\[\d+\])*)", part)  # OmegaConf's `key[i]` (shape_meta.obs.rgb.shape[1])
+        key, idx = (m.group(1), re.findall(r"\[(\d+)\]", m.group(2))) if m else (part, [])
+        cur = cur[int(key)] if isinstance(cur, list) else cur[key]
+        for i in idx:
+            cur = cur[int(i)]
     return cur
 
 

@@ -52,11 +52,42 @@ class SyntheticVecEnv:
         return self._obs(), reward, terminated, truncated, [{} for _ in range(self.n_envs)]
 
 
+class SyntheticPixelVecEnv(SyntheticVecEnv):
+    """The same linear system observed through a camera: obs = {"state": the first ``state_dim`` coordinates, "rgb": uint8
+    (n_envs, n_obs_steps, C, H, W)} -- a bright square per camera whose position follows two state coordinates over a fixed
+    gradient background (C = 3 per camera).  Exercises the pixel path of the agent without robomimic / robosuite."""
+
+    def __init__(self, n_envs, state_dim, action_dim, rgb_shape, n_obs_steps=1, n_action_steps=4, max_episode_steps=1000, seed=0):
+        super().__init__(n_envs, max(state_dim, 4), action_dim, n_obs_steps, n_action_steps, max_episode_steps, seed)
+        self.state_dim, self.rgb_shape = state_dim, tuple(rgb_shape)
+        C, H, W = self.rgb_shape
+        yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+        self.bg = np.stack([(xx * 255 // max(W - 1, 1)), (yy * 255 // max(H - 1, 1)), ((xx + yy) * 127 // max(H + W - 2, 1))] *
+                           (C // 3)).astype(np.uint8)
+
+    def _obs(self):
+        C, H, W = self.rgb_shape
+        o = np.clip(self.x, -1, 1).astype(np.float32)
+        rgb = np.broadcast_to(self.bg, (self.n_envs, C, H, W)).copy()
+        side = max(H // 8, 2)
+        for cam in range(C // 3):
+            cx = ((o[:, (2 * cam) % self.obs_dim] * 0.5 + 0.5) * (W - side)).astype(np.int64)
+            cy = ((o[:, (2 * cam + 1) % self.obs_dim] * 0.5 + 0.5) * (H - side)).astype(np.int64)
+            for i in range(self.n_envs):
+                rgb[i, 3 * cam:3 * cam + 3, cy[i]:cy[i] + side, cx[i]:cx[i] + side] = 255
+        return {"state": np.repeat(o[:, None, :self.state_dim], self.n_obs_steps, axis=1),
+                "rgb": np.repeat(rgb[:, None], self.n_obs_steps, axis=1)}
+
+
 def make_venv(cfg):
     """cfg.env.name == 'synthetic' -> SyntheticVecEnv; anything else needs the reference's env stack."""
     env = cfg.env
     groups = int(env.get("pipeline_groups", 1))  # > 1: env groups stepped on the host while the device samples the others
     assert env.n_envs % groups == 0, "env.n_envs must be divisible by env.pipeline_groups"
+    if str(env.name).startswith("synthetic-img"):
+        assert groups == 1, "the pixel stand-in is not pipelined over env groups"
+        return SyntheticPixelVecEnv(env.n_envs, cfg.obs_dim, cfg.action_dim, list(cfg.shape_meta.obs.rgb.shape), cfg.cond_steps,
+                                    cfg.act_steps, env.get("max_episode_steps", 1000), cfg.get("seed", 42))
     if str(env.name).startswith("synthetic"):
         mk = lambda g: SyntheticVecEnv(env.n_envs // groups, cfg.obs_dim, cfg.action_dim, cfg.cond_steps, cfg.act_steps,
                                        env.get("max_episode_steps", 1000), cfg.get("seed", 42) + g * (env.n_envs // groups))

@@ -338,3 +338,158 @@ def test_agent_fine_tunes_a_conv_denoiser(tmp_path, monkeypatch):
     assert not torch.equal(agent.model.actor_ft.flat_params(), w0) and torch.equal(agent.model.actor.flat_params(), base0)
     ck = torch.load(os.path.join(str(tmp_path), "synthetic", "checkpoint", "state_2.pt"), weights_only=True)
     assert "actor_ft.down_modules.0.0.blocks.0.block.0.weight" in ck["model"] and "actor_ft.final_conv.1.bias" in ck["model"]
+
+
+# ------------------------------------------------------------------ pixel observations (BASELINE configs[4])
+IMG_YAML = textwrap.dedent("""
+    _target_: dppo.agent.finetune.train_ppo_diffusion_img_agent.TrainPPOImgDiffusionAgent
+    logdir: ${oc.env:DPPO_LOG_DIR}/synthetic-img
+    seed: 42
+    device: cuda:0
+    obs_dim: 5
+    action_dim: 3
+    denoising_steps: 100
+    ft_denoising_steps: 5
+    cond_steps: 1
+    img_cond_steps: 1
+    horizon_steps: 4
+    act_steps: 4
+    use_ddim: True
+    wandb: null
+    env:
+      n_envs: 4
+      name: synthetic-img
+      max_episode_steps: 40
+      reset_at_iteration: False
+      best_reward_threshold_for_success: 3
+    shape_meta:
+      obs:
+        rgb:
+          shape: [RGB_C, 40, 40]
+        state:
+          shape: [5]
+      action:
+        shape: [3]
+    train:
+      n_train_itr: 3
+      n_critic_warmup_itr: 0
+      n_steps: 10
+      gamma: 0.99
+      augment: True
+      grad_accumulate: 2
+      actor_lr: 1e-4
+      actor_weight_decay: 0
+      actor_lr_scheduler: {first_cycle_steps: 1000, warmup_steps: 10, min_lr: 1e-4}
+      critic_lr: 1e-3
+      critic_weight_decay: 0
+      critic_lr_scheduler: {first_cycle_steps: 1000, warmup_steps: 10, min_lr: 1e-3}
+      save_model_freq: 100
+      val_freq: 2
+      reward_scale_running: True
+      reward_scale_const: 1.0
+      gae_lambda: 0.95
+      batch_size: 50
+      logprob_batch_size: 20
+      update_epochs: 2
+      vf_coef: 0.5
+      target_kl: 1
+      max_grad_norm: 1.0
+    model:
+      _target_: dppo.model.diffusion.diffusion_ppo.PPODiffusion
+      gamma_denoising: 0.99
+      clip_ploss_coef: 0.01
+      clip_ploss_coef_base: 0.001
+      clip_ploss_coef_rate: 3
+      randn_clip_value: 3
+      min_sampling_denoising_std: 0.1
+      min_logprob_denoising_std: 0.1
+      use_ddim: ${use_ddim}
+      ddim_steps: ${ft_denoising_steps}
+      learn_eta: False
+      eta:
+        base_eta: 1
+        input_dim: ${obs_dim}
+        mlp_dims: [256, 256]
+        action_dim: ${action_dim}
+        min_eta: 0.1
+        max_eta: 1.0
+        _target_: dppo.model.diffusion.eta.EtaFixed
+      network_path: null
+      actor:
+        ACTOR
+        backbone:
+          _target_: dppo.model.common.vit.VitEncoder
+          obs_shape: ${shape_meta.obs.rgb.shape}
+          num_channel: ${eval:'3 * ${img_cond_steps}'}
+          img_h: ${shape_meta.obs.rgb.shape[1]}
+          img_w: ${shape_meta.obs.rgb.shape[2]}
+          cfg: {patch_size: 8, depth: 1, embed_dim: 128, num_heads: 4, embed_style: embed2, embed_norm: 0}
+        augment: False
+        spatial_emb: 128
+        num_img: NUM_IMG
+        img_cond_steps: ${img_cond_steps}
+        cond_dim: ${eval:'${obs_dim} * ${cond_steps}'}
+        action_dim: ${action_dim}
+      critic:
+        _target_: dppo.model.common.critic.ViTCritic
+        spatial_emb: 128
+        augment: False
+        num_img: NUM_IMG
+        backbone:
+          _target_: dppo.model.common.vit.VitEncoder
+          obs_shape: ${shape_meta.obs.rgb.shape}
+          num_channel: ${eval:'3 * ${img_cond_steps}'}
+          img_h: ${shape_meta.obs.rgb.shape[1]}
+          img_w: ${shape_meta.obs.rgb.shape[2]}
+          cfg: {patch_size: 8, depth: 1, embed_dim: 128, num_heads: 4, embed_style: embed2, embed_norm: 0}
+        img_cond_steps: ${img_cond_steps}
+        mlp_dims: [256, 256, 256]
+        activation_type: Mish
+        residual_style: True
+        cond_dim: ${eval:'${obs_dim} * ${cond_steps}'}
+      ft_denoising_steps: ${ft_denoising_steps}
+      horizon_steps: ${horizon_steps}
+      obs_dim: ${obs_dim}
+      action_dim: ${action_dim}
+      denoising_steps: ${denoising_steps}
+      device: ${device}
+""")
+IMG_ACTORS = {  # (the lines of the actor block after dedent: four spaces of indentation)
+    "mlp": ("\n    ".join(["_target_: dppo.model.diffusion.mlp_diffusion.VisionDiffusionMLP", "time_dim: 32",
+                           "mlp_dims: [256, 256, 256]", "residual_style: True", "horizon_steps: ${horizon_steps}"]), 1),
+    "unet_two_cameras": ("\n    ".join(["_target_: dppo.model.diffusion.unet.VisionUnet1D", "diffusion_step_embed_dim: 32",
+                                        "dim: 64", "dim_mults: [1, 2]", "kernel_size: 5", "n_groups: 8",
+                                        "smaller_encoder: False", "cond_predict_scale: True"]), 2),
+}
+
+
+@pytest.mark.parametrize("kind", sorted(IMG_ACTORS))
+def test_agent_fine_tunes_from_pixels(tmp_path, monkeypatch, kind):
+    """TrainPPOImgDiffusionAgent on the synthetic camera env: rollout with {"rgb", "state"}, buffer augmentation, value /
+    log-prob precompute, gradient accumulation over two minibatches per optimiser step, all four flat buffers (two encoders,
+    two trunks) move, the frozen policy does not, and the checkpoint carries the reference's parameter names."""
+    from dppo_amd.cfg.loader import get_class, load_config
+    monkeypatch.setenv("DPPO_LOG_DIR", str(tmp_path))
+    actor, num_img = IMG_ACTORS[kind]
+    p = tmp_path / "ft_img.yaml"
+    p.write_text(IMG_YAML.replace("ACTOR", actor).replace("NUM_IMG", str(num_img)).replace("RGB_C", str(3 * num_img)))
+    cfg = load_config(str(p))
+    agent = get_class(cfg._target_)(cfg)
+    m = agent.model
+    before = [t.clone() for t in (m.actor_ft.flat_params(), m.actor_ft.vis.flat_params(), m.critic.flat_params(),
+                                  m.critic.vis.flat_params())]
+    base0, basev0 = m.actor.flat_params().clone(), m.actor.vis.flat_params().clone()
+    res = agent.run()
+    assert len(res) == 3 and "eval_episode_reward" in res[0] and "pg_loss" in res[1]
+    assert np.isfinite(res[1]["loss"]) and np.isfinite(res[1]["v_loss"]) and res[1]["approx_kl"] < 1.0
+    after = (m.actor_ft.flat_params(), m.actor_ft.vis.flat_params(), m.critic.flat_params(), m.critic.vis.flat_params())
+    for name, b, a in zip(("actor trunk", "actor encoder", "critic trunk", "critic encoder"), before, after):
+        assert not torch.equal(a, b), name + " was not updated"
+        assert torch.isfinite(a).all(), name
+    assert torch.equal(m.actor.flat_params(), base0) and torch.equal(m.actor.vis.flat_params(), basev0)
+    ck = torch.load(os.path.join(str(tmp_path), "synthetic-img", "checkpoint", "state_2.pt"), weights_only=True)
+    head = "compress" if num_img == 1 else "compress1"
+    for key in ("actor_ft.backbone.vit.pos_embed", f"actor_ft.{head}.input_proj.0.weight", "critic.Q1.layers.0.weight",
+                "critic.backbone.vit.net.0.mha.qkv_proj.weight"):
+        assert key in ck["model"], key
+    assert torch.equal(ck["model"]["actor_ft.backbone.vit.pos_embed"].cpu(), m.actor_ft.backbone.vit.pos_embed.detach().cpu())

@@ -199,3 +199,41 @@ def test_every_shipped_state_unet_gaussian_and_eval_cfg_builds():
             assert get_class(cfg.model._target_) is DiffusionEval, p
             n_eval += 1
     assert n_eval >= 10
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason="reference checkout not present (GPU box)")
+def test_every_shipped_pixel_diffusion_cfg_builds():
+    """The image cfgs (ft_ppo_diffusion_{mlp,unet}_img.yaml, pre_diffusion_{mlp,unet}_img.yaml, eval_diffusion_*_img.yaml):
+    the pixel networks build on CPU, their state dict splits into encoder | trunk in the C ABI's two flat layouts, and the
+    fine-tuning cfgs resolve to the image agent with a ViTCritic."""
+    import ctypes as C
+    import glob
+
+    from dppo_amd import hip
+    from dppo_amd.model.common.critic import ViTCritic
+    os.environ.setdefault("DPPO_LOG_DIR", "/tmp/log")
+    os.environ.setdefault("DPPO_DATA_DIR", "/tmp/data")
+    os.environ.setdefault("DPPO_WANDB_ENTITY", "none")
+    lib = hip.load()
+    n = 0
+    for pat in ("*/finetune/*/ft_ppo_diffusion_mlp_img.yaml", "*/finetune/*/ft_ppo_diffusion_unet_img.yaml",
+                "*/pretrain/*/pre_diffusion_mlp_img.yaml", "*/pretrain/*/pre_diffusion_unet_img.yaml",
+                "*/eval/*/eval_diffusion_mlp_img.yaml", "*/eval/*/eval_diffusion_unet_img.yaml"):
+        for p in sorted(glob.glob(os.path.join(REF_CFG, pat))):
+            cfg = load_config(p, overrides=["device=cpu"])
+            node = cfg.model.actor if "actor" in cfg.model else cfg.model.network
+            net = instantiate(node)
+            assert getattr(net, "is_vision", False), p
+            if getattr(net, "is_unet", False):
+                net.horizon_steps = int(cfg.horizon_steps)
+            vis = net.vis
+            assert lib.dppo_vis_param_count(C.byref(vis.desc)) == sum(q.numel() for q in vis.trunk_parameters()), (p, lib.dppo_last_error())
+            assert lib.dppo_vis_workspace_bytes(C.byref(vis.desc), hip.PREC_BF16, 64, 1) > 0
+            assert vis.desc.num_img == (2 if "transport" in p else 1)
+            assert net._abi_param_count() == sum(q.numel() for q in net.trunk_parameters()), p
+            assert len(list(net.parameters())) == len(vis.trunk_parameters()) + len(net.trunk_parameters())
+            if "finetune" in p:
+                assert get_class(cfg._target_).__name__ == "TrainPPOImgDiffusionAgent", p
+                assert isinstance(instantiate(cfg.model.critic), ViTCritic), p
+            n += 1
+    assert n >= 20
