@@ -1049,7 +1049,7 @@ static int sample_impl(const dppo_net_desc& d, const float* pb, const char* kb, 
   a.has_dclip = cfg.has_denoised_clip, a.has_eclip = cfg.has_eps_clip, a.has_fclip = cfg.has_final_clip;
   a.dclip = cfg.denoised_clip, a.eclip = cfg.eps_clip, a.rclip = cfg.randn_clip, a.fclip = cfg.final_clip;
   const int rc = launch_sample_chain<P>(g, a, s);
-  if (rc == -1) return fail(-1, "sampler: hidden=%d / out_dim=%d not instantiated (hidden in {256,512,1024}, out_dim <= 128)", d.hidden, d.out_dim);
+  if (rc == -1) return fail(-1, "sampler: hidden=%d / out_dim=%d not instantiated (hidden in {256,512,768,1024}, out_dim <= 128)", d.hidden, d.out_dim);
   if (rc == -2) return fail(-1, "sampler: LDS image exceeds 160 KiB for hidden=%d at this precision", d.hidden);
   return check_launch();
 }

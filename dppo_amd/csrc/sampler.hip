@@ -454,6 +454,9 @@ int launch_sample_chain(const SamplerGeom& g, const SampleArgs& a, hipStream_t s
   DPPO_CASE(2, 8)
   DPPO_CASE(4, 8)
   DPPO_CASE(8, 8)
+  DPPO_CASE(6, 1)  // hidden 768: the robomimic square / transport image actors (mlp_dims [768, 768, 768])
+  DPPO_CASE(6, 4)
+  DPPO_CASE(6, 8)
 #undef DPPO_CASE
   return -1;
 }

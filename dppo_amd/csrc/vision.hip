@@ -433,13 +433,22 @@ __global__ __launch_bounds__(256) void vis_spatial_bwd_kernel(const float* y, co
     gpart[((size_t)ck * D + d) * 2 * S + S + c] = red[0][2][c] + red[1][2][c] + red[2][2][c] + red[3][2][c];
   }
 }
-// out[i] = sum_k part[k][i]  (fixed order)
-__global__ void vis_reduce_rows_kernel(const float* part, int K, size_t n, float* out, int accumulate) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+// out[i] = sum_k part[k][i]  (fixed order): 16 columns x 16 row-lanes per workgroup, so K partial rows cost K / 16 dependent
+// steps instead of K
+__global__ __launch_bounds__(256) void vis_reduce_rows_kernel(const float* part, int K, size_t n, float* out, int accumulate) {
+  __shared__ float red[16][17];
+  const int c = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const size_t i = (size_t)blockIdx.x * 16 + c;
   float s = 0.f;
-  for (int k = 0; k < K; ++k) s += part[(size_t)k * n + i];
-  out[i] = accumulate ? out[i] + s : s;
+  if (i < n)
+    for (int k = rl; k < K; k += 16) s += part[(size_t)k * n + i];
+  red[rl][c] = s;
+  __syncthreads();
+  if (rl == 0 && i < n) {
+    float t = 0.f;
+    for (int k = 0; k < 16; ++k) t += red[k][c];
+    out[i] = accumulate ? out[i] + t : t;
+  }
 }
 // dfeats[img][p][d] (f32) = dXs[(img * D + d)][p]
 template <class P>
@@ -590,24 +599,42 @@ __global__ __launch_bounds__(256) void vis_col2im2_kernel(const typename P::elem
   typename P::elem_t* o = dz1 + m1 * D + ch * V;
   for (int k = 0; k < V; ++k) o[k] = P::from_f32(P::to_f32(a[k]) > 0.f ? acc[k] : 0.f);
 }
-// dpos[p][c] = sum over images of dx0[img][p][c]
-__global__ void vis_pos_grad_kernel(const float* dx0, int64_t NI, int PD, float* dpos) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= PD) return;
-  float s = 0.f;
-  for (int64_t n = 0; n < NI; ++n) s += dx0[n * PD + i];
-  dpos[i] = s;
-}
-// column sums, two stages (fixed order)
+// column sums, two stages (fixed order).  Stage 1: a workgroup covers CT * 8 columns (16-/32-byte loads, CT = min(N / 8, 32)
+// threads across) with 256 / CT row-lanes over its chunk of the rows; part[row chunk][N].  N % 8 == 0.
 template <class P, bool ELEM>
-__global__ __launch_bounds__(256) void vis_colsum1_kernel(const void* A, int64_t M, int N, int lda, float* part, int blocks) {
-  const int64_t per = (M + blocks - 1) / blocks, r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < M ? r0 + per : M;
-  for (int c = threadIdx.x; c < N; c += 256) {
-    float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r)
-      s += ELEM ? P::to_f32(((const typename P::elem_t*)A)[r * lda + c]) : ((const float*)A)[r * lda + c];
-    part[(size_t)blockIdx.x * N + c] = s;
-  }
+__global__ __launch_bounds__(256) void vis_colsum1_kernel(const void* A, int64_t M, int N, int lda, float* part, int CT) {
+  __shared__ float red[256][9];
+  const int ct = threadIdx.x % CT, rl = threadIdx.x / CT, RL = 256 / CT;
+  const int c0 = (blockIdx.x * CT + ct) * 8;
+  const int64_t per = (M + gridDim.y - 1) / gridDim.y, r0 = (int64_t)blockIdx.y * per, r1 = r0 + per < M ? r0 + per : M;
+  float acc[8];
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  if (c0 < N)
+    for (int64_t r = r0 + rl; r < r1; r += RL) {
+      if (ELEM) {
+        const typename P::elem_t* p = (const typename P::elem_t*)A + r * lda + c0;
+        if constexpr (P::ESIZE == 2) {
+          const u32x4 v = *(const u32x4*)p;
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+          for (int k = 0; k < 4; ++k) acc[2 * k] += bf2f((uint16_t)(w[k] & 0xffff)), acc[2 * k + 1] += bf2f((uint16_t)(w[k] >> 16));
+        } else {
+          const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+          acc[0] += a.x, acc[1] += a.y, acc[2] += a.z, acc[3] += a.w, acc[4] += b.x, acc[5] += b.y, acc[6] += b.z, acc[7] += b.w;
+        }
+      } else {
+        const float* p = (const float*)A + r * lda + c0;
+        const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+        acc[0] += a.x, acc[1] += a.y, acc[2] += a.z, acc[3] += a.w, acc[4] += b.x, acc[5] += b.y, acc[6] += b.z, acc[7] += b.w;
+      }
+    }
+  for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = acc[k];
+  __syncthreads();
+  if (rl == 0 && c0 < N)
+    for (int k = 0; k < 8; ++k) {
+      float t = 0.f;
+      for (int j = 0; j < RL; ++j) t += red[j * CT + ct][k];
+      part[(size_t)blockIdx.y * N + c0 + k] = t;
+    }
 }
 // out[r * ldo + c] = sum_s slab[s][r][c] for c < N2v; mode 1: conv2 unpack out[(o * D + i) * 9 + kk] <- [o][kk * D + i]
 __global__ void vis_slab_out_kernel(const float* slab, int splits, int N1, int N2, int N2v, float* out, int ldo, int mode, int D) {
@@ -673,9 +700,14 @@ struct VisRunner {
       dy = elems((size_t)NI * D * L.S), dXs = elems((size_t)NI * D * L.Pp), dxe = elems((size_t)M2 * D);
       dA = elems((size_t)M2 * 4 * D), dqkv = elems((size_t)M2 * 3 * D), dcols2 = elems((size_t)M2 * L.K2), dz1 = elems((size_t)M1 * D);
       dfa = f32s((size_t)M2 * D), dfb = f32s((size_t)M2 * D), dh = f32s((size_t)M2 * D);
-      slab_floats = (size_t)32 * D * (L.K2 > L.K1p ? L.K2 : L.K1p);
+      slab_floats = (size_t)64 * D * (L.K2 > L.K1p ? L.K2 : L.K1p);  // >= 128 splits of a D x 4D output, 64 of the D x 9D one
       slab = f32s(slab_floats);
-      part = f32s((size_t)8 * D * 3 * L.S > (size_t)256 * 2 * 512 ? (size_t)8 * D * 3 * L.S : (size_t)256 * 2 * 512);
+      {  // partial sums: SpatialEmb (8 chunks of D x 3S), LayerNorm (1024 blocks x 2D), column sums (<= 512 chunks of 256 columns + N)
+        size_t pf = (size_t)8 * D * 3 * L.S;
+        const size_t ln = (size_t)1024 * 2 * D, cs = (size_t)768 * 256 + 2 * (size_t)L.P * D + 4 * (size_t)L.K2;
+        pf = pf > ln ? pf : ln;
+        part = f32s((pf > cs ? pf : cs) + 4096);
+      }
     }
   }
   size_t bytes() const { return al(off); }
@@ -770,8 +802,12 @@ struct VisRunner {
   // ---- backward helpers
   // out[N1][ldo] (first N2v columns) = A^T . B over M rows
   void wgrad(const void* A, int lda, int N1, const void* Bm, int ldb, int N2, int N2v, int64_t M, float* out, int ldo, int mode = 0) {
-    int64_t splits = (M + 4095) / 4096;
-    if (splits > 32) splits = 32;
+    // the outputs are small (one to a few dozen 128 x 128 tiles) and M is large: split the rows until ~512 workgroups exist
+    const int64_t tiles = (int64_t)((N1 + 127) / 128) * ((N2 + 127) / 128);
+    int64_t splits = (512 + tiles - 1) / tiles;
+    if (splits > (M + 255) / 256) splits = (M + 255) / 256;
+    if (splits > 128) splits = 128;
+    if (splits < 1) splits = 1;
     while (splits > 1 && (size_t)splits * N1 * N2 > slab_floats) --splits;
     int64_t rps = ((M + splits - 1) / splits + 63) / 64 * 64;
     splits = (M + rps - 1) / rps;
@@ -785,23 +821,29 @@ struct VisRunner {
                        ldo, mode, L.D);
   }
   void colsum(const void* A, bool elem, int64_t M, int N, int lda, float* out) {
-    const int blocks = 64;
+    const int CT = N / 8 < 32 ? N / 8 : 32;
+    const int cb = (N / 8 + CT - 1) / CT;
+    int rb = (int)((M + 255) / 256);  // >= 256 rows per workgroup
+    const int cap = (512 + cb - 1) / cb;
+    rb = rb < 1 ? 1 : (rb > cap ? cap : rb);
     if (elem)
-      hipLaunchKernelGGL((vis_colsum1_kernel<P, true>), dim3(blocks), dim3(256), 0, s, A, M, N, lda, part, blocks);
+      hipLaunchKernelGGL((vis_colsum1_kernel<P, true>), dim3(cb, rb), dim3(256), 0, s, A, M, N, lda, part, CT);
     else
-      hipLaunchKernelGGL((vis_colsum1_kernel<P, false>), dim3(blocks), dim3(256), 0, s, A, M, N, lda, part, blocks);
-    hipLaunchKernelGGL(vis_reduce_rows_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, blocks, (size_t)N, out, 0);
+      hipLaunchKernelGGL((vis_colsum1_kernel<P, false>), dim3(cb, rb), dim3(256), 0, s, A, M, N, lda, part, CT);
+    reduce_rows(part, rb, (size_t)N, out);
+  }
+  void reduce_rows(const float* src, int K, size_t n, float* out) {
+    hipLaunchKernelGGL(vis_reduce_rows_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, src, K, n, out, 0);
   }
   // dx = dres + LNbwd(dout); d gamma / d beta -> grad
   void ln_bwd(const float* dout, const float* xin, const float* stats, int64_t gw, int64_t gb, const float* dres, float* dx, E* dxe_,
               float* grad) {
-    const int blocks = 256;
+    const int blocks = M2 >= 16384 ? 1024 : 256;
     hipLaunchKernelGGL((vis_ln_bwd_kernel<P>), dim3(blocks), dim3(256), 0, s, dout, xin, stats, prm + gw, dres, M2, L.D, dx, dxe_,
                        part);
     // part [blocks][2 D] -> (d gamma | d beta): weight and bias of a LayerNorm are adjacent in the flat layout
     (void)gb;
-    hipLaunchKernelGGL(vis_reduce_rows_kernel, dim3((2 * L.D + 255) / 256), dim3(256), 0, s, part, blocks, (size_t)2 * L.D,
-                       grad + gw, 0);
+    reduce_rows(part, blocks, (size_t)2 * L.D, grad + gw);
   }
 
   // dobs (B, lddobs): d loss / d obs; the first S * nimg columns are read.  grad: flat, every entry written.
@@ -815,10 +857,9 @@ struct VisRunner {
       float* gpart = part + (size_t)chunks * D * S;
       hipLaunchKernelGGL((vis_spatial_bwd_kernel<P>), dim3(D, chunks), dim3(256), 0, s, y, sst, prm + c.w, prm + c.lnw, prm + c.lnb,
                          dobs, lddobs, n * S, D, S, B, (int64_t)n * B, chunks, dy, wpart, gpart);
-      hipLaunchKernelGGL(vis_reduce_rows_kernel, dim3((D * S + 255) / 256), dim3(256), 0, s, wpart, chunks, (size_t)D * S, grad + c.w, 0);
+      reduce_rows(wpart, chunks, (size_t)D * S, grad + c.w);
       // LayerNorm affine gradients: rows (chunk, d) of [2 S] -> one [2 S] vector (gamma | beta adjacent in the flat layout)
-      hipLaunchKernelGGL(vis_reduce_rows_kernel, dim3((2 * S + 255) / 256), dim3(256), 0, s, gpart, chunks * D, (size_t)2 * S,
-                         grad + c.lnw, 0);
+      reduce_rows(gpart, chunks * D, (size_t)2 * S, grad + c.lnw);
       wgrad(dy + r0 * S, S, S, Xs + r0 * L.Ksp, L.Ksp, L.Ksp, L.P + L.prop, B * D, grad + c.pw, L.P + L.prop);
       colsum(dy + r0 * S, true, B * D, S, S, grad + c.pb);
       gemm(dy + r0 * S, S, B * D, c.ppT, L.Pp, S, nullptr, nullptr, 0, dXs + r0 * L.Pp, nullptr, L.Pp, ACT_NONE);
@@ -855,7 +896,7 @@ struct VisRunner {
       ln_bwd(dh, x[2 * l], st[2 * l], v.ln1w, v.ln1b, dalt, dcur, dxe, grad);  // dcur = d x_i
     }
     // x_0 = conv2(relu(conv1(img))) + pos
-    hipLaunchKernelGGL(vis_pos_grad_kernel, dim3((L.P * D + 255) / 256), dim3(256), 0, s, dcur, NI, L.P * D, grad + L.pos);
+    colsum(dcur, false, NI, L.P * D, L.P * D, grad + L.pos);  // d pos[p][c] = sum over images
     wgrad(dxe, D, D, cols2, L.K2, L.K2, L.K2, M2, grad + L.c2w, 0, 1);
     colsum(dcur, false, M2, D, D, grad + L.c2b);
     gemm(dxe, D, M2, L.pc2T, L.K2, D, nullptr, nullptr, 0, dcols2, nullptr, L.K2, ACT_NONE);

@@ -96,6 +96,9 @@ VIS_CHAIN_CASES = {
     "vunet_ddim100_5": ("vunet_small", 4, dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
                                               randn_clip_value=3, min_sampling_denoising_std=0.1), False),
     "vunet_two_ddpm20_ft10": ("vunet_two", 3, dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3), False),
+    # the shipped square image actor: hidden 768 (cfg/robomimic/finetune/square/ft_ppo_diffusion_mlp_img.yaml:134-140)
+    "vmlp_square_ddim100_5": ("vmlp_square", 2, dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
+                                                    randn_clip_value=3, min_sampling_denoising_std=0.1), False),
 }
 VIS_LOSS_CASES = {
     # name: (net, N, model kwargs, reward_horizon)

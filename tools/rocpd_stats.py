@@ -23,7 +23,8 @@ agg = {}
 for r in rows:
     if r[ix["start"]] < cut:
         continue
-    n = re.sub(r"\(.*$", "", r[ix[name_c]])
+    n = r[ix[name_c]].replace("(anonymous namespace)::", "")
+    n = re.sub(r"\(.*$", "", n)
     n = re.sub(r"^void ", "", n)
     a = agg.setdefault(n, [0, 0])
     a[0] += 1
