@@ -22,6 +22,9 @@ static int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+namespace dppo {
+void set_vis_mfma_attn(int v);  // vision.hip
+}
 namespace dppo {  // the same two helpers for the other translation units that export entry points (unet.hip)
 int api_fail(int code, const char* msg) { return fail(code, "%s", msg); }
 int api_check_launch() {
@@ -2000,6 +2003,10 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 18) {
     g_post_one = value;
+    return 0;
+  }
+  if (knob == 20) {  // visual encoder: attention on the matrix cores (1, default) or the scalar kernels (0)
+    dppo::set_vis_mfma_attn(value);
     return 0;
   }
   return fail(-1, "unknown tuning knob %d", knob);

@@ -313,6 +313,191 @@ __global__ __launch_bounds__(128) void vis_attn_fwd_kernel(const typename P::ele
   }
 }
 
+// ---- attention on the matrix cores (bf16, head dimension 32, T <= 128 tokens: the shipped ViT) ------------------------------
+// One workgroup per (image, head), eight waves.  Scores are computed TRANSPOSED, S^T = K Q^T (A operand = a 16-key tile of K,
+// B operand = the wave's 16-query tile of Q; head dim 32 = one k-step), so that lane (r, g) of the MFMA result holds, for query
+// r, the keys 4g + e of each key tile: a query row lives in four lanes and the softmax reductions are two xor-shuffles.
+// Those registers, rounded to bf16 and packed two key tiles at a time, ARE a B operand whose k-slot (g, s) is key
+// 32 blk + 16 (s / 4) + 4 g + s % 4; the other operand (V^T, K^T, ...) is staged in LDS transposed with its columns in that
+// order (perm_col), so P.V and dS.K need no shuffle or LDS round trip of the probabilities.  The backward makes two passes:
+// per query tile (dQ) and per key tile (dK, dV: scores computed untransposed so the registers contract over queries).
+constexpr int AT_T = 128, AT_LD = 136;
+__device__ __forceinline__ int perm_col(int j) {
+  const int w = j & 31;
+  return (j & ~31) + ((w & 15) >> 2) * 8 + (w >> 4) * 4 + (w & 3);
+}
+__device__ __forceinline__ u32x4 pack8(const f32x4& a, const f32x4& b) {
+  u32x4 o;
+  o.x = (uint32_t)f2bf(a[0]) | ((uint32_t)f2bf(a[1]) << 16);
+  o.y = (uint32_t)f2bf(a[2]) | ((uint32_t)f2bf(a[3]) << 16);
+  o.z = (uint32_t)f2bf(b[0]) | ((uint32_t)f2bf(b[1]) << 16);
+  o.w = (uint32_t)f2bf(b[2]) | ((uint32_t)f2bf(b[3]) << 16);
+  return o;
+}
+__device__ __forceinline__ float xor4(float v, bool mx) {  // reduce over the four lanes (r, 0..3) that share a query row
+  const float a = __shfl_xor(v, 16, 64);
+  v = mx ? fmaxf(v, a) : v + a;
+  const float b = __shfl_xor(v, 32, 64);
+  return mx ? fmaxf(v, b) : v + b;
+}
+// dst[d][perm_col(j)] = src[j][d] for the 32 head columns, zero beyond T
+__device__ __forceinline__ void stage_transposed(uint16_t* dst, const uint16_t* src, int ld, int T) {
+  for (int i = threadIdx.x; i < AT_T * 32; i += blockDim.x) {
+    const int j = i >> 5, d = i & 31;
+    dst[d * AT_LD + perm_col(j)] = j < T ? src[(size_t)j * ld + d] : (uint16_t)0;
+  }
+}
+__device__ __forceinline__ u32x4 row_frag(const uint16_t* src, int ld, int row, int T, int g) {
+  return row < T ? *(const u32x4*)(src + (size_t)row * ld + 8 * g) : (u32x4){0, 0, 0, 0};
+}
+
+__global__ __launch_bounds__(512) void vis_attn_fwd_mfma_kernel(const uint16_t* qkv, int T, int D, int nh, float scale, uint16_t* att,
+                                                                float* lse) {
+  __shared__ __attribute__((aligned(16))) uint16_t VT[32 * AT_LD];
+  const int h = blockIdx.x % nh;
+  const int64_t img = blockIdx.x / nh;
+  const uint16_t* base = qkv + img * T * 3 * D + h * 32;
+  stage_transposed(VT, base + 2 * D, 3 * D, T);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, qt = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  if (16 * qt >= T) return;
+  const int i = 16 * qt + r;
+  const u32x4 qf = row_frag(base, 3 * D, i, T, g);
+  f32x4 p[8];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    p[t] = BF16::mma(row_frag(base + D, 3 * D, 16 * t + r, T, g), qf, (f32x4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      p[t][e] = 16 * t + 4 * g + e < T ? p[t][e] * scale : -INFINITY;
+      mx = fmaxf(mx, p[t][e]);
+    }
+  }
+  mx = xor4(mx, true);
+  float l = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      p[t][e] = __expf(p[t][e] - mx);
+      l += p[t][e];
+    }
+  l = xor4(l, false);
+  f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) {
+    const u32x4 pf = pack8(p[2 * blk], p[2 * blk + 1]);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+      o[dt] = BF16::mma(*(const u32x4*)(VT + (16 * dt + r) * AT_LD + 32 * blk + 8 * g), pf, o[dt]);
+  }
+  if (i < T) {
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      u32x2 w;
+      w.x = (uint32_t)f2bf(o[dt][0] * inv) | ((uint32_t)f2bf(o[dt][1] * inv) << 16);
+      w.y = (uint32_t)f2bf(o[dt][2] * inv) | ((uint32_t)f2bf(o[dt][3] * inv) << 16);
+      *(u32x2*)(att + (img * T + i) * D + h * 32 + 16 * dt + 4 * g) = w;
+    }
+    if (g == 0) lse[((size_t)img * nh + h) * T + i] = mx + __logf(l);
+  }
+}
+
+__global__ __launch_bounds__(512) void vis_attn_bwd_mfma_kernel(const uint16_t* qkv, const uint16_t* att, const uint16_t* datt,
+                                                                const float* lse, int T, int D, int nh, float scale, uint16_t* dqkv) {
+  __shared__ __attribute__((aligned(16))) uint16_t KT[32 * AT_LD], QT[32 * AT_LD], GT[32 * AT_LD];
+  __shared__ float Ls[AT_T], Ds[AT_T];
+  const int h = blockIdx.x % nh;
+  const int64_t img = blockIdx.x / nh;
+  const uint16_t* base = qkv + img * T * 3 * D + h * 32;
+  const uint16_t* gbase = datt + img * T * D + h * 32;
+  const uint16_t* obase = att + img * T * D + h * 32;
+  stage_transposed(QT, base, 3 * D, T);
+  stage_transposed(KT, base + D, 3 * D, T);
+  stage_transposed(GT, gbase, D, T);
+  for (int i = threadIdx.x; i < AT_T; i += blockDim.x) {
+    float dl = 0.f;
+    if (i < T)
+      for (int c = 0; c < 32; ++c) dl += bf2f(gbase[(size_t)i * D + c]) * bf2f(obase[(size_t)i * D + c]);
+    Ds[i] = dl;
+    Ls[i] = i < T ? lse[((size_t)img * nh + h) * T + i] : 1e30f;  // padded queries: exp(s - 1e30) = 0
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wt = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  if (16 * wt >= T) return;
+  uint16_t* dbase = dqkv + img * T * 3 * D + h * 32;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  {  // pass A: this wave's query tile -> dQ
+    const int i = 16 * wt + r;
+    const u32x4 qf = row_frag(base, 3 * D, i, T, g), gf = row_frag(gbase, D, i, T, g);
+    const float li = Ls[i], di = Ds[i];
+    f32x4 ds[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const f32x4 sa = BF16::mma(row_frag(base + D, 3 * D, 16 * t + r, T, g), qf, zero);
+      const f32x4 pa = BF16::mma(row_frag(base + 2 * D, 3 * D, 16 * t + r, T, g), gf, zero);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        ds[t][e] = 16 * t + 4 * g + e < T ? __expf(sa[e] * scale - li) * (pa[e] - di) : 0.f;
+    }
+    f32x4 dq[2] = {zero, zero};
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      const u32x4 bf = pack8(ds[2 * blk], ds[2 * blk + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        dq[dt] = BF16::mma(*(const u32x4*)(KT + (16 * dt + r) * AT_LD + 32 * blk + 8 * g), bf, dq[dt]);
+    }
+    if (i < T)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        u32x2 w;
+        w.x = (uint32_t)f2bf(dq[dt][0] * scale) | ((uint32_t)f2bf(dq[dt][1] * scale) << 16);
+        w.y = (uint32_t)f2bf(dq[dt][2] * scale) | ((uint32_t)f2bf(dq[dt][3] * scale) << 16);
+        *(u32x2*)(dbase + (size_t)i * 3 * D + 16 * dt + 4 * g) = w;
+      }
+  }
+  {  // pass B: this wave's key tile -> dK, dV (scores untransposed: lane (r, g) holds key r, queries 4g + e of each tile)
+    const int j = 16 * wt + r;
+    const u32x4 kf = row_frag(base + D, 3 * D, j, T, g), vf = row_frag(base + 2 * D, 3 * D, j, T, g);
+    f32x4 pp[8], ps[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const f32x4 sa = BF16::mma(row_frag(base, 3 * D, 16 * t + r, T, g), kf, zero);
+      const f32x4 pa = BF16::mma(row_frag(gbase, D, 16 * t + r, T, g), vf, zero);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 16 * t + 4 * g + e;
+        pp[t][e] = __expf(sa[e] * scale - Ls[i]);
+        ps[t][e] = pp[t][e] * (pa[e] - Ds[i]);
+      }
+    }
+    f32x4 dk[2] = {zero, zero}, dv[2] = {zero, zero};
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      const u32x4 pf = pack8(pp[2 * blk], pp[2 * blk + 1]), sf = pack8(ps[2 * blk], ps[2 * blk + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        dv[dt] = BF16::mma(*(const u32x4*)(GT + (16 * dt + r) * AT_LD + 32 * blk + 8 * g), pf, dv[dt]);
+        dk[dt] = BF16::mma(*(const u32x4*)(QT + (16 * dt + r) * AT_LD + 32 * blk + 8 * g), sf, dk[dt]);
+      }
+    }
+    if (j < T)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        u32x2 w;
+        w.x = (uint32_t)f2bf(dk[dt][0] * scale) | ((uint32_t)f2bf(dk[dt][1] * scale) << 16);
+        w.y = (uint32_t)f2bf(dk[dt][2] * scale) | ((uint32_t)f2bf(dk[dt][3] * scale) << 16);
+        *(u32x2*)(dbase + (size_t)j * 3 * D + D + 16 * dt + 4 * g) = w;
+        w.x = (uint32_t)f2bf(dv[dt][0]) | ((uint32_t)f2bf(dv[dt][1]) << 16);
+        w.y = (uint32_t)f2bf(dv[dt][2]) | ((uint32_t)f2bf(dv[dt][3]) << 16);
+        *(u32x2*)(dbase + (size_t)j * 3 * D + 2 * D + 16 * dt + 4 * g) = w;
+      }
+  }
+}
+
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
   return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
@@ -651,6 +836,7 @@ __global__ void vis_slab_out_kernel(const float* slab, int splits, int N1, int N
 // runner: carves the workspace the same way for the forward and the backward call, so the tape is the workspace
 // ---------------------------------------------------------------------------------------------------------------------
 DevLatch g_attn_latch[2][3];
+int g_vis_mfma_attn = 1;  // tuning knob 20 (A/B against the scalar attention kernels)
 
 template <class P>
 struct VisRunner {
@@ -668,7 +854,7 @@ struct VisRunner {
   E *cols1, *a1, *cols2, *h1[MAX_DEPTH], *qkv[MAX_DEPTH], *att[MAX_DEPTH], *h2[MAX_DEPTH], *z[MAX_DEPTH], *ga[MAX_DEPTH], *feats, *Xs;
   float *x[2 * MAX_DEPTH + 1], *st[2 * MAX_DEPTH + 1], *lse[MAX_DEPTH], *y, *sst;
   // backward scratch
-  E *dy, *dXs, *dxe, *dA, *dqkv, *dcols2, *dz1;
+  E *dy, *dXs, *dxe, *dA, *dqkv, *dcols2, *dz1, *dattE;
   float *dfa, *dfb, *dh, *slab, *part;
   size_t slab_floats;
 
@@ -693,13 +879,14 @@ struct VisRunner {
       h2[l] = elems((size_t)M2 * D), z[l] = elems((size_t)M2 * 4 * D), ga[l] = elems((size_t)M2 * 4 * D);
     }
     feats = elems((size_t)M2 * D), Xs = elems((size_t)NI * D * L.Ksp), y = f32s((size_t)NI * D * L.S), sst = f32s((size_t)NI * D * 2);
-    dy = dXs = dxe = dA = dqkv = dcols2 = dz1 = nullptr;
+    dy = dXs = dxe = dA = dqkv = dcols2 = dz1 = dattE = nullptr;
     dfa = dfb = dh = slab = part = nullptr;
     slab_floats = 0;
     if (train) {
       dy = elems((size_t)NI * D * L.S), dXs = elems((size_t)NI * D * L.Pp), dxe = elems((size_t)M2 * D);
       dA = elems((size_t)M2 * 4 * D), dqkv = elems((size_t)M2 * 3 * D), dcols2 = elems((size_t)M2 * L.K2), dz1 = elems((size_t)M1 * D);
       dfa = f32s((size_t)M2 * D), dfb = f32s((size_t)M2 * D), dh = f32s((size_t)M2 * D);
+      dattE = elems((size_t)M2 * D);
       slab_floats = (size_t)64 * D * (L.K2 > L.K1p ? L.K2 : L.K1p);  // >= 128 splits of a D x 4D output, 64 of the D x 9D one
       slab = f32s(slab_floats);
       {  // partial sums: SpatialEmb (8 chunks of D x 3S), LayerNorm (1024 blocks x 2D), column sums (<= 512 chunks of 256 columns + N)
@@ -724,6 +911,9 @@ struct VisRunner {
     hipLaunchKernelGGL((vis_ln_kernel<P>), dim3((unsigned)((M2 + 3) / 4)), dim3(256), 0, s, in, pos, L.P, xout, prm + gw, prm + gb,
                        M2, L.D, out, stats);
   }
+  // bf16 with the shipped head geometry: attention on the matrix cores; otherwise (fp32 parity mode, other head sizes, more
+  // than 128 tokens) the scalar kernels
+  bool mfma_attn() const { return P::ESIZE == 2 && L.hd == 32 && L.P <= AT_T && g_vis_mfma_attn; }
   template <class K>
   void attn_attr(K kern, size_t lds, int which) {
     const int hi = L.hd == 16 ? 0 : (L.hd == 32 ? 1 : 2);
@@ -771,7 +961,10 @@ struct VisRunner {
       float *xi = x[2 * l], *xa = x[2 * l + 1], *xo = x[2 * l + 2];
       ln(xi, l == 0 ? prm + L.pos : nullptr, l == 0 ? xi : nullptr, v.ln1w, v.ln1b, h1[l], st[2 * l]);
       gemm(h1[l], D, M2, v.pqkv, 3 * D, D, prm + v.qkvb, nullptr, 0, qkv[l], nullptr, 3 * D, ACT_NONE);
-      if (L.hd == 16) attn_fwd<16>(l);
+      if (mfma_attn())
+        hipLaunchKernelGGL(vis_attn_fwd_mfma_kernel, dim3((unsigned)(NI * L.nh)), dim3(512), 0, s, (const uint16_t*)qkv[l], L.P, D,
+                           L.nh, 1.f / sqrtf(32.f), (uint16_t*)att[l], lse[l]);
+      else if (L.hd == 16) attn_fwd<16>(l);
       else if (L.hd == 32) attn_fwd<32>(l);
       else attn_fwd<64>(l);
       gemm(att[l], D, M2, v.po, D, D, prm + v.ob, xa, D, nullptr, nullptr, 0, ACT_NONE, xi, D);
@@ -886,10 +1079,16 @@ struct VisRunner {
       // x_a = x_i + out_proj(attn(qkv(LN1(x_i))))
       wgrad(dxe, D, D, att[l], D, D, D, M2, grad + v.ow, D);
       colsum(dalt, false, M2, D, D, grad + v.ob);
-      gemm(dxe, D, M2, v.poT, D, D, nullptr, dh, D, nullptr, nullptr, 0, ACT_NONE);  // d att (f32)
-      if (L.hd == 16) attn_bwd<16>(l, dh);
-      else if (L.hd == 32) attn_bwd<32>(l, dh);
-      else attn_bwd<64>(l, dh);
+      if (mfma_attn()) {
+        gemm(dxe, D, M2, v.poT, D, D, nullptr, nullptr, 0, dattE, nullptr, D, ACT_NONE);  // d att (bf16 operand)
+        hipLaunchKernelGGL(vis_attn_bwd_mfma_kernel, dim3((unsigned)(NI * L.nh)), dim3(512), 0, s, (const uint16_t*)qkv[l],
+                           (const uint16_t*)att[l], (const uint16_t*)dattE, lse[l], L.P, D, L.nh, 1.f / sqrtf(32.f), (uint16_t*)dqkv);
+      } else {
+        gemm(dxe, D, M2, v.poT, D, D, nullptr, dh, D, nullptr, nullptr, 0, ACT_NONE);  // d att (f32)
+        if (L.hd == 16) attn_bwd<16>(l, dh);
+        else if (L.hd == 32) attn_bwd<32>(l, dh);
+        else attn_bwd<64>(l, dh);
+      }
       wgrad(dqkv, 3 * D, 3 * D, h1[l], D, D, D, M2, grad + v.qkvw, D);
       colsum(dqkv, true, M2, 3 * D, 3 * D, grad + v.qkvb);
       gemm(dqkv, 3 * D, M2, v.pqkvT, D, 3 * D, nullptr, dh, D, nullptr, nullptr, 0, ACT_NONE);
@@ -938,6 +1137,7 @@ int backward_impl(const dppo_vis_desc& d, const float* prm, const char* pk, cons
 }
 
 }  // namespace
+void set_vis_mfma_attn(int v) { g_vis_mfma_attn = v; }
 }  // namespace dppo
 
 using namespace dppo;

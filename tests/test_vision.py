@@ -242,28 +242,43 @@ def vis_grad_report(g, prefix, named_grads):
 
 
 @pytest.mark.gpu
-def test_hip_encoder_backward_against_autograd():
-    """dppo_vis_backward alone: d(sum(obs * R)) / d(encoder parameters) against torch autograd on the oracle (fp32)."""
-    v = O.VisSpec(**VIS_SPECS["vis_small"])
+@pytest.mark.parametrize("vname,prec,mfma", [("vis_small", "fp32", 1), ("vis_square", "fp32", 1), ("vis_small", "bf16", 1),
+                                             ("vis_square", "bf16", 1), ("vis_square", "bf16", 0), ("vis_two", "bf16", 1)])
+def test_hip_encoder_backward_against_autograd(vname, prec, mfma):
+    """dppo_vis_backward alone: d(sum(obs * R)) / d(encoder parameters) against torch autograd on the oracle.  fp32: relative
+    error < 2e-3 per tensor.  bf16 (operands rounded, attention on the matrix cores at head dim 32 -- knob 20 -- or the scalar
+    kernels): per-tensor cosine >= 0.99 and norm within 3 %."""
+    from dppo_amd import hip
+    v = O.VisSpec(**VIS_SPECS[vname])
     cspec = O.NetSpec("critic", cond_dim=v.feat_dim + v.prop_dim, mlp_dims=[256, 256, 256], activation="Mish", residual=True)
     p = O.vision_init_params(v, cspec, 5)
     rs = np.random.RandomState(0)
-    B = 7
-    rgb = (rs.randint(0, 256, size=(B, v.in_ch // 3, 3, v.img_h, v.img_w))).astype(np.uint8)
+    B = 3 if v.img_h > 64 else 7
+    rgb = (rs.randint(0, 256, size=(B, v.in_ch // 3, 3 * v.num_img, v.img_h, v.img_w))).astype(np.uint8)
     state = rs.uniform(-1, 1, size=(B, 1, v.prop_dim)).astype(np.float32)
     R = rs.normal(0, 1, size=(B, v.feat_dim + v.prop_dim)).astype(np.float32)
     pr = {k: t.clone().requires_grad_(True) for k, t in p.items() if not k.startswith("Q1")}
     obs_ref = O.vis_features(pr, v, T(rgb), T(state))
     (obs_ref * T(R)).sum().backward()
-    m = hip_vit_critic(v, cspec, p, "fp32")
-    obs = m.encode_obs({"rgb": T(rgb).cuda(), "state": T(state).cuda()}, train=True)
-    np.testing.assert_allclose(obs.cpu().numpy(), obs_ref.detach().numpy(), rtol=3e-4, atol=3e-4)
-    m.vis.backward(T(R).cuda())
+    m = hip_vit_critic(v, cspec, p, prec)
+    hip.check(hip.load().dppo_tune_set(20, mfma), "dppo_tune_set")
+    try:
+        obs = m.encode_obs({"rgb": T(rgb).cuda(), "state": T(state).cuda()}, train=True)
+        m.vis.backward(T(R).cuda())
+    finally:
+        hip.load().dppo_tune_set(20, 1)
+    tol = 3e-4 if prec == "fp32" else 6e-2
+    np.testing.assert_allclose(obs.cpu().numpy(), obs_ref.detach().numpy(), rtol=tol, atol=tol * float(obs_ref.abs().max()))
     names = [n for n, _, _ in O.vis_param_shapes(v)]
     for n, gv in zip(names, m.vis.grad_views()):
-        ref = pr[n].grad.numpy()
-        err = np.linalg.norm(gv.cpu().numpy() - ref) / (np.linalg.norm(ref) + 1e-12)
-        assert err < 2e-3, (n, err)
+        ref, got = pr[n].grad.numpy().reshape(-1).astype(np.float64), gv.cpu().numpy().reshape(-1).astype(np.float64)
+        if prec == "fp32":
+            err = np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-12)
+            assert err < 2e-3, (n, err)
+        else:
+            cos = float(got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
+            ratio = float(np.linalg.norm(got) / (np.linalg.norm(ref) + 1e-30))
+            assert cos > 0.99 and abs(ratio - 1) < 0.03, (n, cos, ratio)
 
 
 @pytest.mark.gpu
