@@ -160,6 +160,40 @@ def cpu_baseline(n_envs, batch, budget_s=25.0):
                       f"(N={batch}: loss fwd + bwd + 2x AdamW), torch {torch.__version__} CPU, {cores} threads"}
 
 
+def pixel_leg(n_envs=256, batch=500, reps=10):
+    """Secondary fields: the pixel path at BASELINE configs[4]'s shapes (robomimic square image cfg: one 96x96 camera, ViT +
+    SpatialEmb, VisionUnet1D denoiser and, beside it, the VisionDiffusionMLP of the same cfg family; DDIM 100 -> 5 steps all
+    fine-tuned, Ta 4, Da 7, ViTCritic), one GPU's share: rollout step for n_envs observations (both encoders are NOT needed
+    there: one ViT pass + the 5-step sampler) and one update minibatch of the cfg's batch_size (two encoders forward with a
+    tape, fused loss forward / backward, two encoders backward).  Synthetic images, random-init weights."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vision_bench", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools",
+                                                                                 "vision_bench.py"))
+    vb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(vb)
+    dev, out = "cuda:0", {"what": pixel_leg.__doc__.split("  Synthetic")[0].replace("\n    ", " "), "n_envs": n_envs,
+                          "minibatch": batch, "dtype": "bf16", "data": "synthetic"}
+    for kind in ("unet", "mlp"):
+        m = vb.build(kind, "bf16", dev)
+        Kft, AF = 5, 28
+        cond_e = {"rgb": torch.randint(0, 256, (n_envs, 1, 3, 96, 96), device=dev, dtype=torch.uint8),
+                  "state": torch.rand(n_envs, 1, 9, device=dev) * 2 - 1}
+        cond_n = {"rgb": torch.randint(0, 256, (batch, 1, 3, 96, 96), device=dev, dtype=torch.uint8),
+                  "state": torch.rand(batch, 1, 9, device=dev) * 2 - 1}
+        chains = m(cond=cond_n).chains.reshape(batch, Kft + 1, AF)
+        kinds = torch.randint(0, Kft, (batch,), device=dev)
+        rows = torch.arange(batch, device=dev)
+        pairs = torch.stack([chains[rows, kinds], chains[rows, kinds + 1]], 1).contiguous()
+        lp = m.get_logprobs(cond_n, chains.reshape(batch, Kft + 1, 4, 7)).reshape(batch, Kft, AF)[rows, kinds].contiguous()
+        ret, val, adv = (torch.randn(batch, device=dev) for _ in range(3))
+        ms_upd = vb.timeit(lambda: m._run_ppo_vision(cond_n, pairs, ret, val, adv, lp, kinds, batch, 4, None), n=reps)
+        ms_smp = vb.timeit(lambda: m(cond=cond_e), n=reps)
+        out[kind + "_img"] = {"update_ms_per_minibatch": ms_upd, "update_samples_per_sec": batch / ms_upd * 1e3,
+                              "rollout_ms_per_step": ms_smp, "env_steps_per_sec": n_envs * 4 / ms_smp * 1e3}
+        del m
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,6 +205,7 @@ def main():
     ap.add_argument("--batch", type=int, default=50000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the secondary fp32 (the reference's own precision) pass")
+    ap.add_argument("--no-pixel", action="store_true", help="skip the secondary pixel-observation pass (BASELINE configs[4] shapes)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu rehearses the data-parallel path with several ranks on ONE GPU")
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
@@ -341,6 +376,11 @@ def main():
         del fp32_run["model"]
         torch.cuda.empty_cache()
 
+    pixel = None
+    if world == 1 and args.prec == "bf16" and not args.no_pixel:
+        pixel = pixel_leg()
+        torch.cuda.empty_cache()
+
     stats = main_run["stats"]
     if rank == 0:
         ms_update = dt_update / args.steps * 1e3
@@ -383,6 +423,8 @@ def main():
                            "peak_tflops": MFMA_PEAK_TFLOPS["fp32"],
                            "update_frac": f_sps * FLOP_PER_SAMPLE / 1e12 / MFMA_PEAK_TFLOPS["fp32"],
                            "sampler_frac": f_cps * FLOP_PER_CHUNK / 1e12 / MFMA_PEAK_TFLOPS["fp32"]}
+        if pixel is not None:
+            out["pixel"] = pixel
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.n_envs, args.batch)
         print(json.dumps(out), flush=True)

@@ -821,15 +821,24 @@ __global__ __launch_bounds__(256) void vis_colsum1_kernel(const void* A, int64_t
       part[(size_t)blockIdx.y * N + c0 + k] = t;
     }
 }
-// out[r * ldo + c] = sum_s slab[s][r][c] for c < N2v; mode 1: conv2 unpack out[(o * D + i) * 9 + kk] <- [o][kk * D + i]
-__global__ void vis_slab_out_kernel(const float* slab, int splits, int N1, int N2, int N2v, float* out, int ldo, int mode, int D) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (size_t)N1 * N2v) return;
+// out[r * ldo + c] = sum_s slab[s][r][c] for c < N2v; mode 1: conv2 unpack out[(o * D + i) * 9 + kk] <- [o][kk * D + i].
+// 16 outputs x 16 split-lanes per workgroup (fixed order)
+__global__ __launch_bounds__(256) void vis_slab_out_kernel(const float* slab, int splits, int N1, int N2, int N2v, float* out, int ldo,
+                                                           int mode, int D) {
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const size_t i = (size_t)blockIdx.x * 16 + cl, n = (size_t)N1 * N2v;
   const int r = (int)(i / N2v), c = (int)(i % N2v);
   float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += slab[((size_t)k * N1 + r) * N2 + c];
-  if (mode == 0) out[(size_t)r * ldo + c] = s;
-  else out[((size_t)r * D + c % D) * 9 + c / D] = s;
+  if (i < n)
+    for (int k = rl; k < splits; k += 16) s += slab[((size_t)k * N1 + r) * N2 + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl != 0 || i >= n) return;
+  float t = 0.f;
+  for (int k = 0; k < 16; ++k) t += red[k][cl];
+  if (mode == 0) out[(size_t)r * ldo + c] = t;
+  else out[((size_t)r * D + c % D) * 9 + c / D] = t;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1010,7 +1019,7 @@ struct VisRunner {
     t.slab = slab, t.ldc = N2, t.splits = (int)splits, t.rows_per_split = (int)rps;
     launch_gemm_tn<P>(t, s);
     const size_t n = (size_t)N1 * N2v;
-    hipLaunchKernelGGL(vis_slab_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slab, (int)splits, N1, N2, N2v, out,
+    hipLaunchKernelGGL(vis_slab_out_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, slab, (int)splits, N1, N2, N2v, out,
                        ldo, mode, L.D);
   }
   void colsum(const void* A, bool elem, int64_t M, int N, int lda, float* out) {

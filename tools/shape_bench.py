@@ -34,7 +34,13 @@ def main():
     ap.add_argument("--prec", default="bf16")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--graph", action="store_true", help="replay the update as captured hipGraphs")
+    ap.add_argument("--tune", default="", help="dppo_tune_set knobs, e.g. 1=0 (layered GEMMs instead of the fused row-tile kernels)")
     args = ap.parse_args()
+    if args.tune:
+        from dppo_amd import hip
+        for kv in args.tune.split(","):
+            k, v = kv.split("=")
+            hip.check(hip.load().dppo_tune_set(int(k), int(v)), "dppo_tune_set")
     dev = torch.device("cuda", 0)
     for name in args.shapes.split(","):
         c = SHAPES[name]
