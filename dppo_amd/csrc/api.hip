@@ -2005,6 +2005,10 @@ int dppo_tune_set(int knob, int value) {
     g_post_one = value;
     return 0;
   }
+  if (knob == 21) {  // gemm_nt: small tiles for small problems (1, default) or the 128 x 128 / 64 x 128 / 16 x 256 shapes only (0)
+    set_gemm_nt_small(value);
+    return 0;
+  }
   if (knob == 20) {  // visual encoder: attention on the matrix cores (1, default) or the scalar kernels (0)
     dppo::set_vis_mfma_attn(value);
     return 0;

@@ -62,6 +62,7 @@ void set_gemm_tn_thin(int v);     // tuning knob 6
 // product path.
 enum { PROBE_GEMM_NT_HIDDEN = 1, PROBE_GEMM_TN = 2, PROBE_FUSED_FWD = 3, PROBE_FUSED_BWD = 4, PROBE_SAMPLER = 5 };
 void set_gemm_nt_variant(int v);  // 0 register staging, 1 LDS-DMA staging where legal (default)
+void set_gemm_nt_small(int v);    // 1 (default): 64 x 64 / 64 x 32 tiles when 128 x 128 tiles would give < 192 workgroups
 int probe_arm(int kernel_id, int max_launches);
 int probe_collect(double* total_ms, int* launches, double* flops, double* bytes = nullptr);
 bool probe_begin(int kernel_id, hipStream_t s);  // true if this launch is being timed

@@ -260,6 +260,8 @@ void probe_end(hipStream_t s, double flops, double bytes) {
 
 static int g_nt_variant = 1;  // 0 = register staging everywhere, 1 = LDS-DMA staging where legal (bench A/B knob)
 void set_gemm_nt_variant(int v) { g_nt_variant = v; }
+static int g_nt_small = 1;  // tuning knob 21: smaller tiles for small problems
+void set_gemm_nt_small(int v) { g_nt_small = v; }
 
 template <class P, int WN, int WM, int TN, int TM, int TAG, int DMA>
 static void launch_nt_cfg(const GemmNT& a, hipStream_t s) {
@@ -283,6 +285,22 @@ template <class P>
 void launch_gemm_nt(const GemmNT& a, hipStream_t s) {
   if (a.M <= 0) return;
   const bool dma = g_nt_variant == 1 && a.N % 128 == 0;
+  // Small problems (the conv denoiser's per-block GEMMs: a few thousand rows, N = 64..256): 128 x 128 tiles leave most of
+  // the 256 CUs idle and the launch is one workgroup's serial k-loop long.  Shrink the tile until ~200 workgroups exist
+  // (each output's accumulation order over k is unchanged: bit-identical results).
+  const int64_t wg128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
+  if (g_nt_small && a.N > 16 && wg128 < 192) {
+    const bool dma64 = g_nt_variant == 1 && a.N % 64 == 0;
+    const int64_t wg64 = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64);
+    if (wg64 >= 192) {
+      if (dma64) launch_nt_cfg<P, 2, 2, 2, 2, 0, 1>(a, s);  // 64 x 64
+      else launch_nt_cfg<P, 2, 2, 2, 2, 0, 0>(a, s);
+    } else {
+      if (dma64) launch_nt_cfg<P, 2, 2, 2, 1, 0, 1>(a, s);  // 64 features x 32 rows
+      else launch_nt_cfg<P, 2, 2, 2, 1, 0, 0>(a, s);
+    }
+    return;
+  }
   if (a.N <= 16)
     launch_nt_cfg<P, 1, 4, 1, 4, 0, 0>(a, s);  // 16 features x 256 rows
   else if (a.N <= 64)
