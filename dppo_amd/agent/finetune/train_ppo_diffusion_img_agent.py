@@ -65,7 +65,7 @@ class TrainPPOImgDiffusionAgent(TrainPPODiffusionAgent):
 
     def run(self):
         model, dev = self.model, self.device
-        Kft = model.ft_denoising_steps
+        Kft = getattr(model, "ft_denoising_steps", 0)  # 0: a one-shot (Gaussian) policy, the "chain" is the action itself
         Ta, Da = self.horizon_steps, self.action_dim
         AF = Ta * Da
         S, E = self.n_steps, self.n_envs
@@ -96,9 +96,9 @@ class TrainPPOImgDiffusionAgent(TrainPPODiffusionAgent):
                 cond = self._cond(prev_obs)
                 for k in bufs:
                     bufs[k][step * E:(step + 1) * E] = cond[k]
-                smp = model(cond=cond, deterministic=eval_mode, return_chain=True)
-                chains_buf[step * E:(step + 1) * E] = smp.chains.reshape(E, Kft + 1, AF)
-                action = smp.trajectories.cpu().numpy()[:, :self.act_steps]
+                traj, chain = self._sample(cond, eval_mode)
+                chains_buf[step * E:(step + 1) * E] = chain.reshape(E, Kft + 1, AF)
+                action = traj.cpu().numpy()[:, :self.act_steps]
                 prev_obs, reward, terminated, truncated, _ = self.venv.step(action)
                 if isinstance(prev_obs, list):
                     prev_obs = {k: np.stack([o[k] for o in prev_obs]) for k in prev_obs[0]}
@@ -123,7 +123,8 @@ class TrainPPOImgDiffusionAgent(TrainPPODiffusionAgent):
             if self.itr >= self.n_critic_warmup_itr:
                 self.actor_lr_scheduler.step()
             self.critic_lr_scheduler.step()
-            model.step()
+            if hasattr(model, "step"):
+                model.step()
             if self.itr % self.save_model_freq == 0 or self.itr == self.n_train_itr - 1:
                 self.save_model()
             rec = {"itr": self.itr, "step": cnt_train_step}
@@ -144,7 +145,21 @@ class TrainPPOImgDiffusionAgent(TrainPPODiffusionAgent):
             self.itr += 1
         return run_results
 
+    def _sample(self, cond, eval_mode):
+        """(trajectories (E,Ta,Da), chains (E,Kft+1,Ta,Da)) of one env step."""
+        smp = self.model(cond=cond, deterministic=eval_mode, return_chain=True)
+        return smp.trajectories, smp.chains
+
     # ------------------------------------------------------------------------------------------------- update
+    def _augment_buffer(self, bufs, R):
+        """One random shift per stored image, before anything reads the buffer (reference :188-200)."""
+        rgb = bufs["rgb"]
+        dt = rgb.dtype
+        for lo in range(0, R, 4096):
+            x = rgb[lo:lo + 4096]
+            y = self.aug(x.reshape(-1, *x.shape[2:]))  # "(s e t) c h w": every frame of the history shifts on its own
+            rgb[lo:lo + 4096] = y.reshape(x.shape).to(dt)
+
     def _grad_bufs(self):
         a, c = self.model.actor_ft, self.model.critic
         return [a.flat_grads(), a.vis.flat_grads(), c.flat_grads(), c.vis.flat_grads()]
@@ -185,13 +200,8 @@ class TrainPPOImgDiffusionAgent(TrainPPODiffusionAgent):
         S, E = self.n_steps, self.n_envs
         Ta, Da = self.horizon_steps, self.action_dim
         AF = Ta * Da
-        if self.augment:  # one random shift per stored image, before anything reads the buffer (reference :188-200)
-            rgb = bufs["rgb"]
-            dt = rgb.dtype
-            for lo in range(0, R, 4096):
-                x = rgb[lo:lo + 4096]
-                y = self.aug(x.reshape(-1, *x.shape[2:]))  # "(s e t) c h w": every frame of the history shifts on its own
-                rgb[lo:lo + 4096] = y.reshape(x.shape).to(dt)
+        if self.augment:
+            self._augment_buffer(bufs, R)
         values_buf = torch.empty(R, device=dev)
         logp_buf = torch.empty(R, Kft, AF, device=dev)
         for lo in range(0, R, self.logprob_batch_size):

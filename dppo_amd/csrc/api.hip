@@ -1591,7 +1591,7 @@ static int gauss_ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const
                           const char* ck, const dppo_gaussian_cfg& cfg, const float* logvar, const float* obs,
                           const float* actions, const float* returns, const float* oldvalues, const float* adv,
                           const float* oldlogp, int64_t N, const double* gmom, float* agrad, float* cgrad, float* lvgrad,
-                          double* stats, void* ws, int64_t wsb, hipStream_t s) {
+                          double* stats, void* ws, int64_t wsb, hipStream_t s, const dppo_obs_io* oio = nullptr) {
   Carver c{(char*)ws, 0, (size_t)wsb};
   MlpBufs<P> A, Cb;
   double *moments, *scratch, *partial;
@@ -1600,7 +1600,8 @@ static int gauss_ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const
   const PackLayout LA = pack_layout<P>(a, 0), LC = pack_layout<P>(cr, 0);
   // the critic pipeline on the side stream beside the actor's forward (one fork here, one join at the end)
   hipStream_t s2 = fork_side(s);
-  launch_build_direct<P>(nullptr, nullptr, obs, nullptr, 0, 0, cr.cond_dim, N, Cb.in, LC.Kp0, s2);
+  launch_build_direct<P>(nullptr, nullptr, oio && oio->obs_critic ? oio->obs_critic : obs, nullptr, 0, 0, cr.cond_dim, N, Cb.in,
+                         LC.Kp0, s2);
   mlp_forward<P>(cr, cp, ck, LC, N, Cb, true, s2);
   launch_build_direct<P>(nullptr, nullptr, obs, nullptr, 0, 0, a.cond_dim, N, A.in, LA.Kp0, s);
   if (gmom == nullptr) launch_gauss_moments(adv, N, moments, scratch, s);
@@ -1615,9 +1616,37 @@ static int gauss_ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const
   launch_gauss_loss<P>(g, s);
   s2 = fork_side(s);
   mlp_backward<P>(cr, cp, ck, LC, N, Cb, cgrad, nullptr, nullptr, 0, s2, false, -1);
+  if (oio && oio->d_obs_critic) obs_grad<P>(cr, cp, N, Cb, oio->d_obs_critic, s2);
   mlp_backward<P>(a, ap, ak, LA, N, A, agrad, nullptr, nullptr, 0, s, false, 1);
+  if (oio && oio->d_obs_actor) obs_grad<P>(a, ap, N, A, oio->d_obs_actor, s);
   if (s2 != s) join_side(s, s2);
   return check_launch();
+}
+static int gauss_ppo_entry(const dppo_net_desc* actor, const dppo_net_desc* critic, int prec,
+                                   const float* actor_params, const void* actor_packed, const float* critic_params,
+                                   const void* critic_packed, const dppo_gaussian_cfg* cfg, const float* logvar,
+                                   const float* obs, const float* actions, const float* returns,
+                                   const float* oldvalues, const float* adv, const float* oldlogp, int64_t N,
+                                   const double* global_moments, float* actor_grad, float* critic_grad,
+                                   float* logvar_grad, double* stats, void* workspace, int64_t workspace_bytes,
+                                   dppo_stream_t stream, const dppo_obs_io* io) {
+  if (int e = check_gauss(actor, cfg, logvar)) return e;
+  if (int e = check_net(critic)) return e;
+  if (int e = check_prec(prec)) return e;
+  if (critic->kind != 1 || critic->out_dim != 1) return fail(-1, "critic descriptor must be kind 1 with out_dim 1");
+  if (actor->cond_dim != critic->cond_dim && !(io && io->obs_critic))
+    return fail(-1, "actor and critic observe different cond_dim");
+  if (!actor_params || !actor_packed || !critic_params || !critic_packed || !obs || !actions || !returns || !oldvalues ||
+      !adv || !oldlogp || !actor_grad || !critic_grad || !stats || !workspace)
+    return fail(-1, "null pointer");
+  if (cfg->std_mode == 1 && !logvar_grad) return fail(-1, "std_mode 1 needs logvar_grad");
+  if (N < 2 || N > 0x7fffffff) return fail(-1, "N out of range");
+#define CALL(P)                                                                                                          \
+  gauss_ppo_impl<P>(*actor, *critic, actor_params, (const char*)actor_packed, critic_params, (const char*)critic_packed, *cfg, \
+                    logvar, obs, actions, returns, oldvalues, adv, oldlogp, N, global_moments, actor_grad, critic_grad,       \
+                    logvar_grad, stats, workspace, workspace_bytes, (hipStream_t)stream, io)
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
 }
 int dppo_gaussian_ppo_loss_fwd_bwd(const dppo_net_desc* actor, const dppo_net_desc* critic, int prec,
                                    const float* actor_params, const void* actor_packed, const float* critic_params,
@@ -1627,22 +1656,22 @@ int dppo_gaussian_ppo_loss_fwd_bwd(const dppo_net_desc* actor, const dppo_net_de
                                    const double* global_moments, float* actor_grad, float* critic_grad,
                                    float* logvar_grad, double* stats, void* workspace, int64_t workspace_bytes,
                                    dppo_stream_t stream) {
-  if (int e = check_gauss(actor, cfg, logvar)) return e;
-  if (int e = check_net(critic)) return e;
-  if (int e = check_prec(prec)) return e;
-  if (critic->kind != 1 || critic->out_dim != 1) return fail(-1, "critic descriptor must be kind 1 with out_dim 1");
-  if (actor->cond_dim != critic->cond_dim) return fail(-1, "actor and critic observe different cond_dim");
-  if (!actor_params || !actor_packed || !critic_params || !critic_packed || !obs || !actions || !returns || !oldvalues ||
-      !adv || !oldlogp || !actor_grad || !critic_grad || !stats || !workspace)
-    return fail(-1, "null pointer");
-  if (cfg->std_mode == 1 && !logvar_grad) return fail(-1, "std_mode 1 needs logvar_grad");
-  if (N < 2 || N > 0x7fffffff) return fail(-1, "N out of range");
-#define CALL(P)                                                                                                          \
-  gauss_ppo_impl<P>(*actor, *critic, actor_params, (const char*)actor_packed, critic_params, (const char*)critic_packed, *cfg, \
-                    logvar, obs, actions, returns, oldvalues, adv, oldlogp, N, global_moments, actor_grad, critic_grad,       \
-                    logvar_grad, stats, workspace, workspace_bytes, (hipStream_t)stream)
-  return DPPO_DISPATCH(prec, CALL);
-#undef CALL
+  return gauss_ppo_entry(actor, critic, prec, actor_params, actor_packed, critic_params, critic_packed, cfg, logvar, obs, actions,
+                         returns, oldvalues, adv, oldlogp, N, global_moments, actor_grad, critic_grad, logvar_grad, stats,
+                         workspace, workspace_bytes, stream, nullptr);
+}
+int dppo_gaussian_ppo_loss_fwd_bwd_obs(const dppo_net_desc* actor, const dppo_net_desc* critic, int prec,
+                                       const float* actor_params, const void* actor_packed, const float* critic_params,
+                                       const void* critic_packed, const dppo_gaussian_cfg* cfg, const float* logvar,
+                                       const float* obs, const float* actions, const float* returns,
+                                       const float* oldvalues, const float* adv, const float* oldlogp, int64_t N,
+                                       const double* global_moments, float* actor_grad, float* critic_grad,
+                                       float* logvar_grad, double* stats, void* workspace, int64_t workspace_bytes,
+                                       dppo_stream_t stream, const dppo_obs_io* io) {
+  if (!io) return fail(-1, "null pointer");
+  return gauss_ppo_entry(actor, critic, prec, actor_params, actor_packed, critic_params, critic_packed, cfg, logvar, obs, actions,
+                         returns, oldvalues, adv, oldlogp, N, global_moments, actor_grad, critic_grad, logvar_grad, stats,
+                         workspace, workspace_bytes, stream, io);
 }
 
 // ---- conv denoiser: PPO update and supervised loss (unet.hip does the network, this file the loss and the critic) -------

@@ -124,6 +124,8 @@ SYMBOLS = {
     "dppo_unet_ppo_loss_fwd_bwd_obs": (_I, [C.POINTER(UnetDesc), _ND, _I, _P, _P, _P, _P, C.POINTER(DiffusionCfg),
                                             C.POINTER(PpoCfg), _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P,
                                             C.POINTER(ObsIO)]),
+    "dppo_gaussian_ppo_loss_fwd_bwd_obs": (_I, [_ND, _ND, _I, _P, _P, _P, _P, C.POINTER(GaussianCfg), _P, _P, _P, _P, _P, _P,
+                                            _P, _L, _P, _P, _P, _P, _P, _P, _L, _P, C.POINTER(ObsIO)]),
     "dppo_denoise_mse_fwd_bwd_obs": (_I, [_ND, _I, _P, _P, _P, _I, _P, _P, _P, _L, _P, _P, _P, _L, _P, _P]),
     "dppo_unet_denoise_mse_fwd_bwd_obs": (_I, [C.POINTER(UnetDesc), _I, _P, _P, _P, _I, _P, _P, _P, _L, _P, _P, _P, _L, _P, _P]),
     "dppo_vis_param_count": (_L, [C.POINTER(VisDesc)]),

@@ -41,7 +41,7 @@ class GaussianModel(torch.nn.Module):
         hip.require_gpu(state, type(self).__name__ + ".forward")
         B, dev = state.shape[0], state.device
         AF = net.action_dim * net.horizon_steps
-        obs = state.reshape(B, -1).contiguous().float()
+        obs = net.encode_obs(cond) if getattr(net, "is_vision", False) else state.reshape(B, -1).contiguous().float()
         lib, d = hip.load(), net.net_desc()
         cfg = net.gaussian_cfg(deterministic=deterministic, randn_clip=self.randn_clip_value)
         if noise is None:

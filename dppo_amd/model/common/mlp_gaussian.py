@@ -17,6 +17,7 @@ from torch import nn
 
 from dppo_amd import hip
 from dppo_amd.model.common.mlp import HipNet, ResidualMLP
+from dppo_amd.model.common.vit import VisionMixin
 
 
 class Gaussian_MLP(HipNet):
@@ -93,3 +94,23 @@ class Gaussian_MLP(HipNet):
         else:
             scale = torch.full_like(mean, self.fixed_std)
         return mean, scale
+
+
+class Gaussian_VisionMLP(VisionMixin, Gaussian_MLP):
+    """ViT backbone + SpatialEmb, then the Gaussian head's trunk on cat[feat, state]; the mean is always tanh-squashed.
+    Mirrors ``dppo/model/common/mlp_gaussian.py:112-281``."""
+
+    def __init__(self, backbone, action_dim, horizon_steps, cond_dim, img_cond_steps=1, mlp_dims=[256, 256, 256],
+                 activation_type="Mish", residual_style=False, use_layernorm=False, fixed_std=None, learn_fixed_std=False,
+                 std_min=0.01, std_max=1, spatial_emb=0, visual_feature_dim=128, dropout=0, num_img=1, augment=False,
+                 precision="bf16"):
+        Gaussian_MLP.__init__(self, action_dim, horizon_steps, cond_dim + spatial_emb * num_img, mlp_dims=mlp_dims,
+                              activation_type=activation_type, tanh_output=True, residual_style=residual_style,
+                              use_layernorm=use_layernorm, dropout=0.0, fixed_std=fixed_std, learn_fixed_std=learn_fixed_std,
+                              std_min=std_min, std_max=std_max, precision=precision)
+        self._init_vision(backbone, cond_dim, img_cond_steps, spatial_emb, num_img, augment, dropout, precision)
+        self._vision_modules_first("backbone", "compress", "compress1", "compress2")
+
+    @torch.no_grad()
+    def forward(self, cond):
+        return Gaussian_MLP.forward(self, {"state": self.encode_obs(cond)})

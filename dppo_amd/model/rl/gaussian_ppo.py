@@ -39,8 +39,16 @@ class PPO_Gaussian(VPG_Gaussian):
         object.__setattr__(self, "_lv_grad", None)
 
     def _run(self, obs, actions, returns, oldvalues, adv, oldlogp, global_moments=None):
-        lib, dev = hip.load(), obs.device
+        """obs: (N, To*Do) tensor, or for pixel networks the cond dict {"rgb", "state"}: both encoders then run with a tape,
+        the loss entry returns d loss / d observation and the encoders' backward fills their own flat gradients."""
+        lib = hip.load()
         net = self.actor_ft
+        vision = isinstance(obs, dict)
+        if vision:
+            cond = obs
+            obs = net.encode_obs(cond, train=True)
+            obs_c = self.critic.encode_obs(cond, train=True, augment=False)
+        dev = obs.device
         da, dc = net.net_desc(), self.critic.net_desc()
         N = obs.shape[0]
         if self._stats is None or self._stats.device != dev:
@@ -53,19 +61,25 @@ class PPO_Gaussian(VPG_Gaussian):
         if wsb < 0:
             hip.check(int(wsb), "dppo_gaussian_workspace_bytes")
         ws = self._ws_ppo.get(wsb, dev)
-        hip.check(lib.dppo_gaussian_ppo_loss_fwd_bwd(
-            C.byref(da), C.byref(dc), self.prec, net.flat_params().data_ptr(), net.packed(self.prec, 0).data_ptr(),
-            self.critic.flat_params().data_ptr(), self.critic.packed(self.prec, 0).data_ptr(), C.byref(cfg),
-            net.logvar_ptr(), hip.ptr(obs), hip.ptr(actions), hip.ptr(returns), hip.ptr(oldvalues), hip.ptr(adv),
-            hip.ptr(oldlogp), N, hip.ptr(global_moments), net.flat_grads().data_ptr(), self.critic.flat_grads().data_ptr(),
-            self._lv_grad.data_ptr(), self._stats.data_ptr(), ws.data_ptr(), ws.numel(), hip.stream()),
-            "dppo_gaussian_ppo_loss_fwd_bwd")
+        args = (C.byref(da), C.byref(dc), self.prec, net.flat_params().data_ptr(), net.packed(self.prec, 0).data_ptr(),
+                self.critic.flat_params().data_ptr(), self.critic.packed(self.prec, 0).data_ptr(), C.byref(cfg),
+                net.logvar_ptr(), hip.ptr(obs), hip.ptr(actions), hip.ptr(returns), hip.ptr(oldvalues), hip.ptr(adv),
+                hip.ptr(oldlogp), N, hip.ptr(global_moments), net.flat_grads().data_ptr(), self.critic.flat_grads().data_ptr(),
+                self._lv_grad.data_ptr(), self._stats.data_ptr(), ws.data_ptr(), ws.numel(), hip.stream())
+        if vision:
+            d_a, d_c = torch.empty_like(obs), torch.empty_like(obs_c)
+            io = hip.ObsIO(obs_c.data_ptr(), d_a.data_ptr(), d_c.data_ptr())
+            hip.check(lib.dppo_gaussian_ppo_loss_fwd_bwd_obs(*args, C.byref(io)), "dppo_gaussian_ppo_loss_fwd_bwd_obs")
+            net.vis.backward(d_a)
+            self.critic.vis.backward(d_c)
+        else:
+            hip.check(lib.dppo_gaussian_ppo_loss_fwd_bwd(*args), "dppo_gaussian_ppo_loss_fwd_bwd")
         return self._stats
 
     def ppo_update(self, obs, actions, returns, oldvalues, adv, oldlogp, global_moments=None):
         """One minibatch, no host sync: gradients land in the flat gradient buffers of ``actor_ft`` / ``critic`` (and
         ``_lv_grad`` for a learned std); returns the device statistics (float64[GAUSS_STAT_COUNT])."""
-        hip.require_gpu(obs, "PPO_Gaussian.ppo_update")
+        hip.require_gpu(obs["state"] if isinstance(obs, dict) else obs, "PPO_Gaussian.ppo_update")
         return self._run(obs, actions, returns, oldvalues, adv, oldlogp, global_moments)
 
     def loss(self, obs, actions, returns, oldvalues, advantages, oldlogprobs, use_bc_loss=False):
@@ -79,9 +93,13 @@ class PPO_Gaussian(VPG_Gaussian):
         net = self.actor_ft
         AF = net.action_dim * net.horizon_steps
         f = lambda t, *shape: t.reshape(*shape).contiguous().float()
-        stats = self._run(f(state, N, -1), f(actions, N, AF), f(returns, N), f(oldvalues, N), f(advantages, N),
+        vision = getattr(net, "is_vision", False)
+        stats = self._run(obs if vision else f(state, N, -1), f(actions, N, AF), f(returns, N), f(oldvalues, N), f(advantages, N),
                           f(oldlogprobs, N))
-        a_params, c_params = net.trunk_parameters(), list(self.critic.parameters())
+        a_params, a_grads = net.trunk_parameters(), net.grad_views()
+        if vision:  # + the encoder's parameters and the gradients its backward produced
+            a_params, a_grads = net.vis.trunk_parameters() + a_params, net.vis.grad_views() + a_grads
+        c_params = list(self.critic.parameters())
         lv_pg = lv_ent = None
         extra = []
         if net.learn_fixed_std:
@@ -90,7 +108,7 @@ class PPO_Gaussian(VPG_Gaussian):
             lv_pg = self._lv_grad.clone()
             lv_ent = -0.5 / net.action_dim * inside  # d(-entropy) / d logvar_j, through the clamp
             extra = [net.logvar]
-        pg, ent, vl = _FusedGaussLoss.apply(stats, net.grad_views(), self.critic.grad_views(), lv_pg, lv_ent, len(a_params),
+        pg, ent, vl = _FusedGaussLoss.apply(stats, a_grads, self.critic.grad_views_all(), lv_pg, lv_ent, len(a_params),
                                             len(c_params), *a_params, *c_params, *extra)
         host = stats.tolist()  # one D2H sync, like the reference's .item() calls
         return (pg, ent, vl, host[hip.STAT_CLIPFRAC], host[hip.STAT_APPROX_KL], host[hip.STAT_RATIO], 0.0,

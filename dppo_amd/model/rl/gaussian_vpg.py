@@ -34,7 +34,7 @@ class VPG_Gaussian(GaussianModel):
         net = self.actor if use_base_policy else self.actor_ft
         B, dev = state.shape[0], state.device
         AF = net.action_dim * net.horizon_steps
-        obs = state.reshape(B, -1).contiguous().float()
+        obs = net.encode_obs(cond) if getattr(net, "is_vision", False) else state.reshape(B, -1).contiguous().float()
         act = actions.reshape(B, AF).contiguous().float()
         lib, d = hip.load(), net.net_desc()
         cfg = net.gaussian_cfg(randn_clip=self.randn_clip_value)

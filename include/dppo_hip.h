@@ -447,6 +447,14 @@ int dppo_unet_ppo_loss_fwd_bwd_obs(const dppo_unet_desc* actor, const dppo_net_d
                                    const float* adv_k, const float* logprobs_k, const int64_t* kinds, int64_t N,
                                    const double* global_moments, float* actor_grad, float* critic_grad, double* stats,
                                    void* workspace, int64_t workspace_bytes, dppo_stream_t stream, const dppo_obs_io* io);
+int dppo_gaussian_ppo_loss_fwd_bwd_obs(const dppo_net_desc* actor, const dppo_net_desc* critic, int prec,
+                                       const float* actor_params, const void* actor_packed, const float* critic_params,
+                                       const void* critic_packed, const dppo_gaussian_cfg* cfg, const float* logvar,
+                                       const float* obs, const float* actions, const float* returns,
+                                       const float* oldvalues, const float* adv, const float* oldlogp, int64_t N,
+                                       const double* global_moments, float* actor_grad, float* critic_grad,
+                                       float* logvar_grad, double* stats, void* workspace, int64_t workspace_bytes,
+                                       dppo_stream_t stream, const dppo_obs_io* io);
 int dppo_denoise_mse_fwd_bwd_obs(const dppo_net_desc* actor, int prec, const float* params, const void* packed,
                                  const dppo_step* tsteps, int n_time, const float* obs, const float* pairs,
                                  const int64_t* kinds, int64_t N, float* grad, double* loss, void* workspace,

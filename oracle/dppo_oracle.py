@@ -1047,6 +1047,9 @@ class GaussianCfg:
 def gaussian_dist(gc: GaussianCfg, spec: NetSpec, p: Params, logvar: Optional[torch.Tensor], state: torch.Tensor,
                   deterministic: bool = False):
     """(mean, scale), both (B, Ta*Da): Gaussian_MLP.forward (mlp_gaussian.py:346-362) + forward_train (gaussian.py:63-79)."""
+    if getattr(spec, "kind", "") == "vision":  # Gaussian_VisionMLP (mlp_gaussian.py:210-281): the trunk on cat[feat, state]
+        state = vis_features(p, spec.vis, state["rgb"], state["state"])
+        spec = spec.trunk
     B = state.shape[0]
     mean = trunk_forward(p, spec, state.reshape(B, -1))
     if gc.tanh_output:
@@ -1066,7 +1069,7 @@ def gaussian_sample(gc: GaussianCfg, spec: NetSpec, p: Params, logvar, state, no
     mean, scale = gaussian_dist(gc, spec, p, logvar, state, deterministic)
     a = mean + scale * noise.reshape(mean.shape)
     a = torch.max(torch.min(a, mean + gc.randn_clip_value * scale), mean - gc.randn_clip_value * scale)
-    return a.view(state.shape[0], spec.horizon_steps, -1)
+    return a.view(a.shape[0], spec.horizon_steps, -1)
 
 
 def gaussian_logprob(gc: GaussianCfg, spec: NetSpec, p: Params, logvar, state, actions):

@@ -794,6 +794,72 @@ def g17_vision_loss():
     save("g17_vision_loss", **out)
 
 
+# ---------------------------------------------------------------- G18 Gaussian policy on pixel observations
+from make_golden_cases import VIS_GAUSS_CASES  # noqa: E402
+
+
+def vis_gauss_specs(cname):
+    vname, tkw, kw = VIS_GAUSS_CASES[cname]
+    v = O.VisSpec(**VIS_SPECS[vname])
+    cd = v.feat_dim + v.prop_dim
+    trunk = O.NetSpec("gaussian", cond_dim=cd, residual=True, **tkw)
+    critic = O.NetSpec("critic", cond_dim=cd, mlp_dims=[256, 256, 256], activation="Mish", residual=True)
+    return v, trunk, critic, kw
+
+
+def g18_vision_gaussian():
+    """PPO_Gaussian over Gaussian_VisionMLP (model/common/mlp_gaussian.py:112-281) + ViTCritic: sampling with recorded noise,
+    get_logprobs, the loss 8-tuple and every gradient (both encoders, both trunks, the learned logvar)."""
+    from dppo.model.common.mlp_gaussian import Gaussian_VisionMLP
+    from dppo.model.rl.gaussian_ppo import PPO_Gaussian
+    out = {}
+    rs = np.random.RandomState(1800)
+    N = 20
+    for cname in VIS_GAUSS_CASES:
+        v, a, c, kw = vis_gauss_specs(cname)
+        actor = Gaussian_VisionMLP(backbone=ref_vit(v), action_dim=a.action_dim, horizon_steps=a.horizon_steps, cond_dim=v.prop_dim,
+                                   img_cond_steps=v.in_ch // 3, mlp_dims=list(a.mlp_dims), activation_type=a.activation,
+                                   residual_style=True, fixed_std=kw["fixed_std"], learn_fixed_std=kw["learn_fixed_std"],
+                                   std_min=kw["std_min"], std_max=kw["std_max"], spatial_emb=v.spatial_emb, num_img=v.num_img,
+                                   augment=False)
+        sd = dict(O.vision_init_params(v, a, 71))
+        sd["logvar_min"], sd["logvar_max"] = actor.logvar_min.data.clone(), actor.logvar_max.data.clone()
+        if kw["learn_fixed_std"]:
+            sd["logvar"] = gauss_logvar(a, kw, 73)
+        actor.load_state_dict(sd, strict=True)
+        m = PPO_Gaussian(actor=actor, critic=ref_vit_critic(v, c, O.vision_init_params(v, c, 72)), horizon_steps=a.horizon_steps,
+                         device="cpu", clip_ploss_coef=kw["clip_ploss_coef"], clip_vloss_coef=kw.get("clip_vloss_coef"),
+                         norm_adv=True, randn_clip_value=kw["randn_clip_value"])
+        rgb, state = vis_inputs(rs, v, N)
+        cond = vis_cond(rgb, state)
+        noise = torch.from_numpy(rs.randn(N, a.horizon_steps * a.action_dim).astype(np.float32))
+        normal0 = torch.normal
+        torch.normal = lambda loc, scale, *a_, **k_: loc + scale * noise
+        try:
+            actions = m(cond=cond, deterministic=False)
+        finally:
+            torch.normal = normal0
+        with torch.no_grad():
+            lp, ent, std = m.get_logprobs(cond, actions)
+            oldv = m.critic(cond).view(-1) + torch.from_numpy(rs.normal(0, 0.3, N).astype(np.float32))
+        oldlp = lp + torch.from_numpy(rs.normal(0, 0.02, N).astype(np.float32))
+        ret = torch.from_numpy(rs.normal(0, 1, N).astype(np.float32))
+        adv = torch.from_numpy(rs.normal(0.3, 2.0, N).astype(np.float32))
+        res = m.loss(cond, actions, ret, oldv, adv.clone(), oldlp, use_bc_loss=False)
+        (res[0] + 0.01 * res[1] + 0.5 * res[2]).backward()
+        out.update({f"{cname}_rgb": rgb, f"{cname}_state": state, f"{cname}_noise": noise, f"{cname}_actions": actions,
+                    f"{cname}_logprobs": lp, f"{cname}_oldlogprobs": oldlp, f"{cname}_oldvalues": oldv, f"{cname}_returns": ret,
+                    f"{cname}_adv": adv,
+                    f"{cname}_stats": np.array([res[0].item(), res[1].item(), res[2].item(), res[3], res[4], res[5],
+                                                float(res[6]), res[7]], dtype=np.float64)})
+        for k, p in m.actor_ft.named_parameters():
+            if p.grad is not None:
+                put_grad(out, f"{cname}_gactor_{k}", p.grad)
+        for k, p in m.critic.named_parameters():
+            put_grad(out, f"{cname}_gcritic_{k}", p.grad)
+    save("g18_vision_gaussian", **out)
+
+
 # ---------------------------------------------------------------- G10 LR schedule trace
 from make_golden_cases import SCHED_CASES  # noqa: E402
 
@@ -819,6 +885,6 @@ def g10_scheduler():
 if __name__ == "__main__":
     only = sys.argv[1:]  # e.g. `make_golden.py g8_bc` regenerates one file (each generator owns its RNG stream)
     for fn in (g1_tables, g2_forward, g3_g4_chains, g5_loss, g6_reward_scaler, g7_adamw, g8_bc, g9_denoise_mse, g10_scheduler, g11_eval, g12_gaussian, g13_unet, g14_unet_loss, g15_unet_dim40, g16_vision,
-               g17_vision_loss):
+               g17_vision_loss, g18_vision_gaussian):
         if not only or fn.__name__ in only:
             fn()

@@ -111,3 +111,14 @@ VIS_LOSS_CASES = {
                                                clip_ploss_coef=0.01, clip_ploss_coef_base=0.001, min_sampling_denoising_std=0.1), 4),
 }
 VIS_MSE_CASES = {"vmlp_mse": ("vmlp_small", 20, 16), "vunet_mse": ("vunet_small", 20, 12)}
+
+# Gaussian policy on pixels (Gaussian_VisionMLP + ViTCritic): name -> (vis spec, trunk kwargs, model kwargs)
+VIS_GAUSS_CASES = {
+    # cfg/robomimic/finetune/can/ft_ppo_gaussian_mlp_img.yaml:98-124 at small maps: learned std from 0.1, residual 512 trunk
+    "vgauss_small": ("vis_small", dict(mlp_dims=[512, 512, 512], activation="Mish", action_dim=3, horizon_steps=4),
+                     dict(fixed_std=0.1, learn_fixed_std=True, std_min=0.01, std_max=0.2, clip_ploss_coef=0.01,
+                          randn_clip_value=3)),
+    "vgauss_two_fixed": ("vis_two", dict(mlp_dims=[256, 256, 256], activation="ReLU", action_dim=4, horizon_steps=4),
+                         dict(fixed_std=0.08, learn_fixed_std=False, std_min=0.01, std_max=1.0, clip_ploss_coef=0.02,
+                              clip_vloss_coef=0.2, randn_clip_value=3)),
+}

@@ -237,3 +237,12 @@ def test_every_shipped_pixel_diffusion_cfg_builds():
                 assert isinstance(instantiate(cfg.model.critic), ViTCritic), p
             n += 1
     assert n >= 20
+    n_g = 0
+    for p in sorted(glob.glob(os.path.join(REF_CFG, "*", "finetune", "*", "ft_ppo_gaussian_mlp_img.yaml"))):
+        cfg = load_config(p, overrides=["device=cpu"])
+        net = instantiate(cfg.model.actor)
+        assert getattr(net, "is_vision", False) and net.learn_fixed_std and net.tanh_output, p
+        assert get_class(cfg._target_).__name__ == "TrainPPOImgGaussianAgent", p
+        assert lib.dppo_vis_param_count(C.byref(net.vis.desc)) == sum(q.numel() for q in net.vis.trunk_parameters())
+        n_g += 1
+    assert n_g == 4

@@ -316,3 +316,105 @@ def test_hip_vision_denoise_mse_and_grads(golden, case):
     loss.backward()
     (worst, e), nerr = vis_grad_report(g, f"{case}_g", [(k, p.grad) for k, p in net.named_parameters()])
     assert e < 5e-3 and nerr < 1e-3, (worst, e, nerr)
+
+
+# ------------------------------------------------------------------ G18: Gaussian policy on pixels
+from tests.golden.make_golden_cases import VIS_GAUSS_CASES  # noqa: E402
+
+
+def gauss_specs(cname):
+    vname, tkw, kw = VIS_GAUSS_CASES[cname]
+    v = O.VisSpec(**VIS_SPECS[vname])
+    cd = v.feat_dim + v.prop_dim
+    trunk = O.NetSpec("gaussian", cond_dim=cd, residual=True, **tkw)
+    critic = O.NetSpec("critic", cond_dim=cd, mlp_dims=[256, 256, 256], activation="Mish", residual=True)
+    return v, trunk, critic, kw
+
+
+def gauss_logvar(spec, kw, seed):  # the generator's recipe (tests/golden/make_golden.py)
+    rs = np.random.RandomState(seed)
+    return T((np.log(kw["fixed_std"] ** 2) + rs.uniform(-0.4, 0.4, size=spec.action_dim)).astype(np.float32))
+
+
+@pytest.mark.parametrize("case", sorted(VIS_GAUSS_CASES))
+def test_oracle_vision_gaussian(golden, case):
+    g = golden("g18_vision_gaussian")
+    v, a, c, kw = gauss_specs(case)
+    gc = O.GaussianCfg(fixed_std=kw["fixed_std"], learn_fixed_std=kw["learn_fixed_std"], std_min=kw["std_min"], std_max=kw["std_max"],
+                       tanh_output=True, randn_clip_value=kw["randn_clip_value"], clip_ploss_coef=kw["clip_ploss_coef"],
+                       clip_vloss_coef=kw.get("clip_vloss_coef"), norm_adv=True)
+    ft = {k: t.clone().requires_grad_(True) for k, t in O.vision_init_params(v, a, 71).items()}
+    cr = {k: t.clone().requires_grad_(True) for k, t in O.vision_init_params(v, c, 72).items()}
+    lv = gauss_logvar(a, kw, 73).requires_grad_(True) if kw["learn_fixed_std"] else None
+    cond = cond_of(g, case)
+    aspec, cspec = O.VisionSpec(v, a), O.VisionSpec(v, c)
+    with torch.no_grad():
+        act = O.gaussian_sample(gc, aspec, ft, lv, cond, T(g[f"{case}_noise"]))
+        lp, _, _ = O.gaussian_logprob(gc, aspec, ft, lv, cond, T(g[f"{case}_actions"]))
+    np.testing.assert_allclose(act.numpy(), g[f"{case}_actions"], rtol=3e-4, atol=3e-4)
+    np.testing.assert_allclose(lp.numpy(), g[f"{case}_logprobs"], rtol=2e-3, atol=2e-3)
+    d = lambda k: T(g[f"{case}_{k}"])
+    res = O.gaussian_ppo_loss(gc, aspec, cspec, ft, lv, cr, cond, d("actions"), d("returns"), d("oldvalues"), d("adv"), d("oldlogprobs"))
+    got = np.array([res[0].item(), res[1].item(), res[2].item(), res[3], res[4], res[5], float(res[6]), res[7]])
+    np.testing.assert_allclose(got, g[f"{case}_stats"], rtol=2e-4, atol=2e-5)
+    (res[0] + 0.01 * res[1] + 0.5 * res[2]).backward()
+    for k, p in ft.items():
+        check_grad(g, f"{case}_gactor_{k}", p.grad, rtol=5e-3, atol=5e-6)
+    for k, p in cr.items():
+        check_grad(g, f"{case}_gcritic_{k}", p.grad, rtol=2e-3, atol=2e-6)
+    if lv is not None:
+        check_grad(g, f"{case}_gactor_logvar", lv.grad, rtol=1e-3, atol=1e-6)
+
+
+def hip_gauss_model(case, prec):
+    from dppo_amd.model.common.mlp_gaussian import Gaussian_VisionMLP
+    from dppo_amd.model.rl.gaussian_ppo import PPO_Gaussian
+    v, a, c, kw = gauss_specs(case)
+    actor = Gaussian_VisionMLP(backbone=hip_backbone(v, prec), action_dim=a.action_dim, horizon_steps=a.horizon_steps,
+                               cond_dim=v.prop_dim, img_cond_steps=v.in_ch // 3, mlp_dims=list(a.mlp_dims), activation_type=a.activation,
+                               residual_style=True, fixed_std=kw["fixed_std"], learn_fixed_std=kw["learn_fixed_std"],
+                               std_min=kw["std_min"], std_max=kw["std_max"], spatial_emb=v.spatial_emb, num_img=v.num_img,
+                               precision=prec)
+    sd = dict(O.vision_init_params(v, a, 71))
+    sd["logvar_min"], sd["logvar_max"] = actor.logvar_min.data.clone(), actor.logvar_max.data.clone()
+    if kw["learn_fixed_std"]:
+        sd["logvar"] = gauss_logvar(a, kw, 73)
+    actor.load_state_dict(sd, strict=True)
+    critic = hip_vit_critic(v, c, O.vision_init_params(v, c, 72), prec)
+    m = PPO_Gaussian(actor=actor, critic=critic, horizon_steps=a.horizon_steps, device="cuda:0", clip_ploss_coef=kw["clip_ploss_coef"],
+                     clip_vloss_coef=kw.get("clip_vloss_coef"), norm_adv=True, randn_clip_value=kw["randn_clip_value"], precision=prec)
+    return m, v, a, c, kw
+
+
+def test_gaussian_vision_state_dict_matches_the_reference_names():
+    from dppo_amd.model.common.mlp_gaussian import Gaussian_VisionMLP
+    v, a, c, kw = gauss_specs("vgauss_small")
+    m = Gaussian_VisionMLP(backbone=hip_backbone(v, "fp32"), action_dim=a.action_dim, horizon_steps=a.horizon_steps, cond_dim=v.prop_dim,
+                           img_cond_steps=v.in_ch // 3, mlp_dims=list(a.mlp_dims), residual_style=True, fixed_std=0.1,
+                           learn_fixed_std=True, spatial_emb=v.spatial_emb, precision="fp32")
+    want = ["logvar", "logvar_min", "logvar_max"] + [n for n, _, _ in O.vis_param_shapes(v)] + [n for n, _, _ in O.param_shapes(a)]
+    assert list(m.state_dict()) == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(VIS_GAUSS_CASES))
+def test_hip_vision_gaussian(golden, case):
+    """PPO_Gaussian with pixel networks (fp32): sampling with recorded noise, log-probs, loss statistics and every gradient
+    (both encoders, both trunks, logvar) against the reference."""
+    g = golden("g18_vision_gaussian")
+    m, v, a, c, kw = hip_gauss_model(case, "fp32")
+    cond = cuda_cond(g, case, u8=True)
+    act = m(cond=cond, deterministic=False, noise=T(g[f"{case}_noise"]).cuda())
+    np.testing.assert_allclose(act.cpu().numpy(), g[f"{case}_actions"], rtol=5e-4, atol=5e-4)
+    lp, _, _ = m.get_logprobs(cond, T(g[f"{case}_actions"]).cuda())
+    np.testing.assert_allclose(lp.cpu().numpy(), g[f"{case}_logprobs"], rtol=5e-3, atol=5e-3)
+    d = lambda k: T(g[f"{case}_{k}"]).cuda()
+    res = m.loss(cond, d("actions"), d("returns"), d("oldvalues"), d("adv"), d("oldlogprobs"), use_bc_loss=False)
+    got = np.array([res[0].item(), res[1].item(), res[2].item(), res[3], res[4], res[5], float(res[6]), res[7]])
+    np.testing.assert_allclose(got, g[f"{case}_stats"], rtol=2e-3, atol=2e-4)
+    (res[0] + 0.01 * res[1] + 0.5 * res[2]).backward()
+    named = [(k, p.grad) for k, p in m.actor_ft.named_parameters() if p.grad is not None]
+    (worst, e), nerr = vis_grad_report(g, f"{case}_gactor", named)
+    assert e < 2e-2 and nerr < 2e-3, ("actor", worst, e, nerr)
+    (worst, e), nerr = vis_grad_report(g, f"{case}_gcritic", [(k, p.grad) for k, p in m.critic.named_parameters()])
+    assert e < 5e-3 and nerr < 1e-3, ("critic", worst, e, nerr)
