@@ -418,3 +418,35 @@ def test_hip_vision_gaussian(golden, case):
     assert e < 2e-2 and nerr < 2e-3, ("actor", worst, e, nerr)
     (worst, e), nerr = vis_grad_report(g, f"{case}_gcritic", [(k, p.grad) for k, p in m.critic.named_parameters()])
     assert e < 5e-3 and nerr < 1e-3, ("critic", worst, e, nerr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["vmlp_loss", "vunet_loss"])
+def test_hip_vision_ppo_loss_bf16(golden, case):
+    """The benchmarked precision of the pixel update against the reference: v_loss within 5e-2 relative, the policy statistics
+    within the bf16 log-ratio error of the state path, gradient cosine per network >= 0.97 for the critic (no clip
+    branches) and >= 0.3 for the actor: at eps_k = 0.001..0.01 the bf16 log-ratio error flips the clip branch of a few samples,
+    and with 16-24 samples in the fixture two flips move the cosine that far (measured 0.44; the state path's N = 50,000 test
+    holds 0.995: tests/test_bf16_parity.py)."""
+    g = golden("g17_vision_loss")
+    name, N, kw, rh = VIS_LOSS_CASES[case]
+    m, v, trunk, cspec = hip_vision_model(name, 31, "bf16", kw)
+    d = lambda k: T(g[f"{case}_{k}"]).cuda()
+    res = m.loss(cuda_cond(g, case, u8=True), d("prev"), d("next"), d("kinds"), d("returns"), d("oldvalues"), d("adv"),
+                 d("oldlogprobs"), use_bc_loss=False, reward_horizon=rh)
+    ref = g[f"{case}_stats"]
+    assert abs(res[2].item() - ref[2]) <= 5e-2 * abs(ref[2]) + 1e-3
+    assert abs(res[5] - ref[5]) < 0.05 and np.isfinite(res[0].item()) and abs(res[4] - ref[4]) < 5e-3
+    (res[0] + 0.5 * res[2]).backward()
+
+    def cos(prefix, net):
+        num = den_a = den_b = 0.0
+        for k, p in net.named_parameters():
+            x = p.grad.double().cpu().numpy().reshape(-1)
+            key = f"{case}_{prefix}_{k}"
+            r, xs = (g[key].astype(np.float64).reshape(-1), x) if key in g else (g[key + "__sub"].astype(np.float64), x[::61])
+            num, den_a, den_b = num + float(xs @ r), den_a + float(xs @ xs), den_b + float(r @ r)
+        return num / (np.sqrt(den_a * den_b) + 1e-30)
+
+    assert cos("gcritic", m.critic) > 0.97
+    assert cos("gactor", m.actor_ft) > 0.3
