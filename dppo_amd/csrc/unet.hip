@@ -605,6 +605,11 @@ struct Runner {
   Ws<P>& W;
   int64_t rows;
   hipStream_t s;
+  // sampler: FiLM parameters of every block precomputed for all steps (they depend on (t_k, obs) only, not on x): film[b] is
+  // block b's table in forward order, this step's rows start at film_row0; null = run the encoders in place
+  float* const* film = nullptr;
+  int64_t film_row0 = 0;
+  int block_idx = 0;
 
   // GEMM over image rows: start row `r0` of the padded image, row stride `stride` images rows, K = Kp
   void gemm(const Img& in, int r0, int stride, const void* Wp, int N, int Kp, const float* bias, float* out, int ldo) {
@@ -618,23 +623,26 @@ struct Runner {
   void conv(const Conv& c, const Img& in, float* out, int ldo) {
     gemm(in, PAD - c.ks / 2, 1, pk + c.pk, c.co, c.Kp, prm + c.b, out, ldo);
   }
-  void encoder(const ResBlock& r) {  // FiLM parameters of one block from the conditioning vector (unet.py:76-90,102)
+  // FiLM parameters of one block from the conditioning vector (unet.py:76-90,102): `n` rows of g -> out [n][rup(cc, 16)]
+  void encoder(const ResBlock& r, const void* gsrc = nullptr, int64_t n = -1, float* out = nullptr, void* e1 = nullptr,
+               void* e2 = nullptr) {
     GemmNT g;
-    const void* x = W.g;
+    const void* x = gsrc ? gsrc : W.g;
+    if (n < 0) n = rows;
     int K = L.Kg;
     for (int i = 0; i < r.n_enc; ++i) {
       const Lin& l = r.enc[i];
       memset(&g, 0, sizeof(g));
-      g.X = x, g.ldx = K, g.M = (int)rows, g.N = l.out, g.Kp = l.Kp, g.W = pk + l.pk, g.ldw = l.Kp, g.bias = prm + l.b;
+      g.X = x, g.ldx = K, g.M = (int)n, g.N = l.out, g.Kp = l.Kp, g.W = pk + l.pk, g.ldw = l.Kp, g.bias = prm + l.b;
       if (i + 1 < r.n_enc) {
-        g.out_act = i == 0 ? W.e1 : W.e2, g.ldo = rup(l.out, 64), g.act = d.act;
+        g.out_act = i == 0 ? (e1 ? e1 : W.e1) : (e2 ? e2 : W.e2), g.ldo = rup(l.out, 64), g.act = d.act;
         x = g.out_act, K = g.ldo;
       } else {
-        g.out_f32 = W.emb, g.ldo32 = rup(r.cc, 16);
+        g.out_f32 = out ? out : W.emb, g.ldo32 = rup(r.cc, 16);
       }
       launch_gemm_nt<P>(g, s);
       if (i + 1 < r.n_enc && rup(l.out, 16) < g.ldo)  // the next GEMM's K runs over the padded width
-        launch_zero_cols<P>(g.out_act, (int)rows, rup(l.out, 16), g.ldo, g.ldo, s);
+        launch_zero_cols<P>(g.out_act, (int)n, rup(l.out, 16), g.ldo, g.ldo, s);
     }
   }
   // ResidualBlock1D.forward (unet.py:100-118): in -> out image (channel offset coff of an image of width ldd), optionally
@@ -642,12 +650,15 @@ struct Runner {
   void resblock(const ResBlock& r, const Img& in, void* mid_img, void* out_img, int ldd, int coff, int zero_pads,
                 void* dst2 = nullptr, int ldd2 = 0, int coff2 = 0, int zero2 = 0) {
     const int T = in.T, Tp = in.Tp(), ldc = rup(r.co, 16), Cw = rup(r.co, 64);
-    encoder(r);
+    const float* emb = W.emb;
+    if (film) emb = film[block_idx] + (size_t)film_row0 * rup(r.cc, 16);
+    else encoder(r);
+    ++block_idx;
     conv(r.c1, in, W.conv, ldc);
     GnArgs a;
     memset(&a, 0, sizeof(a));
     a.src = W.conv, a.lds = ldc, a.Tps = Tp, a.T = T, a.C = r.co, a.Cw = Cw, a.G = d.n_groups, a.gamma = prm + r.n1.g;
-    a.beta = prm + r.n1.b, a.eps = d.groupnorm_eps, a.act = d.act, a.film = d.cond_predict_scale ? 2 : 1, a.emb = W.emb;
+    a.beta = prm + r.n1.b, a.eps = d.groupnorm_eps, a.act = d.act, a.film = d.cond_predict_scale ? 2 : 1, a.emb = emb;
     a.lde = rup(r.cc, 16), a.dst = mid_img, a.ldd = Cw, a.coff = 0, a.zero_pads = 1;
     hipLaunchKernelGGL((unet_gn_kernel<P>), dim3((unsigned)rows), dim3(256), 0, s, a);
     Img mid{mid_img, T, Cw};
@@ -670,6 +681,7 @@ struct Runner {
   // (every map sits in its image padded to a multiple of 64 channels, the padding written as zeros: Img.C is that stride)
   void forward(float* out) {
     const int nl = d.n_levels, T0 = d.horizon_steps;
+    block_idx = 0;
     Img cur{W.in_img, T0, 64};
     void* bufs[3] = {W.bufA, W.bufB, W.bufC};
     auto pick = [&](const void* x0, const void* x1) {  // a scratch image that is neither of the two in use
@@ -1697,6 +1709,43 @@ int forward_impl(const dppo_unet_desc& d, const float* prm, const char* pk, cons
   return api_check_launch();
 }
 
+// the ResidualBlock1Ds in the order Runner::forward runs them
+int forward_order(const Layout& L, int nl, const ResBlock** out) {
+  int n = 0;
+  for (int i = 0; i < nl; ++i) out[n++] = &L.down[2 * i], out[n++] = &L.down[2 * i + 1];
+  out[n++] = &L.mid[0], out[n++] = &L.mid[1];
+  for (int j = 0; j < nl - 1; ++j) out[n++] = &L.up[2 * j], out[n++] = &L.up[2 * j + 1];
+  return n;
+}
+template <class P>
+struct FilmPlan {
+  void *g, *e1, *e2;  // [n_steps * B][Kg] conditioning rows; encoder hidden activations
+  float* film[64];    // per block: [n_steps * B][rup(cc, 16)]
+  size_t bytes;
+};
+// carve the FiLM tables of a sampling call out of `avail` bytes at `base`; false (and nothing used) if they do not fit
+template <class P>
+bool plan_film(const dppo_unet_desc& d, const Layout& L, int64_t B, int n_steps, char* base, int64_t avail, FilmPlan<P>& F) {
+  const ResBlock* order[64];
+  const int nb = forward_order(L, d.n_levels, order);
+  const size_t R = (size_t)B * n_steps;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    off = al(off);
+    void* p = base ? base + off : nullptr;
+    off += bytes + 65536;
+    return p;
+  };
+  int ccmax = 64;
+  for (int b = 0; b < nb; ++b) ccmax = rup(order[b]->cc, 64) > ccmax ? rup(order[b]->cc, 64) : ccmax;
+  F.g = take(R * L.Kg * P::ESIZE);
+  F.e1 = take(R * ccmax * P::ESIZE);
+  F.e2 = take(R * ccmax * P::ESIZE);
+  for (int b = 0; b < nb; ++b) F.film[b] = (float*)take(R * rup(order[b]->cc, 16) * 4);
+  F.bytes = al(off);
+  return base != nullptr && avail >= (int64_t)F.bytes;
+}
+
 template <class P>
 int sample_impl(const dppo_unet_desc& d, const float* pb, const char* kb, const float* pf, const char* kf,
                 const dppo_diffusion_cfg& cfg, const dppo_step* sched, int n_steps, const float* obs, const float* noise,
@@ -1708,6 +1757,29 @@ int sample_impl(const dppo_unet_desc& d, const float* pb, const char* kb, const 
   const int AF = d.horizon_steps * d.action_dim;
   const int64_t n = B * AF;
   const unsigned blocks = (unsigned)((n + 255) / 256);
+  // FiLM tables for all steps, when the caller's workspace has the room (dppo_unet_sample_workspace_bytes): the encoders of
+  // every block see (t_k, obs) only, so their 3 GEMMs x 8-12 blocks leave the per-step chain (~a third of its launches)
+  FilmPlan<P> F;
+  const bool pre = plan_film<P>(d, L, B, n_steps, (char*)ws + W.bytes, wsb - (int64_t)W.bytes, F);
+  if (pre) {
+    for (int i = 0; i < n_steps; ++i)
+      hipLaunchKernelGGL((unet_cond_rows_kernel<P>), dim3((unsigned)B), dim3(64), 0, s,
+                         (const float*)((sched[i].net ? kf : kb) + L.temb) + (size_t)sched[i].t * d.time_dim,
+                         (const int64_t*)nullptr, obs, d.time_dim, d.cond_dim, 1,
+                         (typename P::elem_t*)F.g + (size_t)i * B * L.Kg, L.Kg, d.larger_encoder ? -1 : d.act);
+    // runs of consecutive steps on the same network share one encoder pass
+    for (int a0 = 0; a0 < n_steps;) {
+      int a1 = a0 + 1;
+      while (a1 < n_steps && sched[a1].net == sched[a0].net) ++a1;
+      Runner<P> R{d, L, sched[a0].net ? pf : pb, sched[a0].net ? kf : kb, W, B, s};
+      const ResBlock* order[64];
+      const int nbk = forward_order(L, d.n_levels, order);
+      for (int b = 0; b < nbk; ++b)
+        R.encoder(*order[b], (const char*)F.g + (size_t)a0 * B * L.Kg * P::ESIZE, (int64_t)(a1 - a0) * B,
+                  F.film[b] + (size_t)a0 * B * rup(order[b]->cc, 16), F.e1, F.e2);
+      a0 = a1;
+    }
+  }
   hipLaunchKernelGGL(unet_init_kernel, dim3(blocks), dim3(256), 0, s, noise, cfg.seed_lo, cfg.seed_hi, n, AF, W.x, chains,
                      chain_len, init_slot);
   for (int i = 0; i < n_steps; ++i) {
@@ -1716,10 +1788,12 @@ int sample_impl(const dppo_unet_desc& d, const float* pb, const char* kb, const 
     const char* pk = st.net ? kf : kb;
     hipLaunchKernelGGL((unet_input_kernel<P>), dim3((unsigned)B), dim3(256), 0, s, W.x, d.horizon_steps, d.action_dim,
                        (typename P::elem_t*)W.in_img, 64);
-    hipLaunchKernelGGL((unet_cond_rows_kernel<P>), dim3((unsigned)B), dim3(64), 0, s,
-                       (const float*)(pk + L.temb) + (size_t)st.t * d.time_dim, (const int64_t*)nullptr, obs, d.time_dim,
-                       d.cond_dim, 1, (typename P::elem_t*)W.g, L.Kg, d.larger_encoder ? -1 : d.act);
+    if (!pre)
+      hipLaunchKernelGGL((unet_cond_rows_kernel<P>), dim3((unsigned)B), dim3(64), 0, s,
+                         (const float*)(pk + L.temb) + (size_t)st.t * d.time_dim, (const int64_t*)nullptr, obs, d.time_dim,
+                         d.cond_dim, 1, (typename P::elem_t*)W.g, L.Kg, d.larger_encoder ? -1 : d.act);
     Runner<P> R{d, L, prm, pk, W, B, s};
+    if (pre) R.film = F.film, R.film_row0 = (int64_t)i * B;
     R.forward(W.eps);
     StepArgs a;
     memset(&a, 0, sizeof(a));
@@ -1794,6 +1868,21 @@ int64_t dppo_unet_workspace_bytes(const dppo_unet_desc* net, int prec, int64_t r
   Ws<BF16> W;
   carve<BF16>(*net, L, rows, nullptr, W);
   return (int64_t)W.bytes;
+}
+int64_t dppo_unet_sample_workspace_bytes(const dppo_unet_desc* net, int prec, int64_t B, int n_steps) {
+  const int64_t base = dppo_unet_workspace_bytes(net, prec, B);
+  if (base < 0) return base;
+  if (n_steps < 1 || n_steps > 100000) return api_fail(-1, "n_steps out of range");
+  const bool f32 = prec == DPPO_PREC_F32;
+  const Layout L = make_layout(*net, f32 ? 4 : 2, 0);
+  if (f32) {
+    FilmPlan<F32> F;
+    plan_film<F32>(*net, L, B, n_steps, nullptr, 0, F);
+    return base + (int64_t)F.bytes;
+  }
+  FilmPlan<BF16> F;
+  plan_film<BF16>(*net, L, B, n_steps, nullptr, 0, F);
+  return base + (int64_t)F.bytes;
 }
 int dppo_unet_forward(const dppo_unet_desc* net, int prec, const float* params, const void* packed, const float* x,
                       const int64_t* t, const float* state, int64_t rows, float* eps, void* workspace,

@@ -136,6 +136,7 @@ SYMBOLS = {
     "dppo_vis_backward": (_I, [C.POINTER(VisDesc), _I, _P, _P, _P, _I, _L, _P, _P, _L, _P]),
     "dppo_unet_pack": (_I, [C.POINTER(UnetDesc), _I, _I, _P, _P, _P]),
     "dppo_unet_workspace_bytes": (_L, [C.POINTER(UnetDesc), _I, _L]),
+    "dppo_unet_sample_workspace_bytes": (_L, [C.POINTER(UnetDesc), _I, _L, _I]),
     "dppo_unet_forward": (_I, [C.POINTER(UnetDesc), _I, _P, _P, _P, _P, _P, _L, _P, _P, _L, _P]),
     "dppo_unet_sample_chain": (_I, [C.POINTER(UnetDesc), _I, _P, _P, _P, _P, C.POINTER(DiffusionCfg), _P, _I, _P, _P, _L, _P,
                                     _P, _I, _I, _P, _L, _P]),

@@ -225,7 +225,7 @@ class DiffusionModel(nn.Module):
             chp = chains.data_ptr() if return_chain else None
             cl, isl = (chain_len if return_chain else 0), (init_slot if return_chain and a == 0 else -1)
             if is_unet:  # conv denoiser: host loop over the steps, dppo_unet_sample_chain
-                ws = base.workspace(B, dev)
+                ws = base.workspace(B, dev, n_steps=b - a)
                 hip.check(lib.dppo_unet_sample_chain(
                     C.byref(d), self.prec, base.flat_params().data_ptr(), base.packed(self.prec, K).data_ptr(),
                     ft.flat_params().data_ptr(), ft.packed(self.prec, K).data_ptr(), C.byref(cfg), tab[a:b].ctypes.data, b - a,

@@ -133,9 +133,12 @@ class Unet1D(HipNet):
         hip.check(hip.load().dppo_unet_pack(C.byref(d), prec, n_time, self.flat_params().data_ptr(), buf.data_ptr(),
                                             hip.stream()), "dppo_unet_pack")
 
-    def workspace(self, rows: int, device) -> torch.Tensor:
+    def workspace(self, rows: int, device, n_steps: int = 0) -> torch.Tensor:
+        """n_steps > 0: sized for a sampling call of that many steps with its FiLM tables precomputed."""
         d = self.net_desc()
-        wsb = hip.load().dppo_unet_workspace_bytes(C.byref(d), self.prec, rows)
+        lib = hip.load()
+        wsb = (lib.dppo_unet_sample_workspace_bytes(C.byref(d), self.prec, rows, n_steps) if n_steps > 0 else
+               lib.dppo_unet_workspace_bytes(C.byref(d), self.prec, rows))
         if wsb < 0:
             hip.check(int(wsb), "dppo_unet_workspace_bytes")
         return self.__dict__.setdefault("_ws", hip.Workspace()).get(wsb, device)

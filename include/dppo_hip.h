@@ -303,6 +303,10 @@ int64_t dppo_unet_packed_bytes(const dppo_unet_desc* net, int prec, int n_time);
 int dppo_unet_pack(const dppo_unet_desc* net, int prec, int n_time, const float* params, void* packed,
                    dppo_stream_t stream);
 int64_t dppo_unet_workspace_bytes(const dppo_unet_desc* net, int prec, int64_t rows);
+/* Workspace of one dppo_unet_sample_chain call with room for the FiLM tables of all its steps: the cond encoders of every
+ * block see (t_k, obs) only, so with this much workspace they are evaluated once up front (all steps in one pass per network)
+ * instead of inside every denoising step.  With the smaller dppo_unet_workspace_bytes(B) the call still works, encoders in place. */
+int64_t dppo_unet_sample_workspace_bytes(const dppo_unet_desc* net, int prec, int64_t B, int n_steps);
 /* eps (rows,Ta,Da) = Unet1D(x (rows,Ta,Da), t (rows,) int64, state (rows,cond)) */
 int dppo_unet_forward(const dppo_unet_desc* net, int prec, const float* params, const void* packed, const float* x,
                       const int64_t* t, const float* state, int64_t rows, float* eps, void* workspace,
