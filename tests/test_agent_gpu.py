@@ -569,3 +569,53 @@ def test_gaussian_agent_fine_tunes_from_pixels(tmp_path, monkeypatch):
     for name, b, a in zip(("actor trunk", "actor encoder", "critic trunk", "critic encoder", "logvar"), before, after):
         assert not torch.equal(a, b), name + " was not updated"
         assert torch.isfinite(a).all(), name
+
+
+# ------------------------------------------------------------------ data parallel, two ranks sharing the one GPU of the box
+def _img_dp_worker(rank, world, port, yaml_text, logdir, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DPPO_LOG_DIR=logdir, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # (RCCL cannot put two ranks on one device)
+    from dppo_amd.cfg.loader import get_class, load_config
+    p = os.path.join(logdir, f"ft_{rank}.yaml")
+    with open(p, "w") as f:
+        f.write(yaml_text)
+    cfg = load_config(p)
+    agent = get_class(cfg._target_)(cfg)
+    m = agent.model
+    start = [t.clone() for t in (m.actor_ft.flat_params(), m.actor_ft.vis.flat_params(), m.critic.vis.flat_params())]
+    agent.run()
+    end = (m.actor_ft.flat_params(), m.actor_ft.vis.flat_params(), m.critic.flat_params(), m.critic.vis.flat_params())
+    q.put((rank, [float(t.double().sum()) for t in end] + [float(t.double().abs().sum()) for t in end],
+           [bool(torch.equal(a, b)) for a, b in zip(start, end)], float(torch.rand(1))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_image_agent_two_ranks_keep_identical_weights(tmp_path):
+    """TrainPPOImgDiffusionAgent under torch.distributed (gloo, both ranks on cuda:0): the encoders are broadcast with the trunks,
+    every optimiser step all-reduces the one bucket of the four accumulators, so both ranks end with bit-identical weights
+    although each rolled out its own env shard with its own random stream."""
+    import socket
+
+    import torch.multiprocessing as mp
+    actor, num_img = IMG_ACTORS["mlp"]
+    text = IMG_YAML.replace("ACTOR", actor).replace("NUM_IMG", str(num_img)).replace("RGB_C", "3").replace(
+        "  n_train_itr: 3\n", "  n_train_itr: 2\n  force_train: True\n")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_img_dp_worker, args=(r, 2, port, text, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, (sums, same, rnd)) for r, sums, same, rnd in (q.get(timeout=600) for _ in range(2)))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[0][0] == got[1][0], (got[0][0], got[1][0])  # checksums of all four flat buffers, bit for bit
+    assert not any(got[0][1]) and not any(got[1][1])  # ... and they moved
+    assert got[0][2] != got[1][2]  # each rank has its own random stream
