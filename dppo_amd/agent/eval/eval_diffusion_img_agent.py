@@ -1,0 +1,6 @@
+"""``EvalImgDiffusionAgent`` of the reference (``dppo/agent/eval/eval_diffusion_img_agent.py``): see eval_agent.py."""
+from dppo_amd.agent.eval.eval_agent import EvalAgent
+
+
+class EvalImgDiffusionAgent(EvalAgent):
+    obs_keys = ("rgb", "state")

@@ -619,3 +619,53 @@ def test_image_agent_two_ranks_keep_identical_weights(tmp_path):
     assert got[0][0] == got[1][0], (got[0][0], got[1][0])  # checksums of all four flat buffers, bit for bit
     assert not any(got[0][1]) and not any(got[1][1])  # ... and they moved
     assert got[0][2] != got[1][2]  # each rank has its own random stream
+
+
+# ------------------------------------------------------------------ evaluation agents on fine-tuning checkpoints
+def _eval_yaml(train_yaml, target, ckpt, model_target, extra_model=""):
+    """The reference's eval cfg shape (cfg/*/eval/*/eval_diffusion_*.yaml) derived from a training YAML of this file: same
+    env / shapes / network block, model = DiffusionEval reading the checkpoint."""
+    head = train_yaml[:train_yaml.index("train:\n")]
+    head = head.replace(head[head.index("_target_:"):head.index("\n", head.index("_target_:"))], f"_target_: {target}")
+    actor = train_yaml[train_yaml.index("  actor:\n"):train_yaml.index("  critic:\n")].replace("  actor:\n", "  network:\n")
+    return (head + f"n_steps: 12\nrender_num: 0\nddim_steps: 5\nbase_policy_path: {ckpt}\n"
+            f"model:\n  _target_: {model_target}\n  ft_denoising_steps: ${{ft_denoising_steps}}\n  randn_clip_value: 3\n"
+            "  network_path: ${base_policy_path}\n" + extra_model + actor +
+            "  horizon_steps: ${horizon_steps}\n  obs_dim: ${obs_dim}\n  action_dim: ${action_dim}\n"
+            "  denoising_steps: ${denoising_steps}\n  device: ${device}\n")
+
+
+@pytest.mark.parametrize("pixels", [False, True])
+def test_eval_agent_runs_a_fine_tuning_checkpoint(tmp_path, monkeypatch, pixels):
+    """Fine-tune for two iterations, then EvalDiffusionAgent / EvalImgDiffusionAgent (reference agent/eval/*) load that
+    checkpoint through DiffusionEval and roll the deterministic policy: the result file carries the reference's statistics,
+    and the evaluated network is the checkpoint's fine-tuned one."""
+    from dppo_amd.cfg.loader import get_class, load_config
+    monkeypatch.setenv("DPPO_LOG_DIR", str(tmp_path))
+    if pixels:
+        actor, num_img = IMG_ACTORS["mlp"]
+        train = IMG_YAML.replace("ACTOR", actor).replace("NUM_IMG", str(num_img)).replace("RGB_C", "3")
+        sub, target = "synthetic-img", "dppo.agent.eval.eval_diffusion_img_agent.EvalImgDiffusionAgent"
+        extra = "  use_ddim: True\n  ddim_steps: ${ddim_steps}\n"
+    else:
+        train, sub, target, extra = YAML, "synthetic", "dppo.agent.eval.eval_diffusion_agent.EvalDiffusionAgent", ""
+    p = tmp_path / "ft.yaml"
+    p.write_text(train)
+    cfg = load_config(str(p))
+    agent = get_class(cfg._target_)(cfg)
+    agent.run()
+    ckpt = os.path.join(str(tmp_path), sub, "checkpoint", "state_2.pt")
+    assert os.path.exists(ckpt)
+    ey = tmp_path / "eval.yaml"
+    ey.write_text(_eval_yaml(train, target, ckpt, "dppo.model.diffusion.diffusion_eval.DiffusionEval", extra).replace(
+        f"logdir: ${{oc.env:DPPO_LOG_DIR}}/{sub}", f"logdir: ${{oc.env:DPPO_LOG_DIR}}/{sub}-eval"))
+    ecfg = load_config(str(ey))
+    ev = get_class(ecfg._target_)(ecfg)
+    assert torch.equal(ev.model.actor_ft.flat_params(), agent.model.actor_ft.flat_params())
+    if pixels:
+        assert torch.equal(ev.model.actor_ft.vis.flat_params(), agent.model.actor_ft.vis.flat_params())
+    res = ev.run()
+    assert set(res) >= {"num_episode", "eval_success_rate", "eval_episode_reward", "eval_best_reward"}
+    assert np.isfinite(res["eval_episode_reward"])
+    saved = np.load(os.path.join(str(tmp_path), sub + "-eval", "result.npz"))
+    assert int(saved["num_episode"]) == res["num_episode"]
