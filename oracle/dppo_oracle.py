@@ -13,7 +13,9 @@ Parity status: PINNED.  The reference ships no tests or golden vectors
 (SURVEY.md section 4), so the oracle is pinned against outputs of the
 reference itself, imported in the build container by
 ``tests/golden/make_golden.py`` and committed as ``tests/golden/*.npz``;
-``tests/test_oracle_golden.py`` checks every fixture.
+``tests/test_oracle_golden.py`` (g1-g10), ``tests/test_eval.py`` (g11), ``tests/test_gaussian.py`` (g12),
+``tests/test_unet.py`` (g13-g15) and ``tests/test_vision.py`` (g16-g18: ViT encoder, SpatialEmb, pixel networks) check
+every fixture.
 
 Parameters are plain ``dict[str, torch.Tensor]`` keyed by the reference's
 state-dict names without the module prefix, e.g. ``time_embedding.1.weight``,
