@@ -76,6 +76,7 @@ static ParamLayout param_layout(const dppo_net_desc& d) {
   for (int b = 0; b < d.n_blocks; ++b) {
     L.l1w[b] = o, o += (int64_t)H * H;
     L.l1b[b] = o, o += H;
+    if (d.plain) continue;  // a plain MLP's hidden layers are single Linear(H, H) modules (mlp.py:46-74)
     L.l2w[b] = o, o += (int64_t)H * H;
     L.l2b[b] = o, o += H;
     if (d.use_layernorm) {
@@ -119,7 +120,7 @@ static PackLayout pack_layout(const dppo_net_desc& d, int n_time) {
   L.Wout = o, o = al256(o + (size_t)d.out_dim * H * ES);
   L.WoutT = o, o = al256(o + (size_t)H * L.Kpo * ES);
   if (d.kind == 0) L.W0tT = o, o = al256(o + (size_t)d.time_dim * H * ES);
-  {  // per-wave fragment streams: forward (sampler + fused forward), out layer, backward (fused backward)
+  if (!d.plain) {  // per-wave fragment streams: forward (sampler + fused forward), out layer, backward (fused backward)
     const SamplerGeom g = sampler_geom<P>(d);
     const FusedGeom fg = fused_geom<P>(d);
     L.sstream = o, o = al256(o + (size_t)SAMPLER_WAVES * g.hidden_frags_per_wave * 64 * 16);
@@ -146,7 +147,12 @@ static PackLayout pack_layout(const dppo_net_desc& d, int n_time) {
 static int check_net(const dppo_net_desc* d) {
   if (!d) return fail(-1, "null net descriptor");
   if (d->kind != 0 && d->kind != 1) return fail(-1, "net.kind must be 0 (actor) or 1 (critic)");
-  if (d->hidden < 128 || d->hidden % 128) return fail(-1, "hidden=%d must be a positive multiple of 128", d->hidden);
+  if (d->plain != 0 && d->plain != 1) return fail(-1, "plain must be 0 or 1");
+  if (d->plain) {  // non-residual MLP trunk (model/common/mlp.py:27-81): layered GEMM path only
+    if (d->hidden < 64 || d->hidden % 64) return fail(-1, "plain MLP: hidden=%d must be a positive multiple of 64", d->hidden);
+    if (d->n_blocks < 1) return fail(-1, "plain MLP: at least two hidden widths (n_blocks = hidden-to-hidden layers >= 1)");
+    if (d->use_layernorm || d->cond_hidden || d->cond_out) return fail(-1, "plain MLP: LayerNorm / cond_mlp are not built");
+  } else if (d->hidden < 128 || d->hidden % 128) return fail(-1, "hidden=%d must be a positive multiple of 128", d->hidden);
   if (d->n_blocks < 0 || d->n_blocks > MAX_BLOCKS) return fail(-1, "n_blocks=%d out of [0,%d]", d->n_blocks, MAX_BLOCKS);
   if (d->act != DPPO_ACT_RELU && d->act != DPPO_ACT_MISH) return fail(-1, "activation %d unsupported", d->act);
   if (d->out_dim < 1 || d->out_dim > 128) return fail(-1, "out_dim=%d out of [1,128]", d->out_dim);
@@ -180,6 +186,7 @@ static int g_use_fused = 1;  // tuning knob 1: 1 = fused row-tile kernels where 
 template <class P>
 static bool fused_ok(const dppo_net_desc& d) {
   // the input tile (width round_up(in_dim, .)) and the d_out tile share an H-wide LDS image with the activations
+  if (d.plain) return false;
   return (g_use_fused || d.use_layernorm) && fused_rows_per_tile<P>(d) > 0 && d.out_dim <= 128 && d.hidden <= 1024 &&
          sampler_geom<P>(d).Kp0 <= d.hidden && fused_geom<P>(d).KpB0 <= d.hidden;
 }
@@ -196,8 +203,22 @@ static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char*
   const ParamLayout pl = param_layout(d);
   const PackLayout L = pack_layout<P>(d, n_time);
   const int H = d.hidden;
-  const bool one_launch = fused_ok<P>(d) && g_pack_one && pack_net_supports(d.time_dim);
   if (deferred) *deferred = false;
+  if (d.plain) {  // row-major operands of the layered path only
+    if (d.kind == 0) {
+      launch_time_table(prm + pl.te1_w, prm + pl.te1_b, prm + pl.te2_w, prm + pl.te2_b, d.time_dim, n_time, (float*)(pk + L.temb), s);
+      launch_transpose_cast<P>(prm + pl.W0, H, d.time_dim, d.in_dim, d.act_flat, pk + L.W0tT, H, s);
+    }
+    launch_cast_pad<P>(prm + pl.W0, H, d.in_dim, d.in_dim, pk + L.W0, L.Kp0, s);
+    for (int b = 0; b < d.n_blocks; ++b) {
+      launch_cast_pad<P>(prm + pl.l1w[b], H, H, H, pk + L.W1[b], H, s);
+      launch_transpose_cast<P>(prm + pl.l1w[b], H, H, H, 0, pk + L.W1T[b], H, s);
+    }
+    launch_cast_pad<P>(prm + pl.Wout, d.out_dim, H, H, pk + L.Wout, H, s);
+    launch_transpose_cast<P>(prm + pl.Wout, d.out_dim, H, H, 0, pk + L.WoutT, L.Kpo, s);
+    return check_launch();
+  }
+  const bool one_launch = fused_ok<P>(d) && g_pack_one && pack_net_supports(d.time_dim);
   if (d.kind == 0 && !one_launch)
     launch_time_table(prm + pl.te1_w, prm + pl.te1_b, prm + pl.te2_w, prm + pl.te2_b, d.time_dim, n_time,
                       (float*)(pk + L.temb), s);
@@ -396,7 +417,7 @@ static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, b
       B.dh_all[b] = c.take((size_t)M * H * ES);
       B.dz1_all[b] = b == 0 ? B.dz1 : c.take((size_t)M * H * ES);
     }
-    const int mt = fused_rows_per_tile<P>(d);
+    const int mt = d.plain ? 0 : fused_rows_per_tile<P>(d);
     B.tiles = mt > 0 ? (int)((M + mt - 1) / mt) : 0;
     B.tile_colsum = (float*)c.take((size_t)(2 * nb + 2 + (d.use_layernorm ? 4 * nb : 0)) * (B.tiles > 0 ? B.tiles : 1) * H * 4);
     const int tdp = round_up(d.time_dim > 0 ? d.time_dim : 1, 16);
@@ -473,6 +494,25 @@ static void mlp_forward(const dppo_net_desc& d, const float* prm, const char* pk
       f.ln_stats = d.use_layernorm ? B.ln_stats : nullptr;
     }
     g_fused_fault = launch_fused_forward<P>(d, f, s);
+    return;
+  }
+  if (d.plain) {  // x -> act(W0 x) -> act(W_b .) ... -> Wout .   (pre-activations kept for the backward: hpre[0], z1[b])
+    GemmNT q;
+    memset(&q, 0, sizeof(q));
+    q.M = (int)M, q.X = B.in, q.ldx = L.Kp0, q.W = pk + L.W0, q.ldw = L.Kp0, q.Kp = L.Kp0, q.N = H, q.bias = prm + pl.b0;
+    q.ldo = H, q.act = d.act, q.out_act = B.a1[0], q.out_pre = keep ? B.hpre[0] : nullptr;
+    launch_gemm_nt<P>(q, s);
+    for (int b = 0; b < nb; ++b) {
+      memset(&q, 0, sizeof(q));
+      q.M = (int)M, q.N = H, q.Kp = H, q.ldx = H, q.ldw = H, q.ldo = H, q.act = d.act;
+      q.X = b == 0 ? B.a1[0] : B.a2[b - 1], q.W = pk + L.W1[b], q.bias = prm + pl.l1b[b];
+      q.out_pre = keep ? B.z1[b] : nullptr, q.out_act = B.a2[b];
+      launch_gemm_nt<P>(q, s);
+    }
+    memset(&q, 0, sizeof(q));
+    q.M = (int)M, q.N = d.out_dim, q.Kp = H, q.ldx = H, q.ldw = H;
+    q.X = B.a2[nb - 1], q.W = pk + L.Wout, q.bias = prm + pl.bout, q.out_f32 = B.out, q.ldo32 = B.ldout;
+    launch_gemm_nt<P>(q, s);
     return;
   }
   GemmNT g;
@@ -802,6 +842,34 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       return;
     }
   }
+  if (d.plain) {
+    if (fin) launch_loss_finalize(*fin, s);
+    weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.a2[nb - 1], H, H, M, B, grad + pl.Wout, H, s);
+    launch_colsum<P>(B.d_out, (int)M, d.out_dim, L.Kpo, B.part, REDUCE_BLOCKS, grad + pl.bout, 1.f, s);
+    GemmNT q;  // dz = (upstream . W) * act'(z): starts from d_out . Wout at the last hidden layer's pre-activation
+    memset(&q, 0, sizeof(q));
+    q.M = (int)M, q.N = H, q.Kp = L.Kpo, q.ldx = L.Kpo, q.ldw = L.Kpo, q.ldo = H;
+    q.X = B.d_out, q.W = pk + L.WoutT, q.dsrc = B.z1[nb - 1], q.dsrc_kind = 2, q.dsrc_ld = H, q.dact = d.act, q.out_pre = B.dh;
+    launch_gemm_nt<P>(q, s);
+    void* dz = B.dh;
+    void* other = B.dz1;
+    for (int b = nb - 1; b >= 0; --b) {
+      weight_grad<P>(dz, H, H, b == 0 ? B.a1[0] : B.a2[b - 1], H, H, M, B, grad + pl.l1w[b], H, s);
+      launch_colsum<P>(dz, (int)M, H, H, B.part, REDUCE_BLOCKS, grad + pl.l1b[b], 1.f, s);
+      memset(&q, 0, sizeof(q));
+      q.M = (int)M, q.N = H, q.Kp = H, q.ldx = H, q.ldw = H, q.ldo = H;
+      q.X = dz, q.W = pk + L.W1T[b], q.dsrc = b == 0 ? B.hpre[0] : B.z1[b - 1], q.dsrc_kind = 2, q.dsrc_ld = H, q.dact = d.act;
+      q.out_pre = other;
+      launch_gemm_nt<P>(q, s);
+      void* t = dz;
+      dz = other, other = t;
+    }
+    weight_grad<P>(dz, H, H, B.in, L.Kp0, d.in_dim, M, B, grad + pl.W0, d.in_dim, s);
+    launch_colsum<P>(dz, (int)M, H, H, B.part, REDUCE_BLOCKS, grad + pl.b0, 1.f, s);
+    if (d.kind == 0) time_embedding_grad<P>(d, prm, pk, L, M, B, dz, grad, krow, ksteps, Kft, s);
+    B.dh0_final = dz;
+    return;
+  }
   if (fin) launch_loss_finalize(*fin, s);
   // output layer parameters
   weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.hE, H, H, M, B, grad + pl.Wout, H, s);
@@ -1057,8 +1125,74 @@ static int sample_impl(const dppo_net_desc& d, const float* pb, const char* kb, 
   return check_launch();
 }
 
+// ---- plain (non-residual) trunks: the K-step loop on the host, one layered forward + one posterior kernel per step -------
+template <class P>
+static size_t carve_plain_sample(Carver& c, const dppo_net_desc& d, int64_t B, MlpBufs<P>& Bz, float*& x) {
+  carve_mlp<P>(c, d, B, false, false, Bz);
+  x = (float*)c.take((size_t)B * d.act_flat * 4);
+  return al256(c.off);
+}
+int64_t dppo_plain_sample_workspace_bytes(const dppo_net_desc* actor, int prec, int64_t B) {
+  if (check_net(actor) || check_prec(prec)) return -1;
+  if (actor->kind != 0 || !actor->plain) return fail(-1, "dppo_plain_sample_chain needs a plain actor descriptor");
+  if (B < 1 || B > 0x7fffffff) return fail(-1, "B out of range");
+  Carver c{nullptr, 0, 0};
+  float* x;
+  if (prec == DPPO_PREC_F32) {
+    MlpBufs<F32> Bz;
+    return (int64_t)carve_plain_sample<F32>(c, *actor, B, Bz, x);
+  }
+  MlpBufs<BF16> Bz;
+  return (int64_t)carve_plain_sample<BF16>(c, *actor, B, Bz, x);
+}
+template <class P>
+static int plain_sample_impl(const dppo_net_desc& d, const float* pb, const char* kb, const float* pf, const char* kf,
+                             const dppo_diffusion_cfg& cfg, const dppo_step* sched, int n_steps, const float* obs,
+                             const float* noise, int64_t B, float* traj, float* chains, int chain_len, int init_slot, void* ws,
+                             int64_t wsb, hipStream_t s) {
+  Carver c{(char*)ws, 0, (size_t)wsb};
+  MlpBufs<P> Bz;
+  float* x;
+  const size_t need = carve_plain_sample<P>(c, d, B, Bz, x);
+  if ((int64_t)need > wsb) return fail(-1, "workspace too small: need %zu bytes, got %lld", need, (long long)wsb);
+  const PackLayout L = pack_layout<P>(d, 0);
+  const int AF = d.act_flat;
+  const int64_t n = B * AF;
+  launch_chain_init(noise, cfg.seed_lo, cfg.seed_hi, n, AF, x, chains, chain_len, init_slot, s);
+  for (int i = 0; i < n_steps; ++i) {
+    const dppo_step& st = sched[i];
+    const float* prm = st.net ? pf : pb;
+    const char* pk = st.net ? kf : kb;
+    // rows [x | temb(t) | obs]: the table pointer is offset to row t, so every row reads its row 0
+    launch_build_direct<P>(x, nullptr, obs, (const float*)(pk + L.temb) + (size_t)st.t * d.time_dim, AF, d.time_dim, d.cond_dim, B,
+                           Bz.in, L.Kp0, s);
+    mlp_forward<P>(d, prm, pk, L, B, Bz, false, s);
+    launch_chain_step(cfg, st, x, Bz.out, Bz.ldout, noise, (size_t)(i + 1) * n, n, AF, chain_len, i + 1 == n_steps, chains, traj, s);
+  }
+  return check_launch();
+}
+int dppo_plain_sample_chain(const dppo_net_desc* actor, int prec, const float* params_base, const void* packed_base,
+                            const float* params_ft, const void* packed_ft, const dppo_diffusion_cfg* cfg,
+                            const dppo_step* sched_host, int n_steps, const float* obs, const float* noise, int64_t B,
+                            float* traj, float* chains, int chain_len, int init_slot, void* workspace,
+                            int64_t workspace_bytes, dppo_stream_t stream) {
+  if (int e = check_net(actor)) return e;
+  if (int e = check_prec(prec)) return e;
+  if (actor->kind != 0 || !actor->plain) return fail(-1, "dppo_plain_sample_chain needs a plain actor descriptor");
+  if (!params_base || !packed_base || !params_ft || !packed_ft || !cfg || !sched_host || !obs || !traj || !workspace)
+    return fail(-1, "null pointer");
+  if (B < 1 || B > 0x7fffffff || n_steps < 1) return fail(-1, "B / n_steps out of range");
+  if (chains != nullptr && chain_len < 1) return fail(-1, "chain_len must be >= 1 when chains are requested");
+#define CALL(P)                                                                                                             \
+  plain_sample_impl<P>(*actor, params_base, (const char*)packed_base, params_ft, (const char*)packed_ft, *cfg, sched_host, n_steps, \
+                       obs, noise, B, traj, chains, chain_len, init_slot, workspace, workspace_bytes, (hipStream_t)stream)
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
+}
+
 int64_t dppo_sample_chain_workspace_bytes(const dppo_net_desc* actor, int prec, int64_t B) {
   if (check_net(actor) || check_prec(prec)) return -1;
+  if (actor->plain) return fail(-1, "plain MLP trunks sample through dppo_plain_sample_chain (dppo_plain_sample_workspace_bytes)");
   if (B < 1) return fail(-1, "B out of range");
   return prec == DPPO_PREC_F32 ? (int64_t)sample_ws<F32>(*actor, B) : (int64_t)sample_ws<BF16>(*actor, B);
 }
@@ -1070,6 +1204,7 @@ int dppo_sample_chain(const dppo_net_desc* actor, int prec, const float* params_
                       dppo_stream_t stream) {
   if (int e = check_net(actor)) return e;
   if (int e = check_prec(prec)) return e;
+  if (actor->plain) return fail(-1, "plain MLP trunks sample through dppo_plain_sample_chain (host-looped steps)");
   if (actor->kind != 0) return fail(-1, "dppo_sample_chain needs an actor descriptor");
   if (!params_base || !packed_base || !params_ft || !packed_ft || !cfg || !sched || !obs || !traj)  // noise may be NULL
     return fail(-1, "null pointer");

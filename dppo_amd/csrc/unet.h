@@ -30,6 +30,10 @@ void unet_trainer_backward(UnetTrainer<P>* t, const void* d_eps, int ldde, float
 template <class P>
 void unet_trainer_free(UnetTrainer<P>* t);
 int unet_check_desc(const dppo_unet_desc* d);
+void launch_chain_init(const float* noise, uint32_t k0, uint32_t k1, int64_t n, int AF, float* x, float* chains, int chain_len,
+                       int init_slot, hipStream_t s);
+void launch_chain_step(const dppo_diffusion_cfg& cfg, const dppo_step& st, float* x, const float* eps, int lde, const float* noise,
+                       size_t nz0, int64_t n, int AF, int chain_len, int last, float* chains, float* traj, hipStream_t s);
 // brow[n], krow[n] of sample n (rollout mode: ind / Kft, ind % Kft; gathered mode: n, kinds[n])
 void launch_unet_index(const int64_t* inds, const int64_t* kinds, int Kft, int64_t N, int32_t* brow, int32_t* krow,
                        hipStream_t s);

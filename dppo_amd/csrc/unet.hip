@@ -501,13 +501,14 @@ struct StepArgs {
   int64_t n;         // B * AF
   int AF, chain_len, last;
   float *chains, *traj;
+  int lde;  // row stride of eps (0 = AF: dense)
 };
 __global__ void unet_step_kernel(const StepArgs a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
   const dppo_step& st = a.st;
   const float x = a.x[i];
-  float eps = a.eps[i], x0, mu;
+  float eps = a.lde ? a.eps[(i / a.AF) * a.lde + i % a.AF] : a.eps[i], x0, mu;
   if (!a.cfg.use_ddim) {
     x0 = st.c0 * x - st.c1 * eps;
     if (a.cfg.has_denoised_clip) x0 = fminf(fmaxf(x0, -a.cfg.denoised_clip), a.cfg.denoised_clip);
@@ -1667,6 +1668,20 @@ void unet_trainer_free(UnetTrainer<P>* t) {
   delete t;
 }
 int unet_check_desc(const dppo_unet_desc* d) { return check_desc(d); }
+// the sampler's two elementwise kernels, for any denoiser whose K-step loop runs on the host (plain MLP trunks: api.hip)
+void launch_chain_init(const float* noise, uint32_t k0, uint32_t k1, int64_t n, int AF, float* x, float* chains, int chain_len,
+                       int init_slot, hipStream_t s) {
+  hipLaunchKernelGGL(unet_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, noise, k0, k1, n, AF, x, chains,
+                     chain_len, init_slot);
+}
+void launch_chain_step(const dppo_diffusion_cfg& cfg, const dppo_step& st, float* x, const float* eps, int lde, const float* noise,
+                       size_t nz0, int64_t n, int AF, int chain_len, int last, float* chains, float* traj, hipStream_t s) {
+  StepArgs a;
+  memset(&a, 0, sizeof(a));
+  a.cfg = cfg, a.st = st, a.x = x, a.eps = eps, a.lde = lde, a.noise = noise, a.nz0 = nz0, a.n = n, a.AF = AF;
+  a.chain_len = chain_len, a.last = last, a.chains = chains, a.traj = traj;
+  hipLaunchKernelGGL(unet_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+}
 __global__ void unet_index_kernel(const int64_t* inds, const int64_t* kinds, int Kft, int64_t N, int32_t* brow, int32_t* krow) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;

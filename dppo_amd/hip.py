@@ -28,7 +28,7 @@ PREC_BY_NAME = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": 
 class NetDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("kind", "in_dim", "hidden", "n_blocks", "out_dim", "act", "time_dim", "act_flat", "cond_dim",
-                 "cond_hidden", "cond_out", "use_layernorm")]
+                 "cond_hidden", "cond_out", "use_layernorm", "plain")]
 
 
 class DiffusionCfg(C.Structure):
@@ -100,6 +100,9 @@ SYMBOLS = {
     "dppo_sample_chain_workspace_bytes": (_L, [_ND, _I, _L]),
     "dppo_sample_chain": (_I, [_ND, _I, _P, _P, _P, _P, C.POINTER(DiffusionCfg), _P, _I, _P, _P, _L, _P, _P, _I, _I,
                                _P, _L, _P]),
+    "dppo_plain_sample_workspace_bytes": (_L, [_ND, _I, _L]),
+    "dppo_plain_sample_chain": (_I, [_ND, _I, _P, _P, _P, _P, C.POINTER(DiffusionCfg), _P, _I, _P, _P, _L, _P, _P, _I, _I, _P,
+                                     _L, _P]),
     "dppo_chain_logprob_workspace_bytes": (_L, [_ND, _I, _L, _I]),
     "dppo_chain_logprob": (_I, [_ND, _I, _P, _P, C.POINTER(DiffusionCfg), _P, _I, _P, _P, _L, _P, _P, _L, _P]),
     "dppo_bc_loss_workspace_bytes": (_L, [_ND, _I, _L, _I]),

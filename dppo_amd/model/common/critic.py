@@ -7,7 +7,7 @@ from typing import Union
 import torch
 
 from dppo_amd import hip
-from dppo_amd.model.common.mlp import HipNet, ResidualMLP
+from dppo_amd.model.common.mlp import MLP, HipNet, ResidualMLP
 from dppo_amd.model.common.vit import VisionMixin
 
 
@@ -17,10 +17,8 @@ class CriticObs(HipNet):
     def __init__(self, cond_dim, mlp_dims, activation_type="Mish", use_layernorm=False, residual_style=False,
                  precision="bf16", **kwargs):
         super().__init__()
-        if not residual_style:
-            raise NotImplementedError("dppo_amd: CriticObs needs residual_style=True (plain MLP not built yet)")
-        self.Q1 = ResidualMLP([cond_dim] + list(mlp_dims) + [1], activation_type=activation_type,
-                              out_activation_type="Identity", use_layernorm=use_layernorm)
+        self.Q1 = (ResidualMLP if residual_style else MLP)([cond_dim] + list(mlp_dims) + [1], activation_type=activation_type,
+                                                           out_activation_type="Identity", use_layernorm=use_layernorm)
         self.cond_dim = cond_dim
         self.prec = hip.PREC_BY_NAME[precision]
         object.__setattr__(self, "_ws", hip.Workspace())
@@ -31,7 +29,7 @@ class CriticObs(HipNet):
             q = self.Q1
             d = hip.NetDesc(kind=1, in_dim=self.cond_dim, hidden=q.hidden, n_blocks=q.n_blocks, out_dim=1, act=q.act,
                             time_dim=0, act_flat=0, cond_dim=self.cond_dim, cond_hidden=0, cond_out=0,
-                            use_layernorm=q.use_layernorm)
+                            use_layernorm=q.use_layernorm, plain=q.plain)
             object.__setattr__(self, "_desc_cache", d)
         return d
 

@@ -58,6 +58,35 @@ class ResidualMLP(nn.Module):
         self.in_dim, self.out_dim = dim_list[0], dim_list[-1]
         self.act = SUPPORTED_ACT[activation_type]
         self.use_layernorm = int(bool(use_layernorm))
+        self.plain = 0
+
+
+class MLP(nn.Module):
+    """Plain trunk: Linear(in,H) -> act -> n x [Linear(H,H) -> act] -> Linear(H,out); ``moduleList.{i}.linear_1`` names as in
+    reference mlp.py:27-81.  Built for one hidden width (a multiple of 64), at least two hidden layers, no LayerNorm / dropout /
+    appended inputs; runs on the library's layered GEMM path (``NetDesc.plain = 1``)."""
+
+    def __init__(self, dim_list: List[int], activation_type: str = "Tanh", out_activation_type: str = "Identity",
+                 use_layernorm: bool = False, use_layernorm_final: bool = False, dropout: float = 0, append_dim: int = 0,
+                 append_layers=None, use_drop_final: bool = False, verbose: bool = False):
+        super().__init__()
+        if use_layernorm or use_layernorm_final or dropout or append_dim:
+            raise NotImplementedError("dppo_amd: plain MLP with LayerNorm / dropout / appended inputs is not built")
+        if out_activation_type != "Identity":
+            raise NotImplementedError("dppo_amd: only out_activation_type='Identity' is built")
+        if activation_type not in SUPPORTED_ACT:
+            raise NotImplementedError(f"dppo_amd: activation {activation_type!r} not built (ReLU, Mish are)")
+        hidden = dim_list[1]
+        if len(dim_list) < 4 or any(d != hidden for d in dim_list[1:-1]) or hidden % 64:
+            raise NotImplementedError("dppo_amd: plain MLP needs >= 2 hidden layers of one width (a multiple of 64)")
+        self.moduleList = nn.ModuleList()
+        for i in range(len(dim_list) - 1):
+            layer = nn.Module()
+            layer.linear_1 = nn.Linear(dim_list[i], dim_list[i + 1])
+            self.moduleList.append(layer)
+        self.hidden, self.n_blocks = hidden, len(dim_list) - 3  # hidden-to-hidden layers
+        self.in_dim, self.out_dim = dim_list[0], dim_list[-1]
+        self.act, self.use_layernorm, self.plain = SUPPORTED_ACT[activation_type], 0, 1
 
 
 class HipNet(nn.Module):

@@ -53,7 +53,7 @@ class Gaussian_MLP(HipNet):
             m = self.mlp_mean
             d = hip.NetDesc(kind=1, in_dim=self.cond_dim, hidden=m.hidden, n_blocks=m.n_blocks, out_dim=m.out_dim, act=m.act,
                             time_dim=0, act_flat=0, cond_dim=self.cond_dim, cond_hidden=0, cond_out=0,
-                            use_layernorm=m.use_layernorm)
+                            use_layernorm=m.use_layernorm, plain=m.plain)
             object.__setattr__(self, "_desc_cache", d)
         return d
 

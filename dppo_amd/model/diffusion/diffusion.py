@@ -224,7 +224,15 @@ class DiffusionModel(nn.Module):
                 nz = noise[:b + 1]
             chp = chains.data_ptr() if return_chain else None
             cl, isl = (chain_len if return_chain else 0), (init_slot if return_chain and a == 0 else -1)
-            if is_unet:  # conv denoiser: host loop over the steps, dppo_unet_sample_chain
+            if getattr(base, "is_plain", False):  # plain MLP trunk: host loop over the steps on the layered GEMM path
+                wsb = lib.dppo_plain_sample_workspace_bytes(C.byref(d), self.prec, B)
+                ws = self.__dict__.setdefault("_ws_sample", hip.Workspace()).get(wsb, dev)
+                hip.check(lib.dppo_plain_sample_chain(
+                    C.byref(d), self.prec, base.flat_params().data_ptr(), base.packed(self.prec, K).data_ptr(),
+                    ft.flat_params().data_ptr(), ft.packed(self.prec, K).data_ptr(), C.byref(cfg), tab[a:b].ctypes.data, b - a,
+                    ob.data_ptr(), nz.data_ptr() if nz is not None else None, B, traj.data_ptr(), chp, cl, isl,
+                    ws.data_ptr(), ws.numel(), hip.stream()), "dppo_plain_sample_chain")
+            elif is_unet:  # conv denoiser: host loop over the steps, dppo_unet_sample_chain
                 ws = base.workspace(B, dev, n_steps=b - a)
                 hip.check(lib.dppo_unet_sample_chain(
                     C.byref(d), self.prec, base.flat_params().data_ptr(), base.packed(self.prec, K).data_ptr(),

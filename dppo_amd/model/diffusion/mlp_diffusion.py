@@ -7,7 +7,7 @@ import torch
 from torch import nn
 
 from dppo_amd import hip
-from dppo_amd.model.common.mlp import HipNet, ResidualMLP
+from dppo_amd.model.common.mlp import MLP, HipNet, ResidualMLP
 from dppo_amd.model.common.vit import VisionMixin
 
 
@@ -39,8 +39,8 @@ class DiffusionMLP(HipNet):
         super().__init__()
         if cond_mlp_dims is not None and len(cond_mlp_dims) != 2:
             raise NotImplementedError("dppo_amd: cond_mlp is built for two layers (every shipped cfg: [hidden, out])")
-        if not residual_style:
-            raise NotImplementedError("dppo_amd: DiffusionMLP needs residual_style=True (plain MLP not built yet)")
+        if not residual_style and (cond_mlp_dims is not None or use_layernorm):
+            raise NotImplementedError("dppo_amd: a plain (residual_style=False) DiffusionMLP is built without cond_mlp / LayerNorm")
         self.time_embedding = nn.Sequential(_NoParams(), nn.Linear(time_dim, time_dim * 2), _NoParams(),
                                             nn.Linear(time_dim * 2, time_dim))
         out_dim = action_dim * horizon_steps
@@ -50,8 +50,10 @@ class DiffusionMLP(HipNet):
                 raise NotImplementedError(f"dppo_amd: activation {activation_type!r} not built (ReLU, Mish are)")
             self.cond_mlp = _PlainMLP([cond_dim] + list(cond_mlp_dims))
         in_dim = time_dim + out_dim + (cond_mlp_dims[-1] if cond_mlp_dims is not None else cond_dim)
-        self.mlp_mean = ResidualMLP([in_dim] + list(mlp_dims) + [out_dim], activation_type=activation_type,
-                                    out_activation_type=out_activation_type, use_layernorm=use_layernorm)
+        self.mlp_mean = (ResidualMLP if residual_style else MLP)(
+            [in_dim] + list(mlp_dims) + [out_dim], activation_type=activation_type, out_activation_type=out_activation_type,
+            use_layernorm=use_layernorm)
+        self.is_plain = not residual_style
         self.time_dim, self.action_dim, self.horizon_steps, self.cond_dim = time_dim, action_dim, horizon_steps, cond_dim
         self.prec = hip.PREC_BY_NAME[precision]
         self.n_time = 1000  # rows of the time-embedding table built for stand-alone forward() calls
@@ -65,7 +67,7 @@ class DiffusionMLP(HipNet):
         ch, co = self.cond_mlp_dims if self.cond_mlp_dims is not None else (0, 0)
         d = hip.NetDesc(kind=0, in_dim=m.in_dim, hidden=m.hidden, n_blocks=m.n_blocks, out_dim=m.out_dim, act=m.act,
                         time_dim=self.time_dim, act_flat=m.out_dim, cond_dim=self.cond_dim, cond_hidden=ch,
-                        cond_out=co, use_layernorm=m.use_layernorm)
+                        cond_out=co, use_layernorm=m.use_layernorm, plain=m.plain)
         object.__setattr__(self, "_desc_cache", d)
         return d
 

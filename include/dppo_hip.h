@@ -66,6 +66,11 @@ typedef struct dppo_net_desc {
    * (model/common/mlp.py:139-154); parameters norm1.{weight,bias}, norm2.{weight,bias} follow l2 in each block.
    * Needs a fused-kernel shape: hidden in {256, 512, 1024}. */
   int32_t use_layernorm;
+  /* 1: plain (non-residual) MLP trunk, model/common/mlp.py:27-81 (residual_style: False): Linear(in, H) -> act ->
+   * n_blocks x [Linear(H, H) -> act] -> Linear(H, out), parameters moduleList.{i}.linear_1.{weight,bias}.  One hidden width
+   * (a multiple of 64), n_blocks >= 1, no LayerNorm, no cond_mlp; runs on the layered gemm_nt path (no fused kernels, and
+   * sampling through dppo_plain_sample_chain).  No shipped DPPO / PPO cfg uses it. */
+  int32_t plain;
 } dppo_net_desc;
 
 /* One denoising step, host-prepared in fp32 exactly as the reference computes its tables
@@ -164,6 +169,15 @@ int dppo_sample_chain(const dppo_net_desc* actor, int prec, const float* params_
                       const dppo_step* sched, int n_steps, const float* obs, const float* noise, int64_t B,
                       float* traj, float* chains, int chain_len, int init_slot, void* workspace,
                       int64_t workspace_bytes, dppo_stream_t stream);
+
+/* dppo_sample_chain for a plain (non-residual, net.plain = 1) denoiser: same arguments except that the step table is in HOST
+ * memory (the loop over steps runs on the host: one layered forward + one posterior / noise kernel per step). */
+int64_t dppo_plain_sample_workspace_bytes(const dppo_net_desc* actor, int prec, int64_t B);
+int dppo_plain_sample_chain(const dppo_net_desc* actor, int prec, const float* params_base, const void* packed_base,
+                            const float* params_ft, const void* packed_ft, const dppo_diffusion_cfg* cfg,
+                            const dppo_step* sched_host, int n_steps, const float* obs, const float* noise, int64_t B,
+                            float* traj, float* chains, int chain_len, int init_slot, void* workspace,
+                            int64_t workspace_bytes, dppo_stream_t stream);
 
 /* ---- A8: VPGDiffusion.get_logprobs (diffusion_vpg.py:319-396) ----------------------------- */
 /* obs (B,cond), chains (B,Kft+1,Ta*Da) -> logprobs (B,Kft,Ta*Da).  ksteps: Kft device entries,

@@ -14,7 +14,8 @@ Parity status: PINNED.  The reference ships no tests or golden vectors
 reference itself, imported in the build container by
 ``tests/golden/make_golden.py`` and committed as ``tests/golden/*.npz``;
 ``tests/test_oracle_golden.py`` (g1-g10), ``tests/test_eval.py`` (g11), ``tests/test_gaussian.py`` (g12),
-``tests/test_unet.py`` (g13-g15) and ``tests/test_vision.py`` (g16-g18: ViT encoder, SpatialEmb, pixel networks) check
+``tests/test_unet.py`` (g13-g15), ``tests/test_vision.py`` (g16-g18: ViT encoder, SpatialEmb, pixel networks) and
+``tests/test_plain_mlp.py`` (g19) check
 every fixture.
 
 Parameters are plain ``dict[str, torch.Tensor]`` keyed by the reference's
@@ -211,6 +212,10 @@ def named_specs(name: str) -> Tuple[NetSpec, NetSpec]:
         return (NetSpec("gaussian", cond_dim=58, mlp_dims=[512] * 5, activation="ReLU", residual=True, action_dim=10,
                         horizon_steps=8),
                 NetSpec("critic", cond_dim=58, mlp_dims=[512, 512, 512], activation="Mish", residual=True))
+    if name == "plain_256":  # non-residual trunks at a GEMM-friendly width (ReLU actor of three hidden layers, Mish critic of two)
+        return (NetSpec("actor", cond_dim=11, mlp_dims=[256, 256, 256], activation="ReLU", residual=False,
+                        action_dim=3, horizon_steps=4, time_dim=16),
+                NetSpec("critic", cond_dim=11, mlp_dims=[256, 256], activation="Mish", residual=False))
     if name == "plain_mlp":
         return (NetSpec("actor", cond_dim=11, mlp_dims=[64, 64], activation="Mish", residual=False,
                           action_dim=3, horizon_steps=4, time_dim=16),

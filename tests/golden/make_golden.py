@@ -860,6 +860,70 @@ def g18_vision_gaussian():
     save("g18_vision_gaussian", **out)
 
 
+# ---------------------------------------------------------------- G19 plain (non-residual) MLP trunks
+from make_golden_cases import PLAIN_CASES  # noqa: E402
+
+
+def g19_plain_mlp():
+    """DiffusionMLP / CriticObs with residual_style=False (model/common/mlp.py:27-81): forward, a K-step chain + log-probs,
+    PPODiffusion.loss with every gradient, and the supervised loss with every gradient."""
+    out = {}
+    rs = np.random.RandomState(1900)
+    N = 48
+    for cname, (sname, kw) in PLAIN_CASES.items():
+        a, c = specs(sname)
+        kw2 = dict(kw, eta=EtaFixed(base_eta=1.0)) if kw.get("use_ddim") else kw
+        m = ref_model(a, c, 31, gamma_denoising=0.99, randn_clip_value=3, **kw2)
+        Kft = kw["ft_denoising_steps"]
+        n_steps = kw["ddim_steps"] if kw.get("use_ddim") else kw["denoising_steps"]
+        state = torch.from_numpy(rs.uniform(-1, 1, size=(N, 1, a.cond_dim)).astype(np.float32))
+        noise = torch.from_numpy(rs.randn(n_steps + 1, N, a.horizon_steps, a.action_dim).astype(np.float32))
+        with recorded_noise(list(noise)):
+            smp = m(cond={"state": state}, deterministic=False, return_chain=True)
+        chains = smp.chains
+        x = torch.from_numpy(rs.randn(N, a.horizon_steps, a.action_dim).astype(np.float32))
+        t = torch.from_numpy(rs.randint(0, 20, size=(N,)).astype(np.int64))
+        with torch.no_grad():
+            eps = m.actor_ft(x, t, cond={"state": state})
+            val = m.critic({"state": state})
+            lp_all = m.get_logprobs({"state": state}, chains)
+        kinds = torch.from_numpy(rs.randint(0, Kft, size=(N,)).astype(np.int64))
+        rows = torch.arange(N)
+        prev, nxt = chains[rows, kinds], chains[rows, kinds + 1]
+        oldlp = lp_all.reshape(N, Kft, a.horizon_steps, a.action_dim)[rows, kinds] + torch.from_numpy(
+            rs.normal(0, 0.02, size=(N, a.horizon_steps, a.action_dim)).astype(np.float32))
+        oldv = val.view(-1) + torch.from_numpy(rs.normal(0, 0.3, N).astype(np.float32))
+        ret = torch.from_numpy(rs.normal(0, 1, N).astype(np.float32))
+        adv = torch.from_numpy(rs.normal(0.3, 2.0, N).astype(np.float32))
+        res = m.loss({"state": state}, prev, nxt, kinds, ret, oldv, adv.clone(), oldlp, use_bc_loss=False, reward_horizon=4)
+        (res[0] + 0.5 * res[2]).backward()
+        out.update({f"{cname}_state": state, f"{cname}_noise": noise, f"{cname}_traj": smp.trajectories, f"{cname}_chains": chains,
+                    f"{cname}_logprobs": lp_all, f"{cname}_x": x, f"{cname}_t": t, f"{cname}_eps": eps, f"{cname}_value": val,
+                    f"{cname}_prev": prev, f"{cname}_next": nxt, f"{cname}_kinds": kinds, f"{cname}_returns": ret,
+                    f"{cname}_oldvalues": oldv, f"{cname}_adv": adv, f"{cname}_oldlogprobs": oldlp,
+                    f"{cname}_stats": np.array([res[0].item(), float(res[1]), res[2].item(), res[3], res[4], res[5],
+                                                float(res[6]), res[7]], dtype=np.float64)})
+        for k, p in m.actor_ft.named_parameters():
+            put_grad(out, f"{cname}_gactor_{k}", p.grad)
+        for k, p in m.critic.named_parameters():
+            put_grad(out, f"{cname}_gcritic_{k}", p.grad)
+        # supervised loss on the base network
+        K = kw["denoising_steps"]
+        net = m.network
+        for p in net.parameters():
+            p.requires_grad_(True)
+        x0 = torch.from_numpy(rs.uniform(-1, 1, size=(N, a.horizon_steps, a.action_dim)).astype(np.float32))
+        tm = torch.from_numpy(rs.randint(0, K, size=(N,)).astype(np.int64))
+        nz = torch.from_numpy(rs.randn(N, a.horizon_steps, a.action_dim).astype(np.float32))
+        with recorded_noise([nz]):
+            loss = m.p_losses(x0, {"state": state}, tm)
+        loss.backward()
+        out.update({f"{cname}_mse_x0": x0, f"{cname}_mse_t": tm, f"{cname}_mse_noise": nz, f"{cname}_mse_loss": np.float64(loss.item())})
+        for k, p in net.named_parameters():
+            put_grad(out, f"{cname}_mse_g_{k}", p.grad)
+    save("g19_plain_mlp", **out)
+
+
 # ---------------------------------------------------------------- G10 LR schedule trace
 from make_golden_cases import SCHED_CASES  # noqa: E402
 
@@ -885,6 +949,6 @@ def g10_scheduler():
 if __name__ == "__main__":
     only = sys.argv[1:]  # e.g. `make_golden.py g8_bc` regenerates one file (each generator owns its RNG stream)
     for fn in (g1_tables, g2_forward, g3_g4_chains, g5_loss, g6_reward_scaler, g7_adamw, g8_bc, g9_denoise_mse, g10_scheduler, g11_eval, g12_gaussian, g13_unet, g14_unet_loss, g15_unet_dim40, g16_vision,
-               g17_vision_loss, g18_vision_gaussian):
+               g17_vision_loss, g18_vision_gaussian, g19_plain_mlp):
         if not only or fn.__name__ in only:
             fn()

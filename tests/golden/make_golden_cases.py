@@ -122,3 +122,10 @@ VIS_GAUSS_CASES = {
                          dict(fixed_std=0.08, learn_fixed_std=False, std_min=0.01, std_max=1.0, clip_ploss_coef=0.02,
                               clip_vloss_coef=0.2, randn_clip_value=3)),
 }
+
+# plain (non-residual) MLP trunks, model/common/mlp.py:27-81: name -> (spec, model kwargs)
+PLAIN_CASES = {
+    "plain_ddpm": ("plain_256", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01, clip_ploss_coef_base=0.001)),
+    "plain_small_ddim": ("plain_mlp", dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5, clip_ploss_coef=0.01,
+                                           clip_vloss_coef=0.2)),
+}

@@ -90,11 +90,27 @@ def test_unsupported_variants_fail_loudly():
     from dppo_amd.model.diffusion.mlp_diffusion import DiffusionMLP
     with pytest.raises(NotImplementedError):  # LayerNorm blocks exist only on the fused kernels' widths
         DiffusionMLP(3, 4, 11, mlp_dims=[384, 384, 384], residual_style=True, use_layernorm=True)
+    with pytest.raises(NotImplementedError):  # plain trunks: one hidden width, no LayerNorm / cond_mlp
+        DiffusionMLP(3, 4, 11, mlp_dims=[512, 512, 512], residual_style=False, use_layernorm=True)
     with pytest.raises(NotImplementedError):
-        DiffusionMLP(3, 4, 11, mlp_dims=[512, 512, 512], residual_style=False)
+        DiffusionMLP(3, 4, 11, mlp_dims=[512, 256], residual_style=False)
     d = hopper_desc()
     d.use_layernorm, d.hidden = 1, 384
     assert hip.load().dppo_net_param_count(C.byref(d)) < 0
+
+
+def test_plain_mlp_layout_matches_reference_names():
+    """residual_style=False: moduleList.{i}.linear_1 names (reference mlp.py:46-74) and the C ABI's flat size."""
+    from dppo_amd.model.common.critic import CriticObs
+    from dppo_amd.model.diffusion.mlp_diffusion import DiffusionMLP
+    a = DiffusionMLP(3, 4, 11, mlp_dims=[64, 64], residual_style=False)
+    names = [n for n in dict(a.named_parameters()) if n.startswith("mlp_mean.")]
+    assert names == [f"mlp_mean.moduleList.{i}.linear_1.{w}" for i in range(3) for w in ("weight", "bias")]
+    d = a.net_desc()
+    assert d.plain == 1 and d.n_blocks == 1 and d.hidden == 64
+    assert a.flat_params().numel() == hip.load().dppo_net_param_count(C.byref(d))
+    c = CriticObs(cond_dim=11, mlp_dims=[64, 64], residual_style=False)
+    assert c.flat_params().numel() == hip.load().dppo_net_param_count(C.byref(c.net_desc())) == 11 * 64 + 64 + 64 * 64 + 64 + 64 + 1
 
 
 def test_layernorm_layout_matches_reference_names():
