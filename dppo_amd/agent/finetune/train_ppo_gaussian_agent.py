@@ -38,6 +38,8 @@ class TrainPPOGaussianAgent(TrainPPODiffusionAgent):
         self.logvar_optimizer = None
         if getattr(net, "learn_fixed_std", False):
             self.logvar_optimizer = FlatAdamW(net.logvar.data, lr=cfg.train.actor_lr, weight_decay=cfg.train.actor_weight_decay)
+        if getattr(self.model, "entropy_in_kernel", False):  # PPO_GMM: the entropy term's gradient rides the fused backward
+            self.model.ent_coef = float(self.ent_coef)
 
     def _policy(self):
         return _OneShotPolicy(self.model)
@@ -82,7 +84,8 @@ class TrainPPOGaussianAgent(TrainPPODiffusionAgent):
                     g = model._lv_grad.clone()
                     if self.world > 1:
                         dist.all_reduce(g)  # per-rank pg parts are already divided by the GLOBAL count: SUM gives the whole
-                    g -= self.ent_coef * 0.5 / Da * ((lv >= net.logvar_min) & (lv <= net.logvar_max)).float()
+                    if not getattr(model, "entropy_in_kernel", False):
+                        g -= self.ent_coef * 0.5 / Da * ((lv >= net.logvar_min) & (lv <= net.logvar_max)).float()
                     self.logvar_optimizer.param_groups[0]["lr"] = self.actor_optimizer.param_groups[0]["lr"]
                     self.logvar_optimizer.step(g.contiguous())
                 stats = st.tolist()

@@ -9,6 +9,7 @@
 #include "gemm.h"
 #include "ppo.h"
 #include "gaussian.h"
+#include "gmm.h"
 #include "unet.h"
 #include "sampler.h"
 
@@ -120,7 +121,7 @@ static PackLayout pack_layout(const dppo_net_desc& d, int n_time) {
   L.Wout = o, o = al256(o + (size_t)d.out_dim * H * ES);
   L.WoutT = o, o = al256(o + (size_t)H * L.Kpo * ES);
   if (d.kind == 0) L.W0tT = o, o = al256(o + (size_t)d.time_dim * H * ES);
-  if (!d.plain) {  // per-wave fragment streams: forward (sampler + fused forward), out layer, backward (fused backward)
+  if (!d.plain && d.out_dim <= 128) {  // per-wave fragment streams: forward (sampler + fused forward), out layer, backward
     const SamplerGeom g = sampler_geom<P>(d);
     const FusedGeom fg = fused_geom<P>(d);
     L.sstream = o, o = al256(o + (size_t)SAMPLER_WAVES * g.hidden_frags_per_wave * 64 * 16);
@@ -155,7 +156,10 @@ static int check_net(const dppo_net_desc* d) {
   } else if (d->hidden < 128 || d->hidden % 128) return fail(-1, "hidden=%d must be a positive multiple of 128", d->hidden);
   if (d->n_blocks < 0 || d->n_blocks > MAX_BLOCKS) return fail(-1, "n_blocks=%d out of [0,%d]", d->n_blocks, MAX_BLOCKS);
   if (d->act != DPPO_ACT_RELU && d->act != DPPO_ACT_MISH) return fail(-1, "activation %d unsupported", d->act);
-  if (d->out_dim < 1 || d->out_dim > 128) return fail(-1, "out_dim=%d out of [1,128]", d->out_dim);
+  // (out_dim > 128 -- the mixture-of-Gaussians head, Ta*Da*num_modes outputs -- runs on the layered GEMM path only: no
+  // fragment streams are packed, and such a descriptor is refused by the K-step sampler)
+  if (d->out_dim < 1 || d->out_dim > 1024) return fail(-1, "out_dim=%d out of [1,1024]", d->out_dim);
+  if (d->out_dim > 128 && d->kind == 0) return fail(-1, "a denoiser's out_dim = Ta*Da must be <= 128");
   if (d->kind == 0) {
     if (d->time_dim < 4 || d->time_dim % 2) return fail(-1, "time_dim=%d must be even and >= 4", d->time_dim);
     if (d->act_flat != d->out_dim) return fail(-1, "actor out_dim must equal act_flat");
@@ -244,6 +248,7 @@ static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char*
     launch_transpose_cast<P>(prm + pl.c2w, d.cond_out, d.cond_hidden, d.cond_hidden, 0, pk + L.Wc2T, L.Ep, s);
     launch_transpose_cast<P>(prm + pl.W0, H, d.cond_out, d.in_dim, d.act_flat + d.time_dim, pk + L.W0eT, H, s);
   }
+  if (d.out_dim > 128) return check_launch();  // layered path only (fused_ok() is false: the row-major operands above are it)
   {
     const SamplerGeom g = sampler_geom<P>(d);
     const FusedGeom fg = fused_geom<P>(d);
@@ -417,7 +422,7 @@ static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, b
       B.dh_all[b] = c.take((size_t)M * H * ES);
       B.dz1_all[b] = b == 0 ? B.dz1 : c.take((size_t)M * H * ES);
     }
-    const int mt = d.plain ? 0 : fused_rows_per_tile<P>(d);
+    const int mt = d.plain || d.out_dim > 128 ? 0 : fused_rows_per_tile<P>(d);
     B.tiles = mt > 0 ? (int)((M + mt - 1) / mt) : 0;
     B.tile_colsum = (float*)c.take((size_t)(2 * nb + 2 + (d.use_layernorm ? 4 * nb : 0)) * (B.tiles > 0 ? B.tiles : 1) * H * 4);
     const int tdp = round_up(d.time_dim > 0 ? d.time_dim : 1, 16);
@@ -1807,6 +1812,161 @@ int dppo_gaussian_ppo_loss_fwd_bwd_obs(const dppo_net_desc* actor, const dppo_ne
   return gauss_ppo_entry(actor, critic, prec, actor_params, actor_packed, critic_params, critic_packed, cfg, logvar, obs, actions,
                          returns, oldvalues, adv, oldlogp, N, global_moments, actor_grad, critic_grad, logvar_grad, stats,
                          workspace, workspace_bytes, stream, io);
+}
+
+// ---- mixture-of-Gaussians policy PPO (gmm.hip) ---------------------------------------------------------------------------
+static int check_gmm(const dppo_net_desc* mean, const dppo_net_desc* wts, const dppo_gmm_cfg* cfg, const float* logvar) {
+  if (int e = check_net(mean)) return e;
+  if (int e = check_net(wts)) return e;
+  if (!cfg) return fail(-1, "null cfg");
+  if (mean->kind != 1 || wts->kind != 1) return fail(-1, "GMM trunks are kind-1 descriptors on the observation");
+  if (cfg->num_modes < 1 || cfg->num_modes > GMM_MAX_MODES) return fail(-1, "num_modes out of [1, %d]", GMM_MAX_MODES);
+  if (cfg->horizon_steps < 1 || cfg->action_dim < 1) return fail(-1, "bad Ta / Da");
+  if (mean->out_dim != cfg->num_modes * cfg->horizon_steps * cfg->action_dim) return fail(-1, "mean trunk out_dim != num_modes * Ta * Da");
+  if (wts->out_dim != cfg->num_modes) return fail(-1, "weights trunk out_dim != num_modes");
+  if (mean->cond_dim != wts->cond_dim) return fail(-1, "the two trunks observe different cond_dim");
+  if (cfg->std_mode != 0 && cfg->std_mode != 1) return fail(-1, "std_mode must be 0 or 1");
+  if (cfg->std_mode == 1 && !logvar) return fail(-1, "std_mode 1 needs logvar");
+  return 0;
+}
+template <class P>
+static size_t carve_gmm(Carver& c, const dppo_net_desc& am, const dppo_net_desc& aw, const dppo_net_desc* cr, int64_t N, int K,
+                        bool train, MlpBufs<P>& Am, MlpBufs<P>& Aw, MlpBufs<P>& Cb, double*& moments, double*& scratch,
+                        double*& partial) {
+  moments = (double*)c.take(4 * sizeof(double));
+  scratch = (double*)c.take(2 * 64 * sizeof(double));
+  partial = (double*)c.take((size_t)gmm_blocks(N) * (8 + K) * sizeof(double));
+  carve_mlp<P>(c, am, N, train, train, Am);
+  carve_mlp<P>(c, aw, N, train, train, Aw);
+  if (cr) carve_mlp<P>(c, *cr, N, train, train, Cb);
+  return al256(c.off);
+}
+int64_t dppo_gmm_workspace_bytes(const dppo_net_desc* mean, const dppo_net_desc* weights, const dppo_net_desc* critic, int prec,
+                                 int64_t N) {
+  if (check_net(mean) || check_net(weights) || (critic && check_net(critic)) || check_prec(prec)) return -1;
+  if (N < 1 || N > 0x7fffffff) return fail(-1, "N out of range");
+  Carver c{nullptr, 0, 0};
+  double *m, *sc, *pa;
+  const int K = GMM_MAX_MODES * 64;
+  if (prec == DPPO_PREC_F32) {
+    MlpBufs<F32> Am, Aw, Cb;
+    return (int64_t)carve_gmm<F32>(c, *mean, *weights, critic, N, K, critic != nullptr, Am, Aw, Cb, m, sc, pa);
+  }
+  MlpBufs<BF16> Am, Aw, Cb;
+  return (int64_t)carve_gmm<BF16>(c, *mean, *weights, critic, N, K, critic != nullptr, Am, Aw, Cb, m, sc, pa);
+}
+template <class P>
+static int gmm_infer_impl(const dppo_net_desc& am, const dppo_net_desc& aw, const float* mp, const char* mk, const float* wp,
+                          const char* wk, const dppo_gmm_cfg& cfg, const float* logvar, const float* obs, const int64_t* modes,
+                          const float* noise, const float* actions, int64_t N, float* out_actions, float* out_logp, void* ws,
+                          int64_t wsb, hipStream_t s) {
+  Carver c{(char*)ws, 0, (size_t)wsb};
+  MlpBufs<P> Am, Aw, Cb;
+  double *moments, *scratch, *partial;
+  const size_t need = carve_gmm<P>(c, am, aw, nullptr, N, GMM_MAX_MODES * 64, false, Am, Aw, Cb, moments, scratch, partial);
+  if ((int64_t)need > wsb) return fail(-1, "workspace too small: need %zu bytes, got %lld", need, (long long)wsb);
+  const PackLayout LM = pack_layout<P>(am, 0), LW = pack_layout<P>(aw, 0);
+  launch_build_direct<P>(nullptr, nullptr, obs, nullptr, 0, 0, am.cond_dim, N, Am.in, LM.Kp0, s);
+  launch_build_direct<P>(nullptr, nullptr, obs, nullptr, 0, 0, aw.cond_dim, N, Aw.in, LW.Kp0, s);
+  mlp_forward<P>(am, mp, mk, LM, N, Am, false, s);
+  mlp_forward<P>(aw, wp, wk, LW, N, Aw, false, s);
+  GmmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.cfg = cfg, g.mean_pre = Am.out, g.ldm = Am.ldout, g.logits = Aw.out, g.ldl = Aw.ldout, g.logvar = logvar, g.N = N;
+  g.AF = cfg.horizon_steps * cfg.action_dim, g.modes_in = modes, g.noise = noise, g.actions = actions;
+  g.out_actions = out_actions, g.out_logp = out_logp;
+  if (out_actions) launch_gmm_sample(g, s);
+  else launch_gmm_logprob(g, s);
+  return check_launch();
+}
+int dppo_gmm_sample(const dppo_net_desc* mean, const dppo_net_desc* weights, int prec, const float* mean_params,
+                    const void* mean_packed, const float* weights_params, const void* weights_packed, const dppo_gmm_cfg* cfg,
+                    const float* logvar, const float* obs, const int64_t* modes, const float* noise, int64_t B, float* actions,
+                    void* workspace, int64_t workspace_bytes, dppo_stream_t stream) {
+  if (int e = check_gmm(mean, weights, cfg, logvar)) return e;
+  if (int e = check_prec(prec)) return e;
+  if (!mean_params || !mean_packed || !weights_params || !weights_packed || !obs || !actions || !workspace) return fail(-1, "null pointer");
+  if (B < 1 || B > 0x7fffffff) return fail(-1, "B out of range");
+#define CALL(P)                                                                                                                \
+  gmm_infer_impl<P>(*mean, *weights, mean_params, (const char*)mean_packed, weights_params, (const char*)weights_packed, *cfg, logvar, \
+                    obs, modes, noise, nullptr, B, actions, nullptr, workspace, workspace_bytes, (hipStream_t)stream)
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
+}
+int dppo_gmm_logprob(const dppo_net_desc* mean, const dppo_net_desc* weights, int prec, const float* mean_params,
+                     const void* mean_packed, const float* weights_params, const void* weights_packed, const dppo_gmm_cfg* cfg,
+                     const float* logvar, const float* obs, const float* actions, int64_t N, float* logp, void* workspace,
+                     int64_t workspace_bytes, dppo_stream_t stream) {
+  if (int e = check_gmm(mean, weights, cfg, logvar)) return e;
+  if (int e = check_prec(prec)) return e;
+  if (!mean_params || !mean_packed || !weights_params || !weights_packed || !obs || !actions || !logp || !workspace)
+    return fail(-1, "null pointer");
+  if (N < 1 || N > 0x7fffffff) return fail(-1, "N out of range");
+#define CALL(P)                                                                                                                \
+  gmm_infer_impl<P>(*mean, *weights, mean_params, (const char*)mean_packed, weights_params, (const char*)weights_packed, *cfg, logvar, \
+                    obs, nullptr, nullptr, actions, N, nullptr, logp, workspace, workspace_bytes, (hipStream_t)stream)
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
+}
+template <class P>
+static int gmm_ppo_impl(const dppo_net_desc& am, const dppo_net_desc& aw, const dppo_net_desc& cr, const float* mp, const char* mk,
+                        const float* wp, const char* wk, const float* cp, const char* ck, const dppo_gmm_cfg& cfg,
+                        const float* logvar, const float* obs, const float* actions, const float* returns, const float* oldvalues,
+                        const float* adv, const float* oldlogp, int64_t N, const double* gmom, float* mgrad, float* wgrad,
+                        float* cgrad, float* lvgrad, double* stats, void* ws, int64_t wsb, hipStream_t s) {
+  Carver c{(char*)ws, 0, (size_t)wsb};
+  MlpBufs<P> Am, Aw, Cb;
+  double *moments, *scratch, *partial;
+  const size_t need = carve_gmm<P>(c, am, aw, &cr, N, GMM_MAX_MODES * 64, true, Am, Aw, Cb, moments, scratch, partial);
+  if ((int64_t)need > wsb) return fail(-1, "workspace too small: need %zu bytes, got %lld", need, (long long)wsb);
+  const PackLayout LM = pack_layout<P>(am, 0), LW = pack_layout<P>(aw, 0), LC = pack_layout<P>(cr, 0);
+  hipStream_t s2 = fork_side(s);  // the critic pipeline beside the two actor trunks
+  launch_build_direct<P>(nullptr, nullptr, obs, nullptr, 0, 0, cr.cond_dim, N, Cb.in, LC.Kp0, s2);
+  mlp_forward<P>(cr, cp, ck, LC, N, Cb, true, s2);
+  launch_build_direct<P>(nullptr, nullptr, obs, nullptr, 0, 0, am.cond_dim, N, Am.in, LM.Kp0, s);
+  launch_build_direct<P>(nullptr, nullptr, obs, nullptr, 0, 0, aw.cond_dim, N, Aw.in, LW.Kp0, s);
+  if (gmom == nullptr) launch_gauss_moments(adv, N, moments, scratch, s);
+  mlp_forward<P>(am, mp, mk, LM, N, Am, true, s);
+  mlp_forward<P>(aw, wp, wk, LW, N, Aw, true, s);
+  if (s2 != s) join_side(s, s2);
+  GmmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.cfg = cfg, g.mean_pre = Am.out, g.ldm = Am.ldout, g.logits = Aw.out, g.ldl = Aw.ldout, g.logvar = logvar, g.actions = actions;
+  g.N = N, g.AF = cfg.horizon_steps * cfg.action_dim, g.vnew = Cb.out, g.ldv = Cb.ldout, g.returns = returns;
+  g.oldvalues = oldvalues, g.adv = adv, g.oldlogp = oldlogp, g.moments = gmom ? gmom : moments;
+  g.d_mean = Am.d_out, g.lddm = LM.Kpo, g.d_logits = Aw.d_out, g.lddl = LW.Kpo, g.d_v = Cb.d_out, g.lddv = LC.Kpo;
+  g.partial = partial, g.stats = stats, g.logvar_grad = lvgrad;
+  launch_gmm_loss<P>(g, s);
+  s2 = fork_side(s);
+  mlp_backward<P>(cr, cp, ck, LC, N, Cb, cgrad, nullptr, nullptr, 0, s2, false, -1);
+  mlp_backward<P>(am, mp, mk, LM, N, Am, mgrad, nullptr, nullptr, 0, s, false, 1);
+  mlp_backward<P>(aw, wp, wk, LW, N, Aw, wgrad, nullptr, nullptr, 0, s, false, 1);
+  if (s2 != s) join_side(s, s2);
+  return check_launch();
+}
+int dppo_gmm_ppo_loss_fwd_bwd(const dppo_net_desc* mean, const dppo_net_desc* weights, const dppo_net_desc* critic, int prec,
+                              const float* mean_params, const void* mean_packed, const float* weights_params,
+                              const void* weights_packed, const float* critic_params, const void* critic_packed,
+                              const dppo_gmm_cfg* cfg, const float* logvar, const float* obs, const float* actions,
+                              const float* returns, const float* oldvalues, const float* adv, const float* oldlogp, int64_t N,
+                              const double* global_moments, float* mean_grad, float* weights_grad, float* critic_grad,
+                              float* logvar_grad, double* stats, void* workspace, int64_t workspace_bytes, dppo_stream_t stream) {
+  if (int e = check_gmm(mean, weights, cfg, logvar)) return e;
+  if (int e = check_net(critic)) return e;
+  if (int e = check_prec(prec)) return e;
+  if (critic->kind != 1 || critic->out_dim != 1) return fail(-1, "critic descriptor must be kind 1 with out_dim 1");
+  if (mean->cond_dim != critic->cond_dim) return fail(-1, "actor and critic observe different cond_dim");
+  if (!mean_params || !mean_packed || !weights_params || !weights_packed || !critic_params || !critic_packed || !obs || !actions ||
+      !returns || !oldvalues || !adv || !oldlogp || !mean_grad || !weights_grad || !critic_grad || !stats || !workspace)
+    return fail(-1, "null pointer");
+  if (cfg->std_mode == 1 && !logvar_grad) return fail(-1, "std_mode 1 needs logvar_grad");
+  if (N < 2 || N > 0x7fffffff) return fail(-1, "N out of range");
+#define CALL(P)                                                                                                                  \
+  gmm_ppo_impl<P>(*mean, *weights, *critic, mean_params, (const char*)mean_packed, weights_params, (const char*)weights_packed,        \
+                  critic_params, (const char*)critic_packed, *cfg, logvar, obs, actions, returns, oldvalues, adv, oldlogp, N,          \
+                  global_moments, mean_grad, weights_grad, critic_grad, logvar_grad, stats, workspace, workspace_bytes, (hipStream_t)stream)
+  return DPPO_DISPATCH(prec, CALL);
+#undef CALL
 }
 
 // ---- conv denoiser: PPO update and supervised loss (unet.hip does the network, this file the loss and the critic) -------

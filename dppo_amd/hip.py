@@ -76,6 +76,14 @@ class VisDesc(C.Structure):  # struct dppo_vis_desc
                 ("spatial_emb", C.c_int32), ("num_img", C.c_int32)]
 
 
+class GmmCfg(C.Structure):  # struct dppo_gmm_cfg
+    _fields_ = [("horizon_steps", C.c_int32), ("action_dim", C.c_int32), ("num_modes", C.c_int32), ("std_mode", C.c_int32),
+                ("norm_adv", C.c_int32), ("has_vclip", C.c_int32), ("deterministic", C.c_int32), ("pad", C.c_int32),
+                ("fixed_std", C.c_float), ("logvar_min", C.c_float), ("logvar_max", C.c_float), ("ent_coef", C.c_float),
+                ("clip_ploss_coef", C.c_double), ("clip_vloss_coef", C.c_double), ("seed_lo", C.c_uint32),
+                ("seed_hi", C.c_uint32)]
+
+
 class ObsIO(C.Structure):  # struct dppo_obs_io
     _fields_ = [("obs_critic", C.c_void_p), ("d_obs_actor", C.c_void_p), ("d_obs_critic", C.c_void_p)]
 
@@ -121,6 +129,11 @@ SYMBOLS = {
                                             _P, _L, _P, _P, _P, _P, _P, _P, _L, _P]),
     "dppo_unet_param_count": (_L, [C.POINTER(UnetDesc)]),
     "dppo_unet_packed_bytes": (_L, [C.POINTER(UnetDesc), _I, _I]),
+    "dppo_gmm_workspace_bytes": (_L, [_ND, _ND, _ND, _I, _L]),
+    "dppo_gmm_sample": (_I, [_ND, _ND, _I, _P, _P, _P, _P, C.POINTER(GmmCfg), _P, _P, _P, _P, _L, _P, _P, _L, _P]),
+    "dppo_gmm_logprob": (_I, [_ND, _ND, _I, _P, _P, _P, _P, C.POINTER(GmmCfg), _P, _P, _P, _L, _P, _P, _L, _P]),
+    "dppo_gmm_ppo_loss_fwd_bwd": (_I, [_ND, _ND, _ND, _I, _P, _P, _P, _P, _P, _P, C.POINTER(GmmCfg), _P, _P, _P, _P, _P, _P, _P,
+                                       _L, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     # the *_obs entries: pre-gathered mode only (no `inds`), + dppo_obs_io* / d_obs
     "dppo_ppo_loss_fwd_bwd_obs": (_I, [_ND, _ND, _I, _P, _P, _P, _P, C.POINTER(DiffusionCfg), C.POINTER(PpoCfg), _P,
                                        _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P, C.POINTER(ObsIO)]),

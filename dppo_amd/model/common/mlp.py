@@ -236,7 +236,7 @@ class HipNet(nn.Module):
 def pack_pair(net0: "HipNet", n_time0: int, net1: "HipNet", n_time1: int, prec: int) -> None:
     """Re-pack two networks after an optimiser step: when both images are stale, both composites and both images go out
     in two launches (dppo_pack_nets) instead of four."""
-    if getattr(net0, "is_unet", False) or getattr(net1, "is_unet", False):  # the conv denoiser packs through its own entry
+    if any(getattr(n, a, False) for n in (net0, net1) for a in ("is_unet", "is_composite")):  # own pack entry / two images
         net0.packed(prec, n_time0)
         net1.packed(prec, n_time1)
         return

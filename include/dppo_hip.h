@@ -439,6 +439,46 @@ int dppo_gemm_nt_raw(int prec, const void* X, const void* W, const float* bias, 
 int dppo_gemm_tn_raw(int prec, const void* A, int lda, int N1, const void* B, int ldb, int N2, int64_t M,
                      int rows_per_split, float* slab, float* C, dppo_stream_t stream);
 
+/* ---- 8f row 4 (second half): mixture-of-Gaussians policy PPO ---------------------------------------------------------
+ * Replaces model/common/mlp_gmm.py:11-110 (GMM_MLP.forward: component means tanh(mlp_mean(s)) (B, modes, Ta*Da), fixed or
+ * learned per-(mode, action dim) std, mixture logits mlp_weights(s)), model/common/gmm.py:48-97 (GMMModel.forward_train /
+ * forward: MixtureSameFamily(Categorical(logits), Independent(Normal, 1))), model/rl/gmm_vpg.py:33-43 (get_logprobs) and
+ * model/rl/gmm_ppo.py:39-112 (PPO_GMM.loss).  The actor is TWO trunks on the observation (kind-1 descriptors: out_dim =
+ * num_modes*Ta*Da and num_modes), each with its own flat parameter buffer; out_dim above 128 runs on the layered GEMM path.
+ * log p(a) = logsumexp_m(log pi_m + sum_j log N(a_j; mu_mj, sigma_mj)) -- summed over Ta*Da, as the reference's Independent. */
+typedef struct dppo_gmm_cfg {
+  int32_t horizon_steps, action_dim, num_modes;
+  int32_t std_mode;      /* 0: fixed_std ; 1: sigma_md = exp(0.5 clamp(logvar[m*Da + d], logvar_min, logvar_max))       */
+  int32_t norm_adv, has_vclip;
+  int32_t deterministic; /* forward_train(deterministic=True): sigma = 1e-4 (the component is still drawn)               */
+  int32_t pad;
+  float fixed_std, logvar_min, logvar_max;
+  float ent_coef;        /* the returned actor-side gradients are those of pg_loss + ent_coef * entropy_loss             */
+  double clip_ploss_coef, clip_vloss_coef;
+  uint32_t seed_lo, seed_hi;
+} dppo_gmm_cfg;
+int64_t dppo_gmm_workspace_bytes(const dppo_net_desc* mean, const dppo_net_desc* weights, const dppo_net_desc* critic, int prec,
+                                 int64_t N);
+/* actions (B,Ta*Da) = mu_k + sigma_k z with k = modes[b] (or, if NULL, drawn from softmax(logits) in the kernel) and z = noise
+ * (B,Ta*Da) (or drawn in the kernel). */
+int dppo_gmm_sample(const dppo_net_desc* mean, const dppo_net_desc* weights, int prec, const float* mean_params,
+                    const void* mean_packed, const float* weights_params, const void* weights_packed, const dppo_gmm_cfg* cfg,
+                    const float* logvar, const float* obs, const int64_t* modes, const float* noise, int64_t B, float* actions,
+                    void* workspace, int64_t workspace_bytes, dppo_stream_t stream);
+int dppo_gmm_logprob(const dppo_net_desc* mean, const dppo_net_desc* weights, int prec, const float* mean_params,
+                     const void* mean_packed, const float* weights_params, const void* weights_packed, const dppo_gmm_cfg* cfg,
+                     const float* logvar, const float* obs, const float* actions, int64_t N, float* logp, void* workspace,
+                     int64_t workspace_bytes, dppo_stream_t stream);
+/* stats as dppo_gaussian_ppo_loss_fwd_bwd (entropy = mean_b sum_m pi_m H_m, std = mean_b sum_m pi_m mean_j sigma_mj).
+ * mean_grad / weights_grad / logvar_grad (num_modes*Da) <- d (pg_loss + ent_coef * entropy_loss), critic_grad <- d v_loss. */
+int dppo_gmm_ppo_loss_fwd_bwd(const dppo_net_desc* mean, const dppo_net_desc* weights, const dppo_net_desc* critic, int prec,
+                              const float* mean_params, const void* mean_packed, const float* weights_params,
+                              const void* weights_packed, const float* critic_params, const void* critic_packed,
+                              const dppo_gmm_cfg* cfg, const float* logvar, const float* obs, const float* actions,
+                              const float* returns, const float* oldvalues, const float* adv, const float* oldlogp, int64_t N,
+                              const double* global_moments, float* mean_grad, float* weights_grad, float* critic_grad,
+                              float* logvar_grad, double* stats, void* workspace, int64_t workspace_bytes, dppo_stream_t stream);
+
 /* ---- loss entries that also return d loss / d observation (a visual encoder sits in front of the trunk) ------------
  * Same arguments as the entry without the suffix, in pre-gathered mode (one observation row per sample, `kinds` given), plus:
  *   obs_critic   (N, critic cond_dim) or NULL: the critic's own observation rows -- ViTCritic encodes the images with its own

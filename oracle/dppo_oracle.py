@@ -15,7 +15,7 @@ reference itself, imported in the build container by
 ``tests/golden/make_golden.py`` and committed as ``tests/golden/*.npz``;
 ``tests/test_oracle_golden.py`` (g1-g10), ``tests/test_eval.py`` (g11), ``tests/test_gaussian.py`` (g12),
 ``tests/test_unet.py`` (g13-g15), ``tests/test_vision.py`` (g16-g18: ViT encoder, SpatialEmb, pixel networks) and
-``tests/test_plain_mlp.py`` (g19) check
+``tests/test_plain_mlp.py`` (g19), ``tests/test_gmm.py`` (g20) check
 every fixture.
 
 Parameters are plain ``dict[str, torch.Tensor]`` keyed by the reference's
@@ -843,6 +843,93 @@ def unet_forward(p: Params, spec: UnetSpec, x: torch.Tensor, t: torch.Tensor, st
     h = conv1d_block(p, "final_conv.0", h, spec)
     h = F.conv1d(h, p["final_conv.1.weight"], p["final_conv.1.bias"])
     return h.transpose(1, 2)
+
+
+# --------------------------------------------------------------------------
+# 8f row 4 (second half)  mixture-of-Gaussians policy PPO
+# --------------------------------------------------------------------------
+@dataclass
+class GmmCfg:
+    num_modes: int = 5
+    fixed_std: float = 0.1
+    learn_fixed_std: bool = False
+    std_min: float = 0.01
+    std_max: float = 1.0
+    clip_ploss_coef: float = 0.01
+    clip_vloss_coef: Optional[float] = None
+    norm_adv: bool = True
+
+
+def gmm_specs(cond_dim: int, mlp_dims, activation: str, residual: bool, action_dim: int, horizon_steps: int, num_modes: int):
+    """(mean trunk, weights trunk) of a GMM_MLP (mlp_gmm.py:29-79): the same trunk with Ta*Da*num_modes / num_modes outputs."""
+    mk = lambda out: NetSpec("gaussian", cond_dim=cond_dim, mlp_dims=list(mlp_dims), activation=activation, residual=residual,
+                             action_dim=out, horizon_steps=1)
+    return mk(action_dim * horizon_steps * num_modes), mk(num_modes)
+
+
+def gmm_init_params(mean_spec: NetSpec, w_spec: NetSpec, seed: int) -> Params:
+    """State dict of a GMM_MLP without the logvar entries: mlp_mean.* from ``seed``, mlp_weights.* from ``seed + 5``."""
+    p = dict(init_params(mean_spec, seed))
+    p.update({k.replace("mlp_mean.", "mlp_weights."): v for k, v in init_params(w_spec, seed + 5).items()})
+    return p
+
+
+def gmm_dist(gc: GmmCfg, mean_spec: NetSpec, w_spec: NetSpec, p: Params, logvar, state, Da: int, Ta: int):
+    """GMM_MLP.forward (mlp_gmm.py:81-110) -> (means (B,M,AF), scales (B,M,AF), logits (B,M))."""
+    B, M = state.shape[0], gc.num_modes
+    x = state.reshape(B, -1)
+    means = torch.tanh(trunk_forward(p, mean_spec, x)).view(B, M, Ta * Da)
+    pw = {k.replace("mlp_weights.", "mlp_mean."): v for k, v in p.items() if k.startswith("mlp_weights.")}
+    logits = trunk_forward(pw, w_spec, x).view(B, M)
+    if gc.learn_fixed_std:
+        lv = torch.clamp(logvar, math.log(gc.std_min ** 2), math.log(gc.std_max ** 2))
+        scales = torch.exp(0.5 * lv).view(1, M, Da).repeat(B, 1, Ta)
+    else:
+        scales = torch.ones_like(means) * gc.fixed_std
+    return means, scales, logits
+
+
+def gmm_logprob(gc: GmmCfg, mean_spec, w_spec, p: Params, logvar, state, actions, Da: int, Ta: int):
+    """VPG_GMM.get_logprobs (gmm_vpg.py:33-43) through GMMModel.forward_train (gmm.py:48-86): (log p (B,), entropy, std)."""
+    means, scales, logits = gmm_dist(gc, mean_spec, w_spec, p, logvar, state, Da, Ta)
+    B = means.shape[0]
+    comp = torch.distributions.Normal(means, scales).log_prob(actions.reshape(B, 1, -1).expand_as(means)).sum(-1)
+    logpi = torch.log_softmax(logits, -1)
+    lp = torch.logsumexp(logpi + comp, dim=-1)
+    comp_ent = torch.distributions.Normal(means, scales).entropy().sum(-1)
+    pi = logits.softmax(-1)
+    return lp, (pi * comp_ent).sum(-1).mean(), (pi * scales.mean(-1)).sum(-1).mean()
+
+
+def gmm_sample(gc: GmmCfg, mean_spec, w_spec, p: Params, logvar, state, modes, noise, Da: int, Ta: int):
+    """GMMModel.forward (gmm.py:88-97) with the recorded draws: component modes[b], a = mu + sigma z."""
+    means, scales, _ = gmm_dist(gc, mean_spec, w_spec, p, logvar, state, Da, Ta)
+    rows = torch.arange(means.shape[0])
+    return (means[rows, modes] + scales[rows, modes] * noise).view(-1, Ta, Da)
+
+
+def gmm_ppo_loss(gc: GmmCfg, mean_spec, w_spec, cspec: NetSpec, ft: Params, logvar, critic: Params, obs, actions, returns, oldvalues,
+                 advantages, oldlogprobs, Da: int, Ta: int):
+    """PPO_GMM.loss (gmm_ppo.py:39-112): (pg, entropy_loss, v, clipfrac, kl, ratio, 0, std)."""
+    newlp, entropy, std = gmm_logprob(gc, mean_spec, w_spec, ft, logvar, obs, actions, Da, Ta)
+    newlp = newlp.clamp(min=-5, max=2)
+    oldlp = oldlogprobs.clamp(min=-5, max=2)
+    logratio = newlp - oldlp
+    ratio = logratio.exp()
+    with torch.no_grad():
+        approx_kl = ((ratio - 1) - logratio).mean()
+        clipfrac = ((ratio - 1.0).abs() > gc.clip_ploss_coef).float().mean().item()
+    adv = advantages
+    if gc.norm_adv:
+        adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+    pg = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1 - gc.clip_ploss_coef, 1 + gc.clip_ploss_coef)).mean()
+    newv = critic_forward(critic, cspec, obs).view(-1)
+    if gc.clip_vloss_coef is not None:
+        vcl = oldvalues + torch.clamp(newv - oldvalues, -gc.clip_vloss_coef, gc.clip_vloss_coef)
+        v_loss = 0.5 * torch.max((newv - returns) ** 2, (vcl - returns) ** 2).mean()
+    else:
+        v_loss = 0.5 * ((newv - returns) ** 2).mean()
+    return pg, -entropy, v_loss, clipfrac, approx_kl.item(), ratio.mean().item(), 0, std.item()
 
 
 # --------------------------------------------------------------------------

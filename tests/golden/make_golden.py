@@ -924,6 +924,68 @@ def g19_plain_mlp():
     save("g19_plain_mlp", **out)
 
 
+# ---------------------------------------------------------------- G20 mixture-of-Gaussians PPO
+from make_golden_cases import GMM_CASES  # noqa: E402
+
+
+def gmm_logvar(Da, M, fixed_std, seed):
+    rs = np.random.RandomState(seed)
+    return torch.from_numpy((np.log(fixed_std ** 2) + rs.uniform(-0.4, 0.4, size=Da * M)).astype(np.float32))
+
+
+def g20_gmm():
+    """PPO_GMM (model/rl/gmm_ppo.py) over GMM_MLP (model/common/mlp_gmm.py) + CriticObs: sampling with recorded component and
+    noise draws, get_logprobs, the loss 8-tuple and every gradient of pg + 0.01 entropy_loss + 0.5 v."""
+    from dppo.model.common.mlp_gmm import GMM_MLP
+    from dppo.model.rl.gmm_ppo import PPO_GMM
+    out = {}
+    rs = np.random.RandomState(2000)
+    N = 40
+    for cname, (cond, tkw, Ta, Da, gkw, cdims) in GMM_CASES.items():
+        M = gkw["num_modes"]
+        ms, ws = O.gmm_specs(cond, tkw["mlp_dims"], tkw["activation"], tkw["residual"], Da, Ta, M)
+        c = O.NetSpec("critic", cond_dim=cond, mlp_dims=cdims, activation="Mish", residual=True)
+        actor = GMM_MLP(action_dim=Da, horizon_steps=Ta, cond_dim=cond, mlp_dims=list(tkw["mlp_dims"]), num_modes=M,
+                        activation_type=tkw["activation"], residual_style=tkw["residual"], fixed_std=gkw["fixed_std"],
+                        learn_fixed_std=gkw["learn_fixed_std"], std_min=gkw["std_min"], std_max=gkw["std_max"])
+        sd = dict(O.gmm_init_params(ms, ws, 71))
+        sd["logvar_min"], sd["logvar_max"] = actor.logvar_min.data.clone(), actor.logvar_max.data.clone()
+        if gkw["learn_fixed_std"]:
+            sd["logvar"] = gmm_logvar(Da, M, gkw["fixed_std"], 73)
+        actor.load_state_dict(sd, strict=True)
+        m = PPO_GMM(actor=actor, critic=ref_critic(c, O.init_params(c, 72)), horizon_steps=Ta, device="cpu",
+                    clip_ploss_coef=gkw["clip_ploss_coef"], clip_vloss_coef=gkw.get("clip_vloss_coef"), norm_adv=True)
+        state = torch.from_numpy(rs.uniform(-1, 1, size=(N, 1, cond)).astype(np.float32))
+        modes = torch.from_numpy(rs.randint(0, M, size=(N,)).astype(np.int64))
+        noise_all = torch.from_numpy(rs.randn(N, M, Ta * Da).astype(np.float32))
+        normal0, multi0 = torch.normal, torch.multinomial
+        torch.normal = lambda loc, scale, *a_, **k_: loc + scale * noise_all
+        torch.multinomial = lambda probs, n, repl=True, **k_: modes.view(-1, 1)
+        try:
+            actions = m(cond={"state": state}, deterministic=False)
+        finally:
+            torch.normal, torch.multinomial = normal0, multi0
+        with torch.no_grad():
+            lp, ent, std = m.get_logprobs({"state": state}, actions)
+            oldv = m.critic({"state": state}).view(-1) + torch.from_numpy(rs.normal(0, 0.3, N).astype(np.float32))
+        oldlp = lp + torch.from_numpy(rs.normal(0, 0.05, N).astype(np.float32))
+        ret = torch.from_numpy(rs.normal(0, 1, N).astype(np.float32))
+        adv = torch.from_numpy(rs.normal(0.3, 2.0, N).astype(np.float32))
+        res = m.loss({"state": state}, actions, ret, oldv, adv.clone(), oldlp)
+        (res[0] + 0.01 * res[1] + 0.5 * res[2]).backward()
+        out.update({f"{cname}_state": state, f"{cname}_modes": modes, f"{cname}_noise": noise_all[torch.arange(N), modes],
+                    f"{cname}_actions": actions, f"{cname}_logprobs": lp, f"{cname}_oldlogprobs": oldlp, f"{cname}_oldvalues": oldv,
+                    f"{cname}_returns": ret, f"{cname}_adv": adv,
+                    f"{cname}_stats": np.array([res[0].item(), res[1].item(), res[2].item(), res[3], res[4], res[5],
+                                                float(res[6]), res[7]], dtype=np.float64)})
+        for k, p in m.actor_ft.named_parameters():
+            if p.grad is not None:
+                put_grad(out, f"{cname}_gactor_{k}", p.grad)
+        for k, p in m.critic.named_parameters():
+            put_grad(out, f"{cname}_gcritic_{k}", p.grad)
+    save("g20_gmm", **out)
+
+
 # ---------------------------------------------------------------- G10 LR schedule trace
 from make_golden_cases import SCHED_CASES  # noqa: E402
 
@@ -949,6 +1011,6 @@ def g10_scheduler():
 if __name__ == "__main__":
     only = sys.argv[1:]  # e.g. `make_golden.py g8_bc` regenerates one file (each generator owns its RNG stream)
     for fn in (g1_tables, g2_forward, g3_g4_chains, g5_loss, g6_reward_scaler, g7_adamw, g8_bc, g9_denoise_mse, g10_scheduler, g11_eval, g12_gaussian, g13_unet, g14_unet_loss, g15_unet_dim40, g16_vision,
-               g17_vision_loss, g18_vision_gaussian, g19_plain_mlp):
+               g17_vision_loss, g18_vision_gaussian, g19_plain_mlp, g20_gmm):
         if not only or fn.__name__ in only:
             fn()

@@ -129,3 +129,17 @@ PLAIN_CASES = {
     "plain_small_ddim": ("plain_mlp", dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5, clip_ploss_coef=0.01,
                                            clip_vloss_coef=0.2)),
 }
+
+# mixture-of-Gaussians PPO: name -> (cond_dim, trunk kwargs, Ta, Da, GmmCfg kwargs, critic mlp_dims)
+GMM_CASES = {
+    # cfg/robomimic/finetune/can/ft_ppo_gmm_mlp.yaml:80-99: residual 512 trunks, 5 modes, Ta 4, Da 7 (140 mean outputs), learned std.
+    # The reference clamps the SUMMED log-prob to [-5, 2] (gmm_ppo.py:62-63): at the shipped std 0.1 it sits near +25 and the policy
+    # gradient is identically zero; the fixtures use stds that put most samples inside the window (0.27 here, 0.4 below) so that
+    # the pass-through mask, the responsibilities and both trunks' gradients are exercised.
+    "gmm_can": (23, dict(mlp_dims=[512, 512, 512], activation="Mish", residual=True), 4, 7,
+                dict(num_modes=5, fixed_std=0.27, learn_fixed_std=True, std_min=0.01, std_max=0.5, clip_ploss_coef=0.01), [256, 256, 256]),
+    # cfg/d3il/finetune/avoid_m1/ft_ppo_gmm_mlp.yaml:84-103: plain 256 x 2 trunks, fixed std, Ta 4, Da 2
+    "gmm_d3il": (4, dict(mlp_dims=[256, 256], activation="ReLU", residual=False), 4, 2,
+                 dict(num_modes=5, fixed_std=0.4, learn_fixed_std=False, std_min=0.01, std_max=1.0, clip_ploss_coef=0.1,
+                      clip_vloss_coef=0.2), [256, 256, 256]),
+}

@@ -669,3 +669,53 @@ def test_eval_agent_runs_a_fine_tuning_checkpoint(tmp_path, monkeypatch, pixels)
     assert np.isfinite(res["eval_episode_reward"])
     saved = np.load(os.path.join(str(tmp_path), sub + "-eval", "result.npz"))
     assert int(saved["num_episode"]) == res["num_episode"]
+
+
+GMM_YAML = GAUSS_YAML[:GAUSS_YAML.index("model:\n")] + textwrap.dedent("""
+    model:
+      _target_: dppo.model.rl.gmm_ppo.PPO_GMM
+      clip_ploss_coef: 0.1
+      network_path: null
+      actor:
+        _target_: dppo.model.common.mlp_gmm.GMM_MLP
+        mlp_dims: [256, 256]
+        residual_style: False
+        fixed_std: 0.4
+        learn_fixed_std: True
+        std_min: 0.05
+        std_max: 1.0
+        num_modes: 5
+        cond_dim: ${eval:'${obs_dim} * ${cond_steps}'}
+        horizon_steps: ${horizon_steps}
+        action_dim: ${action_dim}
+      critic:
+        _target_: dppo.model.common.critic.CriticObs
+        cond_dim: ${eval:'${obs_dim} * ${cond_steps}'}
+        mlp_dims: [256, 256, 256]
+        activation_type: Mish
+        residual_style: True
+      horizon_steps: ${horizon_steps}
+      device: ${device}
+""") if "GAUSS_YAML" in globals() else None
+
+
+def test_gaussian_agent_drives_a_gmm_policy(tmp_path, monkeypatch):
+    """The reference points its ft_ppo_gmm_mlp cfgs at TrainPPOGaussianAgent: rollout, log-prob precompute, minibatch updates of
+    both trunks (one flat buffer), the learned per-(mode, dim) std and the critic."""
+    from dppo_amd.cfg.loader import get_class, load_config
+    monkeypatch.setenv("DPPO_LOG_DIR", str(tmp_path))
+    p = tmp_path / "ft_gmm.yaml"
+    p.write_text(GMM_YAML)
+    cfg = load_config(str(p))
+    agent = get_class(cfg._target_)(cfg)
+    m = agent.model
+    net = m.actor_ft
+    n_mean = net.mean_net.flat_params().numel()
+    w0, c0, lv0 = net.flat_params().clone(), m.critic.flat_params().clone(), net.logvar.data.clone()
+    res = agent.run()
+    assert len(res) == 3 and "pg_loss" in res[1] and np.isfinite(res[1]["loss"]) and np.isfinite(res[1]["std"])
+    w1 = net.flat_params()
+    assert not torch.equal(w1[:n_mean], w0[:n_mean]), "mean trunk was not updated"
+    assert not torch.equal(w1[n_mean:], w0[n_mean:]), "weights trunk was not updated"
+    assert not torch.equal(m.critic.flat_params(), c0) and not torch.equal(net.logvar.data, lv0)
+    assert torch.isfinite(w1).all()

@@ -246,3 +246,32 @@ def test_every_shipped_pixel_diffusion_cfg_builds():
         assert lib.dppo_vis_param_count(C.byref(net.vis.desc)) == sum(q.numel() for q in net.vis.trunk_parameters())
         n_g += 1
     assert n_g == 4
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason="reference checkout not present (GPU box)")
+def test_every_shipped_gmm_mlp_cfg_builds():
+    """ft_ppo_gmm_mlp.yaml (d3il: plain 256 x 2 trunks; robomimic: residual trunks with 140 / 560 mean outputs): the model builds,
+    the two trunk descriptors pass the C ABI's checks, and the cfg resolves to the Gaussian agent like in the reference."""
+    import ctypes as C
+    import glob
+
+    from dppo_amd import hip
+    from dppo_amd.model.rl.gmm_ppo import PPO_GMM
+    os.environ.setdefault("DPPO_LOG_DIR", "/tmp/log")
+    os.environ.setdefault("DPPO_DATA_DIR", "/tmp/data")
+    os.environ.setdefault("DPPO_WANDB_ENTITY", "none")
+    lib = hip.load()
+    n = 0
+    for p in sorted(glob.glob(os.path.join(REF_CFG, "*", "finetune", "*", "ft_ppo_gmm_mlp.yaml"))):
+        cfg = load_config(p, overrides=["device=cpu"])
+        cfg.model.network_path = None
+        model = instantiate(cfg.model)
+        assert isinstance(model, PPO_GMM) and get_class(cfg._target_).__name__ == "TrainPPOGaussianAgent", p
+        net = model.actor_ft
+        for t in (net.mean_net, net.weights_net):
+            assert lib.dppo_net_param_count(C.byref(t.net_desc())) == t.flat_params().numel(), (p, lib.dppo_last_error())
+        assert net.mean_net.net_desc().out_dim == int(cfg.action_dim) * int(cfg.horizon_steps) * int(cfg.num_modes)
+        assert lib.dppo_gmm_workspace_bytes(C.byref(net.mean_net.net_desc()), C.byref(net.weights_net.net_desc()),
+                                            C.byref(model.critic.net_desc()), hip.PREC_BF16, 256) > 0
+        n += 1
+    assert n == 7
