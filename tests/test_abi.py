@@ -130,3 +130,44 @@ def test_cond_mlp_layout_matches_reference_names():
     assert names[8] == "mlp_mean.layers.0.weight" and tuple(a.mlp_mean.layers[0].weight.shape) == (256, 36 + 16 + 32)
     lib = hip.load()
     assert a.flat_params().numel() == lib.dppo_net_param_count(C.byref(a.net_desc()))
+
+
+def test_new_entry_points_reject_bad_descriptors_with_a_message():
+    """Argument validation of the round-2 entries runs on the host (no GPU needed): every refusal leaves its reason in
+    dppo_last_error()."""
+    lib = hip.load()
+    v = hip.VisDesc(in_ch=3, img_h=96, img_w=96, embed_dim=128, num_heads=4, depth=1, embed_norm=0, prop_dim=9, spatial_emb=128,
+                    num_img=1)
+    assert lib.dppo_vis_param_count(C.byref(v)) == 419712
+    for field, value, word in (("img_h", 97, b"image"), ("embed_dim", 100, b"embed_dim"), ("num_heads", 3, b"num_heads"),
+                               ("depth", 9, b"depth"), ("num_img", 3, b"num_img"), ("embed_norm", 1, b"embed_norm"),
+                               ("img_w", 512, b"patches")):
+        bad = hip.VisDesc.from_buffer_copy(v)
+        setattr(bad, field, value)
+        assert lib.dppo_vis_param_count(C.byref(bad)) == -1, field
+        assert word in lib.dppo_last_error(), (field, lib.dppo_last_error())
+    assert lib.dppo_vis_workspace_bytes(C.byref(v), hip.PREC_BF16, 0, 1) == -1
+    # plain trunks: multiples of 64, no LayerNorm / cond_mlp; wide outputs only off the denoiser
+    d = hopper_desc()
+    d.plain, d.hidden, d.in_dim = 1, 64, 39
+    assert lib.dppo_net_param_count(C.byref(d)) == 2 * 16 * 16 + 2 * 16 + 2 * 16 * 16 + 16 + 39 * 64 + 64 + 64 * 64 + 64 + 12 * 64 + 12
+    d.use_layernorm = 1
+    assert lib.dppo_net_param_count(C.byref(d)) == -1 and b"plain" in lib.dppo_last_error()
+    d = hopper_desc()
+    d.out_dim = d.act_flat = 140
+    d.in_dim = 140 + 16 + 11
+    assert lib.dppo_net_param_count(C.byref(d)) == -1 and b"out_dim" in lib.dppo_last_error()
+    wide = hip.NetDesc(kind=1, in_dim=23, hidden=512, n_blocks=1, out_dim=140, act=hip.ACT_MISH, time_dim=0, act_flat=0,
+                       cond_dim=23, cond_hidden=0, cond_out=0)
+    assert lib.dppo_net_param_count(C.byref(wide)) == 23 * 512 + 512 + 2 * (512 * 512 + 512) + 140 * 512 + 140
+    assert lib.dppo_sample_chain_workspace_bytes(C.byref(d), hip.PREC_BF16, 16) == -1
+    # GMM: the two trunks must agree with the cfg
+    wts = hip.NetDesc(kind=1, in_dim=23, hidden=512, n_blocks=1, out_dim=5, act=hip.ACT_MISH, time_dim=0, act_flat=0, cond_dim=23,
+                      cond_hidden=0, cond_out=0)
+    crit = hip.NetDesc(kind=1, in_dim=23, hidden=256, n_blocks=1, out_dim=1, act=hip.ACT_MISH, time_dim=0, act_flat=0, cond_dim=23,
+                       cond_hidden=0, cond_out=0)
+    assert lib.dppo_gmm_workspace_bytes(C.byref(wide), C.byref(wts), C.byref(crit), hip.PREC_BF16, 64) > 0
+    cfg = hip.GmmCfg(horizon_steps=4, action_dim=7, num_modes=4, std_mode=0, fixed_std=0.1)
+    assert lib.dppo_gmm_logprob(C.byref(wide), C.byref(wts), hip.PREC_BF16, None, None, None, None, C.byref(cfg), None, None, None,
+                                4, None, None, 0, None) == -1
+    assert b"out_dim" in lib.dppo_last_error()

@@ -124,3 +124,28 @@ def test_hip_gmm_samples_follow_the_mixture():
     assert float(near.max()) < 5e-3  # every draw is one of the five component means (+- 1e-4 z)
     freq = torch.bincount(which, minlength=5).float() / 20000
     assert int((freq > 0.01).sum()) >= 2 and float(freq.max()) < 0.99  # the component is drawn, not fixed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(GMM_CASES))
+def test_hip_gmm_bf16(golden, case):
+    """bf16 operands: log-probs within 0.15 absolute of the reference (a sum over Ta*Da = 8..28 element log-probs whose means carry
+    bf16 rounding), value loss within 5e-2 relative, ratio statistics finite and close, critic gradient cosine >= 0.98."""
+    g = golden("g20_gmm")
+    m = build(case, "bf16")
+    d = lambda k: T(g[f"{case}_{k}"]).cuda()
+    cond = {"state": d("state")}
+    lp, _, _ = m.get_logprobs(cond, d("actions"))
+    assert float(np.abs(lp.cpu().numpy() - g[f"{case}_logprobs"]).max()) < 0.15
+    res = m.loss(cond, d("actions"), d("returns"), d("oldvalues"), d("adv"), d("oldlogprobs"))
+    ref = g[f"{case}_stats"]
+    assert abs(res[2].item() - ref[2]) <= 5e-2 * abs(ref[2]) + 1e-3 and abs(res[5] - ref[5]) < 0.05 and np.isfinite(res[0].item())
+    assert abs(res[7] - ref[7]) < 1e-3 and abs(float(res[1]) - ref[1]) < 2e-2
+    (res[0] + 0.5 * res[2]).backward()
+    num = a2 = b2 = 0.0
+    for k, p in m.critic.named_parameters():
+        x = p.grad.double().cpu().numpy().reshape(-1)
+        key = f"{case}_gcritic_{k}"
+        r, xs = (g[key].astype(np.float64).reshape(-1), x) if key in g else (g[key + "__sub"].astype(np.float64), x[::61])
+        num, a2, b2 = num + float(xs @ r), a2 + float(xs @ xs), b2 + float(r @ r)
+    assert num / np.sqrt(a2 * b2) > 0.98
