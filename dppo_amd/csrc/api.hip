@@ -1454,7 +1454,6 @@ struct PpoWs {
   float* loss_tab;  // [2 Kft], Kft <= 1024
   double* loss_partial;
   double* loss_partial_v;  // the value half's, when it runs on the critic's stream
-  float* loss_partial_cs;
 };
 template <class P>
 static size_t carve_ppo(Carver& c, const dppo_net_desc& a, const dppo_net_desc& cr, int64_t N, PpoWs<P>& W) {
@@ -1462,7 +1461,6 @@ static size_t carve_ppo(Carver& c, const dppo_net_desc& a, const dppo_net_desc& 
   W.loss_tab = (float*)c.take(2 * 1024 * sizeof(float));
   W.loss_partial = (double*)c.take((size_t)loss_blocks(N) * 8 * sizeof(double));
   W.loss_partial_v = (double*)c.take((size_t)loss_blocks(N) * 8 * sizeof(double));
-  W.loss_partial_cs = (float*)c.take((size_t)loss_blocks(N) * 65 * sizeof(float));
   W.brow = (int32_t*)c.take((size_t)N * 4);
   W.brow_c = (int32_t*)c.take((size_t)N * 4);
   W.krow = (int32_t*)c.take((size_t)N * 4);

@@ -9,6 +9,9 @@
 #ifndef DPPO_BWD_LATE
 #define DPPO_BWD_LATE 1
 #endif
+#ifndef DPPO_FLAGS
+#define DPPO_FLAGS 1  // layer hand-over by per-wave LDS flags instead of workgroup barriers (0: barriers, for A/B runs)
+#endif
 
 namespace dppo {
 
@@ -72,9 +75,35 @@ struct Engine {
 #pragma unroll
       for (int tp = 0; tp < TPW; ++tp) ring[p][tp] = s[(p * TPW + tp) * 64];
   }
-  // acc += W(layer at stream position pos .. pos+nks) . src^T ; src: swizzled LDS image with row bytes rb
-  __device__ __forceinline__ void run(f32x4 (&acc)[TPW][MR], const char* src, int rb, int km, int nks, int r, int g) {
+  // acc += W(layer at stream position pos .. pos+nks) . src^T ; src: swizzled LDS image with row bytes rb.
+  // flags != nullptr: the image is being produced by the other waves' emits of the previous layer (wave p writes the
+  // features of k-steps [p nks/8, (p+1) nks/8) and then sets flags[p] = need, see hand_over()): each group of PD k-steps
+  // first makes sure its producers have arrived -- no workgroup barrier between two layers.
+  __device__ __forceinline__ void run(f32x4 (&acc)[TPW][MR], const char* src, int rb, int km, int nks, int r, int g,
+                                      const volatile uint32_t* flags = nullptr, uint32_t need = 0) {
+    uint32_t ready = 0xffu;
+    const int kpp_shift = 28 - __builtin_clz((unsigned)(nks | 8));  // log2(k-steps per producer wave): nks = 8, 16, 32, 64 with flags
+    if (flags != nullptr) {
+      ready = 0;
+      const u32x4 f0 = *(const volatile u32x4*)flags, f1 = *(const volatile u32x4*)(flags + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)f0[i]) - need) >= 0) ready |= 1u << i;
+        if ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)f1[i]) - need) >= 0) ready |= 16u << i;
+      }
+      asm volatile("" ::: "memory");  // the image reads below stay behind the flag reads
+    }
     for (int k0 = 0; k0 < nks; k0 += PD) {
+      if (ready != 0xffu) {
+        const int p_lo = k0 >> kpp_shift, p_hi = (k0 + PD - 1) >> kpp_shift;
+        const uint32_t grp = ((2u << p_hi) - 1u) & ~((1u << p_lo) - 1u);
+        if (grp & ~ready) {
+          for (int p = p_lo; p <= p_hi; ++p)
+            while ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)flags[p]) - need) < 0) __builtin_amdgcn_s_sleep(1);
+          ready |= grp;
+          asm volatile("" ::: "memory");
+        }
+      }
 #pragma unroll
       for (int p = 0; p < PD; ++p) {
         const int ks = k0 + p;
@@ -96,6 +125,21 @@ struct Engine {
     if (pos >= total) pos -= total;
   }
 };
+
+// Layer hand-over by flags instead of a workgroup barrier (kernels without LayerNorm).  A wave that has written its
+// features of a layer's output into the LDS image publishes the layer's sequence number in flags[wave]; the next layer's
+// k-loop (Engine::run) waits per producer.  LDS executes one wave's instructions in order, so the data are in place when
+// the flag is, and a reader's image loads are issued behind its flag load.  Why it is safe without a barrier on the two
+// alternating images: a wave can finish layer L+1's k-loop -- and only then overwrite the image layer L read -- after it
+// has seen EVERY wave's layer-L flag, which each wave sets after its own layer-L k-loop, the last reader of that image.
+// What it buys: the two waves of a SIMD drift apart (the older one wins the MFMA arbitration), and one's emit phase
+// (activation, stores, column sums) then runs under the other's MFMAs instead of both waiting at the barrier for the
+// slower one: profiles/r01_h_fused_phase_stamps.txt shows 3.5-6.5k cycles of barrier wait per layer.
+__device__ __forceinline__ void hand_over(volatile uint32_t* flags, int wid, int lane, uint32_t seq) {
+  asm volatile("" ::: "memory");  // the emit's LDS stores stay ahead of the flag store
+  if (lane == 0) flags[wid] = seq;
+  asm volatile("" ::: "memory");
+}
 
 // ReLU'(x) of a lane's 4*TPW features of one row is a bit mask: the forward stores it as one 32-bit word per (row, wave,
 // lane group g) -- [M][SIGN_WORDS] -- and the backward reads 128 bytes per row instead of the whole activated tensor.
@@ -241,12 +285,16 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_forward_kernel(const Fused
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // layer hand-over flags, one per wave (see hand_over()); LayerNorm needs the whole workgroup at every layer anyway
+  constexpr bool FLAGS = !LN && DPPO_FLAGS;
 #ifndef DPPO_NO_SETPRIO
-  // static priority for the younger half of the workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4): waves 4-7
-  // lose every VALU arbitration against their SIMD partners and reach each layer's barrier 3.5-6.5k cycles late
-  // (profiles/r01_h_fused_phase_stamps.txt); measured +0.8 % on the update step (profiles/r02_i_setprio_ab.txt).  The
-  // same line in the sampler costs 7 % there (one 16-row tile per workgroup: the older half is the critical path).
-  if (wid >= 4) __builtin_amdgcn_s_setprio(1);
+  // Barrier variants only: static priority for the younger half of the workgroup (MI355X_MICROARCH.md, two waves per SIMD,
+  // item 4): waves 4-7 lose every VALU arbitration against their SIMD partners and reach each layer's barrier 3.5-6.5k
+  // cycles late (profiles/r01_h_fused_phase_stamps.txt); measured +0.8 % on the update step (profiles/r02_i_setprio_ab.txt).
+  // With the flag hand-over the lag is useful (the older wave's emit runs under the younger's MFMAs) and equal priorities
+  // measure best (profiles/r02_flags_ab.txt).  The same line in the sampler costs 7 % there (one 16-row tile per workgroup:
+  // the older half is the critical path).
+  if (!FLAGS && wid >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
   const int r = lane & 15, g = lane >> 4;
   const int Kp0 = a.Kp0, nb = a.nb, M = a.M;
@@ -259,7 +307,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_forward_kernel(const Fused
   // (KSPLIT*OT <= 8 sub-tiles of 1 KB per 16 rows <= 16*H*ES always)
   float* part = (float*)bufB;
   static_assert(KSPLIT * OT * 16 * 16 * 4 <= 16 * HRB, "out-layer partials must fit in buffer B");
-  float* lnred = (float*)(bufB + MT * HRB);  // [8 waves][MR][16] LayerNorm row-reduction table (LN only)
+  volatile uint32_t* flags = (volatile uint32_t*)(bufB + MT * HRB);  // [16 words]
+  float* lnred = (float*)(bufB + MT * HRB + 64);  // [8 waves][MR][16] LayerNorm row-reduction table (LN only)
   // Constants of the whole launch, staged once per workgroup where LDS allows (the launcher decides, a.consts_lds):
   // a global load issued at a layer's start waits behind every weight fragment the ring has in flight (vmcnt is in
   // issue order) -- measured ~2k cycles per layer for the bias and ~6k for the out-layer fragments of a 48k-cycle tile.
@@ -274,6 +323,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_forward_kernel(const Fused
   }
   if (wout_lds)
     for (int idx = tid; idx < KSH * OT * 64; idx += 512) woutL[idx] = a.ostream[idx];
+  if (tid < 16) flags[tid] = 0;
+  uint32_t seq = 0;  // the same in every wave: hand-overs so far
   // (visible after the first tile's barrier)
 
   Engine<P, TPW, MR, PD> eng;
@@ -334,12 +385,15 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_forward_kernel(const Fused
     else
       emit<P, TPW, MR>(h, ACT_NONE, bufA, a.hpre[0], H, wbase, g, r, row0, M);
     STAMP(3);
-    __syncthreads();
+    if (FLAGS && nb > 0)
+      hand_over(flags, wid, lane, ++seq);
+    else
+      __syncthreads();
     STAMP(4);
     // ---- residual blocks
     for (int b = 0; b < nb; ++b) {
       bias_init(1 + 2 * b);
-      eng.run(acc, bufA, HRB, 15, KSH, r, g);
+      eng.run(acc, bufA, HRB, 15, KSH, r, g, FLAGS ? flags : nullptr, seq);
       STAMP(5);
       if constexpr (LN) {
         if (a.z1[b] != nullptr) emit<P, TPW, MR>(acc, ACT_NONE, nullptr, a.z1[b], H, wbase, g, r, row0, M);
@@ -355,10 +409,13 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_forward_kernel(const Fused
       }
       emit<P, TPW, MR>(acc, ACT, bufB, a.a2[b], H, wbase, g, r, row0, M, LN ? nullptr : a.z1[b]);  // z1[b] <- act'(z1_b) (Mish)
       STAMP(6);
-      __syncthreads();
+      if constexpr (FLAGS)
+        hand_over(flags, wid, lane, ++seq);
+      else
+        __syncthreads();
       STAMP(7);
       bias_init(2 + 2 * b);
-      eng.run(acc, bufB, HRB, 15, KSH, r, g);
+      eng.run(acc, bufB, HRB, 15, KSH, r, g, FLAGS ? flags : nullptr, seq);
       STAMP(8);
 #pragma unroll
       for (int tp = 0; tp < TPW; ++tp)
@@ -369,7 +426,10 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_forward_kernel(const Fused
       else
         emit<P, TPW, MR>(h, ACT_NONE, bufA, a.hpre[nb], H, wbase, g, r, row0, M);
       STAMP(9);
-      __syncthreads();
+      if (FLAGS && b + 1 < nb)
+        hand_over(flags, wid, lane, ++seq);
+      else
+        __syncthreads();  // the out layer's work items read every wave's features
       STAMP(10);
     }
     // ---- output layer: work items (row sub-tile m, out tile to, K slice kh) dealt to the 8 waves
@@ -436,8 +496,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr bool FLAGS = !LN && DPPO_FLAGS;  // see hand_over()
 #ifndef DPPO_NO_SETPRIO
-  if (wid >= 4) __builtin_amdgcn_s_setprio(1);  // see fused_forward_kernel
+  if (!FLAGS && wid >= 4) __builtin_amdgcn_s_setprio(1);  // see fused_forward_kernel
 #endif
   const int r = lane & 15, g = lane >> 4;
   const int nb = a.nb, M = a.M;
@@ -446,7 +507,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
   char* bufA = smem;
   char* bufB = bufA + MT * HRB;
   char* xin = bufB;  // d_out tile: consumed by the first layer and by the top block's composite layer
-  float* lnred = (float*)(bufB + MT * HRB);  // [8 waves][2][MR][16] LayerNorm row-reduction table (LN only)
+  volatile uint32_t* flags = (volatile uint32_t*)(bufB + MT * HRB);  // [16 words]
+  float* lnred = (float*)(bufB + MT * HRB + 64);  // [8 waves][2][MR][16] LayerNorm row-reduction table (LN only)
   constexpr int DRED_COLS = 128;             // d_out is at most 128 columns wide
   float* dred = lnred + (LN ? LN_WAVES * 2 * MR * 16 : 0);  // [8 waves][128] column sums of the d_out tile
   const int wbase = wid * 16 * TPW;  // lane features: wbase + feat_off<P>(g, tp) + e
@@ -454,6 +516,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
 
   Engine<P, TPW, MR, PD> eng;
   eng.prime(a.bstream + (size_t)wid * total * TPW * 64 + lane, total);
+  if (tid < 16) flags[tid] = 0;  // (visible after the first tile's barrier)
+  uint32_t seq = 0;
 
   // column sums over this tile's rows of v -> colsum[slot][tile][H]; rows past M hold exact zeros
   auto colsum = [&](const f32x4 (&v)[TPW][MR], int slot, int tile) {
@@ -536,14 +600,22 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
     STAMP(19);
     colsum(dh, 0, tile);
     STAMP(20);
-    __syncthreads();
-    STAMP(21);
-    if (a.dout_slot >= 0 && tid < a.KpB0) {  // part 2: the eight waves' partial sums
-      float t = 0.f;
+    auto dout_sums = [&]() {  // part 2: the eight waves' partial sums
+      if (a.dout_slot >= 0 && tid < a.KpB0) {
+        float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < SAMPLER_WAVES; ++w) t += dred[w * DRED_COLS + tid];
-      a.colsum[((size_t)a.dout_slot * ntiles + tile) * H + tid] = t;
+        for (int w = 0; w < SAMPLER_WAVES; ++w) t += dred[w * DRED_COLS + tid];
+        a.colsum[((size_t)a.dout_slot * ntiles + tile) * H + tid] = t;
+      }
+    };
+    // With blocks and flags nothing was written to an LDS image yet (the top block reads the d_out tile again), so
+    // there is nothing to wait for; part 2 then runs behind the top block's second k-loop, which has seen every wave's flag.
+    const bool defer_sums = FLAGS && nb >= 1;
+    if (!defer_sums) {
+      __syncthreads();
+      dout_sums();
     }
+    STAMP(21);
     // pa: image the block's first layer reads (dh[b+1]) and its second layer's emit target; pb: the other one.  The top
     // block reads the d_out tile (which lives in bufB) instead, so its dz1 goes to bufA and the roles swap from there on.
     char* pa = bufA;
@@ -558,7 +630,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
       if constexpr (!FETCH_LATE) fetch<P, ACT == ACT_RELU && !LN, TPW>(d, a.m1[b], H, wbase, g, r, row0, M);
       zero_acc();
       // (one call site with selected operands: a second inlined copy of the k-loop costs 150 spilled VGPRs)
-      eng.run(acc, top ? xin : pa, top ? in_rb : HRB, top ? in_km : 15, top ? KSB0 : KSH, r, g);
+      eng.run(acc, top ? xin : pa, top ? in_rb : HRB, top ? in_km : 15, top ? KSB0 : KSH, r, g,
+              FLAGS && !top ? flags : nullptr, seq);
       if constexpr (FETCH_LATE) fetch<P, ACT == ACT_RELU && !LN, TPW>(d, a.m1[b], H, wbase, g, r, row0, M);
       STAMP(22);
       if constexpr (LN) {
@@ -586,12 +659,16 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
       STAMP(23);
       colsum(acc, (nb + 1) + (nb - 1 - b), tile);
       STAMP(24);
-      __syncthreads();
+      if constexpr (FLAGS)
+        hand_over(flags, wid, lane, ++seq);
+      else
+        __syncthreads();
       STAMP(25);
       // ---- dh[b] = dh[b+1] + (dz1 . W1) * act'(h_b)       [LayerNorm: back through act(LN1(h_b))]
       if constexpr (!FETCH_LATE) fetch<P, ACT == ACT_RELU && !LN, TPW>(d, a.m0[b], H, wbase, g, r, row0, M);
       zero_acc();
-      eng.run(acc, pb, HRB, 15, KSH, r, g);
+      eng.run(acc, pb, HRB, 15, KSH, r, g, FLAGS ? flags : nullptr, seq);
+      if (top && defer_sums) dout_sums();
       if constexpr (FETCH_LATE) fetch<P, ACT == ACT_RELU && !LN, TPW>(d, a.m0[b], H, wbase, g, r, row0, M);
       STAMP(26);
       if constexpr (LN) {
@@ -615,11 +692,14 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
 #pragma unroll
             for (int e = 0; e < 4; ++e) dh[tp][m][e] += acc[tp][m][e] * grad_at<P, ACT>(d, tp, m, e);
       }
-      emit<P, TPW, MR>(dh, ACT_NONE, pa, a.dh[b], H, wbase, g, r, row0, M);
+      emit<P, TPW, MR>(dh, ACT_NONE, b > 0 ? pa : nullptr, a.dh[b], H, wbase, g, r, row0, M);  // (nobody reads dh[0]'s image)
       STAMP(27);
       colsum(dh, nb - b, tile);
       STAMP(28);
-      __syncthreads();
+      if (FLAGS && b > 0)
+        hand_over(flags, wid, lane, ++seq);
+      else
+        __syncthreads();  // tile end: the next tile's d_out lands in buffer B
       STAMP(29);
     }
   }
@@ -696,7 +776,7 @@ static void raise_lds(K kern, DevLatch& done) {
 template <class P, int TPW, int MR, int OT, bool LN, int ACT, int OCC = 1>
 static int launch_fwd_cfg(const FusedFwdArgs& a, hipStream_t s) {
   constexpr int ES = P::ESIZE, MT = 16 * MR, H = 128 * TPW;
-  size_t lds = 2 * (size_t)MT * H * ES + (LN ? (size_t)LN_WAVES * MR * 16 * 4 : 0);
+  size_t lds = 2 * (size_t)MT * H * ES + 64 + (LN ? (size_t)LN_WAVES * MR * 16 * 4 : 0);
   constexpr size_t cap = 160 * 1024 / OCC;  // OCC workgroups share a CU's LDS
   if (lds > cap || a.Kp0 > H) return -2;
   FusedFwdArgs b = a;  // constants staged in LDS as far as it reaches: biases first, then the out-layer fragments
@@ -751,7 +831,7 @@ template int launch_fused_forward<BF16>(const dppo_net_desc&, const FusedFwdArgs
 template <class P, int TPW, int MR, bool LN, int ACT, int OCC = 1>
 static int launch_bwd_cfg(const FusedBwdArgs& a, hipStream_t s) {
   constexpr int ES = P::ESIZE, MT = 16 * MR, H = 128 * TPW;
-  const size_t lds = 2 * (size_t)MT * H * ES + (LN ? (size_t)LN_WAVES * 2 * MR * 16 * 4 : 0) + SAMPLER_WAVES * 128 * 4;
+  const size_t lds = 2 * (size_t)MT * H * ES + 64 + (LN ? (size_t)LN_WAVES * 2 * MR * 16 * 4 : 0) + SAMPLER_WAVES * 128 * 4;
   if (lds > 160 * 1024 / OCC || a.KpB0 > H || a.KpB0 > 128) return -2;
   static DevLatch attr;
   raise_lds(fused_backward_kernel<P, TPW, MR, LN, ACT, OCC>, attr);

@@ -146,11 +146,6 @@ struct LossArgs {
   int lddv;
   double* stats;    // [DPPO_STAT_COUNT], zeroed by the caller
   double* partial;  // [loss_blocks(N)][8] scratch
-  // optional fused out-layer bias gradients (needs ldde == 64): column sums of d_eps -> gb_actor[out_dim], of d_v -> gb_critic[0]
-  float* partial_cs;  // [loss_blocks(N)][65] scratch, or null
-  float* gb_actor;
-  float* gb_critic;
-  int out_dim;
 };
 int loss_blocks(int64_t N);
 template <class P>

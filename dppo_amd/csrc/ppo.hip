@@ -475,186 +475,215 @@ void launch_adv_moments(const float* adv_k, const int32_t* brow, int64_t N, doub
   hipLaunchKernelGGL(adv_moments_kernel, dim3(blocks), dim3(256), 0, s, adv_k, brow, N, moments);
 }
 
-// 16 lanes per sample (lane j owns chunk elements j, j+16, ...): every global access of a sample is one contiguous
-// segment; the two log-prob sums are reduced with 4 shuffles; scalar per-sample math is done redundantly by the 16 lanes
-constexpr int LOSS_PASSES = 2;  // samples per block = 16 * LOSS_PASSES: short blocks, many in flight (the gathers are latency-bound)
+// One lane per sample, 64 samples per block.  The first version gave a sample 16 lanes (one element each) and had all 16
+// redo the per-sample scalar math (normalisation, exp, clip schedule, value loss, five double-precision statistics): a wave
+// then finished 4 samples per pass and the kernel was VALU-bound at 34 us for 50,000 samples (profiles/r01_h_bench_serial_
+// kernel_stats.csv) while moving 10 MB.  Here a lane walks its sample's elements itself (16-byte loads where the row pitch
+// allows), the scalar math runs once per sample, and the elements' contribution to d loss / d eps stays in registers between
+// the log-prob sum and the store (up to NREG elements; beyond that the second pass recomputes it from L1-resident inputs).
+// Both log-prob sums run over j in ascending order, so unchanged weights still give ratio == 1 exactly.
+constexpr int LOSS_THREADS = 64;
 
-template <class P>
-__global__ __launch_bounds__(256) void ppo_loss_kernel(const LossArgs a) {
+template <class P, int NREG>
+__global__ __launch_bounds__(LOSS_THREADS) void ppo_loss_kernel(const LossArgs a) {
   typedef typename P::elem_t E;
+  constexpr int EPC = 16 / P::ESIZE;  // elements per 16-byte chunk of the outputs
   // per-k constants (only Kft distinct values exist): denoising discount and clip range, built once per block in
   // the reference's precision recipe (double pow / exp, then fp32) instead of per lane
   extern __shared__ float tab[];  // [Kft] discount, [Kft] eps_k, [2] adv mean / std
   const dppo_ppo_cfg& pc = a.pcfg;
   const int Kft = pc.ft_denoising_steps, AF = a.AF, Da = pc.action_dim;
-  if (a.tab != nullptr) {
-    for (int k = threadIdx.x; k < 2 * Kft; k += 256) tab[k] = a.tab[k];
-  } else {
-    for (int k = threadIdx.x; k < Kft; k += 256) loss_table_entry(pc, k, tab);
+  const bool pol = (a.part & 1) != 0, val = (a.part & 2) != 0;
+  if (pol) {
+    if (a.tab != nullptr) {
+      for (int k = threadIdx.x; k < 2 * Kft; k += LOSS_THREADS) tab[k] = a.tab[k];
+    } else {
+      for (int k = threadIdx.x; k < Kft; k += LOSS_THREADS) loss_table_entry(pc, k, tab);
+    }
+    if (threadIdx.x == 0) {
+      const double Nm = a.moments[2], mean = a.moments[0] / Nm;
+      const double varu = (a.moments[1] - Nm * mean * mean) / (Nm - 1.0);  // unbiased (torch.std)
+      tab[2 * Kft] = (float)mean;
+      tab[2 * Kft + 1] = (float)sqrt(varu > 0 ? varu : 0);
+    }
+    __syncthreads();
   }
-  if (threadIdx.x == 0 && (a.part & 1)) {
-    const double Nm = a.moments[2], mean = a.moments[0] / Nm;
-    const double varu = (a.moments[1] - Nm * mean * mean) / (Nm - 1.0);  // unbiased (torch.std)
-    tab[2 * Kft] = (float)mean;
-    tab[2 * Kft + 1] = (float)sqrt(varu > 0 ? varu : 0);
-  }
-  __syncthreads();
-  const int sub = threadIdx.x & 15;
   const int rh = pc.reward_horizon < pc.horizon_steps ? pc.reward_horizon : pc.horizon_steps;
   const int cnt = rh * Da;
   double s_pg = 0, s_v = 0, s_kl = 0, s_cf = 0, s_ratio = 0;
-  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cs_v = 0.f;  // column sums of d_eps (this lane's 4 columns) and of d_v
   const double Nn = a.n_count > 0 ? a.n_count : a.moments[2];  // samples in the (global) minibatch: means and 1/N scaling
-  for (int pass = 0; pass < LOSS_PASSES; ++pass) {
-    const int64_t n = ((int64_t)blockIdx.x * LOSS_PASSES + pass) * 16 + (threadIdx.x >> 4);
-    const bool live = n < a.N;
-    const int64_t nn = live ? n : a.N - 1;  // out-of-range lanes shadow the last sample (shuffles need all lanes), write nothing
-    const int b = a.brow[nn], k = (a.part & 1) ? a.krow[nn] : 0;  // the value half never looks at the denoising step
-    const dppo_step st = a.ksteps[k];
-    const float* ch = a.gathered ? a.chains + (size_t)b * 2 * AF : a.chains + ((size_t)b * (Kft + 1) + k) * AF;
-    const float* olp = a.gathered ? a.logprobs_k + (size_t)b * AF : a.logprobs_k + ((size_t)b * Kft + k) * AF;
-    const float* ep = a.eps + (size_t)nn * a.lde;
-    const float var = st.std * st.std, lstd = logf(st.std);
-    const bool pol = (a.part & 1) != 0, val = (a.part & 2) != 0;
-    // ---- new / old log-probs, clamped to [-5, 2], averaged over the first `rh` chunk steps (:93-102)
-    float sum_new = 0.f, sum_old = 0.f;
-    for (int j = sub; pol && j < cnt; j += 16) {
-      float mu, dmu;
-      posterior(a.dcfg, st, ch[j], ep[j], mu, dmu);
-      const float d = ch[AF + j] - mu;
-      const float lp = -(d * d) / (2.f * var) - lstd - DPPO_LOG_SQRT_2PI;
-      sum_new += fminf(fmaxf(lp, -5.f), 2.f);
-      sum_old += fminf(fmaxf(olp[j], -5.f), 2.f);
-    }
+  const int64_t n = (int64_t)blockIdx.x * LOSS_THREADS + threadIdx.x;
+  if (n < a.N) {
+    const int b = a.brow[n];
+    if (pol) {
+      const int k = a.krow[n];
+      const dppo_step st = a.ksteps[k];
+      const float* ch = a.gathered ? a.chains + (size_t)b * 2 * AF : a.chains + ((size_t)b * (Kft + 1) + k) * AF;
+      const float* olp = a.gathered ? a.logprobs_k + (size_t)b * AF : a.logprobs_k + ((size_t)b * Kft + k) * AF;
+      const float* ep = a.eps + (size_t)n * a.lde;
+      const float var = st.std * st.std, lstd = logf(st.std);
+      // 16-byte loads when every row of the four tensors starts on a 16-byte boundary
+      const bool vec = ((AF | a.lde | cnt) & 3) == 0;
+      // ---- new / old log-probs, clamped to [-5, 2], averaged over the first `rh` chunk steps (:93-102)
+      float sum_new = 0.f, sum_old = 0.f;
+      float gsrc[NREG > 0 ? NREG : 1];  // (d / var) * d mu / d eps where the clamp passes the gradient, else 0
+      auto element = [&](float x, float xn, float e, float o, float& gs) {
+        float mu, dmu;
+        posterior(a.dcfg, st, x, e, mu, dmu);
+        const float d = xn - mu;
+        const float lp = -(d * d) / (2.f * var) - lstd - DPPO_LOG_SQRT_2PI;
+        sum_new += fminf(fmaxf(lp, -5.f), 2.f);
+        sum_old += fminf(fmaxf(o, -5.f), 2.f);
+        gs = (lp >= -5.f && lp <= 2.f) ? (d / var) * dmu : 0.f;
+      };
+      if constexpr (NREG > 0) {
+        if (vec) {
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-      sum_new += __shfl_xor(sum_new, o);
-      sum_old += __shfl_xor(sum_old, o);
-    }
-    const float newlp = sum_new / (float)cnt, oldlp = sum_old / (float)cnt;
-    // ---- advantage: normalise over the minibatch, quantile clip, denoising discount (:129-144)
-    float adv = a.adv_k[b];
-    if (pc.norm_adv) adv = (adv - tab[2 * Kft]) / (tab[2 * Kft + 1] + 1e-8f);
-    if (pc.has_adv_clip) adv = fminf(fmaxf(adv, pc.adv_clip_lo), pc.adv_clip_hi);
-    adv *= tab[k];
-    // ---- ratio, per-step clip range (:147-159)
-    const float logratio = newlp - oldlp;
-    const float ratio = expf(logratio);
-    const float eps_k = tab[Kft + k];
-    // ---- clipped surrogate (:170-174) and d L / d ratio with torch.max / clamp sub-gradients
-    const float lo = 1.f - eps_k, hi = 1.f + eps_k;
-    const float rc = fminf(fmaxf(ratio, lo), hi);
-    const float pg1 = -adv * ratio, pg2 = -adv * rc;
-    const float w1 = pg1 > pg2 ? 1.f : (pg1 == pg2 ? 0.5f : 0.f);
-    const float within = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
-    const float dL_dratio = -adv * (w1 + (1.f - w1) * within);
-    const float coef = dL_dratio * ratio / ((float)Nn * (float)cnt);  // d mean(L) / d lp_j (before clamp mask)
-    // ---- value loss (:177-189)
-    const float v = val ? a.vnew[(size_t)nn * a.ldv] : 0.f;
-    const float ret = a.returns_k[b];
-    float dv, lv;
-    if (pc.has_vclip) {
-      const float ov = a.values_k[b];
-      const float c = (float)pc.clip_vloss_coef;
-      const float dlt = v - ov;
-      const float vc = ov + fminf(fmaxf(dlt, -c), c);
-      const float lu = (v - ret) * (v - ret), lc = (vc - ret) * (vc - ret);
-      lv = 0.5f * fmaxf(lu, lc);
-      const float inr = (dlt >= -c && dlt <= c) ? 1.f : 0.f;
-      const float wu = lu > lc ? 1.f : (lu == lc ? 0.5f : 0.f);
-      dv = wu * (v - ret) + (1.f - wu) * (vc - ret) * inr;
-    } else {
-      lv = 0.5f * ((v - ret) * (v - ret));
-      dv = v - ret;
-    }
-    if (live) {
-      if (sub == 0 && pol) {
-        s_kl += (double)((ratio - 1.f) - logratio);
-        s_cf += fabsf(ratio - 1.f) > eps_k ? 1.0 : 0.0;
-        s_ratio += ratio;
-        s_pg += fmaxf(pg1, pg2);
-      }
-      if (sub == 0 && val) s_v += lv;
-      // ---- d loss / d eps and d loss / d v, zero padded to the GEMM K width, 16 lanes x 4 elements per pass
-      E* de = (E*)a.d_eps + (size_t)n * a.ldde;
-      for (int j0 = 4 * sub; pol && j0 < a.ldde; j0 += 64) {
-        float gq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int j = j0 + q;
-          float gj = 0.f;
-          if (j < cnt) {
-            float mu, dmu;
-            posterior(a.dcfg, st, ch[j], ep[j], mu, dmu);
-            const float d = ch[AF + j] - mu;
-            const float lp = -(d * d) / (2.f * var) - lstd - DPPO_LOG_SQRT_2PI;
-            if (lp >= -5.f && lp <= 2.f) gj = coef * (d / var) * dmu;
+          for (int j0 = 0; j0 < NREG; j0 += 4) {
+            if (j0 < cnt) {
+              const float4 x = *(const float4*)(ch + j0), xn = *(const float4*)(ch + AF + j0);
+              const float4 e = *(const float4*)(ep + j0), o = *(const float4*)(olp + j0);
+              element(x.x, xn.x, e.x, o.x, gsrc[j0]);
+              element(x.y, xn.y, e.y, o.y, gsrc[j0 + 1]);
+              element(x.z, xn.z, e.z, o.z, gsrc[j0 + 2]);
+              element(x.w, xn.w, e.w, o.w, gsrc[j0 + 3]);
+            }
           }
-          gq[q] = gj;
+        } else {
+#pragma unroll
+          for (int j = 0; j < NREG; ++j)
+            if (j < cnt) element(ch[j], ch[AF + j], ep[j], olp[j], gsrc[j]);
         }
+      } else {
+        float gs;
+        for (int j = 0; j < cnt; ++j) element(ch[j], ch[AF + j], ep[j], olp[j], gs);
+      }
+      const float newlp = sum_new / (float)cnt, oldlp = sum_old / (float)cnt;
+      // ---- advantage: normalise over the minibatch, quantile clip, denoising discount (:129-144)
+      float adv = a.adv_k[b];
+      if (pc.norm_adv) adv = (adv - tab[2 * Kft]) / (tab[2 * Kft + 1] + 1e-8f);
+      if (pc.has_adv_clip) adv = fminf(fmaxf(adv, pc.adv_clip_lo), pc.adv_clip_hi);
+      adv *= tab[k];
+      // ---- ratio, per-step clip range (:147-159)
+      const float logratio = newlp - oldlp;
+      const float ratio = expf(logratio);
+      const float eps_k = tab[Kft + k];
+      // ---- clipped surrogate (:170-174) and d L / d ratio with torch.max / clamp sub-gradients
+      const float lo = 1.f - eps_k, hi = 1.f + eps_k;
+      const float rc = fminf(fmaxf(ratio, lo), hi);
+      const float pg1 = -adv * ratio, pg2 = -adv * rc;
+      const float w1 = pg1 > pg2 ? 1.f : (pg1 == pg2 ? 0.5f : 0.f);
+      const float within = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+      const float dL_dratio = -adv * (w1 + (1.f - w1) * within);
+      const float coef = dL_dratio * ratio / ((float)Nn * (float)cnt);  // d mean(L) / d lp_j (before clamp mask)
+      s_kl = (double)((ratio - 1.f) - logratio);
+      s_cf = fabsf(ratio - 1.f) > eps_k ? 1.0 : 0.0;
+      s_ratio = ratio;
+      s_pg = fmaxf(pg1, pg2);
+      // ---- d loss / d eps, zero padded to the GEMM K width: whole 16-byte chunks, then a scalar remainder
+      E* de = (E*)a.d_eps + (size_t)n * a.ldde;
+      auto grad_at = [&](int j) -> float {
+        if (j >= cnt) return 0.f;
+        if constexpr (NREG > 0) {
+          return coef * gsrc[j];  // (j is a compile-time constant after unrolling: the array stays in registers)
+        } else {
+          float mu, dmu;
+          posterior(a.dcfg, st, ch[j], ep[j], mu, dmu);
+          const float d = ch[AF + j] - mu;
+          const float lp = -(d * d) / (2.f * var) - lstd - DPPO_LOG_SQRT_2PI;
+          return (lp >= -5.f && lp <= 2.f) ? coef * ((d / var) * dmu) : 0.f;
+        }
+      };
+      auto pack_store = [&](E* dst, const float (&v)[EPC]) {
+        u32x4 o;
+        if constexpr (P::ESIZE == 4) {
+          o = (u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+        } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) de[j0 + q] = P::from_f32(gq[q]);
-        if (j0 < 64) {
+          for (int q = 0; q < 4; ++q) o[q] = (uint32_t)f2bf(v[2 * q]) | ((uint32_t)f2bf(v[2 * q + 1]) << 16);
+        }
+        *(u32x4*)dst = o;
+      };
+      const int nch = a.ldde / EPC;
+      int c = 0;
+      if constexpr (NREG > 0) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) cs[q] += gq[q];
+        for (int cc = 0; cc < NREG / EPC; ++cc) {
+          if (cc < nch) {
+            float v[EPC];
+#pragma unroll
+            for (int q = 0; q < EPC; ++q) v[q] = grad_at(cc * EPC + q);
+            pack_store(de + cc * EPC, v);
+          }
+        }
+        c = NREG / EPC < nch ? NREG / EPC : nch;
+        const u32x4 z = (u32x4){0, 0, 0, 0};  // cnt <= NREG: everything behind the register chunks is padding
+        for (; c < nch; ++c) *(u32x4*)(de + c * EPC) = z;
+      } else {
+        for (; c < nch; ++c) {
+          float v[EPC];
+#pragma unroll
+          for (int q = 0; q < EPC; ++q) v[q] = grad_at(c * EPC + q);
+          pack_store(de + c * EPC, v);
         }
       }
-      if (sub == 0) cs_v += dv / (float)Nn;
+      for (int j = nch * EPC; j < a.ldde; ++j) {
+        float g = 0.f;
+        if constexpr (NREG == 0) g = grad_at(j);  // (NREG > 0 is only launched with ldde a multiple of EPC)
+        de[j] = P::from_f32(g);
+      }
+    }
+    if (val) {
+      // ---- value loss (:177-189)
+      const float v = a.vnew[(size_t)n * a.ldv];
+      const float ret = a.returns_k[b];
+      float dv, lv;
+      if (pc.has_vclip) {
+        const float ov = a.values_k[b];
+        const float c = (float)pc.clip_vloss_coef;
+        const float dlt = v - ov;
+        const float vc = ov + fminf(fmaxf(dlt, -c), c);
+        const float lu = (v - ret) * (v - ret), lc = (vc - ret) * (vc - ret);
+        lv = 0.5f * fmaxf(lu, lc);
+        const float inr = (dlt >= -c && dlt <= c) ? 1.f : 0.f;
+        const float wu = lu > lc ? 1.f : (lu == lc ? 0.5f : 0.f);
+        dv = wu * (v - ret) + (1.f - wu) * (vc - ret) * inr;
+      } else {
+        lv = 0.5f * ((v - ret) * (v - ret));
+        dv = v - ret;
+      }
+      s_v = lv;
+      // ---- d loss / d v: column 0 of a zero-padded row
       E* dvp = (E*)a.d_v + (size_t)n * a.lddv;
-      for (int j0 = 4 * sub; val && j0 < a.lddv; j0 += 64)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dvp[j0 + q] = P::from_f32(j0 + q == 0 ? dv / (float)Nn : 0.f);
+      const int nch = a.lddv / EPC;
+      u32x4 o = (u32x4){0, 0, 0, 0};
+      if constexpr (P::ESIZE == 4)
+        o[0] = __float_as_uint(dv / (float)Nn);
+      else
+        o[0] = (uint32_t)f2bf(dv / (float)Nn);
+      if (nch > 0) *(u32x4*)dvp = o;
+      const u32x4 z = (u32x4){0, 0, 0, 0};
+      for (int c = 1; c < nch; ++c) *(u32x4*)(dvp + c * EPC) = z;
+      for (int j = nch * EPC; j < a.lddv; ++j) dvp[j] = P::from_f32(j == 0 ? dv / (float)Nn : 0.f);
     }
   }
   // per-block partial sums; loss_finalize_kernel adds them in block order (no atomics: reproducible, and thousands of
   // double atomics on five addresses serialise in L2)
-  {  // the five sums in one pass (same per-value order as block_sum(): wave shuffle, then the four waves' partials)
-    __shared__ double sh5[4][5];
-    double v5[5] = {s_pg, s_v, s_kl, s_cf, s_ratio};
+  double v5[5] = {s_pg, s_v, s_kl, s_cf, s_ratio};
 #pragma unroll
-    for (int q = 0; q < 5; ++q)
-      for (int o = 32; o > 0; o >>= 1) v5[q] += __shfl_down(v5[q], o);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) {
-#pragma unroll
-      for (int q = 0; q < 5; ++q) sh5[w][q] = v5[q];
-    }
-    __syncthreads();
-    s_pg = sh5[0][0] + sh5[1][0] + sh5[2][0] + sh5[3][0];
-    s_v = sh5[0][1] + sh5[1][1] + sh5[2][1] + sh5[3][1];
-    s_kl = sh5[0][2] + sh5[1][2] + sh5[2][2] + sh5[3][2];
-    s_cf = sh5[0][3] + sh5[1][3] + sh5[2][3] + sh5[3][3];
-    s_ratio = sh5[0][4] + sh5[1][4] + sh5[2][4] + sh5[3][4];
-  }
+  for (int q = 0; q < 5; ++q)
+    for (int o = 32; o > 0; o >>= 1) v5[q] += __shfl_down(v5[q], o);
   if (threadIdx.x == 0) {
     double* o = a.partial + (size_t)blockIdx.x * 8;
-    o[DPPO_STAT_PG_LOSS] = s_pg, o[DPPO_STAT_V_LOSS] = s_v, o[DPPO_STAT_APPROX_KL] = s_kl;
-    o[DPPO_STAT_CLIPFRAC] = s_cf, o[DPPO_STAT_RATIO] = s_ratio;
-  }
-  // out-layer bias gradients: sum this block's 16 sample groups -> partial_cs[block][65] (64 d_eps columns, d_v)
-  if (a.partial_cs != nullptr) {
-    __shared__ float cred[16][65];
-    const int grp = threadIdx.x >> 4;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) cred[grp][4 * sub + q] = cs[q];
-    if (sub == 0) cred[grp][64] = cs_v;
-    __syncthreads();
-    if (threadIdx.x < 65) {
-      float t = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) t += cred[i][threadIdx.x];
-      a.partial_cs[(size_t)blockIdx.x * 65 + threadIdx.x] = t;
-    }
+    o[DPPO_STAT_PG_LOSS] = v5[0], o[DPPO_STAT_V_LOSS] = v5[1], o[DPPO_STAT_APPROX_KL] = v5[2];
+    o[DPPO_STAT_CLIPFRAC] = v5[3], o[DPPO_STAT_RATIO] = v5[4];
   }
 }
 
-// one block of 1024 threads: statistics (5 doubles over the blocks) and the 65 out-layer bias-gradient columns
-// (64 column lanes x 16 block lanes, 4 independent chains each); fixed order => reproducible
+// one block of 1024 threads: the five statistics, summed over the loss kernel's blocks in a fixed order => reproducible
 __global__ __launch_bounds__(1024) void loss_finalize_kernel(const double* partial, int blocks, const double* moments,
-                                                             double* stats, const float* partial_cs, float* gb_actor,
-                                                             int out_dim, float* gb_critic, int part, double n_count) {
+                                                             double* stats, int part, double n_count) {
   __shared__ double shd[16];
-  __shared__ float red[16][65];
   const double Nn = n_count > 0 ? n_count : moments[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int k = 0; k < 5; ++k) {
@@ -671,30 +700,6 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const double* parti
       stats[k] = t / Nn;  // each entry has exactly one owner launch
     }
   }
-  if (partial_cs != nullptr) {
-    for (int c0 = 0; c0 < 65; c0 += 64) {  // columns 0..63, then column 64 (d_v)
-      const int c = c0 + lane;
-      float p[4] = {0.f, 0.f, 0.f, 0.f};
-      if (c < 65) {
-        int b = w;
-        for (; b + 48 < blocks; b += 64) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) p[u] += partial_cs[(size_t)(b + 16 * u) * 65 + c];
-        }
-        for (; b < blocks; b += 16) p[0] += partial_cs[(size_t)b * 65 + c];
-      }
-      __syncthreads();
-      red[w][lane] = (p[0] + p[1]) + (p[2] + p[3]);
-      __syncthreads();
-      if (w == 0 && c < 65) {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t += red[i][lane];
-        if (c < out_dim) gb_actor[c] = t;
-        if (c == 64) gb_critic[0] = t;
-      }
-    }
-  }
   if (tid == 0 && (part & 1)) {  // the policy half owns these (its stream is the one the moments were pooled on)
     const double mean = moments[0] / Nn;
     const double varu = Nn > 1 ? (moments[1] - Nn * mean * mean) / (Nn - 1.0) : 0.0;
@@ -703,20 +708,29 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const double* parti
   }
 }
 
-int loss_blocks(int64_t N) { return (int)((N + 16 * LOSS_PASSES - 1) / (16 * LOSS_PASSES)); }
+int loss_blocks(int64_t N) { return (int)((N + LOSS_THREADS - 1) / LOSS_THREADS); }
 
 template <class P>
 void launch_ppo_loss(const LossArgs& a, hipStream_t s) {
   if (a.N <= 0) return;
   const size_t lds = (size_t)(2 * a.pcfg.ft_denoising_steps + 2) * sizeof(float);
   const int blocks = loss_blocks(a.N);
-  hipLaunchKernelGGL((ppo_loss_kernel<P>), dim3(blocks), dim3(256), lds, s, a);
+  const int rh = a.pcfg.reward_horizon < a.pcfg.horizon_steps ? a.pcfg.reward_horizon : a.pcfg.horizon_steps;
+  const int cnt = rh * a.pcfg.action_dim;
+  constexpr int EPC = 16 / P::ESIZE;
+  const bool regs = (a.part & 1) && a.ldde % EPC == 0;  // the register variants store whole chunks
+  if (regs && cnt <= 16)
+    hipLaunchKernelGGL((ppo_loss_kernel<P, 16>), dim3(blocks), dim3(LOSS_THREADS), lds, s, a);
+  else if (regs && cnt <= 32)
+    hipLaunchKernelGGL((ppo_loss_kernel<P, 32>), dim3(blocks), dim3(LOSS_THREADS), lds, s, a);
+  else
+    hipLaunchKernelGGL((ppo_loss_kernel<P, 0>), dim3(blocks), dim3(LOSS_THREADS), lds, s, a);
 }
 // the statistics (and nothing the backward pass reads): any stream ordered after the loss kernel will do
 void launch_loss_finalize(const LossArgs& a, hipStream_t s) {
   if (a.N <= 0) return;
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, s, a.partial, loss_blocks(a.N), a.moments, a.stats,
-                     a.partial_cs, a.gb_actor, a.out_dim, a.gb_critic, a.part, a.n_count);
+                     a.part, a.n_count);
 }
 template void launch_ppo_loss<F32>(const LossArgs&, hipStream_t);
 template void launch_ppo_loss<BF16>(const LossArgs&, hipStream_t);
