@@ -96,8 +96,9 @@ static ParamLayout param_layout(const dppo_net_desc& d) {
 struct PackLayout {  // byte offsets into the packed image
   // every offset depends on (net, prec) only; the time table sits last so that only `total` grows with n_time
   size_t W0, W1[MAX_BLOCKS], W2[MAX_BLOCKS], Wout, W1T[MAX_BLOCKS], W2T[MAX_BLOCKS], WoutT, W0tT, sstream, ostream,
-      bstream, wcomp, ostream2, cbias, Wc1, Wc2, Wc2T, W0eT, temb, total;
+      bstream, wcomp, ostream2, cbias, w0comp, ostream0, cbias2, Wc1, Wc2, Wc2T, W0eT, temb, total;
   int Kp0, Kpo, tdp;
+  int Kp0s, CNT0;  // one-block networks: padded K of the first-layer composite Wout . W0 and its out-stream k-steps per wave
   int Kpc, C1p, Ep;  // cond_mlp: padded K of the encoder layers (cond, hidden) and padded encoder width
 };
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -131,6 +132,12 @@ static PackLayout pack_layout(const dppo_net_desc& d, int n_time) {
     // merged out layer (inference): out = Wout . h_in + (Wout . W2) . act(z1) + cbias, cbias = bout + Wout . b2
     L.ostream2 = o, o = al256(o + (size_t)SAMPLER_WAVES * g.out_frags_per_wave * 64 * 16);
     L.cbias = o, o = al256(o + (size_t)round_up(d.out_dim, 16) * 4);
+    if (d.n_blocks == 1) {  // the fused forward's merged out layer (FusedFwdArgs::merge_top)
+      L.Kp0s = g.Kp0, L.CNT0 = (g.KS0 + SAMPLER_WAVES - 1) / SAMPLER_WAVES;
+      L.w0comp = o, o = al256(o + (size_t)d.out_dim * L.Kp0s * 4);
+      L.ostream0 = o, o = al256(o + (size_t)SAMPLER_WAVES * L.CNT0 * g.OT * 64 * 16);
+      L.cbias2 = o, o = al256(o + (size_t)round_up(d.out_dim, 16) * 4);
+    }
   }
   L.Kpc = round_up(d.cond_dim > 0 ? d.cond_dim : 1, 64);
   if (d.cond_hidden > 0) {  // observation encoder: row-major GEMM operands (small), W2^T and the encoder columns of W0
@@ -271,8 +278,13 @@ static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char*
         float* wc = (float*)(pk + L.wcomp);
         ComposeJobs cq;
         cq.n = 1;
-        cq.j[0] = ComposeJob{prm + pl.Wout, prm + pl.l2w[b], prm + pl.l2b[b], prm + pl.bout, wc, (float*)(pk + L.cbias), H,
-                             d.out_dim};
+        memset(&cq.j[0], 0, sizeof(cq.j[0]));
+        cq.j[0].Wout = prm + pl.Wout, cq.j[0].W2 = prm + pl.l2w[b], cq.j[0].b2 = prm + pl.l2b[b], cq.j[0].bout = prm + pl.bout;
+        cq.j[0].Wc = wc, cq.j[0].cbias = (float*)(pk + L.cbias), cq.j[0].H = H, cq.j[0].out_dim = d.out_dim;
+        if (d.n_blocks == 1) {
+          cq.j[0].W0 = prm + pl.W0, cq.j[0].b0 = prm + pl.b0, cq.j[0].W0c = (float*)(pk + L.w0comp);
+          cq.j[0].cbias2 = (float*)(pk + L.cbias2), cq.j[0].in_dim = d.in_dim, cq.j[0].Kp0s = L.Kp0s;
+        }
         if (one_launch && defer_cj != nullptr)
           *defer_cj = cq.j[0];
         else
@@ -293,6 +305,8 @@ static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char*
       pn.Wout = prm + pl.Wout, pn.out_dim = d.out_dim, pn.H = H, pn.OT = g.OT, pn.CNT = g.CNT;
       pn.ostream = (u32x4*)(pk + L.ostream);
       if (d.n_blocks >= 1) pn.Wc = (const float*)(pk + L.wcomp), pn.ostream2 = (u32x4*)(pk + L.ostream2);
+      if (d.n_blocks == 1)
+        pn.W0c = (const float*)(pk + L.w0comp), pn.ostream0 = (u32x4*)(pk + L.ostream0), pn.Kp0s = L.Kp0s, pn.CNT0 = L.CNT0;
       if (d.kind == 0) {
         pn.te_w1 = prm + pl.te1_w, pn.te_b1 = prm + pl.te1_b, pn.te_w2 = prm + pl.te2_w, pn.te_b2 = prm + pl.te2_b;
         pn.td = d.time_dim, pn.n_time = n_time, pn.temb = (float*)(pk + L.temb);
@@ -310,6 +324,8 @@ static int pack_impl(const dppo_net_desc& d, int n_time, const float* prm, char*
       launch_pack_out<P>(prm + pl.Wout, d.out_dim, H, g.OT, g.CNT, (u32x4*)(pk + L.ostream), s);
       if (d.n_blocks >= 1)
         launch_pack_out<P>((const float*)(pk + L.wcomp), d.out_dim, H, g.OT, g.CNT, (u32x4*)(pk + L.ostream2), s);
+      if (d.n_blocks == 1)
+        launch_pack_out<P>((const float*)(pk + L.w0comp), d.out_dim, L.Kp0s, g.OT, L.CNT0, (u32x4*)(pk + L.ostream0), s);
     }
   }
   return check_launch();
@@ -369,6 +385,8 @@ struct MlpBufs {  // activations of one network for M rows
   int join_idx[2], n_join;
   float* part;  // column-sum / segment-sum partials
   float* lowrank;  // [out_dim][H] T = d_out^T . act(z1) of the top block (see lowrank_dw_kernel)
+  float* lowrank_u;  // [out_dim][Kp0] U = d_out^T . x (merged-top networks: dWout is rebuilt from U and T, see PostReduce)
+  bool merged;       // this network's forward ran merged (fused_can_merge): h_nb was never stored
   bool post_zeroed;      // the caller's row builder zeroed post_counter in this call
   double* post_counter;  // 8 zeroed bytes: arrival counter of post_reduce_kernel (zeroed by the row builder, left zero)
   size_t slab_floats, part_floats;
@@ -438,6 +456,7 @@ static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, b
     B.part_floats = (size_t)REDUCE_BLOCKS * (H > 1024 ? H : 1024);
     B.part = (float*)c.take(B.part_floats * 4);
     B.lowrank = (float*)c.take((size_t)round_up(d.out_dim, 16) * H * 4);
+    B.lowrank_u = (float*)c.take((size_t)round_up(d.out_dim, 16) * Kp0 * 4);
     B.post_counter = (double*)c.take(8);
     B.post_zeroed = false;
     B.w0T = c.take((size_t)round_up(d.cond_dim > 0 ? d.cond_dim : 1, 16) * H * ES);
@@ -497,6 +516,12 @@ static void mlp_forward(const dppo_net_desc& d, const float* prm, const char* pk
       }
       f.hpre[nb] = B.hE;
       f.ln_stats = d.use_layernorm ? B.ln_stats : nullptr;
+    }
+    B.merged = fused_can_merge<P>(d);
+    if (B.merged) {  // the block's second layer folded into the out layer: h_nb is never formed (fused_forward_merged_kernel)
+      f.merge_top = 1, f.ks0v = (d.in_dim + P::KB - 1) / P::KB, f.hpre[nb] = nullptr;
+      f.ostream0 = (const u32x4*)(pk + L.ostream0), f.ostream2 = (const u32x4*)(pk + L.ostream2);
+      f.cbias2 = (const float*)(pk + L.cbias2);
     }
     g_fused_fault = launch_fused_forward<P>(d, f, s);
     return;
@@ -806,11 +831,17 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       launch_reduce_slots(B.tile_colsum, B.tiles, H, so, aux);
       const int oh = d.kind == 0 ? temb_onehot_col<P>(d, L, Kft, B) : -1;  // must match what the row builder was told
       if (d.kind == 0 && oh < 0) time_embedding_grad<P>(d, prm, pk, L, M, B, B.dh_all[0], grad, krow, ksteps, Kft, aux);
-      weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.hE, H, H, M, B, grad + pl.Wout, H, s, true);
+      // merged top (the forward never formed h_nb): dWout = d_out^T . h_nb is rebuilt behind the slab reduce from
+      // U = d_out^T . x and T = d_out^T . act(z1) (PostReduce::U); T is then needed whether or not dW2 uses it
+      const bool merged = B.merged;
+      if (merged)
+        weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.in, L.Kp0, d.in_dim, M, B, B.lowrank_u, L.Kp0, s, true);
+      else
+        weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.hE, H, H, M, B, grad + pl.Wout, H, s, true);
       for (int b = nb - 1; b >= 0; --b) {
-        if (lowrank && b == nb - 1)  // T = d_out^T . act(z1), [out_dim][H]; dW2 = Wout^T . T after the slab reduce
+        if ((lowrank || merged) && b == nb - 1)  // T = d_out^T . act(z1), [out_dim][H]; dW2 = Wout^T . T after the slab reduce
           weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.a2[b], H, H, M, B, B.lowrank, H, s, true);
-        else
+        if (!(lowrank && b == nb - 1))
           weight_grad<P>(B.dh_all[b + 1], H, H, B.a2[b], H, H, M, B, grad + pl.l2w[b], H, s, true);
         weight_grad<P>(B.dz1_all[b], H, H, B.a1[b], H, H, M, B, grad + pl.l1w[b], H, s, true);
       }
@@ -822,11 +853,15 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       if (aux != s && g_early_join) B.join_s[B.n_join] = aux, B.join_idx[B.n_join++] = aux_idx;
       flush_slabs(B, s);  // every slab of this backward in one reduction launch
       if (aux != s && !g_early_join) join_side(s, aux, aux_idx);
+      PostReduce q;
+      memset(&q, 0, sizeof(q));
+      q.H = H, q.out_dim = d.out_dim, q.T = B.lowrank;
+      if (merged) {  // (cs = column sums of d_out = the out-layer bias gradient, reduced on the aux stream joined above)
+        q.U = B.lowrank_u, q.ldu = L.Kp0, q.in_dim = d.in_dim, q.W0 = prm + pl.W0, q.ldw0 = d.in_dim, q.W2 = prm + pl.l2w[nb - 1];
+        q.b0 = prm + pl.b0, q.b2 = prm + pl.l2b[nb - 1], q.cs = grad + pl.bout, q.dWout = grad + pl.Wout;
+      }
       if (g_post_one && B.post_zeroed && (lowrank || oh >= 0)) {  // both in one launch (knob 18)
-        PostReduce q;
-        memset(&q, 0, sizeof(q));
-        q.H = H;
-        if (lowrank) q.Wout = prm + pl.Wout, q.T = B.lowrank, q.dW = grad + pl.l2w[nb - 1], q.out_dim = d.out_dim;
+        if (lowrank) q.Wout = prm + pl.Wout, q.dW = grad + pl.l2w[nb - 1];
         if (oh >= 0) {
           q.S = B.part, q.W0 = prm + pl.W0, q.ldw0 = d.in_dim, q.AF = d.act_flat, q.Kft = Kft, q.td = d.time_dim;
           q.G = B.part + (size_t)H * Kft, q.w1 = prm + pl.te1_w, q.b1 = prm + pl.te1_b, q.w2 = prm + pl.te2_w;
@@ -836,6 +871,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
         q.counter = (unsigned*)B.post_counter;
         launch_post_reduce(q, s);
       } else {
+        if (merged) launch_wout_grad(q, s);
         if (lowrank) launch_lowrank_dw(prm + pl.Wout, B.lowrank, d.out_dim, H, grad + pl.l2w[nb - 1], s);
         if (oh >= 0)
           launch_time_backward_from_sums(prm + pl.te1_w, prm + pl.te1_b, prm + pl.te2_w, B.part, prm + pl.W0, d.in_dim,
@@ -2325,6 +2361,10 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 18) {
     g_post_one = value;
+    return 0;
+  }
+  if (knob == 22) {  // fused forward of one-block networks: second layer merged into the out layer (1, default) or not (0);
+    set_fused_merge_fwd(value);  // takes effect at the next pack (the images of both forms are always packed)
     return 0;
   }
   if (knob == 21) {  // gemm_nt: small tiles for small problems (1, default) or the 128 x 128 / 64 x 128 / 16 x 256 shapes only (0)

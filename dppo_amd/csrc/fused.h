@@ -45,6 +45,12 @@ struct FusedFwdArgs {
   void* hpre[MAX_BLOCKS + 1];  // elem(h_b)     (needed for Mish'; hpre[nb] = hE is always the out-layer input)
   float* out;  // [M][ldout]
   int ldout;
+  // merged top (one-block networks, fused_can_merge()): the block's second layer is folded into the out layer --
+  // out = (Wout W0) x + (Wout W2) act(z1) + cbias2; hpre[nb] is then neither formed nor stored (fused_forward_merged_kernel)
+  int merge_top, ks0v;      // ks0v: k-steps of the input that hold data, ceil(in_dim / KB)
+  const u32x4* ostream0;    // fragments of Wout W0, [ks][to][lane]
+  const u32x4* ostream2;    // fragments of Wout W2, [ks][to][lane]
+  const float* cbias2;      // [out_dim] bout + Wout (b0 + b2)
 };
 
 struct FusedBwdArgs {
@@ -79,6 +85,9 @@ int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStrea
 template <class P>
 int launch_fused_backward(const dppo_net_desc& d, const FusedBwdArgs& a, hipStream_t s);
 void set_fused_short_tiles(int v);  // tuning knob 7
+void set_fused_merge_fwd(int v);    // tuning knob 22
+template <class P>
+bool fused_can_merge(const dppo_net_desc& d);  // the forward of this network runs merged (and the backward must rebuild dWout)
 template <class P>
 int fused_rows_per_tile(const dppo_net_desc& d);  // rows per tile of the BACKWARD kernel (sizes the per-tile column sums), 0 if not covered
 

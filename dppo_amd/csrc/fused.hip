@@ -483,6 +483,138 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_forward_kernel(const Fused
 }
 
 // =================================================================================================
+// forward, one-block networks: the block's second layer merged into the out layer
+// =================================================================================================
+// h_1 = h_0 + W2 act(z1) + b2 feeds the out layer only, and h_0 = W0 x + b0 is linear in the input rows, so
+//     out = Wout h_1 + bout = (Wout W0) x + (Wout W2) act(z1) + [bout + Wout (b0 + b2)]
+// (exact in real arithmetic; in bf16 one rounding of two composite weights instead of a rounding of the 512-wide h_1).
+// The H x H layer W2 -- half of the tile's weight stream, which is what paces the k-loops (64 B/clk of L1 fill per CU) --
+// is never run, h_1 is never formed or stored, and the out layer costs what it did: its K = H pass now reads act(z1)
+// with the fragments of Wout W2 (the sampler's ostream2), and the K = in_dim pass on the input tile is 2-3 k-steps.
+// The weight-gradient side (api.hip, mlp_backward): dWout = d_out^T h_1 is rebuilt from U = d_out^T x and T = d_out^T act(z1).
+template <class P, int TPW, int MR, int OT, int ACT>
+__global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const FusedFwdArgs a) {
+  constexpr int PD = ring_depth<TPW, MR>(), ES = P::ESIZE, KB = P::KB;
+  constexpr int H = 128 * TPW, KSH = H / KB, HRB = H * ES, MT = 16 * MR;
+  constexpr int KSPLIT = MR * OT >= 8 ? 1 : 8 / (MR * OT);
+  constexpr int KPER = KSH / KSPLIT, NITEMS = MR * OT * KSPLIT, NI = (NITEMS + SAMPLER_WAVES - 1) / SAMPLER_WAVES;
+  constexpr bool FLAGS = DPPO_FLAGS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int Kp0 = a.Kp0, M = a.M, ks0v = a.ks0v;
+  const int in_rb = Kp0 * ES, in_km = kmask16(in_rb), KS0 = Kp0 / KB;
+  const int total = KS0 + 2 * KSH;  // the stream as packed (W2 last); the ring walks total - KSH positions
+  char* bufA = smem;
+  char* bufB = bufA + MT * HRB;
+  char* xin = bufB;             // the input tile is dead once layer 0 and the out layer's first pass have run
+  float* part = (float*)bufA;   // out-layer partials: the K = H pass reads buffer B
+  static_assert(KSPLIT * OT * 16 * 16 * 4 <= 16 * HRB, "out-layer partials must fit in buffer A");
+  volatile uint32_t* flags = (volatile uint32_t*)(bufB + MT * HRB);  // [16 words]
+  float* biasL = (float*)(bufB + MT * HRB + 64);                       // [2][H] b0, b1, then [OT*16] the out constant
+  u32x4* woutL = (u32x4*)(biasL + ((2 * H + OT * 16 + 3) & ~3));       // [KSH][OT][64] fragments of Wout W2
+  u32x4* w0cL = woutL + KSH * OT * 64;                                 // [ks0v][OT][64] fragments of Wout W0
+  const int wbase = wid * 16 * TPW;
+  for (int idx = tid; idx < 2 * H; idx += 512) biasL[idx] = a.params[a.bias_off[idx / H] + idx % H];
+  for (int idx = tid; idx < OT * 16; idx += 512) biasL[2 * H + idx] = idx < a.out_dim ? a.cbias2[idx] : 0.f;
+  for (int idx = tid; idx < KSH * OT * 64; idx += 512) woutL[idx] = a.ostream2[idx];
+  for (int idx = tid; idx < ks0v * OT * 64; idx += 512) w0cL[idx] = a.ostream0[idx];
+  if (tid < 16) flags[tid] = 0;
+  uint32_t seq = 0;
+  // (visible after the first tile's barrier)
+
+  Engine<P, TPW, MR, PD> eng;
+  eng.prime(a.wstream + (size_t)wid * total * TPW * 64 + lane, total - KSH);
+
+  const int ntiles = (M + MT - 1) / MT;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row0 = tile * MT;
+    STAMP(0);
+    load_tile<MT>(xin, in_rb, in_km, (const char*)a.in, a.ld_in * ES, row0, M);
+    __syncthreads();
+    STAMP(1);
+    f32x4 acc[TPW][MR];
+    auto bias_init = [&](int layer) {
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp) {
+        const f32x4 b = *(const f32x4*)(biasL + layer * H + wbase + feat_off<P>(g, tp));
+#pragma unroll
+        for (int m = 0; m < MR; ++m) acc[tp][m] = b;
+      }
+    };
+    // ---- layer 0, and the out layer's first pass on the same input tile: work item it = (row sub-tile m, out tile to,
+    // K slice kh) belongs to wave it % 8 in both passes, so the partial result waits in registers
+    bias_init(0);
+    eng.run(acc, xin, in_rb, in_km, KS0, r, g);
+    STAMP(2);
+    f32x4 o1[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int it = wid + SAMPLER_WAVES * i;
+      o1[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (it < MR * OT) {  // kh == 0
+        const int m = it % MR, to = it / MR;
+        for (int ks = 0; ks < ks0v; ++ks) {
+          const u32x4 xb = *(const u32x4*)(xin + (16 * m + r) * in_rb + (((ks * 4 + g) ^ (r & in_km)) << 4));
+          o1[i] = P::mma(w0cL[(ks * OT + to) * 64 + lane], xb, o1[i]);
+        }
+      }
+    }
+    emit<P, TPW, MR>(acc, ACT, bufA, a.a1[0], H, wbase, g, r, row0, M, a.hpre[0]);  // hpre[0] <- act'(h_0) (Mish) / sign words
+    STAMP(3);
+    if constexpr (FLAGS)
+      hand_over(flags, wid, lane, ++seq);
+    else
+      __syncthreads();
+    STAMP(4);
+    // ---- the block's first layer
+    bias_init(1);
+    eng.run(acc, bufA, HRB, 15, KSH, r, g, FLAGS ? flags : nullptr, seq);
+    STAMP(5);
+    emit<P, TPW, MR>(acc, ACT, bufB, a.a2[0], H, wbase, g, r, row0, M, a.z1[0]);  // z1[0] <- act'(z1) (Mish) / sign words
+    STAMP(6);
+    __syncthreads();  // the out layer's work items read every wave's features
+    STAMP(7);
+    // ---- out layer, second pass: (Wout W2) on act(z1)
+    int r_ = r, g_ = g, lane_ = lane;
+    asm volatile("" : "+v"(r_), "+v"(g_), "+v"(lane_));  // (see fused_forward_kernel: addresses recomputed, not spilled)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int it = wid + SAMPLER_WAVES * i;
+      if (it < NITEMS) {
+        const int m = it % MR, to = (it / MR) % OT, kh = it / (MR * OT);
+        f32x4 oacc = o1[i];
+#pragma unroll 8
+        for (int c = 0; c < KPER; ++c) {
+          const int ks = kh * KPER + c;
+          const u32x4 xb = *(const u32x4*)(bufB + (16 * m + r_) * HRB + (((ks * 4 + g_) ^ (r_ & 15)) << 4));
+          oacc = P::mma(woutL[(ks * OT + to) * 64 + lane_], xb, oacc);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[(((kh * MR + m) * OT + to) * 16 + 4 * g_ + e) * 16 + r_] = oacc[e];
+      }
+    }
+    STAMP(11);
+    __syncthreads();
+    STAMP(12);
+    int tid_ = tid;
+    asm volatile("" : "+v"(tid_));
+    for (int idx = tid_; idx < MT * a.out_dim; idx += 512) {
+      const int row = idx / a.out_dim, j = idx - row * a.out_dim;
+      const int m = row >> 4, rr = row & 15, to = j >> 4, jj = j & 15;
+      float s = biasL[2 * H + j];
+#pragma unroll
+      for (int kh = 0; kh < KSPLIT; ++kh) s += part[(((kh * MR + m) * OT + to) * 16 + jj) * 16 + rr];
+      if (row0 + row < M) a.out[(size_t)(row0 + row) * a.ldout + j] = s;
+    }
+    STAMP(13);
+    __syncthreads();  // the next tile's input lands in buffer B; its layer-0 emit in buffer A, where the partials were read
+    STAMP(14);
+  }
+}
+
+// =================================================================================================
 // backward (data gradients + column sums)
 // =================================================================================================
 template <class P, int TPW, int MR, bool LN, int ACT, int OCC>
@@ -797,12 +929,57 @@ static int launch_fwd_cfg(const FusedFwdArgs& a, hipStream_t s) {
   return 0;
 }
 
+// merged-top forward (fused_forward_merged_kernel): its LDS need; everything it stages must fit, or there is no merge
+template <class P>
+static size_t merged_lds(int hidden, int out_tiles, int ks0v) {
+  const int mr = pick_mr<P>(hidden);
+  return 2 * (size_t)16 * mr * hidden * P::ESIZE + 64 + (((size_t)2 * hidden + out_tiles * 16 + 3) & ~(size_t)3) * 4 +
+         ((size_t)(hidden / P::KB) + ks0v) * out_tiles * 64 * 16;
+}
+static int g_merge_fwd = 1;  // tuning knob 22: the fused forward of one-block networks merges the block's second layer into the out layer
+void set_fused_merge_fwd(int v) { g_merge_fwd = v; }
+template <class P>
+bool fused_can_merge(const dppo_net_desc& d) {
+  if (!g_merge_fwd || d.plain || d.use_layernorm || d.n_blocks != 1 || d.hidden % 128 || pick_mr<P>(d.hidden) == 0) return false;
+  if (d.out_dim > 16) return false;  // one out tile: wider heads do not fit their two fragment sets beside the images
+  const int ks0v = (d.in_dim + P::KB - 1) / P::KB;
+  return d.hidden <= 512 && merged_lds<P>(d.hidden, 1, ks0v) <= 160 * 1024;
+}
+template bool fused_can_merge<F32>(const dppo_net_desc&);
+template bool fused_can_merge<BF16>(const dppo_net_desc&);
+
+template <class P, int TPW, int MR, int ACT>
+static int launch_fwd_merged_cfg(const FusedFwdArgs& a, hipStream_t s) {
+  constexpr int MT = 16 * MR, H = 128 * TPW;
+  const size_t lds = merged_lds<P>(H, 1, a.ks0v);
+  if (lds > 160 * 1024 || a.Kp0 > H || a.nb != 1) return -2;
+  static DevLatch attr;
+  raise_lds(fused_forward_merged_kernel<P, TPW, MR, 1, ACT>, attr);
+  const int ntiles = (a.M + MT - 1) / MT;
+  const bool probe = probe_begin(PROBE_FUSED_FWD, s);
+  hipLaunchKernelGGL((fused_forward_merged_kernel<P, TPW, MR, 1, ACT>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512),
+                     lds, s, a);
+  if (probe) probe_end(s, 2.0 * a.M * ((double)a.in_valid * H + 2.0 * a.nb * H * H + (double)H * a.out_dim));
+  return 0;
+}
+
 template <class P>
 int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStream_t s) {
   const int tpw = d.hidden / 128, mr = pick_mr<P>(d.hidden);
   const int nt = (d.out_dim + 15) / 16, ot = nt <= 1 ? 1 : (nt <= 4 ? 4 : (nt <= 8 ? 8 : 0));
   if (mr == 0 || ot == 0 || a.M <= 0) return -1;
   const bool relu = a.act == ACT_RELU;  // check_net admits ReLU and Mish only
+  if (a.merge_top) {  // (the caller asked fused_can_merge() first)
+#define DPPO_FWDM(T, R) \
+  if (tpw == T && mr == R) return relu ? launch_fwd_merged_cfg<P, T, R, ACT_RELU>(a, s) : launch_fwd_merged_cfg<P, T, R, ACT_MISH>(a, s);
+    if constexpr (P::ESIZE == 2) {
+      DPPO_FWDM(2, 8) DPPO_FWDM(4, 4)
+    } else {
+      DPPO_FWDM(2, 4) DPPO_FWDM(4, 2)
+    }
+#undef DPPO_FWDM
+    return -1;
+  }
   if constexpr (P::ESIZE == 2) {
     if (short_tiles<P>(d.hidden, a.use_ln, 1) && ot == 1)
       return relu ? launch_fwd_cfg<P, 4, 2, 1, false, ACT_RELU, 2>(a, s) : launch_fwd_cfg<P, 4, 2, 1, false, ACT_MISH, 2>(a, s);

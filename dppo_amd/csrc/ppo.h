@@ -208,6 +208,9 @@ struct PackNet {
   u32x4* ostream;
   const float* Wc;  // non-null: fp32 [out_dim][H] composite Wout . W2 of the top block -> ostream2 (same layout as ostream)
   u32x4* ostream2;
+  const float* W0c;  // non-null: fp32 [out_dim][Kp0s] composite Wout . W0 -> ostream0, [ks][to][lane] for ks < 8 * CNT0
+  u32x4* ostream0;
+  int Kp0s, CNT0;
   const float *te_w1, *te_b1, *te_w2, *te_b2;  // n_time = 0: no table
   int td, n_time;
   float* temb;
@@ -251,6 +254,12 @@ struct ComposeJob {
   const float *Wout, *W2, *b2, *bout;
   float *Wc, *cbias;
   int H, out_dim;
+  // one-block networks, the fused forward's merged out layer (see FusedFwdArgs::merge_top): h_0 = W0 x + b0 is linear in
+  // the input, so Wout . h_1 = (Wout . W0) x + (Wout . W2) act(z1) + Wout (b0 + b2).  W0c: fp32 [out_dim][Kp0s], columns
+  // >= in_dim zero; cbias2 = bout + Wout (b0 + b2).  W0 == null: not wanted.
+  const float *W0, *b0;
+  float *W0c, *cbias2;
+  int in_dim, Kp0s;
 };
 struct ComposeJobs {
   ComposeJob j[2];
@@ -268,8 +277,14 @@ struct PostReduce {  // see post_reduce_kernel; dW == null: no low-rank part; G 
   const dppo_step* ksteps;
   float *gw1, *gb1, *gw2, *gb2;
   unsigned* counter;  // zero on entry; left zero
-  int n_lowrank, n_temb;  // set by the launcher
+  // merged top (U != null): dWout[o][h] = sum_c U[o][c] W0[h][c] + sum_j T[o][j] W2[h][j] + cs[o] (b0[h] + b2[h]), the
+  // out-layer weight gradient d_out^T . h_1 without h_1 (U = d_out^T . x, [out_dim][ldu]; cs = column sums of d_out)
+  const float *U, *W2, *b0, *b2, *cs;
+  float* dWout;
+  int ldu, in_dim;
+  int n_lowrank, n_temb, n_wout;  // set by the launcher
 };
+void launch_wout_grad(const PostReduce& q, hipStream_t s);  // the merged-top part alone (no arrival counter needed)
 void launch_post_reduce(PostReduce& q, hipStream_t s);
 size_t time_backward_lds_bytes(int Kft, int td);  // LDS of the time MLP's backward block: must stay <= 156 KB
 void launch_lowrank_dw(const float* Wout, const float* T, int out_dim, int H, float* dW, hipStream_t s);

@@ -101,6 +101,14 @@ __device__ __forceinline__ void pack_net_block(const PackNet& n, int b, float* s
     }
     b -= n_out;
   }
+  if (n.W0c != nullptr) {  // the fused forward's merged out layer, first half: (Wout . W0) on the input rows
+    const int n_out0 = SAMPLER_WAVES * n.CNT0 * n.OT;
+    if (b < n_out0) {
+      pack_out_block<P>(n.W0c, n.out_dim, n.Kp0s, n.OT, n.CNT0, n.ostream0, b);
+      return;
+    }
+    b -= n_out0;
+  }
   if (b < n.n_time) {
     time_table_block(n.te_w1, n.te_b1, n.te_w2, n.te_b2, n.td, n.temb, b, sh);
     return;
@@ -114,7 +122,8 @@ __device__ __forceinline__ void pack_net_block(const PackNet& n, int b, float* s
 }
 static size_t pack_net_blocks(const PackNet& n) {
   const size_t tblocks = ((size_t)n.t_cols * n.t_ldd + 63) / 64;
-  return (size_t)n.ps_x * n.ps.n_layers + (size_t)SAMPLER_WAVES * n.CNT * n.OT * (n.Wc ? 2 : 1) + n.n_time + tblocks;
+  return (size_t)n.ps_x * n.ps.n_layers + (size_t)SAMPLER_WAVES * n.CNT * n.OT * (n.Wc ? 2 : 1) +
+         (n.W0c ? (size_t)SAMPLER_WAVES * n.CNT0 * n.OT : 0) + n.n_time + tblocks;
 }
 template <class P>
 __global__ __launch_bounds__(64) void pack_net_kernel(const PackNet n) {
@@ -846,10 +855,31 @@ __global__ __launch_bounds__(256) void time_backward_kernel(const float* w1, con
 // Everything that follows the slab reduction of a backward pass, in ONE launch: the low-rank dW2 (lowrank_dw_kernel's
 // body), G = W0_temb^T . S (temb_from_sums_kernel's, one wave per output) and, in the block that finishes G last, the
 // time MLP's backward -- three dependent-looking launches of 5-17 us that only shared the slab reduction as an input.
+// dWout[o][h] of a merged-top network (see PostReduce::U): one wave per output, lanes over the contraction
+__device__ __forceinline__ void wout_grad_block(const PostReduce& q, int b) {
+  const int lane = threadIdx.x & 63, out = b * 4 + (threadIdx.x >> 6);
+  if (out >= q.out_dim * q.H) return;
+  const int o = out / q.H, h = out - o * q.H;
+  float acc = 0.f;
+  for (int j = lane; j < q.H; j += 64) acc += q.T[(size_t)o * q.H + j] * q.W2[(size_t)h * q.H + j];
+  for (int c = lane; c < q.in_dim; c += 64) acc += q.U[(size_t)o * q.ldu + c] * q.W0[(size_t)h * q.ldw0 + c];
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d);
+  if (lane == 0) q.dWout[out] = acc + q.cs[o] * (q.b0[h] + q.b2[h]);
+}
+__global__ __launch_bounds__(256) void wout_grad_kernel(const PostReduce q) { wout_grad_block(q, blockIdx.x); }
+void launch_wout_grad(const PostReduce& q, hipStream_t s) {
+  const int blocks = (q.out_dim * q.H + 3) / 4;
+  if (q.U != nullptr && blocks > 0) hipLaunchKernelGGL(wout_grad_kernel, dim3(blocks), dim3(256), 0, s, q);
+}
+
 __global__ __launch_bounds__(256) void post_reduce_kernel(const PostReduce q) {
   extern __shared__ float sh[];
   __shared__ bool last;
   const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= q.n_lowrank + q.n_temb) {
+    wout_grad_block(q, blockIdx.x - q.n_lowrank - q.n_temb);
+    return;
+  }
   if ((int)blockIdx.x < q.n_lowrank) {
     const size_t idx = (size_t)blockIdx.x * 256 + tid;
     if (idx >= (size_t)q.H * q.H) return;
@@ -881,7 +911,8 @@ __global__ __launch_bounds__(256) void post_reduce_kernel(const PostReduce q) {
 void launch_post_reduce(PostReduce& q, hipStream_t s) {
   q.n_lowrank = q.dW != nullptr ? (int)(((size_t)q.H * q.H + 255) / 256) : 0;
   q.n_temb = q.G != nullptr ? (q.Kft * q.td + 3) / 4 : 0;
-  const int blocks = q.n_lowrank + q.n_temb;
+  q.n_wout = q.U != nullptr ? (q.out_dim * q.H + 3) / 4 : 0;
+  const int blocks = q.n_lowrank + q.n_temb + q.n_wout;
   static DevLatch raised;
   if (raised.need()) raise_dyn_lds(post_reduce_kernel), raised.done();
   if (blocks > 0)
@@ -1095,47 +1126,60 @@ __global__ __launch_bounds__(1024) void compose_wc_kernel(const ComposeJobs q) {
   const float *Wout = jb.Wout, *W2 = jb.W2, *b2 = jb.b2, *bout = jb.bout;
   float *Wc = jb.Wc, *cbias = jb.cbias;
   const int H = jb.H, cols = (H + 63) / 64;
-  if ((int)blockIdx.y >= jb.out_dim || (int)blockIdx.x > cols) return;  // the grid is sized for the larger network
+  const int cols0 = jb.W0 != nullptr ? (jb.Kp0s + 63) / 64 : 0;
+  if ((int)blockIdx.y >= jb.out_dim || (int)blockIdx.x > cols + cols0) return;  // the grid is sized for the larger network
   const int o = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if ((int)blockIdx.x == cols) {  // extra column: cbias[o] = bout[o] + Wout[o] . b2 (the merged out layer's constant)
-    float t = 0.f;
-    for (int j = threadIdx.x; j < H; j += 1024) t += Wout[(size_t)o * H + j] * b2[j];
-    for (int d = 32; d > 0; d >>= 1) t += __shfl_down(t, d);
-    if (lane == 0) red[w][0] = t;
+    float t = 0.f, t0 = 0.f;      // and cbias2[o] = cbias[o] + Wout[o] . b0
+    for (int j = threadIdx.x; j < H; j += 1024) {
+      t += Wout[(size_t)o * H + j] * b2[j];
+      if (jb.W0 != nullptr) t0 += Wout[(size_t)o * H + j] * jb.b0[j];
+    }
+    for (int d = 32; d > 0; d >>= 1) t += __shfl_down(t, d), t0 += __shfl_down(t0, d);
+    if (lane == 0) red[w][0] = t, red[w][1] = t0;
     __syncthreads();
     if (threadIdx.x == 0) {
-      float u = bout[o];
-      for (int i = 0; i < 16; ++i) u += red[i][0];
+      float u = bout[o], u0 = 0.f;
+      for (int i = 0; i < 16; ++i) u += red[i][0], u0 += red[i][1];
       cbias[o] = u;
+      if (jb.W0 != nullptr) jb.cbias2[o] = u + u0;
     }
     return;
   }
-  const int k = blockIdx.x * 64 + lane;
+  const bool first = (int)blockIdx.x > cols;  // W0c[o][k] = sum_j Wout[o][j] * W0[j][k] instead (W0 is [H][in_dim])
+  const int k = (first ? (int)blockIdx.x - cols - 1 : (int)blockIdx.x) * 64 + lane;
+  const float* Wr = first ? jb.W0 : W2;
+  const int ldr = first ? jb.in_dim : H, kmax = first ? jb.in_dim : H;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (k < H) {
+  if (k < kmax) {
     int j = w;
     for (; j + 7 * 16 < H; j += 8 * 16) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc[u] += Wout[(size_t)o * H + j + 16 * u] * W2[(size_t)(j + 16 * u) * H + k];
+      for (int u = 0; u < 8; ++u) acc[u] += Wout[(size_t)o * H + j + 16 * u] * Wr[(size_t)(j + 16 * u) * ldr + k];
     }
-    for (; j < H; j += 16) acc[0] += Wout[(size_t)o * H + j] * W2[(size_t)j * H + k];
+    for (; j < H; j += 16) acc[0] += Wout[(size_t)o * H + j] * Wr[(size_t)j * ldr + k];
   }
   red[w][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
-  if (w == 0 && k < H) {
+  if (w == 0) {
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += red[i][lane];
-    Wc[(size_t)o * H + k] = t;
+    if (first) {
+      if (k < jb.Kp0s) jb.W0c[(size_t)o * jb.Kp0s + k] = k < kmax ? t : 0.f;
+    } else if (k < H) {
+      Wc[(size_t)o * H + k] = t;
+    }
   }
 }
 void launch_compose(const ComposeJobs& q, hipStream_t s) {
-  int cols = 0, rows = 0;
+  int gx = 0, rows = 0;
   for (int i = 0; i < q.n; ++i) {
-    cols = q.j[i].H > cols ? q.j[i].H : cols;
+    const int x = (q.j[i].H + 63) / 64 + 1 + (q.j[i].W0 != nullptr ? (q.j[i].Kp0s + 63) / 64 : 0);
+    gx = x > gx ? x : gx;
     rows = q.j[i].out_dim > rows ? q.j[i].out_dim : rows;
   }
-  if (q.n > 0) hipLaunchKernelGGL(compose_wc_kernel, dim3((cols + 63) / 64 + 1, rows, q.n), dim3(1024), 0, s, q);
+  if (q.n > 0) hipLaunchKernelGGL(compose_wc_kernel, dim3(gx, rows, q.n), dim3(1024), 0, s, q);
 }
 
 // dW[i][j] = sum_o Wout[o][i] * T[o][j]: the top block's second-layer weight gradient from T = d_out^T . act(z1).

@@ -591,3 +591,52 @@ def test_fused_path_matches_layered_path(prec, tol, sname):
     assert cos(ga1, ga0) >= lim and cos(gc1, gc0) >= lim
     assert np.linalg.norm(ga1) == pytest.approx(np.linalg.norm(ga0), rel=max(tol * 5, 1e-4))
     assert np.linalg.norm(gc1) == pytest.approx(np.linalg.norm(gc0), rel=max(tol * 5, 1e-4))
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("sname", ["hopper", "can"])
+def test_merged_top_layer_matches_unmerged(prec, tol, sname):
+    """One-block networks run their fused forward with the block's second layer folded into the out layer and rebuild the
+    out-layer weight gradient from d_out^T x and d_out^T act(z1) (tuning knob 22; hopper: actor and critic in bf16, the
+    critic in fp32; can: the critic).  Same log-probs, values, loss statistics and gradients -- the out layer's included,
+    tensor by tensor -- as the kernels that form h_1."""
+    from dppo_amd import hip
+    lib = hip.load()
+    kw = dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01, randn_clip_value=3)
+    m, a, c = build_model(sname, kw, 73, prec)
+    R, N, Kft = 200, 1500, 10
+    AF = a.horizon_steps * a.action_dim
+    out = {}
+    try:
+        for merged in (1, 0):
+            lib.dppo_tune_set(22, merged)
+            for net in (m.actor, m.actor_ft, m.critic):
+                net.mark_updated()
+            gen = torch.Generator(device="cpu").manual_seed(5)
+            obs = (torch.rand(R, 1, a.cond_dim, generator=gen) * 2 - 1).to(DEV)
+            chains = (torch.randn(R, Kft + 1, a.horizon_steps, a.action_dim, generator=gen) * 0.5).to(DEV)
+            logp = m.get_logprobs({"state": obs}, chains).reshape(R, Kft, AF)
+            val = m.critic({"state": obs}).reshape(R)
+            ret = val + torch.randn(R, generator=gen).to(DEV)
+            adv = torch.randn(R, generator=gen).to(DEV)
+            inds = torch.randperm(R * Kft, generator=gen)[:N].to(DEV).contiguous()
+            st = m.ppo_update(obs.reshape(R, -1).contiguous(), chains.reshape(R, Kft + 1, AF).contiguous(), ret, val,
+                              adv, logp + 0.01, inds).cpu().numpy().copy()
+            grads = {}
+            for tag, net in (("a", m.actor_ft), ("c", m.critic)):
+                for (k, _), gv in zip(net.named_parameters(), net.grad_views()):
+                    grads[(tag, k)] = gv.detach().cpu().numpy().copy()
+            out[merged] = (logp.cpu().numpy(), val.cpu().numpy(), st, grads)
+    finally:
+        lib.dppo_tune_set(22, 1)
+        for net in (m.actor, m.actor_ft, m.critic):
+            net.mark_updated()
+    lp1, v1, s1, g1 = out[1]
+    lp0, v0, s0, g0 = out[0]
+    np.testing.assert_allclose(lp1, lp0, rtol=tol * 30, atol=tol * 30)
+    np.testing.assert_allclose(v1, v0, rtol=tol, atol=tol)
+    np.testing.assert_allclose(s1[:5], s0[:5], rtol=max(tol * 50, 1e-4), atol=max(tol * 5, 1e-5))
+    for key in g0:  # every tensor: relative L2 error (fp32 1e-4 class; bf16: the operand rounding)
+        x, y = g1[key].reshape(-1).astype(np.float64), g0[key].reshape(-1).astype(np.float64)
+        err = np.linalg.norm(x - y) / (np.linalg.norm(y) + 1e-30)
+        assert err <= (2e-4 if prec == "fp32" else 6e-2), (key, err)

@@ -424,10 +424,14 @@ def test_hip_vision_gaussian(golden, case):
 @pytest.mark.parametrize("case", ["vmlp_loss", "vunet_loss"])
 def test_hip_vision_ppo_loss_bf16(golden, case):
     """The benchmarked precision of the pixel update against the reference: v_loss within 5e-2 relative, the policy statistics
-    within the bf16 log-ratio error of the state path, gradient cosine per network >= 0.97 for the critic (no clip
-    branches) and >= 0.3 for the actor: at eps_k = 0.001..0.01 the bf16 log-ratio error flips the clip branch of a few samples,
-    and with 16-24 samples in the fixture two flips move the cosine that far (measured 0.44; the state path's N = 50,000 test
-    holds 0.995: tests/test_bf16_parity.py)."""
+    within the bf16 log-ratio error of the state path, gradient cosine >= 0.97 for the critic (no clip branches).
+    The actor's gradient is checked in two parts.  (1) With the clip range opened (eps_k = 1 for every step, so no sample
+    sits on a branch boundary) the bf16 gradient must agree with the fp32 HIP gradient of the same loss -- which
+    test_hip_vision_ppo_loss_and_grads pins tensor by tensor to the reference -- at cosine >= 0.97: that is the bf16 error
+    of the network arithmetic.  (2) At the fixture's own eps_k = 0.001..0.01 the bf16 log-ratio error flips the clip branch
+    of a few samples, and with 16-24 samples in the fixture two flips move the cosine against the reference's gradient a
+    long way (measured 0.44 and 0.27 for two roundings of the same forward; the state path's N = 50,000 test holds 0.995:
+    tests/test_bf16_parity.py), so there only the sign is asserted."""
     g = golden("g17_vision_loss")
     name, N, kw, rh = VIS_LOSS_CASES[case]
     m, v, trunk, cspec = hip_vision_model(name, 31, "bf16", kw)
@@ -449,4 +453,13 @@ def test_hip_vision_ppo_loss_bf16(golden, case):
         return num / (np.sqrt(den_a * den_b) + 1e-30)
 
     assert cos("gcritic", m.critic) > 0.97
-    assert cos("gactor", m.actor_ft) > 0.3
+    assert cos("gactor", m.actor_ft) > 0.0
+    grads = {}
+    for prec in ("fp32", "bf16"):
+        mo, _, _, _ = hip_vision_model(name, 31, prec, dict(kw, clip_ploss_coef=1.0, clip_ploss_coef_base=1.0))
+        r2 = mo.loss(cuda_cond(g, case, u8=True), d("prev"), d("next"), d("kinds"), d("returns"), d("oldvalues"), d("adv"),
+                     d("oldlogprobs"), use_bc_loss=False, reward_horizon=rh)
+        (r2[0] + 0.5 * r2[2]).backward()
+        grads[prec] = torch.cat([p.grad.double().reshape(-1) for p in mo.actor_ft.parameters()])
+    c = float(grads["fp32"] @ grads["bf16"] / (grads["fp32"].norm() * grads["bf16"].norm() + 1e-30))
+    assert c > 0.97, c
