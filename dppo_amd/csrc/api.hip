@@ -394,6 +394,13 @@ struct MlpBufs {  // activations of one network for M rows
 
 constexpr int REDUCE_BLOCKS = 256;
 
+static bool lowrank_top(const dppo_net_desc& d, int64_t M);
+// the one-block backward kernel writes no dh_nb tensor: it needs the low-rank dW2
+template <class P>
+static bool bwd_one(const dppo_net_desc& d, int64_t M) {
+  return fused_bwd_one_block<P>(d) && d.out_dim <= 128 && lowrank_top(d, M);
+}
+
 template <class P>
 static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, bool bwd, MlpBufs<P>& B) {
   const size_t ES = P::ESIZE;
@@ -440,7 +447,7 @@ static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, b
       B.dh_all[b] = c.take((size_t)M * H * ES);
       B.dz1_all[b] = b == 0 ? B.dz1 : c.take((size_t)M * H * ES);
     }
-    const int mt = d.plain || d.out_dim > 128 ? 0 : fused_rows_per_tile<P>(d);
+    const int mt = d.plain || d.out_dim > 128 ? 0 : fused_rows_per_tile<P>(d, bwd_one<P>(d, M));
     B.tiles = mt > 0 ? (int)((M + mt - 1) / mt) : 0;
     B.tile_colsum = (float*)c.take((size_t)(2 * nb + 2 + (d.use_layernorm ? 4 * nb : 0)) * (B.tiles > 0 ? B.tiles : 1) * H * 4);
     const int tdp = round_up(d.time_dim > 0 ? d.time_dim : 1, 16);
@@ -641,6 +648,11 @@ static int g_early_join = 1;       // tuning knob 14: side streams joined right 
 static int g_tn_group = 1;         // tuning knob 12: one launch for all weight-gradient GEMMs of a backward pass
 static int g_tn_target = 256;      // tuning knob 3: workgroups a weight-gradient GEMM aims for (tiles x row splits)
 static int g_tn_max_splits = 128;  // tuning knob 4: cap on its row splits (each split costs one fp32 slab of the output)
+// (the out_dim-deep product costs H^2 out_dim scalar MACs against the M H^2 MFMA MACs it saves: on for M >= 200 out_dim;
+// measured a loss at out_dim = 112, M = 10,000)
+static bool lowrank_top(const dppo_net_desc& d, int64_t M) {
+  return g_lowrank_top && d.n_blocks >= 1 && M >= (int64_t)200 * d.out_dim;
+}
 // Time-embedding gradient through the first layer's weight-gradient GEMM: with a one-hot of the row's denoising step k in
 // the K padding of the input rows, dW0's extra columns are S[h][k] = sum over the rows of step k of dh0[row][h], and
 // d loss / d temb[k] = W0[:, temb columns]^T S[:, k] -- no second pass over dh0, no segmented reduction (tuning knob 11).
@@ -794,10 +806,10 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       f.dz1[b] = B.dz1_all[b];
     }
     for (int b = 0; b <= nb; ++b) f.dh[b] = B.dh_all[b];
-    // (the out_dim-deep product costs H^2 out_dim scalar MACs against the M H^2 MFMA MACs it saves: on for M >= 200 out_dim;
-    // measured a loss at out_dim = 112, M = 10,000)
-    const bool lowrank = g_lowrank_top && nb >= 1 && M >= (int64_t)200 * d.out_dim;
+    const bool lowrank = lowrank_top(d, M);
     if (lowrank) f.dh[nb] = nullptr;  // only dW2 of the top block read it: see lowrank_dw_kernel
+    const bool one = bwd_one<P>(d, M);  // (what carve_mlp sized the per-tile column sums for)
+    f.one_block = one ? 1 : 0;
     if (g_dbg & 1)  // timing experiment: no gradient stores (the weight-gradient GEMMs then read stale buffers)
       for (int b = 0; b <= nb; ++b) f.dh[b] = nullptr, f.dz1[b < nb ? b : 0] = nullptr;
     if (g_dbg & 2)  // timing experiment: no derivative-source fetch
@@ -823,6 +835,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
         so.n_slots += 4 * nb;
       }
       for (int i = 0; i < so.n_slots; ++i) so.n[i] = H;
+      if (one) so.n[0] = 0;  // colsum(dh_nb) is not formed by the one-block kernel: db2 comes from PostReduce::db2
       if (!bout_done) so.out[so.n_slots] = grad + pl.bout, so.n[so.n_slots] = d.out_dim, ++so.n_slots;  // the d_out slot
       // the latency-bound tail (bias sums, time-embedding gradient; they share B.part) runs beside the weight-gradient
       // GEMMs (which share B.slab and stay in order on s)
@@ -860,6 +873,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
         q.U = B.lowrank_u, q.ldu = L.Kp0, q.in_dim = d.in_dim, q.W0 = prm + pl.W0, q.ldw0 = d.in_dim, q.W2 = prm + pl.l2w[nb - 1];
         q.b0 = prm + pl.b0, q.b2 = prm + pl.l2b[nb - 1], q.cs = grad + pl.bout, q.dWout = grad + pl.Wout;
       }
+      if (one) q.db2 = grad + pl.l2b[0], q.Wout_b = prm + pl.Wout, q.cs = grad + pl.bout;
       if (g_post_one && B.post_zeroed && (lowrank || oh >= 0)) {  // both in one launch (knob 18)
         if (lowrank) q.Wout = prm + pl.Wout, q.dW = grad + pl.l2w[nb - 1];
         if (oh >= 0) {
@@ -871,7 +885,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
         q.counter = (unsigned*)B.post_counter;
         launch_post_reduce(q, s);
       } else {
-        if (merged) launch_wout_grad(q, s);
+        launch_wout_grad(q, s);  // (merged top and / or one-block backward; nothing otherwise)
         if (lowrank) launch_lowrank_dw(prm + pl.Wout, B.lowrank, d.out_dim, H, grad + pl.l2w[nb - 1], s);
         if (oh >= 0)
           launch_time_backward_from_sums(prm + pl.te1_w, prm + pl.te1_b, prm + pl.te2_w, B.part, prm + pl.W0, d.in_dim,
@@ -2361,6 +2375,10 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 18) {
     g_post_one = value;
+    return 0;
+  }
+  if (knob == 23) {  // fused backward of one-block networks: the specialised kernel (1, default) or the general one (0)
+    set_fused_bwd_one(value);
     return 0;
   }
   if (knob == 22) {  // fused forward of one-block networks: second layer merged into the out layer (1, default) or not (0);

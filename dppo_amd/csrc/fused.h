@@ -78,6 +78,7 @@ struct FusedBwdArgs {
   float* colsum;
   int dout_slot;
   int dbg;  // timing experiments only (tuning knob 8): bit 1 = do not fetch the derivative sources (wrong results)
+  int one_block;  // fused_backward_one_kernel (fused_bwd_one_block(), nb == 1): dh[1] and column-sum slot 0 are not produced
 };
 
 template <class P>
@@ -89,7 +90,10 @@ void set_fused_merge_fwd(int v);    // tuning knob 22
 template <class P>
 bool fused_can_merge(const dppo_net_desc& d);  // the forward of this network runs merged (and the backward must rebuild dWout)
 template <class P>
-int fused_rows_per_tile(const dppo_net_desc& d);  // rows per tile of the BACKWARD kernel (sizes the per-tile column sums), 0 if not covered
+int fused_rows_per_tile(const dppo_net_desc& d, bool one_block = false);  // rows per tile of the BACKWARD kernel (sizes the per-tile column sums), 0 if not covered
+template <class P>
+bool fused_bwd_one_block(const dppo_net_desc& d);  // shape covered by fused_backward_one_kernel (the caller adds: low-rank dW2 on)
+void set_fused_bwd_one(int v);  // tuning knob 23
 
 // Fragment packing of a whole stream in ONE launch: layer l occupies positions [pos0, pos0 + KS); element
 // (feature f, contraction index k) of its weight matrix is W[f*rs + k*cs] (rs = ld, cs = 1 for W; rs = 1, cs = ld for W^T)

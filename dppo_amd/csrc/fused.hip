@@ -66,14 +66,14 @@ struct Engine {
   const u32x4* stream;  // this wave's stream + lane
   int total, pos;
 
-  __device__ __forceinline__ void prime(const u32x4* s, int total_pos) {
+  __device__ __forceinline__ void prime(const u32x4* s, int total_pos, int pos0 = 0) {  // pos0 + PD <= total_pos
     stream = s;
     total = total_pos;
-    pos = 0;
+    pos = pos0;
 #pragma unroll
     for (int p = 0; p < PD; ++p)
 #pragma unroll
-      for (int tp = 0; tp < TPW; ++tp) ring[p][tp] = s[(p * TPW + tp) * 64];
+      for (int tp = 0; tp < TPW; ++tp) ring[p][tp] = s[((size_t)(pos0 + p) * TPW + tp) * 64];
   }
   // acc += W(layer at stream position pos .. pos+nks) . src^T ; src: swizzled LDS image with row bytes rb.
   // flags != nullptr: the image is being produced by the other waves' emits of the previous layer (wave p writes the
@@ -837,6 +837,133 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
   }
 }
 
+// =================================================================================================
+// backward, one-block networks
+// =================================================================================================
+// With one block, dh_0 = dh_1 + (dz1 . W1) o act'(h_0) and dh_1 = d_out . Wout is a K = out_dim product on the d_out tile
+// that stays in LDS for the whole tile: it is added LAST, into the accumulators of the W1^T layer, instead of first into a
+// running dh that then occupies 16 * TPW * MR / 64 registers per lane through both H-wide phases.  What that buys: no
+// dh_1 phase (emit + column sums: 6k of a 51k-cycle tile; the second layer's bias gradient colsum(dh_1) = colsum(d_out) . Wout
+// is formed behind the slab reduce, PostReduce::db2), room to fetch the derivative sources BEFORE each k-loop again (their
+// latency hides under it), and at H = 256 room for the forward's 128-row tile (half the weight stream per row).  The stream
+// is the ordinary backward stream [Wout^T | (Wout W2)^T | W1^T] walked from its second layer on: the ring wraps at the end
+// of a tile anyway.  Needs the low-rank dW2 (no dh_1 tensor is written).
+template <class P, int TPW, int MR, int ACT>
+__global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedBwdArgs a) {
+  constexpr int ES = P::ESIZE, KB = P::KB, PD = ring_depth<TPW, MR>();
+  constexpr int H = 128 * TPW, KSH = H / KB, HRB = H * ES, MT = 16 * MR;
+  constexpr bool FLAGS = DPPO_FLAGS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int M = a.M;
+  const int in_rb = a.KpB0 * ES, in_km = kmask16(in_rb), KSB0 = a.KpB0 / KB;
+  const int total = 2 * KSB0 + KSH;
+  char* bufA = smem;
+  char* bufB = bufA + MT * HRB;
+  char* xin = bufB;  // the d_out tile: read by the composite layer first and by the Wout^T layer last
+  volatile uint32_t* flags = (volatile uint32_t*)(bufB + MT * HRB);  // [16 words]
+  constexpr int DRED_COLS = 128;
+  float* dred = (float*)(bufB + MT * HRB + 64);  // [8 waves][128] column sums of the d_out tile
+  const int wbase = wid * 16 * TPW;
+  const int ntiles = (M + MT - 1) / MT;
+
+  Engine<P, TPW, MR, PD> eng;
+  eng.prime(a.bstream + (size_t)wid * total * TPW * 64 + lane, total, KSB0);
+  if (tid < 16) flags[tid] = 0;  // (visible after the first tile's barrier)
+  uint32_t seq = 0;
+
+  auto colsum = [&](const f32x4 (&v)[TPW][MR], int slot, int tile) {
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) {
+      f32x4 s = v[tp][0];
+#pragma unroll
+      for (int m = 1; m < MR; ++m) s += v[tp][m];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = s[e];
+        x += __shfl_xor(x, 1);
+        x += __shfl_xor(x, 2);
+        x += __shfl_xor(x, 4);
+        x += __shfl_xor(x, 8);
+        s[e] = x;
+      }
+      if (r == 0) *(f32x4*)(a.colsum + ((size_t)slot * ntiles + tile) * H + wbase + feat_off<P>(g, tp)) = s;
+    }
+  };
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row0 = tile * MT;
+    STAMP(16);
+    load_tile<MT>(xin, in_rb, in_km, (const char*)a.d_out, a.ld_dout * ES, row0, M);
+    __syncthreads();
+    STAMP(17);
+    if (a.dout_slot >= 0) {  // out-layer bias gradient: column sums of the d_out tile (rows past M are zero), part 1
+      typedef typename P::elem_t E;
+      for (int c = lane; c < a.KpB0; c += 64) {
+        const int cb = c * ES;
+        float t = 0.f;
+        for (int row = wid; row < MT; row += SAMPLER_WAVES)
+          t += P::to_f32(*(const E*)(xin + row * in_rb + ((((cb >> 4) ^ (row & in_km)) << 4) | (cb & 15))));
+        dred[wid * DRED_COLS + c] = t;
+      }
+    }
+    f32x4 acc[TPW][MR];
+    u32x4 d[MR][Chunks<P, TPW>::CH];
+    auto zero_acc = [&]() {
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+        for (int m = 0; m < MR; ++m) acc[tp][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    // ---- dz1 = (dh_1 . W2) o act'(z1), dh_1 . W2 = d_out . (Wout . W2): a K = out_dim layer on the d_out tile
+    fetch<P, ACT == ACT_RELU, TPW>(d, a.m1[0], H, wbase, g, r, row0, M);
+    zero_acc();
+    eng.run(acc, xin, in_rb, in_km, KSB0, r, g);
+    STAMP(22);
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[tp][m][e] *= grad_at<P, ACT>(d, tp, m, e);
+    emit<P, TPW, MR>(acc, ACT_NONE, bufA, a.dz1[0], H, wbase, g, r, row0, M);
+    STAMP(23);
+    colsum(acc, 2, tile);
+    STAMP(24);
+    if constexpr (FLAGS)
+      hand_over(flags, wid, lane, ++seq);
+    else
+      __syncthreads();
+    STAMP(25);
+    // ---- dh_0 = (dz1 . W1) o act'(h_0) + d_out . Wout
+    fetch<P, ACT == ACT_RELU, TPW>(d, a.m0[0], H, wbase, g, r, row0, M);
+    zero_acc();
+    eng.run(acc, bufA, HRB, 15, KSH, r, g, FLAGS ? flags : nullptr, seq);
+    STAMP(26);
+    if (a.dout_slot >= 0 && tid < a.KpB0) {  // part 2 (every wave has passed part 1: its flag / the barrier came later)
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < SAMPLER_WAVES; ++w) t += dred[w * DRED_COLS + tid];
+      a.colsum[((size_t)a.dout_slot * ntiles + tile) * H + tid] = t;
+    }
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[tp][m][e] *= grad_at<P, ACT>(d, tp, m, e);
+    eng.run(acc, xin, in_rb, in_km, KSB0, r, g);
+    emit<P, TPW, MR>(acc, ACT_NONE, nullptr, a.dh[0], H, wbase, g, r, row0, M);
+    STAMP(27);
+    colsum(acc, 1, tile);
+    STAMP(28);
+    __syncthreads();  // tile end: the next tile's d_out lands in buffer B, its dz1 image in buffer A
+    STAMP(29);
+  }
+}
+
 #ifdef DPPO_STAMPS
 extern "C" int dppo_debug_stamps(unsigned long long* out) {  // out: [8 waves][32]
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8 * 32);
@@ -874,12 +1001,22 @@ static int pick_mr_bwd(int hidden, int ln) {
   if (ln && mr > 1) mr /= 2;
   return mr;
 }
+// one-block backward (fused_backward_one_kernel): the forward's tile height
+static int g_bwd_one = 1;  // tuning knob 23
+void set_fused_bwd_one(int v) { g_bwd_one = v; }
 template <class P>
-int fused_rows_per_tile(const dppo_net_desc& d) {
-  return 16 * pick_mr_bwd<P>(d.hidden, d.use_layernorm);
+bool fused_bwd_one_block(const dppo_net_desc& d) {
+  return g_bwd_one && !d.plain && !d.use_layernorm && d.n_blocks == 1 && d.hidden % 128 == 0 && d.hidden <= 512 &&
+         pick_mr<P>(d.hidden) > 0;
 }
-template int fused_rows_per_tile<F32>(const dppo_net_desc&);
-template int fused_rows_per_tile<BF16>(const dppo_net_desc&);
+template bool fused_bwd_one_block<F32>(const dppo_net_desc&);
+template bool fused_bwd_one_block<BF16>(const dppo_net_desc&);
+template <class P>
+int fused_rows_per_tile(const dppo_net_desc& d, bool one_block) {
+  return 16 * (one_block ? pick_mr<P>(d.hidden) : pick_mr_bwd<P>(d.hidden, d.use_layernorm));
+}
+template int fused_rows_per_tile<F32>(const dppo_net_desc&, bool);
+template int fused_rows_per_tile<BF16>(const dppo_net_desc&, bool);
 
 template <class P>
 FusedGeom fused_geom(const dppo_net_desc& d) {
@@ -1020,11 +1157,38 @@ static int launch_bwd_cfg(const FusedBwdArgs& a, hipStream_t s) {
   return 0;
 }
 
+template <class P, int TPW, int MR, int ACT>
+static int launch_bwd_one_cfg(const FusedBwdArgs& a, hipStream_t s) {
+  constexpr int ES = P::ESIZE, MT = 16 * MR, H = 128 * TPW;
+  const size_t lds = 2 * (size_t)MT * H * ES + 64 + SAMPLER_WAVES * 128 * 4;
+  if (lds > 160 * 1024 || a.KpB0 > H || a.KpB0 > 128 || a.nb != 1) return -2;
+  static DevLatch attr;
+  raise_lds(fused_backward_one_kernel<P, TPW, MR, ACT>, attr);
+  const int ntiles = (a.M + MT - 1) / MT;
+  const bool probe = probe_begin(PROBE_FUSED_BWD, s);
+  hipLaunchKernelGGL((fused_backward_one_kernel<P, TPW, MR, ACT>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512), lds, s, a);
+  if (probe) probe_end(s, 2.0 * a.M * ((double)a.out_valid * H + 2.0 * a.nb * H * H));
+  return 0;
+}
+
 template <class P>
 int launch_fused_backward(const dppo_net_desc& d, const FusedBwdArgs& a, hipStream_t s) {
+  const bool relu = a.act == ACT_RELU;
+  if (a.one_block) {  // (the caller asked fused_bwd_one_block() and sized the column sums for the forward's tile height)
+    const int t = d.hidden / 128, q = pick_mr<P>(d.hidden);
+    if (a.M <= 0) return -1;
+#define DPPO_BWD1(T, R) \
+  if (t == T && q == R) return relu ? launch_bwd_one_cfg<P, T, R, ACT_RELU>(a, s) : launch_bwd_one_cfg<P, T, R, ACT_MISH>(a, s);
+    if constexpr (P::ESIZE == 2) {
+      DPPO_BWD1(2, 8) DPPO_BWD1(4, 4)
+    } else {
+      DPPO_BWD1(2, 4) DPPO_BWD1(4, 2)
+    }
+#undef DPPO_BWD1
+    return -1;
+  }
   const int tpw = d.hidden / 128, mr = pick_mr_bwd<P>(d.hidden, a.use_ln);
   if (mr == 0 || a.M <= 0) return -1;
-  const bool relu = a.act == ACT_RELU;
   if constexpr (P::ESIZE == 2) {
     if (short_tiles<P>(d.hidden, a.use_ln, 0))
       return relu ? launch_bwd_cfg<P, 4, 2, false, ACT_RELU, 2>(a, s) : launch_bwd_cfg<P, 4, 2, false, ACT_MISH, 2>(a, s);

@@ -282,9 +282,13 @@ struct PostReduce {  // see post_reduce_kernel; dW == null: no low-rank part; G 
   const float *U, *W2, *b0, *b2, *cs;
   float* dWout;
   int ldu, in_dim;
+  // one-block backward (db2 != null): the second layer's bias gradient colsum(dh_1) = cs . Wout_b, which the kernel no
+  // longer forms (fused_backward_one_kernel)
+  const float* Wout_b;
+  float* db2;
   int n_lowrank, n_temb, n_wout;  // set by the launcher
 };
-void launch_wout_grad(const PostReduce& q, hipStream_t s);  // the merged-top part alone (no arrival counter needed)
+void launch_wout_grad(const PostReduce& q, hipStream_t s);  // the merged-top / one-block parts alone (no arrival counter needed)
 void launch_post_reduce(PostReduce& q, hipStream_t s);
 size_t time_backward_lds_bytes(int Kft, int td);  // LDS of the time MLP's backward block: must stay <= 156 KB
 void launch_lowrank_dw(const float* Wout, const float* T, int out_dim, int H, float* dW, hipStream_t s);

@@ -855,21 +855,36 @@ __global__ __launch_bounds__(256) void time_backward_kernel(const float* w1, con
 // Everything that follows the slab reduction of a backward pass, in ONE launch: the low-rank dW2 (lowrank_dw_kernel's
 // body), G = W0_temb^T . S (temb_from_sums_kernel's, one wave per output) and, in the block that finishes G last, the
 // time MLP's backward -- three dependent-looking launches of 5-17 us that only shared the slab reduction as an input.
-// dWout[o][h] of a merged-top network (see PostReduce::U): one wave per output, lanes over the contraction
+// dWout[o][h] of a merged-top network (see PostReduce::U) and db2[h] of a one-block backward (PostReduce::db2): one wave
+// per output, lanes over the contraction
 __device__ __forceinline__ void wout_grad_block(const PostReduce& q, int b) {
-  const int lane = threadIdx.x & 63, out = b * 4 + (threadIdx.x >> 6);
-  if (out >= q.out_dim * q.H) return;
-  const int o = out / q.H, h = out - o * q.H;
-  float acc = 0.f;
-  for (int j = lane; j < q.H; j += 64) acc += q.T[(size_t)o * q.H + j] * q.W2[(size_t)h * q.H + j];
-  for (int c = lane; c < q.in_dim; c += 64) acc += q.U[(size_t)o * q.ldu + c] * q.W0[(size_t)h * q.ldw0 + c];
-  for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d);
-  if (lane == 0) q.dWout[out] = acc + q.cs[o] * (q.b0[h] + q.b2[h]);
+  const int lane = threadIdx.x & 63;
+  int out = b * 4 + (threadIdx.x >> 6);
+  const int n1 = q.U != nullptr ? q.out_dim * q.H : 0;
+  if (out < n1) {
+    const int o = out / q.H, h = out - o * q.H;
+    float acc = 0.f;
+    for (int j = lane; j < q.H; j += 64) acc += q.T[(size_t)o * q.H + j] * q.W2[(size_t)h * q.H + j];
+    for (int c = lane; c < q.in_dim; c += 64) acc += q.U[(size_t)o * q.ldu + c] * q.W0[(size_t)h * q.ldw0 + c];
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d);
+    if (lane == 0) q.dWout[out] = acc + q.cs[o] * (q.b0[h] + q.b2[h]);
+    return;
+  }
+  out -= n1;
+  if (q.db2 != nullptr && out < q.H) {  // colsum(dh_1) = colsum(d_out) . Wout
+    float acc = 0.f;
+    for (int o = lane; o < q.out_dim; o += 64) acc += q.cs[o] * q.Wout_b[(size_t)o * q.H + out];
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d);
+    if (lane == 0) q.db2[out] = acc;
+  }
+}
+static int wout_grad_blocks(const PostReduce& q) {
+  return ((q.U != nullptr ? q.out_dim * q.H : 0) + (q.db2 != nullptr ? q.H : 0) + 3) / 4;
 }
 __global__ __launch_bounds__(256) void wout_grad_kernel(const PostReduce q) { wout_grad_block(q, blockIdx.x); }
 void launch_wout_grad(const PostReduce& q, hipStream_t s) {
-  const int blocks = (q.out_dim * q.H + 3) / 4;
-  if (q.U != nullptr && blocks > 0) hipLaunchKernelGGL(wout_grad_kernel, dim3(blocks), dim3(256), 0, s, q);
+  const int blocks = wout_grad_blocks(q);
+  if (blocks > 0) hipLaunchKernelGGL(wout_grad_kernel, dim3(blocks), dim3(256), 0, s, q);
 }
 
 __global__ __launch_bounds__(256) void post_reduce_kernel(const PostReduce q) {
@@ -911,7 +926,7 @@ __global__ __launch_bounds__(256) void post_reduce_kernel(const PostReduce q) {
 void launch_post_reduce(PostReduce& q, hipStream_t s) {
   q.n_lowrank = q.dW != nullptr ? (int)(((size_t)q.H * q.H + 255) / 256) : 0;
   q.n_temb = q.G != nullptr ? (q.Kft * q.td + 3) / 4 : 0;
-  q.n_wout = q.U != nullptr ? (q.out_dim * q.H + 3) / 4 : 0;
+  q.n_wout = wout_grad_blocks(q);
   const int blocks = q.n_lowrank + q.n_temb + q.n_wout;
   static DevLatch raised;
   if (raised.need()) raise_dyn_lds(post_reduce_kernel), raised.done();

@@ -431,7 +431,9 @@ int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* 
  *          (default 1)
  * knob 22: fused forward of one-block networks (no LayerNorm, out_dim <= 16, hidden <= 512) never runs the block's second
  *          layer: out = (Wout W0) x + (Wout W2) act(z1) + const, and the out-layer weight gradient is rebuilt from
- *          d_out^T x and d_out^T act(z1) (default 1) */
+ *          d_out^T x and d_out^T act(z1) (default 1)
+ * knob 23: fused backward of one-block networks (no LayerNorm, hidden <= 512, low-rank dW2 on): dh_1 = d_out . Wout is added
+ *          last, into the W1^T layer's accumulators, instead of carried in registers; forward-sized tiles (default 1) */
 int dppo_tune_set(int knob, int value);
 /* one bare layer GEMM: out[M][ldo] = act(X[M][Kp] . W[N][Kp]^T + bias) with elem = prec operands;
  * out_f32 and/or out_elem may be NULL; ldo >= round_up(N,16) */

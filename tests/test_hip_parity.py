@@ -595,21 +595,24 @@ def test_fused_path_matches_layered_path(prec, tol, sname):
 
 @pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
 @pytest.mark.parametrize("sname", ["hopper", "can"])
-def test_merged_top_layer_matches_unmerged(prec, tol, sname):
-    """One-block networks run their fused forward with the block's second layer folded into the out layer and rebuild the
-    out-layer weight gradient from d_out^T x and d_out^T act(z1) (tuning knob 22; hopper: actor and critic in bf16, the
-    critic in fp32; can: the critic).  Same log-probs, values, loss statistics and gradients -- the out layer's included,
-    tensor by tensor -- as the kernels that form h_1."""
+@pytest.mark.parametrize("knob", [22, 23])
+def test_one_block_kernels_match_the_general_ones(prec, tol, sname, knob):
+    """One-block networks have their own fused kernels.  Knob 22: the forward folds the block's second layer into the out
+    layer and the out-layer weight gradient is rebuilt from d_out^T x and d_out^T act(z1) (hopper: actor and critic in
+    bf16, the critic in fp32; can: the critic).  Knob 23: the backward adds dh_1 = d_out . Wout last instead of carrying it,
+    in forward-sized tiles, and the second layer's bias gradient comes from colsum(d_out) . Wout (every one-block network
+    once the minibatch is large enough for the low-rank dW2).  Same log-probs, values, loss statistics and gradients --
+    tensor by tensor -- as the general kernels."""
     from dppo_amd import hip
     lib = hip.load()
     kw = dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01, randn_clip_value=3)
     m, a, c = build_model(sname, kw, 73, prec)
-    R, N, Kft = 200, 1500, 10
+    R, N, Kft = 800, 6500, 10  # N >= 200 x out_dim: the low-rank dW2 (and with it the one-block backward) is on
     AF = a.horizon_steps * a.action_dim
     out = {}
     try:
         for merged in (1, 0):
-            lib.dppo_tune_set(22, merged)
+            lib.dppo_tune_set(knob, merged)
             for net in (m.actor, m.actor_ft, m.critic):
                 net.mark_updated()
             gen = torch.Generator(device="cpu").manual_seed(5)
@@ -628,7 +631,7 @@ def test_merged_top_layer_matches_unmerged(prec, tol, sname):
                     grads[(tag, k)] = gv.detach().cpu().numpy().copy()
             out[merged] = (logp.cpu().numpy(), val.cpu().numpy(), st, grads)
     finally:
-        lib.dppo_tune_set(22, 1)
+        lib.dppo_tune_set(knob, 1)
         for net in (m.actor, m.actor_ft, m.critic):
             net.mark_updated()
     lp1, v1, s1, g1 = out[1]
