@@ -665,7 +665,8 @@ static int temb_onehot_col(const dppo_net_desc& d, const PackLayout& L, int Kft,
   return d.in_dim;
 }
 template <class P>
-static void flush_slabs(MlpBufs<P>& B, hipStream_t s) {
+static void flush_slabs(MlpBufs<P>& B, hipStream_t s, const SlotOuts* slots = nullptr, int slot_width = 0) {
+  // slots: the fused backward's per-tile column sums, reduced right behind the GEMM launch (see mlp_backward)
   if (B.tn_group.n > 0) {
     GemmTNGroup& gr = B.tn_group;
     for (int i = 1; i < gr.n; ++i)  // longest row ranges first (insertion sort: the short jobs fill the last round)
@@ -679,6 +680,7 @@ static void flush_slabs(MlpBufs<P>& B, hipStream_t s) {
     launch_gemm_tn_group<P>(gr, s);
     gr.n = 0;
   }
+  if (slots != nullptr) launch_reduce_slots(B.tile_colsum, B.tiles, slot_width, *slots, s);
   for (int i = 0; i < B.n_join; ++i) join_side(s, B.join_s[i], B.join_idx[i]);
   B.n_join = 0;
   launch_slab_reduce_batch(B.slab_jobs, s);
@@ -841,7 +843,9 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       // GEMMs (which share B.slab and stay in order on s)
       hipStream_t aux = aux_idx >= 0 ? fork_side(s, aux_idx) : s;
       if (fin && aux != s) launch_loss_finalize(*fin, aux);
-      launch_reduce_slots(B.tile_colsum, B.tiles, H, so, aux);
+      // (without an aux stream the bias sums go BEHIND the weight-gradient launch: they are latency-bound and nothing before
+      // the post-reduce step reads them, while the GEMMs are what the stream's next 40-80 us are about)
+      if (aux != s) launch_reduce_slots(B.tile_colsum, B.tiles, H, so, aux);
       const int oh = d.kind == 0 ? temb_onehot_col<P>(d, L, Kft, B) : -1;  // must match what the row builder was told
       if (d.kind == 0 && oh < 0) time_embedding_grad<P>(d, prm, pk, L, M, B, B.dh_all[0], grad, krow, ksteps, Kft, aux);
       // merged top (the forward never formed h_nb): dWout = d_out^T . h_nb is rebuilt behind the slab reduce from
@@ -864,7 +868,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       else
         weight_grad<P>(B.dh_all[0], H, H, B.in, L.Kp0, d.in_dim, M, B, grad + pl.W0, d.in_dim, s, true);
       if (aux != s && g_early_join) B.join_s[B.n_join] = aux, B.join_idx[B.n_join++] = aux_idx;
-      flush_slabs(B, s);  // every slab of this backward in one reduction launch
+      flush_slabs(B, s, aux == s ? &so : nullptr, H);  // every slab of this backward in one reduction launch
       if (aux != s && !g_early_join) join_side(s, aux, aux_idx);
       PostReduce q;
       memset(&q, 0, sizeof(q));

@@ -1006,7 +1006,7 @@ static int g_bwd_one = 1;  // tuning knob 23
 void set_fused_bwd_one(int v) { g_bwd_one = v; }
 template <class P>
 bool fused_bwd_one_block(const dppo_net_desc& d) {
-  return g_bwd_one && !d.plain && !d.use_layernorm && d.n_blocks == 1 && d.hidden % 128 == 0 && d.hidden <= 512 &&
+  return g_bwd_one && !d.plain && !d.use_layernorm && d.n_blocks == 1 && d.hidden % 128 == 0 && d.hidden <= 1024 &&
          pick_mr<P>(d.hidden) > 0;
 }
 template bool fused_bwd_one_block<F32>(const dppo_net_desc&);
@@ -1180,9 +1180,9 @@ int launch_fused_backward(const dppo_net_desc& d, const FusedBwdArgs& a, hipStre
 #define DPPO_BWD1(T, R) \
   if (t == T && q == R) return relu ? launch_bwd_one_cfg<P, T, R, ACT_RELU>(a, s) : launch_bwd_one_cfg<P, T, R, ACT_MISH>(a, s);
     if constexpr (P::ESIZE == 2) {
-      DPPO_BWD1(2, 8) DPPO_BWD1(4, 4)
+      DPPO_BWD1(2, 8) DPPO_BWD1(4, 4) DPPO_BWD1(8, 2)
     } else {
-      DPPO_BWD1(2, 4) DPPO_BWD1(4, 2)
+      DPPO_BWD1(2, 4) DPPO_BWD1(4, 2) DPPO_BWD1(8, 1)
     }
 #undef DPPO_BWD1
     return -1;

@@ -594,8 +594,7 @@ def test_fused_path_matches_layered_path(prec, tol, sname):
 
 
 @pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
-@pytest.mark.parametrize("sname", ["hopper", "can"])
-@pytest.mark.parametrize("knob", [22, 23])
+@pytest.mark.parametrize("sname,knob", [("hopper", 22), ("can", 22), ("hopper", 23), ("can", 23), ("square_like", 23)])
 def test_one_block_kernels_match_the_general_ones(prec, tol, sname, knob):
     """One-block networks have their own fused kernels.  Knob 22: the forward folds the block's second layer into the out
     layer and the out-layer weight gradient is rebuilt from d_out^T x and d_out^T act(z1) (hopper: actor and critic in
