@@ -665,8 +665,10 @@ static int temb_onehot_col(const dppo_net_desc& d, const PackLayout& L, int Kft,
   return d.in_dim;
 }
 template <class P>
-static void flush_slabs(MlpBufs<P>& B, hipStream_t s, const SlotOuts* slots = nullptr, int slot_width = 0) {
-  // slots: the fused backward's per-tile column sums, reduced right behind the GEMM launch (see mlp_backward)
+static void flush_slabs(MlpBufs<P>& B, hipStream_t s, const SlotOuts* slots = nullptr, int slot_width = 0,
+                        const LossArgs* fin = nullptr) {
+  // slots / fin: the fused backward's per-tile column sums and the loss statistics ride in the reduction launch (see
+  // tail_reduce_kernel)
   if (B.tn_group.n > 0) {
     GemmTNGroup& gr = B.tn_group;
     for (int i = 1; i < gr.n; ++i)  // longest row ranges first (insertion sort: the short jobs fill the last round)
@@ -680,10 +682,17 @@ static void flush_slabs(MlpBufs<P>& B, hipStream_t s, const SlotOuts* slots = nu
     launch_gemm_tn_group<P>(gr, s);
     gr.n = 0;
   }
-  if (slots != nullptr) launch_reduce_slots(B.tile_colsum, B.tiles, slot_width, *slots, s);
   for (int i = 0; i < B.n_join; ++i) join_side(s, B.join_s[i], B.join_idx[i]);
   B.n_join = 0;
-  launch_slab_reduce_batch(B.slab_jobs, s);
+  if (slots != nullptr || fin != nullptr) {
+    TailReduce t;
+    memset(&t, 0, sizeof(t));
+    t.jobs = B.slab_jobs;
+    if (slots != nullptr) t.colsum = B.tile_colsum, t.tiles = B.tiles, t.width = slot_width, t.slots = *slots;
+    launch_tail_reduce(t, fin, s);
+  } else {
+    launch_slab_reduce_batch(B.slab_jobs, s);
+  }
   B.slab_jobs.n = 0, B.slab_used = 0;
 }
 // gw[N1][N2] (ld ldgw) = A[M][N1]^T . B[M][N2].  A thin N1 (the out layer) is computed transposed, B^T . A, so that the
@@ -839,15 +848,13 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       for (int i = 0; i < so.n_slots; ++i) so.n[i] = H;
       if (one) so.n[0] = 0;  // colsum(dh_nb) is not formed by the one-block kernel: db2 comes from PostReduce::db2
       if (!bout_done) so.out[so.n_slots] = grad + pl.bout, so.n[so.n_slots] = d.out_dim, ++so.n_slots;  // the d_out slot
-      // the latency-bound tail (bias sums, time-embedding gradient; they share B.part) runs beside the weight-gradient
-      // GEMMs (which share B.slab and stay in order on s)
-      hipStream_t aux = aux_idx >= 0 ? fork_side(s, aux_idx) : s;
-      if (fin && aux != s) launch_loss_finalize(*fin, aux);
-      // (without an aux stream the bias sums go BEHIND the weight-gradient launch: they are latency-bound and nothing before
-      // the post-reduce step reads them, while the GEMMs are what the stream's next 40-80 us are about)
-      if (aux != s) launch_reduce_slots(B.tile_colsum, B.tiles, H, so, aux);
+      // The bias sums and the loss statistics ride in the slab-reduction launch behind the GEMMs (tail_reduce_kernel).
+      // Only the rare time-embedding gradient WITHOUT the one-hot columns (a gemm_nt + segmented sum over all rows, see
+      // temb_onehot_col) still runs beside the GEMMs on a side stream (it shares B.part with nothing on s).
       const int oh = d.kind == 0 ? temb_onehot_col<P>(d, L, Kft, B) : -1;  // must match what the row builder was told
-      if (d.kind == 0 && oh < 0) time_embedding_grad<P>(d, prm, pk, L, M, B, B.dh_all[0], grad, krow, ksteps, Kft, aux);
+      const bool need_aux = d.kind == 0 && oh < 0;
+      hipStream_t aux = aux_idx >= 0 && need_aux ? fork_side(s, aux_idx) : s;
+      if (need_aux) time_embedding_grad<P>(d, prm, pk, L, M, B, B.dh_all[0], grad, krow, ksteps, Kft, aux);
       // merged top (the forward never formed h_nb): dWout = d_out^T . h_nb is rebuilt behind the slab reduce from
       // U = d_out^T . x and T = d_out^T . act(z1) (PostReduce::U); T is then needed whether or not dW2 uses it
       const bool merged = B.merged;
@@ -868,7 +875,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       else
         weight_grad<P>(B.dh_all[0], H, H, B.in, L.Kp0, d.in_dim, M, B, grad + pl.W0, d.in_dim, s, true);
       if (aux != s && g_early_join) B.join_s[B.n_join] = aux, B.join_idx[B.n_join++] = aux_idx;
-      flush_slabs(B, s, aux == s ? &so : nullptr, H);  // every slab of this backward in one reduction launch
+      flush_slabs(B, s, &so, H, fin);  // every slab of this backward, its bias sums and the loss statistics: one launch
       if (aux != s && !g_early_join) join_side(s, aux, aux_idx);
       PostReduce q;
       memset(&q, 0, sizeof(q));
@@ -896,7 +903,6 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
                                          d.act_flat, H, B.part + (size_t)H * Kft, ksteps, Kft, d.time_dim, grad + pl.te1_w,
                                          grad + pl.te1_b, grad + pl.te2_w, grad + pl.te2_b, s);
       }
-      if (fin && aux == s) launch_loss_finalize(*fin, s);
       B.dh0_final = B.dh_all[0];
       return;
     }

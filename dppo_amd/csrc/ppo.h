@@ -183,6 +183,18 @@ struct SlabJobs {
   int n;
 };
 void launch_slab_reduce_batch(const SlabJobs& jobs, hipStream_t s);
+struct LossArgs;
+struct TailReduce {  // see tail_reduce_kernel
+  SlabJobs jobs;
+  const float* colsum;  // [slots][tiles][width] per-tile column sums of the fused backward
+  int tiles, width;
+  SlotOuts slots;       // n_slots = 0: none
+  const double *fin_partial, *fin_moments;  // set by the launcher from the loss's arguments
+  double* fin_stats;
+  int fin_blocks, fin_part;
+  double fin_n_count;
+};
+void launch_tail_reduce(TailReduce& t, const LossArgs* fin, hipStream_t s);  // fin: loss statistics to finalise, or null
 void launch_slab_reduce_2d(const float* slab, int splits, int rows, int cols, int lds, float* out, int ldo,
                            float scale, hipStream_t s, int transpose = 0);
 

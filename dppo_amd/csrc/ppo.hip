@@ -690,31 +690,41 @@ __global__ __launch_bounds__(LOSS_THREADS) void ppo_loss_kernel(const LossArgs a
 }
 
 // one block of 1024 threads: the five statistics, summed over the loss kernel's blocks in a fixed order => reproducible
-__global__ __launch_bounds__(1024) void loss_finalize_kernel(const double* partial, int blocks, const double* moments,
-                                                             double* stats, int part, double n_count) {
-  __shared__ double shd[16];
+__device__ __forceinline__ void loss_finalize_block(const double* partial, int blocks, const double* moments, double* stats,
+                                                    int part, double n_count) {
+  // all five statistics in ONE pass and one barrier: this block may ride in the reduction launch on the update's critical
+  // path (tail_reduce_kernel), where five passes with two barriers each were 8 us of latency
+  __shared__ double shd[16][5];
   const double Nn = n_count > 0 ? n_count : moments[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  for (int k = 0; k < 5; ++k) {
-    if (!((k == DPPO_STAT_V_LOSS ? 2 : 1) & part)) continue;  // the other half's launch owns this entry
-    double s = 0;
-    for (int b = tid; b < blocks; b += 1024) s += partial[(size_t)b * 8 + k];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-    __syncthreads();
-    if (lane == 0) shd[w] = s;
-    __syncthreads();
-    if (tid == 0) {
-      double t = 0;
-      for (int i = 0; i < 16; ++i) t += shd[i];
-      stats[k] = t / Nn;  // each entry has exactly one owner launch
-    }
+  double v[5] = {0, 0, 0, 0, 0};
+  for (int b = tid; b < blocks; b += 1024) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] += partial[(size_t)b * 8 + k];
   }
-  if (tid == 0 && (part & 1)) {  // the policy half owns these (its stream is the one the moments were pooled on)
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+    for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) shd[w][k] = v[k];
+  }
+  __syncthreads();
+  if (tid < 5 && ((tid == DPPO_STAT_V_LOSS ? 2 : 1) & part)) {  // the other half's launch owns the other entries
+    double t = 0;
+    for (int i = 0; i < 16; ++i) t += shd[i][tid];
+    stats[tid] = t / Nn;  // each entry has exactly one owner launch
+  }
+  if (tid == 64 && (part & 1)) {  // the policy half owns these (its stream is the one the moments were pooled on)
     const double mean = moments[0] / Nn;
     const double varu = Nn > 1 ? (moments[1] - Nn * mean * mean) / (Nn - 1.0) : 0.0;
     stats[DPPO_STAT_ADV_MEAN] = mean;
     stats[DPPO_STAT_ADV_STD] = sqrt(varu > 0 ? varu : 0);
   }
+}
+__global__ __launch_bounds__(1024) void loss_finalize_kernel(const double* partial, int blocks, const double* moments,
+                                                             double* stats, int part, double n_count) {
+  loss_finalize_block(partial, blocks, moments, stats, part, n_count);
 }
 
 int loss_blocks(int64_t N) { return (int)((N + LOSS_THREADS - 1) / LOSS_THREADS); }
@@ -787,9 +797,9 @@ static void raise_dyn_lds(K kern) {  // above 64 KB of dynamic LDS a kernel need
     (void)hipGetLastError();  // not fatal: launches below 64 KB do not need it
 }
 // single block: recompute the tiny time MLP per fine-tuned step and back-propagate G[k][td] through it
-__device__ __forceinline__ void time_backward_block(const float* w1, const float* b1, const float* w2, const float* G_in,
-                                                    const dppo_step* ksteps, int Kft, int td, float* gw1, float* gb1,
-                                                    float* gw2, float* gb2, float* sh) {
+// part A: what does not depend on the gradient G -- weights staged in LDS, sinusoidal features, z1 and a1 of every step
+__device__ __forceinline__ void time_backward_prepare(const float* w1, const float* b1, const float* w2,
+                                                      const dppo_step* ksteps, int Kft, int td, float* sh) {
   // sh: per k: e0[td], z1[2td], a1[2td], dz1[2td]; then w1[2td][td], w2[td][2td], b1[2td], G[Kft][td] staged once (each
   // phase below otherwise pays an L2 latency per inner-loop iteration: this block is the tail of the update's critical path)
   const int per = 7 * td;
@@ -797,11 +807,8 @@ __device__ __forceinline__ void time_backward_block(const float* w1, const float
   float* w1s = sh + Kft * per;
   float* w2s = w1s + 2 * td * td;
   float* b1s = w2s + 2 * td * td;
-  float* Gs = b1s + 2 * td;
   for (int i = tid; i < 2 * td * td; i += 256) w1s[i] = w1[i], w2s[i] = w2[i];
   for (int i = tid; i < 2 * td; i += 256) b1s[i] = b1[i];
-  for (int i = tid; i < Kft * td; i += 256) Gs[i] = G_in[i];
-  const float* G = Gs;
   for (int i = tid; i < Kft * td; i += 256) {
     const int k = i / td, j = i % td;
     sh[k * per + j] = sinus_feat(ksteps[k].t, j, td);
@@ -811,15 +818,25 @@ __device__ __forceinline__ void time_backward_block(const float* w1, const float
     const int k = i / (2 * td), o = i % (2 * td);
     float s = b1s[o];
     for (int j = 0; j < td; ++j) s += w1s[o * td + j] * sh[k * per + j];
-    sh[k * per + td + o] = s;
+    sh[k * per + td + o] = mish_grad_f(s);  // (only the derivative of z1 is needed below)
     sh[k * per + 3 * td + o] = mish_f(s);
   }
+}
+// part B: G[Kft][td] -> gradients of the four parameter tensors
+__device__ __forceinline__ void time_backward_finish(const float* G_in, int Kft, int td, float* gw1, float* gb1, float* gw2,
+                                                     float* gb2, float* sh) {
+  const int per = 7 * td;
+  const int tid = threadIdx.x;
+  const float* w2s = sh + Kft * per + 2 * td * td;
+  float* Gs = sh + Kft * per + 4 * td * td + 2 * td;
+  for (int i = tid; i < Kft * td; i += 256) Gs[i] = __builtin_nontemporal_load(&G_in[i]);
+  const float* G = Gs;
   __syncthreads();
   for (int i = tid; i < Kft * 2 * td; i += 256) {
     const int k = i / (2 * td), o = i % (2 * td);
     float s = 0.f;
     for (int j = 0; j < td; ++j) s += w2s[j * 2 * td + o] * G[k * td + j];
-    sh[k * per + 5 * td + o] = s * mish_grad_f(sh[k * per + td + o]);
+    sh[k * per + 5 * td + o] = s * sh[k * per + td + o];
   }
   __syncthreads();
   for (int i = tid; i < td * 2 * td; i += 256) {  // gw2[o][j] = sum_k G[k][o] a1[k][j]
@@ -844,6 +861,12 @@ __device__ __forceinline__ void time_backward_block(const float* w1, const float
     for (int k = 0; k < Kft; ++k) s += sh[k * per + 5 * td + o];
     gb1[o] = s;
   }
+}
+__device__ __forceinline__ void time_backward_block(const float* w1, const float* b1, const float* w2, const float* G_in,
+                                                    const dppo_step* ksteps, int Kft, int td, float* gw1, float* gb1,
+                                                    float* gw2, float* gb2, float* sh) {
+  time_backward_prepare(w1, b1, w2, ksteps, Kft, td, sh);
+  time_backward_finish(G_in, Kft, td, gw1, gb1, gw2, gb2, sh);
 }
 __global__ __launch_bounds__(256) void time_backward_kernel(const float* w1, const float* b1, const float* w2,
                                                             const float* G_in, const dppo_step* ksteps, int Kft, int td,
@@ -889,7 +912,6 @@ void launch_wout_grad(const PostReduce& q, hipStream_t s) {
 
 __global__ __launch_bounds__(256) void post_reduce_kernel(const PostReduce q) {
   extern __shared__ float sh[];
-  __shared__ bool last;
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= q.n_lowrank + q.n_temb) {
     wout_grad_block(q, blockIdx.x - q.n_lowrank - q.n_temb);
@@ -913,15 +935,26 @@ __global__ __launch_bounds__(256) void post_reduce_kernel(const PostReduce q) {
     if (lane == 0) q.G[out] = acc;
   }
   __syncthreads();
+  // The time MLP's backward belongs to the LAST block of the range: it prepares everything that does not depend on G while
+  // the others finish, then waits for their arrivals.  (Workgroups are dispatched in index order, so every block it waits
+  // for is already running or done: the wait cannot starve them.)
+  if (tb != q.n_temb - 1) {
+    if (tid == 0) {
+      __threadfence();
+      atomicAdd(q.counter, 1u);
+    }
+    return;
+  }
+  time_backward_prepare(q.w1, q.b1, q.w2, q.ksteps, q.Kft, q.td, sh);
   if (tid == 0) {
     __threadfence();
-    last = atomicAdd(q.counter, 1u) == (unsigned)q.n_temb - 1;
+    while (__hip_atomic_load(q.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)q.n_temb - 1)
+      __builtin_amdgcn_s_sleep(2);
+    __threadfence();
+    *q.counter = 0;  // ready for the next call
   }
   __syncthreads();
-  if (!last) return;
-  __threadfence();
-  if (tid == 0) *q.counter = 0;  // ready for the next call
-  time_backward_block(q.w1, q.b1, q.w2, q.G, q.ksteps, q.Kft, q.td, q.gw1, q.gb1, q.gw2, q.gb2, sh);
+  time_backward_finish(q.G, q.Kft, q.td, q.gw1, q.gb1, q.gw2, q.gb2, sh);
 }
 void launch_post_reduce(PostReduce& q, hipStream_t s) {
   q.n_lowrank = q.dW != nullptr ? (int)(((size_t)q.H * q.H + 255) / 256) : 0;
@@ -983,8 +1016,7 @@ void launch_slab_reduce_2d(const float* slab, int splits, int rows, int cols, in
                      cols, lds, out, ldo, scale, transpose);
 }
 
-__global__ __launch_bounds__(256) void slab_reduce_batch_kernel(const SlabJobs jobs) {
-  const SlabJob J = jobs.j[blockIdx.y];
+__device__ __forceinline__ void slab_job_block(const SlabJob& J) {
   const size_t n = (size_t)J.rows * J.cols;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int r = (int)(i / J.cols), c = (int)(i % J.cols);
@@ -1001,6 +1033,65 @@ __global__ __launch_bounds__(256) void slab_reduce_batch_kernel(const SlabJobs j
     else
       J.out[(size_t)r * J.ldo + c] = v;
   }
+}
+__global__ __launch_bounds__(256) void slab_reduce_batch_kernel(const SlabJobs jobs) { slab_job_block(jobs.j[blockIdx.y]); }
+
+// Everything that only waits for a backward pass's weight-gradient GEMMs and data-gradient kernel, in ONE launch of
+// 1024-thread blocks: the slab reductions (blockIdx.y = job), the bias gradients = per-tile column sums of the fused
+// backward reduced over tiles (one y per slot, 64 columns per block: reduce_slots_kernel's body), and the loss statistics
+// (one block).  They were three launches on two streams; the second stream's join was a barrier packet (~5 us) between the
+// GEMMs and the reductions on the update's critical path.
+__global__ __launch_bounds__(1024) void tail_reduce_kernel(const TailReduce t) {
+  const int y = blockIdx.y;
+  if (y < t.jobs.n) {
+    slab_job_block(t.jobs.j[y]);
+    return;
+  }
+  if (y < t.jobs.n + t.slots.n_slots) {
+    __shared__ float red[16][65];
+    const int slot = y - t.jobs.n, n = t.width;
+    if ((int)blockIdx.x * 64 >= n) return;
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const float* src = t.colsum + (size_t)slot * t.tiles * n;
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < n && t.slots.n[slot] > 0) {
+      int r = rl;
+      for (; r + 48 < t.tiles; r += 64) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] += src[(size_t)(r + 16 * u) * n + c];
+      }
+      for (; r < t.tiles; r += 16) p[0] += src[(size_t)r * n + c];
+    }
+    red[rl][cl] = (p[0] + p[1]) + (p[2] + p[3]);
+    __syncthreads();
+    if (rl == 0 && c < t.slots.n[slot]) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s += red[i][cl];
+      t.slots.out[slot][c] = s;
+    }
+    return;
+  }
+  if (blockIdx.x == 0) loss_finalize_block(t.fin_partial, t.fin_blocks, t.fin_moments, t.fin_stats, t.fin_part, t.fin_n_count);
+}
+void launch_tail_reduce(TailReduce& t, const LossArgs* fin, hipStream_t s) {
+  size_t most = 0;
+  for (int i = 0; i < t.jobs.n; ++i) {
+    const size_t n = (size_t)t.jobs.j[i].rows * t.jobs.j[i].cols;
+    most = n > most ? n : most;
+  }
+  const bool has_fin = fin != nullptr && fin->N > 0;
+  if (has_fin) {
+    t.fin_partial = fin->partial, t.fin_blocks = loss_blocks(fin->N), t.fin_moments = fin->moments, t.fin_stats = fin->stats;
+    t.fin_part = fin->part, t.fin_n_count = fin->n_count;
+  }
+  unsigned gx = (unsigned)((most + 1023) / 1024);
+  const unsigned gs = t.slots.n_slots > 0 ? (unsigned)((t.width + 63) / 64) : 0;
+  gx = gx > gs ? gx : gs;
+  const unsigned gy = (unsigned)(t.jobs.n + t.slots.n_slots + (has_fin ? 1 : 0));
+  if (gx == 0) gx = 1;
+  if (gy > 0) hipLaunchKernelGGL(tail_reduce_kernel, dim3(gx, gy), dim3(1024), 0, s, t);
 }
 void launch_slab_reduce_batch(const SlabJobs& jobs, hipStream_t s) {
   if (jobs.n <= 0) return;
