@@ -2387,6 +2387,10 @@ int dppo_tune_set(int knob, int value) {
     g_post_one = value;
     return 0;
   }
+  if (knob == 25) {  // one-block kernels: short layers walked without their padding k-steps (1, default) or padded (0)
+    set_fused_compact(value);
+    return 0;
+  }
   if (knob == 23) {  // fused backward of one-block networks: the specialised kernel (1, default) or the general one (0)
     set_fused_bwd_one(value);
     return 0;

@@ -94,6 +94,7 @@ int fused_rows_per_tile(const dppo_net_desc& d, bool one_block = false);  // row
 template <class P>
 bool fused_bwd_one_block(const dppo_net_desc& d);  // shape covered by fused_backward_one_kernel (the caller adds: low-rank dW2 on)
 void set_fused_bwd_one(int v);  // tuning knob 23
+void set_fused_compact(int v);  // tuning knob 25
 
 // Fragment packing of a whole stream in ONE launch: layer l occupies positions [pos0, pos0 + KS); element
 // (feature f, contraction index k) of its weight matrix is W[f*rs + k*cs] (rs = ld, cs = 1 for W; rs = 1, cs = ld for W^T)

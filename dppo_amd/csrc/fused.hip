@@ -141,6 +141,107 @@ __device__ __forceinline__ void hand_over(volatile uint32_t* flags, int wid, int
   asm volatile("" ::: "memory");
 }
 
+// The one-block kernels' walk of a weight stream, without the padding of its short layers.  A stream position is one
+// k-step of one layer, and the ring wants every layer to be a multiple of its depth long (slot = k-step mod depth is then a
+// compile-time register index): the layers on the input tile (K = in_dim) and on the d_out tile (K = out_dim) are padded
+// to 4 k-steps of which 1-2 carry data -- 2 x 3 of the backward's 24 positions per tile, 2 of the merged forward's 20,
+// streamed and multiplied for nothing in kernels whose k-loops are paced by exactly that stream.  Here a tile is a FIXED
+// sequence of S1 + KSH + S2 real positions (short layer, H-wide layer, short layer) padded with holes -- positions that
+// are never loaded -- to a multiple of the depth, so that slots stay compile-time and every tile starts at slot 0.
+template <class P, int TPW, int MR, int S1, int KSH, int S2>
+struct CEngine {
+  static constexpr int PD = 4, T = S1 + KSH + S2, HOLES = (PD - T % PD) % PD, TT = T + HOLES;
+  static_assert(KSH % PD == 0 && S1 >= 1 && S1 <= PD && S2 >= 0 && S2 <= PD && T >= PD, "CEngine layout");
+  u32x4 ring[PD][TPW];
+  const u32x4* stream;  // this wave's stream + lane
+  int p1, pl, p2;       // stream positions where the three segments start
+
+  __device__ __forceinline__ int phys(int c) const {  // compact position of a tile -> stream position, -1 for a hole
+    return c < S1 ? p1 + c : (c < S1 + KSH ? pl + (c - S1) : (c < T ? p2 + (c - S1 - KSH) : -1));
+  }
+  template <int SLOT>
+  __device__ __forceinline__ void refill(int c) {  // the slot gave up compact position c: fetch c + PD (of the next tile, maybe)
+    int n = c + PD;
+    n = n >= TT ? n - TT : n;
+    int q = phys(n);
+    q = q >= 0 ? q : p1;  // a hole: straight-line code beats a skipped load (a branch in the k-loop costs registers and time)
+    const u32x4* w = stream + (size_t)q * TPW * 64;
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) ring[SLOT][tp] = w[tp * 64];
+  }
+  __device__ __forceinline__ void prime(const u32x4* s, int p1_, int pl_, int p2_) {
+    stream = s, p1 = p1_, pl = pl_, p2 = p2_;
+#pragma unroll
+    for (int p = 0; p < PD; ++p) {
+      const u32x4* w = s + (size_t)phys(p) * TPW * 64;
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp) ring[p][tp] = w[tp * 64];
+    }
+  }
+  template <int SLOT>
+  __device__ __forceinline__ void step(f32x4 (&acc)[TPW][MR], const char* src, int rb, int km, int ks, int c, int r, int g) {
+    u32x4 xb[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) xb[m] = *(const u32x4*)(src + (16 * m + r) * rb + (((ks * 4 + g) ^ (r & km)) << 4));
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+      for (int m = 0; m < MR; ++m) acc[tp][m] = P::mma(ring[SLOT][tp], xb[m], acc[tp][m]);
+    refill<SLOT>(c);
+  }
+  // acc += (first short layer) . src^T : k-steps 0 .. S1-1 of src
+  __device__ __forceinline__ void short1(f32x4 (&acc)[TPW][MR], const char* src, int rb, int km, int r, int g) {
+    if constexpr (S1 >= 1) step<0>(acc, src, rb, km, 0, 0, r, g);
+    if constexpr (S1 >= 2) step<1>(acc, src, rb, km, 1, 1, r, g);
+    if constexpr (S1 >= 3) step<2>(acc, src, rb, km, 2, 2, r, g);
+    if constexpr (S1 >= 4) step<3>(acc, src, rb, km, 3, 3, r, g);
+  }
+  // acc += (H-wide layer) . src^T, with the flag waits of Engine::run (KSH / 8 k-steps per producer wave)
+  __device__ __forceinline__ void wide(f32x4 (&acc)[TPW][MR], const char* src, int rb, int km, int r, int g,
+                                       const volatile uint32_t* flags = nullptr, uint32_t need = 0) {
+    uint32_t ready = 0xffu;
+    constexpr int kpp_shift = KSH >= 64 ? 3 : (KSH >= 32 ? 2 : (KSH >= 16 ? 1 : 0));
+    if (flags != nullptr) {
+      ready = 0;
+      const u32x4 f0 = *(const volatile u32x4*)flags, f1 = *(const volatile u32x4*)(flags + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)f0[i]) - need) >= 0) ready |= 1u << i;
+        if ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)f1[i]) - need) >= 0) ready |= 16u << i;
+      }
+      asm volatile("" ::: "memory");
+    }
+    for (int k0 = 0; k0 < KSH; k0 += PD) {
+      if (ready != 0xffu) {
+        const int p_lo = k0 >> kpp_shift, p_hi = (k0 + PD - 1) >> kpp_shift;
+        const uint32_t grp = ((2u << p_hi) - 1u) & ~((1u << p_lo) - 1u);
+        if (grp & ~ready) {
+          for (int p = p_lo; p <= p_hi; ++p)
+            while ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)flags[p]) - need) < 0) __builtin_amdgcn_s_sleep(1);
+          ready |= grp;
+          asm volatile("" ::: "memory");
+        }
+      }
+      step<(S1 + 0) % PD>(acc, src, rb, km, k0 + 0, S1 + k0 + 0, r, g);
+      step<(S1 + 1) % PD>(acc, src, rb, km, k0 + 1, S1 + k0 + 1, r, g);
+      step<(S1 + 2) % PD>(acc, src, rb, km, k0 + 2, S1 + k0 + 2, r, g);
+      step<(S1 + 3) % PD>(acc, src, rb, km, k0 + 3, S1 + k0 + 3, r, g);
+    }
+  }
+  // acc += (last short layer) . src^T : k-steps 0 .. S2-1 of src
+  __device__ __forceinline__ void short2(f32x4 (&acc)[TPW][MR], const char* src, int rb, int km, int r, int g) {
+    if constexpr (S2 >= 1) step<(S1 + 0) % PD>(acc, src, rb, km, 0, S1 + KSH + 0, r, g);
+    if constexpr (S2 >= 2) step<(S1 + 1) % PD>(acc, src, rb, km, 1, S1 + KSH + 1, r, g);
+    if constexpr (S2 >= 3) step<(S1 + 2) % PD>(acc, src, rb, km, 2, S1 + KSH + 2, r, g);
+    if constexpr (S2 >= 4) step<(S1 + 3) % PD>(acc, src, rb, km, 3, S1 + KSH + 3, r, g);
+  }
+  __device__ __forceinline__ void end_tile() {  // the holes' slots take the next tile's positions
+    if constexpr (HOLES >= 1) refill<(T + 0) % PD>(T + 0);
+    if constexpr (HOLES >= 2) refill<(T + 1) % PD>(T + 1);
+    if constexpr (HOLES >= 3) refill<(T + 2) % PD>(T + 2);
+  }
+};
+
 // ReLU'(x) of a lane's 4*TPW features of one row is a bit mask: the forward stores it as one 32-bit word per (row, wave,
 // lane group g) -- [M][SIGN_WORDS] -- and the backward reads 128 bytes per row instead of the whole activated tensor.
 constexpr int SIGN_WORDS = 32;  // 8 waves x 4 lane groups
@@ -492,9 +593,12 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_forward_kernel(const Fused
 // is never run, h_1 is never formed or stored, and the out layer costs what it did: its K = H pass now reads act(z1)
 // with the fragments of Wout W2 (the sampler's ostream2), and the K = in_dim pass on the input tile is 2-3 k-steps.
 // The weight-gradient side (api.hip, mlp_backward): dWout = d_out^T h_1 is rebuilt from U = d_out^T x and T = d_out^T act(z1).
-template <class P, int TPW, int MR, int OT, int ACT>
+// S1 > 0 (ring depth 4): the input tile's layer is walked as its S1 = ks0v <= 2 k-steps that hold data instead of the
+// padded four (CEngine); S1 = 0: the padded walk.
+template <class P, int TPW, int MR, int OT, int ACT, int S1>
 __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const FusedFwdArgs a) {
   constexpr int PD = ring_depth<TPW, MR>(), ES = P::ESIZE, KB = P::KB;
+  static_assert(S1 == 0 || PD == 4, "the compact walk is written for a ring of four positions");
   constexpr int H = 128 * TPW, KSH = H / KB, HRB = H * ES, MT = 16 * MR;
   constexpr int KSPLIT = MR * OT >= 8 ? 1 : 8 / (MR * OT);
   constexpr int KPER = KSH / KSPLIT, NITEMS = MR * OT * KSPLIT, NI = (NITEMS + SAMPLER_WAVES - 1) / SAMPLER_WAVES;
@@ -524,8 +628,11 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
   uint32_t seq = 0;
   // (visible after the first tile's barrier)
 
-  Engine<P, TPW, MR, PD> eng;
-  eng.prime(a.wstream + (size_t)wid * total * TPW * 64 + lane, total - KSH);
+  typename std::conditional<(S1 > 0), CEngine<P, TPW, MR, (S1 > 0 ? S1 : 1), KSH, 0>, Engine<P, TPW, MR, PD>>::type eng;
+  if constexpr (S1 > 0)
+    eng.prime(a.wstream + (size_t)wid * total * TPW * 64 + lane, 0, KS0, 0);
+  else
+    eng.prime(a.wstream + (size_t)wid * total * TPW * 64 + lane, total - KSH);
 
   const int ntiles = (M + MT - 1) / MT;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -546,7 +653,10 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
     // ---- layer 0, and the out layer's first pass on the same input tile: work item it = (row sub-tile m, out tile to,
     // K slice kh) belongs to wave it % 8 in both passes, so the partial result waits in registers
     bias_init(0);
-    eng.run(acc, xin, in_rb, in_km, KS0, r, g);
+    if constexpr (S1 > 0)
+      eng.short1(acc, xin, in_rb, in_km, r, g);
+    else
+      eng.run(acc, xin, in_rb, in_km, KS0, r, g);
     STAMP(2);
     f32x4 o1[NI];
 #pragma unroll
@@ -570,7 +680,12 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
     STAMP(4);
     // ---- the block's first layer
     bias_init(1);
-    eng.run(acc, bufA, HRB, 15, KSH, r, g, FLAGS ? flags : nullptr, seq);
+    if constexpr (S1 > 0) {
+      eng.wide(acc, bufA, HRB, 15, r, g, FLAGS ? flags : nullptr, seq);
+      eng.end_tile();
+    } else {
+      eng.run(acc, bufA, HRB, 15, KSH, r, g, FLAGS ? flags : nullptr, seq);
+    }
     STAMP(5);
     emit<P, TPW, MR>(acc, ACT, bufB, a.a2[0], H, wbase, g, r, row0, M, a.z1[0]);  // z1[0] <- act'(z1) (Mish) / sign words
     STAMP(6);
@@ -848,9 +963,12 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
 // latency hides under it), and at H = 256 room for the forward's 128-row tile (half the weight stream per row).  The stream
 // is the ordinary backward stream [Wout^T | (Wout W2)^T | W1^T] walked from its second layer on: the ring wraps at the end
 // of a tile anyway.  Needs the low-rank dW2 (no dh_1 tensor is written).
-template <class P, int TPW, int MR, int ACT>
+// COMPACT (out_dim <= one k-step, ring depth 4): the two layers on the d_out tile are walked as ONE k-step each instead of
+// their padded four (CEngine).
+template <class P, int TPW, int MR, int ACT, bool COMPACT>
 __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedBwdArgs a) {
   constexpr int ES = P::ESIZE, KB = P::KB, PD = ring_depth<TPW, MR>();
+  static_assert(!COMPACT || PD == 4, "the compact walk is written for a ring of four positions");
   constexpr int H = 128 * TPW, KSH = H / KB, HRB = H * ES, MT = 16 * MR;
   constexpr bool FLAGS = DPPO_FLAGS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -869,8 +987,11 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
   const int wbase = wid * 16 * TPW;
   const int ntiles = (M + MT - 1) / MT;
 
-  Engine<P, TPW, MR, PD> eng;
-  eng.prime(a.bstream + (size_t)wid * total * TPW * 64 + lane, total, KSB0);
+  typename std::conditional<COMPACT, CEngine<P, TPW, MR, 1, KSH, 1>, Engine<P, TPW, MR, PD>>::type eng;
+  if constexpr (COMPACT)
+    eng.prime(a.bstream + (size_t)wid * total * TPW * 64 + lane, KSB0, 2 * KSB0, 0);
+  else
+    eng.prime(a.bstream + (size_t)wid * total * TPW * 64 + lane, total, KSB0);
   if (tid < 16) flags[tid] = 0;  // (visible after the first tile's barrier)
   uint32_t seq = 0;
 
@@ -920,7 +1041,10 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
     // ---- dz1 = (dh_1 . W2) o act'(z1), dh_1 . W2 = d_out . (Wout . W2): a K = out_dim layer on the d_out tile
     fetch<P, ACT == ACT_RELU, TPW>(d, a.m1[0], H, wbase, g, r, row0, M);
     zero_acc();
-    eng.run(acc, xin, in_rb, in_km, KSB0, r, g);
+    if constexpr (COMPACT)
+      eng.short1(acc, xin, in_rb, in_km, r, g);
+    else
+      eng.run(acc, xin, in_rb, in_km, KSB0, r, g);
     STAMP(22);
 #pragma unroll
     for (int tp = 0; tp < TPW; ++tp)
@@ -940,7 +1064,10 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
     // ---- dh_0 = (dz1 . W1) o act'(h_0) + d_out . Wout
     fetch<P, ACT == ACT_RELU, TPW>(d, a.m0[0], H, wbase, g, r, row0, M);
     zero_acc();
-    eng.run(acc, bufA, HRB, 15, KSH, r, g, FLAGS ? flags : nullptr, seq);
+    if constexpr (COMPACT)
+      eng.wide(acc, bufA, HRB, 15, r, g, FLAGS ? flags : nullptr, seq);
+    else
+      eng.run(acc, bufA, HRB, 15, KSH, r, g, FLAGS ? flags : nullptr, seq);
     STAMP(26);
     if (a.dout_slot >= 0 && tid < a.KpB0) {  // part 2 (every wave has passed part 1: its flag / the barrier came later)
       float t = 0.f;
@@ -954,7 +1081,12 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
       for (int m = 0; m < MR; ++m)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[tp][m][e] *= grad_at<P, ACT>(d, tp, m, e);
-    eng.run(acc, xin, in_rb, in_km, KSB0, r, g);
+    if constexpr (COMPACT) {
+      eng.short2(acc, xin, in_rb, in_km, r, g);
+      eng.end_tile();
+    } else {
+      eng.run(acc, xin, in_rb, in_km, KSB0, r, g);
+    }
     emit<P, TPW, MR>(acc, ACT_NONE, nullptr, a.dh[0], H, wbase, g, r, row0, M);
     STAMP(27);
     colsum(acc, 1, tile);
@@ -1085,19 +1217,28 @@ bool fused_can_merge(const dppo_net_desc& d) {
 template bool fused_can_merge<F32>(const dppo_net_desc&);
 template bool fused_can_merge<BF16>(const dppo_net_desc&);
 
-template <class P, int TPW, int MR, int ACT>
-static int launch_fwd_merged_cfg(const FusedFwdArgs& a, hipStream_t s) {
+template <class P, int TPW, int MR, int ACT, int S1>
+static int launch_fwd_merged_cfg2(const FusedFwdArgs& a, hipStream_t s) {
   constexpr int MT = 16 * MR, H = 128 * TPW;
   const size_t lds = merged_lds<P>(H, 1, a.ks0v);
   if (lds > 160 * 1024 || a.Kp0 > H || a.nb != 1) return -2;
   static DevLatch attr;
-  raise_lds(fused_forward_merged_kernel<P, TPW, MR, 1, ACT>, attr);
+  raise_lds(fused_forward_merged_kernel<P, TPW, MR, 1, ACT, S1>, attr);
   const int ntiles = (a.M + MT - 1) / MT;
   const bool probe = probe_begin(PROBE_FUSED_FWD, s);
-  hipLaunchKernelGGL((fused_forward_merged_kernel<P, TPW, MR, 1, ACT>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512),
+  hipLaunchKernelGGL((fused_forward_merged_kernel<P, TPW, MR, 1, ACT, S1>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512),
                      lds, s, a);
   if (probe) probe_end(s, 2.0 * a.M * ((double)a.in_valid * H + 2.0 * a.nb * H * H + (double)H * a.out_dim));
   return 0;
+}
+int fused_compact_on();
+template <class P, int TPW, int MR, int ACT>
+static int launch_fwd_merged_cfg(const FusedFwdArgs& a, hipStream_t s) {
+  if constexpr (ring_depth<TPW, MR>() == 4) {
+    if (fused_compact_on() && a.ks0v == 1) return launch_fwd_merged_cfg2<P, TPW, MR, ACT, 1>(a, s);
+    if (fused_compact_on() && a.ks0v == 2) return launch_fwd_merged_cfg2<P, TPW, MR, ACT, 2>(a, s);
+  }
+  return launch_fwd_merged_cfg2<P, TPW, MR, ACT, 0>(a, s);
 }
 
 template <class P>
@@ -1157,18 +1298,29 @@ static int launch_bwd_cfg(const FusedBwdArgs& a, hipStream_t s) {
   return 0;
 }
 
-template <class P, int TPW, int MR, int ACT>
-static int launch_bwd_one_cfg(const FusedBwdArgs& a, hipStream_t s) {
+static int g_compact = 1;  // tuning knob 25: the one-block kernels skip the padding k-steps of their short layers (CEngine)
+void set_fused_compact(int v) { g_compact = v; }
+int fused_compact_on() { return g_compact; }
+template <class P, int TPW, int MR, int ACT, bool COMPACT>
+static int launch_bwd_one_cfg2(const FusedBwdArgs& a, hipStream_t s) {
   constexpr int ES = P::ESIZE, MT = 16 * MR, H = 128 * TPW;
   const size_t lds = 2 * (size_t)MT * H * ES + 64 + SAMPLER_WAVES * 128 * 4;
   if (lds > 160 * 1024 || a.KpB0 > H || a.KpB0 > 128 || a.nb != 1) return -2;
   static DevLatch attr;
-  raise_lds(fused_backward_one_kernel<P, TPW, MR, ACT>, attr);
+  raise_lds(fused_backward_one_kernel<P, TPW, MR, ACT, COMPACT>, attr);
   const int ntiles = (a.M + MT - 1) / MT;
   const bool probe = probe_begin(PROBE_FUSED_BWD, s);
-  hipLaunchKernelGGL((fused_backward_one_kernel<P, TPW, MR, ACT>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((fused_backward_one_kernel<P, TPW, MR, ACT, COMPACT>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512),
+                     lds, s, a);
   if (probe) probe_end(s, 2.0 * a.M * ((double)a.out_valid * H + 2.0 * a.nb * H * H));
   return 0;
+}
+template <class P, int TPW, int MR, int ACT>
+static int launch_bwd_one_cfg(const FusedBwdArgs& a, hipStream_t s) {
+  if constexpr (ring_depth<TPW, MR>() == 4) {
+    if (g_compact && a.out_valid <= P::KB) return launch_bwd_one_cfg2<P, TPW, MR, ACT, true>(a, s);
+  }
+  return launch_bwd_one_cfg2<P, TPW, MR, ACT, false>(a, s);
 }
 
 template <class P>
