@@ -153,6 +153,17 @@ __device__ __forceinline__ float philox_normal(uint64_t idx, uint32_t k0, uint32
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// Sum over the 16 lanes of a DPP row (lanes with the same lane >> 4), every lane gets the total: four VALU adds with a DPP
+// operand (quad_perm xor 1, xor 2, row_half_mirror, row_mirror) instead of four ds_bpermute round trips through the LDS
+// crossbar (__shfl_xor by 1, 2, 4, 8).  Same pairing of the partial sums as the xor butterfly: bit-identical results.
+__device__ __forceinline__ float row16_sum(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));
+  return x;
+}
+
 // Which features of its wave's 16*TPW-feature slice a lane owns in the streamed-weight kernels (sampler, fused):
 // MFMA output row i = 4g + e of tile tp is feature feat_off(g, tp) + e.  Tiles are grouped so that one 16-byte chunk
 // (EPC = 16 / ESIZE elements) holds consecutive features of ONE lane and the four lanes g = 0..3 own four consecutive

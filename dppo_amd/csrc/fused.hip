@@ -31,6 +31,14 @@ __device__ unsigned long long g_stamps[8][32];
 
 namespace {
 
+// the layer hand-over flags live in LDS and are accessed as workgroup-scope relaxed atomics through an LDS-address-space
+// pointer: `volatile` on a generic pointer compiles to FLAT accesses with system coherence bits and an s_waitcnt vmcnt(0)
+// behind each one -- every flag access then drained the weight ring and the emit's stores
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ uint32_t flag_load(lds_u32* f) {
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+
 __device__ __forceinline__ int kmask16(int rb) {
   const int n = rb >> 4;
   const int p = n & (-n);
@@ -80,17 +88,14 @@ struct Engine {
   // features of k-steps [p nks/8, (p+1) nks/8) and then sets flags[p] = need, see hand_over()): each group of PD k-steps
   // first makes sure its producers have arrived -- no workgroup barrier between two layers.
   __device__ __forceinline__ void run(f32x4 (&acc)[TPW][MR], const char* src, int rb, int km, int nks, int r, int g,
-                                      const volatile uint32_t* flags = nullptr, uint32_t need = 0) {
+                                      lds_u32* flags = nullptr, uint32_t need = 0) {
     uint32_t ready = 0xffu;
     const int kpp_shift = 28 - __builtin_clz((unsigned)(nks | 8));  // log2(k-steps per producer wave): nks = 8, 16, 32, 64 with flags
     if (flags != nullptr) {
       ready = 0;
-      const u32x4 f0 = *(const volatile u32x4*)flags, f1 = *(const volatile u32x4*)(flags + 4);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)f0[i]) - need) >= 0) ready |= 1u << i;
-        if ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)f1[i]) - need) >= 0) ready |= 16u << i;
-      }
+      for (int i = 0; i < 8; ++i)
+        if ((int32_t)(flag_load(flags + i) - need) >= 0) ready |= 1u << i;
       asm volatile("" ::: "memory");  // the image reads below stay behind the flag reads
     }
     for (int k0 = 0; k0 < nks; k0 += PD) {
@@ -99,7 +104,7 @@ struct Engine {
         const uint32_t grp = ((2u << p_hi) - 1u) & ~((1u << p_lo) - 1u);
         if (grp & ~ready) {
           for (int p = p_lo; p <= p_hi; ++p)
-            while ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)flags[p]) - need) < 0) __builtin_amdgcn_s_sleep(1);
+            while ((int32_t)(flag_load(flags + p) - need) < 0) __builtin_amdgcn_s_sleep(1);
           ready |= grp;
           asm volatile("" ::: "memory");
         }
@@ -135,9 +140,9 @@ struct Engine {
 // What it buys: the two waves of a SIMD drift apart (the older one wins the MFMA arbitration), and one's emit phase
 // (activation, stores, column sums) then runs under the other's MFMAs instead of both waiting at the barrier for the
 // slower one: profiles/r01_h_fused_phase_stamps.txt shows 3.5-6.5k cycles of barrier wait per layer.
-__device__ __forceinline__ void hand_over(volatile uint32_t* flags, int wid, int lane, uint32_t seq) {
+__device__ __forceinline__ void hand_over(lds_u32* flags, int wid, int lane, uint32_t seq) {
   asm volatile("" ::: "memory");  // the emit's LDS stores stay ahead of the flag store
-  if (lane == 0) flags[wid] = seq;
+  if (lane == 0) __hip_atomic_store(flags + wid, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   asm volatile("" ::: "memory");
 }
 
@@ -198,17 +203,14 @@ struct CEngine {
   }
   // acc += (H-wide layer) . src^T, with the flag waits of Engine::run (KSH / 8 k-steps per producer wave)
   __device__ __forceinline__ void wide(f32x4 (&acc)[TPW][MR], const char* src, int rb, int km, int r, int g,
-                                       const volatile uint32_t* flags = nullptr, uint32_t need = 0) {
+                                       lds_u32* flags = nullptr, uint32_t need = 0) {
     uint32_t ready = 0xffu;
     constexpr int kpp_shift = KSH >= 64 ? 3 : (KSH >= 32 ? 2 : (KSH >= 16 ? 1 : 0));
     if (flags != nullptr) {
       ready = 0;
-      const u32x4 f0 = *(const volatile u32x4*)flags, f1 = *(const volatile u32x4*)(flags + 4);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)f0[i]) - need) >= 0) ready |= 1u << i;
-        if ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)f1[i]) - need) >= 0) ready |= 16u << i;
-      }
+      for (int i = 0; i < 8; ++i)
+        if ((int32_t)(flag_load(flags + i) - need) >= 0) ready |= 1u << i;
       asm volatile("" ::: "memory");
     }
     for (int k0 = 0; k0 < KSH; k0 += PD) {
@@ -217,7 +219,7 @@ struct CEngine {
         const uint32_t grp = ((2u << p_hi) - 1u) & ~((1u << p_lo) - 1u);
         if (grp & ~ready) {
           for (int p = p_lo; p <= p_hi; ++p)
-            while ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)flags[p]) - need) < 0) __builtin_amdgcn_s_sleep(1);
+            while ((int32_t)(flag_load(flags + p) - need) < 0) __builtin_amdgcn_s_sleep(1);
           ready |= grp;
           asm volatile("" ::: "memory");
         }
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_forward_kernel(const Fused
   // (KSPLIT*OT <= 8 sub-tiles of 1 KB per 16 rows <= 16*H*ES always)
   float* part = (float*)bufB;
   static_assert(KSPLIT * OT * 16 * 16 * 4 <= 16 * HRB, "out-layer partials must fit in buffer B");
-  volatile uint32_t* flags = (volatile uint32_t*)(bufB + MT * HRB);  // [16 words]
+  lds_u32* flags = (lds_u32*)(bufB + MT * HRB);              // [16 words]
   float* lnred = (float*)(bufB + MT * HRB + 64);  // [8 waves][MR][16] LayerNorm row-reduction table (LN only)
   // Constants of the whole launch, staged once per workgroup where LDS allows (the launcher decides, a.consts_lds):
   // a global load issued at a layer's start waits behind every weight fragment the ring has in flight (vmcnt is in
@@ -615,7 +617,7 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
   char* xin = bufB;             // the input tile is dead once layer 0 and the out layer's first pass have run
   float* part = (float*)bufA;   // out-layer partials: the K = H pass reads buffer B
   static_assert(KSPLIT * OT * 16 * 16 * 4 <= 16 * HRB, "out-layer partials must fit in buffer A");
-  volatile uint32_t* flags = (volatile uint32_t*)(bufB + MT * HRB);  // [16 words]
+  lds_u32* flags = (lds_u32*)(bufB + MT * HRB);              // [16 words]
   float* biasL = (float*)(bufB + MT * HRB + 64);                       // [2][H] b0, b1, then [OT*16] the out constant
   u32x4* woutL = (u32x4*)(biasL + ((2 * H + OT * 16 + 3) & ~3));       // [KSH][OT][64] fragments of Wout W2
   u32x4* w0cL = woutL + KSH * OT * 64;                                 // [ks0v][OT][64] fragments of Wout W0
@@ -754,7 +756,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
   char* bufA = smem;
   char* bufB = bufA + MT * HRB;
   char* xin = bufB;  // d_out tile: consumed by the first layer and by the top block's composite layer
-  volatile uint32_t* flags = (volatile uint32_t*)(bufB + MT * HRB);  // [16 words]
+  lds_u32* flags = (lds_u32*)(bufB + MT * HRB);              // [16 words]
   float* lnred = (float*)(bufB + MT * HRB + 64);  // [8 waves][2][MR][16] LayerNorm row-reduction table (LN only)
   constexpr int DRED_COLS = 128;             // d_out is at most 128 columns wide
   float* dred = lnred + (LN ? LN_WAVES * 2 * MR * 16 : 0);  // [8 waves][128] column sums of the d_out tile
@@ -775,12 +777,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
       for (int m = 1; m < MR; ++m) s += v[tp][m];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float x = s[e];
-        x += __shfl_xor(x, 1);
-        x += __shfl_xor(x, 2);
-        x += __shfl_xor(x, 4);
-        x += __shfl_xor(x, 8);
-        s[e] = x;
+        s[e] = row16_sum(s[e]);
       }
       if (r == 0) *(f32x4*)(a.colsum + ((size_t)slot * ntiles + tile) * H + wbase + feat_off<P>(g, tp)) = s;
     }
@@ -792,12 +789,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
       f32x4 s = v[tp];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float x = s[e];
-        x += __shfl_xor(x, 1);
-        x += __shfl_xor(x, 2);
-        x += __shfl_xor(x, 4);
-        x += __shfl_xor(x, 8);
-        s[e] = x;
+        s[e] = row16_sum(s[e]);
       }
       if (r == 0) *(f32x4*)(a.colsum + ((size_t)slot * ntiles + tile) * H + wbase + feat_off<P>(g, tp)) = s;
     }
@@ -819,7 +811,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
     STAMP(17);
     if (a.dout_slot >= 0) {  // out-layer bias gradient: column sums of the d_out tile (rows past M are zero), part 1:
       typedef typename P::elem_t E;  // wave w adds rows w, w + 8, ...; lane = column
-      for (int c = lane; c < a.KpB0; c += 64) {
+      for (int c = lane; c < a.out_valid; c += 64) {  // (columns past out_dim are zero padding)
         const int cb = c * ES;
         float t = 0.f;
         for (int row = wid; row < MT; row += SAMPLER_WAVES)
@@ -848,7 +840,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
     colsum(dh, 0, tile);
     STAMP(20);
     auto dout_sums = [&]() {  // part 2: the eight waves' partial sums
-      if (a.dout_slot >= 0 && tid < a.KpB0) {
+      if (a.dout_slot >= 0 && tid < a.out_valid) {
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < SAMPLER_WAVES; ++w) t += dred[w * DRED_COLS + tid];
@@ -981,7 +973,7 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
   char* bufA = smem;
   char* bufB = bufA + MT * HRB;
   char* xin = bufB;  // the d_out tile: read by the composite layer first and by the Wout^T layer last
-  volatile uint32_t* flags = (volatile uint32_t*)(bufB + MT * HRB);  // [16 words]
+  lds_u32* flags = (lds_u32*)(bufB + MT * HRB);              // [16 words]
   constexpr int DRED_COLS = 128;
   float* dred = (float*)(bufB + MT * HRB + 64);  // [8 waves][128] column sums of the d_out tile
   const int wbase = wid * 16 * TPW;
@@ -1003,12 +995,7 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
       for (int m = 1; m < MR; ++m) s += v[tp][m];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float x = s[e];
-        x += __shfl_xor(x, 1);
-        x += __shfl_xor(x, 2);
-        x += __shfl_xor(x, 4);
-        x += __shfl_xor(x, 8);
-        s[e] = x;
+        s[e] = row16_sum(s[e]);
       }
       if (r == 0) *(f32x4*)(a.colsum + ((size_t)slot * ntiles + tile) * H + wbase + feat_off<P>(g, tp)) = s;
     }
@@ -1017,12 +1004,15 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int row0 = tile * MT;
     STAMP(16);
+    // the first phase's derivative sources: issued with the tile's own loads, so that one memory latency covers both
+    u32x4 d[MR][Chunks<P, TPW>::CH];
+    fetch<P, ACT == ACT_RELU, TPW>(d, a.m1[0], H, wbase, g, r, row0, M);
     load_tile<MT>(xin, in_rb, in_km, (const char*)a.d_out, a.ld_dout * ES, row0, M);
     __syncthreads();
     STAMP(17);
     if (a.dout_slot >= 0) {  // out-layer bias gradient: column sums of the d_out tile (rows past M are zero), part 1
       typedef typename P::elem_t E;
-      for (int c = lane; c < a.KpB0; c += 64) {
+      for (int c = lane; c < a.out_valid; c += 64) {  // (columns past out_dim are zero padding)
         const int cb = c * ES;
         float t = 0.f;
         for (int row = wid; row < MT; row += SAMPLER_WAVES)
@@ -1030,8 +1020,8 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
         dred[wid * DRED_COLS + c] = t;
       }
     }
+    STAMP(18);
     f32x4 acc[TPW][MR];
-    u32x4 d[MR][Chunks<P, TPW>::CH];
     auto zero_acc = [&]() {
 #pragma unroll
       for (int tp = 0; tp < TPW; ++tp)
@@ -1039,8 +1029,8 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
         for (int m = 0; m < MR; ++m) acc[tp][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     };
     // ---- dz1 = (dh_1 . W2) o act'(z1), dh_1 . W2 = d_out . (Wout . W2): a K = out_dim layer on the d_out tile
-    fetch<P, ACT == ACT_RELU, TPW>(d, a.m1[0], H, wbase, g, r, row0, M);
     zero_acc();
+    STAMP(19);
     if constexpr (COMPACT)
       eng.short1(acc, xin, in_rb, in_km, r, g);
     else
@@ -1052,6 +1042,7 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
       for (int m = 0; m < MR; ++m)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[tp][m][e] *= grad_at<P, ACT>(d, tp, m, e);
+    STAMP(20);
     emit<P, TPW, MR>(acc, ACT_NONE, bufA, a.dz1[0], H, wbase, g, r, row0, M);
     STAMP(23);
     colsum(acc, 2, tile);
@@ -1064,12 +1055,13 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
     // ---- dh_0 = (dz1 . W1) o act'(h_0) + d_out . Wout
     fetch<P, ACT == ACT_RELU, TPW>(d, a.m0[0], H, wbase, g, r, row0, M);
     zero_acc();
+    STAMP(21);
     if constexpr (COMPACT)
       eng.wide(acc, bufA, HRB, 15, r, g, FLAGS ? flags : nullptr, seq);
     else
       eng.run(acc, bufA, HRB, 15, KSH, r, g, FLAGS ? flags : nullptr, seq);
     STAMP(26);
-    if (a.dout_slot >= 0 && tid < a.KpB0) {  // part 2 (every wave has passed part 1: its flag / the barrier came later)
+    if (a.dout_slot >= 0 && tid < a.out_valid) {  // part 2 (every wave has passed part 1: its flag / the barrier came later)
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < SAMPLER_WAVES; ++w) t += dred[w * DRED_COLS + tid];
