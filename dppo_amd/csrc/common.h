@@ -151,6 +151,18 @@ __device__ __forceinline__ float philox_normal(uint64_t idx, uint32_t k0, uint32
   return sqrtf(-2.f * __logf(u1)) * __cosf(6.283185307179586f * u2);
 }
 
+// Loads with the address space spelled out.  Where a value comes from LDS on one path and from global memory on the other,
+// the compiler merges the two loads into ONE flat_load through a generic pointer -- and a FLAT access ticks both memory
+// counters, so it is followed by s_waitcnt vmcnt(0) lgkmcnt(0): every weight fragment the ring has in flight is waited for.
+template <class T>
+__device__ __forceinline__ T lds_load(const T* p) {
+  return *(const __attribute__((address_space(3))) T*)p;
+}
+template <class T>
+__device__ __forceinline__ T glb_load(const T* p) {
+  return *(const __attribute__((address_space(1))) T*)p;
+}
+
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // Sum over the 16 lanes of a DPP row (lanes with the same lane >> 4), every lane gets the total: four VALU adds with a DPP

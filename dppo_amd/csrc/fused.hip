@@ -443,15 +443,18 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_forward_kernel(const Fused
 
     f32x4 h[TPW][MR], acc[TPW][MR];
     auto bias_init = [&](int layer) {  // layer: 0, then 1 + 2b / 2 + 2b
-      const float* src = bias_lds ? biasL + layer * H : a.params + a.bias_off[layer];
+      // (two pointers, never one selected at run time: a pointer that may be LDS or global is a GENERIC pointer, its loads
+      // are FLAT, and a FLAT load is followed by s_waitcnt vmcnt(0) lgkmcnt(0) -- the weight ring drained at every layer)
+      const float* srcL = biasL + layer * H;
+      const float* srcG = a.params + a.bias_off[layer];
 #pragma unroll
       for (int tp = 0; tp < TPW; ++tp) {
         f32x4 b;
         if (bias_lds) {
-          b = *(const f32x4*)(src + wbase + feat_off<P>(g, tp));
+          b = lds_load((const f32x4*)(srcL + wbase + feat_off<P>(g, tp)));
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) b[e] = src[wbase + feat_off<P>(g, tp) + e];
+          for (int e = 0; e < 4; ++e) b[e] = glb_load(srcG + wbase + feat_off<P>(g, tp) + e);
         }
 #pragma unroll
         for (int m = 0; m < MR; ++m) acc[tp][m] = b;
@@ -574,7 +577,11 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_forward_kernel(const Fused
     for (int idx = tid_; idx < MT * a.out_dim; idx += 512) {
       const int row = idx / a.out_dim, j = idx - row * a.out_dim;
       const int m = row >> 4, rr = row & 15, to = j >> 4, jj = j & 15;
-      float s = bias_lds ? biasL[(1 + 2 * nb) * H + j] : a.params[a.bias_off[1 + 2 * nb] + j];
+      float s;  // (an if / else, not a ?: the compiler turns into ONE load through a generic pointer: see bias_init)
+      if (bias_lds)
+        s = lds_load(biasL + (1 + 2 * nb) * H + j);
+      else
+        s = glb_load(a.params + a.bias_off[1 + 2 * nb] + j);
 #pragma unroll
       for (int kh = 0; kh < KSPLIT; ++kh) s += part[(((kh * MR + m) * OT + to) * 16 + jj) * 16 + rr];
       if (row0 + row < M) a.out[(size_t)(row0 + row) * a.ldout + j] = s;

@@ -23,6 +23,15 @@ __device__ __forceinline__ void lds_put(char* buf, int rb, int kmask, int row, i
   *(typename P::elem_t*)p = P::from_f32(v);
 }
 
+// Pointers that arrive inside the by-value argument struct and are then picked by a run-time index (ws[net], params[net]
+// ...) reach the loads as GENERIC pointers: the compiler emitted flat_load for every weight fragment of the ring, and a
+// FLAT access ticks both memory counters and may complete out of order with LDS traffic, so each use was preceded by
+// s_waitcnt vmcnt(0) lgkmcnt(0) -- the whole ring drained at every k-step group and the prefetch distance was zero.
+// Everything the step loop touches in global memory goes through explicit global-address-space pointers instead.
+typedef const __attribute__((address_space(1))) u32x4* gfrag_p;
+typedef const __attribute__((address_space(1))) float* gfloat_p;
+typedef __attribute__((address_space(1))) float* gfloat_w;
+
 template <class P, int TPW, int OT, bool LN, int ACT, int PDX = sampler_pd(128 * TPW)>
 __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
   // PDX: ring depth.  (A depth of 8 at H = 512 -- legal once layer 0 is LDS-resident and never passes through the ring --
@@ -102,11 +111,16 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
   }
 
   const size_t wave_stride = (size_t)total * TPW * 64;
-  const u32x4* ws[2] = {a.wstream[0] + wid * wave_stride + lane, a.wstream[1] + wid * wave_stride + lane};
-  const u32x4* os[2] = {a.ostream[0] + (size_t)wid * CNT * OT * 64 + lane,
-                        a.ostream[1] + (size_t)wid * CNT * OT * 64 + lane};
-  const u32x4* os2[2] = {a.ostream2[0] + (size_t)wid * CNT * OT * 64 + lane,
-                         a.ostream2[1] + (size_t)wid * CNT * OT * 64 + lane};
+  const gfrag_p ws[2] = {(gfrag_p)(a.wstream[0] + wid * wave_stride + lane), (gfrag_p)(a.wstream[1] + wid * wave_stride + lane)};
+  const gfrag_p os[2] = {(gfrag_p)(a.ostream[0] + (size_t)wid * CNT * OT * 64 + lane),
+                         (gfrag_p)(a.ostream[1] + (size_t)wid * CNT * OT * 64 + lane)};
+  const gfrag_p os2[2] = {(gfrag_p)(a.ostream2[0] + (size_t)wid * CNT * OT * 64 + lane),
+                          (gfrag_p)(a.ostream2[1] + (size_t)wid * CNT * OT * 64 + lane)};
+  const gfloat_p g_params[2] = {(gfloat_p)a.params[0], (gfloat_p)a.params[1]};
+  const gfloat_p g_temb[2] = {(gfloat_p)a.temb[0], (gfloat_p)a.temb[1]};
+  const gfloat_p g_cbias[2] = {(gfloat_p)a.cbias[0], (gfloat_p)a.cbias[1]};
+  const gfloat_p g_noise = (gfloat_p)a.noise;
+  const gfloat_w g_chains = (gfloat_w)a.chains, g_traj = (gfloat_w)a.traj;
   const int total_eff = total - (merge ? KSH : 0);  // the ring never sees the top block's second layer when merged
   const int wbase = wid * 16 * TPW;  // this wave's feature slice; the lane's features: wbase + feat_off<P>(g, tp) + e
 
@@ -135,9 +149,10 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
     const dppo_step st = a.sched[i];
     const int net = st.net;
     const int nnet = (i + 1 < a.n_steps) ? a.sched[i + 1].net : net;
-    const u32x4* cur = ws[net];
-    const u32x4* nxt = ws[nnet];
-    const float* prm = a.params[net];
+    const gfrag_p cur = ws[net];
+    const gfrag_p nxt = ws[nnet];
+    const gfloat_p prm = g_params[net];
+    const float* prm_ln = a.params[net];  // (LayerNorm parameters go through tile_ln.h's generic-pointer interface)
     // this step's noise draw and the next step's time embedding are needed at the very end of the step, right behind the
     // ring's prefetches: issued here, they have a whole step to land; issued there, they would wait for every weight
     // fragment in flight (vmcnt is in issue order) -- 20 times per call
@@ -146,9 +161,9 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
     if (tid < 16 * AF) {
       const int row = tid / AF, j = tid - row * AF;
       const size_t ni = (size_t)(i + 1) * B * AF + (size_t)min(grow0 + row, B - 1) * AF + j;
-      z_pre = a.noise != nullptr ? a.noise[ni] : philox_normal(ni, a.seed_lo, a.seed_hi);
+      z_pre = a.noise != nullptr ? g_noise[ni] : philox_normal(ni, a.seed_lo, a.seed_hi);
     }
-    if (tid < 16 * td) te_pre = a.temb[sn.net][sn.t * td + tid % td];
+    if (tid < 16 * td) te_pre = g_temb[sn.net][sn.t * td + tid % td];
 
     // out-layer fragments, in groups of OG out tiles: one group, prefetched at the top of the step, when it is small;
     // loaded right before use at H = 1024 (the registers are needed) and for wide outputs (two groups)
@@ -190,7 +205,7 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
           for (int tp = 0; tp < TPW; ++tp) acc[tp][0] = P::mma(ring[p][tp], xb, acc[tp][0]);
           // refill the slot just consumed with the fragments PD positions ahead (next layer / next step included)
           const int np = pos + ks + PD;
-          const u32x4* src_w =
+          const gfrag_p src_w =
               np < total_eff ? cur + (size_t)np * TPW * 64 : nxt + (size_t)(np - total_eff + skip) * TPW * 64;
 #pragma unroll
           for (int tp = 0; tp < TPW; ++tp) ring[p][tp] = src_w[tp * 64];
@@ -233,7 +248,7 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
     float ln_m[1], ln_r[1];
     auto put_block_input = [&](int b) {
       if constexpr (LN) {
-        ln_forward<P, TPW, 1>(h, acc, prm + a.ln_off[4 * b], prm + a.ln_off[4 * b + 1], H, wbase, g, r, wid, lnred, ln_m,
+        ln_forward<P, TPW, 1>(h, acc, prm_ln + a.ln_off[4 * b], prm_ln + a.ln_off[4 * b + 1], H, wbase, g, r, wid, lnred, ln_m,
                               ln_r);
         put_hidden(bufA, acc, ACT);
       } else {
@@ -275,7 +290,7 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
     for (int b = 0; b < nb; ++b) {
       run_layer(bufA, HRB, 15, KSH, 1 + 2 * b);
       if constexpr (LN)
-        ln_forward<P, TPW, 1>(acc, acc, prm + a.ln_off[4 * b + 2], prm + a.ln_off[4 * b + 3], H, wbase, g, r, wid, lnred,
+        ln_forward<P, TPW, 1>(acc, acc, prm_ln + a.ln_off[4 * b + 2], prm_ln + a.ln_off[4 * b + 3], H, wbase, g, r, wid, lnred,
                               ln_m, ln_r);
       put_hidden(bufB, acc, ACT);
       __syncthreads();
@@ -335,7 +350,7 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
         const int row = idx / AF, j = idx - row * AF;
         const int grow = grow0 + row;
         float eps = bias_lds ? biasL[net * bias_stride + (1 + 2 * nb) * H + j]
-                             : (merge ? a.cbias[net][j] : prm[a.bias_off[1 + 2 * nb] + j]);
+                             : (merge ? g_cbias[net][j] : prm[a.bias_off[1 + 2 * nb] + j]);
 #pragma unroll
         for (int w = 0; w < SAMPLER_WAVES; ++w) eps += part[(w * OT * 16 + j) * 16 + row];
         const float x = xcur[row * AF + j];
@@ -356,7 +371,7 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
         float z = z_pre;  // first pass: prefetched / drawn at the step's top
         if (idx != tid) {
           const size_t ni = nz0 + (size_t)min(grow, B - 1) * AF + j;
-          z = a.noise != nullptr ? a.noise[ni] : philox_normal(ni, a.seed_lo, a.seed_hi);
+          z = a.noise != nullptr ? g_noise[ni] : philox_normal(ni, a.seed_lo, a.seed_hi);
         }
         z = fminf(fmaxf(z, -a.rclip), a.rclip);
         float xn = mu + st.std * z;
@@ -364,13 +379,13 @@ __global__ __launch_bounds__(512) void sample_chain_kernel(const SampleArgs a) {
         xcur[row * AF + j] = xn;
         lds_put<P>(xin, in_rb, in_km, row, j, xn);
         if (grow < B) {
-          if (st.chain_slot >= 0 && a.chains != nullptr) a.chains[((size_t)grow * a.chain_len + st.chain_slot) * AF + j] = xn;
-          if (i + 1 == a.n_steps) a.traj[(size_t)grow * AF + j] = xn;
+          if (st.chain_slot >= 0 && a.chains != nullptr) g_chains[((size_t)grow * a.chain_len + st.chain_slot) * AF + j] = xn;
+          if (i + 1 == a.n_steps) g_traj[(size_t)grow * AF + j] = xn;
         }
       }
       for (int idx = tid; idx < 16 * td; idx += 512) {
         const int row = idx / td, j = idx - row * td;
-        lds_put<P>(xin, in_rb, in_km, row, AF + j, idx == tid ? te_pre : a.temb[sn.net][sn.t * td + j]);
+        lds_put<P>(xin, in_rb, in_km, row, AF + j, idx == tid ? te_pre : g_temb[sn.net][sn.t * td + j]);
       }
       // a cond_mlp encodes the observation per network: swap the state columns when the next step switches network
       if (sn.net != st.net && a.obs[0] != a.obs[1]) put_state(sn.net);
