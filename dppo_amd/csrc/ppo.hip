@@ -1042,14 +1042,17 @@ __global__ __launch_bounds__(256) void slab_reduce_batch_kernel(const SlabJobs j
 // (one block).  They were three launches on two streams; the second stream's join was a barrier packet (~5 us) between the
 // GEMMs and the reductions on the update's critical path.
 __global__ __launch_bounds__(1024) void tail_reduce_kernel(const TailReduce t) {
+  // y order: the loss statistics (one block, a chain of dependent loads), the slots (49 dependent loads per lane at C2),
+  // then the slab jobs (8 independent loads per lane): workgroups are dispatched in index order, the long chains go first
+  const int nfin = t.fin_stats != nullptr ? 1 : 0;
   const int y = blockIdx.y;
-  if (y < t.jobs.n) {
-    slab_job_block(t.jobs.j[y]);
+  if (y < nfin) {
+    if (blockIdx.x == 0) loss_finalize_block(t.fin_partial, t.fin_blocks, t.fin_moments, t.fin_stats, t.fin_part, t.fin_n_count);
     return;
   }
-  if (y < t.jobs.n + t.slots.n_slots) {
+  if (y < nfin + t.slots.n_slots) {
     __shared__ float red[16][65];
-    const int slot = y - t.jobs.n, n = t.width;
+    const int slot = y - nfin, n = t.width;
     if ((int)blockIdx.x * 64 >= n) return;
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -1073,7 +1076,7 @@ __global__ __launch_bounds__(1024) void tail_reduce_kernel(const TailReduce t) {
     }
     return;
   }
-  if (blockIdx.x == 0) loss_finalize_block(t.fin_partial, t.fin_blocks, t.fin_moments, t.fin_stats, t.fin_part, t.fin_n_count);
+  slab_job_block(t.jobs.j[y - nfin - t.slots.n_slots]);
 }
 void launch_tail_reduce(TailReduce& t, const LossArgs* fin, hipStream_t s) {
   size_t most = 0;
@@ -1082,6 +1085,7 @@ void launch_tail_reduce(TailReduce& t, const LossArgs* fin, hipStream_t s) {
     most = n > most ? n : most;
   }
   const bool has_fin = fin != nullptr && fin->N > 0;
+  t.fin_stats = nullptr;
   if (has_fin) {
     t.fin_partial = fin->partial, t.fin_blocks = loss_blocks(fin->N), t.fin_moments = fin->moments, t.fin_stats = fin->stats;
     t.fin_part = fin->part, t.fin_n_count = fin->n_count;
