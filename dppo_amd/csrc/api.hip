@@ -2387,6 +2387,10 @@ int dppo_tune_set(int knob, int value) {
     g_post_one = value;
     return 0;
   }
+  if (knob == 26) {  // grouped weight-gradient GEMM: LDS stages (1, default: three workgroups per CU; 2)
+    set_gemm_tn_nbuf(value);
+    return 0;
+  }
   if (knob == 25) {  // one-block kernels: short layers walked without their padding k-steps (1, default) or padded (0)
     set_fused_compact(value);
     return 0;

@@ -55,6 +55,7 @@ void launch_gemm_nt(const GemmNT& a, hipStream_t s);
 template <class P>
 void launch_gemm_tn_group(const GemmTNGroup& gr, hipStream_t s);
 void set_gemm_tn_variant(int v);  // tuning knob 5
+void set_gemm_tn_nbuf(int v);     // tuning knob 26
 void set_gemm_tn_thin(int v);     // tuning knob 6
 
 // Measurement hook (bench.py's roofline): while armed for a kernel id, every launch of that kernel is bracketed by

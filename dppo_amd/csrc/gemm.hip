@@ -332,7 +332,11 @@ template void launch_gemm_nt<BF16>(const GemmNT&, hipStream_t);
 //   <2,2,4,4> 128 x 128 : the H x H gradients
 //   <4,1,8,4> 512 x  64 : thin outputs (dW0: H x in_dim; dWout computed transposed as H x out_dim) -- one block
 //                         covers the whole output, all parallelism comes from the split over batch rows
-template <class P, int WA, int WB, int TA, int TB>
+// NBUF: LDS stages.  2: the next stage's registers are stored while slower waves may still multiply the current one.  1: one
+// buffer, two barriers per stage -- half the LDS, so that THREE workgroups fit a CU (154 VGPRs allow three waves per SIMD):
+// the kernel is paced by the per-stage chain inside a workgroup (transposed LDS reads → MFMAs → LDS stores → barrier), which
+// more resident waves hide.
+template <class P, int WA, int WB, int TA, int TB, int NBUF = 2>
 __device__ __forceinline__ void tn_tile(const GemmTN& a, const int split, const int fa0, const int fb0) {
   constexpr int ES = P::ESIZE;
   constexpr int BA = WA * TA * 16, BB = WB * TB * 16;
@@ -399,7 +403,7 @@ __device__ __forceinline__ void tn_tile(const GemmTN& a, const int split, const 
   }
   __syncthreads();
   for (int st = 0; st < nst; ++st) {
-    const int cur = st & 1;
+    const int cur = NBUF == 2 ? (st & 1) : 0;
     if (st + 1 < nst) gload(m_begin + (st + 1) * ROWS);
     const char* As = smem + cur * (OPA + OPB);
     const char* Bs = As + OPA;
@@ -451,7 +455,8 @@ __device__ __forceinline__ void tn_tile(const GemmTN& a, const int split, const 
 #pragma unroll
         for (int j = 0; j < TB; ++j) acc[i][j] = P::mma(af[i], bf[j], acc[i][j]);
     }
-    if (st + 1 < nst) sstore(cur ^ 1);
+    if constexpr (NBUF == 1) __syncthreads();  // every wave is done with the buffer before it is overwritten
+    if (st + 1 < nst) sstore(NBUF == 2 ? cur ^ 1 : 0);
     __syncthreads();
   }
 
@@ -480,8 +485,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN a) {
 // Every weight gradient of one backward pass in one launch: 128 x 128 tiles of all jobs, job after job (long ones
 // first), within a job the split index fastest (bases and split counts are multiples of 8: one split's tiles share an
 // XCD, as above).  No inter-kernel gaps, and the last round of one GEMM is filled by the first of the next.
-template <class P>
-__global__ __launch_bounds__(256) void gemm_tn_group_kernel(const GemmTNGroup gr) {
+template <class P, int NBUF>
+__global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_tn_group_kernel(const GemmTNGroup gr) {
   int j = 0;
 #pragma unroll
   for (int i = 1; i < MAX_TN_JOBS; ++i)
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(256) void gemm_tn_group_kernel(const GemmTNGroup gr
   const int local = blockIdx.x - gr.base[j];
   const int split = local % a.splits, tile = local / a.splits;
   const int tb = (a.N2 + 127) / 128;
-  tn_tile<P, 2, 2, 4, 4>(a, split, (tile / tb) * 128, (tile % tb) * 128);
+  tn_tile<P, 2, 2, 4, 4, NBUF>(a, split, (tile / tb) * 128, (tile % tb) * 128);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -677,6 +682,8 @@ static void launch_tn_cfg(const GemmTN& a, hipStream_t s) {
   if (probe) probe_end(s, 2.0 * a.M * a.N1 * a.N2);
 }
 
+static int g_tn_nbuf = 1;  // tuning knob 26: LDS stages of the grouped weight-gradient kernel (1: three workgroups per CU; 2)
+void set_gemm_tn_nbuf(int v) { g_tn_nbuf = v == 2 ? 2 : 1; }
 template <class P>
 void launch_gemm_tn_group(const GemmTNGroup& gr, hipStream_t s) {
   if (gr.n <= 0) return;
@@ -684,7 +691,7 @@ void launch_gemm_tn_group(const GemmTNGroup& gr, hipStream_t s) {
   constexpr int LDS = 2 * ROWS * 2 * (128 * ES + 32);
   static DevLatch attr_set;
   if (attr_set.need()) {
-    (void)hipFuncSetAttribute((const void*)gemm_tn_group_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_group_kernel<P, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set.done();
   }
   double flops = 0, bytes = 0;
@@ -694,7 +701,10 @@ void launch_gemm_tn_group(const GemmTNGroup& gr, hipStream_t s) {
     bytes += (double)a.M * (a.N1 + a.N2) * ES + 4.0 * a.N1 * a.N2;  // both operands once + the fp32 result
   }
   const bool probe = probe_begin(PROBE_GEMM_TN, s);
-  hipLaunchKernelGGL((gemm_tn_group_kernel<P>), dim3(gr.base[gr.n]), dim3(256), LDS, s, gr);
+  if (g_tn_nbuf == 1)
+    hipLaunchKernelGGL((gemm_tn_group_kernel<P, 1>), dim3(gr.base[gr.n]), dim3(256), LDS / 2, s, gr);
+  else
+    hipLaunchKernelGGL((gemm_tn_group_kernel<P, 2>), dim3(gr.base[gr.n]), dim3(256), LDS, s, gr);
   if (probe) probe_end(s, flops, bytes);
 }
 template void launch_gemm_tn_group<F32>(const GemmTNGroup&, hipStream_t);

@@ -435,7 +435,8 @@ int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* 
  * knob 23: fused backward of one-block networks (no LayerNorm, hidden <= 512, low-rank dW2 on): dh_1 = d_out . Wout is added
  *          last, into the W1^T layer's accumulators, instead of carried in registers; forward-sized tiles (default 1)
  * knob 25: the one-block kernels walk their short layers (K = in_dim on the input tile, K = out_dim on the d_out tile)
- *          as the 1-2 k-steps that hold data instead of the 4 the weight stream pads them to (default 1) */
+ *          as the 1-2 k-steps that hold data instead of the 4 the weight stream pads them to (default 1)
+ * knob 26: LDS stages of the grouped weight-gradient GEMM: 1 (default; 36.9 KB per workgroup, three workgroups per CU) or 2 */
 int dppo_tune_set(int knob, int value);
 /* one bare layer GEMM: out[M][ldo] = act(X[M][Kp] . W[N][Kp]^T + bias) with elem = prec operands;
  * out_f32 and/or out_elem may be NULL; ldo >= round_up(N,16) */
