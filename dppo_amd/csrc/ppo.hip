@@ -1051,29 +1051,33 @@ __global__ __launch_bounds__(1024) void tail_reduce_kernel(const TailReduce t) {
     return;
   }
   if (y < nfin + t.slots.n_slots) {
-    __shared__ float red[16][65];
+    // 16 columns x 64 tile-lanes per block: a lane adds tiles / 64 values in four independent chains (12 loads at C2's 782
+    // tiles; with 64 columns x 16 tile-lanes it was 49, and this block was the longest dependent chain of the launch)
+    __shared__ float red[64][17];
     const int slot = y - nfin, n = t.width;
-    if ((int)blockIdx.x * 64 >= n) return;
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    if ((int)blockIdx.x * 16 >= n) return;
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     const float* src = t.colsum + (size_t)slot * t.tiles * n;
     float p[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < n && t.slots.n[slot] > 0) {
       int r = rl;
-      for (; r + 48 < t.tiles; r += 64) {
+      for (; r + 192 < t.tiles; r += 256) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) p[u] += src[(size_t)(r + 16 * u) * n + c];
+        for (int u = 0; u < 4; ++u) p[u] += src[(size_t)(r + 64 * u) * n + c];
       }
-      for (; r < t.tiles; r += 16) p[0] += src[(size_t)r * n + c];
+      for (; r < t.tiles; r += 64) p[0] += src[(size_t)r * n + c];
     }
     red[rl][cl] = (p[0] + p[1]) + (p[2] + p[3]);
     __syncthreads();
-    if (rl == 0 && c < t.slots.n[slot]) {
+    if (rl < 4) {  // 64 partial sums per column: four lanes x 16, then three adds
       float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s += red[i][cl];
-      t.slots.out[slot][c] = s;
+      for (int i = 0; i < 16; ++i) s += red[rl * 16 + i][cl];
+      red[rl][cl] = s;
     }
+    __syncthreads();
+    if (rl == 0 && c < t.slots.n[slot]) t.slots.out[slot][c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
     return;
   }
   slab_job_block(t.jobs.j[y - nfin - t.slots.n_slots]);
@@ -1091,7 +1095,7 @@ void launch_tail_reduce(TailReduce& t, const LossArgs* fin, hipStream_t s) {
     t.fin_part = fin->part, t.fin_n_count = fin->n_count;
   }
   unsigned gx = (unsigned)((most + 1023) / 1024);
-  const unsigned gs = t.slots.n_slots > 0 ? (unsigned)((t.width + 63) / 64) : 0;
+  const unsigned gs = t.slots.n_slots > 0 ? (unsigned)((t.width + 15) / 16) : 0;
   gx = gx > gs ? gx : gs;
   const unsigned gy = (unsigned)(t.jobs.n + t.slots.n_slots + (has_fin ? 1 : 0));
   if (gx == 0) gx = 1;
