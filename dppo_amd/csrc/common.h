@@ -90,6 +90,19 @@ __device__ __forceinline__ void mish_both(float x, float& val, float& grad) {
   val = x * th;
   grad = th + 4.f * x * (e * (1.f + e)) * (R * R);
 }
+// Two values at a time on the packed-fp32 VALU (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two lanes' worth of work per
+// issue slot): the fused forward's Mish emits are VALU-bound (a 128-row critic tile spends 20k of its 34k cycles in them),
+// and 12 of the ~14 instructions per value are plain multiplies and adds.  Same operation order per value as mish_both().
+typedef float float2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mish_both2(float2v x, float2v& val, float2v& grad) {
+  const float2v e = {__expf(fminf(x.x, 20.f)), __expf(fminf(x.y, 20.f))};
+  const float2v n = e * (e + 2.f);
+  const float2v w = n + 2.f;
+  const float2v R = {__builtin_amdgcn_rcpf(w.x), __builtin_amdgcn_rcpf(w.y)};
+  const float2v th = n * R;
+  val = x * th;
+  grad = th + 4.f * x * (e * (1.f + e)) * (R * R);
+}
 __device__ __forceinline__ float mish_f(float x) {
   const float e = __expf(fminf(x, 20.f));
   const float n = e * (e + 2.f);

@@ -278,13 +278,20 @@ __device__ __forceinline__ void emit(const f32x4 (&v)[TPW][MR], int actk, char* 
 #pragma unroll
       for (int tp = 0; tp < TPW; tp += TPC) {
         float av[4 * TPC], dv[4 * TPC];
+        if constexpr (ACT == ACT_MISH) {  // pairs on the packed-fp32 VALU; without the derivative its half is dead code
 #pragma unroll
-        for (int q = 0; q < 4 * TPC; ++q) {
-          const float x = v[tp + q / 4][m][q % 4];
-          if constexpr (with_mask) bits |= (x > 0.f ? 1u : 0u) << (4 * tp + q);
-          if constexpr (ACT == ACT_MISH && with_grad) {
-            mish_both(x, av[q], dv[q]);
-          } else {
+          for (int q = 0; q < 4 * TPC; q += 2) {
+            const float2v x = {v[tp + q / 4][m][q % 4], v[tp + (q + 1) / 4][m][(q + 1) % 4]};
+            float2v a2, d2;
+            mish_both2(x, a2, d2);
+            av[q] = a2.x, av[q + 1] = a2.y;
+            dv[q] = with_grad ? d2.x : 0.f, dv[q + 1] = with_grad ? d2.y : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4 * TPC; ++q) {
+            const float x = v[tp + q / 4][m][q % 4];
+            if constexpr (with_mask) bits |= (x > 0.f ? 1u : 0u) << (4 * tp + q);
             av[q] = act_c<ACT>(x);
             dv[q] = 0.f;
           }
