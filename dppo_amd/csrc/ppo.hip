@@ -494,7 +494,7 @@ void launch_adv_moments(const float* adv_k, const int32_t* brow, int64_t N, doub
 constexpr int LOSS_THREADS = 64;
 
 template <class P, int NREG>
-__global__ __launch_bounds__(LOSS_THREADS) void ppo_loss_kernel(const LossArgs a) {
+__global__ __launch_bounds__(LOSS_THREADS, 8) void ppo_loss_kernel(const LossArgs a) {
   typedef typename P::elem_t E;
   constexpr int EPC = 16 / P::ESIZE;  // elements per 16-byte chunk of the outputs
   // per-k constants (only Kft distinct values exist): denoising discount and clip range, built once per block in
