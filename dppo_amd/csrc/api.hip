@@ -885,7 +885,9 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
         q.b0 = prm + pl.b0, q.b2 = prm + pl.l2b[nb - 1], q.cs = grad + pl.bout, q.dWout = grad + pl.Wout;
       }
       if (one) q.db2 = grad + pl.l2b[0], q.Wout_b = prm + pl.Wout, q.cs = grad + pl.bout;
-      if (g_post_one && B.post_zeroed && (lowrank || oh >= 0)) {  // both in one launch (knob 18)
+      // everything behind the reduction in one launch (knob 18); its arrival counter (zeroed by the row builder) is only
+      // needed by the time-embedding part
+      if (g_post_one && (oh < 0 || B.post_zeroed) && (lowrank || oh >= 0 || merged || one)) {
         if (lowrank) q.Wout = prm + pl.Wout, q.dW = grad + pl.l2w[nb - 1];
         if (oh >= 0) {
           q.S = B.part, q.W0 = prm + pl.W0, q.ldw0 = d.in_dim, q.AF = d.act_flat, q.Kft = Kft, q.td = d.time_dim;
