@@ -95,6 +95,11 @@ __device__ __forceinline__ void mish_both(float x, float& val, float& grad) {
 // and 12 of the ~14 instructions per value are plain multiplies and adds.  Same operation order per value as mish_both().
 typedef float float2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void mish_both2(float2v x, float2v& val, float2v& grad) {
+  // no contraction: the training forward (value + derivative) and the inference forward (value only: the derivative's half
+  // is dead code) must round `val` identically -- the update's recomputed log-probs equal the precomputed ones bit for bit
+  // (ratio == 1 with unchanged weights) only if the compiler cannot fuse n + 2 into an fma in one instantiation and not in
+  // the other
+#pragma clang fp contract(off)
   const float2v e = {__expf(fminf(x.x, 20.f)), __expf(fminf(x.y, 20.f))};
   const float2v n = e * (e + 2.f);
   const float2v w = n + 2.f;

@@ -644,3 +644,30 @@ def test_one_block_kernels_match_the_general_ones(prec, tol, sname, knob):
         x, y = g1[key].reshape(-1).astype(np.float64), g0[key].reshape(-1).astype(np.float64)
         err = np.linalg.norm(x - y) / (np.linalg.norm(y) + 1e-30)
         assert err <= (2e-4 if prec == "fp32" else 6e-2), (key, err)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("sname", ["can", "kitchen_like", "square_like", "halfcheetah"])
+def test_recomputed_logprobs_equal_precomputed_ones_for_every_kernel_family(prec, sname):
+    """ratio == 1 and kl == 0 bit for bit with unchanged weights, for the networks the hopper test above does not reach:
+    Mish actors (the activation is evaluated by the inference forward without and by the training forward with its
+    derivative: both must round the value identically), a cond_mlp encoder, H = 1024, a ReLU actor on the general
+    (unmerged) forward."""
+    from dppo_amd import hip
+    kw = dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01, clip_ploss_coef_base=0.001,
+              randn_clip_value=3, gamma_denoising=0.99)
+    m, a, c = build_model(sname, kw, 45, prec)
+    R, N, Kft = 96, 700, 10
+    AF = a.horizon_steps * a.action_dim
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    obs = (torch.rand(R, 1, a.cond_dim, generator=gen) * 2 - 1).to(DEV)
+    chains = (torch.randn(R, Kft + 1, a.horizon_steps, a.action_dim, generator=gen) * 0.5).to(DEV)
+    logp = m.get_logprobs({"state": obs}, chains).reshape(R, Kft, AF).contiguous()
+    val = m.critic({"state": obs}).reshape(R)
+    ret = val + torch.randn(R, generator=gen).to(DEV)
+    adv = torch.randn(R, generator=gen).to(DEV)
+    inds = torch.randperm(R * Kft, generator=gen)[:N].to(DEV).contiguous()
+    stats = m.ppo_update(obs.reshape(R, -1).contiguous(), chains.reshape(R, Kft + 1, AF).contiguous(), ret, val, adv, logp,
+                         inds, reward_horizon=a.horizon_steps).cpu().numpy()
+    assert stats[hip.STAT_RATIO] == pytest.approx(1.0, abs=1e-12)
+    assert abs(stats[hip.STAT_APPROX_KL]) <= 1e-12 and stats[hip.STAT_CLIPFRAC] == 0.0
