@@ -1130,10 +1130,18 @@ int dppo_critic_forward(const dppo_net_desc* net, int prec, const float* params,
 
 // ---- sampler -----------------------------------------------------------------------------------------
 template <class P>
-static size_t sample_carve(Carver& c, const dppo_net_desc& d, int64_t B, MlpBufs<P>& Bz, float*& enc) {
+static bool sample_split(const dppo_net_desc& d, int64_t B) {
+  return sampler_split_ok(d, P::ESIZE == 2, B, g_merge_top && d.n_blocks >= 1);
+}
+template <class P>
+static size_t sample_carve(Carver& c, const dppo_net_desc& d, int64_t B, MlpBufs<P>& Bz, float*& enc, void** xch = nullptr) {
   memset(&Bz, 0, sizeof(Bz));
   enc = nullptr;
-  if (d.cond_hidden <= 0) return 0;
+  if (sample_split<P>(d, B)) {  // the split sampler's exchange block: first, so that its memset starts at the allocation
+    void* x = c.take(sampler_split_xch_bytes(d, B));
+    if (xch) *xch = x;
+  }
+  if (d.cond_hidden <= 0) return al256(c.off);
   const size_t ES = P::ESIZE;
   Bz.cin = c.take((size_t)B * round_up(d.cond_dim, 64) * ES);
   Bz.ca = c.take((size_t)B * round_up(d.cond_hidden, 64) * ES);
@@ -1169,23 +1177,33 @@ static int sample_impl(const dppo_net_desc& d, const float* pb, const char* kb, 
   a.use_ln = d.use_layernorm;
   if (d.use_layernorm) fill_ln_off(d, pl, a.ln_off);
   a.obs[0] = a.obs[1] = obs, a.cond = d.cond_dim, a.ld_obs = d.cond_dim;
-  if (d.cond_hidden > 0) {  // per-network encoded observation, computed once per call (constant over the K steps)
+  void* xch = nullptr;
+  const bool split = sample_split<P>(d, B);
+  if (d.cond_hidden > 0 || split) {
     MlpBufs<P> Bz;
     float* enc = nullptr;
-    if (!ws || (int64_t)sample_ws<P>(d, B) > wsb) return fail(-1, "sampler workspace too small: need %zu bytes", sample_ws<P>(d, B));
+    if (!ws || (int64_t)sample_ws<P>(d, B) > wsb)
+      return fail(-1, "sampler workspace too small: need %zu bytes (dppo_sample_chain_workspace_bytes)", sample_ws<P>(d, B));
     Carver c{(char*)ws, 0, (size_t)wsb};
-    sample_carve<P>(c, d, B, Bz, enc);
-    const int lde = round_up(d.cond_out, 16);
-    launch_build_direct<P>(nullptr, nullptr, obs, nullptr, 0, 0, d.cond_dim, B, Bz.cin, L.Kpc, s);
-    cond_encode<P>(d, pb, kb, L, B, Bz.cin, Bz, nullptr, enc, lde, false, s);
-    cond_encode<P>(d, pf, kf, L, B, Bz.cin, Bz, nullptr, enc + (size_t)B * lde, lde, false, s);
-    a.obs[0] = enc, a.obs[1] = enc + (size_t)B * lde, a.cond = d.cond_out, a.ld_obs = lde;
+    sample_carve<P>(c, d, B, Bz, enc, &xch);
+    if (d.cond_hidden > 0) {  // per-network encoded observation, computed once per call (constant over the K steps)
+      const int lde = round_up(d.cond_out, 16);
+      launch_build_direct<P>(nullptr, nullptr, obs, nullptr, 0, 0, d.cond_dim, B, Bz.cin, L.Kpc, s);
+      cond_encode<P>(d, pb, kb, L, B, Bz.cin, Bz, nullptr, enc, lde, false, s);
+      cond_encode<P>(d, pf, kf, L, B, Bz.cin, Bz, nullptr, enc + (size_t)B * lde, lde, false, s);
+      a.obs[0] = enc, a.obs[1] = enc + (size_t)B * lde, a.cond = d.cond_out, a.ld_obs = lde;
+    }
   }
   a.noise = noise, a.seed_lo = cfg.seed_lo, a.seed_hi = cfg.seed_hi, a.traj = traj, a.chains = chains, a.sched = sched;
   a.B = (int)B, a.AF = d.act_flat, a.td = d.time_dim, a.Kp0 = g.Kp0, a.nb = d.n_blocks;
   a.n_steps = n_steps, a.chain_len = chain_len, a.init_slot = init_slot, a.act = d.act, a.use_ddim = cfg.use_ddim;
   a.has_dclip = cfg.has_denoised_clip, a.has_eclip = cfg.has_eps_clip, a.has_fclip = cfg.has_final_clip;
   a.dclip = cfg.denoised_clip, a.eclip = cfg.eps_clip, a.rclip = cfg.randn_clip, a.fclip = cfg.final_clip;
+  if (split) {
+    const int rs = launch_sample_chain_split(g, a, xch, sampler_split_xch_bytes(d, B), s);
+    if (rs == 0) return check_launch();
+    if (rs != -1) return fail(-1, "split sampler: launch failed (%d)", rs);
+  }
   const int rc = launch_sample_chain<P>(g, a, s);
   if (rc == -1) return fail(-1, "sampler: hidden=%d / out_dim=%d not instantiated (hidden in {256,512,768,1024}, out_dim <= 128)", d.hidden, d.out_dim);
   if (rc == -2) return fail(-1, "sampler: LDS image exceeds 160 KiB for hidden=%d at this precision", d.hidden);
@@ -2387,6 +2405,14 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 18) {
     g_post_one = value;
+    return 0;
+  }
+  if (knob == 27) {  // sampler: one 16-row tile over eight workgroups for small env batches (1, default) or one (0)
+    set_sampler_split(value);
+    return 0;
+  }
+  if (knob == 28) {  // split sampler: 64-cycle sleep periods between a member's exchange store and its first sweep (default 8)
+    set_sampler_split_pre_sweep(value);
     return 0;
   }
   if (knob == 26) {  // grouped weight-gradient GEMM: LDS stages (1, default: three workgroups per CU; 2)

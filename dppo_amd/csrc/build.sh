@@ -28,6 +28,7 @@ cd "$HERE"
 build "$HERE/gemm.hip"
 build "$HERE/fused.hip"
 build "$HERE/sampler.hip" -ffp-contract=off
+build "$HERE/sampler_split.hip" -ffp-contract=off
 build "$HERE/ppo.hip" -ffp-contract=off
 build "$HERE/gaussian.hip" -ffp-contract=off
 build "$HERE/gmm.hip" -ffp-contract=off
@@ -35,5 +36,5 @@ build "$HERE/unet.hip" -ffp-contract=off
 build "$HERE/vision.hip"
 build "$HERE/api.hip"
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/$LIB" "$OBJ"/gemm.o "$OBJ"/fused.o "$OBJ"/sampler.o "$OBJ"/ppo.o "$OBJ"/gaussian.o "$OBJ"/gmm.o "$OBJ"/unet.o "$OBJ"/vision.o "$OBJ"/api.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/$LIB" "$OBJ"/gemm.o "$OBJ"/fused.o "$OBJ"/sampler.o "$OBJ"/sampler_split.o "$OBJ"/ppo.o "$OBJ"/gaussian.o "$OBJ"/gmm.o "$OBJ"/unet.o "$OBJ"/vision.o "$OBJ"/api.o
 echo "built $OUT/$LIB"

@@ -51,12 +51,22 @@ struct SampleArgs {
   int consts_lds;  // set by the launcher: 1 = both networks' biases staged in LDS
   int ks0v;        // set by the launcher: k-steps of layer 0 that hold input columns (the rest of its KS0 is zero padding)
   int l0_lds;      // set by the launcher: 1 = layer-0 fragments of the current network live in LDS, not in the stream
+  int pre_sweep;   // split sampler, set by its launcher: sleep periods between the exchange store and the first sweep (knob 28)
   float dclip, eclip, rclip, fclip;
 };
 
 template <class P>
 int launch_sample_chain(const SamplerGeom& g, const SampleArgs& a, hipStream_t s);  // 0 ok, <0 unsupported
 void set_sampler_l0_lds(int v);  // tuning knob 15
+
+// One tile over eight workgroups (sampler_split.hip): small env batches of one-block bf16 networks at hidden 512.
+// `xch`: the exchange block at the START of the caller's workspace (zeroed by the launcher before every launch; its first
+// word is the time-out word: 0 = every hand-over completed, else 1 + the step a member gave up at).
+bool sampler_split_ok(const dppo_net_desc& d, bool bf16, int64_t B, bool merge_top);
+size_t sampler_split_xch_bytes(const dppo_net_desc& d, int64_t B);
+int launch_sample_chain_split(const SamplerGeom& g, const SampleArgs& a, void* xch, size_t xch_bytes, hipStream_t s);  // -1: not covered
+void set_sampler_split(int v);  // tuning knob 27
+void set_sampler_split_pre_sweep(int v);  // tuning knob 28
 
 // W: [H][ld] fp32 (nn.Linear layout).  Writes the fragments of one hidden layer (KS k-steps) into
 // every wave's stream at position pos0.

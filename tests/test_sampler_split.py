@@ -1,0 +1,108 @@
+"""GPU: the eight-workgroups-per-tile sampler (csrc/sampler_split.hip, knob 27) against the one-workgroup kernel it
+replaces for small env batches.  Same packed fragments, same partial sums added in the same order; the only arithmetic
+difference is the tag bit: each fp32 partial sum of the out layer travels between workgroups with its least significant
+bit replaced by a tag (cleared on arrival), i.e. <= 1 ulp = 6e-8 relative per partial.  A difference of that size moves
+x_{t-1} by ~1e-7, which now and then crosses a bf16 rounding boundary of the next step's input (4e-3 relative on one
+input element) -- so the two kernels agree to fp32 rounding on almost every element and to the bf16 input rounding on
+a few: stated tolerance mean |d| <= 1e-4, max |d| <= 3e-2 (the bf16 chains are held to 5e-2 against the reference's
+goldens, tests/test_hip_parity.py, which runs with the knob at its default).  Run to run the split kernel is bit-reproducible.
+Reference path: model/diffusion/diffusion_vpg.py:139-315.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_hip_parity import DEV, build_model
+
+pytestmark = pytest.mark.gpu
+
+DDPM = dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3)
+CASES = {
+    # name: (spec, diffusion kwargs)                      out tiles / layer-0 k-steps / activation of the actor
+    "hopper_ddpm": ("hopper", DDPM),                      # 1 / 2 / ReLU   (BASELINE configs[1])
+    "hopper_all_ft": ("hopper", dict(DDPM, ft_denoising_steps=20)),
+    "hopper_clips": ("hopper", dict(DDPM, denoised_clip_value=1.0, final_action_clip_value=1.0)),
+    "hopper_ddim": ("hopper", dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
+                                   randn_clip_value=3, eps_clip_value=1.0, denoised_clip_value=1.0)),
+    "halfcheetah_ddpm": ("halfcheetah", DDPM),            # 4 / 2 / ReLU   (BASELINE configs[3])
+    "can_k100": ("can", dict(denoising_steps=100, ft_denoising_steps=10, randn_clip_value=3)),  # 4 / 3 / Mish (configs[2])
+    "can_relu": ("can_relu", DDPM),                       # 4 / 3 / ReLU
+}
+
+
+def timeout_word(m):
+    ws = m.__dict__.get("_ws_sample")
+    assert ws is not None and ws.buf is not None, "the split sampler takes its exchange block from the sampling workspace"
+    return int(ws.buf[:4].view(torch.int32).item())
+
+
+@pytest.mark.parametrize("B", [1, 37, 512])
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_split_sampler_matches_the_one_workgroup_kernel(case, B):
+    from dppo_amd import hip
+    sname, kw = CASES[case]
+    m, a, _ = build_model(sname, kw, 5, "bf16")
+    lib = hip.load()
+    gen = torch.Generator(device="cpu").manual_seed(B + 1)
+    st = (torch.rand(B, 1, a.cond_dim, generator=gen) * 2 - 1).to(DEV)
+    n_steps = kw.get("ddim_steps", kw["denoising_steps"])
+    noise = torch.randn(n_steps + 1, B, a.horizon_steps, a.action_dim, generator=gen).to(DEV)
+    out = {}
+    try:
+        for split in (0, 1, 2):  # 2 = the split kernel a second time: bit-reproducible
+            assert lib.dppo_tune_set(27, min(split, 1)) == 0
+            given = m(cond={"state": st}, noise=noise, return_chain=True)
+            torch.manual_seed(77)
+            drawn = m(cond={"state": st}, return_chain=True)  # in-kernel Philox draws
+            out[split] = (given.chains.clone(), given.trajectories.clone(), drawn.chains.clone(), drawn.trajectories.clone())
+            if split:
+                assert timeout_word(m) == 0
+    finally:
+        lib.dppo_tune_set(27, 1)
+    for x, y, y2 in zip(out[0], out[1], out[2]):
+        assert torch.isfinite(y).all()
+        assert torch.equal(y, y2)
+        d = (x - y).abs()
+        assert d.max().item() <= 3e-2 and d.mean().item() <= 1e-4, (d.max().item(), d.mean().item())
+
+
+def test_split_sampler_many_calls_reuse_the_exchange_block():
+    """Back-to-back calls on one stream reuse the same exchange slots with the same tags: every call must start from a
+    zeroed block (the launcher's memset) and never read the previous call's partial sums."""
+    from dppo_amd import hip
+    m, a, _ = build_model("hopper", DDPM, 9, "bf16")
+    lib = hip.load()
+    B = 512
+    sts = [(torch.rand(B, 1, a.cond_dim, device=DEV) * 2 - 1) for _ in range(6)]
+    noise = torch.randn(21, B, a.horizon_steps, a.action_dim, device=DEV)
+    try:
+        lib.dppo_tune_set(27, 0)
+        ref = [m(cond={"state": s}, noise=noise).chains.clone() for s in sts]
+        lib.dppo_tune_set(27, 1)
+        got = [m(cond={"state": s}, noise=noise).chains for s in sts * 3]  # no host sync between the 18 calls
+        torch.cuda.synchronize()
+        assert timeout_word(m) == 0
+    finally:
+        lib.dppo_tune_set(27, 1)
+    for i, c in enumerate(got):
+        assert torch.equal(c, got[i % len(sts)])  # the same inputs give the same bits, call after call
+        d = (c - ref[i % len(sts)]).abs()
+        assert d.max().item() <= 3e-2 and d.mean().item() <= 1e-4
+
+
+def test_split_sampler_leaves_larger_batches_to_the_one_workgroup_kernel():
+    """tiles * 8 must fit the device's CUs (all members of a tile resident while they wait for each other): above that the
+    entry point runs sample_chain_kernel, and the workspace query says so (no exchange block)."""
+    import ctypes as C
+    from dppo_amd import hip
+    m, a, _ = build_model("hopper", DDPM, 9, "bf16")
+    lib = hip.load()
+    d = m.actor.net_desc()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    small = lib.dppo_sample_chain_workspace_bytes(C.byref(d), hip.PREC_BF16, 16 * (cus // 8))
+    large = lib.dppo_sample_chain_workspace_bytes(C.byref(d), hip.PREC_BF16, 16 * (cus // 8) + 1)
+    assert small > 0 and large == 0
+    assert lib.dppo_sample_chain_workspace_bytes(C.byref(d), hip.PREC_F32, 64) == 0  # fp32 operands: one-workgroup kernel
+    st = torch.rand(16 * (cus // 8) + 40, 1, a.cond_dim, device=DEV) * 2 - 1
+    s = m(cond={"state": st})
+    assert torch.isfinite(s.chains).all()
