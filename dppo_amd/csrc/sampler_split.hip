@@ -14,7 +14,7 @@
 // BIT of the fp32 partial sum (slot = step parity, tag = parity of step / 2, inverted so that the zeroed block of the
 // call's start never matches), so a word validates itself whatever the tearing of the 16-byte store, a lane's hand-over is
 // ONE store and eight loads, and a sweep of the eight members' partials moves 8 KB instead of the 16 KB of {tag, value}
-// pairs (a sweep is latency- and size-bound: 1.5 us at 16 KB).  Every member then adds the eight partials (tag bit cleared:
+// pairs (a sweep is latency- and size-bound: 1.5 us at 16 KB).  Every member then adds the eight partials (tag bit and all:
 // the sums differ from sample_chain_kernel's by at most one ulp of an fp32 partial, 6e-8 relative) in slice order and
 // runs the posterior for all 16 rows redundantly, so no second exchange is needed and x_{t-1} is bit-identical on all
 // eight members.  The step's noise (Philox is counter based) is drawn by the waves that own no out tile while the owners
@@ -49,9 +49,14 @@ __device__ unsigned long long g_split_stamps[4][16];
   do {                                                                                \
     if (blockIdx.x == 0 && lane == 0 && i == 5) g_split_stamps[wid][k] = (v);         \
   } while (0)
+#define SSTAMP_ONCE(k)                                                                \
+  do {                                                                                \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_split_stamps[threadIdx.x >> 6][k] = clock64(); \
+  } while (0)
 #else
 #define SSTAMP(k)
 #define SSTAMP_VAL(k, v)
+#define SSTAMP_ONCE(k)
 #endif
 constexpr unsigned SPLIT_SPINS = 1u << 20;
 
@@ -97,6 +102,7 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
   constexpr int KSH = H / KB, CNT = KSH / SPLIT, HRB = H * ES;
   static_assert(KSH % SPLIT == 0 && ES == 2, "bf16 at H = 512");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  SSTAMP_ONCE(10);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..3: tile tp of the member's slice; out tile
@@ -121,59 +127,12 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
   float* teL = (float*)(schedL + a.n_steps);  // [n_steps][td]
   float* zL = teL + a.n_steps * a.td;         // [16][AF]: this step's draws (written by the waves that own no out tile)
 
-  for (int net = 0; net < 2; ++net) {
-    for (int idx = tid; idx < 2 * H; idx += 256) biasL[net * BSTR + idx] = a.params[net][a.bias_off[idx / H] + idx % H];
-    for (int idx = tid; idx < OT * 16; idx += 256) biasL[net * BSTR + 2 * H + idx] = idx < AF ? a.cbias[net][idx] : 0.f;
-  }
-  if (tid == 0) *failL = 0;
-  for (int idx = tid; idx < a.n_steps * (int)(sizeof(dppo_step) / 4); idx += 256) ((int*)schedL)[idx] = ((const int*)a.sched)[idx];
-  for (int idx = tid; idx < a.n_steps * td; idx += 256) {
-    const dppo_step sx = a.sched[idx / td];
-    teL[idx] = a.temb[sx.net][sx.t * td + idx % td];
-  }
-
-  auto put_state = [&](int net) {
-    const float* ob = a.obs[net];
-    for (int idx = tid; idx < 16 * Kp0; idx += 256) {
-      const int row = idx / Kp0, c = idx - row * Kp0;
-      if (c >= AF + td) {
-        const int j = c - AF - td;
-        const int grow = min(grow0 + row, B - 1);
-        split_lds_put<P>(xin, in_rb, in_km, row, c, j < cond ? ob[(size_t)grow * a.ld_obs + j] : 0.f);
-      }
-    }
-  };
-  put_state(a.sched[0].net);
-
   const sgfloat_p g_noise = (sgfloat_p)a.noise;
   const sgfloat_w g_chains = (sgfloat_w)a.chains, g_traj = (sgfloat_w)a.traj;
   const bool owner = wid < OT;        // this wave owns out tile `wid`: columns wid*16 + 4g + e of batch row r
   const int jcol = wid * 16 + 4 * g;  // first of the lane's four action columns
   const int grow = grow0 + r, growc = min(grow, B - 1);
   const bool writer = m == 0 && grow < B;
-
-  // x_K, and the time embedding of step 0
-  float xc[4] = {0.f, 0.f, 0.f, 0.f};
-  if (owner) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int j = jcol + e;
-      if (j < AF) {
-        const size_t ni = (size_t)growc * AF + j;
-        const float v = a.noise != nullptr ? g_noise[ni] : philox_normal(ni, a.seed_lo, a.seed_hi);
-        xc[e] = v;
-        split_lds_put<P>(xin, in_rb, in_km, r, j, v);
-        if (a.init_slot >= 0 && a.chains != nullptr && writer) g_chains[((size_t)grow * a.chain_len + a.init_slot) * AF + j] = v;
-      }
-    }
-  }
-  {
-    const dppo_step s0 = a.sched[0];
-    for (int idx = tid; idx < 16 * td; idx += 256) {
-      const int row = idx / td, j = idx - row * td;
-      split_lds_put<P>(xin, in_rb, in_km, row, AF + j, a.temb[s0.net][s0.t * td + j]);
-    }
-  }
 
   // ---- the member's weights, resident in registers.  Layer 0: wave `wid` computes the tiles of stream slices 2 wid and
   // 2 wid + 1 (8 tiles x KS0V k-steps); first block layer: tile `wid` of slice m (KSH k-steps); out layer: out tile `wid`
@@ -198,7 +157,82 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
       for (int c = 0; c < CNT; ++c) of[c] = o1[(c * OT + wid) * 64], of2[c] = o2[(c * OT + wid) * 64];
     }
   };
-  load_weights(a.sched[0].net);
+  // ---- prologue.  Everything the call needs from memory is requested before anything is waited for (weights, biases,
+  // step table, state columns, x_K): issued one after the other with a wait in between, as five dependent phases, this took
+  // 17k cycles = 7 us of an 80 us call.
+  const int net0 = a.sched[0].net;
+  load_weights(net0);
+  float bv[2][4], cbv[2];
+#pragma unroll
+  for (int net = 0; net < 2; ++net) {
+    const float* p0 = a.params[net] + a.bias_off[0];
+    const float* p1 = a.params[net] + a.bias_off[1];
+    bv[net][0] = p0[tid], bv[net][1] = p0[tid + 256], bv[net][2] = p1[tid], bv[net][3] = p1[tid + 256];
+    cbv[net] = tid < AF ? a.cbias[net][tid] : 0.f;  // (AF <= 64 < 256)
+  }
+  // x_K: given, or drawn here -- one element per thread (16 x AF <= 1024 elements), not four per owner lane
+  float zk[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = tid + 256 * q;
+    zk[q] = 0.f;
+    if (idx < 16 * AF) {
+      const int row = idx / AF;
+      const size_t ni = (size_t)min(grow0 + row, B - 1) * AF + (idx - row * AF);
+      zk[q] = a.noise != nullptr ? g_noise[ni] : philox_normal(ni, a.seed_lo, a.seed_hi);
+    }
+  }
+  // zero the input image (padding columns stay zero for the whole call)
+  for (int idx = tid; idx < in_rb; idx += 256) *(u32x4*)(xin + idx * 16) = (u32x4){0u, 0u, 0u, 0u};
+  if (tid == 0) *failL = 0;
+  __syncthreads();
+#pragma unroll
+  for (int net = 0; net < 2; ++net) {
+    float* bl = biasL + net * BSTR;
+    bl[tid] = bv[net][0], bl[tid + 256] = bv[net][1], bl[H + tid] = bv[net][2], bl[H + tid + 256] = bv[net][3];
+    if (tid < OT * 16) bl[2 * H + tid] = cbv[net];
+  }
+  for (int idx = tid; idx < a.n_steps * (int)(sizeof(dppo_step) / 4); idx += 256) ((int*)schedL)[idx] = ((const int*)a.sched)[idx];
+  for (int idx = tid; idx < a.n_steps * (td >> 2); idx += 256) {  // one (step, four columns) piece per thread; td % 4 == 0
+    const int st_i = idx / (td >> 2), c4 = (idx - st_i * (td >> 2)) * 4;
+    const dppo_step sx = a.sched[st_i];
+    const float* src = a.temb[sx.net] + sx.t * td + c4;
+    const float t0 = src[0], t1 = src[1], t2 = src[2], t3 = src[3];
+    float* dst = teL + st_i * td + c4;
+    dst[0] = t0, dst[1] = t1, dst[2] = t2, dst[3] = t3;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (tid + 256 * q < 16 * AF) zL[tid + 256 * q] = zk[q];
+
+  auto put_state = [&](int net) {  // the observation columns of the input image (the rest of it is never touched)
+    const float* ob = a.obs[net];
+    for (int idx = tid; idx < 16 * cond; idx += 256) {
+      const int row = idx / cond, j = idx - row * cond;
+      split_lds_put<P>(xin, in_rb, in_km, row, AF + td + j, ob[(size_t)min(grow0 + row, B - 1) * a.ld_obs + j]);
+    }
+  };
+  put_state(net0);
+  __syncthreads();
+
+  // x_K into the owners' registers, the image and the chain; the time embedding of step 0
+  float xc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (owner) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = jcol + e;
+      if (j < AF) {
+        const float v = zL[r * AF + j];
+        xc[e] = v;
+        split_lds_put<P>(xin, in_rb, in_km, r, j, v);
+        if (a.init_slot >= 0 && a.chains != nullptr && writer) g_chains[((size_t)grow * a.chain_len + a.init_slot) * AF + j] = v;
+      }
+    }
+  }
+  for (int idx = tid; idx < 16 * td; idx += 256) {
+    const int row = idx / td, j = idx - row * td;
+    split_lds_put<P>(xin, in_rb, in_km, row, AF + j, teL[j]);
+  }
   __syncthreads();
 
   // exchange slots: [tile][step parity][member][out tile][lane] 16 bytes = the lane's four partial sums, tag in bit 0 of each
@@ -217,6 +251,7 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
   const uint32_t seed_lo = a.seed_lo, seed_hi = a.seed_hi;
   const int te_row = tid / td, te_j = tid - te_row * td;
 
+  SSTAMP_ONCE(11);
   for (int i = 0; i < n_steps; ++i) {
     SSTAMP(0);
     const dppo_step st = schedL[i];
@@ -311,15 +346,17 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
         __builtin_amdgcn_raw_buffer_store_b128(pv, rsrc, off0 + m * SLOT, 0, 16);  // aux 16 = sc1: write-through
       }
       SSTAMP(5);
-      // the members reach this point within a few hundred cycles of each other and a store takes ~1k cycles to become visible:
-      // a sweep issued right behind the own store finds the others' slots still empty and costs a second round trip
-      for (int q = 0; q < a.pre_sweep; ++q) __builtin_amdgcn_s_sleep(1);
+      // One sweep = eight 16-byte sc1 loads per lane, ~2k cycles for the 6-8 KB a wave pulls across the fabric (two full
+      // sweeps in flight take 3k: the cost is bytes as much as latency).  The members reach this point within a few hundred
+      // cycles of each other and a store takes ~1.5k cycles to become visible, so the first sweep usually finds a slot or
+      // two still empty: a retry re-reads ONLY the members a lane is still missing (`need`, one bit per member).
+      unsigned need = active ? (1u << SPLIT) - 1u : 0u;
       auto sweep = [&]() {
-        if (active) {
 #pragma unroll
-          for (int w = 0; w < SPLIT; ++w) raw[w] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off0 + w * SLOT, 0, 16);  // sc1
-        }
+        for (int w = 0; w < SPLIT; ++w)
+          if ((need >> w) & 1u) raw[w] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off0 + w * SLOT, 0, 16);  // sc1
       };
+      for (int q = 0; q < a.pre_sweep; ++q) __builtin_amdgcn_s_sleep(1);
       sweep();
       if constexpr (OT == 4) {  // every wave owns an out tile: each draws its own columns' noise while its loads are in flight
         const size_t ni = (size_t)(i + 1) * B * AF + (size_t)growc * AF + jcol;
@@ -331,19 +368,17 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
       }
       unsigned spins = 0;
       for (;;) {
-        bool ok = true;
-        if (active) {
 #pragma unroll
-          for (int w = 0; w < SPLIT; ++w)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ok &= (raw[w][e] & 1u) == tbit;
+        for (int w = 0; w < SPLIT; ++w) {
+          const bool got = ((raw[w][0] & raw[w][1] & raw[w][2] & raw[w][3] & 1u) == tbit) &&
+                           (((raw[w][0] | raw[w][1] | raw[w][2] | raw[w][3]) & 1u) == tbit);
+          if (got) need &= ~(1u << w);
         }
-        if (__all(ok)) break;
+        if (__all(need == 0u)) break;
         if (++spins >= SPLIT_SPINS) {
           failed = true;
           break;
         }
-        __builtin_amdgcn_s_sleep(1);
         sweep();
       }
       SSTAMP(6);
@@ -377,7 +412,7 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
         for (int e = 0; e < 4; ++e) {
           float eps = bL[2 * H + jcol + e];
 #pragma unroll
-          for (int w = 0; w < SPLIT; ++w) eps += active ? __uint_as_float(raw[w][e] & ~1u) : 0.f;
+          for (int w = 0; w < SPLIT; ++w) eps += __uint_as_float(raw[w][e]);  // (lanes without action columns: unused)
           eps4[e] = eps;
           ze4[e] = z[e];
           if constexpr (OT < 4) ze4[e] = zL[r * AF + min(jcol + e, AF - 1)];
@@ -445,6 +480,7 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
     SSTAMP(8);
     if (*(volatile int*)failL) break;
   }
+  SSTAMP_ONCE(12);
   if (*(volatile int*)failL && m == 0 && owner && grow < B) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -455,7 +491,7 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
 // ------------------------------------------------------------------------------------------------
 static int g_sampler_split = 1;  // tuning knob 27
 void set_sampler_split(int v) { g_sampler_split = v; }
-static int g_split_pre_sweep = 8;  // tuning knob 28: s_sleep(1) periods (64 cycles each) between the own store and the first sweep
+static int g_split_pre_sweep = 0;  // tuning knob 28: s_sleep(1) periods (64 cycles each) between a member's exchange store and its first sweep
 void set_sampler_split_pre_sweep(int v) { g_split_pre_sweep = v < 0 ? 0 : (v > 64 ? 64 : v); }
 
 static int device_cus() {
@@ -512,7 +548,7 @@ static int launch_split_cfg(const SamplerGeom& g, const SampleArgs& a, void* xch
 // 0 launched; -1 shape not covered (caller uses sample_chain_kernel); < -1 error
 int launch_sample_chain_split(const SamplerGeom& g, const SampleArgs& a, void* xch, size_t xch_bytes, hipStream_t s) {
   const int ks0v = (g.in_dim + BF16::KB - 1) / BF16::KB;
-  if (g.H != 512 || g.nb != 1 || !a.merge_top || a.use_ln || ks0v > 3 || g.OT > 4 || g.KS0 < ks0v) return -1;
+  if (g.H != 512 || g.nb != 1 || !a.merge_top || a.use_ln || ks0v > 3 || g.OT > 4 || g.KS0 < ks0v || (a.td & 3)) return -1;
   const bool relu = a.act == ACT_RELU;
 #define DPPO_SPLIT_CASE(K, O)                                                                      \
   if ((ks0v <= 2 ? 2 : 3) == K && g.OT == O)                                                       \

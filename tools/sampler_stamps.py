@@ -55,7 +55,8 @@ def main():
             t = buf[w].astype(np.int64)
             d = [int(t[k] - t[k - 1]) if t[k] and t[k - 1] else None for k in range(1, 9)]
             print(f"wave {w}: " + "  ".join(f"{NAMES[k]}={d[k - 1]}" for k in range(1, 9)) +
-                  f"  step={int(t[8] - t[0])} ticks  polling passes={int(t[9])}")
+                  f"  step={int(t[8] - t[0])} ticks  polling passes={int(t[9])}"
+                  f"  | prologue={int(t[11] - t[10])}  all steps={int(t[12] - t[11])}")
 
 
 if __name__ == "__main__":
