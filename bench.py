@@ -344,7 +344,7 @@ def main():
                      2: "gemm_tn_group_kernel (all weight gradients of one network's backward pass, one launch)"
                      if grouped else "gemm_tn_kernel (H x H weight gradients)",
                      3: "fused_forward_kernel (actor_ft + critic)", 4: "fused_backward_kernel (actor_ft + critic)",
-                     5: "sample_chain_kernel"}
+                     5: "sample_chain_split_kernel (a 16-row tile over eight workgroups; sample_chain_kernel with --tune 27=0)"}
             traffic = None  # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)
             tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_probe{args.probe}{'g' if grouped else ''}_{args.prec}.json")
             if os.path.exists(tpath):

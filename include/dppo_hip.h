@@ -163,7 +163,14 @@ int dppo_critic_forward(const dppo_net_desc* net, int prec, const float* params,
  * noise: (n_steps+1, B, Ta*Da) pre-drawn N(0,1) (noise[0] = x_K, noise[i+1] = the draw of step i; parity runs), or NULL:
  * the kernel then draws them itself (Philox4x32-10 keyed by cfg->seed_*, counter = the element's index in that tensor,
  * Box-Muller) -- same distribution as the reference's torch.randn / randn_like, one launch instead of two. */
-int64_t dppo_sample_chain_workspace_bytes(const dppo_net_desc* actor, int prec, int64_t B); /* 0 without cond_mlp */
+/* Workspace: the cond_mlp encodings (if any) and, where the call runs as the eight-workgroups-per-tile kernel (knob 27: bf16,
+ * hidden 512, one residual block, no LayerNorm, out_dim <= 64, in_dim <= 96, time_dim % 4 == 0, ceil(B / 16) * 8 <= the
+ * device's CU count, i.e. B <= 512 on MI355X), its exchange block, which comes first; 0 when neither applies.  Contents
+ * need no initialisation (the call zeroes the exchange block on `stream` before its launch).  Two calls that may run
+ * concurrently (different streams) must not share a workspace.  After the call the first 32-bit word of an exchange block
+ * is 0, or 1 + the denoising step at which a workgroup gave up waiting for its tile's other seven (bounded spin; the rows
+ * of `traj` it owned are NaN then) -- never observed; the tests check the word. */
+int64_t dppo_sample_chain_workspace_bytes(const dppo_net_desc* actor, int prec, int64_t B);
 int dppo_sample_chain(const dppo_net_desc* actor, int prec, const float* params_base, const void* packed_base,
                       const float* params_ft, const void* packed_ft, const dppo_diffusion_cfg* cfg,
                       const dppo_step* sched, int n_steps, const float* obs, const float* noise, int64_t B,
@@ -436,7 +443,10 @@ int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* 
  *          last, into the W1^T layer's accumulators, instead of carried in registers; forward-sized tiles (default 1)
  * knob 25: the one-block kernels walk their short layers (K = in_dim on the input tile, K = out_dim on the d_out tile)
  *          as the 1-2 k-steps that hold data instead of the 4 the weight stream pads them to (default 1)
- * knob 26: LDS stages of the grouped weight-gradient GEMM: 1 (default; 36.9 KB per workgroup, three workgroups per CU) or 2 */
+ * knob 26: LDS stages of the grouped weight-gradient GEMM: 1 (default; 36.9 KB per workgroup, three workgroups per CU) or 2
+ * knob 27: sampler, small env batches of one-block bf16 networks at hidden 512: one 16-row tile over eight workgroups with
+ *          the weights resident in registers (default 1; see dppo_sample_chain_workspace_bytes) or over one (0)
+ * knob 28: knob 27's kernel: 64-cycle sleep periods between a workgroup's exchange store and its first sweep (default 0) */
 int dppo_tune_set(int knob, int value);
 /* one bare layer GEMM: out[M][ldo] = act(X[M][Kp] . W[N][Kp]^T + bias) with elem = prec operands;
  * out_f32 and/or out_elem may be NULL; ldo >= round_up(N,16) */

@@ -106,3 +106,30 @@ def test_split_sampler_leaves_larger_batches_to_the_one_workgroup_kernel():
     st = torch.rand(16 * (cus // 8) + 40, 1, a.cond_dim, device=DEV) * 2 - 1
     s = m(cond={"state": st})
     assert torch.isfinite(s.chains).all()
+
+
+def test_split_sampler_under_uneven_load_on_a_second_stream():
+    """The hand-over must not depend on timing or placement: with another stream keeping CUs and the memory system busy
+    (GEMMs and copies of uneven sizes, so that workgroups of a tile start at different times and some members wait for a
+    free CU while the others spin), every call gives the bits of the quiet run, and no member times out."""
+    m, a, _ = build_model("hopper", DDPM, 11, "bf16")
+    B = 512
+    sts = [(torch.rand(B, 1, a.cond_dim, device=DEV) * 2 - 1) for _ in range(4)]
+    noise = torch.randn(21, B, a.horizon_steps, a.action_dim, device=DEV)
+    quiet = [m(cond={"state": s}, noise=noise).chains.clone() for s in sts]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    x = torch.randn(4096, 4096, device=DEV, dtype=torch.bfloat16)
+    big = torch.empty(64 << 20, device=DEV, dtype=torch.float32)
+    got = []
+    for rep in range(6):
+        with torch.cuda.stream(side):
+            for k in range(3):
+                y = x[: 512 * (1 + (rep + k) % 8)] @ x  # 512 .. 4096 rows: a different number of busy CUs every time
+                big[: (8 << 20) * (1 + k)].copy_(big[(32 << 20): (32 << 20) + (8 << 20) * (1 + k)])
+        for s in sts:
+            got.append(m(cond={"state": s}, noise=noise).chains)
+    torch.cuda.synchronize()
+    assert timeout_word(m) == 0
+    for i, c in enumerate(got):
+        assert torch.equal(c, quiet[i % len(sts)])

@@ -1,6 +1,6 @@
 # GPU box: the artefacts of the round's final build (copied from gpurun_out/r02fin2 into profiles/ afterwards).
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02fin2; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${OUT_TAG:-r02fin2}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 echo "[1] bench full"; timeout -k 10 500 python3 $R/bench.py > $O/bench.json 2> $O/bench.err && tail -c 400 $O/bench.json && echo
 echo "[2] rocprof stats"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-pixel --no-fp32 > $O/stats.log 2>&1 && echo ok
@@ -20,3 +20,6 @@ rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/trace $O/stats $O/stats_serial
 echo "[5] fused bench"; timeout -k 10 200 python3 tools/fused_bench.py > $O/fused_bench.txt 2>&1 && tail -6 $O/fused_bench.txt
 echo "[6] shapes"; timeout -k 10 300 python3 tools/shape_bench.py > $O/shapes.txt 2>&1 && tail -5 $O/shapes.txt
 echo "[7] dp2 rehearsal"; HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --share-gpu --no-cpu-baseline --no-pixel --no-fp32 --n-steps 50 > $O/dp2.log 2>&1 && tail -1 $O/dp2.log | cut -c1-300
+echo "[8] sampler kernel probe"; timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-pixel --no-fp32 --probe 5 > $O/bench_probe5.json 2> $O/bench_probe5.err && tail -c 600 $O/bench_probe5.json
+echo "[9] sampler, one workgroup per tile (knob 27 = 0)"; timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-pixel --no-fp32 --probe 5 --tune 27=0 > $O/bench_probe5_nosplit.json 2> $O/bench_probe5_nosplit.err && tail -c 600 $O/bench_probe5_nosplit.json
+if [ -f dppo_amd/lib/libdppo_hip_stamps.so ]; then echo "[10] split sampler stamps"; DPPO_HIP_LIB=$R/dppo_amd/lib/libdppo_hip_stamps.so timeout -k 10 120 python3 tools/sampler_stamps.py > $O/split_sampler_stamps.txt 2>/dev/null; cat $O/split_sampler_stamps.txt; fi
