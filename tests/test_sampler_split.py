@@ -3,9 +3,11 @@ replaces for small env batches.  Same packed fragments, same partial sums added 
 difference is the tag bit: each fp32 partial sum of the out layer travels between workgroups with its least significant
 bit replaced by a tag (cleared on arrival), i.e. <= 1 ulp = 6e-8 relative per partial.  A difference of that size moves
 x_{t-1} by ~1e-7, which now and then crosses a bf16 rounding boundary of the next step's input (4e-3 relative on one
-input element) -- so the two kernels agree to fp32 rounding on almost every element and to the bf16 input rounding on
-a few: stated tolerance mean |d| <= 1e-4, max |d| <= 3e-2 (the bf16 chains are held to 5e-2 against the reference's
-goldens, tests/test_hip_parity.py, which runs with the knob at its default).  Run to run the split kernel is bit-reproducible.
+input element) -- so the two kernels agree to fp32 rounding on almost every element (~88 % are bit-identical) and to the
+bf16 input rounding on a few.  Measured over the cases below (profiles/r02_final3_split_vs_one_workgroup_chain_diffs.txt):
+max |d| 3.5e-4, mean |d| <= 4e-7; stated tolerance max |d| <= 5e-3, mean |d| <= 1e-5 (the bf16 chains are held to 5e-2
+against the reference's goldens, tests/test_hip_parity.py, which runs with the knob at its default).  Run to run the split
+kernel is bit-reproducible.
 Reference path: model/diffusion/diffusion_vpg.py:139-315.
 """
 import numpy as np
@@ -63,7 +65,7 @@ def test_split_sampler_matches_the_one_workgroup_kernel(case, B):
         assert torch.isfinite(y).all()
         assert torch.equal(y, y2)
         d = (x - y).abs()
-        assert d.max().item() <= 3e-2 and d.mean().item() <= 1e-4, (d.max().item(), d.mean().item())
+        assert d.max().item() <= 5e-3 and d.mean().item() <= 1e-5, (d.max().item(), d.mean().item())
 
 
 def test_split_sampler_many_calls_reuse_the_exchange_block():
@@ -87,7 +89,7 @@ def test_split_sampler_many_calls_reuse_the_exchange_block():
     for i, c in enumerate(got):
         assert torch.equal(c, got[i % len(sts)])  # the same inputs give the same bits, call after call
         d = (c - ref[i % len(sts)]).abs()
-        assert d.max().item() <= 3e-2 and d.mean().item() <= 1e-4
+        assert d.max().item() <= 5e-3 and d.mean().item() <= 1e-5
 
 
 def test_split_sampler_leaves_larger_batches_to_the_one_workgroup_kernel():
