@@ -107,7 +107,17 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..3: tile tp of the member's slice; out tile
   const int r = lane & 15, g = lane >> 4;
-  const int tile = blockIdx.x / SPLIT, m = blockIdx.x % SPLIT;
+  // Block id -> (tile, member): the eight members of a tile get ids that are congruent modulo 8 and consecutive within their
+  // residue class.  Blocks are observed to be dealt round-robin over the 8 XCDs, each XCD placing its share in order, so a
+  // tile's members sit on ONE XCD and whatever part of the grid is resident -- another queue or process may hold CUs -- is,
+  // per XCD, a run of complete tiles plus at most one partial one: complete tiles always finish and free their CUs.  (With
+  // tile = id / 8 a tile has one member on each XCD, and two kernels sharing the chip can each hold XCDs the other one's tiles
+  // need: measured 8-9 ms per call with three processes sampling at once, against 0.21-0.26 ms with this mapping, and 70 us
+  // instead of 77 us for one process alone.)  Only speed and
+  // robustness depend on the placement, never results.  The grid is padded to a multiple of 64 blocks; empty tiles leave here.
+  const int xcd_class = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int m = jx & 7, tile = xcd_class + 8 * (jx >> 3);
+  if (tile * 16 >= a.B) return;
   const int grow0 = tile * 16;
   const int AF = a.AF, td = a.td, cond = a.cond, Kp0 = a.Kp0, B = a.B;
   const int in_rb = Kp0 * ES, in_km = split_kmask_of(in_rb);
@@ -182,6 +192,27 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
       zk[q] = a.noise != nullptr ? g_noise[ni] : philox_normal(ni, a.seed_lo, a.seed_hi);
     }
   }
+  // the first network's observation columns (up to 4 elements per thread here, the rest in put_state's loop) and the
+  // step table's words, requested with the rest
+  float ob0[4];
+  int sw[2];
+  {
+    const float* ob = a.obs[net0];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = tid + 256 * q;
+      ob0[q] = 0.f;
+      if (idx < 16 * cond) {
+        const int row = idx / cond;
+        ob0[q] = ob[(size_t)min(grow0 + row, B - 1) * a.ld_obs + (idx - row * cond)];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int idx = tid + 256 * q;
+      sw[q] = idx < a.n_steps * (int)(sizeof(dppo_step) / 4) ? ((const int*)a.sched)[idx] : 0;
+    }
+  }
   // zero the input image (padding columns stay zero for the whole call)
   for (int idx = tid; idx < in_rb; idx += 256) *(u32x4*)(xin + idx * 16) = (u32x4){0u, 0u, 0u, 0u};
   if (tid == 0) *failL = 0;
@@ -192,7 +223,10 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
     bl[tid] = bv[net][0], bl[tid + 256] = bv[net][1], bl[H + tid] = bv[net][2], bl[H + tid + 256] = bv[net][3];
     if (tid < OT * 16) bl[2 * H + tid] = cbv[net];
   }
-  for (int idx = tid; idx < a.n_steps * (int)(sizeof(dppo_step) / 4); idx += 256) ((int*)schedL)[idx] = ((const int*)a.sched)[idx];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+    if (tid + 256 * q < a.n_steps * (int)(sizeof(dppo_step) / 4)) ((int*)schedL)[tid + 256 * q] = sw[q];
+  for (int idx = tid + 512; idx < a.n_steps * (int)(sizeof(dppo_step) / 4); idx += 256) ((int*)schedL)[idx] = ((const int*)a.sched)[idx];
   for (int idx = tid; idx < a.n_steps * (td >> 2); idx += 256) {  // one (step, four columns) piece per thread; td % 4 == 0
     const int st_i = idx / (td >> 2), c4 = (idx - st_i * (td >> 2)) * 4;
     const dppo_step sx = a.sched[st_i];
@@ -205,14 +239,22 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
   for (int q = 0; q < 4; ++q)
     if (tid + 256 * q < 16 * AF) zL[tid + 256 * q] = zk[q];
 
-  auto put_state = [&](int net) {  // the observation columns of the input image (the rest of it is never touched)
+  auto put_state = [&](int net, int first) {  // the observation columns of the input image (the rest of it is never touched)
     const float* ob = a.obs[net];
-    for (int idx = tid; idx < 16 * cond; idx += 256) {
+    for (int idx = tid + first; idx < 16 * cond; idx += 256) {
       const int row = idx / cond, j = idx - row * cond;
       split_lds_put<P>(xin, in_rb, in_km, row, AF + td + j, ob[(size_t)min(grow0 + row, B - 1) * a.ld_obs + j]);
     }
   };
-  put_state(net0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = tid + 256 * q;
+    if (idx < 16 * cond) {
+      const int row = idx / cond;
+      split_lds_put<P>(xin, in_rb, in_km, row, AF + td + (idx - row * cond), ob0[q]);
+    }
+  }
+  put_state(net0, 1024);
   __syncthreads();
 
   // x_K into the owners' registers, the image and the chain; the time embedding of step 0
@@ -473,7 +515,7 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
     }
     SSTAMP(7);
     if (nnet != net) {  // the step table switches network: state columns of a cond_mlp actor, and every register weight
-      if (a.obs[0] != a.obs[1]) put_state(nnet);
+      if (a.obs[0] != a.obs[1]) put_state(nnet, 0);
       load_weights(nnet);
     }
     lds_barrier();
@@ -540,7 +582,7 @@ static int launch_split_cfg(const SamplerGeom& g, const SampleArgs& a, void* xch
   b.pre_sweep = g_split_pre_sweep;
   const int tiles = (a.B + 15) / 16;
   const bool probe = probe_begin(PROBE_SAMPLER, s);
-  hipLaunchKernelGGL(kern, dim3(tiles * SPLIT), dim3(256), lds, s, b, (char*)xch + 256, (int)(xch_bytes - 256), (unsigned*)xch);
+  hipLaunchKernelGGL(kern, dim3((tiles + 7) / 8 * 64), dim3(256), lds, s, b, (char*)xch + 256, (int)(xch_bytes - 256), (unsigned*)xch);
   if (probe) probe_end(s, 2.0 * a.B * a.n_steps * ((double)g.in_dim * g.H + 2.0 * g.nb * g.H * g.H + (double)g.H * g.out_dim));
   return 0;
 }
