@@ -2411,7 +2411,7 @@ int dppo_tune_set(int knob, int value) {
     set_sampler_split(value);
     return 0;
   }
-  if (knob == 28) {  // split sampler: 64-cycle sleep periods between a member's exchange store and its first sweep (default 0)
+  if (knob == 28) {  // split sampler: 64-cycle sleep periods between a member's exchange store and its first sweep (default 4)
     set_sampler_split_pre_sweep(value);
     return 0;
   }

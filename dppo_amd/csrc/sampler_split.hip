@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
 // ------------------------------------------------------------------------------------------------
 static int g_sampler_split = 1;  // tuning knob 27
 void set_sampler_split(int v) { g_sampler_split = v; }
-static int g_split_pre_sweep = 0;  // tuning knob 28: s_sleep(1) periods (64 cycles each) between a member's exchange store and its first sweep
+static int g_split_pre_sweep = 4;  // tuning knob 28: s_sleep(1) periods (64 cycles each) between a member's exchange store and its first sweep
 void set_sampler_split_pre_sweep(int v) { g_split_pre_sweep = v < 0 ? 0 : (v > 64 ? 64 : v); }
 
 static int device_cus() {

@@ -446,7 +446,7 @@ int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* 
  * knob 26: LDS stages of the grouped weight-gradient GEMM: 1 (default; 36.9 KB per workgroup, three workgroups per CU) or 2
  * knob 27: sampler, small env batches of one-block bf16 networks at hidden 512: one 16-row tile over eight workgroups with
  *          the weights resident in registers (default 1; see dppo_sample_chain_workspace_bytes) or over one (0)
- * knob 28: knob 27's kernel: 64-cycle sleep periods between a workgroup's exchange store and its first sweep (default 0) */
+ * knob 28: knob 27's kernel: 64-cycle sleep periods between a workgroup's exchange store and its first sweep (default 4) */
 int dppo_tune_set(int knob, int value);
 /* one bare layer GEMM: out[M][ldo] = act(X[M][Kp] . W[N][Kp]^T + bias) with elem = prec operands;
  * out_f32 and/or out_elem may be NULL; ldo >= round_up(N,16) */
