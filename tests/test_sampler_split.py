@@ -135,3 +135,23 @@ def test_split_sampler_under_uneven_load_on_a_second_stream():
     assert timeout_word(m) == 0
     for i, c in enumerate(got):
         assert torch.equal(c, quiet[i % len(sts)])
+
+
+def test_split_sampler_results_do_not_depend_on_the_polling_delay():
+    """Knob 28 moves the first sweep of every hand-over from right behind the exchange store (0: most first sweeps find
+    empty slots and retry) to 2k cycles later (32: every slot is long written): timing only, the bits must not change."""
+    from dppo_amd import hip
+    m, a, _ = build_model("halfcheetah", DDPM, 13, "bf16")
+    lib = hip.load()
+    B = 200
+    st = torch.rand(B, 1, a.cond_dim, device=DEV) * 2 - 1
+    noise = torch.randn(21, B, a.horizon_steps, a.action_dim, device=DEV)
+    out = []
+    try:
+        for delay in (0, 4, 32):
+            assert lib.dppo_tune_set(28, delay) == 0
+            out.append(m(cond={"state": st}, noise=noise).chains.clone())
+            assert timeout_word(m) == 0
+    finally:
+        lib.dppo_tune_set(28, 4)
+    assert torch.equal(out[0], out[1]) and torch.equal(out[0], out[2])
