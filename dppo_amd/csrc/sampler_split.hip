@@ -139,7 +139,10 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
 
   const sgfloat_p g_noise = (sgfloat_p)a.noise;
   const sgfloat_w g_chains = (sgfloat_w)a.chains, g_traj = (sgfloat_w)a.traj;
-  const bool owner = wid < OT;        // this wave owns out tile `wid`: columns wid*16 + 4g + e of batch row r
+  // a wave owns out tile `wid` (columns wid*16 + 4g + e of batch row r) if that tile holds action columns; the other waves
+  // ("helpers": 3 at Ta*Da <= 16, none above 48) draw the noise while the owners wait for the exchange
+  const int n_own = (AF + 15) >> 4;
+  const bool owner = wid < n_own;
   const int jcol = wid * 16 + 4 * g;  // first of the lane's four action columns
   const int grow = grow0 + r, growc = min(grow, B - 1);
   const bool writer = m == 0 && grow < B;
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
       };
       for (int q = 0; q < a.pre_sweep; ++q) __builtin_amdgcn_s_sleep(1);
       sweep();
-      if constexpr (OT == 4) {  // every wave owns an out tile: each draws its own columns' noise while its loads are in flight
+      if (n_own == 4) {  // every wave owns an out tile: each draws its own columns' noise while its loads are in flight
         const size_t ni = (size_t)(i + 1) * B * AF + (size_t)growc * AF + jcol;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -430,11 +433,11 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
         *failL = 1;
       }
     }
-    if constexpr (OT < 4) {
+    if (n_own < 4) {
       // the waves without an out tile draw this step's noise for the whole tile while the owners wait for the exchange
       if (!owner) {
-        constexpr int NH = (4 - OT) * 64;
-        for (int idx = (wid - OT) * 64 + lane; idx < 16 * AF; idx += NH) {
+        const int NH = (4 - n_own) * 64;
+        for (int idx = (wid - n_own) * 64 + lane; idx < 16 * AF; idx += NH) {
           const int row = idx / AF;
           const size_t ni = (size_t)(i + 1) * B * AF + (size_t)min(grow0 + row, B - 1) * AF + (idx - row * AF);
           zL[idx] = have_noise ? g_noise[ni] : philox_normal(ni, seed_lo, seed_hi);
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
           for (int w = 0; w < SPLIT; ++w) eps += __uint_as_float(raw[w][e]);  // (lanes without action columns: unused)
           eps4[e] = eps;
           ze4[e] = z[e];
-          if constexpr (OT < 4) ze4[e] = zL[r * AF + min(jcol + e, AF - 1)];
+          if (n_own < 4) ze4[e] = zL[r * AF + min(jcol + e, AF - 1)];
         }
         if (!use_ddim) {
 #pragma unroll

@@ -21,6 +21,7 @@ from dppo_amd.util.optim import FlatAdamW, step_and_repack  # noqa: E402
 # (obs, act, Ta, actor dims, act fn, LN, cond_mlp, time_dim, critic dims, K, Kft, ddim, n_envs, batch) from cfg/*/finetune/*/ft_ppo_diffusion_mlp.yaml
 SHAPES = {
     "hopper": dict(obs=11, act=3, ta=4, dims=[512] * 3, fn="ReLU", ln=False, cm=None, td=16, cdims=[256] * 3, K=20, Kft=10, ddim=False, envs=512, batch=50000),
+    "halfcheetah": dict(obs=17, act=6, ta=4, dims=[512] * 3, fn="ReLU", ln=False, cm=None, td=16, cdims=[256] * 3, K=20, Kft=10, ddim=False, envs=512, batch=50000),
     "can": dict(obs=23, act=7, ta=4, dims=[512] * 3, fn="Mish", ln=False, cm=None, td=16, cdims=[256] * 3, K=20, Kft=10, ddim=False, envs=256, batch=7500),
     "square": dict(obs=23, act=7, ta=4, dims=[1024] * 3, fn="Mish", ln=False, cm=[512, 64], td=32, cdims=[256] * 3, K=20, Kft=10, ddim=False, envs=256, batch=10000),
     "transport": dict(obs=59, act=14, ta=8, dims=[1024] * 3, fn="Mish", ln=False, cm=None, td=32, cdims=[256] * 3, K=20, Kft=10, ddim=False, envs=256, batch=10000),
