@@ -159,3 +159,25 @@ def test_sampling_and_logprob_step_tables_follow_the_reference_formulas():
         lp = np.frombuffer(m._logprob_schedule("cpu").numpy().tobytes(), dtype=hip.STEP_DTYPE)
         assert len(lp) == m.ft_denoising_steps and all(r["std"] >= np.float32(0.1) for r in lp)  # min_logprob_denoising_std
         assert [int(r["t"]) for r in lp] == ([80, 60, 40, 20, 0] if use_ddim else list(reversed(range(10))))
+
+
+def test_split_sampler_block_id_mapping_is_a_bijection_with_tiles_on_one_residue_class():
+    """csrc/sampler_split.hip maps block id b -> (tile, member) = ((b & 7) + 8 * (b >> 6), (b >> 3) & 7) on a grid padded to
+    64 * ceil(tiles / 8) blocks (restated here): every (tile < tiles, member < 8) pair must be hit exactly once, all eight
+    members of a tile must share b mod 8 (= one XCD under the observed round-robin placement) and be consecutive within
+    that residue class (= resident together under in-order placement), and blocks of tiles >= `tiles` must be the ones that
+    exit."""
+    for tiles in range(1, 33):
+        grid = (tiles + 7) // 8 * 64
+        seen = {}
+        for b in range(grid):
+            tile, m = (b & 7) + 8 * (b >> 6), (b >> 3) & 7
+            if tile < tiles:
+                assert (tile, m) not in seen
+                seen[(tile, m)] = b
+        assert len(seen) == tiles * 8
+        for t in range(tiles):
+            ids = [seen[(t, m)] for m in range(8)]
+            assert len({b & 7 for b in ids}) == 1
+            ranks = sorted(b >> 3 for b in ids)
+            assert ranks == list(range(ranks[0], ranks[0] + 8))
