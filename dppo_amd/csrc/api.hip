@@ -689,6 +689,9 @@ static void flush_slabs(MlpBufs<P>& B, hipStream_t s, const SlotOuts* slots = nu
     memset(&t, 0, sizeof(t));
     t.jobs = B.slab_jobs;
     if (slots != nullptr) t.colsum = B.tile_colsum, t.tiles = B.tiles, t.width = slot_width, t.slots = *slots;
+    if (g_dbg & 4) t.jobs.n = 0;          // timing experiments (knob 8; results are wrong while set): no slab reductions,
+    if (g_dbg & 8) t.slots.n_slots = 0;   // no bias sums,
+    if (g_dbg & 16) fin = nullptr;        // no loss statistics
     launch_tail_reduce(t, fin, s);
   } else {
     launch_slab_reduce_batch(B.slab_jobs, s);

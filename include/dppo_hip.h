@@ -419,7 +419,9 @@ int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* 
  * knob 7: fused kernels, bit 0 / 1 = 32-row tiles at two workgroups per CU in the backward / forward at H = 512,
  *         bit 2 / 3 = 64- / 32-row tiles at two workgroups per CU in the forward / backward at H = 256 (default 0: none
  *         of them pays)
- * knob 8: timing experiments on the fused backward (results are wrong while set); knob 9: side streams at low priority
+ * knob 8: timing experiments (results are wrong while set): bit 0 / 1 the fused backward without its gradient stores / derivative
+ *         fetch, bit 2 / 3 / 4 the reduction launch behind the weight-gradient GEMMs without its slab reductions / bias sums / loss
+ *         statistics (tools/tail_reduce_parts.sh); knob 9: side streams at low priority
  * knob 5: weight-gradient GEMM kernel, 0 = register-staged (default), 1..8 = an LDS-DMA ring configuration, -1 = by shape
  * knob 6: thin (512 x 64) weight-gradient tiles on / off; knob 10: critic side stream gated on the actor's forward (0 off)
  * knob 11: time-embedding gradient from a one-hot of the denoising step in the K padding of the actor's input rows, so
