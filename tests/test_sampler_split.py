@@ -70,7 +70,7 @@ def test_split_sampler_matches_the_one_workgroup_kernel(case, B):
 
 def test_split_sampler_many_calls_reuse_the_exchange_block():
     """Back-to-back calls on one stream reuse the same exchange slots with the same tags: every call must start from a
-    zeroed block (the launcher's memset) and never read the previous call's partial sums."""
+    zeroed block (the launcher's zeroing kernel) and never read the previous call's partial sums."""
     from dppo_amd import hip
     m, a, _ = build_model("hopper", DDPM, 9, "bf16")
     lib = hip.load()
@@ -155,3 +155,29 @@ def test_split_sampler_results_do_not_depend_on_the_polling_delay():
     finally:
         lib.dppo_tune_set(28, 4)
     assert torch.equal(out[0], out[1]) and torch.equal(out[0], out[2])
+
+
+def test_split_sampler_replays_from_a_hip_graph():
+    """The exchange block is zeroed by a kernel in front of the sampler's and every tag is counted within the call (no
+    per-launch salt), so a captured call can be replayed: each replay on new observations gives the eager call's bits."""
+    m, a, _ = build_model("hopper", DDPM, 17, "bf16")
+    B = 256
+    sts = [(torch.rand(B, 1, a.cond_dim, device=DEV) * 2 - 1) for _ in range(3)]
+    noise = torch.randn(21, B, a.horizon_steps, a.action_dim, device=DEV)
+    eager = [m(cond={"state": s}, noise=noise).chains.clone() for s in sts]
+    st_static = sts[0].clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m(cond={"state": st_static}, noise=noise)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = m(cond={"state": st_static}, noise=noise)
+    for rep in range(2):
+        for k, s in enumerate(sts):
+            st_static.copy_(s)
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out.chains, eager[k])
+    assert timeout_word(m) == 0
