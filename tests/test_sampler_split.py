@@ -18,6 +18,20 @@ from tests.test_hip_parity import DEV, build_model
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _split_kernel_on():
+    """These tests are about knob 27's kernel: switch it on whatever DPPO_TUNE says (the suite is also run with every
+    default-on optimisation off), and put the environment's choice back afterwards."""
+    import os
+    from dppo_amd import hip
+    lib = hip.load()
+    assert lib.dppo_tune_set(27, 1) == 0 and lib.dppo_tune_set(28, 4) == 0
+    yield
+    env = dict(kv.split("=") for kv in filter(None, os.environ.get("DPPO_TUNE", "").split(",")))
+    lib.dppo_tune_set(27, int(env.get("27", 1)))
+    lib.dppo_tune_set(28, int(env.get("28", 4)))
+
 DDPM = dict(denoising_steps=20, ft_denoising_steps=10, randn_clip_value=3)
 CASES = {
     # name: (spec, diffusion kwargs)                      out tiles / layer-0 k-steps / activation of the actor
