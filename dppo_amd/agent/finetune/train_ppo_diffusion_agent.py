@@ -187,6 +187,8 @@ class TrainPPODiffusionAgent:
             # (env.pipeline_groups) software-pipelined against the sampler (dppo_amd/util/rollout.py)
             reward_trajs, terminated_trajs, done_trajs, prev_obs = collect_rollout(
                 self._policy(), self.venv, prev_obs, S, self.act_steps, obs_buf, chains_buf, deterministic=eval_mode)
+            if hasattr(self.model, "check_sampler_health"):
+                self.model.check_sampler_health()  # fail loudly if the split sampler's hand-over ever timed out
             firsts[1:] = done_trajs
             done_venv = done_trajs[-1].astype(bool)
             cnt_train_step += S * E * self.act_steps * self.world if not eval_mode else 0

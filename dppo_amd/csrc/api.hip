@@ -1285,6 +1285,13 @@ int64_t dppo_sample_chain_workspace_bytes(const dppo_net_desc* actor, int prec, 
   return prec == DPPO_PREC_F32 ? (int64_t)sample_ws<F32>(*actor, B) : (int64_t)sample_ws<BF16>(*actor, B);
 }
 
+int64_t dppo_sample_chain_exchange_bytes(const dppo_net_desc* actor, int prec, int64_t B) {
+  if (check_net(actor) || check_prec(prec)) return -1;
+  if (actor->plain || B < 1) return 0;
+  const bool split = prec == DPPO_PREC_F32 ? sample_split<F32>(*actor, B) : sample_split<BF16>(*actor, B);
+  return split ? (int64_t)sampler_split_xch_bytes(*actor, B) : 0;
+}
+
 int dppo_sample_chain(const dppo_net_desc* actor, int prec, const float* params_base, const void* packed_base,
                       const float* params_ft, const void* packed_ft, const dppo_diffusion_cfg* cfg,
                       const dppo_step* sched, int n_steps, const float* obs, const float* noise, int64_t B, float* traj,

@@ -106,6 +106,7 @@ SYMBOLS = {
     "dppo_actor_forward": (_I, [_ND, _I, _P, _P, _P, _P, _P, _L, _P, _P, _L, _P]),
     "dppo_critic_forward": (_I, [_ND, _I, _P, _P, _P, _L, _P, _P, _L, _P]),
     "dppo_sample_chain_workspace_bytes": (_L, [_ND, _I, _L]),
+    "dppo_sample_chain_exchange_bytes": (_L, [_ND, _I, _L]),
     "dppo_sample_chain": (_I, [_ND, _I, _P, _P, _P, _P, C.POINTER(DiffusionCfg), _P, _I, _P, _P, _L, _P, _P, _I, _I,
                                _P, _L, _P]),
     "dppo_plain_sample_workspace_bytes": (_L, [_ND, _I, _L]),

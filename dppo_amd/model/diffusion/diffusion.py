@@ -242,6 +242,9 @@ class DiffusionModel(nn.Module):
             else:
                 wsb = lib.dppo_sample_chain_workspace_bytes(C.byref(d), self.prec, B)
                 ws = self.__dict__.setdefault("_ws_sample", hip.Workspace()).get(wsb, dev) if wsb > 0 else None
+                # a tile over eight workgroups (csrc/sampler_split.hip): the workspace's first word then says whether every
+                # hand-over between them completed -- check_sampler_health() reads it at the caller's next sync point
+                self.__dict__["_ws_sample_has_word"] = wsb > 0 and lib.dppo_sample_chain_exchange_bytes(C.byref(d), self.prec, B) > 0
                 hip.check(lib.dppo_sample_chain(
                     C.byref(d), self.prec, base.flat_params().data_ptr(), base.packed(self.prec, K).data_ptr(),
                     ft.flat_params().data_ptr(), ft.packed(self.prec, K).data_ptr(), C.byref(cfg),
@@ -252,6 +255,18 @@ class DiffusionModel(nn.Module):
         if return_chain:
             chains = chains.view(B, chain_len, self.horizon_steps, self.action_dim)
         return Sample(traj, chains)
+
+    def check_sampler_health(self):
+        """Raises if a workgroup of the last sampling call gave up waiting for its tile's other seven (bounded spin in the
+        eight-workgroups-per-tile kernel; its rows of the trajectory are NaN then).  One 4-byte D2H read: call it where the
+        host synchronises anyway (the rollout loop copies every step's actions to the host)."""
+        ws = self.__dict__.get("_ws_sample")
+        if ws is None or ws.buf is None or not self.__dict__.get("_ws_sample_has_word", False):
+            return
+        word = int(ws.buf[:4].view(torch.int32).item())
+        if word != 0:
+            raise hip.DppoHipError(f"sampler: a workgroup timed out waiting for its tile at denoising step {word - 1} "
+                                   "(dppo_sample_chain, exchange block); the call's trajectories are poisoned with NaN")
 
     @torch.no_grad()
     def forward(self, cond, deterministic=True, noise=None):

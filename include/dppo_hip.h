@@ -171,6 +171,10 @@ int dppo_critic_forward(const dppo_net_desc* net, int prec, const float* params,
  * is 0, or 1 + the denoising step at which a workgroup gave up waiting for its tile's other seven (bounded spin; the rows
  * of `traj` it owned are NaN then) -- never observed; the tests check the word. */
 int64_t dppo_sample_chain_workspace_bytes(const dppo_net_desc* actor, int prec, int64_t B);
+/* Bytes of the exchange block at the head of that workspace, 0 when the call will run one workgroup per tile: tells a caller
+ * whether the workspace's first word is the time-out word described above (a host that already synchronises once per rollout
+ * reads it there and raises; dppo_amd.model.diffusion.DiffusionModel.check_sampler_health does). */
+int64_t dppo_sample_chain_exchange_bytes(const dppo_net_desc* actor, int prec, int64_t B);
 int dppo_sample_chain(const dppo_net_desc* actor, int prec, const float* params_base, const void* packed_base,
                       const float* params_ft, const void* packed_ft, const dppo_diffusion_cfg* cfg,
                       const dppo_step* sched, int n_steps, const float* obs, const float* noise, int64_t B,

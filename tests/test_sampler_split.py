@@ -49,6 +49,8 @@ CASES = {
 def timeout_word(m):
     ws = m.__dict__.get("_ws_sample")
     assert ws is not None and ws.buf is not None, "the split sampler takes its exchange block from the sampling workspace"
+    assert m.__dict__.get("_ws_sample_has_word") is True
+    m.check_sampler_health()  # the product-side check: raises on a non-zero word
     return int(ws.buf[:4].view(torch.int32).item())
 
 
@@ -195,3 +197,16 @@ def test_split_sampler_replays_from_a_hip_graph():
             torch.cuda.synchronize()
             assert torch.equal(out.chains, eager[k])
     assert timeout_word(m) == 0
+
+
+def test_health_check_raises_on_a_time_out_word():
+    from dppo_amd import hip
+    m, a, _ = build_model("hopper", DDPM, 3, "bf16")
+    st = torch.rand(64, 1, a.cond_dim, device=DEV) * 2 - 1
+    m(cond={"state": st})
+    m.check_sampler_health()
+    m.__dict__["_ws_sample"].buf[:4].view(torch.int32).fill_(6)  # what a member that gave up at step 5 leaves behind
+    with pytest.raises(hip.DppoHipError, match="denoising step 5"):
+        m.check_sampler_health()
+    m(cond={"state": st})  # the next call zeroes the block again
+    m.check_sampler_health()
