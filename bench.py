@@ -203,6 +203,8 @@ def main():
     ap.add_argument("--n-envs", type=int, default=512)
     ap.add_argument("--n-steps", type=int, default=500, help="rollout length behind the update buffer")
     ap.add_argument("--batch", type=int, default=50000)
+    ap.add_argument("--spin-up", type=int, default=300,
+                    help="untimed calls in front of each timed region, beyond --warmup, so that the GPU's clocks have ramped")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the secondary fp32 (the reference's own precision) pass")
     ap.add_argument("--no-pixel", action="store_true", help="skip the secondary pixel-observation pass (BASELINE configs[4] shapes)")
@@ -293,20 +295,33 @@ def main():
         def allreduce_only(i):
             dp.allreduce_grads()
 
-        def timed(fn, probe=False):
+        def timed(fn, probe=False, reps=1):
+            """`reps` passes over the same `steps` calls inside one timed region; returns the time of ONE pass."""
             for i in range(args.warmup):
                 fn(i)
+            # Clock spin-up (untimed, same count on every rank): an idle MI355X sits at its lowest sclk level (531 MHz by rocm-smi)
+            # and takes tens of milliseconds of load to ramp.  As the first GPU process on a fresh box the 20 timed update steps
+            # (8 ms of work) ran 6x slower than in the next process (2.4 vs 0.40 ms per step, twice in two tries); `--spin-up`
+            # more untimed calls of the same function in front of the timed region take the ramp out of the measurement.
+            for i in range(args.spin_up):
+                fn(i % n_total)
+                if i % 32 == 31:
+                    torch.cuda.synchronize()
             barrier()
             if probe:
                 hip.check(lib.dppo_probe_arm(probe_id, 16 * args.steps), "dppo_probe_arm")
             t0 = time.perf_counter()
-            for i in range(args.warmup, n_total):
-                fn(i)
+            for _ in range(reps):
+                for i in range(args.warmup, n_total):
+                    fn(i)
             barrier()
-            return max_over_ranks(time.perf_counter() - t0)
+            return max_over_ranks(time.perf_counter() - t0) / reps
 
         r = {"model": model, "prec": prec}
-        r["dt_sample"] = timed(sample_step, probe=(rank == 0 and probe_id == 5))
+        # the sampler leg (secondary): a call is ~0.07 ms, so `steps` calls are timed ten times over in one region (1.4 ms of
+        # work gave 26-30 M env-steps/s from run to run); with the per-launch probe on it stays at one pass
+        probe_sampler = rank == 0 and probe_id == 5
+        r["dt_sample"] = timed(sample_step, probe=probe_sampler, reps=1 if probe_id == 5 else 10)
         r["dt_update"] = timed(update_step)
         # the collective alone, same bucket, same `steps`: lets an N-GPU run be read as compute + all-reduce
         r["dt_allreduce"] = timed(allreduce_only) if nranks > 1 else None
