@@ -10,7 +10,9 @@ One "step" = one pass of the hot path over one batch of synthetic input:
   (b) one PPO minibatch update of 50,000 samples drawn from the device-resident rollout buffer: fused gather,
       actor_ft + critic forward, loss, backward, [gradient all-reduce over ranks], AdamW on both networks and
       re-packing of the updated weights for the next step.
-Both are timed over EXACTLY `steps` steps each, bracketed by barrier + torch.cuda.synchronize(), MAX over ranks.
+Both are timed over EXACTLY `steps` steps each, bracketed by barrier + torch.cuda.synchronize(), MAX over ranks (the update:
+one pass; the sampler, a 0.06 ms call, ten passes over the same `steps` calls in one region).  After the `warmup` steps and
+before each timed region `--spin-up` (default 300) more untimed calls bring the GPU's clocks up (same count on every rank).
 `value` is the headline the north star puts the target on -- PPO-update samples/s, whole job -- and the sampler's
 env-steps/s is reported beside it (BASELINE.json's metric names both).  Weak scaling: per-GPU load is fixed.
 
