@@ -829,7 +829,8 @@ __device__ __forceinline__ void time_backward_finish(const float* G_in, int Kft,
   const int tid = threadIdx.x;
   const float* w2s = sh + Kft * per + 2 * td * td;
   float* Gs = sh + Kft * per + 4 * td * td + 2 * td;
-  for (int i = tid; i < Kft * td; i += 256) Gs[i] = __builtin_nontemporal_load(&G_in[i]);
+  for (int i = tid; i < Kft * td; i += 256)  // sc1 loads: G may have been written by other workgroups of this launch
+    Gs[i] = __hip_atomic_load(&G_in[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const float* G = Gs;
   __syncthreads();
   for (int i = tid; i < Kft * 2 * td; i += 256) {
@@ -932,26 +933,26 @@ __global__ __launch_bounds__(256) void post_reduce_kernel(const PostReduce q) {
     float acc = 0.f;
     for (int h = lane; h < q.H; h += 64) acc += q.W0[(size_t)h * q.ldw0 + q.AF + j] * q.S[(size_t)h * q.Kft + k];
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-    if (lane == 0) q.G[out] = acc;
+    // write-through (sc1) store, read back by the last block with sc1 loads (time_backward_finish): the hand-over then needs
+    // no fence on either side -- every storing wave drains its store, the block's barrier, ONE relaxed agent-scope add
+    // (guide section 6, guideline 16).  With __threadfence() around the counter (buffer_wbl2 + buffer_inv, ~3.5 us each on
+    // gfx950) this chain -- G, fence, add | poll, fence, finish -- was 11 of the launch's 16 us, on the update's critical path.
+    if (lane == 0) __hip_atomic_store(&q.G[out], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // The time MLP's backward belongs to the LAST block of the range: it prepares everything that does not depend on G while
   // the others finish, then waits for their arrivals.  (Workgroups are dispatched in index order, so every block it waits
   // for is already running or done: the wait cannot starve them.)
   if (tb != q.n_temb - 1) {
-    if (tid == 0) {
-      __threadfence();
-      atomicAdd(q.counter, 1u);
-    }
+    if (tid == 0) __hip_atomic_fetch_add(q.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   time_backward_prepare(q.w1, q.b1, q.w2, q.ksteps, q.Kft, q.td, sh);
   if (tid == 0) {
-    __threadfence();
     while (__hip_atomic_load(q.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)q.n_temb - 1)
       __builtin_amdgcn_s_sleep(2);
-    __threadfence();
-    *q.counter = 0;  // ready for the next call
+    __hip_atomic_store(q.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
   }
   __syncthreads();
   time_backward_finish(q.G, q.Kft, q.td, q.gw1, q.gb1, q.gw2, q.gb2, sh);
