@@ -466,15 +466,18 @@ __global__ __launch_bounds__(256) void adv_moments_kernel(const float* adv_k, co
   s = block_sum(s, sh);
   q = block_sum(q, sh);
   if (threadIdx.x == 0) {
-    moments[8 + 2 * blockIdx.x] = s, moments[9 + 2 * blockIdx.x] = q;
-    __threadfence();
-    last = atomicAdd((unsigned long long*)&moments[3], 1ull) == gridDim.x - 1;
+    // write-through stores, drained, then ONE relaxed agent-scope add; the last block reads the partials with sc1 loads behind
+    // its barrier: no __threadfence() on either side (~3.5 us each on gfx950; this launch sits in front of the actor's forward)
+    __hip_atomic_store(&moments[8 + 2 * blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&moments[9 + 2 * blockIdx.x], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = __hip_atomic_fetch_add((unsigned long long*)&moments[3], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+           gridDim.x - 1;
   }
   __syncthreads();
   if (!last) return;
-  __threadfence();
-  s = threadIdx.x < gridDim.x ? __builtin_nontemporal_load(&moments[8 + 2 * threadIdx.x]) : 0.0;
-  q = threadIdx.x < gridDim.x ? __builtin_nontemporal_load(&moments[9 + 2 * threadIdx.x]) : 0.0;
+  s = threadIdx.x < gridDim.x ? __hip_atomic_load(&moments[8 + 2 * threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+  q = threadIdx.x < gridDim.x ? __hip_atomic_load(&moments[9 + 2 * threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
   s = block_sum(s, sh);
   q = block_sum(q, sh);
   if (threadIdx.x == 0) moments[0] = s, moments[1] = q, moments[2] = (double)N;
