@@ -1350,6 +1350,19 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwSlots a) {
     if (i < a.n && (int)blockIdx.x >= a.s[i].block0) si = i;
   const AdamwSlot& sl = a.s[si];
   __shared__ float c[4];
+  // the block's elements are requested BEFORE the step constants are built (two double-precision pow() behind a global load,
+  // then a barrier): issued behind the barrier, their latency came on top of that chain, on the update's critical path
+  const int lb0 = blockIdx.x - sl.block0;
+  constexpr int NV = ADAMW_MULTI_EPT / 4;
+  float4 p4r[NV], m4r[NV], v4r[NV], g4r[NV];
+  if (sl.vec4) {
+    const int64_t n4 = sl.n >> 2;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int64_t q = (int64_t)lb0 * (256 * NV) + u * 256 + threadIdx.x;
+      if (q < n4) p4r[u] = ((const float4*)sl.p)[q], m4r[u] = ((const float4*)sl.m)[q], v4r[u] = ((const float4*)sl.v)[q], g4r[u] = ((const float4*)sl.g)[q];
+    }
+  }
   // the two double-precision pow() calls are the longest dependency of a block: one wave each
   if (threadIdx.x == 0) {
     const double t = (double)(sl.step_dev[0] + 1), lr = (double)sl.lr_dev[0];
@@ -1379,8 +1392,8 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwSlots a) {
     for (int u = 0; u < ADAMW_MULTI_EPT / 4; ++u) {
       const int64_t q = (int64_t)lb * (256 * ADAMW_MULTI_EPT / 4) + u * 256 + threadIdx.x;
       if (q >= n4) break;
-      float4 p4 = ((float4*)sl.p)[q], m4 = ((float4*)sl.m)[q], v4 = ((float4*)sl.v)[q];
-      const float4 g4 = ((const float4*)sl.g)[q];
+      float4 p4 = p4r[u], m4 = m4r[u], v4 = v4r[u];
+      const float4 g4 = g4r[u];
       upd(p4.x, g4.x, m4.x, v4.x), upd(p4.y, g4.y, m4.y, v4.y), upd(p4.z, g4.z, m4.z, v4.z), upd(p4.w, g4.w, m4.w, v4.w);
       ((float4*)sl.p)[q] = p4, ((float4*)sl.m)[q] = m4, ((float4*)sl.v)[q] = v4;
     }
