@@ -364,7 +364,8 @@ def main():
                      5: "sample_chain_split_kernel (a 16-row tile over eight workgroups; sample_chain_kernel with --tune 27=0)"}
             traffic = None  # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)
             tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_probe{args.probe}{'g' if grouped else ''}_{args.prec}.json")
-            if os.path.exists(tpath):
+            one_wg_sampler = args.probe == 5 and any(t.replace(" ", "") == "27=0" for t in args.tune)
+            if os.path.exists(tpath) and not one_wg_sampler:  # (the probe-5 file was measured on the split sampler)
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             kernel_probe = {"kernel": f"{names[args.probe]}, {args.prec}", "avg_launch_ms": avg_ms, "launches": cnt.value,
                             "algorithmic_gflop_per_launch": fl.value / cnt.value / 1e9, "mfma_tflops": tf,

@@ -4,7 +4,7 @@ difference is the tag bit: each fp32 partial sum of the out layer travels betwee
 bit replaced by a tag (cleared on arrival), i.e. <= 1 ulp = 6e-8 relative per partial.  A difference of that size moves
 x_{t-1} by ~1e-7, which now and then crosses a bf16 rounding boundary of the next step's input (4e-3 relative on one
 input element) -- so the two kernels agree to fp32 rounding on almost every element (~88 % are bit-identical) and to the
-bf16 input rounding on a few.  Measured over the cases below (profiles/r02_final5_split_vs_one_workgroup_chain_diffs.txt):
+bf16 input rounding on a few.  Measured over the cases below (profiles/r02_final6_split_vs_one_workgroup_chain_diffs.txt):
 max |d| 3.5e-4, mean |d| <= 4e-7; stated tolerance max |d| <= 5e-3, mean |d| <= 1e-5 (the bf16 chains are held to 5e-2
 against the reference's goldens, tests/test_hip_parity.py, which runs with the knob at its default).  Run to run the split
 kernel is bit-reproducible.
