@@ -5,14 +5,21 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+Both forms work for every N.  Invoked plainly (no WORLD_SIZE in the environment) with N > 1, this process is a LAUNCHER:
+before importing torch or touching a GPU it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
+child, forwards rank 0's one JSON line to stdout (everything else to stderr) and exits with the child's exit code.
+
 One "step" = one pass of the hot path over one batch of synthetic input:
   (a) one K=20 DDPM sampling call for 512 envs (obs -> action chunk + denoising chain), and
   (b) one PPO minibatch update of 50,000 samples drawn from the device-resident rollout buffer: fused gather,
       actor_ft + critic forward, loss, backward, [gradient all-reduce over ranks], AdamW on both networks and
       re-packing of the updated weights for the next step.
-Both are timed over EXACTLY `steps` steps each, bracketed by barrier + torch.cuda.synchronize(), MAX over ranks (the update:
-one pass; the sampler, a 0.06 ms call, ten passes over the same `steps` calls in one region).  After the `warmup` steps and
-before each timed region `--spin-up` (default 300) more untimed calls bring the GPU's clocks up (same count on every rank).
+Each timed region is EXACTLY `steps` steps bracketed by barrier + torch.cuda.synchronize(), MAX over ranks.  The update leg
+is timed `--passes` (10) times over, each pass its own bracketed region of the same `steps` steps: `value` / `ms_per_step`
+are the MEDIAN pass, min / max are reported beside it (`passes`), so the number survives a noisy neighbour or a slow clock
+ramp.  The sampler (a 0.06 ms call) runs ten passes of its `steps` calls inside one region.  After the `warmup` steps and
+before the first timed region of a leg `--spin-up` (default 300, reported as `spin_up`) more untimed calls bring the GPU's
+clocks up (same count on every rank).
 `value` is the headline the north star puts the target on -- PPO-update samples/s, whole job -- and the sampler's
 env-steps/s is reported beside it (BASELINE.json's metric names both).  Weak scaling: per-GPU load is fixed.
 
@@ -27,51 +34,183 @@ The line also carries
                  network's backward pass in one launch) timed live with HIP events on its launch stream: its operand
                  bytes per second against the HBM peak and its own MFMA fraction;
   `fp32`         the same two legs with fp32 operands (the reference's arithmetic), secondary;
+  `configs`      BASELINE configs[2] (robomimic can, K=100 DDPM, Ta=8, 256 envs, minibatch 7,500) and one GPU's share of
+                 configs[3] (halfcheetah, 512 envs, minibatch 50,000): the same two legs, each with its 8(d)-style fraction;
   `allreduce_ms` the gradient bucket's all-reduce alone (N > 1), so an N-GPU run reads as compute + collective;
   `cpu_baseline` the CPU oracle = op-for-op restatement of the reference's PyTorch path, timed on this box's host
-                 cores on a bounded sample.
+                 cores on a bounded sample (median of 10 sampling calls / 5 minibatch updates).
 """
 import argparse
-import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# hopper-medium-v2 ft_ppo_diffusion_mlp (reference cfg/gym/finetune/hopper-v2/ft_ppo_diffusion_mlp.yaml)
-OBS_DIM, ACT_DIM, TA, K, KFT, ACT_STEPS = 11, 3, 4, 20, 10, 4
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md chip table
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # MI355X_MICROARCH.md chip table (dense)
-FLOP_PER_SAMPLE = 4.11e6   # SURVEY.md 8(d): actor_ft 3 x 1.103 + critic 3 x 0.268 MFLOP
-FLOP_PER_CHUNK = 22.06e6   # 20 necessary network evaluations x 1.103 MFLOP
+
+# Workloads = BASELINE.json configs.  hopper: reference cfg/gym/finetune/hopper-v2/ft_ppo_diffusion_mlp.yaml; halfcheetah:
+# cfg/gym/finetune/halfcheetah-v2/ft_ppo_diffusion_mlp.yaml:16-22,88-102; can: the networks of
+# cfg/robomimic/finetune/can/ft_ppo_diffusion_mlp.yaml:18-24,92-105 at BASELINE configs[2]'s K=100 DDPM / Ta=8 / 256 envs.
+WORKLOADS = {
+    "hopper": dict(obs=11, act=3, ta=4, K=20, kft=10, act_steps=4, fn="ReLU", envs=512, n_steps=500, batch=50000,
+                   clip_base=0.01, label="hopper-medium-v2 ft_ppo_diffusion_mlp K=20 Kft=10 Ta=4 (BASELINE configs[1])"),
+    "can": dict(obs=23, act=7, ta=8, K=100, kft=10, act_steps=8, fn="Mish", envs=256, n_steps=300, batch=7500,
+                clip_base=0.001, label="robomimic can state-obs diffusion_mlp K=100 DDPM Kft=10 Ta=8 (BASELINE configs[2])"),
+    "halfcheetah": dict(obs=17, act=6, ta=4, K=20, kft=10, act_steps=4, fn="ReLU", envs=512, n_steps=500, batch=50000,
+                        clip_base=0.01, label="halfcheetah-medium-v2 ft_ppo_diffusion_mlp K=20 Kft=10 Ta=4, one GPU's "
+                                              "share (512 of 4096 envs) of BASELINE configs[3]"),
+}
+TIME_DIM, ACTOR_H, CRITIC_H = 16, 512, 256
+# the headline workload's shape constants (tests and tools import them)
+OBS_DIM, ACT_DIM, TA, K, KFT, ACT_STEPS = (WORKLOADS["hopper"][k] for k in ("obs", "act", "ta", "K", "kft", "act_steps"))
 
 
-def build_model(device, prec):
+def net_flops(wl):
+    """SURVEY.md 8(d)'s count for a workload's networks: one forward of the actor (time MLP + Linear(in, H) + one residual
+    block of two H x H layers + Linear(H, Ta.Da)) and of the critic, 2 FLOP per multiply-add.  hopper: 1.103 / 0.268 MFLOP."""
+    af = wl["ta"] * wl["act"]
+    actor = 2 * ((af + TIME_DIM + wl["obs"]) * ACTOR_H + 2 * ACTOR_H * ACTOR_H + ACTOR_H * af) + 2 * (2 * TIME_DIM * 2 * TIME_DIM)
+    critic = 2 * (wl["obs"] * CRITIC_H + 2 * CRITIC_H * CRITIC_H + CRITIC_H)
+    return actor, critic
+
+
+def flop_per_sample(wl):
+    """One PPO sample updated: forward + backward (2x) of actor_ft and critic -- necessary evaluations only."""
+    a, c = net_flops(wl)
+    return 3.0 * (a + c)
+
+
+def flop_per_chunk(wl):
+    """One action chunk sampled: K necessary network evaluations."""
+    return float(wl["K"] * net_flops(wl)[0])
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--prec", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--n-envs", type=int, default=512)
+    ap.add_argument("--n-steps", type=int, default=500, help="rollout length behind the update buffer")
+    ap.add_argument("--batch", type=int, default=50000)
+    ap.add_argument("--passes", type=int, default=10,
+                    help="timed passes of the update leg, each its own barrier-bracketed region of exactly --steps steps; the "
+                         "line reports the median pass (min / max beside it)")
+    ap.add_argument("--spin-up", type=int, default=300,
+                    help="untimed calls in front of each leg's first timed region, beyond --warmup, so that the GPU's clocks have ramped")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the secondary fp32 (the reference's own precision) pass")
+    ap.add_argument("--no-pixel", action="store_true", help="skip the secondary pixel-observation pass (BASELINE configs[4] shapes)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the secondary BASELINE configs[2] / configs[3] legs")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --share-gpu rehearses the data-parallel path with several ranks on ONE GPU")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
+    ap.add_argument("--probe", type=int, default=2,
+                    help="kernel timed live for `roofline.dominant_kernel`: 2 gemm_tn (weight grads), 3 fused fwd, "
+                         "4 fused bwd, 5 sampler")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the update step as captured hipGraphs (dppo_amd.util.graphed) instead of issuing its "
+                         "launches one by one; pays at small minibatches, not at this workload")
+    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
+                    help="dppo_tune_set knob (include/dppo_hip.h), e.g. 2=0: critic half on the main stream (serial kernels)")
+    ap.add_argument("--master-port", type=int, default=0, help="launcher mode: rendezvous port (default: a free one)")
+    # test hooks of the launcher path (tests/test_bench_launcher.py): ranks rendezvous over gloo on the CPU, report and exit
+    ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--launch-check-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args, argv):
+    """Launcher mode (plain `python bench.py --gpus N`, N > 1, no WORLD_SIZE): start N fresh rank processes through
+    torch.distributed.run BEFORE this process imports torch or makes any GPU call, forward rank 0's JSON line, return the child's
+    exit code.  (An `os.exec*` would do too here -- nothing has touched the GPU -- but a child keeps the one-line contract
+    enforceable: whatever the ranks print besides the result line goes to stderr.)"""
+    assert "torch" not in sys.modules, "the launcher must not import torch"
+    port = args.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["DPPO_BENCH_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench launcher] torch imported: {'torch' in sys.modules}; starting {args.gpus} ranks: {' '.join(cmd)}",
+          file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    n_lines = 0
+    for line in child.stdout:
+        is_result = False
+        if line.lstrip().startswith("{"):
+            try:
+                is_result = isinstance(json.loads(line), dict)
+            except ValueError:
+                pass
+        if is_result and n_lines == 0:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            n_lines += 1
+        else:
+            sys.stderr.write(line)
+    rc = child.wait()
+    if rc == 0 and n_lines != 1:
+        print(f"[bench launcher] ranks exited 0 but printed {n_lines} result lines", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def launch_check(args):
+    """What the ranks do under --launch-check: rendezvous over gloo (CPU only), gather (RANK, WORLD_SIZE), rank 0 prints one
+    JSON line.  Exercises the launcher path where no GPU exists."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    t = torch.zeros(world, dtype=torch.int64)
+    t[rank] = rank + 1
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "world": world, "ranks": (t - 1).tolist(), "gpus_arg": args.gpus,
+                          "env_world_size": int(os.environ["WORLD_SIZE"]), "cuda_initialized": torch.cuda.is_initialized()}),
+              flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == args.launch_check_fail_rank:
+        sys.exit(3)
+
+
+def build_model(device, prec, wl=None):
+    wl = wl or WORKLOADS["hopper"]
+    import torch
     from dppo_amd.model.common.critic import CriticObs
     from dppo_amd.model.diffusion.diffusion_ppo import PPODiffusion
     from dppo_amd.model.diffusion.mlp_diffusion import DiffusionMLP
     torch.manual_seed(42)
-    actor = DiffusionMLP(action_dim=ACT_DIM, horizon_steps=TA, cond_dim=OBS_DIM, time_dim=16,
-                         mlp_dims=[512, 512, 512], activation_type="ReLU", residual_style=True, precision=prec)
-    critic = CriticObs(cond_dim=OBS_DIM, mlp_dims=[256, 256, 256], activation_type="Mish", residual_style=True,
+    actor = DiffusionMLP(action_dim=wl["act"], horizon_steps=wl["ta"], cond_dim=wl["obs"], time_dim=TIME_DIM,
+                         mlp_dims=[ACTOR_H] * 3, activation_type=wl["fn"], residual_style=True, precision=prec)
+    critic = CriticObs(cond_dim=wl["obs"], mlp_dims=[CRITIC_H] * 3, activation_type="Mish", residual_style=True,
                        precision=prec)
-    model = PPODiffusion(actor=actor, critic=critic, ft_denoising_steps=KFT, horizon_steps=TA, obs_dim=OBS_DIM,
-                         action_dim=ACT_DIM, denoising_steps=K, device=device, gamma_denoising=0.99,
-                         clip_ploss_coef=0.01, clip_ploss_coef_base=0.01, clip_ploss_coef_rate=3, randn_clip_value=3,
+    model = PPODiffusion(actor=actor, critic=critic, ft_denoising_steps=wl["kft"], horizon_steps=wl["ta"], obs_dim=wl["obs"],
+                         action_dim=wl["act"], denoising_steps=wl["K"], device=device, gamma_denoising=0.99,
+                         clip_ploss_coef=0.01, clip_ploss_coef_base=wl["clip_base"], clip_ploss_coef_rate=3, randn_clip_value=3,
                          min_sampling_denoising_std=0.1, min_logprob_denoising_std=0.1)
     return model
 
 
-def make_rollout(model, n_envs, n_steps, device, gen):
+def make_rollout(model, n_envs, n_steps, device, gen, wl=None):
+    wl = wl or WORKLOADS["hopper"]
     """Device-resident rollout buffer produced by the sampler itself (R = n_steps * n_envs rows)."""
+    import torch
     from dppo_amd.util.rollout import gae_device
+    OBS_DIM, KFT, TA, ACT_DIM = wl["obs"], wl["kft"], wl["ta"], wl["act"]
     AF = TA * ACT_DIM
     R = n_steps * n_envs
     obs = torch.empty(R, OBS_DIM, device=device)
@@ -110,10 +249,15 @@ def usable_cores():
     return min(n, 64)
 
 
-def cpu_baseline(n_envs, batch, budget_s=25.0):
+def cpu_baseline(n_envs, batch, budget_s=40.0):
     """The CPU oracle (a validated op-for-op restatement of the reference's PyTorch path, incl. the discarded base-net
-    pass and the Python-list discount) on this box's host cores.  Bounded sample, see `sample` in the result."""
+    pass and the Python-list discount) on this box's host cores.  BASELINE.md section 3's protocol: warm-up, then the median of
+    10 sampling calls and of 5 minibatch updates (fewer updates only if `budget_s` runs out; the result says how many)."""
+    import numpy as np
+    import torch
     from oracle import dppo_oracle as O
+    wl = WORKLOADS["hopper"]
+    OBS_DIM, KFT, TA, ACT_DIM, K = wl["obs"], wl["kft"], wl["ta"], wl["act"], wl["K"]
     cores = usable_cores()
     torch.set_num_threads(cores)
     a, c = O.named_specs("hopper")
@@ -123,9 +267,10 @@ def cpu_baseline(n_envs, batch, budget_s=25.0):
     rs = np.random.RandomState(42)
     state = torch.from_numpy(rs.uniform(-1, 1, size=(n_envs, 1, OBS_DIM)).astype(np.float32))
     noise = torch.from_numpy(rs.randn(K + 1, n_envs, TA, ACT_DIM).astype(np.float32))
-    O.sample_chain(cfg, a, base, ft, state, noise)  # warm-up
+    for _ in range(2):
+        O.sample_chain(cfg, a, base, ft, state, noise)  # warm-up
     ts = []
-    for _ in range(5):
+    for _ in range(10):
         t0 = time.perf_counter()
         _, chains = O.sample_chain(cfg, a, base, ft, state, noise)
         ts.append(time.perf_counter() - t0)
@@ -135,7 +280,6 @@ def cpu_baseline(n_envs, batch, budget_s=25.0):
         p.requires_grad_(True)
     opt_a = torch.optim.AdamW(list(ft.values()), lr=1e-4, weight_decay=0)
     opt_c = torch.optim.AdamW(list(cr.values()), lr=1e-3, weight_decay=0)
-    reps = (batch + n_envs - 1) // n_envs
     kinds = torch.from_numpy(rs.randint(0, KFT, size=(batch,)).astype(np.int64))
     rows = torch.from_numpy(rs.randint(0, n_envs, size=(batch,)).astype(np.int64))
     obs_b, prev, nxt = state[rows], chains[rows, kinds], chains[rows, kinds + 1]
@@ -144,8 +288,8 @@ def cpu_baseline(n_envs, batch, budget_s=25.0):
     ret = torch.from_numpy(rs.normal(size=batch).astype(np.float32))
     adv = torch.from_numpy(rs.normal(size=batch).astype(np.float32))
     oldv = torch.zeros(batch)
-    tu, n_done, t_begin = [], 0, time.perf_counter()
-    while n_done < 3 and (n_done < 1 or time.perf_counter() - t_begin < budget_s):
+    tu, n_done, t_begin = [], -1, time.perf_counter()  # the first update is the warm-up (autograd graph, allocator), not counted
+    while n_done < 5 and (n_done < 1 or time.perf_counter() - t_begin < budget_s):
         t0 = time.perf_counter()
         res = O.ppo_loss(cfg, a, c, base, ft, cr, obs_b, prev, nxt, kinds, ret, oldv, adv, oldlp)
         opt_a.zero_grad()
@@ -153,13 +297,14 @@ def cpu_baseline(n_envs, batch, budget_s=25.0):
         (res[0] + 0.5 * res[2]).backward()
         opt_a.step()
         opt_c.step()
-        tu.append(time.perf_counter() - t0)
+        if n_done >= 0:
+            tu.append(time.perf_counter() - t0)
         n_done += 1
     t_update = float(np.median(tu))
     return {"value": batch / t_update, "unit": "PPO-update samples/s", "cores": cores, "kind": "port",
-            "env_steps_per_sec": n_envs * ACT_STEPS / t_sample,
-            "sample": f"median of 5 sampling calls (B={n_envs}, K={K}) and of {n_done} minibatch updates "
-                      f"(N={batch}: loss fwd + bwd + 2x AdamW), torch {torch.__version__} CPU, {cores} threads"}
+            "env_steps_per_sec": n_envs * wl["act_steps"] / t_sample,
+            "sample": f"median of 10 sampling calls (B={n_envs}, K={K}) and of {n_done} minibatch updates "
+                      f"(N={batch}: loss fwd + bwd + 2x AdamW) after warm-up, torch {torch.__version__} CPU, {cores} threads"}
 
 
 def pixel_leg(n_envs=256, batch=500, reps=10):
@@ -169,6 +314,7 @@ def pixel_leg(n_envs=256, batch=500, reps=10):
     there: one ViT pass + the 5-step sampler) and one update minibatch of the cfg's batch_size (two encoders forward with a
     tape, fused loss forward / backward, two encoders backward).  Synthetic images, random-init weights."""
     import importlib.util
+    import torch
     spec = importlib.util.spec_from_file_location("vision_bench", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools",
                                                                                  "vision_bench.py"))
     vb = importlib.util.module_from_spec(spec)
@@ -192,40 +338,34 @@ def pixel_leg(n_envs=256, batch=500, reps=10):
         ms_smp = vb.timeit(lambda: m(cond=cond_e), n=reps)
         out[kind + "_img"] = {"update_ms_per_minibatch": ms_upd, "update_samples_per_sec": batch / ms_upd * 1e3,
                               "rollout_ms_per_step": ms_smp, "env_steps_per_sec": n_envs * 4 / ms_smp * 1e3}
+        if hasattr(vb, "flops"):
+            out[kind + "_img"].update(vb.flops(kind, batch, ms_upd, n_envs, ms_smp, MFMA_PEAK_TFLOPS["bf16"]))
         del m
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--prec", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--n-envs", type=int, default=512)
-    ap.add_argument("--n-steps", type=int, default=500, help="rollout length behind the update buffer")
-    ap.add_argument("--batch", type=int, default=50000)
-    ap.add_argument("--spin-up", type=int, default=300,
-                    help="untimed calls in front of each timed region, beyond --warmup, so that the GPU's clocks have ramped")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fp32", action="store_true", help="skip the secondary fp32 (the reference's own precision) pass")
-    ap.add_argument("--no-pixel", action="store_true", help="skip the secondary pixel-observation pass (BASELINE configs[4] shapes)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo + --share-gpu rehearses the data-parallel path with several ranks on ONE GPU")
-    ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
-    ap.add_argument("--probe", type=int, default=2,
-                    help="kernel timed live for `roofline.dominant_kernel`: 2 gemm_tn (weight grads), 3 fused fwd, "
-                         "4 fused bwd, 5 sampler")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the update step as captured hipGraphs (dppo_amd.util.graphed) instead of issuing its "
-                         "launches one by one; pays at small minibatches, not at this workload")
-    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
-                    help="dppo_tune_set knob (include/dppo_hip.h), e.g. 2=0: critic half on the main stream (serial kernels)")
-    args = ap.parse_args()
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:  # plain invocation for N > 1 GPUs: become the launcher (no torch, no GPU call)
+        sys.exit(launch_ranks(args, argv))
+    if args.launch_check:
+        launch_check(args)
+        return
+    import ctypes as C
+    import statistics
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
+
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:  # the process group is what it is: report it, do not die on it
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: running (and reporting n_gpus =) {world} ranks",
+              file=sys.stderr, flush=True)
     if args.share_gpu:
         local = 0
     if world > 1:
@@ -235,7 +375,6 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group("gloo")
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     from dppo_amd import hip
@@ -260,45 +399,52 @@ def main():
             dt = float(t.item())
         return dt
 
-    def run_path(prec, nranks, probe_id):
+    def run_path(prec, nranks, probe_id, wl, n_envs, n_steps, batch, passes):
         """Both legs of a step at one operand precision: `steps` sampling calls and `steps` update steps, each timed
         between barriers (+ the serial roofline pass of the update when `probe_id` is set).  nranks = 1 runs the path
-        rank-locally (no collective): the secondary fp32 pass."""
-        model = build_model(str(device), prec)  # same seed on every rank => identical initial weights
+        rank-locally (no collective): the secondary passes."""
+        KFT, K = wl["kft"], wl["K"]
+        model = build_model(str(device), prec, wl)  # same seed on every rank => identical initial weights
         gen = torch.Generator(device=device).manual_seed(42 + rank)  # env shards differ per rank
         torch.manual_seed(42 + rank)
         dp = DataParallel(model, nranks)
-        ro = make_rollout(model, args.n_envs, args.n_steps, device, gen)
+        ro = make_rollout(model, n_envs, n_steps, device, gen, wl)
         adv_k = ro[4]
-        R = args.n_envs * args.n_steps
+        R = n_envs * n_steps
         opt_a = FlatAdamW(model.actor_ft.flat_params(), lr=1e-4, weight_decay=0.0)
         opt_c = FlatAdamW(model.critic.flat_params(), lr=1e-3, weight_decay=0.0)
         perm = torch.randperm(R * KFT, device=device, generator=gen)
-        n_mb = (R * KFT) // args.batch
-        minibatches = [perm[(i % n_mb) * args.batch:(i % n_mb + 1) * args.batch].contiguous() for i in range(n_total)]
+        n_mb = (R * KFT) // batch
+        minibatches = [perm[(i % n_mb) * batch:(i % n_mb + 1) * batch].contiguous() for i in range(n_total)]
         moments = dp.minibatch_moments(adv_k, minibatches, KFT)  # ONE small collective for all steps (None if 1 rank)
-        obs_batches = [torch.rand(args.n_envs, 1, OBS_DIM, device=device, generator=gen) * 2 - 1 for _ in range(4)]
-        graphed = GraphedUpdate(model, opt_a, opt_c, dp, ro, args.batch, ACT_STEPS, n_time=K) if args.graph else None
+        obs_batches = [torch.rand(n_envs, 1, wl["obs"], device=device, generator=gen) * 2 - 1 for _ in range(4)]
+        graphed = GraphedUpdate(model, opt_a, opt_c, dp, ro, batch, wl["act_steps"], n_time=K) if args.graph else None
         eager = [False]  # the roofline pass issues the launches one by one (per-launch HIP events cannot be captured)
 
         def update_step(i):
             if graphed is not None and not eager[0]:  # same work as below, launched as hipGraph replays
                 graphed.step(minibatches[i], None if moments is None else moments[i])
                 return
-            model.ppo_update(*ro, minibatches[i], reward_horizon=ACT_STEPS,
-                             global_moments=None if moments is None else moments[i])
-            dp.allreduce_grads()  # one RCCL all-reduce of [actor grads | critic grads | stats]; no-op with one rank
+            model.ppo_update(*ro, minibatches[i], reward_horizon=wl["act_steps"],
+                             global_moments=None if moments is None else moments[i], critic_hook=dp.critic_hook)
+            # RCCL all-reduce of the bucket [critic grads | actor grads | stats] in two slices: the critic's was queued from
+            # inside the call above, on the library's critic stream (it overlaps the actor's backward); the rest here.  No-op
+            # with one rank
+            dp.allreduce_grads()
             # 2 x AdamW, then re-pack so the next sampling / update call sees the new weights (part of the step's cost)
             step_and_repack(model, opt_a, opt_c, n_time=K)
 
         def sample_step(i):
             return model(cond={"state": obs_batches[i % 4]}, deterministic=False, return_chain=True)
 
-        def allreduce_only(i):
+        def allreduce_only(i):  # both slices back to back on the caller's stream, nothing to hide behind
+            if dp.critic_hook is not None:
+                dp.critic_hook(0)
             dp.allreduce_grads()
 
-        def timed(fn, probe=False, reps=1):
-            """`reps` passes over the same `steps` calls inside one timed region; returns the time of ONE pass."""
+        def timed(fn, probe=False, reps=1, passes=1):
+            """`passes` timed regions, each EXACTLY `steps` calls (x `reps` repeats of them inside the region) between
+            barrier + synchronize brackets, MAX over ranks; returns the list of per-pass times of ONE run of the `steps` calls."""
             for i in range(args.warmup):
                 fn(i)
             # Clock spin-up (untimed, same count on every rank): an idle MI355X sits at its lowest sclk level (531 MHz by rocm-smi)
@@ -309,24 +455,28 @@ def main():
                 fn(i % n_total)
                 if i % 32 == 31:
                     torch.cuda.synchronize()
-            barrier()
-            if probe:
-                hip.check(lib.dppo_probe_arm(probe_id, 16 * args.steps), "dppo_probe_arm")
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                for i in range(args.warmup, n_total):
-                    fn(i)
-            barrier()
-            return max_over_ranks(time.perf_counter() - t0) / reps
+            out = []
+            for _ in range(passes):
+                barrier()
+                if probe:
+                    hip.check(lib.dppo_probe_arm(probe_id, 16 * args.steps), "dppo_probe_arm")
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    for i in range(args.warmup, n_total):
+                        fn(i)
+                barrier()
+                out.append(max_over_ranks(time.perf_counter() - t0) / reps)
+            return out
 
         r = {"model": model, "prec": prec}
         # the sampler leg (secondary): a call is ~0.07 ms, so `steps` calls are timed ten times over in one region (1.4 ms of
         # work gave 26-30 M env-steps/s from run to run); with the per-launch probe on it stays at one pass
         probe_sampler = rank == 0 and probe_id == 5
-        r["dt_sample"] = timed(sample_step, probe=probe_sampler, reps=1 if probe_id == 5 else 10)
-        r["dt_update"] = timed(update_step)
+        r["dt_sample"] = timed(sample_step, probe=probe_sampler, reps=1 if probe_id == 5 else 10)[0]
+        r["dt_update_passes"] = timed(update_step, passes=passes)
+        r["dt_update"] = statistics.median(r["dt_update_passes"])
         # the collective alone, same bucket, same `steps`: lets an N-GPU run be read as compute + all-reduce
-        r["dt_allreduce"] = timed(allreduce_only) if nranks > 1 else None
+        r["dt_allreduce"] = timed(allreduce_only)[0] if nranks > 1 else None
         # Roofline pass: the same update steps once more with the library's side streams off (knob 2 = 0).  In the timed
         # region above the critic half and the gradient tails run beside the probed kernel, so an event-bracketed launch
         # duration there includes its co-runners' share of the chip; serial, it is the kernel's own (rocprofv3 on
@@ -336,14 +486,29 @@ def main():
             overlap = next((int(kv.split("=")[1]) for kv in args.tune if kv.split("=")[0] == "2"), 1)
             hip.check(lib.dppo_tune_set(2, 0), "dppo_tune_set")
             eager[0] = True
-            r["dt_serial"] = timed(update_step, probe=(rank == 0))
+            r["dt_serial"] = timed(update_step, probe=(rank == 0))[0]
             eager[0] = False
             hip.check(lib.dppo_tune_set(2, overlap), "dppo_tune_set")
         r["stats"] = model._stats.tolist()
         r["graphed"] = graphed is not None
+        # ... and what of it the step actually waits for: the same update steps with the collectives skipped (gradients stay
+        # rank-local: timing only, run last on a throw-away model state) -- exposed = step - step_without
+        r["dt_update_nocomm"] = None
+        if nranks > 1:
+            dp.skip_collectives = True
+            r["dt_update_nocomm"] = statistics.median(timed(update_step, passes=max(3, passes // 2)))
+            dp.skip_collectives = False
         return r
 
-    main_run = run_path(args.prec, world, args.probe)
+    def passes_ms(r):
+        ps = sorted(x / args.steps * 1e3 for x in r["dt_update_passes"])
+        return {"n": len(ps), "steps_each": args.steps, "min_ms_per_step": ps[0], "median_ms_per_step": statistics.median(ps),
+                "max_ms_per_step": ps[-1]}
+
+    WL = WORKLOADS["hopper"]
+    ACT_STEPS = WL["act_steps"]
+    FLOP_PER_SAMPLE, FLOP_PER_CHUNK = flop_per_sample(WL), flop_per_chunk(WL)  # 4.11 MFLOP, 22.06 MFLOP
+    main_run = run_path(args.prec, world, args.probe, WL, args.n_envs, args.n_steps, args.batch, args.passes)
     model = main_run["model"]
     dt_sample, dt_update, dt_serial = main_run["dt_sample"], main_run["dt_update"], main_run["dt_serial"]
 
@@ -387,12 +552,33 @@ def main():
                 gbs = b_per / (avg_ms * 1e-3) / 1e9
                 kernel_probe.update({"operand_mb_per_launch": b_per / 1e6, "operand_gb_per_s": gbs,
                                      "hbm_frac": gbs / HBM_PEAK_GBS, "flop_per_operand_byte": (fl.value / cnt.value) / b_per})
+    del model
+    main_run.pop("model")
+    torch.cuda.empty_cache()
 
     fp32_run = None
     if world == 1 and args.prec != "fp32" and not args.no_fp32:  # the reference's own arithmetic, same steps, same shapes
-        fp32_run = run_path("fp32", 1, None)
+        fp32_run = run_path("fp32", 1, None, WL, args.n_envs, args.n_steps, args.batch, 3)
         del fp32_run["model"]
         torch.cuda.empty_cache()
+
+    other = None  # BASELINE configs[2] and one GPU's share of configs[3]: same legs, same clocks, secondary
+    if world == 1 and not args.no_configs:
+        other = {}
+        for key, name in (("C3_can", "can"), ("C4_halfcheetah_per_gpu", "halfcheetah")):
+            wl = WORKLOADS[name]
+            r = run_path(args.prec, 1, None, wl, wl["envs"], wl["n_steps"], wl["batch"], max(3, args.passes // 2))
+            del r["model"]
+            torch.cuda.empty_cache()
+            sps = wl["batch"] / (r["dt_update"] / args.steps)
+            cps = wl["envs"] / (r["dt_sample"] / args.steps)
+            peak = MFMA_PEAK_TFLOPS[args.prec]
+            other[key] = {"workload": wl["label"], "n_envs": wl["envs"], "minibatch": wl["batch"], "dtype": args.prec,
+                          "samples_per_sec": sps, "ms_per_step": r["dt_update"] / args.steps * 1e3, "passes": passes_ms(r),
+                          "env_steps_per_sec": cps * wl["act_steps"], "sampler_ms_per_call": r["dt_sample"] / args.steps * 1e3,
+                          "mflop_per_sample": flop_per_sample(wl) / 1e6, "mflop_per_chunk": flop_per_chunk(wl) / 1e6,
+                          "update_frac": sps * flop_per_sample(wl) / 1e12 / peak,
+                          "sampler_frac": cps * flop_per_chunk(wl) / 1e12 / peak}
 
     pixel = None
     if world == 1 and args.prec == "bf16" and not args.no_pixel:
@@ -417,18 +603,24 @@ def main():
                                 "what": "chunks/s x 22.06 MFLOP per action chunk / the same peak"},
                     "dominant_kernel": kernel_probe,
                     "traffic_is": "HBM bytes per launch of dominant_kernel (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"}
+        ar_ms = None if main_run["dt_allreduce"] is None else main_run["dt_allreduce"] / args.steps * 1e3
         out = {
             "metric": "PPO-update samples/sec (+ env-steps/sec of the K=20 sampler), hopper K=20 n_envs=512",
             "value": samples_per_s, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_update, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "spin_up": args.spin_up, "ms_per_step": ms_update, "passes": passes_ms(main_run),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.prec, "data": "synthetic",
             "launch": "hipGraph replay of the update step (captured once in warm-up)" if main_run["graphed"] else "eager",
-            "config": {"workload": "hopper-medium-v2 ft_ppo_diffusion_mlp K=20 Kft=10 Ta=4 (BASELINE configs[1])",
+            "config": {"workload": WL["label"],
                        "n_envs_per_gpu": args.n_envs, "minibatch_per_gpu": args.batch,
                        "rollout_rows_per_gpu": args.n_envs * args.n_steps,
                        "parallelism": f"dp{world} (env-sharded, RCCL grad all-reduce)"},
             "env_steps_per_sec": env_steps_per_s, "sampler_ms_per_call": ms_sample, "chunks_per_sec": chunks_per_s,
-            "allreduce_ms": None if main_run["dt_allreduce"] is None else main_run["dt_allreduce"] / args.steps * 1e3,
+            "allreduce_ms": ar_ms,
+            "allreduce_exposed_ms": None if main_run.get("dt_update_nocomm") is None else
+            (dt_update - main_run["dt_update_nocomm"]) / args.steps * 1e3,
+            "allreduce_is": "gradient bucket [critic | actor | stats] SUM-reduced in two slices; allreduce_ms = both alone, "
+                            "allreduce_exposed_ms = ms_per_step minus the same step with the collectives skipped",
             "last_stats": {"pg_loss": stats[0], "v_loss": stats[1], "approx_kl": stats[2], "ratio": stats[4]},
             "roofline": roofline,
         }
@@ -441,6 +633,8 @@ def main():
                            "peak_tflops": MFMA_PEAK_TFLOPS["fp32"],
                            "update_frac": f_sps * FLOP_PER_SAMPLE / 1e12 / MFMA_PEAK_TFLOPS["fp32"],
                            "sampler_frac": f_cps * FLOP_PER_CHUNK / 1e12 / MFMA_PEAK_TFLOPS["fp32"]}
+        if other is not None:
+            out["configs"] = other
         if pixel is not None:
             out["pixel"] = pixel
         if not args.no_cpu_baseline and world == 1:

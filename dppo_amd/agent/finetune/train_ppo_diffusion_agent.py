@@ -277,7 +277,8 @@ class TrainPPODiffusionAgent:
             for b, inds in enumerate(mbs):
                 st = model.ppo_update(obs_buf, chains_buf, ret_k, values_buf, adv_k, logp_buf, inds,
                                       reward_horizon=self.reward_horizon,
-                                      global_moments=None if moments is None else moments[b])
+                                      global_moments=None if moments is None else moments[b],
+                                      critic_hook=self.dp.critic_hook)  # (ranks > 1: the critic slice's all-reduce rides the call)
                 if self.use_bc_loss:  # + bc_loss * bc_loss_coeff on the minibatch's observations (reference :329-357)
                     rows = torch.div(inds, Kft, rounding_mode="floor")
                     model.add_bc_gradient({"state": obs_buf[rows].reshape(rows.numel(), self.n_cond_step, -1)},

@@ -76,18 +76,25 @@ class TrainPPOGaussianAgent(TrainPPODiffusionAgent):
                 if self.vf_coef != 1:
                     model.critic.flat_grads().mul_(self.vf_coef)
                 self.dp.allreduce_grads()
-                step_and_repack(model, self.actor_optimizer, self.critic_optimizer, update_actor=update_actor,
-                                max_norm=self.max_grad_norm, n_time=0)
+                g_lv = sq = None
                 if self.logvar_optimizer is not None and update_actor:
                     # loss = pg + entropy_loss * ent_coef + ...: d(-entropy)/d logvar_j = -0.5 / Da inside the clamp range
                     lv = net.logvar.detach()
-                    g = model._lv_grad.clone()
+                    g_lv = model._lv_grad.clone()
                     if self.world > 1:
-                        dist.all_reduce(g)  # per-rank pg parts are already divided by the GLOBAL count: SUM gives the whole
+                        dist.all_reduce(g_lv)  # per-rank pg parts are already divided by the GLOBAL count: SUM gives the whole
                     if not getattr(model, "entropy_in_kernel", False):
-                        g -= self.ent_coef * 0.5 / Da * ((lv >= net.logvar_min) & (lv <= net.logvar_max)).float()
+                        g_lv -= self.ent_coef * 0.5 / Da * ((lv >= net.logvar_min) & (lv <= net.logvar_max)).float()
+                    g_lv = g_lv.contiguous()
+                    if self.max_grad_norm is not None:
+                        # the reference clips actor_ft.parameters() as ONE group (train_ppo_gaussian_agent.py:319-322), and
+                        # logvar is one of them: its gradient counts in the norm and is scaled with the trunk's
+                        sq = self.actor_optimizer.sq_norm(net.flat_grads()).clone() + (g_lv.double() ** 2).sum()
+                step_and_repack(model, self.actor_optimizer, self.critic_optimizer, update_actor=update_actor,
+                                max_norm=self.max_grad_norm, n_time=0, actor_sq_norm=sq)
+                if g_lv is not None:
                     self.logvar_optimizer.param_groups[0]["lr"] = self.actor_optimizer.param_groups[0]["lr"]
-                    self.logvar_optimizer.step(g.contiguous())
+                    self.logvar_optimizer.step(g_lv, max_norm=self.max_grad_norm, sq_norm=sq)
                 stats = st.tolist()
                 clipfracs.append(stats[hip.STAT_CLIPFRAC])
                 if self.target_kl is not None and stats[hip.STAT_APPROX_KL] > self.target_kl:

@@ -1576,7 +1576,7 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
                     const float* obs_k, const float* chains_k, const float* returns_k, const float* values_k,
                     const float* adv_k, const float* logprobs_k, const int64_t* inds, const int64_t* kinds, int64_t N,
                     const double* gmom, float* agrad, float* cgrad, double* stats, void* ws, int64_t wsb, hipStream_t s,
-                    const dppo_obs_io* oio = nullptr) {
+                    const dppo_obs_io* oio = nullptr, const dppo_dp_hook* hook = nullptr) {
   Carver c{(char*)ws, 0, (size_t)wsb};
   PpoWs<P> W;
   const size_t need = carve_ppo<P>(c, a, cr, N, W);
@@ -1648,6 +1648,9 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
     // the critic's tail is one 10-us reduction)
     mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s2, fuse_bout, -1, &lv);
     if (oio && oio->d_obs_critic) obs_grad<P>(cr, cp, N, W.C, oio->d_obs_critic, s2);
+    // data parallel: everything that writes critic_grad is enqueued on s2 -- the caller queues the critic slice's
+    // all-reduce behind it THERE, so that it runs while the actor's forward / backward still occupy the main stream
+    if (hook && hook->critic_grads_enqueued) hook->critic_grads_enqueued(hook->user, (dppo_stream_t)s2);
   }
   // actor half
   if (!actor_first) mlp_forward<P>(a, ap, ak, LA, N, W.A, true, s);
@@ -1656,6 +1659,7 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   if (!two_streams) {
     mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s, fuse_bout, -1);
     if (oio && oio->d_obs_critic) obs_grad<P>(cr, cp, N, W.C, oio->d_obs_critic, s);
+    if (hook && hook->critic_grads_enqueued) hook->critic_grads_enqueued(hook->user, (dppo_stream_t)s);
   }
   if (two_streams && g_early_join) W.A.join_s[W.A.n_join] = s2, W.A.join_idx[W.A.n_join++] = 0;
   mlp_backward<P>(a, ap, ak, LA, N, W.A, agrad, W.krow, ksteps, Kft, s, fuse_bout, 1, &la);
@@ -1666,6 +1670,10 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   return check_launch();
 }
 
+static bool hipStreamIsCapturing_safe(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
 static int check_obs_io(const dppo_obs_io* io, const int64_t* kinds, bool actor_has_encoder) {
   if (!io) return 0;
   if (kinds == nullptr) return fail(-1, "the _obs entries take pre-gathered samples (kinds), one observation row per sample");
@@ -1678,7 +1686,8 @@ static int ppo_entry(const dppo_net_desc* actor, const dppo_net_desc* critic, in
                           const float* obs_k, const float* chains_k, const float* returns_k, const float* values_k,
                           const float* adv_k, const float* logprobs_k, const int64_t* inds, const int64_t* kinds,
                           int64_t N, const double* global_moments, float* actor_grad, float* critic_grad,
-                          double* stats, void* workspace, int64_t workspace_bytes, dppo_stream_t stream, const dppo_obs_io* io) {
+                          double* stats, void* workspace, int64_t workspace_bytes, dppo_stream_t stream, const dppo_obs_io* io,
+                          const dppo_dp_hook* hook = nullptr) {
   if (int e = check_net(actor)) return e;
   if (int e = check_net(critic)) return e;
   if (int e = check_prec(prec)) return e;
@@ -1702,9 +1711,23 @@ static int ppo_entry(const dppo_net_desc* actor, const dppo_net_desc* critic, in
 #define CALL(P)                                                                                                        \
   ppo_impl<P>(*actor, *critic, actor_params, (const char*)actor_packed, critic_params, (const char*)critic_packed, *dcfg,     \
               *pcfg, ksteps, obs_k, chains_k, returns_k, values_k, adv_k, logprobs_k, inds, kinds, N, global_moments, actor_grad, critic_grad, stats, \
-              workspace, workspace_bytes, (hipStream_t)stream, io)
+              workspace, workspace_bytes, (hipStream_t)stream, io, hook)
   return DPPO_DISPATCH(prec, CALL);
 #undef CALL
+}
+int dppo_ppo_loss_fwd_bwd_dp(const dppo_net_desc* actor, const dppo_net_desc* critic, int prec, const float* actor_params,
+                             const void* actor_packed, const float* critic_params, const void* critic_packed,
+                             const dppo_diffusion_cfg* dcfg, const dppo_ppo_cfg* pcfg, const dppo_step* ksteps,
+                             const float* obs_k, const float* chains_k, const float* returns_k, const float* values_k,
+                             const float* adv_k, const float* logprobs_k, const int64_t* inds, const int64_t* kinds,
+                             int64_t N, const double* global_moments, float* actor_grad, float* critic_grad,
+                             double* stats, void* workspace, int64_t workspace_bytes, dppo_stream_t stream,
+                             const dppo_dp_hook* hook) {
+  if (hipStreamIsCapturing_safe((hipStream_t)stream) && hook && hook->critic_grads_enqueued)
+    return fail(-1, "dppo_ppo_loss_fwd_bwd_dp: a collective cannot be queued from inside a stream capture");
+  return ppo_entry(actor, critic, prec, actor_params, actor_packed, critic_params, critic_packed, dcfg, pcfg, ksteps, obs_k,
+                   chains_k, returns_k, values_k, adv_k, logprobs_k, inds, kinds, N, global_moments, actor_grad, critic_grad,
+                   stats, workspace, workspace_bytes, stream, nullptr, hook);
 }
 int dppo_ppo_loss_fwd_bwd(const dppo_net_desc* actor, const dppo_net_desc* critic, int prec, const float* actor_params,
                           const void* actor_packed, const float* critic_params, const void* critic_packed,
@@ -2318,8 +2341,11 @@ int dppo_stats_split(const double* stats, float* hi_lo, dppo_stream_t stream) {
   return check_launch();
 }
 int dppo_stats_merge(const float* hi_lo, double* stats, int world, dppo_stream_t stream) {
-  if (!stats || !hi_lo || world < 1) return fail(-1, "bad argument");
-  launch_stats_merge(hi_lo, stats, DPPO_STAT_COUNT, DPPO_STAT_ADV_MEAN, 2, 1.0 / world, (hipStream_t)stream);
+  return dppo_stats_merge_n(hi_lo, stats, world, 2, stream);
+}
+int dppo_stats_merge_n(const float* hi_lo, double* stats, int world, int n_avg, dppo_stream_t stream) {
+  if (!stats || !hi_lo || world < 1 || n_avg < 0 || DPPO_STAT_ADV_MEAN + n_avg > DPPO_STAT_COUNT) return fail(-1, "bad argument");
+  launch_stats_merge(hi_lo, stats, DPPO_STAT_COUNT, DPPO_STAT_ADV_MEAN, n_avg, 1.0 / world, (hipStream_t)stream);
   return check_launch();
 }
 
@@ -2423,6 +2449,10 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 28) {  // split sampler: 64-cycle sleep periods between a member's exchange store and its first sweep (default 4)
     set_sampler_split_pre_sweep(value);
+    return 0;
+  }
+  if (knob == 29) {  // split sampler: sweeps a member waits before giving up (tests force a time-out with 1; <= 0: default 2^20)
+    set_sampler_split_spin_limit(value);
     return 0;
   }
   if (knob == 26) {  // grouped weight-gradient GEMM: LDS stages (1, default: three workgroups per CU; 2)

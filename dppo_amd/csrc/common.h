@@ -40,6 +40,35 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 enum { ACT_RELU = 0, ACT_MISH = 1, ACT_NONE = 2 };
 
+// Fence-free last-block hand-over (guide guideline 16).  The producer's partial results are written with relaxed AGENT-scope
+// atomic stores, the arrival is ONE relaxed atomic add behind `s_waitcnt vmcnt(0)`, and the consumer reads them with relaxed
+// agent-scope atomic loads.  Under the HIP / LLVM memory model that has no release / acquire edge; it is correct BY CODE
+// GENERATION on gfx942 / gfx950 only: agent-scope atomic stores are write-through (sc1) and complete -- vmcnt counts stores
+// -- when L2 has them, agent-scope atomic loads bypass the non-coherent L1 (sc1), and the add is performed at L2 behind the
+// drained stores.  Any other target gets the formal release / acquire pair instead (a __threadfence() each side measured
+// ~3.5 us on gfx950, which is why the shortcut exists).  DPPO_HANDOVER_ARRIVE() / DPPO_HANDOVER_ACQUIRE() wrap the two forms.
+#if defined(__gfx942__) || defined(__gfx950__)
+#define DPPO_HANDOVER_FENCE_FREE 1
+#define DPPO_HANDOVER_ARRIVE_ORDER __ATOMIC_RELAXED
+#define DPPO_HANDOVER_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define DPPO_HANDOVER_ACQUIRE() \
+  do {                          \
+  } while (0)
+#else
+#define DPPO_HANDOVER_FENCE_FREE 0
+#define DPPO_HANDOVER_ARRIVE_ORDER __ATOMIC_RELEASE
+#define DPPO_HANDOVER_DRAIN() \
+  do {                        \
+  } while (0)
+#define DPPO_HANDOVER_ACQUIRE() __atomic_thread_fence(__ATOMIC_ACQUIRE)
+#endif
+
+// Zero `bytes` (a multiple of 4) bytes at the 4-byte aligned `p` on stream `s` with a KERNEL (ppo.hip).  The library never uses
+// hipMemsetAsync: captured into a hipGraph on ROCm 7.2 a memset node left 16 foreign bytes (a size and an address) at the head of
+// its destination from the second replay on (found through the split sampler's time-out word, gpurun_out/s4d/t.log), and every
+// entry point of this library may be captured (dppo_amd.util.graphed.GraphedUpdate takes any model).
+void launch_zero_bytes(void* p, size_t bytes, hipStream_t s);
+
 __device__ __forceinline__ uint16_t f2bf(float x) {
   __bf16 b = (__bf16)x;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
   return __builtin_bit_cast(uint16_t, b);

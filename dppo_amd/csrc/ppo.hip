@@ -385,13 +385,24 @@ __global__ __launch_bounds__(256) void bc_loss_kernel(const BcArgs a) {
   part = block_sum(part, sh);
   finish_loss_sum(part, a.partial, a.loss, sh);
 }
+// see common.h: zeroing is a kernel launch, never a memset node
+__global__ __launch_bounds__(256) void zero_bytes_kernel(uint32_t* p, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) p[i] = 0u;
+}
+void launch_zero_bytes(void* p, size_t bytes, hipStream_t s) {
+  const size_t n4 = bytes / 4;
+  if (n4 == 0) return;
+  const size_t blocks = (n4 + 255) / 256;
+  hipLaunchKernelGGL(zero_bytes_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, (uint32_t*)p, n4);
+}
 int64_t bc_loss_blocks(int64_t M, int ldde) { return (M * ldde + 255) / 256; }
 template <class P>
 void launch_bc_loss(const BcArgs& a, hipStream_t s) {
   const int64_t n = a.M * a.ldde;
   if (n <= 0) return;
   const int64_t blocks = bc_loss_blocks(a.M, a.ldde);
-  (void)hipMemsetAsync(a.partial + blocks, 0, 8, s);  // the arrival counter
+  launch_zero_bytes(a.partial + blocks, 8, s);  // the arrival counter
   hipLaunchKernelGGL((bc_loss_kernel<P>), dim3((unsigned)blocks), dim3(256), 0, s, a);
 }
 template void launch_bc_loss<F32>(const BcArgs&, hipStream_t);
@@ -422,7 +433,7 @@ void launch_mse_loss(const MseArgs& a, hipStream_t s) {
   const int64_t n = a.M * a.ldde;
   if (n <= 0) return;
   const int64_t blocks = bc_loss_blocks(a.M, a.ldde);
-  (void)hipMemsetAsync(a.partial + blocks, 0, 8, s);
+  launch_zero_bytes(a.partial + blocks, 8, s);
   hipLaunchKernelGGL((mse_loss_kernel<P>), dim3((unsigned)blocks), dim3(256), 0, s, a);
 }
 template void launch_mse_loss<F32>(const MseArgs&, hipStream_t);
@@ -470,12 +481,14 @@ __global__ __launch_bounds__(256) void adv_moments_kernel(const float* adv_k, co
     // its barrier: no __threadfence() on either side (~3.5 us each on gfx950; this launch sits in front of the actor's forward)
     __hip_atomic_store(&moments[8 + 2 * blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&moments[9 + 2 * blockIdx.x], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    last = __hip_atomic_fetch_add((unsigned long long*)&moments[3], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+    // (DPPO_HANDOVER_*: common.h -- the fence-free form is an ISA property of gfx942 / gfx950, other targets get release / acquire)
+    DPPO_HANDOVER_DRAIN();
+    last = __hip_atomic_fetch_add((unsigned long long*)&moments[3], 1ull, DPPO_HANDOVER_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT) ==
            gridDim.x - 1;
   }
   __syncthreads();
   if (!last) return;
+  DPPO_HANDOVER_ACQUIRE();
   s = threadIdx.x < gridDim.x ? __hip_atomic_load(&moments[8 + 2 * threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
   q = threadIdx.x < gridDim.x ? __hip_atomic_load(&moments[9 + 2 * threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
   s = block_sum(s, sh);
@@ -942,13 +955,13 @@ __global__ __launch_bounds__(256) void post_reduce_kernel(const PostReduce q) {
     // gfx950) this chain -- G, fence, add | poll, fence, finish -- was 11 of the launch's 16 us, on the update's critical path.
     if (lane == 0) __hip_atomic_store(&q.G[out], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DPPO_HANDOVER_DRAIN();  // (common.h: fence-free on gfx942 / gfx950, release / acquire elsewhere)
   __syncthreads();
   // The time MLP's backward belongs to the LAST block of the range: it prepares everything that does not depend on G while
   // the others finish, then waits for their arrivals.  (Workgroups are dispatched in index order, so every block it waits
   // for is already running or done: the wait cannot starve them.)
   if (tb != q.n_temb - 1) {
-    if (tid == 0) __hip_atomic_fetch_add(q.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_fetch_add(q.counter, 1u, DPPO_HANDOVER_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   time_backward_prepare(q.w1, q.b1, q.w2, q.ksteps, q.Kft, q.td, sh);
@@ -956,6 +969,7 @@ __global__ __launch_bounds__(256) void post_reduce_kernel(const PostReduce q) {
     while (__hip_atomic_load(q.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)q.n_temb - 1)
       __builtin_amdgcn_s_sleep(2);
     __hip_atomic_store(q.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
+    DPPO_HANDOVER_ACQUIRE();
   }
   __syncthreads();
   time_backward_finish(q.G, q.Kft, q.td, q.gw1, q.gb1, q.gw2, q.gb2, sh);

@@ -52,6 +52,7 @@ struct SampleArgs {
   int ks0v;        // set by the launcher: k-steps of layer 0 that hold input columns (the rest of its KS0 is zero padding)
   int l0_lds;      // set by the launcher: 1 = layer-0 fragments of the current network live in LDS, not in the stream
   int pre_sweep;   // split sampler, set by its launcher: sleep periods between the exchange store and the first sweep (knob 28)
+  unsigned spin_limit;  // split sampler, set by its launcher: sweeps a member waits for its tile before it gives up (knob 29)
   float dclip, eclip, rclip, fclip;
 };
 
@@ -67,6 +68,7 @@ size_t sampler_split_xch_bytes(const dppo_net_desc& d, int64_t B);
 int launch_sample_chain_split(const SamplerGeom& g, const SampleArgs& a, void* xch, size_t xch_bytes, hipStream_t s);  // -1: not covered
 void set_sampler_split(int v);  // tuning knob 27
 void set_sampler_split_pre_sweep(int v);  // tuning knob 28
+void set_sampler_split_spin_limit(int v);  // tuning knob 29 (tests only: force a time-out)
 
 // W: [H][ld] fp32 (nn.Linear layout).  Writes the fragments of one hidden layer (KS k-steps) into
 // every wave's stream at position pos0.

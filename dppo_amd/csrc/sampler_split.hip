@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
           if (got) need &= ~(1u << w);
         }
         if (__all(need == 0u)) break;
-        if (++spins >= SPLIT_SPINS) {
+        if (++spins >= a.spin_limit) {
           failed = true;
           break;
         }
@@ -429,7 +429,9 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
       SSTAMP(6);
       SSTAMP_VAL(9, (unsigned long long)spins);
       if (failed && lane == 0) {
-        __hip_atomic_store((sgu32_p)tmo_, (unsigned)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // sticky: the word only ever grows and no launch clears it (split_zero_kernel leaves the head of the block alone), so a
+        // time-out in ANY call since the host last read the word is still there when it looks (once per rollout)
+        __hip_atomic_fetch_max((sgu32_p)tmo_, (unsigned)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *failL = 1;
       }
     }
@@ -526,14 +528,20 @@ __global__ __launch_bounds__(256) void sample_chain_split_kernel(const SampleArg
     if (*(volatile int*)failL) break;
   }
   SSTAMP_ONCE(12);
-  if (*(volatile int*)failL && m == 0 && owner && grow < B) {
+  if (*(volatile int*)failL && m == 0 && owner && grow < B) {  // poison everything the call owed for these rows: the
+    // trajectory and EVERY chain slot (the steps that did not run would otherwise keep a previous call's chain entries)
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      if (jcol + e < AF) g_traj[(size_t)grow * AF + jcol + e] = __uint_as_float(0x7fc00000u);
+      if (jcol + e < AF) {
+        g_traj[(size_t)grow * AF + jcol + e] = __uint_as_float(0x7fc00000u);
+        if (a.chains != nullptr)
+          for (int sl = 0; sl < chain_len; ++sl) g_chains[((size_t)grow * chain_len + sl) * AF + jcol + e] = __uint_as_float(0x7fc00000u);
+      }
   }
 }
 
-// Zeroes the exchange block in front of every launch.  A kernel, not hipMemsetAsync: captured into a hipGraph, the memset node
+// Zeroes the exchange SLOTS in front of every launch -- not the 256-byte head of the block, whose first word is the sticky
+// time-out word: only the host clears that, after reading it.  A kernel, not hipMemsetAsync: captured into a hipGraph, the memset node
 // left 16 bytes of something else (a size and an address) at the head of the block from the second replay on (ROCm 7.2;
 // tests/test_sampler_split.py::test_split_sampler_replays_from_a_hip_graph reads the time-out word there).
 __global__ __launch_bounds__(256) void split_zero_kernel(u32x4* p, size_t n16) {
@@ -546,6 +554,8 @@ static int g_sampler_split = 1;  // tuning knob 27
 void set_sampler_split(int v) { g_sampler_split = v; }
 static int g_split_pre_sweep = 4;  // tuning knob 28: s_sleep(1) periods (64 cycles each) between a member's exchange store and its first sweep
 void set_sampler_split_pre_sweep(int v) { g_split_pre_sweep = v < 0 ? 0 : (v > 64 ? 64 : v); }
+static unsigned g_split_spin_limit = SPLIT_SPINS;  // tuning knob 29 (tests: 1 forces a time-out; <= 0 restores the default)
+void set_sampler_split_spin_limit(int v) { g_split_spin_limit = v <= 0 ? SPLIT_SPINS : (unsigned)v; }
 
 static int device_cus() {
   static std::atomic<int> cus[64];
@@ -572,7 +582,7 @@ bool sampler_split_ok(const dppo_net_desc& d, bool bf16, int64_t B, bool merge_t
 size_t sampler_split_xch_bytes(const dppo_net_desc& d, int64_t B) {
   const size_t tiles = (size_t)((B + 15) / 16);
   const int ot = (d.out_dim + 15) / 16 <= 1 ? 1 : 4;
-  // 256 bytes in front for the time-out word, then the slots; the whole block is zeroed before every launch
+  // 256 bytes in front for the (sticky, host-cleared) time-out word, then the slots, which are zeroed before every launch
   return 256 + tiles * 2 * SPLIT * ot * 64 * 16;
 }
 
@@ -589,9 +599,11 @@ static int launch_split_cfg(const SamplerGeom& g, const SampleArgs& a, void* xch
     attr_set.done();
   }
   if ((xch_bytes & 15) || ((uintptr_t)xch & 15)) return -3;
-  hipLaunchKernelGGL(split_zero_kernel, dim3((unsigned)((xch_bytes / 16 + 255) / 256)), dim3(256), 0, s, (u32x4*)xch, xch_bytes / 16);
+  const size_t n16 = (xch_bytes - 256) / 16;  // the slots behind the head
+  hipLaunchKernelGGL(split_zero_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (u32x4*)xch + 16, n16);
   SampleArgs b = a;
   b.pre_sweep = g_split_pre_sweep;
+  b.spin_limit = g_split_spin_limit;
   const int tiles = (a.B + 15) / 16;
   const bool probe = probe_begin(PROBE_SAMPLER, s);
   hipLaunchKernelGGL(kern, dim3((tiles + 7) / 8 * 64), dim3(256), lds, s, b, (char*)xch + 256, (int)(xch_bytes - 256), (unsigned*)xch);

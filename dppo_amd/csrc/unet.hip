@@ -277,7 +277,7 @@ int pack_impl(const dppo_unet_desc& d, int n_time, const float* prm, char* pk, h
   auto pc = [&](const Conv& c) {
     const int cop = rup(c.co, 64);
     if (!c.transposed) {
-      (void)hipMemsetAsync(pk + c.pk, 0, (size_t)c.co * c.Kp * P::ESIZE, s);
+      launch_zero_bytes(pk + c.pk, (size_t)c.co * c.Kp * P::ESIZE, s);
       const size_t n = (size_t)c.co * c.ci * c.ks;
       hipLaunchKernelGGL((pack_conv_kernel<P>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, prm + c.w, c.co, c.ci,
                          c.ks, c.cip, c.split, (E*)(pk + c.pk));
@@ -1455,7 +1455,7 @@ struct UnetTrainer {
     dobs_out = dobs;
     dg_started = false;
     const int nl = d.n_levels, T0 = d.horizon_steps, Tp0 = T0 + 2 * PAD;
-    if (!dry) (void)hipMemsetAsync(grad, 0, (size_t)L.n_params * 4, s);
+    if (!dry) launch_zero_bytes(grad, (size_t)L.n_params * 4, s);
     // ---- final 1x1 conv
     Img dE = new_img(T0, 64);
     if (!dry)

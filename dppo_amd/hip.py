@@ -84,6 +84,13 @@ class GmmCfg(C.Structure):  # struct dppo_gmm_cfg
                 ("seed_hi", C.c_uint32)]
 
 
+DP_HOOK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)  # void (*)(void* user, dppo_stream_t side)
+
+
+class DpHook(C.Structure):  # struct dppo_dp_hook
+    _fields_ = [("critic_grads_enqueued", DP_HOOK_FN), ("user", C.c_void_p)]
+
+
 class ObsIO(C.Structure):  # struct dppo_obs_io
     _fields_ = [("obs_critic", C.c_void_p), ("d_obs_actor", C.c_void_p), ("d_obs_critic", C.c_void_p)]
 
@@ -123,6 +130,8 @@ SYMBOLS = {
     "dppo_ppo_workspace_bytes": (_L, [_ND, _ND, _I, _L]),
     "dppo_ppo_loss_fwd_bwd": (_I, [_ND, _ND, _I, _P, _P, _P, _P, C.POINTER(DiffusionCfg), C.POINTER(PpoCfg), _P,
                                    _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P]),
+    "dppo_ppo_loss_fwd_bwd_dp": (_I, [_ND, _ND, _I, _P, _P, _P, _P, C.POINTER(DiffusionCfg), C.POINTER(PpoCfg), _P,
+                                      _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P, C.POINTER(DpHook)]),
     "dppo_gaussian_workspace_bytes": (_L, [_ND, _ND, _I, _L]),
     "dppo_gaussian_sample": (_I, [_ND, _I, _P, _P, C.POINTER(GaussianCfg), _P, _P, _P, _L, _P, _P, _P, _L, _P]),
     "dppo_gaussian_logprob": (_I, [_ND, _I, _P, _P, C.POINTER(GaussianCfg), _P, _P, _P, _L, _P, _P, _L, _P]),
@@ -171,6 +180,7 @@ SYMBOLS = {
     "dppo_pack_nets": (_I, [_ND, _I, _P, _P, _ND, _I, _P, _P, _I, _P]),
     "dppo_stats_split": (_I, [_P, _P, _P]),
     "dppo_stats_merge": (_I, [_P, _P, _I, _P]),
+    "dppo_stats_merge_n": (_I, [_P, _P, _I, _I, _P]),
     "dppo_probe_arm": (_I, [_I, _I]),
     "dppo_probe_collect": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "dppo_probe_collect_bytes": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double),
@@ -245,5 +255,6 @@ class Workspace:
 
     def get(self, nbytes: int, device) -> torch.Tensor:
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
-            self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            # zero-filled: a sampling workspace begins with the sticky time-out word (include/dppo_hip.h, dppo_sample_chain)
+            self.buf = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         return self.buf

@@ -257,7 +257,7 @@ class DiffusionModel(nn.Module):
         return Sample(traj, chains)
 
     def check_sampler_health(self):
-        """Raises if a workgroup of the last sampling call gave up waiting for its tile's other seven (bounded spin in the
+        """Raises if a workgroup of ANY sampling call since the last check gave up waiting for its tile's other seven (bounded spin in the
         eight-workgroups-per-tile kernel; its rows of the trajectory are NaN then).  One 4-byte D2H read: call it where the
         host synchronises anyway (the rollout loop copies every step's actions to the host)."""
         ws = self.__dict__.get("_ws_sample")
@@ -265,8 +265,9 @@ class DiffusionModel(nn.Module):
             return
         word = int(ws.buf[:4].view(torch.int32).item())
         if word != 0:
+            ws.buf[:4].zero_()  # sticky on the device side: only this read clears it
             raise hip.DppoHipError(f"sampler: a workgroup timed out waiting for its tile at denoising step {word - 1} "
-                                   "(dppo_sample_chain, exchange block); the call's trajectories are poisoned with NaN")
+                                   "(dppo_sample_chain, exchange block) in some sampling call since the last check; that call's trajectories and chains are NaN")
 
     @torch.no_grad()
     def forward(self, cond, deterministic=True, noise=None):

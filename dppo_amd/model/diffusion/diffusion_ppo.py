@@ -97,7 +97,7 @@ class PPODiffusion(VPGDiffusion):
         return cfg
 
     def _run_ppo(self, obs, chains, returns, values, adv, logprobs, inds, kinds, N, reward_horizon, adv_gathered,
-                 global_moments=None):
+                 global_moments=None, critic_hook=None):
         lib = hip.load()
         dev = obs.device
         da, dc = self.actor_ft.net_desc(), self.critic.net_desc()
@@ -115,6 +115,29 @@ class PPODiffusion(VPGDiffusion):
             hip.check(int(wsb), "dppo_ppo_workspace_bytes")
         ws = self._ws_ppo.get(wsb, dev)
         ga, gc = self.actor_ft.flat_grads(), self.critic.flat_grads()
+        if critic_hook is not None and not unet:
+            # data parallel: the library calls back once every launch that writes the critic's gradient is queued, with the
+            # stream it queued them on (include/dppo_hip.h, dppo_ppo_loss_fwd_bwd_dp); an exception raised in the callback
+            # surfaces here, after the call
+            err = []
+
+            def _cb(_user, side):
+                try:
+                    critic_hook(int(side or 0))
+                except BaseException as e:  # noqa: BLE001 (ctypes would only print it)
+                    err.append(e)
+            hook = hip.DpHook(hip.DP_HOOK_FN(_cb), None)
+            rc = lib.dppo_ppo_loss_fwd_bwd_dp(
+                C.byref(da), C.byref(dc), self.prec, self.actor_ft.flat_params().data_ptr(),
+                self.actor_ft.packed(self.prec, K).data_ptr(), self.critic.flat_params().data_ptr(),
+                self.critic.packed(self.prec, 0).data_ptr(), C.byref(dcfg), C.byref(pcfg), ks.data_ptr(), hip.ptr(obs),
+                hip.ptr(chains), hip.ptr(returns), hip.ptr(values), hip.ptr(adv), hip.ptr(logprobs), hip.ptr(inds),
+                hip.ptr(kinds), N, hip.ptr(global_moments), ga.data_ptr(), gc.data_ptr(), self._stats.data_ptr(),
+                ws.data_ptr(), ws.numel(), hip.stream(), C.byref(hook))
+            if err:
+                raise err[0]
+            hip.check(rc, "dppo_ppo_loss_fwd_bwd_dp")
+            return self._stats
         hip.check(entry(
             C.byref(da), C.byref(dc), self.prec, self.actor_ft.flat_params().data_ptr(),
             self.actor_ft.packed(self.prec, K).data_ptr(), self.critic.flat_params().data_ptr(),
@@ -249,13 +272,15 @@ class PPODiffusion(VPGDiffusion):
 
     # ------------------------------------------------------------------ fused-gather fast path
     def ppo_update(self, obs_k, chains_k, returns_k, values_k, adv_k, logprobs_k, inds, reward_horizon=4,
-                   global_moments=None):
+                   global_moments=None, critic_hook=None):
         """One minibatch straight from the rollout buffer (R rows): gradients land in the flat grad buffers of
         ``actor_ft`` / ``critic``; returns the device stats tensor (float64[8], see hip.STAT_*).  No host sync.
 
         obs_k (R,To*Do), chains_k (R,Kft+1,Ta*Da), returns_k/values_k/adv_k (R,), logprobs_k (R,Kft,Ta*Da),
         inds (N,) int64 in [0, R*Kft)  -- the reference's minibatch assembly
         (agent/finetune/train_ppo_diffusion_agent.py:316-327) fused into the kernel's loader.
+        critic_hook(side_stream_handle): data parallel only (``DataParallel.critic_hook``) -- called from inside the library
+        call once the critic's gradient launches are queued, so its all-reduce overlaps the actor's backward.
         """
         hip.require_gpu(obs_k, "PPODiffusion.ppo_update")
         N = inds.numel()
@@ -263,4 +288,4 @@ class PPODiffusion(VPGDiffusion):
         if (self.clip_advantage_lower_quantile, self.clip_advantage_upper_quantile) != (0, 1):
             adv_g = adv_k[torch.div(inds, self.ft_denoising_steps, rounding_mode="floor")]
         return self._run_ppo(obs_k, chains_k, returns_k, values_k, adv_k, logprobs_k, inds, None, N, reward_horizon,
-                             adv_g, global_moments)
+                             adv_g, global_moments, critic_hook)

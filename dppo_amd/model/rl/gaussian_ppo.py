@@ -30,6 +30,10 @@ class _FusedGaussLoss(torch.autograd.Function):
 
 
 class PPO_Gaussian(VPG_Gaussian):
+    # data parallel (dppo_amd.parallel.DataParallel): statistics slots 5..7 are rank-global values (advantage mean / std and
+    # the entropy, which depends on sigma only), averaged -- not summed -- over ranks
+    dp_avg_stats = 3
+
     def __init__(self, clip_ploss_coef: float, clip_vloss_coef: Optional[float] = None, norm_adv: Optional[bool] = True,
                  **kwargs):
         super().__init__(**kwargs)
@@ -47,7 +51,7 @@ class PPO_Gaussian(VPG_Gaussian):
         if vision:
             cond = obs
             obs = net.encode_obs(cond, train=True)
-            obs_c = self.critic.encode_obs(cond, train=True, augment=False)
+            obs_c = self.critic.encode_obs(cond, train=True, augment=None)  # None: critic.augment decides, as in the reference's self.critic(obs)
         dev = obs.device
         da, dc = net.net_desc(), self.critic.net_desc()
         N = obs.shape[0]

@@ -82,7 +82,8 @@ def step_many(slots) -> None:
 
 
 def step_and_repack(model, actor_opt: "FlatAdamW", critic_opt: "FlatAdamW", update_actor: bool = True,
-                    max_norm: Optional[float] = None, n_time: Optional[int] = None):
+                    max_norm: Optional[float] = None, n_time: Optional[int] = None,
+                    actor_sq_norm: Optional[torch.Tensor] = None):
     """Optimiser step + kernel-image repack of both networks (reference train_ppo_diffusion_agent.py:360-373).
 
     The tail of an update is a chain of launch-latency-bound kernels, so it is kept short: one AdamW launch for both
@@ -92,7 +93,8 @@ def step_and_repack(model, actor_opt: "FlatAdamW", critic_opt: "FlatAdamW", upda
     n_time = model.denoising_steps if n_time is None else n_time
     slots = [critic_opt.slot(model.critic.flat_grads())]
     if update_actor:
-        slots.append(actor_opt.slot(model.actor_ft.flat_grads(), max_norm=max_norm))
+        # actor_sq_norm: a clip norm that spans more than the trunk (a Gaussian head's logvar: train_ppo_gaussian_agent.py)
+        slots.append(actor_opt.slot(model.actor_ft.flat_grads(), max_norm=max_norm, sq_norm=actor_sq_norm))
     step_many(slots)
     model.critic.mark_updated()
     if update_actor:

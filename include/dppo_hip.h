@@ -165,11 +165,13 @@ int dppo_critic_forward(const dppo_net_desc* net, int prec, const float* params,
  * Box-Muller) -- same distribution as the reference's torch.randn / randn_like, one launch instead of two. */
 /* Workspace: the cond_mlp encodings (if any) and, where the call runs as the eight-workgroups-per-tile kernel (knob 27: bf16,
  * hidden 512, one residual block, no LayerNorm, out_dim <= 64, in_dim <= 96, time_dim % 4 == 0, ceil(B / 16) * 8 <= the
- * device's CU count, i.e. B <= 512 on MI355X), its exchange block, which comes first; 0 when neither applies.  Contents
- * need no initialisation (the call zeroes the exchange block on `stream` before its launch).  Two calls that may run
- * concurrently (different streams) must not share a workspace.  After the call the first 32-bit word of an exchange block
- * is 0, or 1 + the denoising step at which a workgroup gave up waiting for its tile's other seven (bounded spin; the rows
- * of `traj` it owned are NaN then) -- never observed; the tests check the word. */
+ * device's CU count, i.e. B <= 512 on MI355X), its exchange block, which comes first; 0 when neither applies.  The
+ * caller zeroes the FIRST 256 BYTES of a new workspace once (the sticky time-out word lives there; no call ever clears it);
+ * the rest needs no initialisation (the call zeroes the exchange slots on `stream` before its launch).  Two calls that may
+ * run concurrently (different streams) must not share a workspace.  The first 32-bit word of an exchange block is 0, or
+ * 1 + the largest denoising step at which a workgroup of ANY call since the host last cleared it gave up waiting for its
+ * tile's other seven (bounded spin; the rows of `traj` and every chain slot that workgroup's tile owned are NaN then) --
+ * never observed outside the test that forces it (knob 29). */
 int64_t dppo_sample_chain_workspace_bytes(const dppo_net_desc* actor, int prec, int64_t B);
 /* Bytes of the exchange block at the head of that workspace, 0 when the call will run one workgroup per tile: tells a caller
  * whether the workspace's first word is the time-out word described above (a host that already synchronises once per rollout
@@ -259,6 +261,28 @@ int dppo_ppo_loss_fwd_bwd(const dppo_net_desc* actor, const dppo_net_desc* criti
                           const float* logprobs_k, const int64_t* inds, const int64_t* kinds, int64_t N,
                           const double* global_moments, float* actor_grad, float* critic_grad, double* stats,
                           void* workspace, int64_t workspace_bytes, dppo_stream_t stream);
+
+/* Data parallel (the reference is single-process, so this entry replaces nothing): the same call with a hook.
+ * `critic_grads_enqueued(user, side)` is called ONCE, on the calling thread, from inside the call, at the point where
+ * everything that writes `critic_grad` has been enqueued on `side` -- the library's critic stream, or `stream` itself when
+ * the critic pipeline runs on the caller's stream (knob 2 = 0) -- and before the actor's forward / backward are enqueued.
+ * Work the hook enqueues on `side` (the critic slice of the gradient all-reduce: torch.distributed under
+ * torch.cuda.ExternalStream(side), or ncclAllReduce) therefore runs while the actor half still occupies `stream`, and is
+ * joined into `stream` with the rest of the critic pipeline before the call's work on `stream` ends.  The hook must not
+ * synchronise with `stream` (deadlock: the join comes later) and cannot be used under stream capture.  hook == NULL or a NULL
+ * function pointer: exactly dppo_ppo_loss_fwd_bwd. */
+typedef struct dppo_dp_hook {
+  void (*critic_grads_enqueued)(void* user, dppo_stream_t side);
+  void* user;
+} dppo_dp_hook;
+int dppo_ppo_loss_fwd_bwd_dp(const dppo_net_desc* actor, const dppo_net_desc* critic, int prec, const float* actor_params,
+                             const void* actor_packed, const float* critic_params, const void* critic_packed,
+                             const dppo_diffusion_cfg* dcfg, const dppo_ppo_cfg* pcfg, const dppo_step* ksteps,
+                             const float* obs_k, const float* chains_k, const float* returns_k, const float* values_k,
+                             const float* adv_k, const float* logprobs_k, const int64_t* inds, const int64_t* kinds,
+                             int64_t N, const double* global_moments, float* actor_grad, float* critic_grad,
+                             double* stats, void* workspace, int64_t workspace_bytes, dppo_stream_t stream,
+                             const dppo_dp_hook* hook);
 
 /* ---- Gaussian-policy PPO on the same trunk kernels --------------------------------------------
  * Replaces model/common/mlp_gaussian.py:283-362 (Gaussian_MLP.forward, fixed / learned-per-dimension std),
@@ -402,6 +426,10 @@ int dppo_adamw_step_multi(const dppo_adamw_slot* slots, int n_slots, dppo_stream
  * `world`.  One launch each way. */
 int dppo_stats_split(const double* stats, float* hi_lo, dppo_stream_t stream);
 int dppo_stats_merge(const float* hi_lo, double* stats, int world, dppo_stream_t stream);
+/* The same with the number of rank-global slots from DPPO_STAT_ADV_MEAN on (values every rank wrote in full, divided by
+ * `world` after the SUM) chosen by the caller: 2 for the diffusion / mixture losses, 3 for the Gaussian head, whose
+ * DPPO_GAUSS_STAT_ENTROPY (slot 7) depends on sigma only and is the same on every rank (mean std, slot 8, never travels). */
+int dppo_stats_merge_n(const float* hi_lo, double* stats, int world, int n_avg, dppo_stream_t stream);
 
 /* ---- measurement hook (bench.py only; process-wide, not thread-safe, off by default) ----------- */
 /* While armed for a kernel, each of its launches is bracketed by HIP events on the launch stream.
@@ -452,7 +480,9 @@ int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* 
  * knob 26: LDS stages of the grouped weight-gradient GEMM: 1 (default; 36.9 KB per workgroup, three workgroups per CU) or 2
  * knob 27: sampler, small env batches of one-block bf16 networks at hidden 512: one 16-row tile over eight workgroups with
  *          the weights resident in registers (default 1; see dppo_sample_chain_workspace_bytes) or over one (0)
- * knob 28: knob 27's kernel: 64-cycle sleep periods between a workgroup's exchange store and its first sweep (default 4) */
+ * knob 28: knob 27's kernel: 64-cycle sleep periods between a workgroup's exchange store and its first sweep (default 4)
+ * knob 29: knob 27's kernel: sweeps a workgroup waits for its tile before it gives up (default 2^20; tests force a time-out
+ *          with 1; <= 0 restores the default) */
 int dppo_tune_set(int knob, int value);
 /* one bare layer GEMM: out[M][ldo] = act(X[M][Kp] . W[N][Kp]^T + bias) with elem = prec operands;
  * out_f32 and/or out_elem may be NULL; ldo >= round_up(N,16) */

@@ -719,3 +719,125 @@ def test_gaussian_agent_drives_a_gmm_policy(tmp_path, monkeypatch):
     assert not torch.equal(w1[n_mean:], w0[n_mean:]), "weights trunk was not updated"
     assert not torch.equal(m.critic.flat_params(), c0) and not torch.equal(net.logvar.data, lv0)
     assert torch.isfinite(w1).all()
+
+
+# ------------------------------------------------------------------ zeroing inside captured entry points
+def _capture(fn):
+    """Warm `fn` up on a side stream, capture one call into a hipGraph and return the graph."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    return g
+
+
+def test_conv_actor_update_replays_from_a_hip_graph():
+    """dppo_unet_ppo_loss_fwd_bwd zeroes the conv actor's whole gradient buffer at its start; as a hipMemsetAsync node that
+    zeroing left foreign bytes at the head of its destination from the second replay on (the split sampler's exchange block
+    showed it: gpurun_out/s4d/t.log).  With the zeroing kernel three replays give the eager call's gradients bit for bit."""
+    from dppo_amd.model.common.critic import CriticObs
+    from dppo_amd.model.diffusion.diffusion_ppo import PPODiffusion
+    from oracle import dppo_oracle as O
+    from tests.golden.make_golden_cases import UNET_SPECS
+    from tests.test_unet import CRITIC, hip_unet
+    u = O.UnetSpec(**UNET_SPECS["unet_square"])
+    dev = "cuda:0"
+    actor = hip_unet(u, 41, "fp32", dev="cpu")
+    critic = CriticObs(cond_dim=u.cond_dim, mlp_dims=[256, 256, 256], residual_style=True, precision="fp32")
+    critic.load_state_dict(O.init_params(CRITIC(u), 43))
+    m = PPODiffusion(actor=actor, critic=critic, horizon_steps=u.horizon_steps, obs_dim=u.cond_dim, action_dim=u.action_dim,
+                     device=dev, gamma_denoising=0.99, clip_ploss_coef=0.01, randn_clip_value=3, denoising_steps=20,
+                     ft_denoising_steps=10)
+    m.actor_ft.load_state_dict(O.unet_init_params(u, 42), strict=True)
+    R, Kft, AF, N = 64, 10, u.horizon_steps * u.action_dim, 256
+    gen = torch.Generator().manual_seed(2)
+    obs = (torch.rand(R, 1, u.cond_dim, generator=gen) * 2 - 1).to(dev)
+    chains = m(cond={"state": obs}, noise=torch.randn(21, R, AF, generator=gen).to(dev)).chains
+    logp = m.get_logprobs({"state": obs}, chains).reshape(R, Kft, AF)
+    val = m.critic({"state": obs}).reshape(R)
+    ret, adv = val + torch.randn(R, generator=gen).to(dev), torch.randn(R, generator=gen).to(dev)
+    mbs = [torch.randperm(R * Kft, generator=gen)[:N].to(dev).contiguous() for _ in range(3)]
+    ro = (obs.reshape(R, -1).contiguous(), chains.reshape(R, Kft + 1, AF).contiguous(), ret, val, adv, logp)
+    eager = []
+    for mb in mbs:
+        m.ppo_update(*ro, mb)
+        eager.append((m.actor_ft.flat_grads().clone(), m.critic.flat_grads().clone(), m._stats.clone()))
+    inds = mbs[0].clone()
+    g = _capture(lambda: m.ppo_update(*ro, inds))
+    for rep in range(2):
+        for mb, (ga, gc, st) in zip(mbs, eager):
+            inds.copy_(mb)
+            m.actor_ft.flat_grads().fill_(float("nan"))  # the call must overwrite every element
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(m.actor_ft.flat_grads(), ga) and torch.equal(m.critic.flat_grads(), gc)
+            assert torch.equal(m._stats, st)
+
+
+def test_bc_loss_replays_from_a_hip_graph():
+    """dppo_bc_loss_fwd_bwd zeroes the 8-byte arrival counter of its loss reduction (launch_bc_loss); the same replay check."""
+    from tests.test_hip_parity import build_model
+    m, a, _ = build_model("hopper", dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01, randn_clip_value=3),
+                          41, "fp32")
+    B = 48
+    gen = torch.Generator().manual_seed(3)
+    states = [(torch.rand(B, 1, a.cond_dim, generator=gen) * 2 - 1).to("cuda:0") for _ in range(3)]
+    noise = torch.randn(21, B, a.horizon_steps, a.action_dim, generator=gen).to("cuda:0")
+    eager = []
+    for s in states:
+        v, gr = m.bc_loss_and_grad({"state": s}, noise=noise)
+        eager.append((v.clone(), gr.clone()))
+    st = states[0].clone()
+    out = {}
+
+    def call():
+        out["v"], out["g"] = m.bc_loss_and_grad({"state": st}, noise=noise)
+    g = _capture(call)
+    for rep in range(2):
+        for s, (v, gr) in zip(states, eager):
+            st.copy_(s)
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out["v"], v) and torch.equal(out["g"], gr)
+
+
+def test_dp_hook_runs_on_the_critic_stream_behind_the_critic_gradients():
+    """dppo_ppo_loss_fwd_bwd_dp: the hook fires once, inside the call, with the stream the critic pipeline was queued on; work
+    it queues there is ordered behind the critic's gradient kernels and joined into the caller's stream by the library.
+    Stand-in for the all-reduce (one process, one GPU): scale the critic's gradient by 2 on that stream."""
+    import bench
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    torch.manual_seed(7)
+    m = bench.build_model(str(dev), "bf16")
+    R, N = 2048, 8000
+    ro = bench.make_rollout(m, R, 1, dev, gen)
+    inds = torch.randperm(R * bench.KFT, device=dev, generator=gen)[:N].contiguous()
+    m.ppo_update(*ro, inds, reward_horizon=bench.ACT_STEPS)
+    torch.cuda.synchronize()
+    ga, gc, st = m.actor_ft.flat_grads().clone(), m.critic.flat_grads().clone(), m._stats.clone()
+    calls = []
+
+    def hook(side):
+        calls.append(side)
+        assert side != 0
+        with torch.cuda.stream(torch.cuda.ExternalStream(side, device=dev)):
+            m.critic.flat_grads().mul_(2.0)
+    for _ in range(3):
+        calls.clear()
+        m.ppo_update(*ro, inds, reward_horizon=bench.ACT_STEPS, critic_hook=hook)
+        torch.cuda.synchronize()
+        assert len(calls) == 1
+        assert torch.equal(m.actor_ft.flat_grads(), ga) and torch.equal(m._stats, st)
+        assert torch.equal(m.critic.flat_grads(), gc * 2.0)
+    # an exception in the hook surfaces from the call
+    def bad(side):
+        raise RuntimeError("collective failed")
+    with pytest.raises(RuntimeError, match="collective failed"):
+        m.ppo_update(*ro, inds, reward_horizon=bench.ACT_STEPS, critic_hook=bad)
+    torch.cuda.synchronize()

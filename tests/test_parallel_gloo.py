@@ -126,8 +126,9 @@ def dp_worker(rank, world, port, out):
     res = {}
     # (1) bucket aliasing: the networks' flat gradient buffers ARE slices of the one bucket
     na, nc = model.actor_ft.flat_params().numel(), model.critic.flat_params().numel()
-    res["alias"] = (model.actor_ft.flat_grads().data_ptr() == dp.bucket.data_ptr()
-                    and model.critic.flat_grads().data_ptr() == dp.bucket.data_ptr() + 4 * na
+    # (layout [critic | actor | stats]: the critic slice is sent first, from inside the library call; the rest is contiguous)
+    res["alias"] = (model.critic.flat_grads().data_ptr() == dp.bucket.data_ptr()
+                    and model.actor_ft.flat_grads().data_ptr() == dp.bucket.data_ptr() + 4 * nc
                     and dp.bucket.numel() == na + nc + 2 * STATS_SLOTS)
     # (2) broadcast: every rank now holds rank 0's weights, and the kernel images were invalidated
     res["weights"] = [model.actor_ft.flat_params().clone(), model.critic.flat_params().clone(),
@@ -144,10 +145,27 @@ def dp_worker(rank, world, port, out):
     st = torch.zeros(STATS_SLOTS, dtype=torch.float64)
     st[:5] = torch.tensor([stats[0], stats[1], stats[2], stats[3], stats[4]])  # pg, v, kl, clipfrac, ratio partial sums
     st[5], st[6] = 0.123456789012345, 1.987654321098765  # adv mean / std: global values every rank writes
+    st_local = st.clone()
     object.__setattr__(model, "_stats", st)
+    local = dp.bucket.clone()
+    # the product's order of events: the critic slice from the library's callback (stream handle 0 here: CPU tensors), then
+    # the rest behind the actor's gradients
+    assert dp.critic_hook is not None
+    dp.critic_hook(0)
+    res["critic_sent_early"] = bool(dp._critic_done)
     dp.allreduce_grads()
     res["grads"] = torch.cat([model.actor_ft.flat_grads(), model.critic.flat_grads()]).clone()
     res["stats"] = model._stats.clone()
+    # ... and the single whole-bucket all-reduce on the same local values gives the same bits (split=False never hooks)
+    split_bucket = dp.bucket.clone()
+    dp.bucket.copy_(local)
+    object.__setattr__(model, "_stats", st_local.clone())
+    dp.split = False
+    assert dp.critic_hook is None
+    dp.allreduce_grads()
+    res["split_equals_single"] = bool(torch.equal(dp.bucket[:na + nc], split_bucket[:na + nc])
+                                      and torch.equal(model._stats, torch.from_numpy(res["stats"].numpy())))
+    dp.split = True
     res["moments"] = mom.clone()
     # (4) after the broadcast every rank draws its own random stream (sampler key, permutations)
     TrainPPODiffusionAgent.reseed(42 + rank)
@@ -174,6 +192,8 @@ def test_data_parallel_class_on_two_ranks():
     a, c, cfg, params, data, inds = make_problem()
     r0, r1 = got[0], got[1]
     assert r0["alias"] and r1["alias"]
+    assert r0["critic_sent_early"] and r1["critic_sent_early"]
+    assert r0["split_equals_single"] and r1["split_equals_single"]
     assert all(r0["epochs_bumped"]) and all(r1["epochs_bumped"])
     for x, y, spec, seed in zip(r0["weights"], r1["weights"], (a, c, a), (300, 200, 100)):
         assert np.array_equal(x, y)
@@ -192,3 +212,74 @@ def test_data_parallel_class_on_two_ranks():
     adv_g = data[3][inds // 10].double()
     np.testing.assert_allclose(r0["moments"], [adv_g.sum().item(), (adv_g * adv_g).sum().item(), 128.0], rtol=1e-12)
     assert r0["sampler_key"] != r1["sampler_key"]
+
+
+# ------------------------------------------------------------------ statistics of a Gaussian head under data parallelism
+class _StubNet:
+    def __init__(self, n, fill):
+        self._p = torch.full((n,), float(fill))
+        self._flat_grad = torch.zeros(n)
+
+    def flat_params(self):
+        return self._p
+
+    def flat_grads(self):
+        return self._flat_grad
+
+    def mark_updated(self):
+        pass
+
+
+class _StubModel:
+    def __init__(self, rank, dp_avg_stats=None):
+        self.actor_ft, self.critic, self.actor = _StubNet(40, rank), _StubNet(24, rank), _StubNet(40, rank)
+        self._stats = None
+        if dp_avg_stats is not None:
+            self.dp_avg_stats = dp_avg_stats
+
+
+def gauss_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dppo_amd.model.rl.gaussian_ppo import PPO_Gaussian
+    from dppo_amd.parallel import DataParallel
+    res = {"class_value": PPO_Gaussian.dp_avg_stats}
+    for name, n_avg in (("gaussian", PPO_Gaussian.dp_avg_stats), ("diffusion", None)):
+        m = _StubModel(rank, n_avg)
+        dp = DataParallel(m, world)
+        # 9 slots like hip.GAUSS_STAT_COUNT: [pg, v, kl, clipfrac, ratio] partial sums, [adv mean, adv std, entropy] written in
+        # full by every rank (the entropy of a state-independent Gaussian depends on sigma only), [mean std] never travels
+        st = torch.tensor([0.1 * (rank + 1), 0.2 * (rank + 1), 0.01, 0.02, 0.5, 0.25, 1.5, -3.75, 0.1], dtype=torch.float64)
+        m._stats = st.clone()
+        m.critic.flat_grads().fill_(rank + 1.0)
+        dp.critic_hook(0)
+        dp.allreduce_grads()
+        res[name] = m._stats.numpy().copy()
+        res[name + "_cgrad"] = float(m.critic.flat_grads()[0])
+    out.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gaussian_entropy_is_not_summed_over_ranks():
+    """DPPO_GAUSS_STAT_ENTROPY (slot 7) is a rank-global value; summed over ranks the logged entropy (and the loss
+    metric built from it) came out world times too large.  PPO_Gaussian.dp_avg_stats = 3 widens the averaged range."""
+    world, port = 2, free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=gauss_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        g, d = got[r]["gaussian"], got[r]["diffusion"]
+        assert got[r]["class_value"] == 3
+        np.testing.assert_allclose(g[:5], [0.3, 0.6, 0.02, 0.04, 1.0], rtol=2e-7)   # partial sums: summed (in the fp32 bucket)
+        np.testing.assert_allclose(g[5:8], [0.25, 1.5, -3.75], rtol=1e-12)           # global values: not doubled
+        assert g[8] == 0.1                                                            # never travelled
+        np.testing.assert_allclose(d[5:7], [0.25, 1.5], rtol=1e-12)
+        assert d[7] == pytest.approx(-7.5, rel=1e-6)  # a diffusion model's slot 7 is an ordinary partial sum (unused there)
+        assert got[r]["gaussian_cgrad"] == 3.0

@@ -200,13 +200,49 @@ def test_split_sampler_replays_from_a_hip_graph():
 
 
 def test_health_check_raises_on_a_time_out_word():
+    """The word is sticky: no launch clears it, only the host's read does (the agent checks once per rollout of
+    n_steps sampler calls, so a time-out in any call but the last must survive the later calls)."""
     from dppo_amd import hip
     m, a, _ = build_model("hopper", DDPM, 3, "bf16")
     st = torch.rand(64, 1, a.cond_dim, device=DEV) * 2 - 1
     m(cond={"state": st})
     m.check_sampler_health()
     m.__dict__["_ws_sample"].buf[:4].view(torch.int32).fill_(6)  # what a member that gave up at step 5 leaves behind
+    m(cond={"state": st})  # later calls do not erase it
+    m(cond={"state": st})
     with pytest.raises(hip.DppoHipError, match="denoising step 5"):
         m.check_sampler_health()
-    m(cond={"state": st})  # the next call zeroes the block again
+    m.check_sampler_health()  # the read cleared it
+
+
+def test_a_forced_time_out_in_an_earlier_call_still_surfaces_and_poisons_the_chains():
+    """Two consecutive calls, the first forced to time out (knob 29: one sweep, knob 28: no pause before it, so some member
+    of some tile is certainly still missing): every workgroup leaves (the call returns), the rows of the tiles that gave up
+    are NaN in the trajectory AND in every chain slot, the second (healthy) call does not erase the word, and the check
+    raises after both."""
+    from dppo_amd import hip
+    lib = hip.load()
+    m, a, _ = build_model("hopper", DDPM, 5, "bf16")
+    B = 512
+    st = torch.rand(B, 1, a.cond_dim, device=DEV) * 2 - 1
+    good = m(cond={"state": st})
+    assert torch.isfinite(good.chains).all()
+    m.check_sampler_health()
+    try:
+        assert lib.dppo_tune_set(29, 1) == 0 and lib.dppo_tune_set(28, 0) == 0
+        bad = m(cond={"state": st})
+        torch.cuda.synchronize()
+        traj, chains = bad.trajectories.clone(), bad.chains.clone()
+    finally:
+        lib.dppo_tune_set(29, 0)
+        lib.dppo_tune_set(28, 4)
+    nan_rows = torch.isnan(traj.reshape(B, -1)).any(1)
+    assert nan_rows.any(), "the forced time-out did not trigger"
+    # a row is poisoned as a whole: trajectory and all chain slots
+    assert torch.isnan(traj.reshape(B, -1)[nan_rows]).all()
+    assert torch.isnan(chains.reshape(B, -1)[nan_rows]).all()
+    again = m(cond={"state": st})  # healthy call on the same workspace
+    assert torch.isfinite(again.chains).all() and torch.isfinite(again.trajectories).all()
+    with pytest.raises(hip.DppoHipError, match="timed out"):
+        m.check_sampler_health()
     m.check_sampler_health()
