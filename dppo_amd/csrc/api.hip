@@ -648,10 +648,12 @@ static int g_early_join = 1;       // tuning knob 14: side streams joined right 
 static int g_tn_group = 1;         // tuning knob 12: one launch for all weight-gradient GEMMs of a backward pass
 static int g_tn_target = 256;      // tuning knob 3: workgroups a weight-gradient GEMM aims for (tiles x row splits)
 static int g_tn_max_splits = 128;  // tuning knob 4: cap on its row splits (each split costs one fp32 slab of the output)
-// (the out_dim-deep product costs H^2 out_dim scalar MACs against the M H^2 MFMA MACs it saves: on for M >= 200 out_dim;
-// measured a loss at out_dim = 112, M = 10,000)
+// (the out_dim-deep product costs H^2 out_dim scalar MACs against the M H^2 MFMA MACs it saves: on for M >= 100 out_dim;
+// measured a loss at out_dim = 112, M = 10,000 -- ratio 89 -- and wins at out_dim 56, M = 7,500 -- ratio 134, BASELINE
+// configs[2], where it also admits the one-block backward; tuning knob 30 moves the ratio)
+static int g_lowrank_ratio = 100;
 static bool lowrank_top(const dppo_net_desc& d, int64_t M) {
-  return g_lowrank_top && d.n_blocks >= 1 && M >= (int64_t)200 * d.out_dim;
+  return g_lowrank_top && d.n_blocks >= 1 && M >= (int64_t)g_lowrank_ratio * d.out_dim;
 }
 // Time-embedding gradient through the first layer's weight-gradient GEMM: with a one-hot of the row's denoising step k in
 // the K padding of the input rows, dW0's extra columns are S[h][k] = sum over the rows of step k of dh0[row][h], and
@@ -2449,6 +2451,10 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 28) {  // split sampler: 64-cycle sleep periods between a member's exchange store and its first sweep (default 4)
     set_sampler_split_pre_sweep(value);
+    return 0;
+  }
+  if (knob == 30 && value >= 1) {  // low-rank dW2 (knob 16) and with it the one-block backward: on for M >= value x out_dim (default 100)
+    g_lowrank_ratio = value;
     return 0;
   }
   if (knob == 29) {  // split sampler: sweeps a member waits before giving up (tests force a time-out with 1; <= 0: default 2^20)

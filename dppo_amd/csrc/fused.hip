@@ -153,53 +153,102 @@ __device__ __forceinline__ void hand_over(lds_u32* flags, int wid, int lane, uin
 // streamed and multiplied for nothing in kernels whose k-loops are paced by exactly that stream.  Here a tile is a FIXED
 // sequence of S1 + KSH + S2 real positions (short layer, H-wide layer, short layer) padded with holes -- positions that
 // are never loaded -- to a multiple of the depth, so that slots stay compile-time and every tile starts at slot 0.
-template <class P, int TPW, int MR, int S1, int KSH, int S2>
+// AUX: the S2 positions of the third segment do not come from the wave's stream but from a second fragment array: position j
+// is the TPW fragments aux[(j TPW + tp) aux_stride], tp = 0 .. TPW-1 (the merged forward's wide out layer: a wave's K slice of
+// one out tile of Wout W2, whose fragments lie OT x 64 apart in the out stream [k-step][out tile][lane]).
+// Which segment a refill fetches from is known at COMPILE time everywhere but in the middle of the H-wide layer, where it is
+// always that layer itself: the walk is written with compile-time compact positions (refill_ct) around a loop that only ever
+// refills from the wide segment (refill_mid) -- no per-step segment selects, holes are not loaded at all, and the AUX
+// segment's runtime-stride addresses exist only at the S2 places that use them (selecting per step cost 14-20 VGPRs in the
+// k-loop: 18-26 spilled in the wide-head kernels).
+template <class P, int TPW, int MR, int S1, int KSH, int S2, bool AUX = false>
 struct CEngine {
   static constexpr int PD = 4, T = S1 + KSH + S2, HOLES = (PD - T % PD) % PD, TT = T + HOLES;
-  static_assert(KSH % PD == 0 && S1 >= 1 && S1 <= PD && S2 >= 0 && S2 <= PD && T >= PD, "CEngine layout");
+  static_assert(KSH % PD == 0 && KSH >= 2 * PD && S1 >= 1 && S1 <= PD && S2 >= 0 && S2 <= PD && T >= PD, "CEngine layout");
   u32x4 ring[PD][TPW];
-  const u32x4* stream;  // this wave's stream + lane
+  // Addresses are (wave-uniform base) + (lane index): the bases stay in SGPRs and ONE 32-bit VGPR serves every load.  As
+  // per-lane 64-bit pointers the next tile's first positions were hoisted out of the persistent tile loop and spilled, and
+  // each scratch reload in the last steps of the H-wide k-loop came with an s_waitcnt vmcnt(0) -- the ring drained four
+  // times per tile.
+  const u32x4* stream;  // this wave's stream (NO lane offset)
+  const u32x4* aux;     // AUX: this wave's first third-segment fragment (NO lane offset)
+  int aux_stride;       // AUX: distance (in u32x4 units) between two consecutive ones
+  unsigned ln;          // the lane index
   int p1, pl, p2;       // stream positions where the three segments start
 
-  __device__ __forceinline__ int phys(int c) const {  // compact position of a tile -> stream position, -1 for a hole
-    return c < S1 ? p1 + c : (c < S1 + KSH ? pl + (c - S1) : (c < T ? p2 + (c - S1 - KSH) : -1));
+  // fetch compact position N (a compile-time constant, already wrapped into [0, TT)) into slot SLOT
+  template <int SLOT, int N>
+  __device__ __forceinline__ void fetch_ct() {
+    unsigned ln = this->ln;
+    asm volatile("" : "+v"(ln));  // the address is formed HERE, once per tile and use: nothing to hoist and spill
+    if constexpr (N < S1 + KSH || (N < T && !(AUX && S2 > 0))) {
+      const int q = N < S1 ? p1 + N : (N < S1 + KSH ? pl + (N - S1) : p2 + (N - S1 - KSH));
+      const u32x4* w = stream + (size_t)q * TPW * 64;
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp) ring[SLOT][tp] = (w + tp * 64)[ln];
+    } else if constexpr (N < T) {  // AUX third segment
+      const u32x4* w = aux + (size_t)((N - S1 - KSH) * TPW) * aux_stride;
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp) ring[SLOT][tp] = (w + (size_t)tp * aux_stride)[ln];
+    }  // else: a hole -- nothing to fetch, the slot is not multiplied before its next refill
+  }
+  template <int SLOT, int C>
+  __device__ __forceinline__ void refill_ct() {  // the slot gave up compact position C: fetch C + PD (of the next tile, maybe)
+    fetch_ct<SLOT, (C + PD >= TT ? C + PD - TT : C + PD)>();
   }
   template <int SLOT>
-  __device__ __forceinline__ void refill(int c) {  // the slot gave up compact position c: fetch c + PD (of the next tile, maybe)
-    int n = c + PD;
-    n = n >= TT ? n - TT : n;
-    int q = phys(n);
-    q = q >= 0 ? q : p1;  // a hole: straight-line code beats a skipped load (a branch in the k-loop costs registers and time)
-    const u32x4* w = stream + (size_t)q * TPW * 64;
+  __device__ __forceinline__ void refill_mid(int c) {  // c + PD lies inside the wide segment
+    const u32x4* w = stream + (size_t)(pl + (c + PD - S1)) * TPW * 64;
 #pragma unroll
-    for (int tp = 0; tp < TPW; ++tp) ring[SLOT][tp] = w[tp * 64];
+    for (int tp = 0; tp < TPW; ++tp) ring[SLOT][tp] = (w + tp * 64)[ln];
   }
-  __device__ __forceinline__ void prime(const u32x4* s, int p1_, int pl_, int p2_) {
-    stream = s, p1 = p1_, pl = pl_, p2 = p2_;
-#pragma unroll
-    for (int p = 0; p < PD; ++p) {
-      const u32x4* w = s + (size_t)phys(p) * TPW * 64;
-#pragma unroll
-      for (int tp = 0; tp < TPW; ++tp) ring[p][tp] = w[tp * 64];
-    }
+  __device__ __forceinline__ void set_aux(const u32x4* a, int stride) { aux = a, aux_stride = stride; }  // before prime()
+  // s: the wave's stream WITHOUT the lane offset (wave-uniform)
+  __device__ __forceinline__ void prime(const u32x4* s, int lane, int p1_, int pl_, int p2_) {
+    stream = s, ln = (unsigned)lane, p1 = p1_, pl = pl_, p2 = p2_;
+    fetch_ct<0, 0>();
+    fetch_ct<1, 1>();
+    fetch_ct<2, 2>();
+    fetch_ct<3, 3>();
   }
-  template <int SLOT>
-  __device__ __forceinline__ void step(f32x4 (&acc)[TPW][MR], const char* src, int rb, int km, int ks, int c, int r, int g) {
+  __device__ __forceinline__ void mult(int SLOTv, f32x4 (&acc)[TPW][MR], const u32x4 (&fr)[TPW], const char* src, int rb, int km, int ks,
+                                       int r, int g) {
+    (void)SLOTv;
     u32x4 xb[MR];
 #pragma unroll
     for (int m = 0; m < MR; ++m) xb[m] = *(const u32x4*)(src + (16 * m + r) * rb + (((ks * 4 + g) ^ (r & km)) << 4));
 #pragma unroll
     for (int tp = 0; tp < TPW; ++tp)
 #pragma unroll
-      for (int m = 0; m < MR; ++m) acc[tp][m] = P::mma(ring[SLOT][tp], xb[m], acc[tp][m]);
-    refill<SLOT>(c);
+      for (int m = 0; m < MR; ++m) acc[tp][m] = P::mma(fr[tp], xb[m], acc[tp][m]);
+  }
+  template <int SLOT, int C>
+  __device__ __forceinline__ void step_ct(f32x4 (&acc)[TPW][MR], const char* src, int rb, int km, int ks, int r, int g) {
+    mult(SLOT, acc, ring[SLOT], src, rb, km, ks, r, g);
+    refill_ct<SLOT, C>();
+  }
+  template <int SLOT>
+  __device__ __forceinline__ void step_mid(f32x4 (&acc)[TPW][MR], const char* src, int rb, int km, int ks, int c, int r, int g) {
+    mult(SLOT, acc, ring[SLOT], src, rb, km, ks, r, g);
+    refill_mid<SLOT>(c);
   }
   // acc += (first short layer) . src^T : k-steps 0 .. S1-1 of src
   __device__ __forceinline__ void short1(f32x4 (&acc)[TPW][MR], const char* src, int rb, int km, int r, int g) {
-    if constexpr (S1 >= 1) step<0>(acc, src, rb, km, 0, 0, r, g);
-    if constexpr (S1 >= 2) step<1>(acc, src, rb, km, 1, 1, r, g);
-    if constexpr (S1 >= 3) step<2>(acc, src, rb, km, 2, 2, r, g);
-    if constexpr (S1 >= 4) step<3>(acc, src, rb, km, 3, 3, r, g);
+    // (a compiler barrier for memory operations between the steps: hoisting every step's B-fragment reads to the top keeps
+    // S1 x MR x 4 registers live beside the accumulators and the ring -- S1 = 2 / 3 spilled 20-26 VGPRs in the wide-head kernels)
+    if constexpr (S1 >= 1) step_ct<0, 0>(acc, src, rb, km, 0, r, g);
+    if constexpr (S1 >= 2) {
+      asm volatile("" ::: "memory");
+      step_ct<1, 1>(acc, src, rb, km, 1, r, g);
+    }
+    if constexpr (S1 >= 3) {
+      asm volatile("" ::: "memory");
+      step_ct<2, 2>(acc, src, rb, km, 2, r, g);
+    }
+    if constexpr (S1 >= 4) {
+      asm volatile("" ::: "memory");
+      step_ct<3, 3>(acc, src, rb, km, 3, r, g);
+    }
   }
   // acc += (H-wide layer) . src^T, with the flag waits of Engine::run (KSH / 8 k-steps per producer wave)
   __device__ __forceinline__ void wide(f32x4 (&acc)[TPW][MR], const char* src, int rb, int km, int r, int g,
@@ -213,7 +262,7 @@ struct CEngine {
         if ((int32_t)(flag_load(flags + i) - need) >= 0) ready |= 1u << i;
       asm volatile("" ::: "memory");
     }
-    for (int k0 = 0; k0 < KSH; k0 += PD) {
+    auto wait_group = [&](int k0) {
       if (ready != 0xffu) {
         const int p_lo = k0 >> kpp_shift, p_hi = (k0 + PD - 1) >> kpp_shift;
         const uint32_t grp = ((2u << p_hi) - 1u) & ~((1u << p_lo) - 1u);
@@ -224,23 +273,54 @@ struct CEngine {
           asm volatile("" ::: "memory");
         }
       }
-      step<(S1 + 0) % PD>(acc, src, rb, km, k0 + 0, S1 + k0 + 0, r, g);
-      step<(S1 + 1) % PD>(acc, src, rb, km, k0 + 1, S1 + k0 + 1, r, g);
-      step<(S1 + 2) % PD>(acc, src, rb, km, k0 + 2, S1 + k0 + 2, r, g);
-      step<(S1 + 3) % PD>(acc, src, rb, km, k0 + 3, S1 + k0 + 3, r, g);
+    };
+    for (int k0 = 0; k0 < KSH - PD; k0 += PD) {  // every refill of these steps stays inside the wide segment
+      wait_group(k0);
+      step_mid<(S1 + 0) % PD>(acc, src, rb, km, k0 + 0, S1 + k0 + 0, r, g);
+      step_mid<(S1 + 1) % PD>(acc, src, rb, km, k0 + 1, S1 + k0 + 1, r, g);
+      step_mid<(S1 + 2) % PD>(acc, src, rb, km, k0 + 2, S1 + k0 + 2, r, g);
+      step_mid<(S1 + 3) % PD>(acc, src, rb, km, k0 + 3, S1 + k0 + 3, r, g);
     }
+    constexpr int KL = KSH - PD;  // the last four: their refills reach the third segment, the holes or the next tile
+    wait_group(KL);
+    step_ct<(S1 + 0) % PD, S1 + KL + 0>(acc, src, rb, km, KL + 0, r, g);
+    step_ct<(S1 + 1) % PD, S1 + KL + 1>(acc, src, rb, km, KL + 1, r, g);
+    step_ct<(S1 + 2) % PD, S1 + KL + 2>(acc, src, rb, km, KL + 2, r, g);
+    step_ct<(S1 + 3) % PD, S1 + KL + 3>(acc, src, rb, km, KL + 3, r, g);
   }
   // acc += (last short layer) . src^T : k-steps 0 .. S2-1 of src
   __device__ __forceinline__ void short2(f32x4 (&acc)[TPW][MR], const char* src, int rb, int km, int r, int g) {
-    if constexpr (S2 >= 1) step<(S1 + 0) % PD>(acc, src, rb, km, 0, S1 + KSH + 0, r, g);
-    if constexpr (S2 >= 2) step<(S1 + 1) % PD>(acc, src, rb, km, 1, S1 + KSH + 1, r, g);
-    if constexpr (S2 >= 3) step<(S1 + 2) % PD>(acc, src, rb, km, 2, S1 + KSH + 2, r, g);
-    if constexpr (S2 >= 4) step<(S1 + 3) % PD>(acc, src, rb, km, 3, S1 + KSH + 3, r, g);
+    if constexpr (S2 >= 1) step_ct<(S1 + 0) % PD, S1 + KSH + 0>(acc, src, rb, km, 0, r, g);
+    if constexpr (S2 >= 2) step_ct<(S1 + 1) % PD, S1 + KSH + 1>(acc, src, rb, km, 1, r, g);
+    if constexpr (S2 >= 3) step_ct<(S1 + 2) % PD, S1 + KSH + 2>(acc, src, rb, km, 2, r, g);
+    if constexpr (S2 >= 4) step_ct<(S1 + 3) % PD, S1 + KSH + 3>(acc, src, rb, km, 3, r, g);
+  }
+  // AUX third segment, position j: o[m] += (fragment tp of the position) . (k-step ks0 + j TPW + tp of src)^T -- one out tile,
+  // TPW consecutive k-steps of this wave's K slice per position
+  template <int J>
+  __device__ __forceinline__ void aux_step(f32x4 (&o)[MR], const char* src, int rb, int km, int ks0, int r, int g) {
+    constexpr int SLOT = (S1 + J) % PD;
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) {
+      const int ks = ks0 + J * TPW + tp;
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        const u32x4 xb = *(const u32x4*)(src + (16 * m + r) * rb + (((ks * 4 + g) ^ (r & km)) << 4));
+        o[m] = P::mma(ring[SLOT][tp], xb, o[m]);
+      }
+    }
+    refill_ct<SLOT, S1 + KSH + J>();
+  }
+  __device__ __forceinline__ void aux_all(f32x4 (&o)[MR], const char* src, int rb, int km, int ks0, int r, int g) {
+    if constexpr (S2 >= 1) aux_step<0>(o, src, rb, km, ks0, r, g);
+    if constexpr (S2 >= 2) aux_step<1>(o, src, rb, km, ks0, r, g);
+    if constexpr (S2 >= 3) aux_step<2>(o, src, rb, km, ks0, r, g);
+    if constexpr (S2 >= 4) aux_step<3>(o, src, rb, km, ks0, r, g);
   }
   __device__ __forceinline__ void end_tile() {  // the holes' slots take the next tile's positions
-    if constexpr (HOLES >= 1) refill<(T + 0) % PD>(T + 0);
-    if constexpr (HOLES >= 2) refill<(T + 1) % PD>(T + 1);
-    if constexpr (HOLES >= 3) refill<(T + 2) % PD>(T + 2);
+    if constexpr (HOLES >= 1) refill_ct<(T + 0) % PD, T + 0>();
+    if constexpr (HOLES >= 2) refill_ct<(T + 1) % PD, T + 1>();
+    if constexpr (HOLES >= 3) refill_ct<(T + 2) % PD, T + 2>();
   }
 };
 
@@ -616,39 +696,56 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
   constexpr int PD = ring_depth<TPW, MR>(), ES = P::ESIZE, KB = P::KB;
   static_assert(S1 == 0 || PD == 4, "the compact walk is written for a ring of four positions");
   constexpr int H = 128 * TPW, KSH = H / KB, HRB = H * ES, MT = 16 * MR;
-  constexpr int KSPLIT = MR * OT >= 8 ? 1 : 8 / (MR * OT);
+  // WIDE (more than one out tile, OT = 4: heads of 17-64 outputs): the Wout W2 fragments (KSH x OT KB) do not fit LDS beside
+  // the two images, so they ride the weight ring instead: wave w owns out tile w % OT and K slice w / OT of the second pass
+  // for ALL row sub-tiles, and its KPER fragments are the ring's third segment (CEngine AUX: KPER / TPW positions per tile,
+  // +12 % of the tile's stream at H = 512 where the general forward streams a whole second H x H layer)
+  constexpr bool WIDE = OT > 1;
+  constexpr int KSPLIT = WIDE ? SAMPLER_WAVES / OT : (MR * OT >= 8 ? 1 : 8 / (MR * OT));
   constexpr int KPER = KSH / KSPLIT, NITEMS = MR * OT * KSPLIT, NI = (NITEMS + SAMPLER_WAVES - 1) / SAMPLER_WAVES;
+  constexpr int S2 = WIDE ? KPER / TPW : 0;   // ring positions of a wave's K slice
+  constexpr int MPW = WIDE ? MR / KSPLIT : 1;  // row sub-tiles per wave in the FIRST pass (K = in_dim: no K split there)
+  static_assert(!WIDE || (S1 > 0 && SAMPLER_WAVES % OT == 0 && KPER % TPW == 0 && S2 >= 1 && S2 <= 4 && MR % KSPLIT == 0),
+                "wide merged head: layout");
   constexpr bool FLAGS = DPPO_FLAGS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int Kp0 = a.Kp0, M = a.M, ks0v = a.ks0v;
-  const int in_rb = Kp0 * ES, in_km = kmask16(in_rb), KS0 = Kp0 / KB;
+  // (WIDE: the input tile keeps only its ks0v k-steps that hold data, 64 bytes each, and lives beside the images -- see xin)
+  const int in_rb = WIDE ? ks0v * 64 : Kp0 * ES, in_km = kmask16(in_rb), KS0 = Kp0 / KB;
   const int total = KS0 + 2 * KSH;  // the stream as packed (W2 last); the ring walks total - KSH positions
   char* bufA = smem;
   char* bufB = bufA + MT * HRB;
-  char* xin = bufB;             // the input tile is dead once layer 0 and the out layer's first pass have run
   float* part = (float*)bufA;   // out-layer partials: the K = H pass reads buffer B
-  static_assert(KSPLIT * OT * 16 * 16 * 4 <= 16 * HRB, "out-layer partials must fit in buffer A");
+  static_assert(KSPLIT * MR * OT * 16 * 16 * 4 <= MT * HRB, "out-layer partials must fit in buffer A");
   lds_u32* flags = (lds_u32*)(bufB + MT * HRB);              // [16 words]
   float* biasL = (float*)(bufB + MT * HRB + 64);                       // [2][H] b0, b1, then [OT*16] the out constant
-  u32x4* woutL = (u32x4*)(biasL + ((2 * H + OT * 16 + 3) & ~3));       // [KSH][OT][64] fragments of Wout W2
-  u32x4* w0cL = woutL + KSH * OT * 64;                                 // [ks0v][OT][64] fragments of Wout W0
+  u32x4* woutL = (u32x4*)(biasL + ((2 * H + OT * 16 + 3) & ~3));       // [KSH][OT][64] fragments of Wout W2 (not WIDE)
+  u32x4* w0cL = woutL + (WIDE ? 0 : KSH * OT * 64);                    // [ks0v][OT][64] fragments of Wout W0
+  // the input tile: aliased with buffer B (dead once layer 0 and the out layer's first pass have run) -- except WIDE, where
+  // the first pass runs late, in the second pass's phase (a partial result carried through the H-wide k-loop is 8-16 more
+  // live registers in a kernel that has none to spare: 24-56 spilled), so the tile gets its own [MT][ks0v * 64 B] region
+  char* xin = WIDE ? (char*)(w0cL + ks0v * OT * 64) : bufB;
   const int wbase = wid * 16 * TPW;
+  const int to_w = wid % OT, kh_w = wid / OT;  // WIDE: this wave's out tile and K slice
   for (int idx = tid; idx < 2 * H; idx += 512) biasL[idx] = a.params[a.bias_off[idx / H] + idx % H];
   for (int idx = tid; idx < OT * 16; idx += 512) biasL[2 * H + idx] = idx < a.out_dim ? a.cbias2[idx] : 0.f;
-  for (int idx = tid; idx < KSH * OT * 64; idx += 512) woutL[idx] = a.ostream2[idx];
+  if constexpr (!WIDE)
+    for (int idx = tid; idx < KSH * OT * 64; idx += 512) woutL[idx] = a.ostream2[idx];
   for (int idx = tid; idx < ks0v * OT * 64; idx += 512) w0cL[idx] = a.ostream0[idx];
   if (tid < 16) flags[tid] = 0;
   uint32_t seq = 0;
   // (visible after the first tile's barrier)
 
-  typename std::conditional<(S1 > 0), CEngine<P, TPW, MR, (S1 > 0 ? S1 : 1), KSH, 0>, Engine<P, TPW, MR, PD>>::type eng;
-  if constexpr (S1 > 0)
-    eng.prime(a.wstream + (size_t)wid * total * TPW * 64 + lane, 0, KS0, 0);
-  else
+  typename std::conditional<(S1 > 0), CEngine<P, TPW, MR, (S1 > 0 ? S1 : 1), KSH, S2, WIDE>, Engine<P, TPW, MR, PD>>::type eng;
+  if constexpr (S1 > 0) {
+    if constexpr (WIDE) eng.set_aux(a.ostream2 + ((size_t)(kh_w * KPER) * OT + to_w) * 64, OT * 64);
+    eng.prime(a.wstream + (size_t)wid * total * TPW * 64, lane, 0, KS0, 0);
+  } else {
     eng.prime(a.wstream + (size_t)wid * total * TPW * 64 + lane, total - KSH);
+  }
 
   const int ntiles = (M + MT - 1) / MT;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -674,16 +771,18 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
     else
       eng.run(acc, xin, in_rb, in_km, KS0, r, g);
     STAMP(2);
-    f32x4 o1[NI];
+    f32x4 o1[WIDE ? 1 : NI];
+    if constexpr (!WIDE) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int it = wid + SAMPLER_WAVES * i;
-      o1[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (it < MR * OT) {  // kh == 0
-        const int m = it % MR, to = it / MR;
-        for (int ks = 0; ks < ks0v; ++ks) {
-          const u32x4 xb = *(const u32x4*)(xin + (16 * m + r) * in_rb + (((ks * 4 + g) ^ (r & in_km)) << 4));
-          o1[i] = P::mma(w0cL[(ks * OT + to) * 64 + lane], xb, o1[i]);
+      for (int i = 0; i < NI; ++i) {
+        const int it = wid + SAMPLER_WAVES * i;
+        o1[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (it < MR * OT) {  // kh == 0
+          const int m = it % MR, to = it / MR;
+          for (int ks = 0; ks < ks0v; ++ks) {
+            const u32x4 xb = *(const u32x4*)(xin + (16 * m + r) * in_rb + (((ks * 4 + g) ^ (r & in_km)) << 4));
+            o1[i] = P::mma(w0cL[(ks * OT + to) * 64 + lane], xb, o1[i]);
+          }
         }
       }
     }
@@ -698,7 +797,7 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
     bias_init(1);
     if constexpr (S1 > 0) {
       eng.wide(acc, bufA, HRB, 15, r, g, FLAGS ? flags : nullptr, seq);
-      eng.end_tile();
+      if constexpr (!WIDE) eng.end_tile();  // (WIDE: the third segment comes first, below)
     } else {
       eng.run(acc, bufA, HRB, 15, KSH, r, g, FLAGS ? flags : nullptr, seq);
     }
@@ -710,6 +809,29 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
     // ---- out layer, second pass: (Wout W2) on act(z1)
     int r_ = r, g_ = g, lane_ = lane;
     asm volatile("" : "+v"(r_), "+v"(g_), "+v"(lane_));  // (see fused_forward_kernel: addresses recomputed, not spilled)
+    if constexpr (WIDE) {
+      f32x4 ow[MR];
+#pragma unroll
+      for (int m = 0; m < MR; ++m) ow[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // first pass, (Wout W0) x: wave (to, kh) takes row sub-tiles kh MPW .. kh MPW + MPW - 1 of its out tile (K = in_dim is not split)
+      for (int ks = 0; ks < ks0v; ++ks) {
+        const u32x4 wf = w0cL[(ks * OT + to_w) * 64 + lane_];
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+          if (m / MPW == kh_w) {
+            const u32x4 xb = *(const u32x4*)(xin + (16 * m + r_) * in_rb + (((ks * 4 + g_) ^ (r_ & in_km)) << 4));
+            ow[m] = P::mma(wf, xb, ow[m]);
+          }
+      }
+      if constexpr (S1 > 0) {
+        eng.aux_all(ow, bufB, HRB, 15, kh_w * KPER, r_, g_);
+        eng.end_tile();
+      }
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[(((kh_w * MR + m) * OT + to_w) * 16 + 4 * g_ + e) * 16 + r_] = ow[m][e];
+    } else
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int it = wid + SAMPLER_WAVES * i;
@@ -995,7 +1117,7 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
 
   typename std::conditional<COMPACT, CEngine<P, TPW, MR, 1, KSH, 1>, Engine<P, TPW, MR, PD>>::type eng;
   if constexpr (COMPACT)
-    eng.prime(a.bstream + (size_t)wid * total * TPW * 64 + lane, KSB0, 2 * KSB0, 0);
+    eng.prime(a.bstream + (size_t)wid * total * TPW * 64, lane, KSB0, 2 * KSB0, 0);
   else
     eng.prime(a.bstream + (size_t)wid * total * TPW * 64 + lane, total, KSB0);
   if (tid < 16) flags[tid] = 0;  // (visible after the first tile's barrier)
@@ -1208,38 +1330,54 @@ static int launch_fwd_cfg(const FusedFwdArgs& a, hipStream_t s) {
 template <class P>
 static size_t merged_lds(int hidden, int out_tiles, int ks0v) {
   const int mr = pick_mr<P>(hidden);
+  // (a wide head's Wout W2 fragments ride the weight ring instead of LDS)
   return 2 * (size_t)16 * mr * hidden * P::ESIZE + 64 + (((size_t)2 * hidden + out_tiles * 16 + 3) & ~(size_t)3) * 4 +
-         ((size_t)(hidden / P::KB) + ks0v) * out_tiles * 64 * 16;
+         ((size_t)(out_tiles > 1 ? 0 : hidden / P::KB) + ks0v) * out_tiles * 64 * 16 +
+         (out_tiles > 1 ? (size_t)16 * mr * ks0v * 64 : 0);  // ... and its input tile has a region of its own
 }
 static int g_merge_fwd = 1;  // tuning knob 22: the fused forward of one-block networks merges the block's second layer into the out layer
-void set_fused_merge_fwd(int v) { g_merge_fwd = v; }
+static int g_merge_wide = 1;  // ... bit 1 of the knob's value switches the 17-64-output form off alone (22 = 1: both on, 3: narrow heads only)
+void set_fused_merge_fwd(int v) { g_merge_fwd = v & 1, g_merge_wide = (v & 2) ? 0 : 1; }
+int fused_compact_on();
+static int round_up_i(int x, int m) { return (x + m - 1) / m * m; }
 template <class P>
 bool fused_can_merge(const dppo_net_desc& d) {
   if (!g_merge_fwd || d.plain || d.use_layernorm || d.n_blocks != 1 || d.hidden % 128 || pick_mr<P>(d.hidden) == 0) return false;
-  if (d.out_dim > 16) return false;  // one out tile: wider heads do not fit their two fragment sets beside the images
   const int ks0v = (d.in_dim + P::KB - 1) / P::KB;
+  if (d.out_dim > 16) {  // 17-64 outputs (out-stream geometry OT = 4): hidden 512, compact walk of the input layer
+    constexpr int PD = 4;
+    return g_merge_wide && fused_compact_on() && d.out_dim <= 64 && d.hidden == 512 && ks0v >= 1 && ks0v <= 3 &&
+           round_up_i(d.in_dim, PD * P::KB) / P::KB >= ks0v && merged_lds<P>(d.hidden, 4, ks0v) <= 160 * 1024;
+  }
   return d.hidden <= 512 && merged_lds<P>(d.hidden, 1, ks0v) <= 160 * 1024;
 }
 template bool fused_can_merge<F32>(const dppo_net_desc&);
 template bool fused_can_merge<BF16>(const dppo_net_desc&);
 
-template <class P, int TPW, int MR, int ACT, int S1>
+template <class P, int TPW, int MR, int ACT, int S1, int OT = 1>
 static int launch_fwd_merged_cfg2(const FusedFwdArgs& a, hipStream_t s) {
   constexpr int MT = 16 * MR, H = 128 * TPW;
-  const size_t lds = merged_lds<P>(H, 1, a.ks0v);
+  const size_t lds = merged_lds<P>(H, OT, a.ks0v);
   if (lds > 160 * 1024 || a.Kp0 > H || a.nb != 1) return -2;
   static DevLatch attr;
-  raise_lds(fused_forward_merged_kernel<P, TPW, MR, 1, ACT, S1>, attr);
+  raise_lds(fused_forward_merged_kernel<P, TPW, MR, OT, ACT, S1>, attr);
   const int ntiles = (a.M + MT - 1) / MT;
   const bool probe = probe_begin(PROBE_FUSED_FWD, s);
-  hipLaunchKernelGGL((fused_forward_merged_kernel<P, TPW, MR, 1, ACT, S1>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512),
+  hipLaunchKernelGGL((fused_forward_merged_kernel<P, TPW, MR, OT, ACT, S1>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512),
                      lds, s, a);
   if (probe) probe_end(s, 2.0 * a.M * ((double)a.in_valid * H + 2.0 * a.nb * H * H + (double)H * a.out_dim));
   return 0;
 }
-int fused_compact_on();
 template <class P, int TPW, int MR, int ACT>
 static int launch_fwd_merged_cfg(const FusedFwdArgs& a, hipStream_t s) {
+  if (a.out_dim > 16) {  // the wide head (fused_can_merge admitted it: hidden 512, compact walk, ks0v <= 3)
+    if constexpr (TPW == 4) {
+      if (a.ks0v == 1) return launch_fwd_merged_cfg2<P, TPW, MR, ACT, 1, 4>(a, s);
+      if (a.ks0v == 2) return launch_fwd_merged_cfg2<P, TPW, MR, ACT, 2, 4>(a, s);
+      if (a.ks0v == 3) return launch_fwd_merged_cfg2<P, TPW, MR, ACT, 3, 4>(a, s);
+    }
+    return -1;
+  }
   if constexpr (ring_depth<TPW, MR>() == 4) {
     if (fused_compact_on() && a.ks0v == 1) return launch_fwd_merged_cfg2<P, TPW, MR, ACT, 1>(a, s);
     if (fused_compact_on() && a.ks0v == 2) return launch_fwd_merged_cfg2<P, TPW, MR, ACT, 2>(a, s);

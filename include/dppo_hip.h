@@ -470,9 +470,10 @@ int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* 
  *          (default 1)
  * knob 18: what follows the slab reduction of the actor's backward (low-rank dW2, time-embedding gradient) in one launch
  *          (default 1)
- * knob 22: fused forward of one-block networks (no LayerNorm, out_dim <= 16, hidden <= 512) never runs the block's second
- *          layer: out = (Wout W0) x + (Wout W2) act(z1) + const, and the out-layer weight gradient is rebuilt from
- *          d_out^T x and d_out^T act(z1) (default 1)
+ * knob 22: fused forward of one-block networks (no LayerNorm; out_dim <= 16 at hidden <= 512, or 17-64 outputs at hidden 512
+ *          with in_dim <= 96 for bf16 / 48 for fp32, where the Wout W2 fragments ride the weight ring) never runs the
+ *          block's second layer: out = (Wout W0) x + (Wout W2) act(z1) + const, and the out-layer weight gradient is
+ *          rebuilt from d_out^T x and d_out^T act(z1).  1 (default): on; 0: off; 3: heads of up to 16 outputs only
  * knob 23: fused backward of one-block networks (no LayerNorm, hidden <= 512, low-rank dW2 on): dh_1 = d_out . Wout is added
  *          last, into the W1^T layer's accumulators, instead of carried in registers; forward-sized tiles (default 1)
  * knob 25: the one-block kernels walk their short layers (K = in_dim on the input tile, K = out_dim on the d_out tile)
@@ -481,6 +482,8 @@ int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* 
  * knob 27: sampler, small env batches of one-block bf16 networks at hidden 512: one 16-row tile over eight workgroups with
  *          the weights resident in registers (default 1; see dppo_sample_chain_workspace_bytes) or over one (0)
  * knob 28: knob 27's kernel: 64-cycle sleep periods between a workgroup's exchange store and its first sweep (default 4)
+ * knob 30: minibatch rows per output column from which the top block's weight gradient is taken low-rank (knob 16) and the
+ *          one-block backward (knob 23) runs: M >= value x out_dim (default 100)
  * knob 29: knob 27's kernel: sweeps a workgroup waits for its tile before it gives up (default 2^20; tests force a time-out
  *          with 1; <= 0 restores the default) */
 int dppo_tune_set(int knob, int value);

@@ -594,12 +594,13 @@ def test_fused_path_matches_layered_path(prec, tol, sname):
 
 
 @pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
-@pytest.mark.parametrize("sname,knob", [("hopper", 22), ("can", 22), ("hopper", 23), ("can", 23), ("square_like", 23),
-                                        ("hopper", 25), ("halfcheetah", 25)])
+@pytest.mark.parametrize("sname,knob", [("hopper", 22), ("can", 22), ("halfcheetah", 22), ("can_relu", 22), ("hopper", 23),
+                                        ("can", 23), ("square_like", 23), ("hopper", 25), ("halfcheetah", 25)])
 def test_one_block_kernels_match_the_general_ones(prec, tol, sname, knob):
     """One-block networks have their own fused kernels.  Knob 22: the forward folds the block's second layer into the out
-    layer and the out-layer weight gradient is rebuilt from d_out^T x and d_out^T act(z1) (hopper: actor and critic in
-    bf16, the critic in fp32; can: the critic).  Knob 23: the backward adds dh_1 = d_out . Wout last instead of carrying it,
+    layer and the out-layer weight gradient is rebuilt from d_out^T x and d_out^T act(z1) (hopper: actor and critic; halfcheetah
+    (24 outputs, ReLU), can (BASELINE configs[2]: 56 outputs, Mish, three input k-steps) and can_relu: the wide-head form, whose
+    Wout W2 fragments ride the weight ring, and the critic).  Knob 23: the backward adds dh_1 = d_out . Wout last instead of carrying it,
     in forward-sized tiles, and the second layer's bias gradient comes from colsum(d_out) . Wout (every one-block network
     once the minibatch is large enough for the low-rank dW2).  Knob 25: both walk their short layers without the weight
     stream's padding k-steps (bit-identical arithmetic: the skipped k-steps multiply zeros).  Same log-probs, values, loss
