@@ -379,6 +379,16 @@ struct MlpBufs {  // activations of one network for M rows
   size_t slab_used;   // floats handed out since the last flush
   SlabJobs slab_jobs; // reductions pending on the pool (flush_slabs)
   GemmTNGroup tn_group;  // weight-gradient GEMMs pending on the pool: launched together by flush_slabs
+  // K-major fragment mode (gemm.h GemmTNFrag; frag_ok()): the four tensors only the weight-gradient GEMMs read are written
+  // as MFMA operand fragments by the one-block fused kernels -- into the SAME buffers a1[0], a2[0], dz1_all[0], dh_all[0]
+  // (carved with rows rounded up to whole tiles) -- and the two small operands get fragment copies
+  bool allow_frag;  // set by the caller between carve and forward: the whole pass (forward, backward, GEMMs) may run in it
+  bool frag;        // decided by the forward (allow_frag && merged), obeyed by the backward
+  u32x4* doutf;     // [ks][dof_nt][64]
+  u32x4* xf;        // [ks][Kp0 / 16][64]
+  int dof_nt;
+  int64_t mpad;     // rows rounded up to the fused kernels' tile height
+  GemmTNFragGroup tnf_group;
   // side streams to join into the flushing stream right behind the GEMM launch: the barrier packets (~10 us each even when
   // the event fired long ago) are then processed while the GEMMs run instead of at the end of the call
   hipStream_t join_s[2];
@@ -412,12 +422,13 @@ static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, b
   float* hbuf[MAX_BLOCKS + 1];
   for (int i = 0; i < nh; ++i) hbuf[i] = (float*)c.take((size_t)M * H * 4);
   for (int b = 0; b <= nb; ++b) B.h[b] = keep ? hbuf[b] : hbuf[b & 1];
+  const size_t Mp = (size_t)round_up((int)M, 128);  // (fragment mode writes whole tiles of up to 128 rows)
   void* a1s = nullptr;
   void* a2s = nullptr;
   for (int b = 0; b < nb; ++b) {
     if (keep || b == 0) {
-      a1s = c.take((size_t)M * H * ES);
-      a2s = c.take((size_t)M * H * ES);
+      a1s = c.take(Mp * H * ES);
+      a2s = c.take(Mp * H * ES);
     }
     B.a1[b] = a1s;
     B.a2[b] = a2s;
@@ -441,12 +452,14 @@ static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, b
   if (bwd) {
     B.d_out = c.take((size_t)M * Kpo * ES);
     B.dh = c.take((size_t)M * H * ES);
-    B.dz1 = c.take((size_t)M * H * ES);
+    B.dz1 = c.take(Mp * H * ES);
     B.dh_all[nb] = B.dh;
     for (int b = 0; b < nb; ++b) {
-      B.dh_all[b] = c.take((size_t)M * H * ES);
+      B.dh_all[b] = c.take(Mp * H * ES);
       B.dz1_all[b] = b == 0 ? B.dz1 : c.take((size_t)M * H * ES);
     }
+    B.doutf = (u32x4*)c.take(Mp * 64 * 2);  // up to four feature tiles of d_out
+    B.xf = (u32x4*)c.take(Mp * Kp0 * 2);
     const int mt = d.plain || d.out_dim > 128 ? 0 : fused_rows_per_tile<P>(d, bwd_one<P>(d, M));
     B.tiles = mt > 0 ? (int)((M + mt - 1) / mt) : 0;
     B.tile_colsum = (float*)c.take((size_t)(2 * nb + 2 + (d.use_layernorm ? 4 * nb : 0)) * (B.tiles > 0 ? B.tiles : 1) * H * 4);
@@ -529,6 +542,12 @@ static void mlp_forward(const dppo_net_desc& d, const float* prm, const char* pk
       f.merge_top = 1, f.ks0v = (d.in_dim + P::KB - 1) / P::KB, f.hpre[nb] = nullptr;
       f.ostream0 = (const u32x4*)(pk + L.ostream0), f.ostream2 = (const u32x4*)(pk + L.ostream2);
       f.cbias2 = (const float*)(pk + L.cbias2);
+    }
+    B.frag = keep && B.allow_frag && B.merged;
+    if (B.frag) {  // act(h_0), act(z1) as K-major fragments, in place of the row-major tensors (frag_ok())
+      const int mt = fused_rows_per_tile<P>(d, true);
+      B.mpad = (M + mt - 1) / mt * mt;
+      f.a1f = (u32x4*)B.a1[0], f.a2f = (u32x4*)B.a2[0];
     }
     g_fused_fault = launch_fused_forward<P>(d, f, s);
     return;
@@ -655,6 +674,11 @@ static int g_lowrank_ratio = 100;
 static bool lowrank_top(const dppo_net_desc& d, int64_t M) {
   return g_lowrank_top && d.n_blocks >= 1 && M >= (int64_t)g_lowrank_ratio * d.out_dim;
 }
+// tuning knob 31: K-major fragment operands for the weight-gradient GEMMs of one-block bf16 networks.  OFF by default: parity
+// green (tests/test_hip_parity.py, knob 31 cases) but not faster yet -- 114-118 us for the step's two launches against 107 with
+// the transposing kernel (DESIGN.md section 13 has the knock-out measurements: 43 us skeleton + 52 us HBM stream + 23 us ring,
+// adding up instead of overlapping)
+static int g_frag = 0;
 // Time-embedding gradient through the first layer's weight-gradient GEMM: with a one-hot of the row's denoising step k in
 // the K padding of the input rows, dW0's extra columns are S[h][k] = sum over the rows of step k of dh0[row][h], and
 // d loss / d temb[k] = W0[:, temb columns]^T S[:, k] -- no second pass over dh0, no segmented reduction (tuning knob 11).
@@ -665,6 +689,21 @@ static int temb_onehot_col(const dppo_net_desc& d, const PackLayout& L, int Kft,
   if (d.cond_out > 0 && d.cond_out % 16) return -1;  // the encoder's epilogue zero-fills up to a multiple of 16 columns
   if (L.Kp0 - d.in_dim < Kft || (size_t)(d.hidden + d.time_dim) * Kft > B.part_floats) return -1;
   return d.in_dim;
+}
+// May this network's whole training pass run in fragment mode?  Everything the forward, the backward and the GEMM group
+// will decide later must already hold: merged forward, one-block backward (hence the low-rank dW2), grouped GEMM launch, the
+// time-embedding gradient through the one-hot columns (the row-major dh_0 has no other reader then), no cond_mlp encoder
+// (its backward reads dh_0 row-major), the caller wants no d loss / d observation, and the backward's LDS holds the extras.
+template <class P>
+static bool frag_ok(const dppo_net_desc& d, int64_t M, const PackLayout& L, int Kft, const MlpBufs<P>& B, bool wants_dobs) {
+  if (!g_frag || P::ESIZE != 2 || wants_dobs || d.cond_hidden > 0 || d.out_dim > 64 || !g_tn_group) return false;
+  if (!fused_ok<P>(d) || B.tiles <= 0 || !fused_can_merge<P>(d) || !bwd_one<P>(d, M)) return false;
+  if (d.kind == 0 && temb_onehot_col<P>(d, L, Kft, B) < 0) return false;
+  const int mt = fused_rows_per_tile<P>(d, true);
+  const FusedGeom fg = fused_geom<P>(d);
+  if (L.Kp0 % 16 || L.Kp0 > 128) return false;
+  return (size_t)mt * ((size_t)fg.KpB0 * 2 + (size_t)L.Kp0 * 2) + (size_t)SAMPLER_WAVES * 32 * 32 * (d.hidden / 128) <=
+         (size_t)mt * d.hidden * 2;
 }
 template <class P>
 static void flush_slabs(MlpBufs<P>& B, hipStream_t s, const SlotOuts* slots = nullptr, int slot_width = 0,
@@ -682,6 +721,18 @@ static void flush_slabs(MlpBufs<P>& B, hipStream_t s, const SlotOuts* slots = nu
     for (int i = 0; i < gr.n; ++i)
       gr.base[i + 1] = gr.base[i] + gr.j[i].splits * ((gr.j[i].N1 + 127) / 128) * ((gr.j[i].N2 + 127) / 128);
     launch_gemm_tn_group<P>(gr, s);
+    gr.n = 0;
+  }
+  if (B.tnf_group.n > 0) {  // fragment-operand jobs (weight_grad_frag): same order rule, same single launch
+    GemmTNFragGroup& gr = B.tnf_group;
+    for (int i = 1; i < gr.n; ++i)
+      for (int k = i; k > 0 && (int64_t)gr.j[k].ks_per_split * gr.j[k].tb > (int64_t)gr.j[k - 1].ks_per_split * gr.j[k - 1].tb; --k) {
+        const GemmTNFrag t = gr.j[k];
+        gr.j[k] = gr.j[k - 1], gr.j[k - 1] = t;
+      }
+    gr.base[0] = 0;
+    for (int i = 0; i < gr.n; ++i) gr.base[i + 1] = gr.base[i] + gemm_tn_frag_blocks(gr.j[i]);
+    launch_gemm_tn_frag_group(gr, B.mpad, s);
     gr.n = 0;
   }
   for (int i = 0; i < B.n_join; ++i) join_side(s, B.join_s[i], B.join_idx[i]);
@@ -750,6 +801,54 @@ static void weight_grad(const void* A, int lda, int N1, const void* Bm, int ldb,
     j2.out = gw2, j2.ldo = ldgw2, j2.c0 = n2a, j2.cols = N2 - n2a;
   }
   if (!defer) flush_slabs(B, s);  // deferred: the caller flushes once after its last GEMM (same stream)
+}
+
+// The same contraction from K-major fragment operands (gemm.h, GemmTNFrag): gw[N1][N2] = FA^T . FB over the batch rows,
+// FA / FB with nta / ntb feature tiles per k-step; always deferred to the caller's flush.  transpose: gw receives the
+// transposed result (the thin side of a thin product is passed as B, the wide one as A: a wave's tile is 64 x 16 tb).
+template <class P>
+static void weight_grad_frag(const u32x4* FA, int nta, int N1, const u32x4* FB, int ntb, int N2, MlpBufs<P>& B, float* gw,
+                             int ldgw, hipStream_t s, bool transpose = false, int n2a = -1, float* gw2 = nullptr,
+                             int ldgw2 = 0) {
+  GemmTNFrag t;
+  memset(&t, 0, sizeof(t));
+  t.A = FA, t.B = FB, t.nta = nta, t.ntb = ntb, t.N1 = N1, t.N2 = N2;
+  if (!gemm_tn_frag_prepare(t)) {  // (frag_ok() admits only shapes the kernel covers: H <= 512, Kp0 <= 128)
+    g_fused_fault = -6;
+    return;
+  }
+  const int nba = (N1 + 63) / 64, nbb = (N2 + 16 * t.tb - 1) / (16 * t.tb);
+  const int64_t wg_tiles = (int64_t)((nba + t.wga - 1) / t.wga) * ((nbb + t.wgb - 1) / t.wgb);
+  t.ks_total = (int)(B.mpad / 32);
+  // workgroups a job aims for: the chip's CUs for the H x H class, half that for the thin ones (their waves carry a
+  // quarter of the MFMAs per k-step and each split costs a slab)
+  const int64_t target = (int64_t)N1 * N2 >= 128 * 128 ? g_tn_target : g_tn_target / 2;
+  int64_t splits = (target + wg_tiles - 1) / wg_tiles;
+  const int64_t max_splits = t.ks_total >= 2 ? t.ks_total / 2 : 1;
+  if (splits > max_splits) splits = max_splits;
+  if (splits > g_tn_max_splits) splits = g_tn_max_splits;
+  if (splits < 1) splits = 1;
+  if ((size_t)splits * N1 * N2 > B.slab_floats - B.slab_used || B.slab_jobs.n + 2 > MAX_SLAB_JOBS ||
+      B.tnf_group.n >= MAX_TN_JOBS)
+    flush_slabs(B, s);
+  while (splits > 1 && (size_t)splits * N1 * N2 > B.slab_floats) --splits;
+  if (splits >= 8) splits = splits / 8 * 8;  // a multiple of the XCD count keeps one split's tiles on one XCD
+  int64_t kps = (t.ks_total + splits - 1) / splits;
+  const int64_t need = (t.ks_total + kps - 1) / kps;
+  if (need < splits) splits = need >= 8 ? (need + 7) / 8 * 8 : need;  // surplus splits see no k-steps and store zeros
+  float* sub = B.slab + B.slab_used;
+  B.slab_used += (size_t)splits * N1 * N2;
+  t.slab = sub, t.ldc = N2, t.splits = (int)splits, t.ks_per_split = (int)kps;
+  B.tnf_group.j[B.tnf_group.n++] = t;
+  SlabJob& j = B.slab_jobs.j[B.slab_jobs.n++];
+  j.slab = sub, j.out = gw, j.splits = (int)splits, j.rows = N1, j.cols = N2, j.lds = N2, j.ldo = ldgw, j.transpose = transpose ? 1 : 0;
+  j.c0 = 0;
+  if (n2a >= 0 && !transpose) {
+    j.cols = n2a;
+    SlabJob& j2 = B.slab_jobs.j[B.slab_jobs.n++];
+    j2 = j;
+    j2.out = gw2, j2.ldo = ldgw2, j2.c0 = n2a, j2.cols = N2 - n2a;
+  }
 }
 
 // d temb = dh0 . W0[:, temb columns]; summed per fine-tuned step; back through the tiny time MLP
@@ -830,6 +929,16 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       for (int b = 0; b <= nb; ++b) f.dh[b] = nullptr, f.dz1[b < nb ? b : 0] = nullptr;
     if (g_dbg & 2)  // timing experiment: no derivative-source fetch
       for (int b = 0; b < nb; ++b) f.m1[b] = f.m0[b] = nullptr;
+    const bool frag = B.frag;
+    if (frag) {  // (frag_ok() held when the forward ran: one-block kernel, one-hot time columns, ...)
+      if (!one || !B.merged || !lowrank) {
+        g_fused_fault = -5;
+        return;
+      }
+      B.dof_nt = d.out_dim <= 16 ? 1 : (d.out_dim <= 32 ? 2 : 4);
+      f.dz1f = (u32x4*)B.dz1_all[0], f.dh0f = (u32x4*)B.dh_all[0], f.doutf = B.doutf, f.dof_nt = B.dof_nt;
+      f.x = B.in, f.ld_x = L.Kp0, f.xf = B.xf;
+    }
     g_fused_fault = launch_fused_backward<P>(d, f, s);
     if (g_fused_fault != 0) return;
     {
@@ -863,6 +972,19 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       // merged top (the forward never formed h_nb): dWout = d_out^T . h_nb is rebuilt behind the slab reduce from
       // U = d_out^T . x and T = d_out^T . act(z1) (PostReduce::U); T is then needed whether or not dW2 uses it
       const bool merged = B.merged;
+      if (frag) {  // the same four products from fragment operands (one block, merged, low-rank: see frag_ok())
+        const int ntx = L.Kp0 / 16, nth = H / 16;
+        // U^T = x^T . d_out  [in_dim][out_dim] -> lowrank_u [out_dim][Kp0]
+        weight_grad_frag<P>(B.xf, ntx, d.in_dim, B.doutf, B.dof_nt, d.out_dim, B, B.lowrank_u, L.Kp0, s, true);
+        // T^T = act(z1)^T . d_out  [H][out_dim] -> lowrank [out_dim][H]
+        weight_grad_frag<P>((const u32x4*)B.a2[0], nth, H, B.doutf, B.dof_nt, d.out_dim, B, B.lowrank, H, s, true);
+        weight_grad_frag<P>((const u32x4*)B.dz1_all[0], nth, H, (const u32x4*)B.a1[0], nth, H, B, grad + pl.l1w[0], H, s);
+        if (oh >= 0)
+          weight_grad_frag<P>((const u32x4*)B.dh_all[0], nth, H, B.xf, ntx, d.in_dim + Kft, B, grad + pl.W0, d.in_dim, s, false,
+                              d.in_dim, B.part, Kft);
+        else
+          weight_grad_frag<P>((const u32x4*)B.dh_all[0], nth, H, B.xf, ntx, d.in_dim, B, grad + pl.W0, d.in_dim, s);
+      } else {
       if (merged)
         weight_grad<P>(B.d_out, L.Kpo, d.out_dim, B.in, L.Kp0, d.in_dim, M, B, B.lowrank_u, L.Kp0, s, true);
       else
@@ -879,6 +1001,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
                        Kft);
       else
         weight_grad<P>(B.dh_all[0], H, H, B.in, L.Kp0, d.in_dim, M, B, grad + pl.W0, d.in_dim, s, true);
+      }
       if (aux != s && g_early_join) B.join_s[B.n_join] = aux, B.join_idx[B.n_join++] = aux_idx;
       flush_slabs(B, s, &so, H, fin);  // every slab of this backward, its bias sums and the loss statistics: one launch
       if (aux != s && !g_early_join) join_side(s, aux, aux_idx);
@@ -910,7 +1033,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
                                          d.act_flat, H, B.part + (size_t)H * Kft, ksteps, Kft, d.time_dim, grad + pl.te1_w,
                                          grad + pl.te1_b, grad + pl.te2_w, grad + pl.te2_b, s);
       }
-      B.dh0_final = B.dh_all[0];
+      B.dh0_final = frag ? nullptr : B.dh_all[0];  // (fragment mode: no row-major dh_0 exists; frag_ok() made sure nobody asks)
       return;
     }
   }
@@ -1585,6 +1708,8 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   if ((int64_t)need > wsb) return fail(-1, "workspace too small: need %zu bytes, got %lld", need, (long long)wsb);
   const PackLayout LA = pack_layout<P>(a, 0), LC = pack_layout<P>(cr, 0);
   const int Kft = pcfg.ft_denoising_steps;
+  W.A.allow_frag = frag_ok<P>(a, N, LA, Kft, W.A, oio && oio->d_obs_actor);
+  W.C.allow_frag = frag_ok<P>(cr, N, LC, Kft, W.C, oio && oio->d_obs_critic);
   // The critic pipeline (rows -> forward -> value loss -> backward -> weight gradients) and the actor pipeline (rows ->
   // advantage moments -> forward -> policy loss -> ...) share nothing but the call's inputs: one fork at entry, one join
   // at the end.  A cross-stream event hop costs 10-17 us of device idle time; at entry it hides behind the actor's row
@@ -2451,6 +2576,22 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 28) {  // split sampler: 64-cycle sleep periods between a member's exchange store and its first sweep (default 4)
     set_sampler_split_pre_sweep(value);
+    return 0;
+  }
+  if (knob == 31) {  // weight-gradient GEMMs of one-block bf16 networks from K-major fragment operands (1, default) or row-major (0)
+    g_frag = value;
+    return 0;
+  }
+  if (knob == 32) {  // fragment GEMM: 0 (default) LDS-ring kernel; 2..4 register-only kernel with that lookahead
+    set_gemm_tn_frag_depth(value);
+    return 0;
+  }
+  if (knob == 34) {  // fragment GEMM, timing experiments (results are wrong while set): 1 no MFMAs, 2 no ring loads, 4 no prefetch
+    set_gemm_tn_frag_dbg(value);
+    return 0;
+  }
+  if (knob == 33) {  // fragment GEMM: k-steps its L2 prefetch runs ahead of the ring's own loads (default 12; 0: none ahead)
+    set_gemm_tn_frag_pfd(value);
     return 0;
   }
   if (knob == 30 && value >= 1) {  // low-rank dW2 (knob 16) and with it the one-block backward: on for M >= value x out_dim (default 100)

@@ -51,6 +51,11 @@ struct FusedFwdArgs {
   const u32x4* ostream0;    // fragments of Wout W0, [ks][to][lane]
   const u32x4* ostream2;    // fragments of Wout W2, [ks][to][lane]
   const float* cbias2;      // [out_dim] bout + Wout (b0 + b2)
+  // K-major fragment stores (gemm.h, GemmTNFrag; merged kernel, bf16, training): act(h_0) and act(z1) -- read by nothing
+  // but the weight-gradient GEMMs -- are written as the MFMA operand fragments those want instead of row-major; a1[0] /
+  // a2[0] are then not written.  [k-step][H / 16][64 lanes] u32x4 each, k-steps of 32 rows, whole tiles.
+  u32x4* a1f;
+  u32x4* a2f;
 };
 
 struct FusedBwdArgs {
@@ -79,6 +84,16 @@ struct FusedBwdArgs {
   int dout_slot;
   int dbg;  // timing experiments only (tuning knob 8): bit 1 = do not fetch the derivative sources (wrong results)
   int one_block;  // fused_backward_one_kernel (fused_bwd_one_block(), nb == 1): dh[1] and column-sum slot 0 are not produced
+  // K-major fragment stores (gemm.h, GemmTNFrag; one-block kernel, bf16): dz1 and dh_0 as fragments instead of row-major
+  // (dz1[0] / dh[0] are then not written), plus fragment copies of the two small operands the GEMMs contract them with: the
+  // d_out tile (first dof_nt feature tiles of it) and the network's input rows x ([M][ld_x] elem, x_nt = ld_x / 16 tiles)
+  u32x4* dz1f;
+  u32x4* dh0f;
+  u32x4* doutf;
+  int dof_nt;
+  const void* x;
+  int ld_x;
+  u32x4* xf;
 };
 
 template <class P>

@@ -324,6 +324,84 @@ struct CEngine {
   }
 };
 
+// ---- K-major fragment stores (gemm.h, GemmTNFrag): bf16 only -------------------------------------------------------------
+// A 16-lane group reading a 4-row x 16-column block of bf16 with ds_read_b64_tr_b16 gets it transposed: lane i ends with
+// column i of the 4 rows.  Two reads (rows 8 kg + 0..3 and + 4..7 of a 32-row k-step) are one lane's 16 bytes of the
+// fragment: feature 16 ft + i, rows 32 ks + 8 kg + s.
+typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
+__device__ __forceinline__ u32x2 lds_tr16(const char* p) {
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)p));
+}
+// this wave's 16 TPW features of a swizzled [16 MR][H] bf16 LDS image (as written by emit(): 16-byte chunk c of row R sits
+// at chunk c ^ (R & 15)) -> out[ks'][ft][lane], ks' = 0 .. MR/2 - 1 the tile's k-steps, NT feature tiles per k-step.
+// A wave reads back only what it wrote itself (LDS executes a wave's instructions in order): no barrier.
+template <int TPW, int MR>
+__device__ __forceinline__ void frag_store_image(const char* img, int HRB, int wid, int lane, u32x4* out, int NT) {
+  static_assert(MR % 2 == 0, "a k-step is two row sub-tiles");
+  const int i = lane & 15, kg = lane >> 4, q = i >> 2, p = i & 3;
+#pragma unroll
+  for (int ks = 0; ks < MR / 2; ++ks) {
+    const int row0 = 32 * ks + 8 * kg + q, row1 = row0 + 4;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int ft = wid * TPW + t, c = 2 * ft + (p >> 1);
+      const u32x2 u0 = lds_tr16(img + row0 * HRB + ((c ^ (row0 & 15)) << 4) + (p & 1) * 8);
+      const u32x2 u1 = lds_tr16(img + row1 * HRB + ((c ^ (row1 & 15)) << 4) + (p & 1) * 8);
+      out[((size_t)ks * NT + ft) * 64 + lane] = (u32x4){u0.x, u0.y, u1.x, u1.y};
+    }
+  }
+}
+// the same for a narrow tile every wave can read (the d_out tile, the input rows: [16 MR][rb bytes], chunk swizzle by
+// row & km, load_tile()): the (k-step, feature tile) pairs are dealt to the eight waves; behind the barrier that made the
+// tile visible.  nt_src: feature tiles to copy (<= rb / 32), NT: tiles per k-step of the destination
+template <int MR>
+__device__ __forceinline__ void frag_store_tile(const char* img, int rb, int km, int nt_src, int wid, int lane, u32x4* out, int NT) {
+  const int i = lane & 15, kg = lane >> 4, q = i >> 2, p = i & 3;
+  for (int item = wid; item < (MR / 2) * nt_src; item += SAMPLER_WAVES) {
+    const int ks = item / nt_src, ft = item - ks * nt_src;
+    const int row0 = 32 * ks + 8 * kg + q, row1 = row0 + 4, c = 2 * ft + (p >> 1);
+    const u32x2 u0 = lds_tr16(img + row0 * rb + ((c ^ (row0 & km)) << 4) + (p & 1) * 8);
+    const u32x2 u1 = lds_tr16(img + row1 * rb + ((c ^ (row1 & km)) << 4) + (p & 1) * 8);
+    out[((size_t)ks * NT + ft) * 64 + lane] = (u32x4){u0.x, u0.y, u1.x, u1.y};
+  }
+}
+// accumulators v[tp][m] (features wbase + feat_off(g, tp) + e of rows 16 m + r) that go to NO LDS image (dh_0 of the one-block
+// backward): staged k-step by k-step through a private [32 rows][16 TPW features] bf16 region of this wave, chunk c of row
+// R at c ^ (R & (2 TPW - 1)), and read back transposed.  stage: this wave's 32 * 32 * TPW bytes.
+template <int TPW, int MR>
+__device__ __forceinline__ void frag_store_acc(const f32x4 (&v)[TPW][MR], char* stage, int wid, int lane, u32x4* out, int NT) {
+  static_assert(MR % 2 == 0 && TPW % 2 == 0, "bf16 chunk = two MFMA tiles; a k-step = two row sub-tiles");
+  constexpr int RS = 32 * TPW, CM = 2 * TPW - 1;  // row bytes, chunk mask
+  const int r = lane & 15, g = lane >> 4;
+  const int i = r, kg = g, q = i >> 2, p = i & 3;
+#pragma unroll
+  for (int ks = 0; ks < MR / 2; ++ks) {
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm) {
+      const int m = 2 * ks + mm, row = 16 * mm + r;
+#pragma unroll
+      for (int tp = 0; tp < TPW; tp += 2) {
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = v[tp + (2 * e) / 4][m][(2 * e) % 4], hi = v[tp + (2 * e + 1) / 4][m][(2 * e + 1) % 4];
+          o[e] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+        }
+        const int c = (feat_off<BF16>(g, tp) * 2) >> 4;  // chunk of the wave's slice: 4 (tp / 2) + g
+        *(u32x4*)(stage + row * RS + ((c ^ (row & CM)) << 4)) = o;
+      }
+    }
+    const int row0 = 8 * kg + q, row1 = row0 + 4;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int c = 2 * t + (p >> 1);
+      const u32x2 u0 = lds_tr16(stage + row0 * RS + ((c ^ (row0 & CM)) << 4) + (p & 1) * 8);
+      const u32x2 u1 = lds_tr16(stage + row1 * RS + ((c ^ (row1 & CM)) << 4) + (p & 1) * 8);
+      out[((size_t)ks * NT + wid * TPW + t) * 64 + lane] = (u32x4){u0.x, u0.y, u1.x, u1.y};
+    }
+  }
+}
+
 // ReLU'(x) of a lane's 4*TPW features of one row is a bit mask: the forward stores it as one 32-bit word per (row, wave,
 // lane group g) -- [M][SIGN_WORDS] -- and the backward reads 128 bytes per row instead of the whole activated tensor.
 constexpr int SIGN_WORDS = 32;  // 8 waves x 4 lane groups
@@ -704,9 +782,7 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
   constexpr int KSPLIT = WIDE ? SAMPLER_WAVES / OT : (MR * OT >= 8 ? 1 : 8 / (MR * OT));
   constexpr int KPER = KSH / KSPLIT, NITEMS = MR * OT * KSPLIT, NI = (NITEMS + SAMPLER_WAVES - 1) / SAMPLER_WAVES;
   constexpr int S2 = WIDE ? KPER / TPW : 0;   // ring positions of a wave's K slice
-  constexpr int MPW = WIDE ? MR / KSPLIT : 1;  // row sub-tiles per wave in the FIRST pass (K = in_dim: no K split there)
-  static_assert(!WIDE || (S1 > 0 && SAMPLER_WAVES % OT == 0 && KPER % TPW == 0 && S2 >= 1 && S2 <= 4 && MR % KSPLIT == 0),
-                "wide merged head: layout");
+  static_assert(!WIDE || (S1 > 0 && SAMPLER_WAVES % OT == 0 && KPER % TPW == 0 && S2 >= 1 && S2 <= 4), "wide merged head: layout");
   constexpr bool FLAGS = DPPO_FLAGS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -786,12 +862,15 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
         }
       }
     }
-    emit<P, TPW, MR>(acc, ACT, bufA, a.a1[0], H, wbase, g, r, row0, M, a.hpre[0]);  // hpre[0] <- act'(h_0) (Mish) / sign words
+    emit<P, TPW, MR>(acc, ACT, bufA, a.a1f ? nullptr : a.a1[0], H, wbase, g, r, row0, M, a.hpre[0]);  // hpre[0] <- act'(h_0) (Mish) / sign words
     STAMP(3);
     if constexpr (FLAGS)
       hand_over(flags, wid, lane, ++seq);
     else
       __syncthreads();
+    if constexpr (ES == 2) {  // act(h_0) as K-major fragments: read back from the image this wave has just written
+      if (a.a1f) frag_store_image<TPW, MR>(bufA, HRB, wid, lane, a.a1f + (size_t)tile * (MR / 2) * (H / 16) * 64, H / 16);
+    }
     STAMP(4);
     // ---- the block's first layer
     bias_init(1);
@@ -802,7 +881,10 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
       eng.run(acc, bufA, HRB, 15, KSH, r, g, FLAGS ? flags : nullptr, seq);
     }
     STAMP(5);
-    emit<P, TPW, MR>(acc, ACT, bufB, a.a2[0], H, wbase, g, r, row0, M, a.z1[0]);  // z1[0] <- act'(z1) (Mish) / sign words
+    emit<P, TPW, MR>(acc, ACT, bufB, a.a2f ? nullptr : a.a2[0], H, wbase, g, r, row0, M, a.z1[0]);  // z1[0] <- act'(z1) (Mish) / sign words
+    if constexpr (ES == 2) {
+      if (a.a2f) frag_store_image<TPW, MR>(bufB, HRB, wid, lane, a.a2f + (size_t)tile * (MR / 2) * (H / 16) * 64, H / 16);
+    }
     STAMP(6);
     __syncthreads();  // the out layer's work items read every wave's features
     STAMP(7);
@@ -813,15 +895,19 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
       f32x4 ow[MR];
 #pragma unroll
       for (int m = 0; m < MR; ++m) ow[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      // first pass, (Wout W0) x: wave (to, kh) takes row sub-tiles kh MPW .. kh MPW + MPW - 1 of its out tile (K = in_dim is not split)
-      for (int ks = 0; ks < ks0v; ++ks) {
-        const u32x4 wf = w0cL[(ks * OT + to_w) * 64 + lane_];
+      // first pass, (Wout W0) x: the waves of K slice 0 take it for every row sub-tile of their out tile (K = in_dim is not
+      // split).  NOT shared out by row sub-tile: a row's partial sums must be added in the same order wherever the row sits
+      // in a tile -- the update's recomputed log-probs equal the precomputed ones bit for bit only then (the inference and the
+      // training call put a sample at different tile rows)
+      if (kh_w == 0) {
+        for (int ks = 0; ks < ks0v; ++ks) {
+          const u32x4 wf = w0cL[(ks * OT + to_w) * 64 + lane_];
 #pragma unroll
-        for (int m = 0; m < MR; ++m)
-          if (m / MPW == kh_w) {
+          for (int m = 0; m < MR; ++m) {
             const u32x4 xb = *(const u32x4*)(xin + (16 * m + r_) * in_rb + (((ks * 4 + g_) ^ (r_ & in_km)) << 4));
             ow[m] = P::mma(wf, xb, ow[m]);
           }
+        }
       }
       if constexpr (S1 > 0) {
         eng.aux_all(ow, bufB, HRB, 15, kh_w * KPER, r_, g_);
@@ -1112,6 +1198,11 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
   lds_u32* flags = (lds_u32*)(bufB + MT * HRB);              // [16 words]
   constexpr int DRED_COLS = 128;
   float* dred = (float*)(bufB + MT * HRB + 64);  // [8 waves][128] column sums of the d_out tile
+  // fragment mode (a.dz1f): buffer B beyond the d_out tile (at most MT x 256 bytes of its MT x HRB) also holds the input-row
+  // tile [MT][ld_x] and each wave's private staging region for dh_0 (frag_store_acc): 16 + 16 + 32 KB of 64 at H = 512
+  // (the launcher checked MT (in_rb + ld_x ES) + 8 x 32 x 32 TPW <= MT HRB: fused_frag_fits())
+  char* xt = bufB + MT * in_rb;
+  char* stage = xt + MT * a.ld_x * ES + wid * (32 * 32 * TPW);
   const int wbase = wid * 16 * TPW;
   const int ntiles = (M + MT - 1) / MT;
 
@@ -1144,7 +1235,16 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
     u32x4 d[MR][Chunks<P, TPW>::CH];
     fetch<P, ACT == ACT_RELU, TPW>(d, a.m1[0], H, wbase, g, r, row0, M);
     load_tile<MT>(xin, in_rb, in_km, (const char*)a.d_out, a.ld_dout * ES, row0, M);
+    const int x_rb = a.ld_x * ES, x_km = kmask16(x_rb);
+    if constexpr (ES == 2) {
+      if (a.xf) load_tile<MT>(xt, x_rb, x_km, (const char*)a.x, x_rb, row0, M);
+    }
     __syncthreads();
+    if constexpr (ES == 2) {  // fragment copies of the two small GEMM operands (rows past M are zero: load_tile)
+      const size_t kbase = (size_t)tile * (MR / 2);
+      if (a.doutf) frag_store_tile<MR>(xin, in_rb, in_km, a.dof_nt, wid, lane, a.doutf + kbase * a.dof_nt * 64, a.dof_nt);
+      if (a.xf) frag_store_tile<MR>(xt, x_rb, x_km, a.ld_x / 16, wid, lane, a.xf + kbase * (a.ld_x / 16) * 64, a.ld_x / 16);
+    }
     STAMP(17);
     if (a.dout_slot >= 0) {  // out-layer bias gradient: column sums of the d_out tile (rows past M are zero), part 1
       typedef typename P::elem_t E;
@@ -1179,7 +1279,7 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[tp][m][e] *= grad_at<P, ACT>(d, tp, m, e);
     STAMP(20);
-    emit<P, TPW, MR>(acc, ACT_NONE, bufA, a.dz1[0], H, wbase, g, r, row0, M);
+    emit<P, TPW, MR>(acc, ACT_NONE, bufA, a.dz1f ? nullptr : a.dz1[0], H, wbase, g, r, row0, M);
     STAMP(23);
     colsum(acc, 2, tile);
     STAMP(24);
@@ -1187,6 +1287,9 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
       hand_over(flags, wid, lane, ++seq);
     else
       __syncthreads();
+    if constexpr (ES == 2) {
+      if (a.dz1f) frag_store_image<TPW, MR>(bufA, HRB, wid, lane, a.dz1f + (size_t)tile * (MR / 2) * (H / 16) * 64, H / 16);
+    }
     STAMP(25);
     // ---- dh_0 = (dz1 . W1) o act'(h_0) + d_out . Wout
     fetch<P, ACT == ACT_RELU, TPW>(d, a.m0[0], H, wbase, g, r, row0, M);
@@ -1215,7 +1318,14 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
     } else {
       eng.run(acc, xin, in_rb, in_km, KSB0, r, g);
     }
-    emit<P, TPW, MR>(acc, ACT_NONE, nullptr, a.dh[0], H, wbase, g, r, row0, M);
+    if constexpr (ES == 2) {
+      if (a.dh0f)  // (rows past M: d_out is zero there, hence dh_0 too)
+        frag_store_acc<TPW, MR>(acc, stage, wid, lane, a.dh0f + (size_t)tile * (MR / 2) * (H / 16) * 64, H / 16);
+      else
+        emit<P, TPW, MR>(acc, ACT_NONE, nullptr, a.dh[0], H, wbase, g, r, row0, M);
+    } else {
+      emit<P, TPW, MR>(acc, ACT_NONE, nullptr, a.dh[0], H, wbase, g, r, row0, M);
+    }
     STAMP(27);
     colsum(acc, 1, tile);
     STAMP(28);
@@ -1450,6 +1560,11 @@ static int launch_bwd_one_cfg2(const FusedBwdArgs& a, hipStream_t s) {
   constexpr int ES = P::ESIZE, MT = 16 * MR, H = 128 * TPW;
   const size_t lds = 2 * (size_t)MT * H * ES + 64 + SAMPLER_WAVES * 128 * 4;
   if (lds > 160 * 1024 || a.KpB0 > H || a.KpB0 > 128 || a.nb != 1) return -2;
+  if (a.dz1f != nullptr || a.dh0f != nullptr || a.xf != nullptr || a.doutf != nullptr) {  // fragment mode: all four or none
+    if (ES != 2 || !a.dz1f || !a.dh0f || !a.xf || !a.doutf || !a.x || a.ld_x % 16 || a.dof_nt < 1 || a.dof_nt * 16 > a.KpB0 ||
+        (size_t)MT * ((size_t)a.KpB0 * ES + (size_t)a.ld_x * ES) + (size_t)SAMPLER_WAVES * 32 * 32 * TPW > (size_t)MT * H * ES)
+      return -4;
+  }
   static DevLatch attr;
   raise_lds(fused_backward_one_kernel<P, TPW, MR, ACT, COMPACT>, attr);
   const int ntiles = (a.M + MT - 1) / MT;

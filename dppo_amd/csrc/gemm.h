@@ -50,6 +50,42 @@ struct GemmTNGroup {  // one launch over the 128 x 128 tiles of n weight-gradien
   int n;
 };
 
+// ---- weight gradients from K-MAJOR FRAGMENT operands (bf16; gemm_tn_frag_kernel) ---------------------------------------------
+// The tensors a weight-gradient GEMM contracts over batch rows -- act(h_0), act(z1), dz1, dh_0, the input rows x and d_out --
+// are written by the one-block fused kernels (fused.hip, frag_store) not row-major but as the MFMA operand fragments the
+// contraction wants: for a tensor of NT feature tiles (16 features each) and k-steps of 32 batch rows,
+//     F[ks][ft][lane][8 bf16]      (16 bytes per lane, 1 KB per (k-step, feature tile), k-steps outermost)
+// where lane (i = lane & 15, kg = lane >> 4) holds feature 16 ft + i of rows 32 ks + 8 kg + s, s = 0..7 -- exactly the register
+// image of a 16x16x32 MFMA operand whose K index is the batch row.  Both operands use the same map, so
+// C[16 ft1 + 4 g + e][16 ft2 + r] += mma(F1[ks][ft1], F2[ks][ft2]) with no transpose, no LDS and no barrier: every load is one
+// perfectly coalesced 1 KB wave instruction.  Rows past the batch are zero in at least one operand of every product
+// (the backward-side tensors are exact zeros there), and the fused kernels write whole tiles, so every k-step below
+// ceil(M / 64) * 2 exists.
+struct GemmTNFrag {
+  const u32x4* A;   // fragments of the tensor that contributes rows of C
+  const u32x4* B;   // ... columns of C
+  int nta, ntb;     // feature tiles per k-step in A / B (their k-step strides)
+  int N1, N2;       // extent of C (rows from A's features, columns from B's)
+  int tb;           // B tiles per wave: 1, 2 or 4 (wave tile = 64 x 16 tb)
+  int wga, wgb;     // waves of a workgroup along A / B (wga * wgb = 4)
+  int dbg;          // timing experiments (knob 34)
+  int npf, pfd;     // L2 prefetch: fragments per wave and k-step, k-steps ahead (gemm_tn_frag_prepare)
+  int ks_total, ks_per_split, splits;
+  float* slab;      // [splits][N1][ldc]
+  int ldc;
+};
+struct GemmTNFragGroup {
+  GemmTNFrag j[MAX_TN_JOBS];
+  int base[MAX_TN_JOBS + 1];
+  int n;
+};
+int gemm_tn_frag_blocks(const GemmTNFrag& j);  // workgroups of one job (tiles x splits)
+bool gemm_tn_frag_prepare(GemmTNFrag& j);      // fills tb, wga, wgb, npf, pfd from N1, N2, nta, ntb; false: shape not covered
+void set_gemm_tn_frag_pfd(int v);              // tuning knob 33
+void set_gemm_tn_frag_dbg(int v);              // tuning knob 34 (timing experiments only)
+void launch_gemm_tn_frag_group(const GemmTNFragGroup& gr, int64_t M, hipStream_t s);
+void set_gemm_tn_frag_depth(int v);  // tuning knob 32: 0 (default) LDS-ring kernel; 2..4 register-only kernel, k-steps of lookahead
+
 template <class P>
 void launch_gemm_nt(const GemmNT& a, hipStream_t s);
 template <class P>

@@ -710,6 +710,314 @@ void launch_gemm_tn_group(const GemmTNGroup& gr, hipStream_t s) {
 template void launch_gemm_tn_group<F32>(const GemmTNGroup&, hipStream_t);
 template void launch_gemm_tn_group<BF16>(const GemmTNGroup&, hipStream_t);
 
+// ------------------------------------------------------------------------------------------------
+// gemm_tn from K-major fragment operands (gemm.h, GemmTNFrag): one WAVE owns a 64 x (16 TB) tile of C for one row split and
+// walks its k-steps with D of them in flight in registers (4 + TB fragments of 1 KB each per k-step); a workgroup is four such
+// waves on neighbouring tiles (2 x 2, or 4 x 1 for thin outputs) that share operand fragments through L1 -- and nothing else:
+// no LDS, no barrier, no transposed read.  Loads return in issue order and the compiler counts vmcnt from the register
+// dependences, so the loop body is "multiply slot d, refill slot d".
+// Work order inside a job: split index fastest (multiples of 8 => a split's tiles share an XCD and its L2, as in
+// gemm_tn_group_kernel).
+template <int TB, int D>
+__device__ __forceinline__ void tn_frag_wave(const GemmTNFrag& a, const int split, const int ablk, const int bblk, const int lane) {
+  constexpr int TA = 4;
+  const int r = lane & 15, g = lane >> 4;
+  const int ks0 = split * a.ks_per_split;
+  int ks1 = ks0 + a.ks_per_split;
+  ks1 = ks1 < a.ks_total ? ks1 : a.ks_total;
+  const int fa0 = ablk * TA, fb0 = bblk * TB;  // first feature tiles
+  // tiles past the tensors' widths (N1 not a multiple of 64, ...) are clamped to the last one and never stored
+  int ta[TA], tbv[TB];
+#pragma unroll
+  for (int i = 0; i < TA; ++i) ta[i] = fa0 + i < a.nta ? fa0 + i : a.nta - 1;
+#pragma unroll
+  for (int j = 0; j < TB; ++j) tbv[j] = fb0 + j < a.ntb ? fb0 + j : a.ntb - 1;
+  f32x4 acc[TA][TB];
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  u32x4 fa[D][TA], fb[D][TB];
+  const u32x4* Ap = a.A + lane;
+  const u32x4* Bp = a.B + lane;
+  auto fetch = [&](int d, int ks) {
+    ks = ks < ks1 ? ks : ks1 - 1;  // past the end: a harmless reload of the last k-step (never multiplied)
+    const u32x4* pa = Ap + (size_t)ks * a.nta * 64;
+    const u32x4* pb = Bp + (size_t)ks * a.ntb * 64;
+#pragma unroll
+    for (int i = 0; i < TA; ++i) fa[d][i] = pa[ta[i] * 64];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) fb[d][j] = pb[tbv[j] * 64];
+  };
+  if (ks1 > ks0) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch(d, ks0 + d);
+    for (int ks = ks0; ks < ks1; ks += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        if (ks + d < ks1) {
+#pragma unroll
+          for (int i = 0; i < TA; ++i)
+#pragma unroll
+            for (int j = 0; j < TB; ++j) acc[i][j] = BF16::mma(fa[d][i], fb[d][j], acc[i][j]);
+        }
+        fetch(d, ks + d + D);
+      }
+    }
+  }
+  float* out = a.slab + (size_t)split * a.N1 * a.ldc;
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n1 = (fa0 + i) * 16 + 4 * g + e;
+      if (n1 >= a.N1) continue;
+#pragma unroll
+      for (int j = 0; j < TB; ++j) {
+        const int n2 = (fb0 + j) * 16 + r;
+        if (n2 < a.N2) out[(size_t)n1 * a.ldc + n2] = acc[i][j][e];
+      }
+    }
+}
+
+// The same contraction with the workgroup's fragments shared through an LDS ring, behind a deep L2 PREFETCH by a fifth wave.
+// Measured (rocprofv3 --pmc, gpurun_out/r3g): in every form of this product tried here -- the transposing LDS kernel
+// (gemm_tn_group_kernel, 75 us per actor group), the register-only form below (80 us), a plain LDS ring (80 us) -- the waves
+// spend 60 % of their cycles in s_waitcnt / barriers with the matrix cores at ~15 %: 39 % of the L2 requests miss (every line is
+// wanted by several output tiles at about the same time and the first asker pays the HBM latency), vmcnt is in ISSUE ORDER,
+// and so each k-step of a ring waits for its slowest line: the look-ahead that should hide HBM is spent waiting on it.
+// A prefetch issued by the consuming waves themselves does not help (it sits in the same in-order queue in front of the
+// ring loads: knob 33 had no effect at any distance).  So the roles are split by WAVE:
+//  * waves 0-3 (2 x 2 tiles of 64 x 64, or 4 x 1 for thin outputs) fetch each fragment of the workgroup's tile ONCE per
+//    k-step, by LDS-DMA (1 KB per wave instruction, landed lane-linear), into NST one-k-step stages, and read their 4 + TB
+//    fragments back with conflict-free ds_read_b128;
+//  * wave 4 computes nothing: per k-step it issues this workgroup's share of the split's fragments (the workgroups of one row
+//    split -- same XCD, same L2: split index fastest, splits a multiple of 8 -- divide each k-step's fragments among them)
+//    PFD k-steps ahead, by LDS-DMA into a dump slot nobody reads, never waits for them, and joins the k-step's barrier to
+//    keep pace.  Its vmcnt is its own: HBM latency lands on loads nobody waits for, the ring sees L2 hits.
+template <int WGA, int TB, int NST, int NPW>
+__device__ __forceinline__ void tn_fragl_wg(const GemmTNFrag& a, const int split, const int tile, char* smem) {
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  constexpr int TA = 4, WGB = 4 / WGA, FA = WGA * TA, FB = WGB * TB, NF = FA + FB, NLD = (NF + 3) / 4;
+  constexpr int STAGE = NLD * 4 * 1024;  // bytes; slots NF .. 4 NLD - 1 receive dummy loads (same vmcnt count on every wave)
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int wa = wid % WGA, wb = (wid & 3) / WGA;
+  const int nab = ((a.N1 + 63) / 64 + WGA - 1) / WGA;
+  const int nbb = ((a.N2 + 16 * TB - 1) / (16 * TB) + WGB - 1) / WGB;  // workgroup tiles along A, B
+  const int fa0 = (tile / nbb) * FA, fb0 = (tile % nbb) * FB;           // the workgroup's first feature tiles
+  const int ks0 = split * a.ks_per_split;
+  int ks1 = ks0 + a.ks_per_split;
+  ks1 = ks1 < a.ks_total ? ks1 : a.ks_total;
+  const int nks = ks1 - ks0;
+  if (wid == 4) {  // ---- the prefetcher
+    if (nks <= 0) return;
+    const int nAu = min(a.nta, (a.N1 + 15) / 16), nBu = min(a.ntb, (a.N2 + 15) / 16), G = nab * nbb;
+    const u32x4* psrc[NPW];
+    int pstride[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      int f = tile + G * i;
+      f = f < nAu + nBu ? f : nAu + nBu - 1;  // (nothing left for this workgroup: a duplicate -- one issue pattern)
+      const bool isA = f < nAu;
+      psrc[i] = (isA ? a.A + (size_t)f * 64 : a.B + (size_t)(f - nAu) * 64) + lane;
+      pstride[i] = (isA ? a.nta : a.ntb) * 64;
+    }
+    char* dump = smem + NST * STAGE;
+    const int lead = NST - 1 + a.pfd;
+    for (int st = 0; st < nks; ++st) {
+      int kp = ks0 + st + lead;
+      if (kp < ks1 && !(a.dbg & 4)) {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i)
+          __builtin_amdgcn_global_load_lds((glb_ptr)(psrc[i] + (size_t)kp * pstride[i]), (lds_ptr)dump, 16, 0, 0);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  if (nks <= 0) {  // a surplus split: zeros (whole workgroup: no barrier is left behind)
+    float* out = a.slab + (size_t)split * a.N1 * a.ldc;
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n1 = (fa0 + wa * TA + i) * 16 + 4 * g + e;
+        if (n1 >= a.N1) continue;
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+          const int n2 = (fb0 + wb * TB + j) * 16 + r;
+          if (n2 < a.N2) out[(size_t)n1 * a.ldc + n2] = 0.f;
+        }
+      }
+    return;
+  }
+  // this wave's NLD loads of a stage: slot f = wid + 4 i -> (operand, feature tile), clamped to the tensor's last tile
+  const u32x4* src[NLD];
+  int kstride[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int f = wid + 4 * i;
+    const bool isA = f < FA || f >= NF;  // (dummy slots reload an A fragment)
+    int t = f < FA ? fa0 + f : (f < NF ? fb0 + (f - FA) : fa0);
+    const int nt = isA ? a.nta : a.ntb;
+    t = t < nt ? t : nt - 1;
+    src[i] = (isA ? a.A : a.B) + (size_t)t * 64 + lane;
+    kstride[i] = nt * 64;
+  }
+  auto dma = [&](int ks, int buf) {
+    char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(src[i] + (size_t)ks * kstride[i]), (lds_ptr)(st + (wid + 4 * i) * 1024), 16, 0, 0);
+  };
+  f32x4 acc[TA][TB];
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < NST - 1; ++p)
+    if (p < nks) dma(ks0 + p, p);
+  for (int st = 0; st < nks; ++st) {
+    // this wave's share of stage st has landed once at most the DMAs of the NST - 2 younger stages are outstanding (vmcnt
+    // counts in issue order); near the end fewer are in flight: wait for all
+    if (st + NST - 2 < nks)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NLD) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // everyone's share landed, and everyone is done reading the stage refilled next
+    if (st + NST - 1 < nks && !(a.dbg & 2)) dma(ks0 + st + NST - 1, (st + NST - 1) % NST);
+    const char* sb = smem + (st % NST) * STAGE + lane * 16;
+    u32x4 af[TA], bf[TB];
+#pragma unroll
+    for (int i = 0; i < TA; ++i) af[i] = *(const u32x4*)(sb + (wa * TA + i) * 1024);
+#pragma unroll
+    for (int j = 0; j < TB; ++j) bf[j] = *(const u32x4*)(sb + (FA + wb * TB + j) * 1024);
+    if (!(a.dbg & 1)) {
+#pragma unroll
+      for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) acc[i][j] = BF16::mma(af[i], bf[j], acc[i][j]);
+    } else {  // (timing experiment: keep the LDS reads alive)
+      acc[0][0][0] += __uint_as_float(af[0].x ^ af[1].x ^ af[2].x ^ af[3].x ^ bf[0].x ^ bf[TB - 1].y);
+    }
+  }
+  float* out = a.slab + (size_t)split * a.N1 * a.ldc;
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n1 = (fa0 + wa * TA + i) * 16 + 4 * g + e;
+      if (n1 >= a.N1) continue;
+#pragma unroll
+      for (int j = 0; j < TB; ++j) {
+        const int n2 = (fb0 + wb * TB + j) * 16 + r;
+        if (n2 < a.N2) out[(size_t)n1 * a.ldc + n2] = acc[i][j][e];
+      }
+    }
+}
+// ring stages: 4 x 16 KB (2 x 2 waves) or 3 x 20 KB (4 x 1), + the prefetcher's 1 KB dump slot: 65 KB, two workgroups per CU
+constexpr int TN_FRAGL_LDS = 4 * 16 * 1024 + 1024;
+static_assert(3 * 20 * 1024 + 1024 <= TN_FRAGL_LDS, "thin configuration's ring");
+__global__ __launch_bounds__(320, 2) void gemm_tn_fragl_kernel(const GemmTNFragGroup gr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int jn = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_TN_JOBS; ++i)
+    if (i < gr.n && (int)blockIdx.x >= gr.base[i]) jn = i;
+  const GemmTNFrag& a = gr.j[jn];
+  const int local = blockIdx.x - gr.base[jn];
+  const int split = local % a.splits, tile = local / a.splits;
+  // (npf: fragments per k-step / workgroups per split, capped at what is instantiated: gemm_tn_frag_prepare)
+  if (a.wga == 2) {
+    if (a.npf <= 4)
+      tn_fragl_wg<2, 4, 4, 4>(a, split, tile, smem);
+    else
+      tn_fragl_wg<2, 4, 4, 8>(a, split, tile, smem);
+  } else if (a.tb == 4) {
+    tn_fragl_wg<4, 4, 3, 8>(a, split, tile, smem);
+  } else if (a.tb == 2) {
+    tn_fragl_wg<4, 2, 3, 8>(a, split, tile, smem);
+  } else {
+    tn_fragl_wg<4, 1, 3, 8>(a, split, tile, smem);
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void gemm_tn_frag_kernel(const GemmTNFragGroup gr) {
+  int jn = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_TN_JOBS; ++i)
+    if (i < gr.n && (int)blockIdx.x >= gr.base[i]) jn = i;
+  const GemmTNFrag& a = gr.j[jn];
+  const int local = blockIdx.x - gr.base[jn];
+  const int split = local % a.splits, tile = local / a.splits;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nbb = ((a.N2 + 16 * a.tb - 1) / (16 * a.tb) + a.wgb - 1) / a.wgb;  // workgroup tiles along B
+  const int ablk = (tile / nbb) * a.wga + wid % a.wga, bblk = (tile % nbb) * a.wgb + wid / a.wga;
+  if (ablk * 64 >= a.N1 || bblk * 16 * a.tb >= a.N2) return;
+  if (a.tb == 4)
+    tn_frag_wave<4, D>(a, split, ablk, bblk, lane);
+  else if (a.tb == 2)
+    tn_frag_wave<2, D>(a, split, ablk, bblk, lane);
+  else
+    tn_frag_wave<1, D>(a, split, ablk, bblk, lane);
+}
+int gemm_tn_frag_blocks(const GemmTNFrag& j) {
+  const int nab = ((j.N1 + 63) / 64 + j.wga - 1) / j.wga;
+  const int nbb = ((j.N2 + 16 * j.tb - 1) / (16 * j.tb) + j.wgb - 1) / j.wgb;
+  return nab * nbb * j.splits;
+}
+static int g_tn_frag_dbg = 0;  // tuning knob 34 (timing experiments, results wrong): 1 no MFMAs, 2 no ring loads, 4 no prefetch
+void set_gemm_tn_frag_dbg(int v) { g_tn_frag_dbg = v; }
+static int g_tn_frag_pfd = 12;  // tuning knob 33: k-steps the L2 prefetch runs ahead of the ring's own loads
+void set_gemm_tn_frag_pfd(int v) { g_tn_frag_pfd = v < 0 ? 0 : (v > 64 ? 64 : v); }
+// wave shape of a job's workgroups and its prefetch share; false if the LDS-ring kernel has no configuration for it
+bool gemm_tn_frag_prepare(GemmTNFrag& j) {
+  j.tb = j.N2 <= 16 ? 1 : (j.N2 <= 32 ? 2 : 4);
+  const int nba = (j.N1 + 63) / 64, nbbk = (j.N2 + 16 * j.tb - 1) / (16 * j.tb);
+  j.wgb = nbbk >= 2 ? 2 : 1, j.wga = 4 / j.wgb;
+  const int nab = (nba + j.wga - 1) / j.wga, nbb = (nbbk + j.wgb - 1) / j.wgb;
+  const int nAu = j.nta < (j.N1 + 15) / 16 ? j.nta : (j.N1 + 15) / 16, nBu = j.ntb < (j.N2 + 15) / 16 ? j.ntb : (j.N2 + 15) / 16;
+  j.npf = (nAu + nBu + nab * nbb - 1) / (nab * nbb);  // fragments per k-step and workgroup of a split
+  j.npf = j.npf < 8 ? j.npf : 8;  // what the kernel instantiates (4 or 8 per k-step: the prefetcher's vmcnt holds 63); a job
+                                  // with more prefetches the first ones only
+  j.pfd = g_tn_frag_pfd;
+  j.dbg = g_tn_frag_dbg;
+  return true;
+}
+static int g_tn_frag_depth = 0;  // tuning knob 32: 0 (default) the LDS-ring kernel; 2..4: the register-only kernel at that depth
+void set_gemm_tn_frag_depth(int v) { g_tn_frag_depth = v <= 0 ? 0 : (v < 2 ? 2 : (v > 4 ? 4 : v)); }
+void launch_gemm_tn_frag_group(const GemmTNFragGroup& gr, int64_t M, hipStream_t s) {
+  if (gr.n <= 0) return;
+  double flops = 0, bytes = 0;
+  for (int i = 0; i < gr.n; ++i) {
+    const GemmTNFrag& a = gr.j[i];
+    flops += 2.0 * M * a.N1 * a.N2;
+    bytes += (double)M * (a.N1 + a.N2) * 2 + 4.0 * a.N1 * a.N2;  // both operands once + the fp32 result
+  }
+  const bool probe = probe_begin(PROBE_GEMM_TN, s);
+  const dim3 grid(gr.base[gr.n]);
+  if (g_tn_frag_depth == 0) {
+    static DevLatch attr_set;
+    if (attr_set.need()) {
+      (void)hipFuncSetAttribute((const void*)gemm_tn_fragl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_FRAGL_LDS);
+      attr_set.done();
+    }
+    hipLaunchKernelGGL(gemm_tn_fragl_kernel, grid, dim3(320), TN_FRAGL_LDS, s, gr);
+  } else if (g_tn_frag_depth == 2)
+    hipLaunchKernelGGL((gemm_tn_frag_kernel<2>), grid, dim3(256), 0, s, gr);
+  else if (g_tn_frag_depth == 4)
+    hipLaunchKernelGGL((gemm_tn_frag_kernel<4>), grid, dim3(256), 0, s, gr);
+  else
+    hipLaunchKernelGGL((gemm_tn_frag_kernel<3>), grid, dim3(256), 0, s, gr);
+  if (probe) probe_end(s, flops, bytes);
+}
+
 static int g_tn_thin = 1;  // tuning knob 6: 0 = no one-tile 512 x 64 configuration for thin outputs
 void set_gemm_tn_thin(int v) { g_tn_thin = v; }
 bool gemm_tn_thin(int N1, int N2) { return g_tn_thin && N2 <= 64 && N1 > 64; }

@@ -482,6 +482,13 @@ int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* 
  * knob 27: sampler, small env batches of one-block bf16 networks at hidden 512: one 16-row tile over eight workgroups with
  *          the weights resident in registers (default 1; see dppo_sample_chain_workspace_bytes) or over one (0)
  * knob 28: knob 27's kernel: 64-cycle sleep periods between a workgroup's exchange store and its first sweep (default 4)
+ * knob 31: weight-gradient GEMMs of one-block bf16 networks (merged forward + one-block backward + one-hot time columns, no
+ *          cond_mlp, PPO update without d loss / d obs): act(h_0), act(z1), dz1, dh_0 are written by the fused kernels as
+ *          K-major MFMA operand fragments and contracted without any transpose (1), or row-major through the transposing
+ *          LDS kernel (0, default: the fragment form is parity-green but not faster yet)
+ * knob 32: 0 (default): the fragments of a workgroup's tile are fetched once per k-step by LDS-DMA into a four-stage ring and
+ *          read back by its four waves; 2..4: every wave loads its own fragments into registers, that many k-steps ahead
+ * knob 33: k-steps (of 32 batch rows) the fragment GEMM's L2 prefetch runs ahead of its ring loads (default 12)
  * knob 30: minibatch rows per output column from which the top block's weight gradient is taken low-rank (knob 16) and the
  *          one-block backward (knob 23) runs: M >= value x out_dim (default 100)
  * knob 29: knob 27's kernel: sweeps a workgroup waits for its tile before it gives up (default 2^20; tests force a time-out

@@ -595,7 +595,8 @@ def test_fused_path_matches_layered_path(prec, tol, sname):
 
 @pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
 @pytest.mark.parametrize("sname,knob", [("hopper", 22), ("can", 22), ("halfcheetah", 22), ("can_relu", 22), ("hopper", 23),
-                                        ("can", 23), ("square_like", 23), ("hopper", 25), ("halfcheetah", 25)])
+                                        ("can", 23), ("square_like", 23), ("hopper", 25), ("halfcheetah", 25), ("hopper", 31),
+                                        ("halfcheetah", 31), ("can", 31)])
 def test_one_block_kernels_match_the_general_ones(prec, tol, sname, knob):
     """One-block networks have their own fused kernels.  Knob 22: the forward folds the block's second layer into the out
     layer and the out-layer weight gradient is rebuilt from d_out^T x and d_out^T act(z1) (hopper: actor and critic; halfcheetah
@@ -603,7 +604,9 @@ def test_one_block_kernels_match_the_general_ones(prec, tol, sname, knob):
     Wout W2 fragments ride the weight ring, and the critic).  Knob 23: the backward adds dh_1 = d_out . Wout last instead of carrying it,
     in forward-sized tiles, and the second layer's bias gradient comes from colsum(d_out) . Wout (every one-block network
     once the minibatch is large enough for the low-rank dW2).  Knob 25: both walk their short layers without the weight
-    stream's padding k-steps (bit-identical arithmetic: the skipped k-steps multiply zeros).  Same log-probs, values, loss
+    stream's padding k-steps (bit-identical arithmetic: the skipped k-steps multiply zeros).  Knob 31 (bf16): act(h_0), act(z1),
+    dz1, dh_0 travel to the weight-gradient GEMMs as K-major MFMA fragments written by the fused kernels, contracted by the
+    LDS-free gemm_tn_frag_kernel (same operand bits; only the fp32 summation order over the batch differs).  Same log-probs, values, loss
     statistics and gradients -- tensor by tensor -- as the general kernels."""
     from dppo_amd import hip
     lib = hip.load()
@@ -612,6 +615,7 @@ def test_one_block_kernels_match_the_general_ones(prec, tol, sname, knob):
     R, N, Kft = 800, 6500, 10  # N >= 200 x out_dim: the low-rank dW2 (and with it the one-block backward) is on
     AF = a.horizon_steps * a.action_dim
     out = {}
+    default = 0 if knob == 31 else 1  # (knob 31 ships off: see csrc/api.hip g_frag)
     try:
         for merged in (1, 0):
             lib.dppo_tune_set(knob, merged)
@@ -633,7 +637,7 @@ def test_one_block_kernels_match_the_general_ones(prec, tol, sname, knob):
                     grads[(tag, k)] = gv.detach().cpu().numpy().copy()
             out[merged] = (logp.cpu().numpy(), val.cpu().numpy(), st, grads)
     finally:
-        lib.dppo_tune_set(knob, 1)
+        lib.dppo_tune_set(knob, default)
         for net in (m.actor, m.actor_ft, m.critic):
             net.mark_updated()
     lp1, v1, s1, g1 = out[1]
