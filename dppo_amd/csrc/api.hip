@@ -382,6 +382,10 @@ struct MlpBufs {  // activations of one network for M rows
   // K-major fragment mode (gemm.h GemmTNFrag; frag_ok()): the four tensors only the weight-gradient GEMMs read are written
   // as MFMA operand fragments by the one-block fused kernels -- into the SAME buffers a1[0], a2[0], dz1_all[0], dh_all[0]
   // (carved with rows rounded up to whole tiles) -- and the two small operands get fragment copies
+  // Folded tail (gemm.h: GemmTN::red_cnt, GemmTNExtra; knob 35): the slab reductions happen inside the GEMM launch (last
+  // workgroup to arrive at an output tile) and the bias sums / loss statistics ride in it, so no reduction launch follows
+  bool fold;          // set by the caller between carve and backward: red_cnt was zeroed in this call (row builder)
+  unsigned* red_cnt;  // [RED_CNT] tile arrival counters, right behind post_counter (zeroed with it, left zero)
   bool allow_frag;  // set by the caller between carve and forward: the whole pass (forward, backward, GEMMs) may run in it
   bool frag;        // decided by the forward (allow_frag && merged), obeyed by the backward
   u32x4* doutf;     // [ks][dof_nt][64]
@@ -403,6 +407,7 @@ struct MlpBufs {  // activations of one network for M rows
 };
 
 constexpr int REDUCE_BLOCKS = 256;
+constexpr int RED_CNT = 192;  // tile counters of the folded slab reduction: with post_counter 97 doubles, one row-builder zero array
 
 static bool lowrank_top(const dppo_net_desc& d, int64_t M);
 // the one-block backward kernel writes no dh_nb tensor: it needs the low-rank dW2
@@ -477,7 +482,8 @@ static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, b
     B.part = (float*)c.take(B.part_floats * 4);
     B.lowrank = (float*)c.take((size_t)round_up(d.out_dim, 16) * H * 4);
     B.lowrank_u = (float*)c.take((size_t)round_up(d.out_dim, 16) * Kp0 * 4);
-    B.post_counter = (double*)c.take(8);
+    B.post_counter = (double*)c.take(8 + RED_CNT * 4);
+    B.red_cnt = (unsigned*)(B.post_counter + 1);
     B.post_zeroed = false;
     B.w0T = c.take((size_t)round_up(d.cond_dim > 0 ? d.cond_dim : 1, 16) * H * ES);
     B.dobs = (float*)c.take((size_t)M * round_up(d.cond_dim > 0 ? d.cond_dim : 1, 16) * 4);
@@ -679,6 +685,12 @@ static bool lowrank_top(const dppo_net_desc& d, int64_t M) {
 // the transposing kernel (DESIGN.md section 13 has the knock-out measurements: 43 us skeleton + 52 us HBM stream + 23 us ring,
 // adding up instead of overlapping)
 static int g_frag = 0;
+// tuning knob 35: slab reductions folded into the grouped weight-gradient GEMM launch (no tail_reduce launch).  OFF by default:
+// correct (160 parity tests with it on) but slower -- the launch goes from 107 to 200 us per step (both networks): a tile's LAST
+// workgroup sums splits x 64 KB alone (1 MB for an H x H tile, 16 such workgroups at the very end of the launch, each at one
+// CU's ~25 GB/s), where tail_reduce_kernel puts the whole chip on the same 22 MB for 17 us.  (With release / acquire fences
+// instead of sc1 stores it was 589 us: buffer_wbl2 flushes the XCD's whole L2 once per wave.)
+static int g_fold = 0;
 // Time-embedding gradient through the first layer's weight-gradient GEMM: with a one-hot of the row's denoising step k in
 // the K padding of the input rows, dW0's extra columns are S[h][k] = sum over the rows of step k of dh0[row][h], and
 // d loss / d temb[k] = W0[:, temb columns]^T S[:, k] -- no second pass over dh0, no segmented reduction (tuning knob 11).
@@ -709,7 +721,8 @@ template <class P>
 static void flush_slabs(MlpBufs<P>& B, hipStream_t s, const SlotOuts* slots = nullptr, int slot_width = 0,
                         const LossArgs* fin = nullptr) {
   // slots / fin: the fused backward's per-tile column sums and the loss statistics ride in the reduction launch (see
-  // tail_reduce_kernel)
+  // tail_reduce_kernel) -- or, with the folded tail, in the GEMM launch itself, and there is no reduction launch
+  bool folded = false;
   if (B.tn_group.n > 0) {
     GemmTNGroup& gr = B.tn_group;
     for (int i = 1; i < gr.n; ++i)  // longest row ranges first (insertion sort: the short jobs fill the last round)
@@ -718,8 +731,39 @@ static void flush_slabs(MlpBufs<P>& B, hipStream_t s, const SlotOuts* slots = nu
         gr.j[k] = gr.j[k - 1], gr.j[k - 1] = t;
       }
     gr.base[0] = 0;
-    for (int i = 0; i < gr.n; ++i)
-      gr.base[i + 1] = gr.base[i] + gr.j[i].splits * ((gr.j[i].N1 + 127) / 128) * ((gr.j[i].N2 + 127) / 128);
+    int tiles_total = 0;
+    for (int i = 0; i < gr.n; ++i) {
+      const int tiles = ((gr.j[i].N1 + 127) / 128) * ((gr.j[i].N2 + 127) / 128);
+      gr.base[i + 1] = gr.base[i] + gr.j[i].splits * tiles;
+      tiles_total += tiles;
+    }
+    memset(&gr.ex, 0, sizeof(gr.ex));
+    // Folded tail: possible when this flush reduces exactly this group's slabs (no GEMM was launched outside the group since
+    // the last flush) and the caller's row builder zeroed the tile counters
+    int n_group_slabs = 0;
+    for (int i = 0; i < gr.n; ++i) n_group_slabs += gr.j[i].red_n2a >= 0 ? 2 : 1;
+    folded = g_fold && B.fold && (slots != nullptr || fin != nullptr) && tiles_total <= RED_CNT &&
+             n_group_slabs == B.slab_jobs.n && !(g_dbg & 28) && (slots == nullptr || slots->n_slots <= TN_MAX_SLOTS);
+    if (folded) {
+      int cnt0 = 0;
+      for (int i = 0; i < gr.n; ++i) {
+        gr.j[i].red_cnt = B.red_cnt + cnt0;
+        cnt0 += ((gr.j[i].N1 + 127) / 128) * ((gr.j[i].N2 + 127) / 128);
+      }
+      GemmTNExtra& e = gr.ex;
+      if (slots != nullptr && slots->n_slots > 0) {
+        e.colsum = B.tile_colsum, e.tiles = B.tiles, e.width = slot_width, e.n_slots = slots->n_slots;
+        e.slot_bx = (slot_width + 15) / 16, e.n_slot_blocks = e.n_slots * e.slot_bx;
+        for (int i = 0; i < slots->n_slots; ++i) e.slot_out[i] = slots->out[i], e.slot_n[i] = slots->n[i];
+      }
+      if (fin != nullptr && fin->N > 0) {
+        e.fin_partial = fin->partial, e.fin_blocks = loss_blocks(fin->N), e.fin_moments = fin->moments, e.fin_stats = fin->stats;
+        e.fin_part = fin->part, e.fin_n_count = fin->n_count;
+      }
+      e.n_blocks = (e.n_slot_blocks + (e.fin_stats != nullptr ? 1 : 0) + 7) / 8 * 8;  // (keeps the GEMM tiles' block id = XCD map)
+    } else {
+      for (int i = 0; i < gr.n; ++i) gr.j[i].red_cnt = nullptr;
+    }
     launch_gemm_tn_group<P>(gr, s);
     gr.n = 0;
   }
@@ -737,7 +781,9 @@ static void flush_slabs(MlpBufs<P>& B, hipStream_t s, const SlotOuts* slots = nu
   }
   for (int i = 0; i < B.n_join; ++i) join_side(s, B.join_s[i], B.join_idx[i]);
   B.n_join = 0;
-  if (slots != nullptr || fin != nullptr) {
+  if (folded) {
+    // everything a reduction launch would do has been done by the GEMM launch
+  } else if (slots != nullptr || fin != nullptr) {
     TailReduce t;
     memset(&t, 0, sizeof(t));
     t.jobs = B.slab_jobs;
@@ -767,15 +813,16 @@ static void weight_grad(const void* A, int lda, int N1, const void* Bm, int ldb,
   }
   const bool group = defer && g_tn_group;  // launched with the caller's other GEMMs, 128 x 128 tiles throughout
   const bool thin = !group && gemm_tn_thin(N1, N2);
+  const size_t N1s = (size_t)round_up(N1, 4);  // (the folded reduction's transposed slabs pad N1 to whole 16-byte pieces)
   const size_t tiles = thin ? (size_t)((N1 + 511) / 512) : (size_t)((N1 + 127) / 128) * ((N2 + 127) / 128);
   int64_t splits = (g_tn_target + tiles - 1) / tiles;
   const int64_t max_splits = (M + 63) / 64;
   if (splits > max_splits) splits = max_splits;
   if (splits > g_tn_max_splits) splits = g_tn_max_splits;
-  if ((size_t)splits * N1 * N2 > B.slab_floats - B.slab_used || B.slab_jobs.n + 2 > MAX_SLAB_JOBS ||
+  if ((size_t)splits * N1s * N2 > B.slab_floats - B.slab_used || B.slab_jobs.n + 2 > MAX_SLAB_JOBS ||
       B.tn_group.n >= MAX_TN_JOBS)
     flush_slabs(B, s);
-  while (splits > 1 && (size_t)splits * N1 * N2 > B.slab_floats) --splits;
+  while (splits > 1 && (size_t)splits * N1s * N2 > B.slab_floats) --splits;
   if (splits >= 8) splits = splits / 8 * 8;  // a multiple of the XCD count keeps one split's tiles on one XCD
   int64_t rps = (M + splits - 1) / splits;
   rps = (rps + 63) / 64 * 64;
@@ -785,8 +832,11 @@ static void weight_grad(const void* A, int lda, int N1, const void* Bm, int ldb,
   memset(&t, 0, sizeof(t));
   t.A = A, t.B = Bm, t.M = (int)M, t.N1 = N1, t.N2 = N2, t.lda = lda, t.ldb = ldb;
   float* sub = B.slab + B.slab_used;
-  B.slab_used += (size_t)splits * N1 * N2;
+  B.slab_used += (size_t)splits * N1s * N2;
   t.slab = sub, t.ldc = N2, t.splits = (int)splits, t.rows_per_split = (int)rps;
+  // (the folded reduction of flush_slabs(): where this product goes -- exactly what the SlabJob(s) below say)
+  t.red_out = gw, t.red_ldo = ldgw, t.red_transpose = swap ? 1 : 0, t.red_n2a = (n2a >= 0 && !swap) ? n2a : -1;
+  t.red_out2 = gw2, t.red_ldo2 = ldgw2;
   if (group)
     B.tn_group.j[B.tn_group.n++] = t;
   else
@@ -1720,7 +1770,9 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   BuildRows br;
   memset(&br, 0, sizeof(br));
   br.zero_b = W.moments, br.n_zero_b = 32;  // zeroed by the row builder (every statistic has one owner launch that writes it)
-  br.zero_a = W.A.post_counter, br.n_zero_a = 1, W.A.post_zeroed = true;  // post_reduce_kernel's arrival counter
+  // post_reduce_kernel's arrival counter and, behind it, the tile counters of the folded slab reduction (both networks')
+  br.zero_a = W.A.post_counter, br.n_zero_a = 1 + RED_CNT / 2, W.A.post_zeroed = true, W.A.fold = true;
+  br.zero_c = W.C.post_counter, br.n_zero_c = 1 + RED_CNT / 2, W.C.fold = true;
   if (Kft <= 1024) br.loss_tab = W.loss_tab, br.pcfg = pcfg;
   br.inds = inds, br.kinds = kinds, br.chains = chains_k, br.obs = obs_k, br.temb = (const float*)(ak + LA.temb);
   br.ksteps = ksteps;
@@ -1733,6 +1785,7 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   if (split) {
     BuildRows bc = br;  // critic rows only, on the critic's stream
     bc.zero_a = bc.zero_b = nullptr, bc.n_zero_a = bc.n_zero_b = 0, bc.loss_tab = nullptr;
+    br.zero_c = nullptr, br.n_zero_c = 0;  // (the critic's row builder zeroes the critic's counters: its own stream's order)
     bc.inA = nullptr, bc.brow = W.brow_c, bc.krow = nullptr;
     if (obs_c) bc.obs = obs_c;
     bc.cond = cr.cond_dim;
@@ -2584,6 +2637,10 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 32) {  // fragment GEMM: 0 (default) LDS-ring kernel; 2..4 register-only kernel with that lookahead
     set_gemm_tn_frag_depth(value);
+    return 0;
+  }
+  if (knob == 35) {  // the reductions behind the weight-gradient GEMMs inside their launch (1, default) or as a launch of their own (0)
+    g_fold = value;
     return 0;
   }
   if (knob == 34) {  // fragment GEMM, timing experiments (results are wrong while set): 1 no MFMAs, 2 no ring loads, 4 no prefetch

@@ -41,13 +41,39 @@ struct GemmTN {
   // readable columns of a row when they differ from its stride (0 = lda / ldb): rows may OVERLAP -- an im2col operand
   // that is a window of stride C and width k*C over a channel-last image (unet.hip).  Register-staged kernel only.
   int ncol_a, ncol_b;
+  // Folded slab reduction (grouped kernel, red_cnt != null): the workgroup that arrives LAST at an output tile's counter
+  // (one per 128 x 128 tile, zero on entry, left zero) sums the tile's `splits` slabs in the fixed order of
+  // slab_job_block() and writes the result: columns [0, red_n2a) of the product to red_out (ld red_ldo; transposed if
+  // red_transpose), columns [red_n2a, N2) to red_out2 (red_n2a < 0: everything to red_out).  No reduction launch follows.
+  unsigned* red_cnt;
+  float* red_out;
+  float* red_out2;
+  int red_ldo, red_ldo2, red_transpose, red_n2a;
+};
+// Work that only waits for what ran BEFORE the weight-gradient GEMMs rides in their launch as extra workgroups (the first
+// ones of the grid): the per-tile column sums of the fused backward reduced over tiles (bias / LayerNorm-parameter
+// gradients; 16 columns of one slot per workgroup) and the loss statistics (one workgroup).  With the folded slab
+// reduction above nothing is left for a reduction launch behind the GEMMs.
+constexpr int TN_MAX_SLOTS = 50;
+struct GemmTNExtra {
+  int n_blocks;  // extra workgroups in front of the GEMM tiles, a multiple of 8 (0: none)
+  int n_slot_blocks, slot_bx;  // slot s, 16-column group x  <->  block s * slot_bx + x
+  const float* colsum;         // [slots][tiles][width]
+  int tiles, width, n_slots;
+  float* slot_out[TN_MAX_SLOTS];
+  int slot_n[TN_MAX_SLOTS];
+  const double *fin_partial, *fin_moments;  // fin_stats != null: one more block finalises the loss statistics
+  double* fin_stats;
+  int fin_blocks, fin_part;
+  double fin_n_count;
 };
 
 constexpr int MAX_TN_JOBS = 8;
 struct GemmTNGroup {  // one launch over the 128 x 128 tiles of n weight-gradient GEMMs (gemm_tn_group_kernel)
   GemmTN j[MAX_TN_JOBS];
-  int base[MAX_TN_JOBS + 1];  // first workgroup of job i; base[n] = grid size
+  int base[MAX_TN_JOBS + 1];  // first workgroup of job i (counted behind the extra ones); base[n] + ex.n_blocks = grid size
   int n;
+  GemmTNExtra ex;
 };
 
 // ---- weight gradients from K-MAJOR FRAGMENT operands (bf16; gemm_tn_frag_kernel) ---------------------------------------------

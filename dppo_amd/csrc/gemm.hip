@@ -1,5 +1,6 @@
 // See gemm.h.  gfx950 only.
 #include "gemm.h"
+#include "tail_blocks.h"
 
 namespace dppo {
 
@@ -460,6 +461,28 @@ __device__ __forceinline__ void tn_tile(const GemmTN& a, const int split, const 
     __syncthreads();
   }
 
+  if (a.red_cnt != nullptr) {
+    // Folded reduction: the slab is stored TRANSPOSED, [split][n2][n1] with N1 padded to N1p = round_up(N1, 4): a lane's four
+    // values (rows 4g .. 4g+3 of C, one column) are then 16 contiguous bytes, the four lanes g of a column 64 -- and they go
+    // out as write-through (sc1) 16-byte stores, which the tile's last workgroup reads back with sc1 loads: no L2
+    // write-back / invalidate on either side (a release fence per wave here made the launch 5x longer: buffer_wbl2 flushes
+    // the whole XCD's L2 every time).
+    const int N1p = (a.N1 + 3) & ~3;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.slab, 0, (int)((size_t)a.splits * a.N2 * N1p * 4), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < TA; ++i) {
+      const int n1 = fa0 + wa * TA * 16 + i * 16 + 4 * g;
+      if (n1 >= N1p) continue;
+#pragma unroll
+      for (int j = 0; j < TB; ++j) {
+        const int n2 = fb0 + wb * TB * 16 + j * 16 + r;
+        if (n2 < a.N2)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsrc,
+                                                 (int)((((size_t)split * a.N2 + n2) * N1p + n1) * 4), 0, 16);  // aux 16 = sc1
+      }
+    }
+    return;
+  }
   float* out = a.slab + (size_t)split * a.N1 * a.ldc;
 #pragma unroll
   for (int i = 0; i < TA; ++i)
@@ -487,15 +510,72 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN a) {
 // XCD, as above).  No inter-kernel gaps, and the last round of one GEMM is filled by the first of the next.
 template <class P, int NBUF>
 __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_tn_group_kernel(const GemmTNGroup gr) {
+  if ((int)blockIdx.x < gr.ex.n_blocks) {  // riders that depend on nothing in this launch (gemm.h, GemmTNExtra)
+    const GemmTNExtra& e = gr.ex;
+    const int b = blockIdx.x;
+    if (b < e.n_slot_blocks) {
+      const int slot = b / e.slot_bx, x = b - slot * e.slot_bx;
+      if (slot < e.n_slots)
+        slot_reduce_block256(e.colsum + (size_t)slot * e.tiles * e.width, e.tiles, e.width, e.slot_n[slot], e.slot_out[slot], x);
+    } else if (b == e.n_slot_blocks && e.fin_stats != nullptr) {
+      loss_finalize_block256(e.fin_partial, e.fin_blocks, e.fin_moments, e.fin_stats, e.fin_part, e.fin_n_count);
+    }
+    return;
+  }
+  const int bid = blockIdx.x - gr.ex.n_blocks;
   int j = 0;
 #pragma unroll
   for (int i = 1; i < MAX_TN_JOBS; ++i)
-    if (i < gr.n && (int)blockIdx.x >= gr.base[i]) j = i;
+    if (i < gr.n && bid >= gr.base[i]) j = i;
   const GemmTN& a = gr.j[j];
-  const int local = blockIdx.x - gr.base[j];
+  const int local = bid - gr.base[j];
   const int split = local % a.splits, tile = local / a.splits;
   const int tb = (a.N2 + 127) / 128;
-  tn_tile<P, 2, 2, 4, 4, NBUF>(a, split, (tile / tb) * 128, (tile % tb) * 128);
+  const int fa0 = (tile / tb) * 128, fb0 = (tile % tb) * 128;
+  tn_tile<P, 2, 2, 4, 4, NBUF>(a, split, fa0, fb0);
+  if (a.red_cnt == nullptr) return;
+  // ---- folded slab reduction (guide section 6, guideline 16: every handed-off byte an sc1 store drained before ONE relaxed
+  // agent-scope add; the workgroup whose add came last reads with sc1 loads behind its barrier)
+  __shared__ int last_s;
+  DPPO_HANDOVER_DRAIN();
+  __syncthreads();
+  if (threadIdx.x == 0)
+    last_s = __hip_atomic_fetch_add(a.red_cnt + tile, 1u, DPPO_HANDOVER_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)a.splits - 1;
+  __syncthreads();
+  if (!last_s) return;
+  DPPO_HANDOVER_ACQUIRE();
+  if (threadIdx.x == 0) __hip_atomic_store(a.red_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
+  const int N1p = (a.N1 + 3) & ~3;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.slab, 0, (int)((size_t)a.splits * a.N2 * N1p * 4), 0x00020000);
+  const int nr4 = (min(128, N1p - fa0) + 3) / 4, nc = min(128, a.N2 - fb0);  // the tile in units of (4 rows of C, 1 column)
+  const size_t sstride = (size_t)a.N2 * N1p * 4;                             // bytes between two splits' slabs
+  for (int i = threadIdx.x; i < nr4 * nc; i += 256) {
+    const int c = fb0 + i / nr4, r0 = fa0 + (i % nr4) * 4;
+    const size_t off = ((size_t)c * N1p + r0) * 4;
+    f32x4 p[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) p[u] = (f32x4){0.f, 0.f, 0.f, 0.f};  // same summation tree per element as slab_job_block()
+    int k = 0;
+    for (; k + 8 <= a.splits; k += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        p[u] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + (k + u) * sstride), 0, 16));  // sc1
+    }
+    for (; k < a.splits; ++k)
+      p[k & 7] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + k * sstride), 0, 16));
+    const f32x4 v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = r0 + e;
+      if (r >= a.N1) continue;
+      if (a.red_n2a >= 0 && c >= a.red_n2a)
+        a.red_out2[(size_t)r * a.red_ldo2 + (c - a.red_n2a)] = v[e];
+      else if (a.red_transpose)
+        a.red_out[(size_t)c * a.red_ldo + r] = v[e];
+      else
+        a.red_out[(size_t)r * a.red_ldo + c] = v[e];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -701,10 +781,11 @@ void launch_gemm_tn_group(const GemmTNGroup& gr, hipStream_t s) {
     bytes += (double)a.M * (a.N1 + a.N2) * ES + 4.0 * a.N1 * a.N2;  // both operands once + the fp32 result
   }
   const bool probe = probe_begin(PROBE_GEMM_TN, s);
+  const dim3 grid(gr.base[gr.n] + gr.ex.n_blocks);
   if (g_tn_nbuf == 1)
-    hipLaunchKernelGGL((gemm_tn_group_kernel<P, 1>), dim3(gr.base[gr.n]), dim3(256), LDS / 2, s, gr);
+    hipLaunchKernelGGL((gemm_tn_group_kernel<P, 1>), grid, dim3(256), LDS / 2, s, gr);
   else
-    hipLaunchKernelGGL((gemm_tn_group_kernel<P, 2>), dim3(gr.base[gr.n]), dim3(256), LDS, s, gr);
+    hipLaunchKernelGGL((gemm_tn_group_kernel<P, 2>), grid, dim3(256), LDS, s, gr);
   if (probe) probe_end(s, flops, bytes);
 }
 template void launch_gemm_tn_group<F32>(const GemmTNGroup&, hipStream_t);

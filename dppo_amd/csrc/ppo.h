@@ -51,7 +51,8 @@ struct BuildRows {
   dppo_ppo_cfg pcfg;
   double* zero_a;  // n <= 128 each; null / 0 = none
   double* zero_b;
-  int n_zero_a, n_zero_b;
+  double* zero_c;
+  int n_zero_a, n_zero_b, n_zero_c;
 };
 template <class P>
 void launch_build_rows(const BuildRows& a, hipStream_t s);

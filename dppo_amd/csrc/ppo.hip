@@ -182,6 +182,7 @@ __global__ __launch_bounds__(256) void build_rows_kernel(const BuildRows a) {
   if (blockIdx.x == 0) {
     if ((int)threadIdx.x < a.n_zero_a) a.zero_a[threadIdx.x] = 0.0;
     if ((int)threadIdx.x >= 128 && (int)threadIdx.x - 128 < a.n_zero_b) a.zero_b[threadIdx.x - 128] = 0.0;
+    if ((int)threadIdx.x < a.n_zero_c) a.zero_c[threadIdx.x] = 0.0;
     if (a.loss_tab != nullptr)
       for (int k = threadIdx.x; k < a.pcfg.ft_denoising_steps; k += blockDim.x) loss_table_entry(a.pcfg, k, a.loss_tab);
   }

@@ -488,6 +488,9 @@ int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* 
  *          LDS kernel (0, default: the fragment form is parity-green but not faster yet)
  * knob 32: 0 (default): the fragments of a workgroup's tile are fetched once per k-step by LDS-DMA into a four-stage ring and
  *          read back by its four waves; 2..4: every wave loads its own fragments into registers, that many k-steps ahead
+ * knob 35: what follows the weight-gradient GEMMs of a backward pass -- slab sums, bias column sums, loss statistics -- inside
+ *          the GEMM launch (1: the last workgroup at an output tile sums its slabs, the small reductions ride as extra
+ *          workgroups; measured slower, 200 vs 107 + 32 us) or as a launch of its own (0, default)
  * knob 33: k-steps (of 32 batch rows) the fragment GEMM's L2 prefetch runs ahead of its ring loads (default 12)
  * knob 30: minibatch rows per output column from which the top block's weight gradient is taken low-rank (knob 16) and the
  *          one-block backward (knob 23) runs: M >= value x out_dim (default 100)

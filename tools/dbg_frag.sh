@@ -1,4 +1,7 @@
 cd $GRAFT_REPO_ROOT
-for t in "31=1" "31=1,34=1" "31=1,34=2" "31=1,34=4" "31=1,34=6" "31=1,34=3" "31=1,34=7"; do
-  bash tools/ab_trace.sh r3f "$t" "$t" 2>&1 | grep -E "^== |gemm_tn_fragl" | head -2
+mkdir -p gpurun_out/r3i
+python -m pytest tests/test_hip_parity.py tests/test_bf16_parity.py tests/test_full_size.py -q -x > gpurun_out/r3i/t1.log 2>&1; tail -4 gpurun_out/r3i/t1.log
+for t in "35=1" "35=0"; do
+  echo "== $t"; python tools/shape_bench.py --shapes hopper,halfcheetah,can --tune $t 2>&1 | grep -v amdgpu.ids
 done
+bash tools/ab_trace.sh r3i "35=1" "35=0" | grep -v "^ *[0-9]" | head -40
