@@ -615,13 +615,14 @@ def g15_unet_dim40():
 
 
 # ---------------------------------------------------------------- G16 / G17 pixel observations: ViT + SpatialEmb networks
-from make_golden_cases import (VIS_CHAIN_CASES, VIS_FWD_BATCH, VIS_LOSS_CASES, VIS_MSE_CASES, VIS_NETS,  # noqa: E402
+from make_golden_cases import (VIS_ALL_NETS, VIS_C5_CHAIN_CASES, VIS_C5_LOSS_CASES, VIS_C5_NETS,  # noqa: E402
+                               VIS_CHAIN_CASES, VIS_FWD_BATCH, VIS_LOSS_CASES, VIS_MSE_CASES, VIS_NETS,
                                VIS_SPECS)
 
 
 def vis_net_specs(name):
     """(VisSpec, trunk spec on cat[feat, state], critic trunk spec) of a VIS_NETS entry."""
-    vname, kind, kw = VIS_NETS[name]
+    vname, kind, kw = VIS_ALL_NETS[name]
     v = O.VisSpec(**VIS_SPECS[vname])
     cd = v.feat_dim + v.prop_dim
     trunk = O.UnetSpec(cond_dim=cd, **kw) if kind == "unet" else O.NetSpec("actor", cond_dim=cd, residual=True, **kw)
@@ -792,6 +793,69 @@ def g17_vision_loss():
         for k, p in net.named_parameters():
             put_grad(out, f"{cname}_g_{k}", p.grad)
     save("g17_vision_loss", **out)
+
+
+def g21_vision_c5():
+    """BASELINE configs[4] end to end at the shipped shape (VisionUnet1D behind the 96 x 96 ViT + SpatialEmb, ViTCritic, DDIM
+    100 -> 5): network forward, a K-step chain with recorded noise + its log-probs, and PPODiffusion.loss with EVERY gradient
+    (both encoders, both trunks).  Same recipes as g16 / g17, which pin the pieces at smaller shapes."""
+    out = {}
+    rs = np.random.RandomState(2100)
+    for name in VIS_C5_NETS:
+        v, trunk, cspec = vis_net_specs(name)
+        B = 2
+        rgb, state = vis_inputs(rs, v, B)
+        net = ref_vision_actor(v, trunk, O.vision_init_params(v, trunk, 71))
+        cr = ref_vit_critic(v, cspec, O.vision_init_params(v, cspec, 73))
+        x = torch.from_numpy(rs.randn(B, trunk.horizon_steps, trunk.action_dim).astype(np.float32))
+        t = torch.from_numpy(rs.randint(0, 20, size=(B,)).astype(np.int64))
+        with torch.no_grad():
+            y = net(x, t, cond=vis_cond(rgb, state))
+            val = cr(vis_cond(rgb, state))
+        out.update({f"{name}_rgb": rgb, f"{name}_state": state, f"{name}_x": x, f"{name}_t": t, f"{name}_eps": y,
+                    f"{name}_value": val})
+    for cname, (name, B, kw, det) in VIS_C5_CHAIN_CASES.items():
+        m, v, trunk, _ = vision_model(name, 21, clip_ploss_coef=0.01, **kw)
+        n_steps = kw["ddim_steps"] if kw.get("use_ddim") else kw["denoising_steps"]
+        rgb, state = vis_inputs(rs, v, B)
+        noise = torch.from_numpy(rs.randn(n_steps + 1, B, trunk.horizon_steps, trunk.action_dim).astype(np.float32))
+        with recorded_noise(list(noise)):
+            smp = m(cond=vis_cond(rgb, state), deterministic=det, return_chain=True)
+        with torch.no_grad():
+            lp = m.get_logprobs(vis_cond(rgb, state), smp.chains)
+        out.update({f"{cname}_rgb": rgb, f"{cname}_state": state, f"{cname}_noise": noise, f"{cname}_traj": smp.trajectories,
+                    f"{cname}_chains": smp.chains, f"{cname}_logprobs": lp})
+    for cname, (name, N, kw, rh) in VIS_C5_LOSS_CASES.items():
+        m, v, trunk, cspec = vision_model(name, 31, **kw)
+        Kft = kw["ft_denoising_steps"]
+        n_steps = kw["ddim_steps"] if kw.get("use_ddim") else kw["denoising_steps"]
+        rgb, state = vis_inputs(rs, v, N)
+        cond = vis_cond(rgb, state)
+        Ta, Da = trunk.horizon_steps, trunk.action_dim
+        noise = torch.from_numpy(rs.randn(n_steps + 1, N, Ta, Da).astype(np.float32))
+        with recorded_noise(list(noise)):
+            chains = m(cond=cond, deterministic=False, return_chain=True).chains
+        kinds = torch.from_numpy(rs.randint(0, Kft, size=(N,)).astype(np.int64))
+        rows = torch.arange(N)
+        prev, nxt = chains[rows, kinds], chains[rows, kinds + 1]
+        with torch.no_grad():
+            oldlp_all = m.get_logprobs(cond, chains).reshape(N, Kft, Ta, Da)
+            oldlp = oldlp_all[rows, kinds] + torch.from_numpy(rs.normal(0, 0.02, size=(N, Ta, Da)).astype(np.float32))
+            oldv = m.critic(cond).view(-1) + torch.from_numpy(rs.normal(0, 0.3, N).astype(np.float32))
+        ret = torch.from_numpy(rs.normal(0, 1, N).astype(np.float32))
+        adv = torch.from_numpy(rs.normal(0.3, 2.0, N).astype(np.float32))
+        res = m.loss(cond, prev, nxt, kinds, ret, oldv, adv.clone(), oldlp, use_bc_loss=False, reward_horizon=rh)
+        (res[0] + 0.5 * res[2]).backward()
+        out.update({f"{cname}_rgb": rgb, f"{cname}_state": state, f"{cname}_prev": prev, f"{cname}_next": nxt,
+                    f"{cname}_kinds": kinds, f"{cname}_returns": ret, f"{cname}_oldvalues": oldv, f"{cname}_adv": adv,
+                    f"{cname}_oldlogprobs": oldlp, f"{cname}_reward_horizon": rh,
+                    f"{cname}_stats": np.array([res[0].item(), float(res[1]), res[2].item(), res[3], res[4], res[5],
+                                                float(res[6]), res[7]], dtype=np.float64)})
+        for k, p in m.actor_ft.named_parameters():
+            put_grad(out, f"{cname}_gactor_{k}", p.grad)
+        for k, p in m.critic.named_parameters():
+            put_grad(out, f"{cname}_gcritic_{k}", p.grad)
+    save("g21_vision_c5", **out)
 
 
 # ---------------------------------------------------------------- G18 Gaussian policy on pixel observations
@@ -1011,6 +1075,6 @@ def g10_scheduler():
 if __name__ == "__main__":
     only = sys.argv[1:]  # e.g. `make_golden.py g8_bc` regenerates one file (each generator owns its RNG stream)
     for fn in (g1_tables, g2_forward, g3_g4_chains, g5_loss, g6_reward_scaler, g7_adamw, g8_bc, g9_denoise_mse, g10_scheduler, g11_eval, g12_gaussian, g13_unet, g14_unet_loss, g15_unet_dim40, g16_vision,
-               g17_vision_loss, g18_vision_gaussian, g19_plain_mlp, g20_gmm):
+               g17_vision_loss, g18_vision_gaussian, g19_plain_mlp, g20_gmm, g21_vision_c5):
         if not only or fn.__name__ in only:
             fn()

@@ -112,6 +112,26 @@ VIS_LOSS_CASES = {
 }
 VIS_MSE_CASES = {"vmlp_mse": ("vmlp_small", 20, 16), "vunet_mse": ("vunet_small", 20, 12)}
 
+# BASELINE configs[4] END TO END at its shipped shape (cfg/robomimic/finetune/square/ft_ppo_diffusion_unet_img.yaml:17-25,
+# 97-139): one 96 x 96 camera, ViT (patch 8, depth 1, 128 wide, 4 heads) + SpatialEmb 128, VisionUnet1D dim 64, mults (1, 2),
+# kernel 5, 8 groups, step embedding 32, Da 7, Ta 4, DDIM 100 -> 5 with EtaFixed, ViTCritic.  Its own fixture file
+# (g21_vision_c5.npz: the entries above keep their files and random streams).
+VIS_C5_NETS = {
+    "vunet_square": ("vis_square", "unet", dict(action_dim=7, horizon_steps=4, diffusion_step_embed_dim=32, dim=64, dim_mults=(1, 2),
+                                                kernel_size=5, n_groups=8, smaller_encoder=False, cond_predict_scale=True)),
+}
+VIS_C5_CHAIN_CASES = {
+    "vunet_square_ddim100_5": ("vunet_square", 2, dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
+                                                      randn_clip_value=3, min_sampling_denoising_std=0.1,
+                                                      min_logprob_denoising_std=0.1), False),
+}
+VIS_C5_LOSS_CASES = {
+    "vunet_square_loss": ("vunet_square", 4, dict(denoising_steps=100, ft_denoising_steps=5, use_ddim=True, ddim_steps=5,
+                                                 clip_ploss_coef=0.01, clip_ploss_coef_base=0.001, clip_ploss_coef_rate=3,
+                                                 min_sampling_denoising_std=0.1, min_logprob_denoising_std=0.1), 4),
+}
+VIS_ALL_NETS = dict(VIS_NETS, **VIS_C5_NETS)
+
 # Gaussian policy on pixels (Gaussian_VisionMLP + ViTCritic): name -> (vis spec, trunk kwargs, model kwargs)
 VIS_GAUSS_CASES = {
     # cfg/robomimic/finetune/can/ft_ppo_gaussian_mlp_img.yaml:98-124 at small maps: learned std from 0.1, residual 512 trunk

@@ -6,8 +6,8 @@ import pytest
 import torch
 
 from oracle import dppo_oracle as O
-from tests.golden.make_golden_cases import (VIS_CHAIN_CASES, VIS_FWD_BATCH, VIS_LOSS_CASES, VIS_MSE_CASES, VIS_NETS,
-                                            VIS_SPECS)
+from tests.golden.make_golden_cases import (VIS_ALL_NETS, VIS_C5_CHAIN_CASES, VIS_C5_LOSS_CASES, VIS_C5_NETS, VIS_CHAIN_CASES,
+                                            VIS_FWD_BATCH, VIS_LOSS_CASES, VIS_MSE_CASES, VIS_NETS, VIS_SPECS)
 from tests.test_oracle_golden import check_grad, make_cfg
 
 T = torch.from_numpy
@@ -15,12 +15,29 @@ T = torch.from_numpy
 
 def net_specs(name):
     """(VisSpec, trunk spec on cat[feat, state], critic trunk spec) of a VIS_NETS entry (as tests/golden/make_golden.py)."""
-    vname, kind, kw = VIS_NETS[name]
+    vname, kind, kw = VIS_ALL_NETS[name]
     v = O.VisSpec(**VIS_SPECS[vname])
     cd = v.feat_dim + v.prop_dim
     trunk = O.UnetSpec(cond_dim=cd, **kw) if kind == "unet" else O.NetSpec("actor", cond_dim=cd, residual=True, **kw)
     critic = O.NetSpec("critic", cond_dim=cd, mlp_dims=[256, 256, 256], activation="Mish", residual=True)
     return v, trunk, critic
+
+
+# BASELINE configs[4] at its shipped shape rides through the same tests from its own fixture file (g21_vision_c5.npz)
+ALL_CHAIN_CASES = dict(VIS_CHAIN_CASES, **VIS_C5_CHAIN_CASES)
+ALL_LOSS_CASES = dict(VIS_LOSS_CASES, **VIS_C5_LOSS_CASES)
+
+
+def fwd_file(name):
+    return "g21_vision_c5" if name in VIS_C5_NETS else "g16_vision"
+
+
+def chain_file(case):
+    return "g21_vision_c5" if case in VIS_C5_CHAIN_CASES else "g16_vision"
+
+
+def loss_file(case):
+    return "g21_vision_c5" if case in VIS_C5_LOSS_CASES else "g17_vision_loss"
 
 
 def cond_of(g, key):
@@ -46,9 +63,9 @@ def test_oracle_vit_and_spatial_emb(golden, vname):
     np.testing.assert_allclose(z.numpy(), g[f"{vname}_z"], rtol=2e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize("name", sorted(VIS_NETS))
+@pytest.mark.parametrize("name", sorted(VIS_ALL_NETS))
 def test_oracle_vision_networks_forward(golden, name):
-    g = golden("g16_vision")
+    g = golden(fwd_file(name))
     v, trunk, cspec = net_specs(name)
     pa, pc = O.vision_init_params(v, trunk, 71), O.vision_init_params(v, cspec, 73)
     with torch.no_grad():
@@ -58,10 +75,10 @@ def test_oracle_vision_networks_forward(golden, name):
     np.testing.assert_allclose(val.numpy(), g[f"{name}_value"], rtol=2e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize("case", sorted(VIS_CHAIN_CASES))
+@pytest.mark.parametrize("case", sorted(ALL_CHAIN_CASES))
 def test_oracle_vision_chains_and_logprobs(golden, case):
-    g = golden("g16_vision")
-    name, B, kw, det = VIS_CHAIN_CASES[case]
+    g = golden(chain_file(case))
+    name, B, kw, det = ALL_CHAIN_CASES[case]
     v, trunk, _ = net_specs(name)
     spec = O.VisionSpec(v, trunk)
     cfg = make_cfg(trunk, dict(kw))
@@ -74,10 +91,10 @@ def test_oracle_vision_chains_and_logprobs(golden, case):
     np.testing.assert_allclose(lp.numpy(), g[f"{case}_logprobs"], rtol=3e-4, atol=3e-4)
 
 
-@pytest.mark.parametrize("case", sorted(VIS_LOSS_CASES))
+@pytest.mark.parametrize("case", sorted(ALL_LOSS_CASES))
 def test_oracle_vision_ppo_loss_and_grads(golden, case):
-    g = golden("g17_vision_loss")
-    name, N, kw, rh = VIS_LOSS_CASES[case]
+    g = golden(loss_file(case))
+    name, N, kw, rh = ALL_LOSS_CASES[case]
     v, trunk, cspec = net_specs(name)
     cfg = make_cfg(trunk, dict(kw, gamma_denoising=0.99, randn_clip_value=3))
     base = O.vision_init_params(v, trunk, 31)
@@ -186,9 +203,9 @@ def test_hip_visual_encoder(golden, vname, prec, tol):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec,tol", [("fp32", 3e-4), ("bf16", 6e-2)])
-@pytest.mark.parametrize("name", sorted(VIS_NETS))
+@pytest.mark.parametrize("name", sorted(VIS_ALL_NETS))
 def test_hip_vision_networks_forward(golden, name, prec, tol):
-    g = golden("g16_vision")
+    g = golden(fwd_file(name))
     v, trunk, cspec = net_specs(name)
     a = hip_vision_actor(v, trunk, O.vision_init_params(v, trunk, 71), prec)
     c = hip_vit_critic(v, cspec, O.vision_init_params(v, cspec, 73), prec)
@@ -217,12 +234,12 @@ def hip_vision_model(name, seed, prec, kw):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-@pytest.mark.parametrize("case", sorted(VIS_CHAIN_CASES))
+@pytest.mark.parametrize("case", sorted(ALL_CHAIN_CASES))
 def test_hip_vision_chains_and_logprobs(golden, case, prec):
     """K-step sampling with recorded noise and the log-probs of the reference's chains, pixels in; the frozen and the fine-tuned
     network each encode with their own ViT (vunet_two_ddpm20_ft10 switches networks mid-chain)."""
-    g = golden("g16_vision")
-    name, B, kw, det = VIS_CHAIN_CASES[case]
+    g = golden(chain_file(case))
+    name, B, kw, det = ALL_CHAIN_CASES[case]
     m, v, trunk, _ = hip_vision_model(name, 21, prec, dict(kw, clip_ploss_coef=0.01))
     cond = cuda_cond(g, case, u8=True)
     smp = m(cond=cond, deterministic=det, return_chain=True, noise=T(g[f"{case}_noise"]).cuda())
@@ -282,12 +299,12 @@ def test_hip_encoder_backward_against_autograd(vname, prec, mfma):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", sorted(VIS_LOSS_CASES))
+@pytest.mark.parametrize("case", sorted(ALL_LOSS_CASES))
 def test_hip_vision_ppo_loss_and_grads(golden, case):
     """PPODiffusion.loss with pixel networks (fp32): statistics and EVERY gradient -- ViT, SpatialEmb and trunk of the
     fine-tuned actor and of the critic -- against the reference's autograd."""
-    g = golden("g17_vision_loss")
-    name, N, kw, rh = VIS_LOSS_CASES[case]
+    g = golden(loss_file(case))
+    name, N, kw, rh = ALL_LOSS_CASES[case]
     m, v, trunk, cspec = hip_vision_model(name, 31, "fp32", kw)
     d = lambda k: T(g[f"{case}_{k}"]).cuda()
     res = m.loss(cuda_cond(g, case, u8=True), d("prev"), d("next"), d("kinds"), d("returns"), d("oldvalues"), d("adv"),
@@ -432,8 +449,8 @@ def test_hip_vision_ppo_loss_bf16(golden, case):
     of a few samples, and with 16-24 samples in the fixture two flips move the cosine against the reference's gradient a
     long way (measured 0.44 and 0.27 for two roundings of the same forward; the state path's N = 50,000 test holds 0.995:
     tests/test_bf16_parity.py), so there only the sign is asserted."""
-    g = golden("g17_vision_loss")
-    name, N, kw, rh = VIS_LOSS_CASES[case]
+    g = golden(loss_file(case))
+    name, N, kw, rh = ALL_LOSS_CASES[case]
     m, v, trunk, cspec = hip_vision_model(name, 31, "bf16", kw)
     d = lambda k: T(g[f"{case}_{k}"]).cuda()
     res = m.loss(cuda_cond(g, case, u8=True), d("prev"), d("next"), d("kinds"), d("returns"), d("oldvalues"), d("adv"),

@@ -36,6 +36,51 @@ def build(kind, prec, dev):
                         eta=EtaFixed(base_eta=1.0), precision=prec)
 
 
+# ---- algorithmic FLOP of the shipped square image cfgs (necessary evaluations only; 2 FLOP per multiply-add) -------------------
+def encoder_mflop():
+    """One 96 x 96 frame through VitEncoder (PatchEmbed2: Conv2d(3->128, k8, s4) + ReLU + Conv2d(128->128, k3, s2) -> 121 tokens;
+    one pre-norm layer of 4 heads, MLP 128 -> 512 -> 128) and SpatialEmb (128 channel rows x (121 + 9) -> 128)
+    (reference model/common/vit.py:28-200, modules.py:10-41)."""
+    conv1 = 23 * 23 * 128 * (3 * 8 * 8)
+    conv2 = 121 * 128 * (128 * 9)
+    layer = 121 * 128 * 384 + 2 * 121 * 121 * 128 + 121 * 128 * 128 + 2 * 121 * 128 * 512
+    semb = 128 * 130 * 128
+    return 2.0 * (conv1 + conv2 + layer + semb) / 1e6
+
+
+def trunk_mflop(kind, cond=137, Ta=4, Da=7):
+    """One evaluation of the denoiser trunk on cat[feat, state] (137 wide)."""
+    if kind == "mlp":  # VisionDiffusionMLP: Linear(28 + 32 + 137, 768), one residual block, Linear(768, 28); time MLP 32 -> 64 -> 32
+        H, AF, td = 768, Ta * Da, 32
+        return 2.0 * ((AF + td + cond) * H + 2 * H * H + H * AF + 2 * td * 2 * td) / 1e6
+    # VisionUnet1D (unet.py:330-618): dim 64, mults (1, 2), kernel 5, FiLM scale + bias from [step embedding 32 | cond]
+    g = 32 + cond
+
+    def res(ci, co, T):
+        return T * co * ci * 5 + T * co * co * 5 + g * 2 * co + (T * co * ci if ci != co else 0)
+    f = res(Da, 64, Ta) + res(64, 64, Ta) + (Ta // 2) * 64 * 64 * 3            # level 0 + Downsample1d
+    f += res(64, 128, Ta // 2) + res(128, 128, Ta // 2) + 2 * res(128, 128, Ta // 2)  # level 1, mid
+    f += res(256, 64, Ta // 2) + res(64, 64, Ta // 2) + Ta * 64 * 64 * 4        # up + Upsample1d (ConvTranspose1d k4)
+    f += Ta * 64 * 64 * 5 + Ta * Da * 64 + 32 * 128 * 2                          # final block, 1x1 conv, time MLP
+    return 2.0 * f / 1e6
+
+
+def critic_mflop(cond=137):
+    return 2.0 * (cond * 256 + 2 * 256 * 256 + 256) / 1e6
+
+
+def flops(kind, batch, ms_upd, n_envs, ms_smp, peak_tflops, Kft=5):
+    """bench.py's `pixel` block: FLOP per PPO sample updated (both encoders and both trunks, forward + backward = 3x) and per
+    env observation sampled (ONE encoder pass + Kft trunk evaluations -- the reference re-encodes inside every denoising step and
+    for both networks, unet.py:573, diffusion_vpg.py:148,162), and the fractions of the dense bf16 MFMA peak they amount to."""
+    e = encoder_mflop()
+    upd = 3.0 * (2 * e + trunk_mflop(kind) + critic_mflop())
+    smp = e + Kft * trunk_mflop(kind)
+    return {"mflop_per_sample": upd, "mflop_per_chunk": smp, "encoder_mflop_per_image": e, "trunk_mflop_per_eval": trunk_mflop(kind),
+            "update_frac": batch / (ms_upd * 1e-3) * upd * 1e6 / (peak_tflops * 1e12),
+            "sampler_frac": n_envs / (ms_smp * 1e-3) * smp * 1e6 / (peak_tflops * 1e12)}
+
+
 def timeit(fn, n=10, warm=2):
     for _ in range(warm):
         fn()
