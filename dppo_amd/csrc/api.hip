@@ -102,13 +102,22 @@ struct PackLayout {  // byte offsets into the packed image
   int Kpc, C1p, Ep;  // cond_mlp: padded K of the encoder layers (cond, hidden) and padded encoder width
 };
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+// Width of a network's input rows x (and of the row-major first-layer operand): in_dim padded to 64 -- and, for a denoiser,
+// with at least 24 spare columns behind in_dim: the one-hot of the row's denoising step lives there (temb_onehot_col), and
+// without room for it the time-embedding gradient costs a gemm_nt over all rows, a segmented sum and two more launches
+// (halfcheetah: in_dim 57, 7 spare of 64: +40 us per update until the rows became 128 wide).
+static int row_kp0(const dppo_net_desc& d) {
+  int k = round_up(d.in_dim, 64);
+  if (d.kind == 0 && k - d.in_dim < 24) k += 64;
+  return k;
+}
 template <class P>
 static PackLayout pack_layout(const dppo_net_desc& d, int n_time) {
   PackLayout L;
   memset(&L, 0, sizeof(L));
   const size_t ES = P::ESIZE;
   const int H = d.hidden;
-  L.Kp0 = round_up(d.in_dim, 64);
+  L.Kp0 = row_kp0(d);
   L.Kpo = round_up(d.out_dim, 64);
   L.tdp = round_up(d.time_dim > 0 ? d.time_dim : 1, 16);
   size_t o = 0;
@@ -420,7 +429,7 @@ template <class P>
 static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, bool bwd, MlpBufs<P>& B) {
   const size_t ES = P::ESIZE;
   const int H = d.hidden, nb = d.n_blocks;
-  const int Kp0 = round_up(d.in_dim, 64), Kpo = round_up(d.out_dim, 64);
+  const int Kp0 = row_kp0(d), Kpo = round_up(d.out_dim, 64);
   memset(&B, 0, sizeof(B));
   B.in = c.take((size_t)M * Kp0 * ES);
   const int nh = keep ? nb + 1 : (nb > 0 ? 2 : 1);

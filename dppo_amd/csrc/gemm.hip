@@ -799,8 +799,10 @@ template void launch_gemm_tn_group<BF16>(const GemmTNGroup&, hipStream_t);
 // dependences, so the loop body is "multiply slot d, refill slot d".
 // Work order inside a job: split index fastest (multiples of 8 => a split's tiles share an XCD and its L2, as in
 // gemm_tn_group_kernel).
+typedef __attribute__((address_space(3))) int lds_int;
 template <int TB, int D>
-__device__ __forceinline__ void tn_frag_wave(const GemmTNFrag& a, const int split, const int ablk, const int bblk, const int lane) {
+__device__ __forceinline__ void tn_frag_wave(const GemmTNFrag& a, const int split, const int ablk, const int bblk, const int lane,
+                                             lds_int* progress) {  // progress: non-null on the wave that paces the prefetcher
   constexpr int TA = 4;
   const int r = lane & 15, g = lane >> 4;
   const int ks0 = split * a.ks_per_split;
@@ -834,6 +836,7 @@ __device__ __forceinline__ void tn_frag_wave(const GemmTNFrag& a, const int spli
 #pragma unroll
     for (int d = 0; d < D; ++d) fetch(d, ks0 + d);
     for (int ks = ks0; ks < ks1; ks += D) {
+      if (progress != nullptr && lane == 0) __hip_atomic_store(progress, ks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         if (ks + d < ks1) {
@@ -1027,8 +1030,14 @@ __global__ __launch_bounds__(320, 2) void gemm_tn_fragl_kernel(const GemmTNFragG
   }
 }
 
+// ... with a fifth, prefetching wave per workgroup (see gemm_tn_fragl_kernel): it fetches this workgroup's share of the row
+// split's fragments a.pfd k-steps ahead of wave 0's progress (an LDS word), by LDS-DMA into a dump slot, and waits for nothing.
 template <int D>
-__global__ __launch_bounds__(256, 2) void gemm_tn_frag_kernel(const GemmTNFragGroup gr) {
+__global__ __launch_bounds__(320, 2) void gemm_tn_frag_kernel(const GemmTNFragGroup gr) {
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  __shared__ __attribute__((aligned(16))) char dump[1024];
+  __shared__ int prog;
   int jn = 0;
 #pragma unroll
   for (int i = 1; i < MAX_TN_JOBS; ++i)
@@ -1038,15 +1047,44 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_frag_kernel(const GemmTNFragGr
   const int split = local % a.splits, tile = local / a.splits;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nbb = ((a.N2 + 16 * a.tb - 1) / (16 * a.tb) + a.wgb - 1) / a.wgb;  // workgroup tiles along B
+  const int nab = ((a.N1 + 63) / 64 + a.wga - 1) / a.wga;
+  const int nbb = ((a.N2 + 16 * a.tb - 1) / (16 * a.tb) + a.wgb - 1) / a.wgb;  // workgroup tiles along A, B
+  const int ks0 = split * a.ks_per_split;
+  int ks1 = ks0 + a.ks_per_split;
+  ks1 = ks1 < a.ks_total ? ks1 : a.ks_total;
+  if (threadIdx.x == 0) prog = ks0;
+  __syncthreads();
+  if (wid == 4) {  // ---- the prefetcher
+    if (a.pfd <= 0 || (a.dbg & 4)) return;
+    const int nAu = min(a.nta, (a.N1 + 15) / 16), nBu = min(a.ntb, (a.N2 + 15) / 16), G = nab * nbb;
+    constexpr int NPW = 8;
+    const int npw = a.npf < NPW ? a.npf : NPW;
+    for (int kp = ks0 + D; kp < ks1; ++kp) {
+      // stay at most pfd k-steps ahead of wave 0 (which may itself have left already: then run to the end)
+      while (kp - __hip_atomic_load((lds_int*)&prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > a.pfd + D) __builtin_amdgcn_s_sleep(8);
+      for (int i = 0; i < npw; ++i) {
+        int f = tile + G * i;
+        if (f >= nAu + nBu) break;
+        const bool isA = f < nAu;
+        const u32x4* src = (isA ? a.A + ((size_t)kp * a.nta + f) * 64 : a.B + ((size_t)kp * a.ntb + (f - nAu)) * 64) + lane;
+        __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)dump, 16, 0, 0);
+      }
+    }
+    return;
+  }
   const int ablk = (tile / nbb) * a.wga + wid % a.wga, bblk = (tile % nbb) * a.wgb + wid / a.wga;
-  if (ablk * 64 >= a.N1 || bblk * 16 * a.tb >= a.N2) return;
+  if (ablk * 64 >= a.N1 || bblk * 16 * a.tb >= a.N2) {
+    if (wid == 0 && lane == 0) prog = 0x3fffffff;  // (nothing to pace: let the prefetcher run out)
+    return;
+  }
+  lds_int* pp = wid == 0 ? (lds_int*)&prog : nullptr;
   if (a.tb == 4)
-    tn_frag_wave<4, D>(a, split, ablk, bblk, lane);
+    tn_frag_wave<4, D>(a, split, ablk, bblk, lane, pp);
   else if (a.tb == 2)
-    tn_frag_wave<2, D>(a, split, ablk, bblk, lane);
+    tn_frag_wave<2, D>(a, split, ablk, bblk, lane, pp);
   else
-    tn_frag_wave<1, D>(a, split, ablk, bblk, lane);
+    tn_frag_wave<1, D>(a, split, ablk, bblk, lane, pp);
+  if (wid == 0 && lane == 0) __hip_atomic_store((lds_int*)&prog, 0x3fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 int gemm_tn_frag_blocks(const GemmTNFrag& j) {
   const int nab = ((j.N1 + 63) / 64 + j.wga - 1) / j.wga;
@@ -1091,11 +1129,11 @@ void launch_gemm_tn_frag_group(const GemmTNFragGroup& gr, int64_t M, hipStream_t
     }
     hipLaunchKernelGGL(gemm_tn_fragl_kernel, grid, dim3(320), TN_FRAGL_LDS, s, gr);
   } else if (g_tn_frag_depth == 2)
-    hipLaunchKernelGGL((gemm_tn_frag_kernel<2>), grid, dim3(256), 0, s, gr);
+    hipLaunchKernelGGL((gemm_tn_frag_kernel<2>), grid, dim3(320), 0, s, gr);
   else if (g_tn_frag_depth == 4)
-    hipLaunchKernelGGL((gemm_tn_frag_kernel<4>), grid, dim3(256), 0, s, gr);
+    hipLaunchKernelGGL((gemm_tn_frag_kernel<4>), grid, dim3(320), 0, s, gr);
   else
-    hipLaunchKernelGGL((gemm_tn_frag_kernel<3>), grid, dim3(256), 0, s, gr);
+    hipLaunchKernelGGL((gemm_tn_frag_kernel<3>), grid, dim3(320), 0, s, gr);
   if (probe) probe_end(s, flops, bytes);
 }
 

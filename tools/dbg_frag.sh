@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3i
-python -m pytest tests/test_hip_parity.py tests/test_bf16_parity.py tests/test_full_size.py -q -x > gpurun_out/r3i/t1.log 2>&1; tail -4 gpurun_out/r3i/t1.log
-for t in "35=1" "35=0"; do
-  echo "== $t"; python tools/shape_bench.py --shapes hopper,halfcheetah,can --tune $t 2>&1 | grep -v amdgpu.ids
+bash tools/shape_trace.sh r3m halfcheetah | head -24
+python -m pytest tests/test_hip_parity.py -q -x -k "one_block_kernels and 31" 2>&1 | tail -2
+for t in "31=0" "31=1,32=2,33=8" "31=1,32=2,33=16" "31=1,32=3,33=8" "31=1,32=2,33=0" "31=1,32=0,33=12"; do
+  bash tools/ab_trace.sh r3m "$t" "$t" 2>&1 | grep -E "^== |gemm_tn_|one update step" | head -3
 done
-bash tools/ab_trace.sh r3i "35=1" "35=0" | grep -v "^ *[0-9]" | head -40
