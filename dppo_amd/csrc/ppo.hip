@@ -510,8 +510,11 @@ void launch_adv_moments(const float* adv_k, const int32_t* brow, int64_t N, doub
 // Both log-prob sums run over j in ascending order, so unchanged weights still give ratio == 1 exactly.
 constexpr int LOSS_THREADS = 64;
 
+// (NREG = 64: action chunks of 33-64 elements, register cap lifted -- such cfgs have small minibatches, a few hundred one-wave
+// blocks on 256 CUs, so occupancy is no concern.  Wider chunks (transport's 112, furniture's 80 elements) take NREG = 0, whose
+// two passes walk the elements with 16-byte loads: as scalar loads they were 80 us for 10,000 samples.)
 template <class P, int NREG>
-__global__ __launch_bounds__(LOSS_THREADS, 8) void ppo_loss_kernel(const LossArgs a) {
+__global__ __launch_bounds__(LOSS_THREADS, NREG <= 32 ? 8 : 1) void ppo_loss_kernel(const LossArgs a) {
   typedef typename P::elem_t E;
   constexpr int EPC = 16 / P::ESIZE;  // elements per 16-byte chunk of the outputs
   // per-k constants (only Kft distinct values exist): denoising discount and clip range, built once per block in
@@ -582,7 +585,18 @@ __global__ __launch_bounds__(LOSS_THREADS, 8) void ppo_loss_kernel(const LossArg
         }
       } else {
         float gs;
-        for (int j = 0; j < cnt; ++j) element(ch[j], ch[AF + j], ep[j], olp[j], gs);
+        if (vec) {  // (same element order: j ascending)
+          for (int j0 = 0; j0 < cnt; j0 += 4) {
+            const float4 x = *(const float4*)(ch + j0), xn = *(const float4*)(ch + AF + j0);
+            const float4 e = *(const float4*)(ep + j0), o = *(const float4*)(olp + j0);
+            element(x.x, xn.x, e.x, o.x, gs);
+            element(x.y, xn.y, e.y, o.y, gs);
+            element(x.z, xn.z, e.z, o.z, gs);
+            element(x.w, xn.w, e.w, o.w, gs);
+          }
+        } else {
+          for (int j = 0; j < cnt; ++j) element(ch[j], ch[AF + j], ep[j], olp[j], gs);
+        }
       }
       const float newlp = sum_new / (float)cnt, oldlp = sum_old / (float)cnt;
       // ---- advantage: normalise over the minibatch, quantile clip, denoising discount (:129-144)
@@ -646,10 +660,27 @@ __global__ __launch_bounds__(LOSS_THREADS, 8) void ppo_loss_kernel(const LossArg
         const u32x4 z = (u32x4){0, 0, 0, 0};  // cnt <= NREG: everything behind the register chunks is padding
         for (; c < nch; ++c) *(u32x4*)(de + c * EPC) = z;
       } else {
+        auto grad_of = [&](float x, float xn, float e) -> float {
+          float mu, dmu;
+          posterior(a.dcfg, st, x, e, mu, dmu);
+          const float d = xn - mu;
+          const float lp = -(d * d) / (2.f * var) - lstd - DPPO_LOG_SQRT_2PI;
+          return (lp >= -5.f && lp <= 2.f) ? coef * ((d / var) * dmu) : 0.f;
+        };
         for (; c < nch; ++c) {
           float v[EPC];
+          if (vec && (c + 1) * EPC <= cnt) {  // a whole chunk of real elements: 16-byte loads (the same arithmetic as grad_at)
 #pragma unroll
-          for (int q = 0; q < EPC; ++q) v[q] = grad_at(c * EPC + q);
+            for (int q = 0; q < EPC; q += 4) {
+              const int j0 = c * EPC + q;
+              const float4 x = *(const float4*)(ch + j0), xn = *(const float4*)(ch + AF + j0), e = *(const float4*)(ep + j0);
+              v[q] = grad_of(x.x, xn.x, e.x), v[q + 1] = grad_of(x.y, xn.y, e.y);
+              v[q + 2] = grad_of(x.z, xn.z, e.z), v[q + 3] = grad_of(x.w, xn.w, e.w);
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < EPC; ++q) v[q] = grad_at(c * EPC + q);
+          }
           pack_store(de + c * EPC, v);
         }
       }
@@ -759,6 +790,8 @@ void launch_ppo_loss(const LossArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((ppo_loss_kernel<P, 16>), dim3(blocks), dim3(LOSS_THREADS), lds, s, a);
   else if (regs && cnt <= 32)
     hipLaunchKernelGGL((ppo_loss_kernel<P, 32>), dim3(blocks), dim3(LOSS_THREADS), lds, s, a);
+  else if (regs && cnt <= 64)
+    hipLaunchKernelGGL((ppo_loss_kernel<P, 64>), dim3(blocks), dim3(LOSS_THREADS), lds, s, a);
   else
     hipLaunchKernelGGL((ppo_loss_kernel<P, 0>), dim3(blocks), dim3(LOSS_THREADS), lds, s, a);
 }
@@ -919,6 +952,28 @@ __device__ __forceinline__ void wout_grad_block(const PostReduce& q, int b) {
     if (lane == 0) q.db2[out] = acc;
   }
 }
+// dW[i][j] = sum_o Wout[o][i] T[o][j] (the top block's second-layer weight gradient from T = d_out^T act(z1)): a block owns
+// LOWRANK_RI rows i x 256 columns j; a thread loads T[o][j] once per o for its 8 rows (the first form, one output per thread,
+// re-read T for every row: 470 MB from L2 and 40-60 us at H = 1024 with 28-112 outputs)
+constexpr int LOWRANK_RI = 8;
+static int lowrank_dw_blocks(int H) { return ((H + LOWRANK_RI - 1) / LOWRANK_RI) * ((H + 255) / 256); }
+__device__ __forceinline__ void lowrank_dw_block(const float* Wout, const float* T, int out_dim, int H, float* dW, int b) {
+  const int jb = (H + 255) / 256;
+  const int i0 = (b / jb) * LOWRANK_RI, j = (b % jb) * 256 + threadIdx.x;
+  if (j >= H) return;
+  float acc[LOWRANK_RI];
+#pragma unroll
+  for (int u = 0; u < LOWRANK_RI; ++u) acc[u] = 0.f;
+  for (int o = 0; o < out_dim; ++o) {
+    const float t = T[(size_t)o * H + j];
+    const float* w = Wout + (size_t)o * H + i0;  // (wave-uniform: scalar loads)
+#pragma unroll
+    for (int u = 0; u < LOWRANK_RI; ++u) acc[u] += (i0 + u < H ? w[u] : 0.f) * t;
+  }
+#pragma unroll
+  for (int u = 0; u < LOWRANK_RI; ++u)
+    if (i0 + u < H) dW[(size_t)(i0 + u) * H + j] = acc[u];
+}
 static int wout_grad_blocks(const PostReduce& q) {
   return ((q.U != nullptr ? q.out_dim * q.H : 0) + (q.db2 != nullptr ? q.H : 0) + 3) / 4;
 }
@@ -936,12 +991,7 @@ __global__ __launch_bounds__(256) void post_reduce_kernel(const PostReduce q) {
     return;
   }
   if ((int)blockIdx.x < q.n_lowrank) {
-    const size_t idx = (size_t)blockIdx.x * 256 + tid;
-    if (idx >= (size_t)q.H * q.H) return;
-    const int i = (int)(idx / q.H), j = (int)(idx - (size_t)i * q.H);
-    float acc = 0.f;
-    for (int o = 0; o < q.out_dim; ++o) acc += q.Wout[(size_t)o * q.H + i] * q.T[(size_t)o * q.H + j];
-    q.dW[idx] = acc;
+    lowrank_dw_block(q.Wout, q.T, q.out_dim, q.H, q.dW, blockIdx.x);
     return;
   }
   const int tb = blockIdx.x - q.n_lowrank, lane = tid & 63, out = tb * 4 + (tid >> 6);
@@ -976,7 +1026,7 @@ __global__ __launch_bounds__(256) void post_reduce_kernel(const PostReduce q) {
   time_backward_finish(q.G, q.Kft, q.td, q.gw1, q.gb1, q.gw2, q.gb2, sh);
 }
 void launch_post_reduce(PostReduce& q, hipStream_t s) {
-  q.n_lowrank = q.dW != nullptr ? (int)(((size_t)q.H * q.H + 255) / 256) : 0;
+  q.n_lowrank = q.dW != nullptr ? lowrank_dw_blocks(q.H) : 0;
   q.n_temb = q.G != nullptr ? (q.Kft * q.td + 3) / 4 : 0;
   q.n_wout = wout_grad_blocks(q);
   const int blocks = q.n_lowrank + q.n_temb + q.n_wout;
@@ -1257,6 +1307,7 @@ void launch_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, i
 // Wc[o][k] = sum_j Wout[o][j] * W2[j][k]  ([out_dim][H], fp32): the composite layer of the fused backward's top block.
 // One block per (o, 64 columns k): sixteen waves split j, lanes are consecutive k (coalesced rows of W2); eight loads in
 // flight per lane (a plain loop over j is one L2 latency per iteration: 128 of them cost 50 us on the optimiser tail).
+constexpr int COMPOSE_OB = 4;
 __global__ __launch_bounds__(1024) void compose_wc_kernel(const ComposeJobs q) {
   __shared__ float red[16][64];
   const ComposeJob& jb = q.j[blockIdx.z];
@@ -1264,22 +1315,29 @@ __global__ __launch_bounds__(1024) void compose_wc_kernel(const ComposeJobs q) {
   float *Wc = jb.Wc, *cbias = jb.cbias;
   const int H = jb.H, cols = (H + 63) / 64;
   const int cols0 = jb.W0 != nullptr ? (jb.Kp0s + 63) / 64 : 0;
-  if ((int)blockIdx.y >= jb.out_dim || (int)blockIdx.x > cols + cols0) return;  // the grid is sized for the larger network
-  const int o = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // blockIdx.y = a group of COMPOSE_OB outputs o: the 64-column slice of W2 (or W0) a block walks is multiplied into all of
+  // them (one output per block re-read the slice for every o: 112 x at transport's head, 470 MB from L2, 46 us)
+  const int o0 = blockIdx.y * COMPOSE_OB;
+  if (o0 >= jb.out_dim || (int)blockIdx.x > cols + cols0) return;  // the grid is sized for the larger network
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if ((int)blockIdx.x == cols) {  // extra column: cbias[o] = bout[o] + Wout[o] . b2 (the merged out layer's constant)
-    float t = 0.f, t0 = 0.f;      // and cbias2[o] = cbias[o] + Wout[o] . b0
-    for (int j = threadIdx.x; j < H; j += 1024) {
-      t += Wout[(size_t)o * H + j] * b2[j];
-      if (jb.W0 != nullptr) t0 += Wout[(size_t)o * H + j] * jb.b0[j];
-    }
-    for (int d = 32; d > 0; d >>= 1) t += __shfl_down(t, d), t0 += __shfl_down(t0, d);
-    if (lane == 0) red[w][0] = t, red[w][1] = t0;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float u = bout[o], u0 = 0.f;
-      for (int i = 0; i < 16; ++i) u += red[i][0], u0 += red[i][1];
-      cbias[o] = u;
-      if (jb.W0 != nullptr) jb.cbias2[o] = u + u0;
+    for (int oo = 0; oo < COMPOSE_OB && o0 + oo < jb.out_dim; ++oo) {  // and cbias2[o] = cbias[o] + Wout[o] . b0
+      const int o = o0 + oo;
+      float t = 0.f, t0 = 0.f;
+      for (int j = threadIdx.x; j < H; j += 1024) {
+        t += Wout[(size_t)o * H + j] * b2[j];
+        if (jb.W0 != nullptr) t0 += Wout[(size_t)o * H + j] * jb.b0[j];
+      }
+      for (int d = 32; d > 0; d >>= 1) t += __shfl_down(t, d), t0 += __shfl_down(t0, d);
+      __syncthreads();
+      if (lane == 0) red[w][0] = t, red[w][1] = t0;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float u = bout[o], u0 = 0.f;
+        for (int i = 0; i < 16; ++i) u += red[i][0], u0 += red[i][1];
+        cbias[o] = u;
+        if (jb.W0 != nullptr) jb.cbias2[o] = u + u0;
+      }
     }
     return;
   }
@@ -1287,25 +1345,43 @@ __global__ __launch_bounds__(1024) void compose_wc_kernel(const ComposeJobs q) {
   const int k = (first ? (int)blockIdx.x - cols - 1 : (int)blockIdx.x) * 64 + lane;
   const float* Wr = first ? jb.W0 : W2;
   const int ldr = first ? jb.in_dim : H, kmax = first ? jb.in_dim : H;
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // same summation tree per output as before: eight interleaved partial sums over j = w, w + 16, ..., then the 16 waves
+  float acc[COMPOSE_OB][8];
+#pragma unroll
+  for (int oo = 0; oo < COMPOSE_OB; ++oo)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[oo][u] = 0.f;
   if (k < kmax) {
     int j = w;
     for (; j + 7 * 16 < H; j += 8 * 16) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc[u] += Wout[(size_t)o * H + j + 16 * u] * Wr[(size_t)(j + 16 * u) * ldr + k];
-    }
-    for (; j < H; j += 16) acc[0] += Wout[(size_t)o * H + j] * Wr[(size_t)j * ldr + k];
-  }
-  red[w][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-  __syncthreads();
-  if (w == 0) {
-    float t = 0.f;
+      for (int u = 0; u < 8; ++u) {
+        const float r = Wr[(size_t)(j + 16 * u) * ldr + k];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) t += red[i][lane];
-    if (first) {
-      if (k < jb.Kp0s) jb.W0c[(size_t)o * jb.Kp0s + k] = k < kmax ? t : 0.f;
-    } else if (k < H) {
-      Wc[(size_t)o * H + k] = t;
+        for (int oo = 0; oo < COMPOSE_OB; ++oo)
+          acc[oo][u] += Wout[(size_t)(o0 + oo < jb.out_dim ? o0 + oo : o0) * H + j + 16 * u] * r;
+      }
+    }
+    for (; j < H; j += 16) {
+      const float r = Wr[(size_t)j * ldr + k];
+#pragma unroll
+      for (int oo = 0; oo < COMPOSE_OB; ++oo) acc[oo][0] += Wout[(size_t)(o0 + oo < jb.out_dim ? o0 + oo : o0) * H + j] * r;
+    }
+  }
+  for (int oo = 0; oo < COMPOSE_OB && o0 + oo < jb.out_dim; ++oo) {
+    const int o = o0 + oo;
+    __syncthreads();
+    red[w][lane] = ((acc[oo][0] + acc[oo][1]) + (acc[oo][2] + acc[oo][3])) + ((acc[oo][4] + acc[oo][5]) + (acc[oo][6] + acc[oo][7]));
+    __syncthreads();
+    if (w == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t += red[i][lane];
+      if (first) {
+        if (k < jb.Kp0s) jb.W0c[(size_t)o * jb.Kp0s + k] = k < kmax ? t : 0.f;
+      } else if (k < H) {
+        Wc[(size_t)o * H + k] = t;
+      }
     }
   }
 }
@@ -1316,22 +1392,17 @@ void launch_compose(const ComposeJobs& q, hipStream_t s) {
     gx = x > gx ? x : gx;
     rows = q.j[i].out_dim > rows ? q.j[i].out_dim : rows;
   }
-  if (q.n > 0) hipLaunchKernelGGL(compose_wc_kernel, dim3(gx, rows, q.n), dim3(1024), 0, s, q);
+  if (q.n > 0) hipLaunchKernelGGL(compose_wc_kernel, dim3(gx, (rows + COMPOSE_OB - 1) / COMPOSE_OB, q.n), dim3(1024), 0, s, q);
 }
 
 // dW[i][j] = sum_o Wout[o][i] * T[o][j]: the top block's second-layer weight gradient from T = d_out^T . act(z1).
 // d loss / d h_nb = d_out . Wout has rank <= out_dim, so dz2^T . a2 = Wout^T . (d_out^T . a2): a thin contraction over the
 // batch plus this out_dim-deep product replace an H x H contraction over the batch, and dh_nb never goes to HBM.
 __global__ __launch_bounds__(256) void lowrank_dw_kernel(const float* Wout, const float* T, int out_dim, int H, float* dW) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)H * H) return;
-  const int i = (int)(idx / H), j = (int)(idx - (size_t)i * H);
-  float acc = 0.f;
-  for (int o = 0; o < out_dim; ++o) acc += Wout[(size_t)o * H + i] * T[(size_t)o * H + j];
-  dW[idx] = acc;
+  lowrank_dw_block(Wout, T, out_dim, H, dW, blockIdx.x);
 }
 void launch_lowrank_dw(const float* Wout, const float* T, int out_dim, int H, float* dW, hipStream_t s) {
-  hipLaunchKernelGGL(lowrank_dw_kernel, dim3((unsigned)(((size_t)H * H + 255) / 256)), dim3(256), 0, s, Wout, T, out_dim, H, dW);
+  hipLaunchKernelGGL(lowrank_dw_kernel, dim3((unsigned)lowrank_dw_blocks(H)), dim3(256), 0, s, Wout, T, out_dim, H, dW);
 }
 
 // float64 statistics <-> (hi, lo) float32 pairs, so that they can ride in the fp32 gradient bucket of the data-parallel
