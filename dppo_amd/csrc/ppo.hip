@@ -1095,6 +1095,15 @@ __device__ __forceinline__ void slab_job_block(const SlabJob& J) {
     const int r = (int)(i / J.cols), c = (int)(i % J.cols);
     float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // same summation tree as slab_reduce_2d_kernel
     int k = 0;
+    // (32 loads in flight per thread where there are that many slabs: the thin products are split 64 ways, and eight
+    // batches of eight loads were eight memory latencies in a row -- the longest chain of the launch)
+    for (; k + 32 <= J.splits; k += 32) {
+      float t[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) t[u] = J.slab[((size_t)(k + u) * J.rows + r) * J.lds + J.c0 + c];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) p[u & 7] += t[u];  // (p[u] still receives k + u, k + u + 8, ... in this order)
+    }
     for (; k + 8 <= J.splits; k += 8) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) p[u] += J.slab[((size_t)(k + u) * J.rows + r) * J.lds + J.c0 + c];
@@ -1307,7 +1316,7 @@ void launch_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, i
 // Wc[o][k] = sum_j Wout[o][j] * W2[j][k]  ([out_dim][H], fp32): the composite layer of the fused backward's top block.
 // One block per (o, 64 columns k): sixteen waves split j, lanes are consecutive k (coalesced rows of W2); eight loads in
 // flight per lane (a plain loop over j is one L2 latency per iteration: 128 of them cost 50 us on the optimiser tail).
-constexpr int COMPOSE_OB = 4;
+template <int COMPOSE_OB>  // outputs per block: 4 for wide heads (operand reuse), 1 for narrow ones (more, shorter blocks)
 __global__ __launch_bounds__(1024) void compose_wc_kernel(const ComposeJobs q) {
   __shared__ float red[16][64];
   const ComposeJob& jb = q.j[blockIdx.z];
@@ -1392,7 +1401,11 @@ void launch_compose(const ComposeJobs& q, hipStream_t s) {
     gx = x > gx ? x : gx;
     rows = q.j[i].out_dim > rows ? q.j[i].out_dim : rows;
   }
-  if (q.n > 0) hipLaunchKernelGGL(compose_wc_kernel, dim3(gx, (rows + COMPOSE_OB - 1) / COMPOSE_OB, q.n), dim3(1024), 0, s, q);
+  if (q.n <= 0) return;
+  if (rows > 32)
+    hipLaunchKernelGGL(compose_wc_kernel<4>, dim3(gx, (rows + 3) / 4, q.n), dim3(1024), 0, s, q);
+  else
+    hipLaunchKernelGGL(compose_wc_kernel<1>, dim3(gx, rows, q.n), dim3(1024), 0, s, q);
 }
 
 // dW[i][j] = sum_o Wout[o][i] * T[o][j]: the top block's second-layer weight gradient from T = d_out^T . act(z1).
