@@ -13,7 +13,8 @@
  *  - return 0 = ok, <0 = bad argument / unsupported shape (dppo_last_error() has the text),
  *    >0 = hipError_t from a launch;
  *  - state: the error string is thread-local; the tuning knobs (dppo_tune_set) and the measurement probe are
- *    process-wide.  dppo_ppo_loss_fwd_bwd / dppo_bc_loss_fwd_bwd / dppo_denoise_mse_fwd_bwd fork onto library-owned side
+ *    process-wide (plain globals read at launch time: set them before issuing work, never concurrently with it; they
+ *    select between implementations that all pass the same parity tests, the product path never touches them).  dppo_ppo_loss_fwd_bwd / dppo_bc_loss_fwd_bwd / dppo_denoise_mse_fwd_bwd fork onto library-owned side
  *    streams (one set per device, joined back into the caller's stream before they return control of it, capture-safe):
  *    issue at most one such call per device at a time.  Every other entry point is re-entrant across streams.
  *
