@@ -112,6 +112,9 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu rehearses the data-parallel path with several ranks on ONE GPU")
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
+    ap.add_argument("--dp-mode", default="split", choices=["split", "single"],
+                    help="N > 1: gradient bucket all-reduced in two slices, the critic's overlapped with the actor's backward "
+                         "(default), or in one piece behind the update")
     ap.add_argument("--probe", type=int, default=2,
                     help="kernel timed live for `roofline.dominant_kernel`: 2 gemm_tn (weight grads), 3 fused fwd, "
                          "4 fused bwd, 5 sampler")
@@ -407,7 +410,7 @@ def main(argv=None):
         model = build_model(str(device), prec, wl)  # same seed on every rank => identical initial weights
         gen = torch.Generator(device=device).manual_seed(42 + rank)  # env shards differ per rank
         torch.manual_seed(42 + rank)
-        dp = DataParallel(model, nranks)
+        dp = DataParallel(model, nranks, split=(args.dp_mode == "split"))
         ro = make_rollout(model, n_envs, n_steps, device, gen, wl)
         adv_k = ro[4]
         R = n_envs * n_steps
@@ -468,7 +471,25 @@ def main(argv=None):
                 out.append(max_over_ranks(time.perf_counter() - t0) / reps)
             return out
 
-        r = {"model": model, "prec": prec}
+        r = {"model": model, "prec": prec, "dp_mode": None}
+        if nranks > 1:
+            # One untimed step of the data-parallel path before anything is timed.  The two-slice form (critic slice from a
+            # callback inside the library call, on the library's critic stream) has run over gloo only -- RCCL refuses two ranks
+            # on one device, and a builder's box has one GPU -- so if it raises under nccl EVERY rank falls back to the plain
+            # one-bucket all-reduce behind the update (same bits: a SUM is elementwise) and the line says so.
+            ok = torch.ones(1, device=device)
+            try:
+                update_step(0)
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                ok.zero_()
+                print(f"[bench rank {rank}] two-slice all-reduce failed ({type(e).__name__}: {e}); falling back to one bucket",
+                      file=sys.stderr, flush=True)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() == 0 and dp.split:
+                dp.split = False
+                dp._critic_done = False
+            r["dp_mode"] = "two slices (critic slice overlapped from inside the update call)" if dp.split else "one bucket"
         # the sampler leg (secondary): a call is ~0.07 ms, so `steps` calls are timed ten times over in one region (1.4 ms of
         # work gave 26-30 M env-steps/s from run to run); with the per-launch probe on it stays at one pass
         probe_sampler = rank == 0 and probe_id == 5
@@ -616,7 +637,7 @@ def main(argv=None):
                        "rollout_rows_per_gpu": args.n_envs * args.n_steps,
                        "parallelism": f"dp{world} (env-sharded, RCCL grad all-reduce)"},
             "env_steps_per_sec": env_steps_per_s, "sampler_ms_per_call": ms_sample, "chunks_per_sec": chunks_per_s,
-            "allreduce_ms": ar_ms,
+            "allreduce_ms": ar_ms, "dp_mode": main_run.get("dp_mode"),
             "allreduce_exposed_ms": None if main_run.get("dt_update_nocomm") is None else
             (dt_update - main_run["dt_update_nocomm"]) / args.steps * 1e3,
             "allreduce_is": "gradient bucket [critic | actor | stats] SUM-reduced in two slices; allreduce_ms = both alone, "

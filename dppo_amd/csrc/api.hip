@@ -717,7 +717,7 @@ static int temb_onehot_col(const dppo_net_desc& d, const PackLayout& L, int Kft,
 // (its backward reads dh_0 row-major), the caller wants no d loss / d observation, and the backward's LDS holds the extras.
 template <class P>
 static bool frag_ok(const dppo_net_desc& d, int64_t M, const PackLayout& L, int Kft, const MlpBufs<P>& B, bool wants_dobs) {
-  if (!g_frag || P::ESIZE != 2 || wants_dobs || d.cond_hidden > 0 || d.out_dim > 64 || !g_tn_group) return false;
+  if (!g_frag || P::ESIZE != 2 || wants_dobs || d.cond_hidden > 0 || !fused_frag_shape(d) || !g_tn_group) return false;
   if (!fused_ok<P>(d) || B.tiles <= 0 || !fused_can_merge<P>(d) || !bwd_one<P>(d, M)) return false;
   if (d.kind == 0 && temb_onehot_col<P>(d, L, Kft, B) < 0) return false;
   const int mt = fused_rows_per_tile<P>(d, true);

@@ -109,6 +109,7 @@ int fused_rows_per_tile(const dppo_net_desc& d, bool one_block = false);  // row
 template <class P>
 bool fused_bwd_one_block(const dppo_net_desc& d);  // shape covered by fused_backward_one_kernel (the caller adds: low-rank dW2 on)
 void set_fused_bwd_one(int v);  // tuning knob 23
+bool fused_frag_shape(const dppo_net_desc& d);  // the fragment-output kernel variants (FusedFwdArgs::a1f, FusedBwdArgs::dz1f) exist for it
 void set_fused_compact(int v);  // tuning knob 25
 
 // Fragment packing of a whole stream in ONE launch: layer l occupies positions [pos0, pos0 + KS); element

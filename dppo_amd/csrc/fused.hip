@@ -769,7 +769,10 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_forward_kernel(const Fused
 // The weight-gradient side (api.hip, mlp_backward): dWout = d_out^T h_1 is rebuilt from U = d_out^T x and T = d_out^T act(z1).
 // S1 > 0 (ring depth 4): the input tile's layer is walked as its S1 = ks0v <= 2 k-steps that hold data instead of the
 // padded four (CEngine); S1 = 0: the padded walk.
-template <class P, int TPW, int MR, int OT, int ACT, int S1>
+// FRAG (bf16, OT = 1, S1 = 1 or 2 only): act(h_0) / act(z1) leave as K-major fragments (a.a1f / a.a2f) instead of row-major.  A
+// template parameter, not a run-time test: compiled into every variant, the fragment code cost the variants that never use it
+// 8-24 spilled registers.
+template <class P, int TPW, int MR, int OT, int ACT, int S1, bool FRAG = false>
 __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const FusedFwdArgs a) {
   constexpr int PD = ring_depth<TPW, MR>(), ES = P::ESIZE, KB = P::KB;
   static_assert(S1 == 0 || PD == 4, "the compact walk is written for a ring of four positions");
@@ -862,15 +865,14 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
         }
       }
     }
-    emit<P, TPW, MR>(acc, ACT, bufA, a.a1f ? nullptr : a.a1[0], H, wbase, g, r, row0, M, a.hpre[0]);  // hpre[0] <- act'(h_0) (Mish) / sign words
+    emit<P, TPW, MR>(acc, ACT, bufA, FRAG ? nullptr : a.a1[0], H, wbase, g, r, row0, M, a.hpre[0]);  // hpre[0] <- act'(h_0) (Mish) / sign words
     STAMP(3);
     if constexpr (FLAGS)
       hand_over(flags, wid, lane, ++seq);
     else
       __syncthreads();
-    if constexpr (ES == 2) {  // act(h_0) as K-major fragments: read back from the image this wave has just written
-      if (a.a1f) frag_store_image<TPW, MR>(bufA, HRB, wid, lane, a.a1f + (size_t)tile * (MR / 2) * (H / 16) * 64, H / 16);
-    }
+    if constexpr (FRAG)  // act(h_0) as K-major fragments: read back from the image this wave has just written
+      frag_store_image<TPW, MR>(bufA, HRB, wid, lane, a.a1f + (size_t)tile * (MR / 2) * (H / 16) * 64, H / 16);
     STAMP(4);
     // ---- the block's first layer
     bias_init(1);
@@ -881,10 +883,8 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
       eng.run(acc, bufA, HRB, 15, KSH, r, g, FLAGS ? flags : nullptr, seq);
     }
     STAMP(5);
-    emit<P, TPW, MR>(acc, ACT, bufB, a.a2f ? nullptr : a.a2[0], H, wbase, g, r, row0, M, a.z1[0]);  // z1[0] <- act'(z1) (Mish) / sign words
-    if constexpr (ES == 2) {
-      if (a.a2f) frag_store_image<TPW, MR>(bufB, HRB, wid, lane, a.a2f + (size_t)tile * (MR / 2) * (H / 16) * 64, H / 16);
-    }
+    emit<P, TPW, MR>(acc, ACT, bufB, FRAG ? nullptr : a.a2[0], H, wbase, g, r, row0, M, a.z1[0]);  // z1[0] <- act'(z1) (Mish) / sign words
+    if constexpr (FRAG) frag_store_image<TPW, MR>(bufB, HRB, wid, lane, a.a2f + (size_t)tile * (MR / 2) * (H / 16) * 64, H / 16);
     STAMP(6);
     __syncthreads();  // the out layer's work items read every wave's features
     STAMP(7);
@@ -1179,7 +1179,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
 // of a tile anyway.  Needs the low-rank dW2 (no dh_1 tensor is written).
 // COMPACT (out_dim <= one k-step, ring depth 4): the two layers on the d_out tile are walked as ONE k-step each instead of
 // their padded four (CEngine).
-template <class P, int TPW, int MR, int ACT, bool COMPACT>
+// FRAG (bf16, COMPACT only): dz1 / dh_0 leave as K-major fragments, with fragment copies of the d_out tile and the input rows.
+template <class P, int TPW, int MR, int ACT, bool COMPACT, bool FRAG = false>
 __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedBwdArgs a) {
   constexpr int ES = P::ESIZE, KB = P::KB, PD = ring_depth<TPW, MR>();
   static_assert(!COMPACT || PD == 4, "the compact walk is written for a ring of four positions");
@@ -1235,15 +1236,16 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
     u32x4 d[MR][Chunks<P, TPW>::CH];
     fetch<P, ACT == ACT_RELU, TPW>(d, a.m1[0], H, wbase, g, r, row0, M);
     load_tile<MT>(xin, in_rb, in_km, (const char*)a.d_out, a.ld_dout * ES, row0, M);
-    const int x_rb = a.ld_x * ES, x_km = kmask16(x_rb);
-    if constexpr (ES == 2) {
-      if (a.xf) load_tile<MT>(xt, x_rb, x_km, (const char*)a.x, x_rb, row0, M);
-    }
-    __syncthreads();
-    if constexpr (ES == 2) {  // fragment copies of the two small GEMM operands (rows past M are zero: load_tile)
+    if constexpr (FRAG) {
+      const int x_rb = a.ld_x * ES, x_km = kmask16(x_rb);
+      load_tile<MT>(xt, x_rb, x_km, (const char*)a.x, x_rb, row0, M);
+      __syncthreads();
+      // fragment copies of the two small GEMM operands (rows past M are zero: load_tile)
       const size_t kbase = (size_t)tile * (MR / 2);
-      if (a.doutf) frag_store_tile<MR>(xin, in_rb, in_km, a.dof_nt, wid, lane, a.doutf + kbase * a.dof_nt * 64, a.dof_nt);
-      if (a.xf) frag_store_tile<MR>(xt, x_rb, x_km, a.ld_x / 16, wid, lane, a.xf + kbase * (a.ld_x / 16) * 64, a.ld_x / 16);
+      frag_store_tile<MR>(xin, in_rb, in_km, a.dof_nt, wid, lane, a.doutf + kbase * a.dof_nt * 64, a.dof_nt);
+      frag_store_tile<MR>(xt, x_rb, x_km, a.ld_x / 16, wid, lane, a.xf + kbase * (a.ld_x / 16) * 64, a.ld_x / 16);
+    } else {
+      __syncthreads();
     }
     STAMP(17);
     if (a.dout_slot >= 0) {  // out-layer bias gradient: column sums of the d_out tile (rows past M are zero), part 1
@@ -1279,7 +1281,7 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[tp][m][e] *= grad_at<P, ACT>(d, tp, m, e);
     STAMP(20);
-    emit<P, TPW, MR>(acc, ACT_NONE, bufA, a.dz1f ? nullptr : a.dz1[0], H, wbase, g, r, row0, M);
+    emit<P, TPW, MR>(acc, ACT_NONE, bufA, FRAG ? nullptr : a.dz1[0], H, wbase, g, r, row0, M);
     STAMP(23);
     colsum(acc, 2, tile);
     STAMP(24);
@@ -1287,9 +1289,7 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
       hand_over(flags, wid, lane, ++seq);
     else
       __syncthreads();
-    if constexpr (ES == 2) {
-      if (a.dz1f) frag_store_image<TPW, MR>(bufA, HRB, wid, lane, a.dz1f + (size_t)tile * (MR / 2) * (H / 16) * 64, H / 16);
-    }
+    if constexpr (FRAG) frag_store_image<TPW, MR>(bufA, HRB, wid, lane, a.dz1f + (size_t)tile * (MR / 2) * (H / 16) * 64, H / 16);
     STAMP(25);
     // ---- dh_0 = (dz1 . W1) o act'(h_0) + d_out . Wout
     fetch<P, ACT == ACT_RELU, TPW>(d, a.m0[0], H, wbase, g, r, row0, M);
@@ -1318,14 +1318,10 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
     } else {
       eng.run(acc, xin, in_rb, in_km, KSB0, r, g);
     }
-    if constexpr (ES == 2) {
-      if (a.dh0f)  // (rows past M: d_out is zero there, hence dh_0 too)
-        frag_store_acc<TPW, MR>(acc, stage, wid, lane, a.dh0f + (size_t)tile * (MR / 2) * (H / 16) * 64, H / 16);
-      else
-        emit<P, TPW, MR>(acc, ACT_NONE, nullptr, a.dh[0], H, wbase, g, r, row0, M);
-    } else {
+    if constexpr (FRAG)  // (rows past M: d_out is zero there, hence dh_0 too)
+      frag_store_acc<TPW, MR>(acc, stage, wid, lane, a.dh0f + (size_t)tile * (MR / 2) * (H / 16) * 64, H / 16);
+    else
       emit<P, TPW, MR>(acc, ACT_NONE, nullptr, a.dh[0], H, wbase, g, r, row0, M);
-    }
     STAMP(27);
     colsum(acc, 1, tile);
     STAMP(28);
@@ -1461,19 +1457,24 @@ bool fused_can_merge(const dppo_net_desc& d) {
   }
   return d.hidden <= 512 && merged_lds<P>(d.hidden, 1, ks0v) <= 160 * 1024;
 }
+// shapes the fragment-output variants are built for: bf16, head of one out tile, at most two input k-steps, compact walks on
+bool fused_frag_shape(const dppo_net_desc& d) {
+  return fused_compact_on() && d.out_dim <= 16 && d.in_dim <= 2 * BF16::KB && (d.hidden == 512 || d.hidden == 256) && fused_can_merge<BF16>(d);
+}
 template bool fused_can_merge<F32>(const dppo_net_desc&);
 template bool fused_can_merge<BF16>(const dppo_net_desc&);
 
-template <class P, int TPW, int MR, int ACT, int S1, int OT = 1>
+template <class P, int TPW, int MR, int ACT, int S1, int OT = 1, bool FRAG = false>
 static int launch_fwd_merged_cfg2(const FusedFwdArgs& a, hipStream_t s) {
   constexpr int MT = 16 * MR, H = 128 * TPW;
   const size_t lds = merged_lds<P>(H, OT, a.ks0v);
   if (lds > 160 * 1024 || a.Kp0 > H || a.nb != 1) return -2;
+  if (FRAG != (a.a1f != nullptr) || FRAG != (a.a2f != nullptr)) return -4;  // (fragment outputs: both or none, and a variant built for them)
   static DevLatch attr;
-  raise_lds(fused_forward_merged_kernel<P, TPW, MR, OT, ACT, S1>, attr);
+  raise_lds(fused_forward_merged_kernel<P, TPW, MR, OT, ACT, S1, FRAG>, attr);
   const int ntiles = (a.M + MT - 1) / MT;
   const bool probe = probe_begin(PROBE_FUSED_FWD, s);
-  hipLaunchKernelGGL((fused_forward_merged_kernel<P, TPW, MR, OT, ACT, S1>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512),
+  hipLaunchKernelGGL((fused_forward_merged_kernel<P, TPW, MR, OT, ACT, S1, FRAG>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512),
                      lds, s, a);
   if (probe) probe_end(s, 2.0 * a.M * ((double)a.in_valid * H + 2.0 * a.nb * H * H + (double)H * a.out_dim));
   return 0;
@@ -1489,6 +1490,13 @@ static int launch_fwd_merged_cfg(const FusedFwdArgs& a, hipStream_t s) {
     return -1;
   }
   if constexpr (ring_depth<TPW, MR>() == 4) {
+    if constexpr (P::ESIZE == 2) {  // fragment outputs: built for the compact narrow-head variants only (fused_frag_shape())
+      if (a.a1f != nullptr) {
+        if (fused_compact_on() && a.ks0v == 1) return launch_fwd_merged_cfg2<P, TPW, MR, ACT, 1, 1, true>(a, s);
+        if (fused_compact_on() && a.ks0v == 2) return launch_fwd_merged_cfg2<P, TPW, MR, ACT, 2, 1, true>(a, s);
+        return -4;
+      }
+    }
     if (fused_compact_on() && a.ks0v == 1) return launch_fwd_merged_cfg2<P, TPW, MR, ACT, 1>(a, s);
     if (fused_compact_on() && a.ks0v == 2) return launch_fwd_merged_cfg2<P, TPW, MR, ACT, 2>(a, s);
   }
@@ -1555,21 +1563,22 @@ static int launch_bwd_cfg(const FusedBwdArgs& a, hipStream_t s) {
 static int g_compact = 1;  // tuning knob 25: the one-block kernels skip the padding k-steps of their short layers (CEngine)
 void set_fused_compact(int v) { g_compact = v; }
 int fused_compact_on() { return g_compact; }
-template <class P, int TPW, int MR, int ACT, bool COMPACT>
+template <class P, int TPW, int MR, int ACT, bool COMPACT, bool FRAG = false>
 static int launch_bwd_one_cfg2(const FusedBwdArgs& a, hipStream_t s) {
   constexpr int ES = P::ESIZE, MT = 16 * MR, H = 128 * TPW;
   const size_t lds = 2 * (size_t)MT * H * ES + 64 + SAMPLER_WAVES * 128 * 4;
   if (lds > 160 * 1024 || a.KpB0 > H || a.KpB0 > 128 || a.nb != 1) return -2;
+  if (FRAG != (a.dz1f != nullptr)) return -4;
   if (a.dz1f != nullptr || a.dh0f != nullptr || a.xf != nullptr || a.doutf != nullptr) {  // fragment mode: all four or none
     if (ES != 2 || !a.dz1f || !a.dh0f || !a.xf || !a.doutf || !a.x || a.ld_x % 16 || a.dof_nt < 1 || a.dof_nt * 16 > a.KpB0 ||
         (size_t)MT * ((size_t)a.KpB0 * ES + (size_t)a.ld_x * ES) + (size_t)SAMPLER_WAVES * 32 * 32 * TPW > (size_t)MT * H * ES)
       return -4;
   }
   static DevLatch attr;
-  raise_lds(fused_backward_one_kernel<P, TPW, MR, ACT, COMPACT>, attr);
+  raise_lds(fused_backward_one_kernel<P, TPW, MR, ACT, COMPACT, FRAG>, attr);
   const int ntiles = (a.M + MT - 1) / MT;
   const bool probe = probe_begin(PROBE_FUSED_BWD, s);
-  hipLaunchKernelGGL((fused_backward_one_kernel<P, TPW, MR, ACT, COMPACT>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512),
+  hipLaunchKernelGGL((fused_backward_one_kernel<P, TPW, MR, ACT, COMPACT, FRAG>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512),
                      lds, s, a);
   if (probe) probe_end(s, 2.0 * a.M * ((double)a.out_valid * H + 2.0 * a.nb * H * H));
   return 0;
@@ -1577,6 +1586,9 @@ static int launch_bwd_one_cfg2(const FusedBwdArgs& a, hipStream_t s) {
 template <class P, int TPW, int MR, int ACT>
 static int launch_bwd_one_cfg(const FusedBwdArgs& a, hipStream_t s) {
   if constexpr (ring_depth<TPW, MR>() == 4) {
+    if constexpr (P::ESIZE == 2) {
+      if (a.dz1f != nullptr) return g_compact && a.out_valid <= P::KB ? launch_bwd_one_cfg2<P, TPW, MR, ACT, true, true>(a, s) : -4;
+    }
     if (g_compact && a.out_valid <= P::KB) return launch_bwd_one_cfg2<P, TPW, MR, ACT, true>(a, s);
   }
   return launch_bwd_one_cfg2<P, TPW, MR, ACT, false>(a, s);

@@ -15,7 +15,7 @@ loss_idx = [i for i, t in enumerate(ts) if 'ppo_loss_kernel' in t[2]]
 build_idx = [i for i, t in enumerate(ts) if 'build_rows_kernel' in t[2]]
 li = loss_idx[int(sys.argv[3]) if len(sys.argv) > 3 else -2]
 start = max(i for i in build_idx if i < li)
-end = min(i for i in build_idx if i > li)
+end = min([i for i in build_idx if i > li] or [len(ts)])  # (the trace's last step has no row builder behind it)
 seg = ts[start:end]
 tot = collections.OrderedDict()
 for s, e, n in seg:
