@@ -700,6 +700,9 @@ static int g_frag = 0;
 // CU's ~25 GB/s), where tail_reduce_kernel puts the whole chip on the same 22 MB for 17 us.  (With release / acquire fences
 // instead of sc1 stores it was 589 us: buffer_wbl2 flushes the XCD's whole L2 once per wave.)
 static int g_fold = 0;
+static int g_mom_rider = 0;  // tuning knob 36: the minibatch's advantage moments as riders of the row builder (1) or a launch of their own (0,
+                              // default: the launch already hides under the critic's forward on the side stream; the riders save 3.5 us only
+                              // in the serial order -- profiles/r03_moments_rider_ab.txt)
 // Time-embedding gradient through the first layer's weight-gradient GEMM: with a one-hot of the row's denoising step k in
 // the K padding of the input rows, dW0's extra columns are S[h][k] = sum over the rows of step k of dh0[row][h], and
 // d loss / d temb[k] = W0[:, temb columns]^T S[:, k] -- no second pass over dh0, no segmented reduction (tuning knob 11).
@@ -1789,11 +1792,14 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   br.inA = W.A.in, br.KpA = LA.Kp0, br.inC = W.C.in, br.KpC = LC.Kp0, br.brow = W.brow, br.krow = W.krow;
   br.obs_in_a = a.cond_hidden > 0 ? 0 : 1;  // with cond_mlp the encoder fills the state columns (from the critic's obs rows)
   br.onehot0 = temb_onehot_col<P>(a, LA, Kft, W.A);
+  // advantage moments as riders of the actor's row builder (knob 36): no launch between the rows and the actor's forward
+  const bool mom_rider = g_mom_rider && gmom == nullptr;
+  if (mom_rider) br.mom_adv = adv_k, br.mom_out = W.moments, br.n_zero_b = 8;  // (block 0 must not zero the riders' slots, [8, ...))
   const float* obs_c = oio && oio->obs_critic ? oio->obs_critic : nullptr;  // the critic's own observation rows (pixel nets)
   const bool split = s2 != s || obs_c != nullptr;
   if (split) {
     BuildRows bc = br;  // critic rows only, on the critic's stream
-    bc.zero_a = bc.zero_b = nullptr, bc.n_zero_a = bc.n_zero_b = 0, bc.loss_tab = nullptr;
+    bc.zero_a = bc.zero_b = nullptr, bc.n_zero_a = bc.n_zero_b = 0, bc.loss_tab = nullptr, bc.mom_adv = nullptr;
     br.zero_c = nullptr, br.n_zero_c = 0;  // (the critic's row builder zeroes the critic's counters: its own stream's order)
     bc.inA = nullptr, bc.brow = W.brow_c, bc.krow = nullptr;
     if (obs_c) bc.obs = obs_c;
@@ -1803,7 +1809,7 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   }
   launch_build_rows<P>(br, s);
   if (a.cond_hidden > 0) cond_encode<P>(a, ap, ak, LA, N, W.C.in, W.A, W.A.in, nullptr, 0, true, s);
-  if (gmom == nullptr) launch_adv_moments(adv_k, W.brow, N, W.moments, s);
+  if (gmom == nullptr && !mom_rider) launch_adv_moments(adv_k, W.brow, N, W.moments, s);
   if (!own_rows) s2 = fork_side(s);
   LossArgs la;
   memset(&la, 0, sizeof(la));
@@ -1812,6 +1818,7 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   la.chains = chains_k, la.logprobs_k = logprobs_k, la.returns_k = returns_k, la.values_k = values_k, la.adv_k = adv_k;
   la.ksteps = ksteps, la.dcfg = dcfg, la.pcfg = pcfg, la.AF = a.act_flat, la.N = N;
   la.moments = gmom ? gmom : W.moments;
+  if (mom_rider) la.mom_blocks = ADV_RIDER_BLOCKS, la.moments_out = W.moments;
   la.tab = Kft <= 1024 ? W.loss_tab : nullptr;
   la.d_eps = W.A.d_out, la.ldde = LA.Kpo, la.d_v = W.C.d_out, la.lddv = LC.Kpo, la.stats = stats;
   const bool fuse_bout = false;  // out-layer bias gradients come from the fused backward's d_out column sums
@@ -2646,6 +2653,10 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 32) {  // fragment GEMM: 0 (default) LDS-ring kernel; 2..4 register-only kernel with that lookahead
     set_gemm_tn_frag_depth(value);
+    return 0;
+  }
+  if (knob == 36) {  // advantage moments: partial sums by the row builder's last blocks, added up by the loss kernel (1, default) or adv_moments_kernel (0)
+    g_mom_rider = value;
     return 0;
   }
   if (knob == 35) {  // the reductions behind the weight-gradient GEMMs inside their launch (1, default) or as a launch of their own (0)

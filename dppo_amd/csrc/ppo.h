@@ -53,6 +53,12 @@ struct BuildRows {
   double* zero_b;
   double* zero_c;
   int n_zero_a, n_zero_b, n_zero_c;
+  // advantage moments as a rider (mom_adv != null): the LAST ADV_RIDER_BLOCKS blocks of the launch also sum adv_k[row] and
+  // its square over the minibatch's samples (row from inds / kinds, nothing this launch writes) and leave their partial
+  // sums in mom_out[8 + 2 i], [9 + 2 i]; the loss kernel adds the ADV_RIDER_BLOCKS partials itself (LossArgs::mom_blocks).
+  // No separate moments launch in front of the actor's forward, no arrival counter.
+  const float* mom_adv;
+  double* mom_out;
 };
 template <class P>
 void launch_build_rows(const BuildRows& a, hipStream_t s);
@@ -136,6 +142,10 @@ struct LossArgs {
   int AF;
   int64_t N;
   const double* moments;  // [3] sum(adv), sum(adv^2), count over the (global) minibatch
+  int mom_blocks;         // > 0: instead, moments[8 + 2 i], [9 + 2 i], i < mom_blocks (<= 64), are partial sums to add up (the
+                          // row builder's riders) and the count is N; block 0 of the policy half stores the totals in
+                          // moments_out[0..2] for the statistics' finalisation
+  double* moments_out;
   const float* tab;       // [2 Kft] per-k discount and clip range built by the row builder (null: built per block)
   double n_count;  // > 0: the (global) minibatch sample count, instead of moments[2] (the value half must not wait for
                    // the advantage-moment kernel on the other stream)
@@ -155,6 +165,7 @@ void launch_loss_finalize(const LossArgs& a, hipStream_t s);  // partial sums ->
 // moments[0] += sum adv_k[brow[n]], [1] += sum of squares, [2] += N (float64; zeroed by the caller)
 // moments: 8 + 2 * ADV_MOMENT_BLOCKS doubles; [3] must be zero on entry (see the kernel)
 constexpr int ADV_MOMENT_BLOCKS = 256;
+constexpr int ADV_RIDER_BLOCKS = 64;  // one partial per lane of the loss kernel's one-wave blocks
 void launch_adv_moments(const float* adv_k, const int32_t* brow, int64_t N, double* moments, hipStream_t s);
 
 // ---- time-embedding backward ---------------------------------------------------------------------

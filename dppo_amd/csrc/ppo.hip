@@ -242,6 +242,29 @@ __global__ __launch_bounds__(256) void build_rows_kernel(const BuildRows a) {
     char* dst = isA ? (char*)a.inA + ((size_t)n * a.KpA + c0) * P::ESIZE : (char*)a.inC + ((size_t)n * a.KpC + c0) * P::ESIZE;
     *(u32x4*)dst = o;
   }
+  // ---- rider: partial advantage moments (see BuildRows::mom_adv).  The last blocks of the grid: they are dispatched last
+  // and have the fewest row chunks left
+  const int rb = (int)gridDim.x - 1 - (int)blockIdx.x;  // rider index
+  if (a.mom_adv != nullptr && rb < ADV_RIDER_BLOCKS) {
+    __shared__ double shm[2][4];
+    const int nr = (int)gridDim.x < ADV_RIDER_BLOCKS ? (int)gridDim.x : ADV_RIDER_BLOCKS;  // riders that exist
+    double s1 = 0, s2 = 0;
+    for (int64_t n = (int64_t)rb * 256 + threadIdx.x; n < a.M; n += (int64_t)nr * 256) {
+      const int64_t b = a.kinds != nullptr ? n : (a.inds ? a.inds[n] : n) / a.Kft;
+      const double v = a.mom_adv[b];
+      s1 += v;
+      s2 += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) s1 += __shfl_down(s1, o), s2 += __shfl_down(s2, o);
+    if ((threadIdx.x & 63) == 0) shm[0][threadIdx.x >> 6] = s1, shm[1][threadIdx.x >> 6] = s2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      a.mom_out[8 + 2 * rb] = (shm[0][0] + shm[0][1]) + (shm[0][2] + shm[0][3]);
+      a.mom_out[9 + 2 * rb] = (shm[1][0] + shm[1][1]) + (shm[1][2] + shm[1][3]);
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x < 64 && (int)threadIdx.x >= nr)  // (a grid of fewer blocks: zero the rest)
+      a.mom_out[8 + 2 * threadIdx.x] = 0.0, a.mom_out[9 + 2 * threadIdx.x] = 0.0;
+  }
 }
 template <class P>
 void launch_build_rows(const BuildRows& a, hipStream_t s) {
@@ -529,7 +552,18 @@ __global__ __launch_bounds__(LOSS_THREADS, NREG <= 32 ? 8 : 1) void ppo_loss_ker
     } else {
       for (int k = threadIdx.x; k < Kft; k += LOSS_THREADS) loss_table_entry(pc, k, tab);
     }
-    if (threadIdx.x == 0) {
+    if (a.mom_blocks > 0) {  // the row builder's partial sums, one per lane, added by a fixed shuffle tree
+      double s1 = (int)threadIdx.x < a.mom_blocks ? a.moments[8 + 2 * threadIdx.x] : 0.0;
+      double s2 = (int)threadIdx.x < a.mom_blocks ? a.moments[9 + 2 * threadIdx.x] : 0.0;
+      for (int o = 32; o > 0; o >>= 1) s1 += __shfl_down(s1, o), s2 += __shfl_down(s2, o);
+      if (threadIdx.x == 0) {
+        const double Nm = (double)a.N, mean = s1 / Nm;
+        const double varu = (s2 - Nm * mean * mean) / (Nm - 1.0);  // unbiased (torch.std)
+        tab[2 * Kft] = (float)mean;
+        tab[2 * Kft + 1] = (float)sqrt(varu > 0 ? varu : 0);
+        if (blockIdx.x == 0) a.moments_out[0] = s1, a.moments_out[1] = s2, a.moments_out[2] = Nm;  // for loss_finalize
+      }
+    } else if (threadIdx.x == 0) {
       const double Nm = a.moments[2], mean = a.moments[0] / Nm;
       const double varu = (a.moments[1] - Nm * mean * mean) / (Nm - 1.0);  // unbiased (torch.std)
       tab[2 * Kft] = (float)mean;
@@ -540,7 +574,7 @@ __global__ __launch_bounds__(LOSS_THREADS, NREG <= 32 ? 8 : 1) void ppo_loss_ker
   const int rh = pc.reward_horizon < pc.horizon_steps ? pc.reward_horizon : pc.horizon_steps;
   const int cnt = rh * Da;
   double s_pg = 0, s_v = 0, s_kl = 0, s_cf = 0, s_ratio = 0;
-  const double Nn = a.n_count > 0 ? a.n_count : a.moments[2];  // samples in the (global) minibatch: means and 1/N scaling
+  const double Nn = a.n_count > 0 ? a.n_count : (a.mom_blocks > 0 ? (double)a.N : a.moments[2]);  // samples in the (global) minibatch
   const int64_t n = (int64_t)blockIdx.x * LOSS_THREADS + threadIdx.x;
   if (n < a.N) {
     const int b = a.brow[n];

@@ -489,6 +489,9 @@ int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* 
  *          LDS kernel (0, default: the fragment form is parity-green but not faster yet)
  * knob 32: 0 (default): the fragments of a workgroup's tile are fetched once per k-step by LDS-DMA into a four-stage ring and
  *          read back by its four waves; 2..4: every wave loads its own fragments into registers, that many k-steps ahead
+ * knob 36: the minibatch's advantage moments (PPO update, single rank): partial sums by the last 64 blocks of the row builder's
+ *          launch, added by every block of the loss kernel (1), or a launch of their own between the rows and the
+ *          actor's forward (0, default: it already overlaps the critic's forward; the riders gain 3.5 us in serial order only)
  * knob 35: what follows the weight-gradient GEMMs of a backward pass -- slab sums, bias column sums, loss statistics -- inside
  *          the GEMM launch (1: the last workgroup at an output tile sums its slabs, the small reductions ride as extra
  *          workgroups; measured slower, 200 vs 107 + 32 us) or as a launch of its own (0, default)
