@@ -395,6 +395,7 @@ struct MlpBufs {  // activations of one network for M rows
   // workgroup to arrive at an output tile) and the bias sums / loss statistics ride in it, so no reduction launch follows
   bool fold;          // set by the caller between carve and backward: red_cnt was zeroed in this call (row builder)
   unsigned* red_cnt;  // [RED_CNT] tile arrival counters, right behind post_counter (zeroed with it, left zero)
+  bool dw0;         // set by the caller between carve and the backward (dw0_ok()): the backward keeps dW0 on chip, dh_0 is never stored
   bool allow_frag;  // set by the caller between carve and forward: the whole pass (forward, backward, GEMMs) may run in it
   bool frag;        // decided by the forward (allow_frag && merged), obeyed by the backward
   u32x4* doutf;     // [ks][dof_nt][64]
@@ -729,6 +730,35 @@ static bool frag_ok(const dppo_net_desc& d, int64_t M, const PackLayout& L, int 
   return (size_t)mt * ((size_t)fg.KpB0 * 2 + (size_t)L.Kp0 * 2) + (size_t)SAMPLER_WAVES * 32 * 32 * (d.hidden / 128) <=
          (size_t)mt * d.hidden * 2;
 }
+// In-kernel first-layer weight gradient (tuning knob 37; fused.h, FusedBwdArgs::dw0_slab).  dh_0 -- a third of the bytes the
+// weight-gradient GEMMs read, for a 512 x 64 output -- is then neither stored nor read back: the one-block backward multiplies each
+// tile of it with the tile's input rows while both are on chip and keeps the partial product in LDS.  The 64 KB that has room for
+// is [H][32]: the network's informative input columns must fit 32.  A denoiser's rows are [x_k | temb(t_k) | obs | one-hot(k)]:
+// the temb columns are a function of k alone (their gradient is rebuilt from the one-hot sums, PostReduce::dW0t; the kernel
+// skips them when it reads the row tile: act_flat and time_dim must be multiples of 4), and of the Kft one-hot columns the last
+// may be left out (every row carries exactly one: PostReduce::S_rest, with the bias gradient taken of the rounded dh_0) --
+// hopper: 12 + 11 + 9 = 32.
+// Needs the one-block backward on its compact walk, the one-hot time columns, post_reduce in one launch, nobody asking for
+// d loss / d observation, no cond_mlp, and a slab per workgroup in the pool.
+static int g_dw0 = 1;
+static int dw0_cols(const dppo_net_desc& d) { return d.kind == 0 ? d.act_flat + d.cond_dim : d.in_dim; }
+static int dw0_nhot(const dppo_net_desc& d, int Kft) {  // one-hot columns that fit behind the data columns
+  const int room = 32 - dw0_cols(d);
+  return d.kind != 0 ? 0 : (room >= Kft ? Kft : room);
+}
+template <class P>
+static bool dw0_ok(const dppo_net_desc& d, int64_t M, const PackLayout& L, int Kft, const MlpBufs<P>& B, bool wants_dobs) {
+  if (!g_dw0 || P::ESIZE != 2 || wants_dobs || d.cond_hidden > 0 || !g_tn_group || !g_post_one) return false;
+  if (!fused_ok<P>(d) || B.tiles <= 0 || !bwd_one<P>(d, M) || !fused_dw0_shape(d) || L.Kp0 < 64) return false;
+  if (d.kind == 0) {
+    if (temb_onehot_col<P>(d, L, Kft, B) < 0 || !B.post_zeroed || d.in_dim != d.act_flat + d.time_dim + d.cond_dim) return false;
+    if (d.act_flat % 4 || d.time_dim % 4 || 32 + d.time_dim > 64) return false;
+    if (dw0_nhot(d, Kft) < Kft - 1) return false;
+  } else if (d.in_dim > 32) {
+    return false;
+  }
+  return (size_t)fused_bwd_one_grid<P>(d, M) * d.hidden * 32 <= B.slab_floats / 2;
+}
 template <class P>
 static void flush_slabs(MlpBufs<P>& B, hipStream_t s, const SlotOuts* slots = nullptr, int slot_width = 0,
                         const LossArgs* fin = nullptr) {
@@ -855,7 +885,7 @@ static void weight_grad(const void* A, int lda, int N1, const void* Bm, int ldb,
     launch_gemm_tn<P>(t, s);
   SlabJob& j = B.slab_jobs.j[B.slab_jobs.n++];
   j.slab = sub, j.out = gw, j.splits = (int)splits, j.rows = N1, j.cols = N2, j.lds = N2, j.ldo = ldgw, j.transpose = swap ? 1 : 0;
-  j.c0 = 0;
+  j.c0 = 0, j.wide = 0;
   if (n2a >= 0 && !swap) {
     j.cols = n2a;
     SlabJob& j2 = B.slab_jobs.j[B.slab_jobs.n++];
@@ -904,7 +934,7 @@ static void weight_grad_frag(const u32x4* FA, int nta, int N1, const u32x4* FB, 
   B.tnf_group.j[B.tnf_group.n++] = t;
   SlabJob& j = B.slab_jobs.j[B.slab_jobs.n++];
   j.slab = sub, j.out = gw, j.splits = (int)splits, j.rows = N1, j.cols = N2, j.lds = N2, j.ldo = ldgw, j.transpose = transpose ? 1 : 0;
-  j.c0 = 0;
+  j.c0 = 0, j.wide = 0;
   if (n2a >= 0 && !transpose) {
     j.cols = n2a;
     SlabJob& j2 = B.slab_jobs.j[B.slab_jobs.n++];
@@ -989,6 +1019,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
     f.one_block = one ? 1 : 0;
     if (g_dbg & 1)  // timing experiment: no gradient stores (the weight-gradient GEMMs then read stale buffers)
       for (int b = 0; b <= nb; ++b) f.dh[b] = nullptr, f.dz1[b < nb ? b : 0] = nullptr;
+    if (g_dbg & 32) f.dh[0] = nullptr;  // timing experiment: dh_0 is not stored (bound of the in-kernel dW0)
     if (g_dbg & 2)  // timing experiment: no derivative-source fetch
       for (int b = 0; b < nb; ++b) f.m1[b] = f.m0[b] = nullptr;
     const bool frag = B.frag;
@@ -1000,6 +1031,24 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       B.dof_nt = d.out_dim <= 16 ? 1 : (d.out_dim <= 32 ? 2 : 4);
       f.dz1f = (u32x4*)B.dz1_all[0], f.dh0f = (u32x4*)B.dh_all[0], f.doutf = B.doutf, f.dof_nt = B.dof_nt;
       f.x = B.in, f.ld_x = L.Kp0, f.xf = B.xf;
+    }
+    // in-kernel dW0 (dw0_ok() held when the rows were built): a slab per workgroup out of the pool, reduced with the GEMMs' slabs
+    const bool dw0 = B.dw0 && one && !frag && !(g_dbg & 33);
+    const int dw0_nh = dw0 ? dw0_nhot(d, Kft) : 0;
+    float* dw0_slab = nullptr;
+    int dw0_grid = 0;
+    if (B.dw0 && !dw0) {
+      g_fused_fault = -7;  // (the compact rows were built for a pass that cannot use them: dw0_ok() and this function disagree)
+      return;
+    }
+    if (dw0) {
+      dw0_grid = fused_bwd_one_grid<P>(d, M);
+      if ((size_t)dw0_grid * H * 32 > B.slab_floats - B.slab_used) flush_slabs(B, s);
+      dw0_slab = B.slab + B.slab_used;
+      B.slab_used += (size_t)dw0_grid * H * 32;
+      f.dh[0] = nullptr, f.dw0_slab = dw0_slab, f.xc = B.in, f.ld_xc = L.Kp0;
+      f.xc_af = d.kind == 0 ? d.act_flat : 64, f.xc_skip = d.kind == 0 ? d.time_dim : 0;
+      f.dw0_round = d.kind == 0 && dw0_nh < Kft ? 1 : 0;  // (the last one-hot column is rebuilt from the bias gradient)
     }
     g_fused_fault = launch_fused_backward<P>(d, f, s);
     if (g_fused_fault != 0) return;
@@ -1023,6 +1072,8 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       }
       for (int i = 0; i < so.n_slots; ++i) so.n[i] = H;
       if (one) so.n[0] = 0;  // colsum(dh_nb) is not formed by the one-block kernel: db2 comes from PostReduce::db2
+      // in-kernel dW0 without room for the last one-hot column: the bias gradient is the column sums of the rounded dh_0
+      const float* s_rest = dw0 && f.dw0_round ? grad + pl.b0 : nullptr;
       if (!bout_done) so.out[so.n_slots] = grad + pl.bout, so.n[so.n_slots] = d.out_dim, ++so.n_slots;  // the d_out slot
       // The bias sums and the loss statistics ride in the slab-reduction launch behind the GEMMs (tail_reduce_kernel).
       // Only the rare time-embedding gradient WITHOUT the one-hot columns (a gemm_nt + segmented sum over all rows, see
@@ -1058,7 +1109,21 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
           weight_grad<P>(B.dh_all[b + 1], H, H, B.a2[b], H, H, M, B, grad + pl.l2w[b], H, s, true);
         weight_grad<P>(B.dz1_all[b], H, H, B.a1[b], H, H, M, B, grad + pl.l1w[b], H, s, true);
       }
-      if (oh >= 0)  // + Kft one-hot columns: their block of the result is S[h][k] (B.part), see temb_onehot_col()
+      if (dw0) {  // the kernel's per-workgroup partials [grid][H][32]: data columns -> dW0, one-hot columns -> S[h][k] (B.part)
+        auto job = [&](int c0, int cols, float* out, int ldo) {
+          SlabJob& j = B.slab_jobs.j[B.slab_jobs.n++];
+          j.slab = dw0_slab, j.out = out, j.splits = dw0_grid, j.rows = H, j.cols = cols, j.lds = 32, j.ldo = ldo, j.transpose = 0;
+          j.c0 = c0, j.wide = dw0_grid >= 32 ? 1 : 0;  // (a slab per workgroup: slab_job_block_wide)
+        };
+        if (d.kind == 0) {
+          job(0, d.act_flat, grad + pl.W0, d.in_dim);
+          job(d.act_flat, d.cond_dim, grad + pl.W0 + d.act_flat + d.time_dim, d.in_dim);
+          job(d.act_flat + d.cond_dim, dw0_nh, B.part, Kft);
+        } else {
+          job(0, d.in_dim, grad + pl.W0, d.in_dim);
+        }
+      } else if (g_dbg & 32) {  // timing experiment: no dW0 product in the group
+      } else if (oh >= 0)  // + Kft one-hot columns: their block of the result is S[h][k] (B.part), see temb_onehot_col()
         weight_grad<P>(B.dh_all[0], H, H, B.in, L.Kp0, d.in_dim + Kft, M, B, grad + pl.W0, d.in_dim, s, true, d.in_dim, B.part,
                        Kft);
       else
@@ -1084,6 +1149,8 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
           q.G = B.part + (size_t)H * Kft, q.w1 = prm + pl.te1_w, q.b1 = prm + pl.te1_b, q.w2 = prm + pl.te2_w;
           q.ksteps = ksteps, q.gw1 = grad + pl.te1_w, q.gb1 = grad + pl.te1_b, q.gw2 = grad + pl.te2_w;
           q.gb2 = grad + pl.te2_b;
+          if (dw0)  // the time-embedding columns of dW0 from the one-hot sums, the last of which may have to be rebuilt
+            q.S_rest = s_rest, q.dW0t = grad + pl.W0, q.temb = (const float*)(pk + L.temb), q.temb_bf16 = P::ESIZE == 2 ? 1 : 0;
         }
         q.counter = (unsigned*)B.post_counter;
         launch_post_reduce(q, s);
@@ -1095,7 +1162,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
                                          d.act_flat, H, B.part + (size_t)H * Kft, ksteps, Kft, d.time_dim, grad + pl.te1_w,
                                          grad + pl.te1_b, grad + pl.te2_w, grad + pl.te2_b, s);
       }
-      B.dh0_final = frag ? nullptr : B.dh_all[0];  // (fragment mode: no row-major dh_0 exists; frag_ok() made sure nobody asks)
+      B.dh0_final = frag || dw0 ? nullptr : B.dh_all[0];  // (fragment mode / in-kernel dW0: no row-major dh_0 exists; frag_ok() / dw0_ok() made sure nobody asks)
       return;
     }
   }
@@ -1785,6 +1852,8 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   // post_reduce_kernel's arrival counter and, behind it, the tile counters of the folded slab reduction (both networks')
   br.zero_a = W.A.post_counter, br.n_zero_a = 1 + RED_CNT / 2, W.A.post_zeroed = true, W.A.fold = true;
   br.zero_c = W.C.post_counter, br.n_zero_c = 1 + RED_CNT / 2, W.C.fold = true;
+  W.A.dw0 = !W.A.allow_frag && dw0_ok<P>(a, N, LA, Kft, W.A, oio && oio->d_obs_actor);
+  W.C.dw0 = !W.C.allow_frag && dw0_ok<P>(cr, N, LC, Kft, W.C, oio && oio->d_obs_critic);
   if (Kft <= 1024) br.loss_tab = W.loss_tab, br.pcfg = pcfg;
   br.inds = inds, br.kinds = kinds, br.chains = chains_k, br.obs = obs_k, br.temb = (const float*)(ak + LA.temb);
   br.ksteps = ksteps;
@@ -2657,6 +2726,10 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 36) {  // advantage moments: partial sums by the row builder's last blocks, added up by the loss kernel (1, default) or adv_moments_kernel (0)
     g_mom_rider = value;
+    return 0;
+  }
+  if (knob == 37) {  // in-kernel first-layer weight gradient of the one-block backward (1, default) or dh_0 stored and a GEMM of its own (0)
+    g_dw0 = value;
     return 0;
   }
   if (knob == 35) {  // the reductions behind the weight-gradient GEMMs inside their launch (1, default) or as a launch of their own (0)

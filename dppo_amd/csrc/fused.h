@@ -94,7 +94,20 @@ struct FusedBwdArgs {
   const void* x;
   int ld_x;
   u32x4* xf;
+  // In-kernel first-layer weight gradient (one-block kernel, bf16; fused_dw0_shape()): dh_0 is never stored.  Every persistent
+  // workgroup keeps dW0_part[H][32] = sum over ITS tiles of bf16(dh_0)^T . x' in LDS and writes it once, at the end, to
+  // dw0_slab[blockIdx.x][H][32] (f32); the caller reduces the gridDim.x slabs.  x' = 32 columns of the input rows xc
+  // ([M][ld_xc] elem, ld_xc >= 64): column c of x' is column c of the row below xc_af and column c + xc_skip from there on.
+  // dw0_round: the column sums of dh_0 (slot 1, the first layer's bias gradient) are taken of the ROUNDED values, the ones the
+  // product saw (a caller that leaves a one-hot column out of the 32 rebuilds its sums from them).
+  float* dw0_slab;
+  const void* xc;
+  int ld_xc, xc_af, xc_skip, dw0_round;
 };
+// workgroups (= slabs) the one-block backward will launch for M rows, and whether its in-kernel dW0 covers the network
+template <class P>
+int fused_bwd_one_grid(const dppo_net_desc& d, int64_t M);
+bool fused_dw0_shape(const dppo_net_desc& d);
 
 template <class P>
 int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStream_t s);   // <0: shape not covered

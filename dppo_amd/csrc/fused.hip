@@ -198,6 +198,8 @@ struct CEngine {
   }
   template <int SLOT>
   __device__ __forceinline__ void refill_mid(int c) {  // c + PD lies inside the wide segment
+    unsigned ln = this->ln;
+    asm volatile("" : "+v"(ln));  // (as in fetch_ct: the unrolled k-loop's addresses were hoisted out of the tile loop as twelve 64-bit pairs)
     const u32x4* w = stream + (size_t)(pl + (c + PD - S1)) * TPW * 64;
 #pragma unroll
     for (int tp = 0; tp < TPW; ++tp) ring[SLOT][tp] = (w + tp * 64)[ln];
@@ -398,6 +400,88 @@ __device__ __forceinline__ void frag_store_acc(const f32x4 (&v)[TPW][MR], char* 
       const u32x2 u0 = lds_tr16(stage + row0 * RS + ((c ^ (row0 & CM)) << 4) + (p & 1) * 8);
       const u32x2 u1 = lds_tr16(stage + row1 * RS + ((c ^ (row1 & CM)) << 4) + (p & 1) * 8);
       out[((size_t)ks * NT + wid * TPW + t) * 64 + lane] = (u32x4){u0.x, u0.y, u1.x, u1.y};
+    }
+  }
+}
+
+// In-kernel first-layer weight gradient (FusedBwdArgs::dw0_slab): C[feature][col] += sum over the tile's rows of
+// bf16(v[row][feature]) * x[row][col'] for this wave's 16 TPW features and 32 columns col of the input rows.  The accumulators v
+// (feature 4g + e of MFMA tile tp at row 16 m + r: the contraction index sits in the LANE) are staged pair of tiles by pair,
+// k-step by k-step, through a private [32 rows][32 features] bf16 region (chunk c of row R at c ^ (R & 3)) and read back
+// transposed as MFMA A fragments (frag_store_acc's path); the B fragments come from the input-row tile `xw` ([16 MR][128 bytes],
+// chunk swizzle by row & 7, load_tile()) the same way, four columns per lane address: column block b of the 32 is the row's
+// columns 4 b .. 4 b + 3, moved up by `skip` columns from column `af` on (a denoiser's rows are [x_k | temb | obs | one-hot]: the
+// time-embedding columns are skipped; af and skip are multiples of 4).  C lives in LDS between tiles -- cacc[(tile t of the wave's
+// 16 TPW features, column tile)][lane] in MFMA D layout, this wave's own region -- because the kernel has no register left to
+// carry it; a tile of it is read and written once per 64 rows.  round_back: v is left holding the rounded values (the caller's
+// column sums then add up what the product saw; a template parameter: as a run-time flag it cost 30 registers).
+// stage: this wave's 2 KB; cacc: this wave's [TPW][2][64] f32x4.
+template <int TPW, int MR, bool round_back>
+__device__ __forceinline__ void dw0_accumulate(f32x4 (&v)[TPW][MR], char* stage, const char* xw, f32x4* cacc, int lane, int af,
+                                               int skip) {
+  static_assert(MR % 4 == 0 && TPW % 2 == 0, "bf16 chunk = two MFMA tiles; two k-steps of two row sub-tiles at a time");
+  // Two k-steps (64 rows) at a time, one pair of feature tiles at a time, with compiler barriers for memory operations between
+  // them: what is live beside the accumulators and the weight ring stays at 2 x 2 A fragments, 2 x 2 B fragments and one C tile.
+  // (Everything hoisted to the top -- the compiler's choice -- is 64 more registers at MR = 8: the kernel then fills the register
+  // file and no other stream's wave fits a SIMD beside its two, which costs the overlapped update step more than the stores saved.)
+#pragma unroll
+  for (int kc = 0; kc < MR / 2; kc += 2) {
+    asm volatile("" : "+v"(lane)::"memory");  // (addresses formed here, once per use: see emit())
+    const int r = lane & 15, g = lane >> 4, q = r >> 2, p = r & 3;
+    u32x4 xb[2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = 16 * nt + 4 * p, sb = 2 * (col + (col >= af ? skip : 0));  // byte of the lane's four columns in a row
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int row0 = 32 * (kc + ks) + 8 * g + q, row1 = row0 + 4;
+        const u32x2 u0 = lds_tr16(xw + row0 * 128 + (((sb >> 4) ^ (row0 & 7)) << 4) + (sb & 15));
+        const u32x2 u1 = lds_tr16(xw + row1 * 128 + (((sb >> 4) ^ (row1 & 7)) << 4) + (sb & 15));
+        xb[ks][nt] = (u32x4){u0.x, u0.y, u1.x, u1.y};
+      }
+    }
+#pragma unroll
+    for (int tp = 0; tp < TPW; tp += 2) {
+      u32x4 fa[2][2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+          const int m = 2 * (kc + ks) + mm, row = 16 * mm + r;
+          u32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = v[tp + (2 * e) / 4][m][(2 * e) % 4], hi = v[tp + (2 * e + 1) / 4][m][(2 * e + 1) % 4];
+            o[e] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+            if constexpr (round_back) {
+              v[tp + (2 * e) / 4][m][(2 * e) % 4] = __uint_as_float(o[e] << 16);
+              v[tp + (2 * e + 1) / 4][m][(2 * e + 1) % 4] = __uint_as_float(o[e] & 0xffff0000u);
+            }
+          }
+          *(u32x4*)(stage + row * 64 + ((g ^ (row & 3)) << 4)) = o;  // features 8 g .. 8 g + 7 of the pair's 32
+        }
+        const int sr0 = 8 * g + q, sr1 = sr0 + 4;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int c = 2 * t + (p >> 1);
+          const u32x2 u0 = lds_tr16(stage + sr0 * 64 + ((c ^ (sr0 & 3)) << 4) + (p & 1) * 8);
+          const u32x2 u1 = lds_tr16(stage + sr1 * 64 + ((c ^ (sr1 & 3)) << 4) + (p & 1) * 8);
+          fa[ks][t] = (u32x4){u0.x, u0.y, u1.x, u1.y};
+        }
+        asm volatile("" ::: "memory");  // (the next k-step's staging stores stay behind this one's reads)
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          f32x4* cp = cacc + ((tp + t) * 2 + nt) * 64 + lane;
+          f32x4 c = *cp;
+          c = BF16::mma(fa[0][t], xb[0][nt], c);
+          c = BF16::mma(fa[1][t], xb[1][nt], c);
+          *cp = c;
+        }
+        asm volatile("" ::: "memory");
+      }
     }
   }
 }
@@ -1180,8 +1264,11 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_backward_kernel(const Fuse
 // COMPACT (out_dim <= one k-step, ring depth 4): the two layers on the d_out tile are walked as ONE k-step each instead of
 // their padded four (CEngine).
 // FRAG (bf16, COMPACT only): dz1 / dh_0 leave as K-major fragments, with fragment copies of the d_out tile and the input rows.
-template <class P, int TPW, int MR, int ACT, bool COMPACT, bool FRAG = false>
+// DW0 (bf16, COMPACT only; 1, or 2 = FusedBwdArgs::dw0_round): dh_0 is not stored at all -- its product with the input rows is
+// accumulated in LDS (dw0_accumulate, FusedBwdArgs::dw0_slab) and buffer B shrinks to the d_out tile.
+template <class P, int TPW, int MR, int ACT, bool COMPACT, bool FRAG = false, int DW0 = 0>
 __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedBwdArgs a) {
+  static_assert(!DW0 || (COMPACT && !FRAG && P::ESIZE == 2), "in-kernel dW0: bf16, compact walk, row-major dz1");
   constexpr int ES = P::ESIZE, KB = P::KB, PD = ring_depth<TPW, MR>();
   static_assert(!COMPACT || PD == 4, "the compact walk is written for a ring of four positions");
   constexpr int H = 128 * TPW, KSH = H / KB, HRB = H * ES, MT = 16 * MR;
@@ -1191,14 +1278,20 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int M = a.M;
-  const int in_rb = a.KpB0 * ES, in_km = kmask16(in_rb), KSB0 = a.KpB0 / KB;
+  // (DW0: the compact walk reads the d_out tile's first k-step only -- its LDS tile keeps just those 64 bytes per row)
+  const int in_rb = DW0 ? 64 : a.KpB0 * ES, in_km = kmask16(in_rb), KSB0 = a.KpB0 / KB;
   const int total = 2 * KSB0 + KSH;
   char* bufA = smem;
   char* bufB = bufA + MT * HRB;
   char* xin = bufB;  // the d_out tile: read by the composite layer first and by the Wout^T layer last
-  lds_u32* flags = (lds_u32*)(bufB + MT * HRB);              // [16 words]
-  constexpr int DRED_COLS = 128;
-  float* dred = (float*)(bufB + MT * HRB + 64);  // [8 waves][128] column sums of the d_out tile
+  const int bsz = DW0 ? MT * in_rb : MT * HRB;                // (DW0: buffer B is the d_out tile alone)
+  lds_u32* flags = (lds_u32*)(bufB + bsz);                    // [16 words]
+  constexpr int DRED_COLS = DW0 ? 32 : 128;  // (the compact walk: at most one k-step of outputs)
+  float* dred = (float*)(bufB + bsz + 64);  // [8 waves][DRED_COLS] column sums of the d_out tile
+  // DW0: the input-row tile [MT][128 B], a 2 KB staging region per wave, the workgroup's dW0 partial [8 waves][TPW][2][64] f32x4
+  char* xw = (char*)(dred + SAMPLER_WAVES * DRED_COLS);
+  char* stage_w = xw + MT * 128 + wid * 2048;
+  f32x4* cacc = (f32x4*)(xw + MT * 128 + SAMPLER_WAVES * 2048) + (size_t)wid * TPW * 2 * 64;
   // fragment mode (a.dz1f): buffer B beyond the d_out tile (at most MT x 256 bytes of its MT x HRB) also holds the input-row
   // tile [MT][ld_x] and each wave's private staging region for dh_0 (frag_store_acc): 16 + 16 + 32 KB of 64 at H = 512
   // (the launcher checked MT (in_rb + ld_x ES) + 8 x 32 x 32 TPW <= MT HRB: fused_frag_fits())
@@ -1214,8 +1307,14 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
     eng.prime(a.bstream + (size_t)wid * total * TPW * 64 + lane, total, KSB0);
   if (tid < 16) flags[tid] = 0;  // (visible after the first tile's barrier)
   uint32_t seq = 0;
+  if constexpr (DW0) {  // (a wave's region is its own: no barrier)
+#pragma unroll
+    for (int i = 0; i < TPW * 2; ++i) cacc[i * 64 + lane] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 
   auto colsum = [&](const f32x4 (&v)[TPW][MR], int slot, int tile) {
+    int g = lane >> 4;
+    asm volatile("" : "+v"(g));  // (the store addresses are formed here, not hoisted out of the tile loop as 64-bit pairs: see emit())
 #pragma unroll
     for (int tp = 0; tp < TPW; ++tp) {
       f32x4 s = v[tp][0];
@@ -1236,6 +1335,7 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
     u32x4 d[MR][Chunks<P, TPW>::CH];
     fetch<P, ACT == ACT_RELU, TPW>(d, a.m1[0], H, wbase, g, r, row0, M);
     load_tile<MT>(xin, in_rb, in_km, (const char*)a.d_out, a.ld_dout * ES, row0, M);
+    if constexpr (DW0) load_tile<MT>(xw, 128, 7, (const char*)a.xc, a.ld_xc * ES, row0, M);  // (the rows' first 64 columns)
     if constexpr (FRAG) {
       const int x_rb = a.ld_x * ES, x_km = kmask16(x_rb);
       load_tile<MT>(xt, x_rb, x_km, (const char*)a.x, x_rb, row0, M);
@@ -1318,7 +1418,9 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
     } else {
       eng.run(acc, xin, in_rb, in_km, KSB0, r, g);
     }
-    if constexpr (FRAG)  // (rows past M: d_out is zero there, hence dh_0 too)
+    if constexpr (DW0) {  // (rows past M: d_out is zero there, hence dh_0 too; the xc tile is zero there as well)
+      dw0_accumulate<TPW, MR, DW0 == 2>(acc, stage_w, xw, cacc, lane, a.xc_af, a.xc_skip);
+    } else if constexpr (FRAG)
       frag_store_acc<TPW, MR>(acc, stage, wid, lane, a.dh0f + (size_t)tile * (MR / 2) * (H / 16) * 64, H / 16);
     else
       emit<P, TPW, MR>(acc, ACT_NONE, nullptr, a.dh[0], H, wbase, g, r, row0, M);
@@ -1327,6 +1429,15 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
     STAMP(28);
     __syncthreads();  // tile end: the next tile's d_out lands in buffer B, its dz1 image in buffer A
     STAMP(29);
+  }
+  if constexpr (DW0) {  // this workgroup's partial dW0 -> dw0_slab[blockIdx.x][H][32]
+    float* sl = a.dw0_slab + (size_t)blockIdx.x * H * 32;
+#pragma unroll
+    for (int i = 0; i < TPW * 2; ++i) {
+      const f32x4 c = cacc[i * 64 + lane];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sl[(size_t)(wbase + 16 * (i >> 1) + 4 * g + e) * 32 + 16 * (i & 1) + r] = c[e];
+    }
   }
 }
 
@@ -1563,23 +1674,32 @@ static int launch_bwd_cfg(const FusedBwdArgs& a, hipStream_t s) {
 static int g_compact = 1;  // tuning knob 25: the one-block kernels skip the padding k-steps of their short layers (CEngine)
 void set_fused_compact(int v) { g_compact = v; }
 int fused_compact_on() { return g_compact; }
-template <class P, int TPW, int MR, int ACT, bool COMPACT, bool FRAG = false>
+// LDS of the in-kernel-dW0 variant: dz1 image, d_out tile, flags, d_out column sums, xc tile, staging, the dW0 partial
+static size_t bwd_one_dw0_lds(int MT, int H) {
+  return (size_t)MT * H * 2 + (size_t)MT * 64 + 64 + SAMPLER_WAVES * 32 * 4 + (size_t)MT * 128 + SAMPLER_WAVES * 2048 +
+         (size_t)SAMPLER_WAVES * (H / 128) * 2 * 64 * 16;
+}
+template <class P, int TPW, int MR, int ACT, bool COMPACT, bool FRAG = false, int DW0 = 0>
 static int launch_bwd_one_cfg2(const FusedBwdArgs& a, hipStream_t s) {
   constexpr int ES = P::ESIZE, MT = 16 * MR, H = 128 * TPW;
-  const size_t lds = 2 * (size_t)MT * H * ES + 64 + SAMPLER_WAVES * 128 * 4;
+  const size_t lds = DW0 ? bwd_one_dw0_lds(MT, H) : 2 * (size_t)MT * H * ES + 64 + SAMPLER_WAVES * 128 * 4;
   if (lds > 160 * 1024 || a.KpB0 > H || a.KpB0 > 128 || a.nb != 1) return -2;
   if (FRAG != (a.dz1f != nullptr)) return -4;
+  if ((DW0 != 0) != (a.dw0_slab != nullptr) || (DW0 == 2) != (a.dw0_round != 0)) return -4;
+  if (DW0 && (a.xc == nullptr || a.ld_xc < 64 || a.ld_xc % 8 || a.xc_af % 4 || a.xc_skip % 4 || a.xc_skip < 0 || a.dh[0] != nullptr ||
+              32 + a.xc_skip > 64 || a.out_valid > 32))
+    return -4;
   if (a.dz1f != nullptr || a.dh0f != nullptr || a.xf != nullptr || a.doutf != nullptr) {  // fragment mode: all four or none
     if (ES != 2 || !a.dz1f || !a.dh0f || !a.xf || !a.doutf || !a.x || a.ld_x % 16 || a.dof_nt < 1 || a.dof_nt * 16 > a.KpB0 ||
         (size_t)MT * ((size_t)a.KpB0 * ES + (size_t)a.ld_x * ES) + (size_t)SAMPLER_WAVES * 32 * 32 * TPW > (size_t)MT * H * ES)
       return -4;
   }
   static DevLatch attr;
-  raise_lds(fused_backward_one_kernel<P, TPW, MR, ACT, COMPACT, FRAG>, attr);
+  raise_lds(fused_backward_one_kernel<P, TPW, MR, ACT, COMPACT, FRAG, DW0>, attr);
   const int ntiles = (a.M + MT - 1) / MT;
   const bool probe = probe_begin(PROBE_FUSED_BWD, s);
-  hipLaunchKernelGGL((fused_backward_one_kernel<P, TPW, MR, ACT, COMPACT, FRAG>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512),
-                     lds, s, a);
+  hipLaunchKernelGGL((fused_backward_one_kernel<P, TPW, MR, ACT, COMPACT, FRAG, DW0>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS),
+                     dim3(512), lds, s, a);
   if (probe) probe_end(s, 2.0 * a.M * ((double)a.out_valid * H + 2.0 * a.nb * H * H));
   return 0;
 }
@@ -1588,12 +1708,32 @@ static int launch_bwd_one_cfg(const FusedBwdArgs& a, hipStream_t s) {
   if constexpr (ring_depth<TPW, MR>() == 4) {
     if constexpr (P::ESIZE == 2) {
       if (a.dz1f != nullptr) return g_compact && a.out_valid <= P::KB ? launch_bwd_one_cfg2<P, TPW, MR, ACT, true, true>(a, s) : -4;
+      if (a.dw0_slab != nullptr)
+        return !(g_compact && a.out_valid <= P::KB) ? -4
+               : a.dw0_round                        ? launch_bwd_one_cfg2<P, TPW, MR, ACT, true, false, 2>(a, s)
+                                                    : launch_bwd_one_cfg2<P, TPW, MR, ACT, true, false, 1>(a, s);
     }
+    if (a.dw0_slab != nullptr) return -4;
     if (g_compact && a.out_valid <= P::KB) return launch_bwd_one_cfg2<P, TPW, MR, ACT, true>(a, s);
   }
   return launch_bwd_one_cfg2<P, TPW, MR, ACT, false>(a, s);
 }
 
+template <class P>
+int fused_bwd_one_grid(const dppo_net_desc& d, int64_t M) {
+  const int mt = 16 * pick_mr<P>(d.hidden);
+  if (mt <= 0 || M <= 0) return 0;
+  const int64_t ntiles = (M + mt - 1) / mt;
+  return (int)(ntiles < NUM_CUS ? ntiles : NUM_CUS);
+}
+template int fused_bwd_one_grid<F32>(const dppo_net_desc&, int64_t);
+template int fused_bwd_one_grid<BF16>(const dppo_net_desc&, int64_t);
+// shapes the in-kernel dW0 is built for: bf16 one-block backward on the compact walk with a ring of four (H = 256, 512), its
+// LDS within the CU's 160 KB (the caller checks the 32-column limit of its input rows)
+bool fused_dw0_shape(const dppo_net_desc& d) {
+  if (!g_compact || !fused_bwd_one_block<BF16>(d) || d.out_dim > BF16::KB || (d.hidden != 512 && d.hidden != 256)) return false;
+  return bwd_one_dw0_lds(16 * pick_mr<BF16>(d.hidden), d.hidden) <= 160 * 1024;
+}
 template <class P>
 int launch_fused_backward(const dppo_net_desc& d, const FusedBwdArgs& a, hipStream_t s) {
   const bool relu = a.act == ACT_RELU;

@@ -188,6 +188,7 @@ struct SlabJob {
   const float* slab;  // [splits][rows][lds]; columns c0 .. c0 + cols of every row are reduced
   float* out;         // [rows][ldo], or its transpose when `transpose`
   int splits, rows, cols, lds, ldo, transpose, c0;
+  int wide;  // 1: many slabs (one per workgroup of the fused backward): 64 elements per block, the block's waves share the slabs
 };
 constexpr int MAX_SLAB_JOBS = 24;
 struct SlabJobs {
@@ -310,7 +311,16 @@ struct PostReduce {  // see post_reduce_kernel; dW == null: no low-rank part; G 
   // longer forms (fused_backward_one_kernel)
   const float* Wout_b;
   float* db2;
-  int n_lowrank, n_temb, n_wout;  // set by the launcher
+  // in-kernel dW0 (api.hip, mlp_backward): S_rest != null: S holds the one-hot sums of the first Kft - 1 steps only, the last
+  // one is S_rest[h] - (their sum) (S_rest = column sums of the rounded dh_0: every row carries exactly one step; G's last row is
+  // then formed from S_rest and corrected by the block that finishes the time MLP's backward).  dW0t != null:
+  // the time-embedding columns of the first layer's weight gradient are formed here from the same sums,
+  // dW0t[h * ldw0 + AF + j] = sum_k S[h][k] elem(temb[t_k][j]) (temb: the table the input rows were built from, rounded as they were)
+  const float* S_rest;
+  float* dW0t;
+  const float* temb;
+  int temb_bf16;  // 1: the rows hold bf16 roundings of the table
+  int n_lowrank, n_temb, n_wout, n_dw0t;  // set by the launcher
 };
 void launch_wout_grad(const PostReduce& q, hipStream_t s);  // the merged-top / one-block parts alone (no arrival counter needed)
 void launch_post_reduce(PostReduce& q, hipStream_t s);

@@ -907,8 +907,9 @@ __device__ __forceinline__ void time_backward_prepare(const float* w1, const flo
   }
 }
 // part B: G[Kft][td] -> gradients of the four parameter tensors
+// last_is_total: G_in's last row holds the sum over ALL steps (PostReduce::S_rest): the other rows are subtracted here first
 __device__ __forceinline__ void time_backward_finish(const float* G_in, int Kft, int td, float* gw1, float* gb1, float* gw2,
-                                                     float* gb2, float* sh) {
+                                                     float* gb2, float* sh, bool last_is_total = false) {
   const int per = 7 * td;
   const int tid = threadIdx.x;
   const float* w2s = sh + Kft * per + 2 * td * td;
@@ -917,6 +918,14 @@ __device__ __forceinline__ void time_backward_finish(const float* G_in, int Kft,
     Gs[i] = __hip_atomic_load(&G_in[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const float* G = Gs;
   __syncthreads();
+  if (last_is_total) {
+    for (int j = tid; j < td; j += 256) {
+      float s = Gs[(Kft - 1) * td + j];
+      for (int k = 0; k < Kft - 1; ++k) s -= Gs[k * td + j];
+      Gs[(Kft - 1) * td + j] = s;
+    }
+    __syncthreads();
+  }
   for (int i = tid; i < Kft * 2 * td; i += 256) {
     const int k = i / (2 * td), o = i % (2 * td);
     float s = 0.f;
@@ -1008,6 +1017,26 @@ __device__ __forceinline__ void lowrank_dw_block(const float* Wout, const float*
   for (int u = 0; u < LOWRANK_RI; ++u)
     if (i0 + u < H) dW[(size_t)(i0 + u) * H + j] = acc[u];
 }
+// dW0[h][AF + j] = sum_k S[h][k] elem(temb[t_k][j]) (PostReduce::dW0t): one thread per output
+__device__ __forceinline__ void dw0_temb_block(const PostReduce& q, int b) {
+  const int out = b * 256 + threadIdx.x;
+  if (out >= q.H * q.td) return;
+  const int h = out / q.td, j = out - h * q.td;
+  float acc = 0.f, rest = q.S_rest != nullptr ? q.S_rest[h] : 0.f;
+  for (int k = 0; k < q.Kft; ++k) {
+    float sk;
+    if (q.S_rest != nullptr && k == q.Kft - 1) {
+      sk = rest;
+    } else {
+      sk = q.S[(size_t)h * q.Kft + k];
+      rest -= sk;
+    }
+    float t = q.temb[(size_t)q.ksteps[k].t * q.td + j];
+    if (q.temb_bf16) t = bf2f(f2bf(t));
+    acc += sk * t;
+  }
+  q.dW0t[(size_t)h * q.ldw0 + q.AF + j] = acc;
+}
 static int wout_grad_blocks(const PostReduce& q) {
   return ((q.U != nullptr ? q.out_dim * q.H : 0) + (q.db2 != nullptr ? q.H : 0) + 3) / 4;
 }
@@ -1020,6 +1049,10 @@ void launch_wout_grad(const PostReduce& q, hipStream_t s) {
 __global__ __launch_bounds__(256) void post_reduce_kernel(const PostReduce q) {
   extern __shared__ float sh[];
   const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= q.n_lowrank + q.n_temb + q.n_wout) {
+    dw0_temb_block(q, blockIdx.x - q.n_lowrank - q.n_temb - q.n_wout);
+    return;
+  }
   if ((int)blockIdx.x >= q.n_lowrank + q.n_temb) {
     wout_grad_block(q, blockIdx.x - q.n_lowrank - q.n_temb);
     return;
@@ -1031,8 +1064,10 @@ __global__ __launch_bounds__(256) void post_reduce_kernel(const PostReduce q) {
   const int tb = blockIdx.x - q.n_lowrank, lane = tid & 63, out = tb * 4 + (tid >> 6);
   if (out < q.Kft * q.td) {
     const int k = out / q.td, j = out % q.td;
+    // (S_rest: the last step's row is formed from the sums over ALL rows; time_backward_finish subtracts the other steps' rows)
+    const bool rest = q.S_rest != nullptr && k == q.Kft - 1;
     float acc = 0.f;
-    for (int h = lane; h < q.H; h += 64) acc += q.W0[(size_t)h * q.ldw0 + q.AF + j] * q.S[(size_t)h * q.Kft + k];
+    for (int h = lane; h < q.H; h += 64) acc += q.W0[(size_t)h * q.ldw0 + q.AF + j] * (rest ? q.S_rest[h] : q.S[(size_t)h * q.Kft + k]);
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
     // write-through (sc1) store, read back by the last block with sc1 loads (time_backward_finish): the hand-over then needs
     // no fence on either side -- every storing wave drains its store, the block's barrier, ONE relaxed agent-scope add
@@ -1057,13 +1092,14 @@ __global__ __launch_bounds__(256) void post_reduce_kernel(const PostReduce q) {
     DPPO_HANDOVER_ACQUIRE();
   }
   __syncthreads();
-  time_backward_finish(q.G, q.Kft, q.td, q.gw1, q.gb1, q.gw2, q.gb2, sh);
+  time_backward_finish(q.G, q.Kft, q.td, q.gw1, q.gb1, q.gw2, q.gb2, sh, q.S_rest != nullptr);
 }
 void launch_post_reduce(PostReduce& q, hipStream_t s) {
   q.n_lowrank = q.dW != nullptr ? lowrank_dw_blocks(q.H) : 0;
   q.n_temb = q.G != nullptr ? (q.Kft * q.td + 3) / 4 : 0;
   q.n_wout = wout_grad_blocks(q);
-  const int blocks = q.n_lowrank + q.n_temb + q.n_wout;
+  q.n_dw0t = q.dW0t != nullptr && q.G != nullptr ? (q.H * q.td + 255) / 256 : 0;
+  const int blocks = q.n_lowrank + q.n_temb + q.n_wout + q.n_dw0t;
   static DevLatch raised;
   if (raised.need()) raise_dyn_lds(post_reduce_kernel), raised.done();
   if (blocks > 0)
@@ -1119,7 +1155,46 @@ void launch_slab_reduce_2d(const float* slab, int splits, int rows, int cols, in
                      cols, lds, out, ldo, scale, transpose);
 }
 
+// A job of very many slabs (SlabJob::wide: the in-kernel dW0's one slab per workgroup of the fused backward, up to 256 of them):
+// a thread per element would add 256 values in eight dependent batches on three CUs (measured 44 us for a 256 x 11 output).  Here
+// 64 consecutive elements belong to a block, wave w of it adds slabs w, w + NW, w + 2 NW, ... (NW = waves per block, at most 16
+// loads in flight per lane, one or two memory latencies), and wave 0 adds the NW partial sums in a fixed order.
+__device__ __forceinline__ void slab_job_block_wide(const SlabJob& J) {
+  __shared__ float wred[16][64];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, NW = blockDim.x >> 6;
+  const size_t n = (size_t)J.rows * J.cols;
+  for (size_t e0 = (size_t)blockIdx.x * 64; e0 < n; e0 += (size_t)gridDim.x * 64) {
+    const size_t i = e0 + lane;
+    const bool live = i < n;
+    const int r = live ? (int)(i / J.cols) : 0, c = live ? (int)(i % J.cols) : 0;
+    const float* src = J.slab + (size_t)r * J.lds + J.c0 + c;
+    const size_t stride = (size_t)J.rows * J.lds;
+    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k0 = w; k0 < J.splits; k0 += 8 * NW) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = live && k0 + u * NW < J.splits ? src[(size_t)(k0 + u * NW) * stride] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p[u] += t[u];
+    }
+    wred[w][lane] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    __syncthreads();
+    if (w == 0 && live) {
+      float v = 0.f;
+      for (int u = 0; u < NW; ++u) v += wred[u][lane];
+      if (J.transpose)
+        J.out[(size_t)c * J.ldo + r] = v;
+      else
+        J.out[(size_t)r * J.ldo + c] = v;
+    }
+    __syncthreads();
+  }
+}
 __device__ __forceinline__ void slab_job_block(const SlabJob& J) {
+  if (J.wide) {  // (uniform over the block)
+    slab_job_block_wide(J);
+    return;
+  }
   // (A 16-byte form of this loop -- a thread owning four consecutive columns, the same summation tree per element, 128 bytes
   // per lane in flight instead of 32 -- was SLOWER: 21.1 vs 17.0 us per launch on average, tools/tail_reduce_parts.sh.  The
   // slabs of one output element lie rows x lds x 4 bytes = 1 MB apart, so what bounds the loop is not the bytes in flight per
@@ -1201,7 +1276,8 @@ __global__ __launch_bounds__(1024) void tail_reduce_kernel(const TailReduce t) {
 void launch_tail_reduce(TailReduce& t, const LossArgs* fin, hipStream_t s) {
   size_t most = 0;
   for (int i = 0; i < t.jobs.n; ++i) {
-    const size_t n = (size_t)t.jobs.j[i].rows * t.jobs.j[i].cols;
+    size_t n = (size_t)t.jobs.j[i].rows * t.jobs.j[i].cols;
+    if (t.jobs.j[i].wide) n *= 16;  // (64 elements per 1024-thread block: slab_job_block_wide)
     most = n > most ? n : most;
   }
   const bool has_fin = fin != nullptr && fin->N > 0;
@@ -1221,7 +1297,8 @@ void launch_slab_reduce_batch(const SlabJobs& jobs, hipStream_t s) {
   if (jobs.n <= 0) return;
   size_t most = 0;
   for (int i = 0; i < jobs.n; ++i) {
-    const size_t n = (size_t)jobs.j[i].rows * jobs.j[i].cols;
+    size_t n = (size_t)jobs.j[i].rows * jobs.j[i].cols;
+    if (jobs.j[i].wide) n *= 4;  // (64 elements per 256-thread block)
     most = n > most ? n : most;
   }
   if (most == 0) return;

@@ -492,6 +492,10 @@ int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* 
  * knob 36: the minibatch's advantage moments (PPO update, single rank): partial sums by the last 64 blocks of the row builder's
  *          launch, added by every block of the loss kernel (1), or a launch of their own between the rows and the
  *          actor's forward (0, default: it already overlaps the critic's forward; the riders gain 3.5 us in serial order only)
+ * knob 37: one-block bf16 networks whose informative input columns fit 32 (a denoiser: action chunk + observation + Kft - 1 one-hot
+ *          step columns; a critic: its observation): the first layer's weight gradient is accumulated inside the fused backward
+ *          kernel, per persistent workgroup in LDS, and d loss / d h_0 is neither stored nor read back (1, default); 0: dh_0 is
+ *          stored and contracted by the weight-gradient GEMM launch
  * knob 35: what follows the weight-gradient GEMMs of a backward pass -- slab sums, bias column sums, loss statistics -- inside
  *          the GEMM launch (1: the last workgroup at an output tile sums its slabs, the small reductions ride as extra
  *          workgroups; measured slower, 200 vs 107 + 32 us) or as a launch of its own (0, default)
