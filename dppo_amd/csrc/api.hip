@@ -426,6 +426,7 @@ static bool bwd_one(const dppo_net_desc& d, int64_t M) {
   return fused_bwd_one_block<P>(d) && d.out_dim <= 128 && lowrank_top(d, M);
 }
 
+static int g_dbg = 0;  // tuning knob 8: timing experiments on the fused kernels (results are wrong while it is set)
 template <class P>
 static void carve_mlp(Carver& c, const dppo_net_desc& d, int64_t M, bool keep, bool bwd, MlpBufs<P>& B) {
   const size_t ES = P::ESIZE;
@@ -556,6 +557,9 @@ static void mlp_forward(const dppo_net_desc& d, const float* prm, const char* pk
     B.merged = fused_can_merge<P>(d);
     if (B.merged) {  // the block's second layer folded into the out layer: h_nb is never formed (fused_forward_merged_kernel)
       f.merge_top = 1, f.ks0v = (d.in_dim + P::KB - 1) / P::KB, f.hpre[nb] = nullptr;
+      if (g_dbg & 64) f.hpre[0] = nullptr;   // timing experiments: the forward does not store act'(h_0) ...
+      if (g_dbg & 128) f.a2[0] = nullptr;    // ... / act(z1)
+      if (g_dbg & 256) f.z1[0] = nullptr;    // ... / act'(z1)
       f.ostream0 = (const u32x4*)(pk + L.ostream0), f.ostream2 = (const u32x4*)(pk + L.ostream2);
       f.cbias2 = (const float*)(pk + L.cbias2);
     }
@@ -675,7 +679,6 @@ static void join_side(hipStream_t main, hipStream_t sidestream, int idx = 0) {
   (void)hipStreamWaitEvent(main, t->join, 0);
 }
 
-static int g_dbg = 0;  // tuning knob 8: timing experiments on the fused backward (results are wrong while it is set)
 static int g_post_one = 1;         // tuning knob 18: low-rank dW2 + time-embedding gradient in one launch after the slab reduce
 static int g_merge_top = 1;        // tuning knob 17: sampler merges the top block's second layer into the out layer
 static int g_lowrank_top = 1;      // tuning knob 16: top block's dW2 from the rank-out_dim factorisation (no H x H GEMM, no dh store)

@@ -9,6 +9,9 @@
 #ifndef DPPO_BWD_LATE
 #define DPPO_BWD_LATE 1
 #endif
+#ifndef DPPO_BWD_PREFETCH
+#define DPPO_BWD_PREFETCH 1  // the in-kernel-dW0 backward requests its next tile's small operands a phase early (0: at the tile's start, for A/B runs)
+#endif
 #ifndef DPPO_FLAGS
 #define DPPO_FLAGS 1  // layer hand-over by per-wave LDS flags instead of workgroup barriers (0: barriers, for A/B runs)
 #endif
@@ -1328,14 +1331,65 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
     }
   };
 
+  // DW0: the NEXT tile's d_out and input-row chunks are requested before this tile's dW0 phase and written to LDS behind the
+  // tile-end barrier (pd / px: one or two 16-byte chunks per thread), and one dword per 128 bytes of its first derivative-source
+  // rows is touched at the same point, so that the fetch at the tile's start finds them in L2: the tile start -- request, wait for
+  // first-touch HBM rows, barrier -- was 5k cycles of a 32k-cycle tile with every wave idle (profiles/r02_final_fused_phase_stamps.txt)
+  constexpr bool PF = DW0 != 0 && DPPO_BWD_PREFETCH;
+  constexpr int ND = (MT * 4 + 511) / 512, NX = (MT * 8 + 511) / 512;
+  u32x4 pd[PF ? ND : 1], px[PF ? NX : 1];
+  uint32_t warm = 0;
+  auto tile_prefetch = [&](int t) {
+    const int prow0 = t * MT;
+    int t0 = tid;
+    asm volatile("" : "+v"(t0));  // (see load_tile)
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int q = t0 + 512 * i, row = q >> 2, c = q & 3, grow = prow0 + row;
+      pd[i] = (u32x4){0, 0, 0, 0};
+      if (q < MT * 4 && c * 16 < a.ld_dout * ES && grow < M) pd[i] = *(const u32x4*)((const char*)a.d_out + (size_t)grow * a.ld_dout * ES + c * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int q = t0 + 512 * i, row = q >> 3, c = q & 7, grow = prow0 + row;
+      px[i] = (u32x4){0, 0, 0, 0};
+      if (q < MT * 8 && grow < M) px[i] = *(const u32x4*)((const char*)a.xc + (size_t)grow * a.ld_xc * ES + c * 16);
+    }
+  };
+  auto tile_commit = [&]() {
+    int t0 = tid;
+    asm volatile("" : "+v"(t0));
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int q = t0 + 512 * i, row = q >> 2, c = q & 3;
+      if (q < MT * 4) *(u32x4*)(xin + row * 64 + ((c ^ (row & 3)) << 4)) = pd[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int q = t0 + 512 * i, row = q >> 3, c = q & 7;
+      if (q < MT * 8) *(u32x4*)(xw + row * 128 + ((c ^ (row & 7)) << 4)) = px[i];
+    }
+  };
+  auto warm_rows = [&](const void* src, int t) {  // the derivative-source rows of tile t: [MT][H] elem, or the ReLU sign words
+    constexpr int RB = ACT == ACT_RELU ? SIGN_WORDS * 4 : HRB;
+    const size_t off = (size_t)t * MT * RB + (size_t)tid * 128;
+    if (src != nullptr && tid * 128 < MT * RB && off + 4 <= (size_t)M * RB) warm = *(const uint32_t*)((const char*)src + off);
+  };
+  if constexpr (PF) tile_prefetch(blockIdx.x);
+
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int row0 = tile * MT;
     STAMP(16);
     // the first phase's derivative sources: issued with the tile's own loads, so that one memory latency covers both
     u32x4 d[MR][Chunks<P, TPW>::CH];
     fetch<P, ACT == ACT_RELU, TPW>(d, a.m1[0], H, wbase, g, r, row0, M);
-    load_tile<MT>(xin, in_rb, in_km, (const char*)a.d_out, a.ld_dout * ES, row0, M);
-    if constexpr (DW0) load_tile<MT>(xw, 128, 7, (const char*)a.xc, a.ld_xc * ES, row0, M);  // (the rows' first 64 columns)
+    if constexpr (PF) {
+      asm volatile("" ::"v"(warm));  // (the touch has landed: its register is free again)
+      tile_commit();
+    } else {
+      load_tile<MT>(xin, in_rb, in_km, (const char*)a.d_out, a.ld_dout * ES, row0, M);
+      if constexpr (DW0) load_tile<MT>(xw, 128, 7, (const char*)a.xc, a.ld_xc * ES, row0, M);  // (the rows' first 64 columns)
+    }
     if constexpr (FRAG) {
       const int x_rb = a.ld_x * ES, x_km = kmask16(x_rb);
       load_tile<MT>(xt, x_rb, x_km, (const char*)a.x, x_rb, row0, M);
@@ -1417,6 +1471,12 @@ __global__ __launch_bounds__(512, 2) void fused_backward_one_kernel(const FusedB
       eng.end_tile();
     } else {
       eng.run(acc, xin, in_rb, in_km, KSB0, r, g);
+    }
+    if constexpr (PF) {
+      if (tile + (int)gridDim.x < ntiles) {
+        tile_prefetch(tile + gridDim.x);
+        warm_rows(a.m1[0], tile + gridDim.x);
+      }
     }
     if constexpr (DW0) {  // (rows past M: d_out is zero there, hence dh_0 too; the xc tile is zero there as well)
       dw0_accumulate<TPW, MR, DW0 == 2>(acc, stage_w, xw, cacc, lane, a.xc_af, a.xc_skip);
