@@ -744,6 +744,12 @@ static bool frag_ok(const dppo_net_desc& d, int64_t M, const PackLayout& L, int 
 // Needs the one-block backward on its compact walk, the one-hot time columns, post_reduce in one launch, nobody asking for
 // d loss / d observation, no cond_mlp, and a slab per workgroup in the pool.
 static int g_dw0 = 1;
+// Tuning knob 38: with the in-kernel dW0 everything the time-embedding gradient needs -- the one-hot sums, the first layer's bias
+// gradient, then G = W0_temb^T . S and the time MLP's backward (a chain of dependent steps: 11 of post_reduce's 16 us) -- comes out
+// of the backward KERNEL, not out of the weight-gradient GEMMs: that reduction and that part of post_reduce run on a side stream
+// under the GEMM launch, with the bias sums and the loss statistics, and only the GEMMs' own slabs, the low-rank dW2 and dWout
+// stay behind the GEMMs on the caller's stream.
+static int g_side_tail = 1;
 static int dw0_cols(const dppo_net_desc& d) { return d.kind == 0 ? d.act_flat + d.cond_dim : d.in_dim; }
 static int dw0_nhot(const dppo_net_desc& d, int Kft) {  // one-hot columns that fit behind the data columns
   const int room = 32 - dw0_cols(d);
@@ -1088,6 +1094,10 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       // merged top (the forward never formed h_nb): dWout = d_out^T . h_nb is rebuilt behind the slab reduce from
       // U = d_out^T . x and T = d_out^T . act(z1) (PostReduce::U); T is then needed whether or not dW2 uses it
       const bool merged = B.merged;
+      const bool side_tail = dw0 && d.kind == 0 && oh >= 0 && aux_idx >= 0 && !need_aux && g_side_tail && g_early_join && g_post_one &&
+                             B.post_zeroed && !(g_dbg & 28);
+      TailReduce side_t;
+      memset(&side_t, 0, sizeof(side_t));
       if (frag) {  // the same four products from fragment operands (one block, merged, low-rank: see frag_ok())
         const int ntx = L.Kp0 / 16, nth = H / 16;
         // U^T = x^T . d_out  [in_dim][out_dim] -> lowrank_u [out_dim][Kp0]
@@ -1114,7 +1124,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       }
       if (dw0) {  // the kernel's per-workgroup partials [grid][H][32]: data columns -> dW0, one-hot columns -> S[h][k] (B.part)
         auto job = [&](int c0, int cols, float* out, int ldo) {
-          SlabJob& j = B.slab_jobs.j[B.slab_jobs.n++];
+          SlabJob& j = side_tail ? side_t.jobs.j[side_t.jobs.n++] : B.slab_jobs.j[B.slab_jobs.n++];
           j.slab = dw0_slab, j.out = out, j.splits = dw0_grid, j.rows = H, j.cols = cols, j.lds = 32, j.ldo = ldo, j.transpose = 0;
           j.c0 = c0, j.wide = dw0_grid >= 32 ? 1 : 0;  // (a slab per workgroup: slab_job_block_wide)
         };
@@ -1132,8 +1142,28 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       else
         weight_grad<P>(B.dh_all[0], H, H, B.in, L.Kp0, d.in_dim, M, B, grad + pl.W0, d.in_dim, s, true);
       }
+      if (side_tail) {
+        // what the backward kernel alone feeds: its dW0 slabs, the bias sums, the loss statistics, then the time-embedding
+        // gradient -- queued on the side stream here, BEHIND the kernel and BESIDE the GEMM launch that follows on s
+        hipStream_t st = fork_side(s, aux_idx);
+        side_t.colsum = B.tile_colsum, side_t.tiles = B.tiles, side_t.width = H, side_t.slots = so;
+        launch_tail_reduce(side_t, fin, st);
+        PostReduce qs;
+        memset(&qs, 0, sizeof(qs));
+        qs.H = H, qs.out_dim = d.out_dim;
+        qs.S = B.part, qs.W0 = prm + pl.W0, qs.ldw0 = d.in_dim, qs.AF = d.act_flat, qs.Kft = Kft, qs.td = d.time_dim;
+        qs.G = B.part + (size_t)H * Kft, qs.w1 = prm + pl.te1_w, qs.b1 = prm + pl.te1_b, qs.w2 = prm + pl.te2_w;
+        qs.ksteps = ksteps, qs.gw1 = grad + pl.te1_w, qs.gb1 = grad + pl.te1_b, qs.gw2 = grad + pl.te2_w, qs.gb2 = grad + pl.te2_b;
+        qs.S_rest = s_rest, qs.dW0t = grad + pl.W0, qs.temb = (const float*)(pk + L.temb), qs.temb_bf16 = P::ESIZE == 2 ? 1 : 0;
+        qs.counter = (unsigned*)B.post_counter;
+        launch_post_reduce(qs, st);
+        B.join_s[B.n_join] = st, B.join_idx[B.n_join++] = aux_idx;  // (joined right behind the GEMM launch: flush_slabs)
+      }
       if (aux != s && g_early_join) B.join_s[B.n_join] = aux, B.join_idx[B.n_join++] = aux_idx;
-      flush_slabs(B, s, &so, H, fin);  // every slab of this backward, its bias sums and the loss statistics: one launch
+      if (side_tail)
+        flush_slabs(B, s);  // the GEMMs' own slabs
+      else
+        flush_slabs(B, s, &so, H, fin);  // every slab of this backward, its bias sums and the loss statistics: one launch
       if (aux != s && !g_early_join) join_side(s, aux, aux_idx);
       PostReduce q;
       memset(&q, 0, sizeof(q));
@@ -1147,7 +1177,7 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       // needed by the time-embedding part
       if (g_post_one && (oh < 0 || B.post_zeroed) && (lowrank || oh >= 0 || merged || one)) {
         if (lowrank) q.Wout = prm + pl.Wout, q.dW = grad + pl.l2w[nb - 1];
-        if (oh >= 0) {
+        if (oh >= 0 && !side_tail) {
           q.S = B.part, q.W0 = prm + pl.W0, q.ldw0 = d.in_dim, q.AF = d.act_flat, q.Kft = Kft, q.td = d.time_dim;
           q.G = B.part + (size_t)H * Kft, q.w1 = prm + pl.te1_w, q.b1 = prm + pl.te1_b, q.w2 = prm + pl.te2_w;
           q.ksteps = ksteps, q.gw1 = grad + pl.te1_w, q.gb1 = grad + pl.te1_b, q.gw2 = grad + pl.te2_w;
@@ -2733,6 +2763,10 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 37) {  // in-kernel first-layer weight gradient of the one-block backward (1, default) or dh_0 stored and a GEMM of its own (0)
     g_dw0 = value;
+    return 0;
+  }
+  if (knob == 38) {  // with knob 37: the reductions the backward kernel alone feeds and the time-embedding gradient on a side stream under the GEMMs (1, default)
+    g_side_tail = value;
     return 0;
   }
   if (knob == 35) {  // the reductions behind the weight-gradient GEMMs inside their launch (1, default) or as a launch of their own (0)

@@ -496,6 +496,9 @@ int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* 
  *          step columns; a critic: its observation): the first layer's weight gradient is accumulated inside the fused backward
  *          kernel, per persistent workgroup in LDS, and d loss / d h_0 is neither stored nor read back (1, default); 0: dh_0 is
  *          stored and contracted by the weight-gradient GEMM launch
+ * knob 38: with knob 37, a denoiser's backward: the reductions that the backward kernel alone feeds (its first-layer slabs, the bias
+ *          sums, the loss statistics) and the time-embedding gradient behind them run on the library's second side stream under
+ *          the weight-gradient GEMM launch (1, default) or behind it with everything else (0)
  * knob 35: what follows the weight-gradient GEMMs of a backward pass -- slab sums, bias column sums, loss statistics -- inside
  *          the GEMM launch (1: the last workgroup at an output tile sums its slabs, the small reductions ride as extra
  *          workgroups; measured slower, 200 vs 107 + 32 us) or as a launch of its own (0, default)

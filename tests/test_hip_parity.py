@@ -597,7 +597,7 @@ def test_fused_path_matches_layered_path(prec, tol, sname):
 @pytest.mark.parametrize("sname,knob", [("hopper", 22), ("can", 22), ("halfcheetah", 22), ("can_relu", 22), ("hopper", 23),
                                         ("can", 23), ("square_like", 23), ("hopper", 25), ("halfcheetah", 25), ("hopper", 31),
                                         ("halfcheetah", 31), ("can", 31), ("hopper", 36), ("can", 36), ("hopper", 37),
-                                        ("halfcheetah", 37), ("can", 37)])
+                                        ("halfcheetah", 37), ("can", 37), ("hopper", 38)])
 def test_one_block_kernels_match_the_general_ones(prec, tol, sname, knob):
     """One-block networks have their own fused kernels.  Knob 22: the forward folds the block's second layer into the out
     layer and the out-layer weight gradient is rebuilt from d_out^T x and d_out^T act(z1) (hopper: actor and critic; halfcheetah
@@ -610,7 +610,8 @@ def test_one_block_kernels_match_the_general_ones(prec, tol, sname, knob):
     LDS-free gemm_tn_frag_kernel (same operand bits; only the fp32 summation order over the batch differs).  Knob 36: the
     advantage moments as partial sums riding the row builder's launch, added in the loss kernel's prologue.  Knob 37 (bf16): the
     first layer's weight gradient accumulated inside the one-block backward (dh_0 never stored; hopper: actor and critic, the
-    others: the critic).  Same log-probs, values, loss
+    others: the critic).  Knob 38: with it, the reductions the backward kernel feeds and the time-embedding gradient on a side
+    stream under the weight-gradient GEMMs.  Same log-probs, values, loss
     statistics and gradients -- tensor by tensor -- as the general kernels."""
     from dppo_amd import hip
     lib = hip.load()
