@@ -599,6 +599,18 @@ def test_fused_path_matches_layered_path(prec, tol, sname):
                                         ("halfcheetah", 31), ("can", 31), ("hopper", 36), ("can", 36), ("hopper", 37),
                                         ("halfcheetah", 37), ("can", 37), ("hopper", 38)])
 def test_one_block_kernels_match_the_general_ones(prec, tol, sname, knob):
+    _one_block_ab(prec, tol, sname, knob)
+
+
+@pytest.mark.parametrize("N,Kft", [(1300, 10), (2100, 10), (6500, 5), (1300, 5), (4103, 7)])
+def test_in_kernel_first_layer_gradient_at_other_grids_and_step_counts(N, Kft):
+    """Knob 37 beyond the headline shape: minibatches of 21 / 33 / 65 / 102 row tiles (a slab per workgroup: below 32 slabs the
+    ordinary reduction, from 32 on the wide one; a last tile with 7 rows), and 5 / 7 fine-tuned steps, where every one-hot column
+    fits the 32 (no column is rebuilt from the bias gradient, which then stays the exact fp32 column sum)."""
+    _one_block_ab("bf16", 2e-2, "hopper", 37, N=N, Kft=Kft)
+
+
+def _one_block_ab(prec, tol, sname, knob, N=6500, Kft=10):
     """One-block networks have their own fused kernels.  Knob 22: the forward folds the block's second layer into the out
     layer and the out-layer weight gradient is rebuilt from d_out^T x and d_out^T act(z1) (hopper: actor and critic; halfcheetah
     (24 outputs, ReLU), can (BASELINE configs[2]: 56 outputs, Mish, three input k-steps) and can_relu: the wide-head form, whose
@@ -615,9 +627,9 @@ def test_one_block_kernels_match_the_general_ones(prec, tol, sname, knob):
     statistics and gradients -- tensor by tensor -- as the general kernels."""
     from dppo_amd import hip
     lib = hip.load()
-    kw = dict(denoising_steps=20, ft_denoising_steps=10, clip_ploss_coef=0.01, randn_clip_value=3)
+    kw = dict(denoising_steps=20, ft_denoising_steps=Kft, clip_ploss_coef=0.01, randn_clip_value=3)
     m, a, c = build_model(sname, kw, 73, prec)
-    R, N, Kft = 800, 6500, 10  # N >= 200 x out_dim: the low-rank dW2 (and with it the one-block backward) is on
+    R = max(800, -(-N // Kft) + 16)  # (N >= 100 x out_dim: the low-rank dW2 -- and with it the one-block backward -- is on)
     AF = a.horizon_steps * a.action_dim
     out = {}
     default = 0 if knob in (31, 36) else 1  # (knobs 31 and 36 ship off: see csrc/api.hip g_frag, g_mom_rider)
