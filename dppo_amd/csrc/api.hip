@@ -830,7 +830,11 @@ static void flush_slabs(MlpBufs<P>& B, hipStream_t s, const SlotOuts* slots = nu
     launch_gemm_tn_frag_group(gr, B.mpad, s);
     gr.n = 0;
   }
-  for (int i = 0; i < B.n_join; ++i) join_side(s, B.join_s[i], B.join_idx[i]);
+  // One wait on the caller's stream however many side streams there are: the earlier ones are joined into the LAST one (their
+  // waits cost nothing there) and only that one into s -- a satisfied event wait is still a barrier packet between the GEMM
+  // launch and the reduction behind it, ~6 us each on the update's critical path (profiles/r03_dw0_ab.txt, knob 38).
+  for (int i = 0; i + 1 < B.n_join; ++i) join_side(B.join_s[B.n_join - 1], B.join_s[i], B.join_idx[i]);
+  if (B.n_join > 0) join_side(s, B.join_s[B.n_join - 1], B.join_idx[B.n_join - 1]);
   B.n_join = 0;
   if (folded) {
     // everything a reduction launch would do has been done by the GEMM launch
