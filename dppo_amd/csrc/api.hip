@@ -533,7 +533,8 @@ static void cond_encode(const dppo_net_desc& d, const float* prm, const char* pk
 
 template <class P>
 static void mlp_forward(const dppo_net_desc& d, const float* prm, const char* pk, const PackLayout& L, int64_t M,
-                        MlpBufs<P>& B, bool keep, hipStream_t s) {
+                        MlpBufs<P>& B, bool keep, hipStream_t s, const LossArgs* fuse_loss = nullptr) {
+  // fuse_loss: the policy half of the PPO loss in the forward kernel's epilogue (fuse_loss_ok() held: the merged fused kernel runs)
   const ParamLayout pl = param_layout(d);
   const int H = d.hidden, nb = d.n_blocks;
   if (fused_ok<P>(d)) {
@@ -569,7 +570,15 @@ static void mlp_forward(const dppo_net_desc& d, const float* prm, const char* pk
       B.mpad = (M + mt - 1) / mt * mt;
       f.a1f = (u32x4*)B.a1[0], f.a2f = (u32x4*)B.a2[0];
     }
-    g_fused_fault = launch_fused_forward<P>(d, f, s);
+    if (fuse_loss != nullptr && (!B.merged || B.frag)) {
+      g_fused_fault = -8;  // (fuse_loss_ok() and this function disagree)
+      return;
+    }
+    g_fused_fault = launch_fused_forward<P>(d, f, s, fuse_loss);
+    return;
+  }
+  if (fuse_loss != nullptr) {
+    g_fused_fault = -8;
     return;
   }
   if (d.plain) {  // x -> act(W0 x) -> act(W_b .) ... -> Wout .   (pre-activations kept for the backward: hpre[0], z1[b])
@@ -750,6 +759,24 @@ static int g_dw0 = 1;
 // under the GEMM launch, with the bias sums and the loss statistics, and only the GEMMs' own slabs, the low-rank dW2 and dWout
 // stay behind the GEMMs on the caller's stream.
 static int g_side_tail = 1;
+// Tuning knob 39: the policy half of the PPO loss in the epilogue of the actor's fused forward (loss_dev.h; fused.hip, LOSSF): no
+// loss launch between the actor's forward and backward, the forward's eps tile never goes to HBM.  bf16 one-block actor on the
+// merged forward with 64-row tiles (hidden 512), a head of at most 16 outputs whose reward-horizon part is a multiple of 4 wide,
+// the two pipelines on two streams (the value half stays a launch on the critic's), the row builder's loss table, no riders.
+// OFF by default: parity green (ratio == 1 bit for bit, tests/test_hip_parity.py knob 39) but the step is 16 us SLOWER -- the
+// variant needs 235 VGPRs where the plain forward needs 223, two waves of it leave a SIMD 32 free registers instead of 64, and the
+// critic's value-loss launch can no longer slip a wave in beside the actor's persistent workgroups (13 -> 80 us: its whole
+// pipeline starts that much later); the epilogue itself (one wave walks the tile's 64 samples) adds ~10 us to the forward
+// (profiles/r03_fused_loss_ab.txt).
+static int g_fuse_loss = 0;
+template <class P>
+static bool fuse_loss_ok(const dppo_net_desc& d, const LossArgs& la, const MlpBufs<P>& B, bool two_streams, bool mom_rider) {
+  if (!g_fuse_loss || P::ESIZE != 2 || !two_streams || mom_rider || B.allow_frag || !fused_ok<P>(d) || !fused_loss_shape(d)) return false;
+  const dppo_ppo_cfg& pc = la.pcfg;
+  const int rh = pc.reward_horizon < pc.horizon_steps ? pc.reward_horizon : pc.horizon_steps, cnt = rh * pc.action_dim;
+  if (la.tab == nullptr || pc.ft_denoising_steps > 64 || cnt > 16 || cnt <= 0) return false;
+  return ((la.AF | cnt) & 3) == 0 && la.AF <= 16 && la.ldde % 8 == 0 && la.ldde >= 16;
+}
 static int dw0_cols(const dppo_net_desc& d) { return d.kind == 0 ? d.act_flat + d.cond_dim : d.in_dim; }
 static int dw0_nhot(const dppo_net_desc& d, int Kft) {  // one-hot columns that fit behind the data columns
   const int room = 32 - dw0_cols(d);
@@ -1932,8 +1959,12 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   // critic half.  (Knob 10 gates its first persistent kernel so that it becomes eligible together with the actor's instead
   // of starting alone and taking every CU first; measured worse, off.)
   const bool actor_first = split && g_gate_critic == 2;  // experiment: the critic's forward waits for the actor's
+  // the policy half of the loss in the actor forward's epilogue (knob 39): its arguments as the policy launch would get them
+  LossArgs lpol = la;
+  lpol.part = 1, lpol.partial = W.loss_partial;
+  const bool fuse_loss = fuse_loss_ok<P>(a, lpol, W.A, two_streams, mom_rider);
   if (actor_first) {
-    mlp_forward<P>(a, ap, ak, LA, N, W.A, true, s);
+    mlp_forward<P>(a, ap, ak, LA, N, W.A, true, s, fuse_loss ? &lpol : nullptr);
     gate_side(s, s2);
   } else if (split && g_gate_critic) {
     gate_side(s, s2);
@@ -1955,9 +1986,9 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
     if (hook && hook->critic_grads_enqueued) hook->critic_grads_enqueued(hook->user, (dppo_stream_t)s2);
   }
   // actor half
-  if (!actor_first) mlp_forward<P>(a, ap, ak, LA, N, W.A, true, s);
+  if (!actor_first) mlp_forward<P>(a, ap, ak, LA, N, W.A, true, s, fuse_loss ? &lpol : nullptr);
   la.part = two_streams ? 1 : 3, la.partial = W.loss_partial;
-  launch_ppo_loss<P>(la, s);
+  if (!fuse_loss) launch_ppo_loss<P>(la, s);
   if (!two_streams) {
     mlp_backward<P>(cr, cp, ck, LC, N, W.C, cgrad, nullptr, nullptr, 0, s, fuse_bout, -1);
     if (oio && oio->d_obs_critic) obs_grad<P>(cr, cp, N, W.C, oio->d_obs_critic, s);
@@ -2771,6 +2802,10 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 38) {  // with knob 37: the reductions the backward kernel alone feeds and the time-embedding gradient on a side stream under the GEMMs (1, default)
     g_side_tail = value;
+    return 0;
+  }
+  if (knob == 39) {  // the policy half of the PPO loss in the epilogue of the actor's fused forward (1) or a launch of its own (0, default)
+    g_fuse_loss = value;
     return 0;
   }
   if (knob == 35) {  // the reductions behind the weight-gradient GEMMs inside their launch (1, default) or as a launch of their own (0)

@@ -109,8 +109,12 @@ template <class P>
 int fused_bwd_one_grid(const dppo_net_desc& d, int64_t M);
 bool fused_dw0_shape(const dppo_net_desc& d);
 
+struct LossArgs;
+// loss != null (fused_loss_shape(), merged forward, training): the policy half of the PPO loss runs in the kernel's epilogue
+// (loss_dev.h): a.out is not written, loss->d_eps and loss->partial are
 template <class P>
-int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStream_t s);   // <0: shape not covered
+int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStream_t s, const LossArgs* loss = nullptr);   // <0: shape not covered
+bool fused_loss_shape(const dppo_net_desc& d);
 template <class P>
 int launch_fused_backward(const dppo_net_desc& d, const FusedBwdArgs& a, hipStream_t s);
 void set_fused_short_tiles(int v);  // tuning knob 7

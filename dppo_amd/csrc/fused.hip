@@ -5,6 +5,7 @@
 #include "gemm.h"
 #include "tile_ln.h"
 #include "pack_dev.h"
+#include "loss_dev.h"
 
 #ifndef DPPO_BWD_LATE
 #define DPPO_BWD_LATE 1
@@ -859,8 +860,14 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_forward_kernel(const Fused
 // FRAG (bf16, OT = 1, S1 = 1 or 2 only): act(h_0) / act(z1) leave as K-major fragments (a.a1f / a.a2f) instead of row-major.  A
 // template parameter, not a run-time test: compiled into every variant, the fragment code cost the variants that never use it
 // 8-24 spilled registers.
-template <class P, int TPW, int MR, int OT, int ACT, int S1, bool FRAG = false>
-__global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const FusedFwdArgs a) {
+// LOSSF (bf16, OT = 1, not FRAG; training): the policy half of the PPO loss runs in the tile's epilogue (loss_dev.h) -- the tile's
+// eps never goes to HBM, there is no loss launch between the actor's forward and backward.  A row's chain pair, old log-probs and
+// advantage are requested behind the H-wide k-loop (their row / step indices were staged with the input tile), land in the dead
+// half of buffer A behind the next barrier, and wave 0 then walks one sample per lane exactly as ppo_loss_kernel does: d loss / d eps
+// rows to HBM, the tile's five statistics -- a tile is 64 samples, the loss kernel's block -- to la.partial[tile].
+template <class P, int TPW, int MR, int OT, int ACT, int S1, bool FRAG = false, bool LOSSF = false>
+__global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const FusedFwdArgs a, const LossArgs la) {
+  static_assert(!LOSSF || (OT == 1 && !FRAG && MR == 4 && P::ESIZE == 2), "fused policy loss: bf16, one out tile, 64-row tiles");
   constexpr int PD = ring_depth<TPW, MR>(), ES = P::ESIZE, KB = P::KB;
   static_assert(S1 == 0 || PD == 4, "the compact walk is written for a ring of four positions");
   constexpr int H = 128 * TPW, KSH = H / KB, HRB = H * ES, MT = 16 * MR;
@@ -894,6 +901,12 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
   // the first pass runs late, in the second pass's phase (a partial result carried through the H-wide k-loop is 8-16 more
   // live registers in a kernel that has none to spare: 24-56 spilled), so the tile gets its own [MT][ks0v * 64 B] region
   char* xin = WIDE ? (char*)(w0cL + ks0v * OT * 64) : bufB;
+  // LOSSF: [MT] (row, step) of the tile's samples, then the loss's per-step table [2 Kft + 2]; in buffer A behind the out-layer
+  // partials (dead from the barrier behind the second emit on): eps tile [MT][16] f32 at +16 KB, gathered inputs [MT][64] f32 at +24 KB
+  long long* metaL = (long long*)(w0cL + ks0v * OT * 64);  // per row: element offsets of its chain pair and of its old log-probs, then (sample's rollout row, step)
+  float* tabL = (float*)(metaL + 3 * MT);
+  float* epsL = (float*)(bufA + 16 * 1024);
+  float* recL = (float*)(bufA + 24 * 1024);
   const int wbase = wid * 16 * TPW;
   const int to_w = wid % OT, kh_w = wid / OT;  // WIDE: this wave's out tile and K slice
   for (int idx = tid; idx < 2 * H; idx += 512) biasL[idx] = a.params[a.bias_off[idx / H] + idx % H];
@@ -901,6 +914,17 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
   if constexpr (!WIDE)
     for (int idx = tid; idx < KSH * OT * 64; idx += 512) woutL[idx] = a.ostream2[idx];
   for (int idx = tid; idx < ks0v * OT * 64; idx += 512) w0cL[idx] = a.ostream0[idx];
+  if constexpr (LOSSF) {  // ppo_loss_kernel's prologue: the per-step table, the advantage moments
+    const int Kft = la.pcfg.ft_denoising_steps;
+    for (int k = tid; k < 2 * Kft; k += 512) tabL[k] = la.tab[k];
+    for (int k = tid; k < Kft; k += 512) tabL[2 * Kft + 2 + k] = la.tab[2 * Kft + k];  // log std_k (build_rows_kernel)
+    if (tid == 0) {
+      const double Nm = la.moments[2], mean = la.moments[0] / Nm;
+      const double varu = (la.moments[1] - Nm * mean * mean) / (Nm - 1.0);  // unbiased (torch.std)
+      tabL[2 * Kft] = (float)mean;
+      tabL[2 * Kft + 1] = (float)sqrt(varu > 0 ? varu : 0);
+    }
+  }
   if (tid < 16) flags[tid] = 0;
   uint32_t seq = 0;
   // (visible after the first tile's barrier)
@@ -918,6 +942,17 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
     const int row0 = tile * MT;
     STAMP(0);
     load_tile<MT>(xin, in_rb, in_km, (const char*)a.in, a.ld_in * ES, row0, M);
+    if constexpr (LOSSF) {
+      int t_ = tid;
+      asm volatile("" : "+v"(t_));
+      if (t_ < MT) {
+        const int n = row0 + t_, Kft = la.pcfg.ft_denoising_steps, AF = la.AF;
+        const long long b = n < M ? la.brow[n] : 0, k = n < M ? la.krow[n] : 0;
+        metaL[3 * t_] = la.gathered ? b * 2 * AF : (b * (Kft + 1) + k) * AF;
+        metaL[3 * t_ + 1] = la.gathered ? b * AF : (b * Kft + k) * AF;
+        metaL[3 * t_ + 2] = (b << 32) | k;
+      }
+    }
     __syncthreads();
     STAMP(1);
     f32x4 acc[TPW][MR];
@@ -975,6 +1010,32 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
     STAMP(6);
     __syncthreads();  // the out layer's work items read every wave's features
     STAMP(7);
+    // LOSSF: request the tile's loss inputs now -- behind the second emit (held across it, their registers pushed the kernel from 223
+    // to 237 VGPRs and the critic's value-loss launch could no longer slip a wave in beside these workgroups: 13 -> 80 us, step
+    // +16 us) --: per row NP 16-byte pieces each of x_k, x_k+1 and the old log-probs, then the row's advantage; slot = row * PPR +
+    // piece, two slots per thread.  They travel under the out layer's second pass and land in buffer A behind it.
+    u32x4 gx[LOSSF ? 2 : 1];
+    if constexpr (LOSSF) {
+      const int NP = la.AF >> 2, PPR = 3 * NP + 1;
+      int t_ = tid;
+      asm volatile("" : "+v"(t_));
+      auto request = [&](int sl, u32x4& dst) {
+        const int row = sl / PPR, pc = sl - row * PPR;
+        dst = (u32x4){0, 0, 0, 0};
+        if (row < MT && row0 + row < M) {
+          if (pc < 2 * NP)  // (x_k+1 follows x_k in memory in both layouts)
+            dst = *(const u32x4*)(la.chains + lds_load(metaL + 3 * row) + 4 * pc);
+          else if (pc < 3 * NP)
+            dst = *(const u32x4*)(la.logprobs_k + lds_load(metaL + 3 * row + 1) + 4 * (pc - 2 * NP));
+          else
+            dst[0] = __float_as_uint(la.adv_k[(int)(lds_load(metaL + 3 * row + 2) >> 32)]);
+        }
+      };
+      request(t_, gx[0]);
+      gx[1] = (u32x4){0, 0, 0, 0};
+      if (wid < 2) request(t_ + 512, gx[1]);  // (at most 13 pieces per row: 832 slots)
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // ---- out layer, second pass: (Wout W2) on act(z1)
     int r_ = r, g_ = g, lane_ = lane;
     asm volatile("" : "+v"(r_), "+v"(g_), "+v"(lane_));  // (see fused_forward_kernel: addresses recomputed, not spilled)
@@ -1032,9 +1093,52 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
       float s = biasL[2 * H + j];
 #pragma unroll
       for (int kh = 0; kh < KSPLIT; ++kh) s += part[(((kh * MR + m) * OT + to) * 16 + jj) * 16 + rr];
-      if (row0 + row < M) a.out[(size_t)(row0 + row) * a.ldout + j] = s;
+      if constexpr (LOSSF)
+        epsL[row * 16 + j] = s;
+      else if (row0 + row < M)
+        a.out[(size_t)(row0 + row) * a.ldout + j] = s;
     }
     STAMP(13);
+    if constexpr (LOSSF) {  // (buffer A behind the out-layer partials has been free since the barrier behind the second emit)
+      const int NP = la.AF >> 2, PPR = 3 * NP + 1;
+      int t_ = tid;
+      asm volatile("" : "+v"(t_));
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int sl = t_ + 512 * i, row = sl / PPR, pc = sl - row * PPR;
+        if (row < MT) {  // row r of recL: x at 0, x_k+1 at 16, old log-probs at 32, advantage at 48
+          const int off = pc < NP ? 4 * pc : (pc < 2 * NP ? 16 + 4 * (pc - NP) : (pc < 3 * NP ? 32 + 4 * (pc - 2 * NP) : 48));
+          if (i == 0 || wid < 2) *(u32x4*)(recL + row * 64 + off) = gx[i];
+        }
+      }
+    }
+    if constexpr (LOSSF) {
+      __syncthreads();  // the eps tile and the gathered inputs are in place
+      if (wid == 0) {   // one sample per lane, as in ppo_loss_kernel (64 samples per block there: this tile)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int n = row0 + ln;
+        const int cnt = (la.pcfg.reward_horizon < la.pcfg.horizon_steps ? la.pcfg.reward_horizon : la.pcfg.horizon_steps) * la.pcfg.action_dim;
+        const double Nn = la.n_count > 0 ? la.n_count : la.moments[2];
+        double s4[4] = {0, 0, 0, 0};
+        if (n < M) {
+          const float* rr = recL + ln * 64;
+          const float adv = lds_load(rr + 48);
+          const int k = (int)(lds_load(metaL + 3 * ln + 2) & 0xffffffffll);
+          policy_loss_row_nc<P>(la, tabL, k, adv, rr, epsL + ln * 16, cnt, Nn, (typename P::elem_t*)la.d_eps + (size_t)n * la.ldde, s4);
+        }
+        // the tile's partial sums by the loss kernel's shuffle tree (v_loss belongs to the value half's launch)
+        double v5[5] = {s4[0], 0.0, s4[1], s4[2], s4[3]};
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+          for (int off = 32; off > 0; off >>= 1) v5[q] += __shfl_down(v5[q], off);
+        if (ln == 0) {
+          double* po = la.partial + (size_t)tile * 8;
+          po[DPPO_STAT_PG_LOSS] = v5[0], po[DPPO_STAT_V_LOSS] = v5[1], po[DPPO_STAT_APPROX_KL] = v5[2];
+          po[DPPO_STAT_CLIPFRAC] = v5[3], po[DPPO_STAT_RATIO] = v5[4];
+        }
+      }
+    }
     __syncthreads();  // the next tile's input lands in buffer B; its layer-0 emit in buffer A, where the partials were read
     STAMP(14);
   }
@@ -1635,23 +1739,35 @@ bool fused_frag_shape(const dppo_net_desc& d) {
 template bool fused_can_merge<F32>(const dppo_net_desc&);
 template bool fused_can_merge<BF16>(const dppo_net_desc&);
 
-template <class P, int TPW, int MR, int ACT, int S1, int OT = 1, bool FRAG = false>
-static int launch_fwd_merged_cfg2(const FusedFwdArgs& a, hipStream_t s) {
+// shapes the fused policy loss covers (the caller adds its own conditions on the loss's arguments: fused_loss_shape())
+constexpr int FUSED_LOSS_MAX_KFT = 64;
+static size_t fused_loss_lds(int Kft) { return (size_t)3 * 64 * 8 + ((size_t)(3 * Kft + 2) * 4 + 15) / 16 * 16; }
+template <class P, int TPW, int MR, int ACT, int S1, int OT = 1, bool FRAG = false, bool LOSSF = false>
+static int launch_fwd_merged_cfg2(const FusedFwdArgs& a, hipStream_t s, const LossArgs* loss = nullptr) {
   constexpr int MT = 16 * MR, H = 128 * TPW;
-  const size_t lds = merged_lds<P>(H, OT, a.ks0v);
+  const size_t lds = merged_lds<P>(H, OT, a.ks0v) + (LOSSF ? fused_loss_lds(loss->pcfg.ft_denoising_steps) : 0);
   if (lds > 160 * 1024 || a.Kp0 > H || a.nb != 1) return -2;
   if (FRAG != (a.a1f != nullptr) || FRAG != (a.a2f != nullptr)) return -4;  // (fragment outputs: both or none, and a variant built for them)
+  if (LOSSF != (loss != nullptr)) return -4;
   static DevLatch attr;
-  raise_lds(fused_forward_merged_kernel<P, TPW, MR, OT, ACT, S1, FRAG>, attr);
+  raise_lds(fused_forward_merged_kernel<P, TPW, MR, OT, ACT, S1, FRAG, LOSSF>, attr);
   const int ntiles = (a.M + MT - 1) / MT;
   const bool probe = probe_begin(PROBE_FUSED_FWD, s);
-  hipLaunchKernelGGL((fused_forward_merged_kernel<P, TPW, MR, OT, ACT, S1, FRAG>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512),
-                     lds, s, a);
+  static const LossArgs no_loss = {};
+  hipLaunchKernelGGL((fused_forward_merged_kernel<P, TPW, MR, OT, ACT, S1, FRAG, LOSSF>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512),
+                     lds, s, a, loss != nullptr ? *loss : no_loss);
   if (probe) probe_end(s, 2.0 * a.M * ((double)a.in_valid * H + 2.0 * a.nb * H * H + (double)H * a.out_dim));
   return 0;
 }
 template <class P, int TPW, int MR, int ACT>
-static int launch_fwd_merged_cfg(const FusedFwdArgs& a, hipStream_t s) {
+static int launch_fwd_merged_cfg(const FusedFwdArgs& a, hipStream_t s, const LossArgs* loss) {
+  if (loss != nullptr) {  // the policy loss in the epilogue: bf16 64-row tiles, one out tile, compact walk (fused_loss_shape())
+    if constexpr (P::ESIZE == 2 && MR == 4 && ring_depth<TPW, MR>() == 4) {
+      if (a.out_dim <= 16 && a.a1f == nullptr && fused_compact_on() && a.ks0v == 1) return launch_fwd_merged_cfg2<P, TPW, MR, ACT, 1, 1, false, true>(a, s, loss);
+      if (a.out_dim <= 16 && a.a1f == nullptr && fused_compact_on() && a.ks0v == 2) return launch_fwd_merged_cfg2<P, TPW, MR, ACT, 2, 1, false, true>(a, s, loss);
+    }
+    return -4;
+  }
   if (a.out_dim > 16) {  // the wide head (fused_can_merge admitted it: hidden 512, compact walk, ks0v <= 3)
     if constexpr (TPW == 4) {
       if (a.ks0v == 1) return launch_fwd_merged_cfg2<P, TPW, MR, ACT, 1, 4>(a, s);
@@ -1674,15 +1790,19 @@ static int launch_fwd_merged_cfg(const FusedFwdArgs& a, hipStream_t s) {
   return launch_fwd_merged_cfg2<P, TPW, MR, ACT, 0>(a, s);
 }
 
+// the fused policy loss exists for: bf16, hidden 512 (64-row tiles), a head of at most 16 outputs, at most two input k-steps
+bool fused_loss_shape(const dppo_net_desc& d) {
+  return fused_compact_on() && d.hidden == 512 && d.out_dim <= 16 && d.in_dim <= 2 * BF16::KB && fused_can_merge<BF16>(d);
+}
 template <class P>
-int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStream_t s) {
+int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStream_t s, const LossArgs* loss) {
   const int tpw = d.hidden / 128, mr = pick_mr<P>(d.hidden);
   const int nt = (d.out_dim + 15) / 16, ot = nt <= 1 ? 1 : (nt <= 4 ? 4 : (nt <= 8 ? 8 : 0));
   if (mr == 0 || ot == 0 || a.M <= 0) return -1;
   const bool relu = a.act == ACT_RELU;  // check_net admits ReLU and Mish only
   if (a.merge_top) {  // (the caller asked fused_can_merge() first)
 #define DPPO_FWDM(T, R) \
-  if (tpw == T && mr == R) return relu ? launch_fwd_merged_cfg<P, T, R, ACT_RELU>(a, s) : launch_fwd_merged_cfg<P, T, R, ACT_MISH>(a, s);
+  if (tpw == T && mr == R) return relu ? launch_fwd_merged_cfg<P, T, R, ACT_RELU>(a, s, loss) : launch_fwd_merged_cfg<P, T, R, ACT_MISH>(a, s, loss);
     if constexpr (P::ESIZE == 2) {
       DPPO_FWDM(2, 8) DPPO_FWDM(4, 4)
     } else {
@@ -1691,6 +1811,7 @@ int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStrea
 #undef DPPO_FWDM
     return -1;
   }
+  if (loss != nullptr) return -4;
   if constexpr (P::ESIZE == 2) {
     if (short_tiles<P>(d.hidden, a.use_ln, 1) && ot == 1)
       return relu ? launch_fwd_cfg<P, 4, 2, 1, false, ACT_RELU, 2>(a, s) : launch_fwd_cfg<P, 4, 2, 1, false, ACT_MISH, 2>(a, s);
@@ -1713,8 +1834,8 @@ int launch_fused_forward(const dppo_net_desc& d, const FusedFwdArgs& a, hipStrea
 #undef DPPO_FWD
   return -1;
 }
-template int launch_fused_forward<F32>(const dppo_net_desc&, const FusedFwdArgs&, hipStream_t);
-template int launch_fused_forward<BF16>(const dppo_net_desc&, const FusedFwdArgs&, hipStream_t);
+template int launch_fused_forward<F32>(const dppo_net_desc&, const FusedFwdArgs&, hipStream_t, const LossArgs*);
+template int launch_fused_forward<BF16>(const dppo_net_desc&, const FusedFwdArgs&, hipStream_t, const LossArgs*);
 
 template <class P, int TPW, int MR, bool LN, int ACT, int OCC = 1>
 static int launch_bwd_cfg(const FusedBwdArgs& a, hipStream_t s) {

@@ -184,7 +184,12 @@ __global__ __launch_bounds__(256) void build_rows_kernel(const BuildRows a) {
     if ((int)threadIdx.x >= 128 && (int)threadIdx.x - 128 < a.n_zero_b) a.zero_b[threadIdx.x - 128] = 0.0;
     if ((int)threadIdx.x < a.n_zero_c) a.zero_c[threadIdx.x] = 0.0;
     if (a.loss_tab != nullptr)
-      for (int k = threadIdx.x; k < a.pcfg.ft_denoising_steps; k += blockDim.x) loss_table_entry(a.pcfg, k, a.loss_tab);
+      for (int k = threadIdx.x; k < a.pcfg.ft_denoising_steps; k += blockDim.x) {
+        loss_table_entry(a.pcfg, k, a.loss_tab);
+        // log(std_k) as THIS translation unit rounds it (the loss and log-prob kernels live here): the forward kernel's fused policy
+        // loss (fused.hip is compiled with contraction on, where the logf expansion ends in an fma instead of an add) reads it
+        if (3 * a.pcfg.ft_denoising_steps <= 2048) a.loss_tab[2 * a.pcfg.ft_denoising_steps + k] = logf(a.ksteps[k].std);
+      }
   }
   const int ca = a.inA != nullptr ? a.KpA / EPC : 0, cc = a.inC != nullptr ? a.KpC / EPC : 0;
   const int64_t total = a.M * (ca + cc);

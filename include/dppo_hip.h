@@ -499,6 +499,10 @@ int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* 
  * knob 38: with knob 37, a denoiser's backward: the reductions that the backward kernel alone feeds (its first-layer slabs, the bias
  *          sums, the loss statistics) and the time-embedding gradient behind them run on the library's second side stream under
  *          the weight-gradient GEMM launch (1, default) or behind it with everything else (0)
+ * knob 39: PPO update of a bf16 one-block actor at hidden 512 with a head of at most 16 outputs, actor and critic on two streams:
+ *          the policy half of the loss (log-probs, ratio, clipped surrogate, d loss / d eps, statistics) runs in the epilogue
+ *          of the actor's fused forward kernel (1) or as a launch of its own between forward and backward (0, default: the fused
+ *          variant's register footprint costs the overlapped step more than the launch it saves)
  * knob 35: what follows the weight-gradient GEMMs of a backward pass -- slab sums, bias column sums, loss statistics -- inside
  *          the GEMM launch (1: the last workgroup at an output tile sums its slabs, the small reductions ride as extra
  *          workgroups; measured slower, 200 vs 107 + 32 us) or as a launch of its own (0, default)

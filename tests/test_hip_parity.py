@@ -597,7 +597,7 @@ def test_fused_path_matches_layered_path(prec, tol, sname):
 @pytest.mark.parametrize("sname,knob", [("hopper", 22), ("can", 22), ("halfcheetah", 22), ("can_relu", 22), ("hopper", 23),
                                         ("can", 23), ("square_like", 23), ("hopper", 25), ("halfcheetah", 25), ("hopper", 31),
                                         ("halfcheetah", 31), ("can", 31), ("hopper", 36), ("can", 36), ("hopper", 37),
-                                        ("halfcheetah", 37), ("can", 37), ("hopper", 38)])
+                                        ("halfcheetah", 37), ("can", 37), ("hopper", 38), ("hopper", 39)])
 def test_one_block_kernels_match_the_general_ones(prec, tol, sname, knob):
     _one_block_ab(prec, tol, sname, knob)
 
@@ -623,7 +623,8 @@ def _one_block_ab(prec, tol, sname, knob, N=6500, Kft=10):
     advantage moments as partial sums riding the row builder's launch, added in the loss kernel's prologue.  Knob 37 (bf16): the
     first layer's weight gradient accumulated inside the one-block backward (dh_0 never stored; hopper: actor and critic, the
     others: the critic).  Knob 38: with it, the reductions the backward kernel feeds and the time-embedding gradient on a side
-    stream under the weight-gradient GEMMs.  Same log-probs, values, loss
+    stream under the weight-gradient GEMMs.  Knob 39 (bf16): the policy half of the loss in the epilogue of the
+    actor's forward kernel.  Same log-probs, values, loss
     statistics and gradients -- tensor by tensor -- as the general kernels."""
     from dppo_amd import hip
     lib = hip.load()
@@ -632,7 +633,7 @@ def _one_block_ab(prec, tol, sname, knob, N=6500, Kft=10):
     R = max(800, -(-N // Kft) + 16)  # (N >= 100 x out_dim: the low-rank dW2 -- and with it the one-block backward -- is on)
     AF = a.horizon_steps * a.action_dim
     out = {}
-    default = 0 if knob in (31, 36) else 1  # (knobs 31 and 36 ship off: see csrc/api.hip g_frag, g_mom_rider)
+    default = 0 if knob in (31, 36, 39) else 1  # (knobs 31, 36 and 39 ship off: see csrc/api.hip g_frag, g_mom_rider, g_fuse_loss)
     try:
         for merged in (1, 0):
             lib.dppo_tune_set(knob, merged)
