@@ -396,6 +396,10 @@ struct MlpBufs {  // activations of one network for M rows
   bool fold;          // set by the caller between carve and backward: red_cnt was zeroed in this call (row builder)
   unsigned* red_cnt;  // [RED_CNT] tile arrival counters, right behind post_counter (zeroed with it, left zero)
   bool dw0;         // set by the caller between carve and the backward (dw0_ok()): the backward keeps dW0 on chip, dh_0 is never stored
+  // riders of the next weight-gradient GEMM launch (knob 40; filled by mlp_backward, consumed by flush_slabs)
+  bool ride;
+  TailReduce ride_t;     // slab jobs (the backward kernel's dW0 slabs), bias-sum slots, loss statistics
+  PostReduce ride_q;     // the time-embedding part (G == null: none)
   bool allow_frag;  // set by the caller between carve and forward: the whole pass (forward, backward, GEMMs) may run in it
   bool frag;        // decided by the forward (allow_frag && merged), obeyed by the backward
   u32x4* doutf;     // [ks][dof_nt][64]
@@ -759,6 +763,15 @@ static int g_dw0 = 1;
 // under the GEMM launch, with the bias sums and the loss statistics, and only the GEMMs' own slabs, the low-rank dW2 and dWout
 // stay behind the GEMMs on the caller's stream.
 static int g_side_tail = 1;
+// Tuning knob 40: ... and instead of a side stream (whose fork is an event record between the backward kernel and the GEMM launch
+// on the caller's stream: ~8 us of idle time there, profiles/r03_dw0_ab.txt) the same work RIDES in the actor's GEMM launch as extra
+// workgroups in front of the GEMM tiles (gemm.h, GemmTNExtra): producers (slab reductions, bias sums, loss statistics) first, then
+// the time-embedding blocks, which wait for the producers on an arrival counter (post_blocks.h).  No stream, no event, no launch.
+// OFF by default: parity green on the first run, but the actor's GEMM launch goes from 68 to 94 us (serial) and the step from 0.350
+// to 0.381 ms -- the riders' dependent chain (reduce, G, the time MLP's backward: latency-bound steps) runs under the GEMM's memory
+// load, every step of it several times slower than alone, and the launch cannot end before it does; on its own stream the same chain
+// is as slow but nobody waits for it (profiles/r03_dw0_ab.txt).
+static int g_tail_riders = 0;
 // Tuning knob 39: the policy half of the PPO loss in the epilogue of the actor's fused forward (loss_dev.h; fused.hip, LOSSF): no
 // loss launch between the actor's forward and backward, the forward's eps tile never goes to HBM.  bf16 one-block actor on the
 // merged forward with 64-row tiles (hidden 512), a head of at most 16 outputs whose reward-horizon part is a multiple of 4 wide,
@@ -841,7 +854,36 @@ static void flush_slabs(MlpBufs<P>& B, hipStream_t s, const SlotOuts* slots = nu
       e.n_blocks = (e.n_slot_blocks + (e.fin_stats != nullptr ? 1 : 0) + 7) / 8 * 8;  // (keeps the GEMM tiles' block id = XCD map)
     } else {
       for (int i = 0; i < gr.n; ++i) gr.j[i].red_cnt = nullptr;
+      if (B.ride) {  // the backward kernel's own reductions and the time-embedding gradient as riders (knob 40)
+        GemmTNExtra& e = gr.ex;
+        const TailReduce& t = B.ride_t;
+        e.colsum = t.colsum, e.tiles = t.tiles, e.width = t.width, e.n_slots = t.slots.n_slots;
+        e.slot_bx = (t.width + 15) / 16, e.n_slot_blocks = e.n_slots * e.slot_bx;
+        for (int i = 0; i < e.n_slots; ++i) e.slot_out[i] = t.slots.out[i], e.slot_n[i] = t.slots.n[i];
+        if (t.fin_stats != nullptr) {
+          e.fin_partial = t.fin_partial, e.fin_blocks = t.fin_blocks, e.fin_moments = t.fin_moments, e.fin_stats = t.fin_stats;
+          e.fin_part = t.fin_part, e.fin_n_count = t.fin_n_count;
+        }
+        int n_prod = e.n_slot_blocks + 1;
+        e.n_rjobs = t.jobs.n;
+        for (int i = 0; i < t.jobs.n; ++i) {
+          e.rjob[i] = t.jobs.j[i];
+          e.rjob_blocks[i] = (int)(((size_t)t.jobs.j[i].rows * t.jobs.j[i].cols + 15) / 16);  // (16 elements per block: slab_job_rider)
+          n_prod += e.rjob_blocks[i];
+        }
+        e.post = B.ride_q;
+        int n_cons = 0;
+        if (e.post.G != nullptr) {
+          e.arrive_cnt = B.red_cnt + RED_CNT - 1;  // (zeroed by the row builder with the post-reduce counter: B.post_zeroed)
+          e.post.wait_cnt = e.arrive_cnt, e.post.wait_need = n_prod;
+          e.post.n_temb = (e.post.Kft * e.post.td + 3) / 4, e.post.n_dw0t = (e.post.H * e.post.td + 255) / 256;
+          e.post.n_lowrank = e.post.n_wout = 0;
+          n_cons = e.post.n_temb + e.post.n_dw0t;
+        }
+        e.n_blocks = (n_prod + n_cons + 7) / 8 * 8;
+      }
     }
+    B.ride = false;
     launch_gemm_tn_group<P>(gr, s);
     gr.n = 0;
   }
@@ -1173,12 +1215,23 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
       else
         weight_grad<P>(B.dh_all[0], H, H, B.in, L.Kp0, d.in_dim, M, B, grad + pl.W0, d.in_dim, s, true);
       }
+      // ... as riders of the GEMM launch (knob 40): needs the grouped launch to exist and take them (three wide jobs, the time MLP's
+      // LDS within the GEMM's own, no folded reduction), else the side stream
+      const bool riders = side_tail && g_tail_riders && !g_fold && B.tn_group.n > 0 && side_t.jobs.n <= 3 && so.n_slots <= TN_MAX_SLOTS &&
+                          time_backward_lds_bytes(Kft, d.time_dim) <= 32 * 1024;
       if (side_tail) {
         // what the backward kernel alone feeds: its dW0 slabs, the bias sums, the loss statistics, then the time-embedding
         // gradient -- queued on the side stream here, BEHIND the kernel and BESIDE the GEMM launch that follows on s
-        hipStream_t st = fork_side(s, aux_idx);
+        hipStream_t st = riders ? s : fork_side(s, aux_idx);
         side_t.colsum = B.tile_colsum, side_t.tiles = B.tiles, side_t.width = H, side_t.slots = so;
-        launch_tail_reduce(side_t, fin, st);
+        if (riders) {
+          if (fin != nullptr && fin->N > 0) {
+            side_t.fin_partial = fin->partial, side_t.fin_blocks = loss_blocks(fin->N), side_t.fin_moments = fin->moments;
+            side_t.fin_stats = fin->stats, side_t.fin_part = fin->part, side_t.fin_n_count = fin->n_count;
+          }
+        } else {
+          launch_tail_reduce(side_t, fin, st);
+        }
         PostReduce qs;
         memset(&qs, 0, sizeof(qs));
         qs.H = H, qs.out_dim = d.out_dim;
@@ -1187,8 +1240,12 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
         qs.ksteps = ksteps, qs.gw1 = grad + pl.te1_w, qs.gb1 = grad + pl.te1_b, qs.gw2 = grad + pl.te2_w, qs.gb2 = grad + pl.te2_b;
         qs.S_rest = s_rest, qs.dW0t = grad + pl.W0, qs.temb = (const float*)(pk + L.temb), qs.temb_bf16 = P::ESIZE == 2 ? 1 : 0;
         qs.counter = (unsigned*)B.post_counter;
-        launch_post_reduce(qs, st);
-        B.join_s[B.n_join] = st, B.join_idx[B.n_join++] = aux_idx;  // (joined right behind the GEMM launch: flush_slabs)
+        if (riders) {
+          B.ride = true, B.ride_t = side_t, B.ride_q = qs;  // (flush_slabs hands them to the group launch)
+        } else {
+          launch_post_reduce(qs, st);
+          B.join_s[B.n_join] = st, B.join_idx[B.n_join++] = aux_idx;  // (joined right behind the GEMM launch: flush_slabs)
+        }
       }
       if (aux != s && g_early_join) B.join_s[B.n_join] = aux, B.join_idx[B.n_join++] = aux_idx;
       if (side_tail)
@@ -2802,6 +2859,10 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 38) {  // with knob 37: the reductions the backward kernel alone feeds and the time-embedding gradient on a side stream under the GEMMs (1, default)
     g_side_tail = value;
+    return 0;
+  }
+  if (knob == 40) {  // with knob 38: that work as riders of the actor's weight-gradient GEMM launch (1) or on a side stream (0, default)
+    g_tail_riders = value;
     return 0;
   }
   if (knob == 39) {  // the policy half of the PPO loss in the epilogue of the actor's fused forward (1) or a launch of its own (0, default)

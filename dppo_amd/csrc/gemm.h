@@ -9,6 +9,7 @@
 // wave instruction covers 16 rows x 128 contiguous bytes.
 #pragma once
 #include "common.h"
+#include "ppo.h"
 
 namespace dppo {
 
@@ -66,6 +67,14 @@ struct GemmTNExtra {
   double* fin_stats;
   int fin_blocks, fin_part;
   double fin_n_count;
+  // More riders (api.hip, knob 40: the in-kernel dW0's backward feeds all of this, not the GEMMs): behind the slot blocks and the
+  // statistics block, rjob_blocks[i] blocks of slab job i (post_blocks.h, slab_job_block_wide) -- together the PRODUCERS: with
+  // arrive_cnt != null each stores write-through and arrives on it -- then the CONSUMERS: post.n_temb blocks of the time-embedding
+  // gradient and post.n_dw0t blocks of dW0's time columns (post.wait_cnt = arrive_cnt, post.wait_need = the producers' count).
+  SlabJob rjob[3];
+  int n_rjobs, rjob_blocks[3];
+  PostReduce post;
+  unsigned* arrive_cnt;
 };
 
 constexpr int MAX_TN_JOBS = 8;

@@ -1,6 +1,7 @@
 // See gemm.h.  gfx950 only.
 #include "gemm.h"
 #include "tail_blocks.h"
+#include "post_blocks.h"
 
 namespace dppo {
 
@@ -510,15 +511,38 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN a) {
 // XCD, as above).  No inter-kernel gaps, and the last round of one GEMM is filled by the first of the next.
 template <class P, int NBUF>
 __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_tn_group_kernel(const GemmTNGroup gr) {
-  if ((int)blockIdx.x < gr.ex.n_blocks) {  // riders that depend on nothing in this launch (gemm.h, GemmTNExtra)
+  if ((int)blockIdx.x < gr.ex.n_blocks) {  // riders: nothing here depends on this launch's GEMM tiles (gemm.h, GemmTNExtra)
+    extern __shared__ __attribute__((aligned(16))) char rider_smem[];
     const GemmTNExtra& e = gr.ex;
-    const int b = blockIdx.x;
-    if (b < e.n_slot_blocks) {
-      const int slot = b / e.slot_bx, x = b - slot * e.slot_bx;
-      if (slot < e.n_slots)
-        slot_reduce_block256(e.colsum + (size_t)slot * e.tiles * e.width, e.tiles, e.width, e.slot_n[slot], e.slot_out[slot], x);
-    } else if (b == e.n_slot_blocks && e.fin_stats != nullptr) {
-      loss_finalize_block256(e.fin_partial, e.fin_blocks, e.fin_moments, e.fin_stats, e.fin_part, e.fin_n_count);
+    int b = blockIdx.x;
+    const bool wt = e.arrive_cnt != nullptr;
+    const int n_prod = e.n_slot_blocks + 1 + (e.n_rjobs > 0 ? e.rjob_blocks[0] : 0) + (e.n_rjobs > 1 ? e.rjob_blocks[1] : 0) +
+                       (e.n_rjobs > 2 ? e.rjob_blocks[2] : 0);
+    if (b < n_prod) {  // producers
+      if (b < e.n_slot_blocks) {
+        const int slot = b / e.slot_bx, x = b - slot * e.slot_bx;
+        if (slot < e.n_slots)
+          slot_reduce_block256(e.colsum + (size_t)slot * e.tiles * e.width, e.tiles, e.width, e.slot_n[slot], e.slot_out[slot], x, wt);
+      } else if (b == e.n_slot_blocks) {
+        if (e.fin_stats != nullptr) loss_finalize_block256(e.fin_partial, e.fin_blocks, e.fin_moments, e.fin_stats, e.fin_part, e.fin_n_count);
+      } else {
+        b -= e.n_slot_blocks + 1;
+        int j = 0;
+        while (j + 1 < e.n_rjobs && b >= e.rjob_blocks[j]) b -= e.rjob_blocks[j], ++j;
+        // (slab_job_block_wide strides by gridDim.x: give it this job's own block index and count)
+        slab_job_rider<true>(e.rjob[j], b, e.rjob_blocks[j]);
+      }
+      if (wt) post_arrive(e.arrive_cnt);
+      return;
+    }
+    b -= n_prod;
+    if (e.post.G != nullptr) {  // consumers
+      if (b < e.post.n_temb) {
+        temb_g_block(e.post, b, (float*)rider_smem);
+      } else if (b < e.post.n_temb + e.post.n_dw0t) {
+        post_wait(e.post);
+        dw0_temb_block(e.post, b - e.post.n_temb);
+      }
     }
     return;
   }

@@ -321,6 +321,10 @@ struct PostReduce {  // see post_reduce_kernel; dW == null: no low-rank part; G 
   const float* temb;
   int temb_bf16;  // 1: the rows hold bf16 roundings of the table
   int n_lowrank, n_temb, n_wout, n_dw0t;  // set by the launcher
+  // riding in the weight-gradient GEMM launch (post_blocks.h): S, S_rest and the bias sums come from other workgroups of the SAME
+  // launch -- wait until *wait_cnt >= wait_need before reading them, and read them past the non-coherent caches.  null: a launch of its own
+  unsigned* wait_cnt;
+  int wait_need;
 };
 void launch_wout_grad(const PostReduce& q, hipStream_t s);  // the merged-top / one-block parts alone (no arrival counter needed)
 void launch_post_reduce(PostReduce& q, hipStream_t s);

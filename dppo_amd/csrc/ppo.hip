@@ -3,6 +3,7 @@
 #include "ppo.h"
 #include "pack_dev.h"
 #include "posterior.h"
+#include "post_blocks.h"
 
 namespace dppo {
 
@@ -44,13 +45,6 @@ template void launch_transpose_cast<F32>(const float*, int, int, int, int, void*
 template void launch_transpose_cast<BF16>(const float*, int, int, int, int, void*, int, hipStream_t);
 
 // sinusoid -> Linear(td,2td) -> Mish -> Linear(2td,td); one block per diffusion time
-__device__ __forceinline__ float sinus_feat(int t, int j, int td) {
-  const int half = td / 2;
-  const float step = (float)(-(log(10000.0) / (double)(half - 1)));  // scalar cast to f32 like torch does
-  const int jj = j < half ? j : j - half;
-  const float ang = (float)t * expf((float)jj * step);
-  return j < half ? sinf(ang) : cosf(ang);
-}
 __device__ __forceinline__ void time_table_block(const float* w1, const float* b1, const float* w2, const float* b2,
                                                  int td, float* temb, const int t, float* sh) {
   float* e0 = sh;  // [td] sinusoid, [2td] hidden
@@ -885,82 +879,6 @@ static void raise_dyn_lds(K kern) {  // above 64 KB of dynamic LDS a kernel need
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
     (void)hipGetLastError();  // not fatal: launches below 64 KB do not need it
 }
-// single block: recompute the tiny time MLP per fine-tuned step and back-propagate G[k][td] through it
-// part A: what does not depend on the gradient G -- weights staged in LDS, sinusoidal features, z1 and a1 of every step
-__device__ __forceinline__ void time_backward_prepare(const float* w1, const float* b1, const float* w2,
-                                                      const dppo_step* ksteps, int Kft, int td, float* sh) {
-  // sh: per k: e0[td], z1[2td], a1[2td], dz1[2td]; then w1[2td][td], w2[td][2td], b1[2td], G[Kft][td] staged once (each
-  // phase below otherwise pays an L2 latency per inner-loop iteration: this block is the tail of the update's critical path)
-  const int per = 7 * td;
-  const int tid = threadIdx.x;
-  float* w1s = sh + Kft * per;
-  float* w2s = w1s + 2 * td * td;
-  float* b1s = w2s + 2 * td * td;
-  for (int i = tid; i < 2 * td * td; i += 256) w1s[i] = w1[i], w2s[i] = w2[i];
-  for (int i = tid; i < 2 * td; i += 256) b1s[i] = b1[i];
-  for (int i = tid; i < Kft * td; i += 256) {
-    const int k = i / td, j = i % td;
-    sh[k * per + j] = sinus_feat(ksteps[k].t, j, td);
-  }
-  __syncthreads();
-  for (int i = tid; i < Kft * 2 * td; i += 256) {
-    const int k = i / (2 * td), o = i % (2 * td);
-    float s = b1s[o];
-    for (int j = 0; j < td; ++j) s += w1s[o * td + j] * sh[k * per + j];
-    sh[k * per + td + o] = mish_grad_f(s);  // (only the derivative of z1 is needed below)
-    sh[k * per + 3 * td + o] = mish_f(s);
-  }
-}
-// part B: G[Kft][td] -> gradients of the four parameter tensors
-// last_is_total: G_in's last row holds the sum over ALL steps (PostReduce::S_rest): the other rows are subtracted here first
-__device__ __forceinline__ void time_backward_finish(const float* G_in, int Kft, int td, float* gw1, float* gb1, float* gw2,
-                                                     float* gb2, float* sh, bool last_is_total = false) {
-  const int per = 7 * td;
-  const int tid = threadIdx.x;
-  const float* w2s = sh + Kft * per + 2 * td * td;
-  float* Gs = sh + Kft * per + 4 * td * td + 2 * td;
-  for (int i = tid; i < Kft * td; i += 256)  // sc1 loads: G may have been written by other workgroups of this launch
-    Gs[i] = __hip_atomic_load(&G_in[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const float* G = Gs;
-  __syncthreads();
-  if (last_is_total) {
-    for (int j = tid; j < td; j += 256) {
-      float s = Gs[(Kft - 1) * td + j];
-      for (int k = 0; k < Kft - 1; ++k) s -= Gs[k * td + j];
-      Gs[(Kft - 1) * td + j] = s;
-    }
-    __syncthreads();
-  }
-  for (int i = tid; i < Kft * 2 * td; i += 256) {
-    const int k = i / (2 * td), o = i % (2 * td);
-    float s = 0.f;
-    for (int j = 0; j < td; ++j) s += w2s[j * 2 * td + o] * G[k * td + j];
-    sh[k * per + 5 * td + o] = s * sh[k * per + td + o];
-  }
-  __syncthreads();
-  for (int i = tid; i < td * 2 * td; i += 256) {  // gw2[o][j] = sum_k G[k][o] a1[k][j]
-    const int o = i / (2 * td), j = i % (2 * td);
-    float s = 0.f;
-    for (int k = 0; k < Kft; ++k) s += G[k * td + o] * sh[k * per + 3 * td + j];
-    gw2[i] = s;
-  }
-  for (int o = tid; o < td; o += 256) {
-    float s = 0.f;
-    for (int k = 0; k < Kft; ++k) s += G[k * td + o];
-    gb2[o] = s;
-  }
-  for (int i = tid; i < 2 * td * td; i += 256) {  // gw1[o][j] = sum_k dz1[k][o] e0[k][j]
-    const int o = i / td, j = i % td;
-    float s = 0.f;
-    for (int k = 0; k < Kft; ++k) s += sh[k * per + 5 * td + o] * sh[k * per + j];
-    gw1[i] = s;
-  }
-  for (int o = tid; o < 2 * td; o += 256) {
-    float s = 0.f;
-    for (int k = 0; k < Kft; ++k) s += sh[k * per + 5 * td + o];
-    gb1[o] = s;
-  }
-}
 __device__ __forceinline__ void time_backward_block(const float* w1, const float* b1, const float* w2, const float* G_in,
                                                     const dppo_step* ksteps, int Kft, int td, float* gw1, float* gb1,
                                                     float* gw2, float* gb2, float* sh) {
@@ -1022,26 +940,6 @@ __device__ __forceinline__ void lowrank_dw_block(const float* Wout, const float*
   for (int u = 0; u < LOWRANK_RI; ++u)
     if (i0 + u < H) dW[(size_t)(i0 + u) * H + j] = acc[u];
 }
-// dW0[h][AF + j] = sum_k S[h][k] elem(temb[t_k][j]) (PostReduce::dW0t): one thread per output
-__device__ __forceinline__ void dw0_temb_block(const PostReduce& q, int b) {
-  const int out = b * 256 + threadIdx.x;
-  if (out >= q.H * q.td) return;
-  const int h = out / q.td, j = out - h * q.td;
-  float acc = 0.f, rest = q.S_rest != nullptr ? q.S_rest[h] : 0.f;
-  for (int k = 0; k < q.Kft; ++k) {
-    float sk;
-    if (q.S_rest != nullptr && k == q.Kft - 1) {
-      sk = rest;
-    } else {
-      sk = q.S[(size_t)h * q.Kft + k];
-      rest -= sk;
-    }
-    float t = q.temb[(size_t)q.ksteps[k].t * q.td + j];
-    if (q.temb_bf16) t = bf2f(f2bf(t));
-    acc += sk * t;
-  }
-  q.dW0t[(size_t)h * q.ldw0 + q.AF + j] = acc;
-}
 static int wout_grad_blocks(const PostReduce& q) {
   return ((q.U != nullptr ? q.out_dim * q.H : 0) + (q.db2 != nullptr ? q.H : 0) + 3) / 4;
 }
@@ -1066,38 +964,7 @@ __global__ __launch_bounds__(256) void post_reduce_kernel(const PostReduce q) {
     lowrank_dw_block(q.Wout, q.T, q.out_dim, q.H, q.dW, blockIdx.x);
     return;
   }
-  const int tb = blockIdx.x - q.n_lowrank, lane = tid & 63, out = tb * 4 + (tid >> 6);
-  if (out < q.Kft * q.td) {
-    const int k = out / q.td, j = out % q.td;
-    // (S_rest: the last step's row is formed from the sums over ALL rows; time_backward_finish subtracts the other steps' rows)
-    const bool rest = q.S_rest != nullptr && k == q.Kft - 1;
-    float acc = 0.f;
-    for (int h = lane; h < q.H; h += 64) acc += q.W0[(size_t)h * q.ldw0 + q.AF + j] * (rest ? q.S_rest[h] : q.S[(size_t)h * q.Kft + k]);
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-    // write-through (sc1) store, read back by the last block with sc1 loads (time_backward_finish): the hand-over then needs
-    // no fence on either side -- every storing wave drains its store, the block's barrier, ONE relaxed agent-scope add
-    // (guide section 6, guideline 16).  With __threadfence() around the counter (buffer_wbl2 + buffer_inv, ~3.5 us each on
-    // gfx950) this chain -- G, fence, add | poll, fence, finish -- was 11 of the launch's 16 us, on the update's critical path.
-    if (lane == 0) __hip_atomic_store(&q.G[out], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  DPPO_HANDOVER_DRAIN();  // (common.h: fence-free on gfx942 / gfx950, release / acquire elsewhere)
-  __syncthreads();
-  // The time MLP's backward belongs to the LAST block of the range: it prepares everything that does not depend on G while
-  // the others finish, then waits for their arrivals.  (Workgroups are dispatched in index order, so every block it waits
-  // for is already running or done: the wait cannot starve them.)
-  if (tb != q.n_temb - 1) {
-    if (tid == 0) __hip_atomic_fetch_add(q.counter, 1u, DPPO_HANDOVER_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT);
-    return;
-  }
-  time_backward_prepare(q.w1, q.b1, q.w2, q.ksteps, q.Kft, q.td, sh);
-  if (tid == 0) {
-    while (__hip_atomic_load(q.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)q.n_temb - 1)
-      __builtin_amdgcn_s_sleep(2);
-    __hip_atomic_store(q.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
-    DPPO_HANDOVER_ACQUIRE();
-  }
-  __syncthreads();
-  time_backward_finish(q.G, q.Kft, q.td, q.gw1, q.gb1, q.gw2, q.gb2, sh, q.S_rest != nullptr);
+  temb_g_block(q, blockIdx.x - q.n_lowrank, sh);
 }
 void launch_post_reduce(PostReduce& q, hipStream_t s) {
   q.n_lowrank = q.dW != nullptr ? lowrank_dw_blocks(q.H) : 0;
@@ -1160,41 +1027,6 @@ void launch_slab_reduce_2d(const float* slab, int splits, int rows, int cols, in
                      cols, lds, out, ldo, scale, transpose);
 }
 
-// A job of very many slabs (SlabJob::wide: the in-kernel dW0's one slab per workgroup of the fused backward, up to 256 of them):
-// a thread per element would add 256 values in eight dependent batches on three CUs (measured 44 us for a 256 x 11 output).  Here
-// 64 consecutive elements belong to a block, wave w of it adds slabs w, w + NW, w + 2 NW, ... (NW = waves per block, at most 16
-// loads in flight per lane, one or two memory latencies), and wave 0 adds the NW partial sums in a fixed order.
-__device__ __forceinline__ void slab_job_block_wide(const SlabJob& J) {
-  __shared__ float wred[16][64];
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, NW = blockDim.x >> 6;
-  const size_t n = (size_t)J.rows * J.cols;
-  for (size_t e0 = (size_t)blockIdx.x * 64; e0 < n; e0 += (size_t)gridDim.x * 64) {
-    const size_t i = e0 + lane;
-    const bool live = i < n;
-    const int r = live ? (int)(i / J.cols) : 0, c = live ? (int)(i % J.cols) : 0;
-    const float* src = J.slab + (size_t)r * J.lds + J.c0 + c;
-    const size_t stride = (size_t)J.rows * J.lds;
-    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int k0 = w; k0 < J.splits; k0 += 8 * NW) {
-      float t[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = live && k0 + u * NW < J.splits ? src[(size_t)(k0 + u * NW) * stride] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) p[u] += t[u];
-    }
-    wred[w][lane] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-    __syncthreads();
-    if (w == 0 && live) {
-      float v = 0.f;
-      for (int u = 0; u < NW; ++u) v += wred[u][lane];
-      if (J.transpose)
-        J.out[(size_t)c * J.ldo + r] = v;
-      else
-        J.out[(size_t)r * J.ldo + c] = v;
-    }
-    __syncthreads();
-  }
-}
 __device__ __forceinline__ void slab_job_block(const SlabJob& J) {
   if (J.wide) {  // (uniform over the block)
     slab_job_block_wide(J);

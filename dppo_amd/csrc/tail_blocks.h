@@ -8,7 +8,8 @@
 namespace dppo {
 
 // out[c] = sum over tiles of colsum[tile][c] for 16 columns starting at 16 x: 16 column-lanes x 16 tile-lanes
-__device__ __forceinline__ void slot_reduce_block256(const float* src, int tiles, int width, int n_out, float* out, int x) {
+__device__ __forceinline__ void slot_reduce_block256(const float* src, int tiles, int width, int n_out, float* out, int x,
+                                                     bool wt = false) {  // wt: result stored write-through (read by riders of the same launch)
   __shared__ float red[16][17];
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = x * 16 + cl;
@@ -27,7 +28,10 @@ __device__ __forceinline__ void slot_reduce_block256(const float* src, int tiles
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += red[i][cl];
-    out[c] = s;
+    if (wt)
+      __hip_atomic_store(out + c, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      out[c] = s;
   }
 }
 

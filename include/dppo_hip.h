@@ -499,6 +499,10 @@ int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* 
  * knob 38: with knob 37, a denoiser's backward: the reductions that the backward kernel alone feeds (its first-layer slabs, the bias
  *          sums, the loss statistics) and the time-embedding gradient behind them run on the library's second side stream under
  *          the weight-gradient GEMM launch (1, default) or behind it with everything else (0)
+ * knob 40: knob 38's work as extra workgroups in front of the tiles of the actor's weight-gradient GEMM launch, the time-embedding
+ *          blocks waiting for the reductions on an arrival counter (1: no side stream, no event, no launch -- measured slower, the
+ *          riders' dependent chain runs under the GEMM's memory load and the launch cannot end before it) or on the side stream
+ *          (0, default)
  * knob 39: PPO update of a bf16 one-block actor at hidden 512 with a head of at most 16 outputs, actor and critic on two streams:
  *          the policy half of the loss (log-probs, ratio, clipped surrogate, d loss / d eps, statistics) runs in the epilogue
  *          of the actor's fused forward kernel (1) or as a launch of its own between forward and backward (0, default: the fused
