@@ -772,6 +772,10 @@ static int g_side_tail = 1;
 // load, every step of it several times slower than alone, and the launch cannot end before it does; on its own stream the same chain
 // is as slow but nobody waits for it (profiles/r03_dw0_ab.txt).
 static int g_tail_riders = 0;
+// Tuning knob 41: with knob 38, what is left behind the actor's GEMMs -- their slab reductions, then the low-rank dW2 / dWout / db2,
+// which read only the two THIN products -- is ONE launch (tail_post_kernel: the thin products' reduce blocks first, the dependent
+// blocks poll their arrival, the big slabs are reduced beside them) instead of two.
+static int g_tail_post = 1;
 // Tuning knob 39: the policy half of the PPO loss in the epilogue of the actor's fused forward (loss_dev.h; fused.hip, LOSSF): no
 // loss launch between the actor's forward and backward, the forward's eps tile never goes to HBM.  bf16 one-block actor on the
 // merged forward with 64-row tiles (hidden 512), a head of at most 16 outputs whose reward-horizon part is a multiple of 4 wide,
@@ -810,7 +814,8 @@ static bool dw0_ok(const dppo_net_desc& d, int64_t M, const PackLayout& L, int K
 }
 template <class P>
 static void flush_slabs(MlpBufs<P>& B, hipStream_t s, const SlotOuts* slots = nullptr, int slot_width = 0,
-                        const LossArgs* fin = nullptr) {
+                        const LossArgs* fin = nullptr, bool defer_reduce = false) {
+  // defer_reduce: launch the GEMMs (and join the side streams) but leave the slab jobs to the caller (tail_post_kernel)
   // slots / fin: the fused backward's per-tile column sums and the loss statistics ride in the reduction launch (see
   // tail_reduce_kernel) -- or, with the folded tail, in the GEMM launch itself, and there is no reduction launch
   bool folded = false;
@@ -905,6 +910,7 @@ static void flush_slabs(MlpBufs<P>& B, hipStream_t s, const SlotOuts* slots = nu
   for (int i = 0; i + 1 < B.n_join; ++i) join_side(B.join_s[B.n_join - 1], B.join_s[i], B.join_idx[i]);
   if (B.n_join > 0) join_side(s, B.join_s[B.n_join - 1], B.join_idx[B.n_join - 1]);
   B.n_join = 0;
+  if (defer_reduce && !folded) return;
   if (folded) {
     // everything a reduction launch would do has been done by the GEMM launch
   } else if (slots != nullptr || fin != nullptr) {
@@ -1248,7 +1254,10 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
         }
       }
       if (aux != s && g_early_join) B.join_s[B.n_join] = aux, B.join_idx[B.n_join++] = aux_idx;
-      if (side_tail)
+      const bool tail_post = side_tail && g_tail_post && !g_fold && (lowrank || merged || one);
+      if (tail_post)
+        flush_slabs(B, s, nullptr, 0, nullptr, true);  // the GEMMs; their slabs are reduced with the post-reduce parts below
+      else if (side_tail)
         flush_slabs(B, s);  // the GEMMs' own slabs
       else
         flush_slabs(B, s, &so, H, fin);  // every slab of this backward, its bias sums and the loss statistics: one launch
@@ -1274,7 +1283,23 @@ static void mlp_backward(const dppo_net_desc& d, const float* prm, const char* p
             q.S_rest = s_rest, q.dW0t = grad + pl.W0, q.temb = (const float*)(pk + L.temb), q.temb_bf16 = P::ESIZE == 2 ? 1 : 0;
         }
         q.counter = (unsigned*)B.post_counter;
-        launch_post_reduce(q, s);
+        if (tail_post) {  // (no time-embedding part here: it went to the side stream)
+          TailPost tp;
+          memset(&tp, 0, sizeof(tp));
+          for (int pass = 0; pass < 2; ++pass)  // the thin products' jobs first
+            for (int i = 0; i < B.slab_jobs.n; ++i) {
+              const SlabJob& j = B.slab_jobs.j[i];
+              const bool thin = j.out == B.lowrank || j.out == B.lowrank_u;
+              if (thin == (pass == 0)) tp.jobs.j[tp.jobs.n++] = j;
+              if (thin && pass == 0) ++tp.n_first_jobs;
+            }
+          tp.q = q;
+          tp.q.wait_cnt = B.red_cnt + RED_CNT - 2;  // (zeroed by the row builder: B.post_zeroed)
+          launch_tail_post(tp, s);
+          B.slab_jobs.n = 0, B.slab_used = 0;
+        } else {
+          launch_post_reduce(q, s);
+        }
       } else {
         launch_wout_grad(q, s);  // (merged top and / or one-block backward; nothing otherwise)
         if (lowrank) launch_lowrank_dw(prm + pl.Wout, B.lowrank, d.out_dim, H, grad + pl.l2w[nb - 1], s);
@@ -2863,6 +2888,10 @@ int dppo_tune_set(int knob, int value) {
   }
   if (knob == 40) {  // with knob 38: that work as riders of the actor's weight-gradient GEMM launch (1) or on a side stream (0, default)
     g_tail_riders = value;
+    return 0;
+  }
+  if (knob == 41) {  // with knob 38: the GEMMs' slab reductions and the post-reduce parts behind them in one launch (1, default) or two (0)
+    g_tail_post = value;
     return 0;
   }
   if (knob == 39) {  // the policy half of the PPO loss in the epilogue of the actor's fused forward (1) or a launch of its own (0, default)

@@ -326,6 +326,14 @@ struct PostReduce {  // see post_reduce_kernel; dW == null: no low-rank part; G 
   unsigned* wait_cnt;
   int wait_need;
 };
+// slab reductions + the post-reduce parts that read only the first n_first_jobs jobs' results, in one launch (tail_post_kernel)
+struct TailPost {
+  SlabJobs jobs;
+  int n_first_jobs;             // jobs [0, n_first_jobs) feed q (the thin products T and U); the others run beside it
+  int job_blocks[MAX_SLAB_JOBS], n_first;  // set by the launcher
+  PostReduce q;                 // low-rank dW2 / dWout / db2 parts only; q.wait_cnt = a zeroed counter
+};
+void launch_tail_post(TailPost& t, hipStream_t s);
 void launch_wout_grad(const PostReduce& q, hipStream_t s);  // the merged-top / one-block parts alone (no arrival counter needed)
 void launch_post_reduce(PostReduce& q, hipStream_t s);
 size_t time_backward_lds_bytes(int Kft, int td);  // LDS of the time MLP's backward block: must stay <= 156 KB

@@ -191,7 +191,8 @@ __global__ __launch_bounds__(256) void build_rows_kernel(const BuildRows a) {
     const bool isA = q < a.M * ca;
     const int64_t qq = isA ? q : q - a.M * ca;
     const int cpr = isA ? ca : cc;
-    const int64_t n = qq / cpr;
+    // (32-bit divisions where the values fit -- they always do in practice: a 64-bit one is ~100 instructions, twice per thread)
+    const int64_t n = (qq >> 31) == 0 ? (int64_t)((uint32_t)qq / (uint32_t)cpr) : qq / cpr;
     const int c0 = (int)(qq - n * cpr) * EPC;
     int64_t b;
     int k;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void build_rows_kernel(const BuildRows a) {
       k = (int)a.kinds[n];
     } else {
       const int64_t ind = a.inds ? a.inds[n] : n;
-      b = ind / a.Kft;
+      b = (ind >> 31) == 0 ? (int64_t)((uint32_t)ind / (uint32_t)a.Kft) : ind / a.Kft;
       k = (int)(ind - b * a.Kft);
     }
     const float* ob = a.obs + (size_t)b * a.cond;
@@ -904,8 +905,8 @@ __device__ __forceinline__ void wout_grad_block(const PostReduce& q, int b) {
   if (out < n1) {
     const int o = out / q.H, h = out - o * q.H;
     float acc = 0.f;
-    for (int j = lane; j < q.H; j += 64) acc += q.T[(size_t)o * q.H + j] * q.W2[(size_t)h * q.H + j];
-    for (int c = lane; c < q.in_dim; c += 64) acc += q.U[(size_t)o * q.ldu + c] * q.W0[(size_t)h * q.ldw0 + c];
+    for (int j = lane; j < q.H; j += 64) acc += post_in(q, q.T + (size_t)o * q.H + j) * q.W2[(size_t)h * q.H + j];
+    for (int c = lane; c < q.in_dim; c += 64) acc += post_in(q, q.U + (size_t)o * q.ldu + c) * q.W0[(size_t)h * q.ldw0 + c];
     for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d);
     if (lane == 0) q.dWout[out] = acc + q.cs[o] * (q.b0[h] + q.b2[h]);
     return;
@@ -923,7 +924,8 @@ __device__ __forceinline__ void wout_grad_block(const PostReduce& q, int b) {
 // re-read T for every row: 470 MB from L2 and 40-60 us at H = 1024 with 28-112 outputs)
 constexpr int LOWRANK_RI = 8;
 static int lowrank_dw_blocks(int H) { return ((H + LOWRANK_RI - 1) / LOWRANK_RI) * ((H + 255) / 256); }
-__device__ __forceinline__ void lowrank_dw_block(const float* Wout, const float* T, int out_dim, int H, float* dW, int b) {
+__device__ __forceinline__ void lowrank_dw_block(const float* Wout, const float* T, int out_dim, int H, float* dW, int b,
+                                                 bool t_sc1 = false) {  // t_sc1: T was produced by other workgroups of this launch
   const int jb = (H + 255) / 256;
   const int i0 = (b / jb) * LOWRANK_RI, j = (b % jb) * 256 + threadIdx.x;
   if (j >= H) return;
@@ -931,7 +933,7 @@ __device__ __forceinline__ void lowrank_dw_block(const float* Wout, const float*
 #pragma unroll
   for (int u = 0; u < LOWRANK_RI; ++u) acc[u] = 0.f;
   for (int o = 0; o < out_dim; ++o) {
-    const float t = T[(size_t)o * H + j];
+    const float t = t_sc1 ? __hip_atomic_load(T + (size_t)o * H + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : T[(size_t)o * H + j];
     const float* w = Wout + (size_t)o * H + i0;  // (wave-uniform: scalar loads)
 #pragma unroll
     for (int u = 0; u < LOWRANK_RI; ++u) acc[u] += (i0 + u < H ? w[u] : 0.f) * t;
@@ -1027,17 +1029,19 @@ void launch_slab_reduce_2d(const float* slab, int splits, int rows, int cols, in
                      cols, lds, out, ldo, scale, transpose);
 }
 
-__device__ __forceinline__ void slab_job_block(const SlabJob& J) {
+template <bool WT = false>  // WT: results stored write-through (read by other workgroups of the same launch: tail_post_kernel)
+__device__ __forceinline__ void slab_job_block(const SlabJob& J, int bx = -1, int nbx = 0) {  // bx >= 0: block bx of nbx
   if (J.wide) {  // (uniform over the block)
-    slab_job_block_wide(J);
+    slab_job_block_wide<WT>(J, bx, nbx);
     return;
   }
+  const size_t b0 = bx >= 0 ? (size_t)bx : blockIdx.x, bn = bx >= 0 ? (size_t)nbx : gridDim.x;
   // (A 16-byte form of this loop -- a thread owning four consecutive columns, the same summation tree per element, 128 bytes
   // per lane in flight instead of 32 -- was SLOWER: 21.1 vs 17.0 us per launch on average, tools/tail_reduce_parts.sh.  The
   // slabs of one output element lie rows x lds x 4 bytes = 1 MB apart, so what bounds the loop is not the bytes in flight per
   // thread; a quarter of the threads with four times the bytes each just spreads the same requests over fewer CUs.)
   const size_t n = (size_t)J.rows * J.cols;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = b0 * blockDim.x + threadIdx.x; i < n; i += bn * blockDim.x) {
     const int r = (int)(i / J.cols), c = (int)(i % J.cols);
     float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // same summation tree as slab_reduce_2d_kernel
     int k = 0;
@@ -1056,13 +1060,59 @@ __device__ __forceinline__ void slab_job_block(const SlabJob& J) {
     }
     for (; k < J.splits; ++k) p[k & 7] += J.slab[((size_t)k * J.rows + r) * J.lds + J.c0 + c];
     const float v = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-    if (J.transpose)
-      J.out[(size_t)c * J.ldo + r] = v;
+    float* dst = J.transpose ? J.out + (size_t)c * J.ldo + r : J.out + (size_t)r * J.ldo + c;
+    if constexpr (WT)
+      __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else
-      J.out[(size_t)r * J.ldo + c] = v;
+      *dst = v;
   }
 }
 __global__ __launch_bounds__(256) void slab_reduce_batch_kernel(const SlabJobs jobs) { slab_job_block(jobs.j[blockIdx.y]); }
+
+// The slab reductions of a backward pass's GEMMs AND what follows them (low-rank dW2, dWout, db2: post_reduce_kernel's parts that
+// read only the two THIN products T and U) in one launch: blocks [0, n_first) reduce the thin products (write-through, one arrival
+// each), the next q.n_lowrank + q.n_wout blocks wait for them (post_blocks.h) and run behind, the rest reduce the other slabs
+// beside them.  One launch boundary less between the GEMMs and AdamW.
+__global__ __launch_bounds__(256) void tail_post_kernel(const TailPost t) {
+  int b = blockIdx.x;
+  if (b < t.n_first) {  // producers: jobs [0, n_first_jobs)
+    int j = 0;
+    while (j + 1 < t.n_first_jobs && b >= t.job_blocks[j]) b -= t.job_blocks[j], ++j;
+    slab_job_block<true>(t.jobs.j[j], b, t.job_blocks[j]);
+    post_arrive(t.q.wait_cnt);
+    return;
+  }
+  b -= t.n_first;
+  if (b < t.q.n_lowrank + t.q.n_wout) {  // consumers
+    post_wait(t.q);
+    if (b < t.q.n_lowrank)
+      lowrank_dw_block(t.q.Wout, t.q.T, t.q.out_dim, t.q.H, t.q.dW, b, true);
+    else
+      wout_grad_block(t.q, b - t.q.n_lowrank);
+    return;
+  }
+  b -= t.q.n_lowrank + t.q.n_wout;
+  int j = t.n_first_jobs;
+  while (j + 1 < t.jobs.n && b >= t.job_blocks[j]) b -= t.job_blocks[j], ++j;
+  if (j < t.jobs.n) slab_job_block<false>(t.jobs.j[j], b, t.job_blocks[j]);
+}
+void launch_tail_post(TailPost& t, hipStream_t s) {
+  t.q.n_lowrank = t.q.dW != nullptr ? lowrank_dw_blocks(t.q.H) : 0;
+  t.q.n_wout = wout_grad_blocks(t.q);
+  t.q.n_temb = t.q.n_dw0t = 0;
+  int total = 0;
+  t.n_first = 0;
+  for (int i = 0; i < t.jobs.n; ++i) {
+    const size_t n = (size_t)t.jobs.j[i].rows * t.jobs.j[i].cols;
+    t.job_blocks[i] = (int)((n + (t.jobs.j[i].wide ? 63 : 255)) / (t.jobs.j[i].wide ? 64 : 256));
+    if (t.job_blocks[i] > 512) t.job_blocks[i] = 512;  // (grid-stride loops inside)
+    if (i < t.n_first_jobs) t.n_first += t.job_blocks[i];
+    total += t.job_blocks[i];
+  }
+  t.q.wait_need = t.n_first;
+  total += t.q.n_lowrank + t.q.n_wout;
+  if (total > 0) hipLaunchKernelGGL(tail_post_kernel, dim3(total), dim3(256), 0, s, t);
+}
 
 // Everything that only waits for a backward pass's weight-gradient GEMMs and data-gradient kernel, in ONE launch of
 // 1024-thread blocks: the slab reductions (blockIdx.y = job), the bias gradients = per-tile column sums of the fused

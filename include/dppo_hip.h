@@ -503,6 +503,9 @@ int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* 
  *          blocks waiting for the reductions on an arrival counter (1: no side stream, no event, no launch -- measured slower, the
  *          riders' dependent chain runs under the GEMM's memory load and the launch cannot end before it) or on the side stream
  *          (0, default)
+ * knob 41: with knob 38: the slab reductions of the actor's weight-gradient GEMMs and what depends on the two thin products among
+ *          them (low-rank dW2, dWout, db2) are one launch -- the dependent workgroups poll the thin reductions' arrival -- (1,
+ *          default) or two launches (0)
  * knob 39: PPO update of a bf16 one-block actor at hidden 512 with a head of at most 16 outputs, actor and critic on two streams:
  *          the policy half of the loss (log-probs, ratio, clipped surrogate, d loss / d eps, statistics) runs in the epilogue
  *          of the actor's fused forward kernel (1) or as a launch of its own between forward and backward (0, default: the fused

@@ -597,7 +597,7 @@ def test_fused_path_matches_layered_path(prec, tol, sname):
 @pytest.mark.parametrize("sname,knob", [("hopper", 22), ("can", 22), ("halfcheetah", 22), ("can_relu", 22), ("hopper", 23),
                                         ("can", 23), ("square_like", 23), ("hopper", 25), ("halfcheetah", 25), ("hopper", 31),
                                         ("halfcheetah", 31), ("can", 31), ("hopper", 36), ("can", 36), ("hopper", 37),
-                                        ("halfcheetah", 37), ("can", 37), ("hopper", 38), ("hopper", 39), ("hopper", 40)])
+                                        ("halfcheetah", 37), ("can", 37), ("hopper", 38), ("hopper", 39), ("hopper", 40), ("hopper", 41)])
 def test_one_block_kernels_match_the_general_ones(prec, tol, sname, knob):
     _one_block_ab(prec, tol, sname, knob)
 
@@ -624,7 +624,7 @@ def _one_block_ab(prec, tol, sname, knob, N=6500, Kft=10):
     first layer's weight gradient accumulated inside the one-block backward (dh_0 never stored; hopper: actor and critic, the
     others: the critic).  Knob 38: with it, the reductions the backward kernel feeds and the time-embedding gradient on a side
     stream under the weight-gradient GEMMs.  Knob 39 (bf16): the policy half of the loss in the epilogue of the
-    actor's forward kernel.  Knob 40: knob 38's work as riders of the actor's weight-gradient GEMM launch instead of a side stream.  Same log-probs, values, loss
+    actor's forward kernel.  Knob 40: knob 38's work as riders of the actor's weight-gradient GEMM launch instead of a side stream.  Knob 41: the GEMMs' slab reductions and the post-reduce parts behind them in one launch.  Same log-probs, values, loss
     statistics and gradients -- tensor by tensor -- as the general kernels."""
     from dppo_amd import hip
     lib = hip.load()
