@@ -717,9 +717,12 @@ static int g_frag = 0;
 // CU's ~25 GB/s), where tail_reduce_kernel puts the whole chip on the same 22 MB for 17 us.  (With release / acquire fences
 // instead of sc1 stores it was 589 us: buffer_wbl2 flushes the XCD's whole L2 once per wave.)
 static int g_fold = 0;
-static int g_mom_rider = 0;  // tuning knob 36: the minibatch's advantage moments as riders of the row builder (1) or a launch of their own (0,
-                              // default: the launch already hides under the critic's forward on the side stream; the riders save 3.5 us only
-                              // in the serial order -- profiles/r03_moments_rider_ab.txt)
+static int g_mom_rider = 0;  // tuning knob 36: the minibatch's advantage moments as riders of the row builder (1: always, 2: never) or a launch
+                              // of their own.  0 (default): riders for minibatches of at most MOM_RIDER_MAX_N samples -- at N = 50,000 the
+                              // launch already hides under the critic's forward on the side stream (the riders save 3.5 us only in the
+                              // serial order, profiles/r03_moments_rider_ab.txt); at BASELINE configs[2]'s 7,500 the step is a chain of
+                              // launches and one fewer is 0.186 -> 0.180 ms
+constexpr int64_t MOM_RIDER_MAX_N = 16384;
 // Time-embedding gradient through the first layer's weight-gradient GEMM: with a one-hot of the row's denoising step k in
 // the K padding of the input rows, dW0's extra columns are S[h][k] = sum over the rows of step k of dh0[row][h], and
 // d loss / d temb[k] = W0[:, temb columns]^T S[:, k] -- no second pass over dh0, no segmented reduction (tuning knob 11).
@@ -2008,7 +2011,7 @@ static int ppo_impl(const dppo_net_desc& a, const dppo_net_desc& cr, const float
   br.obs_in_a = a.cond_hidden > 0 ? 0 : 1;  // with cond_mlp the encoder fills the state columns (from the critic's obs rows)
   br.onehot0 = temb_onehot_col<P>(a, LA, Kft, W.A);
   // advantage moments as riders of the actor's row builder (knob 36): no launch between the rows and the actor's forward
-  const bool mom_rider = g_mom_rider && gmom == nullptr;
+  const bool mom_rider = gmom == nullptr && (g_mom_rider == 1 || (g_mom_rider == 0 && N <= MOM_RIDER_MAX_N));
   if (mom_rider) br.mom_adv = adv_k, br.mom_out = W.moments, br.n_zero_b = 8;  // (block 0 must not zero the riders' slots, [8, ...))
   const float* obs_c = oio && oio->obs_critic ? oio->obs_critic : nullptr;  // the critic's own observation rows (pixel nets)
   const bool split = s2 != s || obs_c != nullptr;

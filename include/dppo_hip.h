@@ -490,8 +490,9 @@ int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* 
  * knob 32: 0 (default): the fragments of a workgroup's tile are fetched once per k-step by LDS-DMA into a four-stage ring and
  *          read back by its four waves; 2..4: every wave loads its own fragments into registers, that many k-steps ahead
  * knob 36: the minibatch's advantage moments (PPO update, single rank): partial sums by the last 64 blocks of the row builder's
- *          launch, added by every block of the loss kernel (1), or a launch of their own between the rows and the
- *          actor's forward (0, default: it already overlaps the critic's forward; the riders gain 3.5 us in serial order only)
+ *          launch, added by every block of the loss kernel (1: always; 0, default: for minibatches of at most 16,384 samples, where
+ *          the step is a chain of launches), or a launch of their own between the rows and the actor's forward (2: always; at
+ *          50,000 samples it already overlaps the critic's forward)
  * knob 37: one-block bf16 networks whose informative input columns fit 32 (a denoiser: action chunk + observation + Kft - 1 one-hot
  *          step columns; a critic: its observation): the first layer's weight gradient is accumulated inside the fused backward
  *          kernel, per persistent workgroup in LDS, and d loss / d h_0 is neither stored nor read back (1, default); 0: dh_0 is

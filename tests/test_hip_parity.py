@@ -636,7 +636,7 @@ def _one_block_ab(prec, tol, sname, knob, N=6500, Kft=10):
     default = 0 if knob in (31, 36, 39, 40) else 1  # (these ship off: see csrc/api.hip g_frag, g_mom_rider, g_fuse_loss, g_tail_riders)
     try:
         for merged in (1, 0):
-            lib.dppo_tune_set(knob, merged)
+            lib.dppo_tune_set(knob, merged if merged or knob != 36 else 2)  # (knob 36: 0 = by minibatch size, 2 = never)
             for net in (m.actor, m.actor_ft, m.critic):
                 net.mark_updated()
             gen = torch.Generator(device="cpu").manual_seed(5)
