@@ -788,7 +788,7 @@ static void launch_tn_cfg(const GemmTN& a, hipStream_t s) {
 
 // tuning knob 26: LDS stages of the grouped weight-gradient kernel: 1 (three workgroups per CU), 2 (two, double-buffered), or
 // 0 (default): by the group's size -- one stage while all its workgroups are co-resident at three per CU (hopper: 576 of 768),
-// two when they are not and the minibatch is large (a group that still carries the first layer's product: halfcheetah 0.393 ->
+// two when they are not and the minibatch is large, 32,768 samples or more (a group that still carries the first layer's product: halfcheetah 0.393 ->
 // 0.387 ms; hopper 0.347 -> 0.356 and can, 7,500 samples, 0.181 -> 0.185 the other way round)
 static int g_tn_nbuf = 0;
 void set_gemm_tn_nbuf(int v) { g_tn_nbuf = v == 2 ? 2 : (v == 1 ? 1 : 0); }
@@ -810,7 +810,7 @@ void launch_gemm_tn_group(const GemmTNGroup& gr, hipStream_t s) {
   }
   const bool probe = probe_begin(PROBE_GEMM_TN, s);
   const dim3 grid(gr.base[gr.n] + gr.ex.n_blocks);
-  const int nbuf = g_tn_nbuf != 0 ? g_tn_nbuf : ((int)grid.x > 3 * 256 && gr.n > 0 && gr.j[0].M >= 16384 ? 2 : 1);
+  const int nbuf = g_tn_nbuf != 0 ? g_tn_nbuf : ((int)grid.x > 3 * 256 && gr.n > 0 && gr.j[0].M >= 32768 ? 2 : 1);
   if (getenv("DPPO_DEBUG_TN")) fprintf(stderr, "tn group: %u workgroups, %d stage(s)\n", grid.x, nbuf);
   if (nbuf == 1)
     hipLaunchKernelGGL((gemm_tn_group_kernel<P, 1>), grid, dim3(256), LDS / 2, s, gr);

@@ -480,7 +480,7 @@ int dppo_probe_collect_bytes(double* total_ms_host, int* launches_host, double* 
  * knob 25: the one-block kernels walk their short layers (K = in_dim on the input tile, K = out_dim on the d_out tile)
  *          as the 1-2 k-steps that hold data instead of the 4 the weight stream pads them to (default 1)
  * knob 26: LDS stages of the grouped weight-gradient GEMM: 1 (36.9 KB per workgroup, three workgroups per CU), 2 (double-buffered,
- *          two per CU), or 0 (default): two for a group of more than 768 workgroups over at least 16,384 samples, else one
+ *          two per CU), or 0 (default): two for a group of more than 768 workgroups over at least 32,768 samples, else one
  * knob 27: sampler, small env batches of one-block bf16 networks at hidden 512: one 16-row tile over eight workgroups with
  *          the weights resident in registers (default 1; see dppo_sample_chain_workspace_bytes) or over one (0)
  * knob 28: knob 27's kernel: 64-cycle sleep periods between a workgroup's exchange store and its first sweep (default 4)
