@@ -1,6 +1,6 @@
 # GPU box: the artefacts of round 3's final build (copied from gpurun_out/r03fin1 into profiles/ as r03_final_* afterwards).
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${OUT_TAG:-r03fin4}; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${OUT_TAG:-r03fin5}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 echo "[1] bench full"; timeout -k 10 500 python3 $R/bench.py > $O/bench.json 2> $O/bench.err && tail -c 400 $O/bench.json && echo
 echo "[2] rocprof stats"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-pixel --no-fp32 > $O/stats.log 2>&1 && echo ok
