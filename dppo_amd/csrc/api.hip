@@ -783,11 +783,12 @@ static int g_tail_post = 1;
 // loss launch between the actor's forward and backward, the forward's eps tile never goes to HBM.  bf16 one-block actor on the
 // merged forward with 64-row tiles (hidden 512), a head of at most 16 outputs whose reward-horizon part is a multiple of 4 wide,
 // the two pipelines on two streams (the value half stays a launch on the critic's), the row builder's loss table, no riders.
-// OFF by default: parity green (ratio == 1 bit for bit, tests/test_hip_parity.py knob 39) but the step is 16 us SLOWER -- the
-// variant needs 235 VGPRs where the plain forward needs 223, two waves of it leave a SIMD 32 free registers instead of 64, and the
-// critic's value-loss launch can no longer slip a wave in beside the actor's persistent workgroups (13 -> 80 us: its whole
-// pipeline starts that much later); the epilogue itself (one wave walks the tile's 64 samples) adds ~10 us to the forward
-// (profiles/r03_fused_loss_ab.txt).
+// OFF by default: parity green (ratio == 1 bit for bit, tests/test_hip_parity.py knob 39), step time EQUAL to the separate launch's.
+// At first it was 16 us slower: the variant allocated 235 VGPRs where the plain forward has 223, two waves of it left a SIMD 32 free
+// registers instead of 64, and the critic's value-loss launch could no longer slip a wave in beside the actor's persistent
+// workgroups (13 -> 80 us: its whole pipeline started that much later).  Capped at 224 (`amdgpu_num_vgpr(112)`: hipcc doubles the
+// request on the unified register file; eight cold values go to scratch) that is gone -- and what remains is a wash: the forward's
+// epilogue (one wave walks the tile's 64 samples, seven wait) costs what the launch cost (profiles/r03_fused_loss_ab.txt).
 static int g_fuse_loss = 0;
 template <class P>
 static bool fuse_loss_ok(const dppo_net_desc& d, const LossArgs& la, const MlpBufs<P>& B, bool two_streams, bool mom_rider) {

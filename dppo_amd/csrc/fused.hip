@@ -257,6 +257,9 @@ struct CEngine {
     }
   }
   // acc += (H-wide layer) . src^T, with the flag waits of Engine::run (KSH / 8 k-steps per producer wave)
+  // TAIL_REFILL = false: the last four steps multiply without fetching what follows the wide segment -- the ring's registers are
+  // dead from here to reprime() at the tile's end (the fused-loss forward: its epilogue needs them)
+  template <bool TAIL_REFILL = true>
   __device__ __forceinline__ void wide(f32x4 (&acc)[TPW][MR], const char* src, int rb, int km, int r, int g,
                                        lds_u32* flags = nullptr, uint32_t need = 0) {
     uint32_t ready = 0xffu;
@@ -289,10 +292,24 @@ struct CEngine {
     }
     constexpr int KL = KSH - PD;  // the last four: their refills reach the third segment, the holes or the next tile
     wait_group(KL);
-    step_ct<(S1 + 0) % PD, S1 + KL + 0>(acc, src, rb, km, KL + 0, r, g);
-    step_ct<(S1 + 1) % PD, S1 + KL + 1>(acc, src, rb, km, KL + 1, r, g);
-    step_ct<(S1 + 2) % PD, S1 + KL + 2>(acc, src, rb, km, KL + 2, r, g);
-    step_ct<(S1 + 3) % PD, S1 + KL + 3>(acc, src, rb, km, KL + 3, r, g);
+    if constexpr (TAIL_REFILL) {
+      step_ct<(S1 + 0) % PD, S1 + KL + 0>(acc, src, rb, km, KL + 0, r, g);
+      step_ct<(S1 + 1) % PD, S1 + KL + 1>(acc, src, rb, km, KL + 1, r, g);
+      step_ct<(S1 + 2) % PD, S1 + KL + 2>(acc, src, rb, km, KL + 2, r, g);
+      step_ct<(S1 + 3) % PD, S1 + KL + 3>(acc, src, rb, km, KL + 3, r, g);
+    } else {
+      static_assert(TAIL_REFILL || S2 == 0, "without a third segment only");
+      mult((S1 + 0) % PD, acc, ring[(S1 + 0) % PD], src, rb, km, KL + 0, r, g);
+      mult((S1 + 1) % PD, acc, ring[(S1 + 1) % PD], src, rb, km, KL + 1, r, g);
+      mult((S1 + 2) % PD, acc, ring[(S1 + 2) % PD], src, rb, km, KL + 2, r, g);
+      mult((S1 + 3) % PD, acc, ring[(S1 + 3) % PD], src, rb, km, KL + 3, r, g);
+    }
+  }
+  __device__ __forceinline__ void reprime() {  // the next tile's first four positions (a tile starts at slot 0)
+    fetch_ct<0, 0>();
+    fetch_ct<1, 1>();
+    fetch_ct<2, 2>();
+    fetch_ct<3, 3>();
   }
   // acc += (last short layer) . src^T : k-steps 0 .. S2-1 of src
   __device__ __forceinline__ void short2(f32x4 (&acc)[TPW][MR], const char* src, int rb, int km, int r, int g) {
@@ -865,8 +882,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void fused_forward_kernel(const Fused
 // advantage are requested behind the H-wide k-loop (their row / step indices were staged with the input tile), land in the dead
 // half of buffer A behind the next barrier, and wave 0 then walks one sample per lane exactly as ppo_loss_kernel does: d loss / d eps
 // rows to HBM, the tile's five statistics -- a tile is 64 samples, the loss kernel's block -- to la.partial[tile].
-template <class P, int TPW, int MR, int OT, int ACT, int S1, bool FRAG = false, bool LOSSF = false>
-__global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const FusedFwdArgs a, const LossArgs la) {
+template <class P, int TPW, int MR, int OT, int ACT, int S1, bool FRAG, bool LOSSF>
+__device__ __forceinline__ void fused_forward_merged_body(const FusedFwdArgs& a, const LossArgs& la) {
   static_assert(!LOSSF || (OT == 1 && !FRAG && MR == 4 && P::ESIZE == 2), "fused policy loss: bf16, one out tile, 64-row tiles");
   constexpr int PD = ring_depth<TPW, MR>(), ES = P::ESIZE, KB = P::KB;
   static_assert(S1 == 0 || PD == 4, "the compact walk is written for a ring of four positions");
@@ -906,7 +923,7 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
   long long* metaL = (long long*)(w0cL + ks0v * OT * 64);  // per row: element offsets of its chain pair and of its old log-probs, then (sample's rollout row, step)
   float* tabL = (float*)(metaL + 3 * MT);
   float* epsL = (float*)(bufA + 16 * 1024);
-  float* recL = (float*)(bufA + 24 * 1024);
+  float* recL = (float*)(bufA + 24 * 1024);  // [MT][3 AF + 1] f32, rounded up to whole 512-dword DMA rounds (<= 16 KB)
   const int wbase = wid * 16 * TPW;
   const int to_w = wid % OT, kh_w = wid / OT;  // WIDE: this wave's out tile and K slice
   for (int idx = tid; idx < 2 * H; idx += 512) biasL[idx] = a.params[a.bias_off[idx / H] + idx % H];
@@ -955,6 +972,22 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
     }
     __syncthreads();
     STAMP(1);
+    // LOSSF: touch the cache lines of the tile's loss inputs now (five dwords per row: both ends of the chain pair and of the old
+    // log-probs, the advantage), a whole tile ahead of their LDS-DMA: gathered cold behind the second emit they cost every wave
+    // 3-5 us of waiting per tile (the fused forward ran 114 us against 86 + a 30 us loss launch)
+    uint32_t warm = 0;
+    if constexpr (LOSSF) {
+      int t_ = tid;
+      asm volatile("" : "+v"(t_));
+      const int row = t_ / 5, part = t_ - row * 5;
+      if (row < MT && row0 + row < M) {
+        const int AF = la.AF;
+        const float* src = part < 2   ? la.chains + lds_load(metaL + 3 * row) + (part ? 2 * AF - 1 : 0)
+                           : part < 4 ? la.logprobs_k + lds_load(metaL + 3 * row + 1) + (part == 3 ? AF - 1 : 0)
+                                      : la.adv_k + (int)(lds_load(metaL + 3 * row + 2) >> 32);
+        warm = *(const uint32_t*)src;
+      }
+    }
     f32x4 acc[TPW][MR];
     auto bias_init = [&](int layer) {
 #pragma unroll
@@ -999,8 +1032,8 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
     // ---- the block's first layer
     bias_init(1);
     if constexpr (S1 > 0) {
-      eng.wide(acc, bufA, HRB, 15, r, g, FLAGS ? flags : nullptr, seq);
-      if constexpr (!WIDE) eng.end_tile();  // (WIDE: the third segment comes first, below)
+      eng.template wide<!LOSSF>(acc, bufA, HRB, 15, r, g, FLAGS ? flags : nullptr, seq);
+      if constexpr (!WIDE && !LOSSF) eng.end_tile();  // (WIDE: the third segment comes first, below; LOSSF: reprime() at the tile's end)
     } else {
       eng.run(acc, bufA, HRB, 15, KSH, r, g, FLAGS ? flags : nullptr, seq);
     }
@@ -1010,31 +1043,32 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
     STAMP(6);
     __syncthreads();  // the out layer's work items read every wave's features
     STAMP(7);
-    // LOSSF: request the tile's loss inputs now -- behind the second emit (held across it, their registers pushed the kernel from 223
-    // to 237 VGPRs and the critic's value-loss launch could no longer slip a wave in beside these workgroups: 13 -> 80 us, step
-    // +16 us) --: per row NP 16-byte pieces each of x_k, x_k+1 and the old log-probs, then the row's advantage; slot = row * PPR +
-    // piece, two slots per thread.  They travel under the out layer's second pass and land in buffer A behind it.
-    u32x4 gx[LOSSF ? 2 : 1];
+    // LOSSF: request the tile's loss inputs now, behind the second emit: per row its AF-element x_k, x_k+1 (adjacent in memory),
+    // old log-probs and its advantage, one dword per slot (slot = row * DPR + element, DPR = 3 AF + 1), by LDS-DMA straight into the
+    // dead part of buffer A -- no registers (held in registers across the emit they pushed the kernel from 223 to 237 VGPRs, and the
+    // critic's value-loss launch could no longer slip a wave in beside these workgroups: 13 -> 80 us, step +16 us).  They travel
+    // under the out layer's second pass.
     if constexpr (LOSSF) {
-      const int NP = la.AF >> 2, PPR = 3 * NP + 1;
+      asm volatile("" ::"v"(warm));  // (the touches have landed long ago: their register is free from here)
+      typedef __attribute__((address_space(3))) void* lds_ptr;
+      typedef const __attribute__((address_space(1))) void* glb_ptr;
+      const int AF = la.AF, DPR = 3 * AF + 1, total = MT * DPR;
       int t_ = tid;
       asm volatile("" : "+v"(t_));
-      auto request = [&](int sl, u32x4& dst) {
-        const int row = sl / PPR, pc = sl - row * PPR;
-        dst = (u32x4){0, 0, 0, 0};
-        if (row < MT && row0 + row < M) {
-          if (pc < 2 * NP)  // (x_k+1 follows x_k in memory in both layouts)
-            dst = *(const u32x4*)(la.chains + lds_load(metaL + 3 * row) + 4 * pc);
-          else if (pc < 3 * NP)
-            dst = *(const u32x4*)(la.logprobs_k + lds_load(metaL + 3 * row + 1) + 4 * (pc - 2 * NP));
-          else
-            dst[0] = __float_as_uint(la.adv_k[(int)(lds_load(metaL + 3 * row + 2) >> 32)]);
-        }
-      };
-      request(t_, gx[0]);
-      gx[1] = (u32x4){0, 0, 0, 0};
-      if (wid < 2) request(t_ + 512, gx[1]);  // (at most 13 pieces per row: 832 slots)
-      __builtin_amdgcn_sched_barrier(0);
+      for (int s0 = 0; s0 < total; s0 += 512) {
+        const int sl = s0 + t_;
+        int row = sl / DPR;
+        const int d = sl - row * DPR;
+        row = row < MT && row0 + row < M ? row : 0;  // (a DMA has no mask: slots past the tile fetch row 0's, nobody reads them)
+        const float* src;
+        if (d < 2 * AF)
+          src = la.chains + lds_load(metaL + 3 * row) + d;
+        else if (d < 3 * AF)
+          src = la.logprobs_k + lds_load(metaL + 3 * row + 1) + (d - 2 * AF);
+        else
+          src = la.adv_k + (int)(lds_load(metaL + 3 * row + 2) >> 32);
+        __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(recL + s0 + (t_ & ~63)), 4, 0, 0);
+      }
     }
     // ---- out layer, second pass: (Wout W2) on act(z1)
     int r_ = r, g_ = g, lane_ = lane;
@@ -1099,20 +1133,8 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
         a.out[(size_t)(row0 + row) * a.ldout + j] = s;
     }
     STAMP(13);
-    if constexpr (LOSSF) {  // (buffer A behind the out-layer partials has been free since the barrier behind the second emit)
-      const int NP = la.AF >> 2, PPR = 3 * NP + 1;
-      int t_ = tid;
-      asm volatile("" : "+v"(t_));
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int sl = t_ + 512 * i, row = sl / PPR, pc = sl - row * PPR;
-        if (row < MT) {  // row r of recL: x at 0, x_k+1 at 16, old log-probs at 32, advantage at 48
-          const int off = pc < NP ? 4 * pc : (pc < 2 * NP ? 16 + 4 * (pc - NP) : (pc < 3 * NP ? 32 + 4 * (pc - 2 * NP) : 48));
-          if (i == 0 || wid < 2) *(u32x4*)(recL + row * 64 + off) = gx[i];
-        }
-      }
-    }
     if constexpr (LOSSF) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the gathered inputs has landed
       __syncthreads();  // the eps tile and the gathered inputs are in place
       if (wid == 0) {   // one sample per lane, as in ppo_loss_kernel (64 samples per block there: this tile)
         int ln = lane;
@@ -1122,10 +1144,12 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
         const double Nn = la.n_count > 0 ? la.n_count : la.moments[2];
         double s4[4] = {0, 0, 0, 0};
         if (n < M) {
-          const float* rr = recL + ln * 64;
-          const float adv = lds_load(rr + 48);
+          const int AF = la.AF;
+          const float* rr = recL + ln * (3 * AF + 1);
+          const float adv = lds_load(rr + 3 * AF);
           const int k = (int)(lds_load(metaL + 3 * ln + 2) & 0xffffffffll);
-          policy_loss_row_nc<P>(la, tabL, k, adv, rr, epsL + ln * 16, cnt, Nn, (typename P::elem_t*)la.d_eps + (size_t)n * la.ldde, s4);
+          policy_loss_row_nc<P>(la, tabL, k, adv, rr, rr + AF, rr + 2 * AF, epsL + ln * 16, cnt, Nn,
+                                (typename P::elem_t*)la.d_eps + (size_t)n * la.ldde, s4);
         }
         // the tile's partial sums by the loss kernel's shuffle tree (v_loss belongs to the value half's launch)
         double v5[5] = {s4[0], 0.0, s4[1], s4[2], s4[3]};
@@ -1139,9 +1163,24 @@ __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const Fuse
         }
       }
     }
+    if constexpr (LOSSF && S1 > 0) eng.reprime();  // (their latency hides under the next tile's input load and barrier)
     __syncthreads();  // the next tile's input lands in buffer B; its layer-0 emit in buffer A, where the partials were read
     STAMP(14);
   }
+}
+
+template <class P, int TPW, int MR, int OT, int ACT, int S1, bool FRAG = false, bool LOSSF = false>
+__global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const FusedFwdArgs a, const LossArgs la) {
+  fused_forward_merged_body<P, TPW, MR, OT, ACT, S1, FRAG, LOSSF>(a, la);
+}
+// The LOSSF variant under a register cap: at 235 VGPRs two of its waves leave a SIMD 32 free registers and the critic's launches
+// can no longer slip a wave in beside them; capped at the plain kernel's 224 (build.sh compiles this file with
+// -amdgpu-spill-vgpr-to-agpr=0: AGPRs used as spill space count against the same register file) the allocator spills the
+// epilogue's cold values to scratch instead.
+template <class P, int TPW, int MR, int ACT, int S1>
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(112))) void fused_forward_merged_loss_kernel(const FusedFwdArgs a,
+                                                                                                              const LossArgs la) {
+  fused_forward_merged_body<P, TPW, MR, 1, ACT, S1, false, true>(a, la);
 }
 
 // =================================================================================================
@@ -1750,10 +1789,18 @@ static int launch_fwd_merged_cfg2(const FusedFwdArgs& a, hipStream_t s, const Lo
   if (FRAG != (a.a1f != nullptr) || FRAG != (a.a2f != nullptr)) return -4;  // (fragment outputs: both or none, and a variant built for them)
   if (LOSSF != (loss != nullptr)) return -4;
   static DevLatch attr;
-  raise_lds(fused_forward_merged_kernel<P, TPW, MR, OT, ACT, S1, FRAG, LOSSF>, attr);
   const int ntiles = (a.M + MT - 1) / MT;
-  const bool probe = probe_begin(PROBE_FUSED_FWD, s);
   static const LossArgs no_loss = {};
+  if constexpr (LOSSF) {  // (its own kernel symbol: the same body under a register cap)
+    raise_lds(fused_forward_merged_loss_kernel<P, TPW, MR, ACT, S1>, attr);
+    const bool probe = probe_begin(PROBE_FUSED_FWD, s);
+    hipLaunchKernelGGL((fused_forward_merged_loss_kernel<P, TPW, MR, ACT, S1>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512), lds, s,
+                       a, *loss);
+    if (probe) probe_end(s, 2.0 * a.M * ((double)a.in_valid * H + 2.0 * a.nb * H * H + (double)H * a.out_dim));
+    return 0;
+  }
+  raise_lds(fused_forward_merged_kernel<P, TPW, MR, OT, ACT, S1, FRAG, LOSSF>, attr);
+  const bool probe = probe_begin(PROBE_FUSED_FWD, s);
   hipLaunchKernelGGL((fused_forward_merged_kernel<P, TPW, MR, OT, ACT, S1, FRAG, LOSSF>), dim3(ntiles < NUM_CUS ? ntiles : NUM_CUS), dim3(512),
                      lds, s, a, loss != nullptr ? *loss : no_loss);
   if (probe) probe_end(s, 2.0 * a.M * ((double)a.in_valid * H + 2.0 * a.nb * H * H + (double)H * a.out_dim));

@@ -63,13 +63,15 @@ __device__ __forceinline__ void loss_element_nc(const dppo_diffusion_cfg& dc, co
   gs = (lp >= -5.f && lp <= 2.f) ? (d / var) * dmu : 0.f;
 }
 
-// tab: [Kft] denoising discount, [Kft] clip range, adv mean, adv std, [Kft] log std_k (the loss kernel's table + one row, in LDS).  rec / eps: the sample's
-// gathered inputs in LDS -- x_k at rec[0..], x_k+1 at rec[16..], old log-probs at rec[32..] -- and the forward's eps row; the first
-// cnt elements count (cnt <= 16, a multiple of 4), read four at a time (all 64 in registers at once spilled the kernel).  de: the
-// sample's row of d loss / d eps ([ldde] elem, whole 16-byte chunks).  s4: pg loss, approx kl, clip fraction, ratio of this sample.
+// tab: [Kft] denoising discount, [Kft] clip range, adv mean, adv std, [Kft] log std_k (the loss kernel's table + one row, in LDS).
+// xs / xns / os: the sample's x_k, x_k+1 and old log-probs in LDS (4-byte aligned), eps: the forward's eps row (16-byte aligned);
+// the first cnt elements count (cnt <= 16, a multiple of 4), read four at a time (all 64 in registers at once spilled the
+// kernel).  de: the sample's row of d loss / d eps ([ldde] elem, whole 16-byte chunks).  s4: pg loss, approx kl, clip fraction,
+// ratio of this sample.
 template <class P>
-__device__ __forceinline__ void policy_loss_row_nc(const LossArgs& a, const float* tab, int k, float adv, const float* rec,
-                                                   const float* eps, int cnt, double Nn, typename P::elem_t* de, double (&s4)[4]) {
+__device__ __forceinline__ void policy_loss_row_nc(const LossArgs& a, const float* tab, int k, float adv, const float* xs,
+                                                   const float* xns, const float* os, const float* eps, int cnt, double Nn,
+                                                   typename P::elem_t* de, double (&s4)[4]) {
 #pragma clang fp contract(off)
   constexpr int EPC = 16 / P::ESIZE;
   const dppo_ppo_cfg& pc = a.pcfg;
@@ -82,8 +84,10 @@ __device__ __forceinline__ void policy_loss_row_nc(const LossArgs& a, const floa
 #pragma unroll
   for (int j0 = 0; j0 < 16; j0 += 4) {
     if (j0 < cnt) {
-      const f32x4 x = lds_load((const f32x4*)(rec + j0)), xn = lds_load((const f32x4*)(rec + 16 + j0));
-      const f32x4 o = lds_load((const f32x4*)(rec + 32 + j0)), e = lds_load((const f32x4*)(eps + j0));
+      f32x4 x, xn, o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x[q] = lds_load(xs + j0 + q), xn[q] = lds_load(xns + j0 + q), o[q] = lds_load(os + j0 + q);
+      const f32x4 e = lds_load((const f32x4*)(eps + j0));
       loss_element_nc(a.dcfg, st, var, lstd, x[0], xn[0], e[0], o[0], sum_new, sum_old, gsrc[j0]);
       loss_element_nc(a.dcfg, st, var, lstd, x[1], xn[1], e[1], o[1], sum_new, sum_old, gsrc[j0 + 1]);
       loss_element_nc(a.dcfg, st, var, lstd, x[2], xn[2], e[2], o[2], sum_new, sum_old, gsrc[j0 + 2]);
