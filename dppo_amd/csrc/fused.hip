@@ -1173,10 +1173,10 @@ template <class P, int TPW, int MR, int OT, int ACT, int S1, bool FRAG = false, 
 __global__ __launch_bounds__(512, 2) void fused_forward_merged_kernel(const FusedFwdArgs a, const LossArgs la) {
   fused_forward_merged_body<P, TPW, MR, OT, ACT, S1, FRAG, LOSSF>(a, la);
 }
-// The LOSSF variant under a register cap: at 235 VGPRs two of its waves leave a SIMD 32 free registers and the critic's launches
-// can no longer slip a wave in beside them; capped at the plain kernel's 224 (build.sh compiles this file with
-// -amdgpu-spill-vgpr-to-agpr=0: AGPRs used as spill space count against the same register file) the allocator spills the
-// epilogue's cold values to scratch instead.
+// The LOSSF variant under a register cap: left alone it allocates 235 VGPRs, two of its waves leave a SIMD 32 free registers and
+// the critic's launches can no longer slip a wave in beside them.  amdgpu_num_vgpr(112): on gfx90a+ the compiler
+// DOUBLES the request (unified VGPR + AGPR file), so this is the plain kernel's 224; the allocator then spills eight cold values
+// (hoisted tile-loop invariants, reloaded once per tile) to scratch, none inside the H-wide k-loop.
 template <class P, int TPW, int MR, int ACT, int S1>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(112))) void fused_forward_merged_loss_kernel(const FusedFwdArgs a,
                                                                                                               const LossArgs la) {
