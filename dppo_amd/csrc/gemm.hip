@@ -811,7 +811,6 @@ void launch_gemm_tn_group(const GemmTNGroup& gr, hipStream_t s) {
   const bool probe = probe_begin(PROBE_GEMM_TN, s);
   const dim3 grid(gr.base[gr.n] + gr.ex.n_blocks);
   const int nbuf = g_tn_nbuf != 0 ? g_tn_nbuf : ((int)grid.x > 3 * 256 && gr.n > 0 && gr.j[0].M >= 32768 ? 2 : 1);
-  if (getenv("DPPO_DEBUG_TN")) fprintf(stderr, "tn group: %u workgroups, %d stage(s)\n", grid.x, nbuf);
   if (nbuf == 1)
     hipLaunchKernelGGL((gemm_tn_group_kernel<P, 1>), grid, dim3(256), LDS / 2, s, gr);
   else
